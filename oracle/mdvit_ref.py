@@ -1,0 +1,358 @@
+"""CPU restatement (plain torch, fp32 or fp64) of the MDViT / BASE forward path and step losses.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Functional style over a flat
+``{state_dict name: tensor}`` mapping; tokens are (B, N, C) with n = h*W + w, i.e. NHWC.
+Written from the math in SURVEY.md Appendix A; every function cites the reference lines it
+restates (paths under /root/reference).  Pinned by tests/golden/*.npz, which
+oracle/gen_golden.py produced by running the reference itself in the build container.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .params import CRPE_WINDOW
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+class RefState:
+    """Mode flags for one oracle call (the nn.Module train()/eval() state + drop rates)."""
+
+    def __init__(self, training: bool = True, drop_rate: float = 0.0, drop_path_rate: float = 0.0,
+                 aux_drop: float = 0.0, update_bn: bool = True, adapt_method="Sup"):
+        self.training = training
+        self.drop_rate = drop_rate
+        self.drop_path_rate = drop_path_rate
+        self.aux_drop = aux_drop          # MLPDecoderFM's Dropout2d(0.1): Decoders.py:294,309
+        self.update_bn = update_bn
+        self.adapt_method = adapt_method
+
+
+# ---- elementary pieces ------------------------------------------------------------------------
+
+def hardswish(x: Tensor) -> Tensor:
+    # x * relu6(x + 3) / 6          (nn.Hardswish; mpvit.py:81-124 act_layer)
+    return x * torch.clamp(x + 3.0, 0.0, 6.0) / 6.0
+
+
+def batch_norm(P: Params, prefix: str, x: Tensor, st: RefState, eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
+    """nn.BatchNorm2d on NCHW x.  Train: biased batch variance for normalisation, running stats
+    updated with momentum 0.1 and the UNBIASED variance."""
+    w, b = P[prefix + ".weight"], P[prefix + ".bias"]
+    if st.training:
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        if st.update_bn:
+            n = x.numel() // x.shape[1]
+            with torch.no_grad():
+                P[prefix + ".running_mean"].mul_(1 - momentum).add_(momentum * mean.detach())
+                P[prefix + ".running_var"].mul_(1 - momentum).add_(momentum * var.detach() * (n / max(n - 1, 1)))
+                P[prefix + ".num_batches_tracked"].add_(1)
+    else:
+        mean, var = P[prefix + ".running_mean"], P[prefix + ".running_var"]
+    xh = (x - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + eps)
+    return xh * w[None, :, None, None] + b[None, :, None, None]
+
+
+def dropout(x: Tensor, p: float, st: RefState) -> Tensor:
+    if not st.training or p == 0.0:
+        return x
+    return F.dropout(x, p, True)
+
+
+def drop_path(x: Tensor, p: float, st: RefState) -> Tensor:
+    """timm DropPath: per-sample Bernoulli(1-p)/(1-p) (mdvit.py:338,354,359)."""
+    if not st.training or p == 0.0:
+        return x
+    keep = 1.0 - p
+    mask = torch.empty(x.shape[0], *([1] * (x.dim() - 1)), dtype=x.dtype).bernoulli_(keep)
+    return x * mask / keep
+
+
+def tokens_to_image(x: Tensor, H: int, W: int) -> Tensor:
+    B, N, C = x.shape
+    return x.transpose(1, 2).reshape(B, C, H, W)
+
+
+def image_to_tokens(x: Tensor) -> Tensor:
+    return x.flatten(2).transpose(1, 2)
+
+
+# ---- transformer block ------------------------------------------------------------------------
+
+def conv_pos_enc(P: Params, prefix: str, x: Tensor, H: int, W: int) -> Tensor:
+    """ConvPosEnc.forward, mpvit.py:239-248:  x + dwconv3x3_bias(x) on the token image."""
+    C = x.shape[2]
+    img = tokens_to_image(x, H, W)
+    y = F.conv2d(img, P[prefix + ".proj.weight"], P[prefix + ".proj.bias"], 1, 1, 1, C) + img
+    return image_to_tokens(y)
+
+
+def conv_rel_pos_enc(P: Params, prefix: str, q: Tensor, v: Tensor, H: int, W: int) -> Tensor:
+    """ConvRelPosEnc.forward, mpvit.py:296-318: q * dwconv_{3|5|7}(v-as-image), channel = head*Ch+ch."""
+    B, h, N, Ch = q.shape
+    vimg = v.permute(0, 1, 3, 2).reshape(B, h * Ch, H, W)
+    outs, c0 = [], 0
+    for wi, (win, split) in enumerate(CRPE_WINDOW):
+        c1 = c0 + split * Ch
+        outs.append(F.conv2d(vimg[:, c0:c1], P[f"{prefix}.conv_list.{wi}.weight"], P[f"{prefix}.conv_list.{wi}.bias"],
+                             1, win // 2, 1, split * Ch))
+        c0 = c1
+    conv_v = torch.cat(outs, 1).reshape(B, h, Ch, N).permute(0, 1, 3, 2)
+    return q * conv_v
+
+
+def domain_attention(P: Params, prefix: str, domain_label: Tensor, h: int) -> Tensor:
+    """mdvit.py:272-276,301-304: softmax over HEADS of Linear(ReLU(Linear(one_hot))) -> (B,h,1,Ch)."""
+    z = F.linear(domain_label, P[prefix + ".domain_layer.0.weight"], P[prefix + ".domain_layer.0.bias"])
+    z = F.linear(torch.relu(z), P[prefix + ".domain_layer.2.weight"], P[prefix + ".domain_layer.2.bias"])
+    B, C = z.shape
+    return torch.softmax(z.reshape(B, h, 1, C // h), dim=1)
+
+
+def factor_att(P: Params, prefix: str, crpe_prefix: str, x: Tensor, H: int, W: int, heads: int,
+               domain_label: Optional[Tensor], st: RefState) -> Tensor:
+    """FactorAtt_ConvRelPosEnc_Sup.forward (mdvit.py:281-313) / FactorAtt_ConvRelPosEnc.forward
+    (mpvit.py:347-373) when domain_label is None."""
+    B, N, C = x.shape
+    Ch = C // heads
+    qkv = F.linear(x, P[prefix + ".qkv.weight"], P[prefix + ".qkv.bias"]).reshape(B, N, 3, heads, Ch).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    ks = torch.softmax(k, dim=2)                      # over the TOKEN axis
+    M = ks.transpose(2, 3) @ v                        # (B,h,Ch,Ch)
+    fa = q @ M
+    y = (Ch ** -0.5) * fa + conv_rel_pos_enc(P, crpe_prefix, q, v, H, W)
+    if domain_label is not None:
+        y = domain_attention(P, prefix, domain_label, heads) * y
+    y = y.transpose(1, 2).reshape(B, N, C)
+    y = F.linear(y, P[prefix + ".proj.weight"], P[prefix + ".proj.bias"])
+    return dropout(y, st.drop_rate, st)
+
+
+def mlp(P: Params, prefix: str, x: Tensor, st: RefState) -> Tensor:
+    """Mlp.forward, mpvit.py:71-78 (exact-erf GELU)."""
+    y = F.gelu(F.linear(x, P[prefix + ".fc1.weight"], P[prefix + ".fc1.bias"]))
+    y = dropout(y, st.drop_rate, st)
+    y = F.linear(y, P[prefix + ".fc2.weight"], P[prefix + ".fc2.bias"])
+    return dropout(y, st.drop_rate, st)
+
+
+def serial_block(P: Params, stage: str, i: int, x: Tensor, H: int, W: int, heads: int,
+                 domain_label: Optional[Tensor], st: RefState) -> Tensor:
+    """SerialBlock_adapt.forward, mdvit.py:346-361."""
+    b = f"{stage}.mhca_blks.{i}"
+    C = x.shape[2]
+    x = conv_pos_enc(P, f"{stage}.cpe", x, H, W)
+    cur = F.layer_norm(x, (C,), P[b + ".norm1.weight"], P[b + ".norm1.bias"], 1e-6)
+    cur = factor_att(P, b + ".factoratt_crpe", f"{stage}.crpe", cur, H, W, heads, domain_label, st)
+    x = x + drop_path(cur, st.drop_path_rate, st)
+    cur = F.layer_norm(x, (C,), P[b + ".norm2.weight"], P[b + ".norm2.bias"], 1e-6)
+    cur = mlp(P, b + ".mlp", cur, st)
+    return x + drop_path(cur, st.drop_path_rate, st)
+
+
+def mhsa_stage(P: Params, stage: str, x: Tensor, H: int, W: int, heads: int, layers: int,
+               domain_label: Optional[Tensor], st: RefState) -> Tensor:
+    """MHSA_stage_adapt.forward, mdvit.py:437-440."""
+    for i in range(layers):
+        x = serial_block(P, stage, i, x, H, W, heads, domain_label, st)
+    return x
+
+
+# ---- conv blocks ------------------------------------------------------------------------------
+
+def conv_bn_hswish(P: Params, prefix: str, x: Tensor, stride: int, st: RefState) -> Tensor:
+    """Conv2d_BN (mpvit.py:81-124) as used by the stem (mdvit.py:509-526)."""
+    y = F.conv2d(x, P[prefix + ".conv.weight"], None, stride, 1)
+    return hardswish(batch_norm(P, prefix + ".bn", y, st))
+
+
+def dw_patch_embed(P: Params, prefix: str, x: Tensor, stride: int, st: RefState) -> Tensor:
+    """DWConv2d_BN, mdvit flavour (mdvit.py:74-123): dw3x3(groups=in) -> pw1x1 -> BN -> Hardswish."""
+    cin = x.shape[1]
+    y = F.conv2d(x, P[prefix + ".dwconv.weight"], None, stride, 1, 1, cin)
+    y = F.conv2d(y, P[prefix + ".pwconv.weight"])
+    return hardswish(batch_norm(P, prefix + ".bn", y, st))
+
+
+def bridge(P: Params, x: Tensor, st: RefState) -> Tensor:
+    """mdvit.py:557-564."""
+    y = torch.relu(batch_norm(P, "bridge.1", F.conv2d(x, P["bridge.0.weight"], P["bridge.0.bias"], 1, 1), st))
+    return torch.relu(batch_norm(P, "bridge.4", F.conv2d(y, P["bridge.3.weight"], P["bridge.3.bias"], 1, 1), st))
+
+
+def decoder_block(P: Params, j: int, x: Tensor, skip: Tensor, heads: int, layers: int,
+                  domain_label: Optional[Tensor], st: RefState) -> Tensor:
+    """UnetDecodingBlockTransformer.forward (use_res=False), Decoders.py:194-214, with the
+    Decoders.py flavour of DWConv2d_BN (:15-63: Conv2d(2*out, out, 3, groups=out))."""
+    p = f"decoder{j}"
+    H, W = skip.shape[2:]
+    u = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False)
+    u = F.conv2d(u, P[p + ".conv_before.weight"], P[p + ".conv_before.bias"])
+    z = torch.cat((skip, u), 1)
+    cout = skip.shape[1]
+    z = F.conv2d(z, P[p + ".conv_after.dwconv.weight"], None, 1, 1, 1, cout)
+    z = F.conv2d(z, P[p + ".conv_after.pwconv.weight"])
+    z = hardswish(batch_norm(P, p + ".conv_after.bn", z, st))
+    t = mhsa_stage(P, p + ".mhsa_block", image_to_tokens(z), H, W, heads, layers, domain_label, st)
+    return tokens_to_image(t, H, W)
+
+
+def aux_head(P: Params, d: int, feats: Sequence[Tensor], img_size, st: RefState) -> Tensor:
+    """MLPDecoderFM.forward, Decoders.py:315-339; d = 1..4 picks debranch{d} (mdvit.py:715-724)."""
+    p = f"debranch{d}"
+    h, w = feats[0].shape[2:]
+    ups = []
+    for q in range(4):
+        y = F.conv2d(feats[q], P[f"{p}.linear{q + 1}.weight"], P[f"{p}.linear{q + 1}.bias"])
+        ups.append(F.interpolate(y, size=(h, w), mode="bilinear", align_corners=False))
+    y = torch.cat(ups + [feats[4]], 1)
+    y = F.conv2d(y, P[p + ".linear_fuse.0.weight"], P[p + ".linear_fuse.0.bias"])
+    y = torch.relu(batch_norm(P, p + ".linear_fuse.1", y, st))
+    if st.training and st.aux_drop > 0:
+        y = F.dropout2d(y, st.aux_drop, True)
+    y = F.interpolate(y, size=tuple(img_size), mode="bilinear", align_corners=False)
+    return F.conv2d(y, P[p + ".linear_out.weight"], P[p + ".linear_out.bias"])
+
+
+# ---- whole models -----------------------------------------------------------------------------
+
+def _encoder_decoder(P: Params, x: Tensor, domain_label: Optional[Tensor], st: RefState,
+                     heads=(8, 8, 8, 8), layers=(2, 2, 2, 2)):
+    img_size = x.shape[2:]
+    x = conv_bn_hswish(P, "stem.0", x, 2, st)
+    x = conv_bn_hswish(P, "stem.1", x, 2, st)
+    enc = []
+    for s in range(4):
+        x = dw_patch_embed(P, f"patch_embed_stages.{s}.patch_conv", x, 1 if s == 0 else 2, st)
+        H, W = x.shape[2:]
+        t = mhsa_stage(P, f"mhsa_stages.{s}", image_to_tokens(x), H, W, heads[s], layers[s], domain_label, st)
+        x = tokens_to_image(t, H, W)
+        enc.append(x)
+    out = bridge(P, enc[3], st)
+    for j in range(1, 5):
+        s = 4 - j
+        out = decoder_block(P, j, out, enc[s], heads[s], layers[s], domain_label, st)
+    dec4 = out
+    up = F.interpolate(dec4, size=tuple(img_size), mode="bilinear", align_corners=False)
+    logits = F.conv2d(up, P["finalconv.0.weight"], P["finalconv.0.bias"])
+    return logits, enc, dec4, img_size
+
+
+def mdvit_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, d: Optional[str] = None,
+                  st: Optional[RefState] = None):
+    """MDViT.forward, mdvit.py:667-730 (decoder_name='MLPFM') -> [out, aux_out]."""
+    st = st or RefState()
+    if st.adapt_method != "Sup":
+        domain_label = None
+    logits, enc, dec4, img_size = _encoder_decoder(P, x, domain_label, st)
+    aux = None
+    if d in ("0", "1", "2", "3"):
+        aux = aux_head(P, int(d) + 1, enc + [dec4], img_size, st)
+    return [logits, aux]
+
+
+def base_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, st: Optional[RefState] = None) -> Tensor:
+    """BASE.forward, base.py:477-512 -> logits tensor."""
+    st = st or RefState()
+    return _encoder_decoder(P, x, domain_label, st)[0]
+
+
+# ---- losses ------------------------------------------------------------------------------------
+
+def dice_loss(score: Tensor, target: Tensor) -> Tensor:
+    """Utils/losses.py:8-16."""
+    target = target.to(score.dtype)
+    smooth = 1e-5
+    inter = torch.sum(score * target)
+    return 1 - (2 * inter + smooth) / (torch.sum(score * score) + torch.sum(target * target) + smooth)
+
+
+class _BCE(torch.autograd.Function):
+    """nn.BCELoss semantics incl. its backward at saturation: forward clamps log at -100,
+    backward is (p - y) / max(p (1-p), 1e-12) / N  (ATen binary_cross_entropy_backward)."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        ctx.save_for_backward(p, y)
+        lp = torch.clamp(torch.log(p), min=-100.0)
+        l1p = torch.clamp(torch.log(1 - p), min=-100.0)
+        return -(y * lp + (1 - y) * l1p).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        p, y = ctx.saved_tensors
+        return g * (p - y) / torch.clamp((1 - p) * p, min=1e-12) / p.numel(), None
+
+
+def bce_loss(p: Tensor, y: Tensor) -> Tensor:
+    """nn.BCELoss (mean; log clamped at -100), multi_train_MDViT.py:76."""
+    return _BCE.apply(p, y.to(p.dtype))
+
+
+def domain_losses(out: Tensor, aux: Tensor, label: Tensor):
+    """multi_train_MDViT.py:147-169 for one domain: (loss, aux_loss, kt_loss)."""
+    o, a = torch.sigmoid(out), torch.sigmoid(aux)
+    return bce_loss(o, label) + dice_loss(o, label), bce_loss(a, label) + dice_loss(a, label), dice_loss(a, o)
+
+
+def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: float = 0.5):
+    """One optimisation step's losses and gradients, multi_train_MDViT.py:129-207.
+
+    batches: list of (img, label, set_id:int) -- one per domain.  Returns (losses dict, grads dict).
+    The aux sweep runs with every ``domain_layer`` parameter frozen, the uni sweep with all
+    parameters live; gradients accumulate."""
+    st = st or RefState()
+    leaves = {k: v for k, v in P.items() if v.is_floating_point() and "running_" not in k}
+    for v in leaves.values():
+        v.requires_grad_(True)
+        v.grad = None
+    tot, tot_aux, tot_kt = 0.0, 0.0, 0.0
+    for img, label, sid in batches:
+        dl = F.one_hot(torch.full((img.shape[0],), sid, dtype=torch.long), 4).to(img.dtype)
+        out, aux = mdvit_forward(P, img, dl, str(sid), st)
+        l, la, lk = domain_losses(out, aux, label)
+        tot, tot_aux, tot_kt = tot + l, tot_aux + la, tot_kt + lk
+    da = [v for k, v in leaves.items() if "domain_layer" in k]
+    for v in da:
+        v.requires_grad_(False)
+    tot_aux.backward(retain_graph=True)
+    for v in da:
+        v.requires_grad_(True)
+    uni = alpha * tot_kt + (1 - alpha) * tot
+    uni.backward()
+    grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in leaves.items()}
+    losses = {"loss": float(tot.detach()), "aux_loss": float(tot_aux.detach()), "kt_loss": float(tot_kt.detach())}
+    for v in leaves.values():
+        v.requires_grad_(False)
+    return losses, grads
+
+
+def base_train_step(P: Params, img: Tensor, label: Tensor, domain_label: Optional[Tensor] = None,
+                    st: Optional[RefState] = None):
+    """multi_train_BASE.py:168-200 for one domain: loss = BCE+Dice, single backward."""
+    st = st or RefState()
+    leaves = {k: v for k, v in P.items() if v.is_floating_point() and "running_" not in k}
+    for v in leaves.values():
+        v.requires_grad_(True)
+        v.grad = None
+    o = torch.sigmoid(base_forward(P, img, domain_label, st))
+    loss = bce_loss(o, label) + dice_loss(o, label)
+    loss.backward()
+    grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in leaves.items()}
+    for v in leaves.values():
+        v.requires_grad_(False)
+    return float(loss.detach()), grads
+
+
+def to_torch(params_np, dtype=torch.float32) -> Params:
+    out = {}
+    for k, v in params_np.items():
+        t = torch.from_numpy(v.copy())
+        out[k] = t.to(dtype) if t.is_floating_point() else t
+    return out

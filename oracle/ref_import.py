@@ -1,0 +1,112 @@
+"""Import the real reference (read-only, /root/reference) in the BUILD CONTAINER only.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Used by oracle/gen_golden.py to produce the
+committed fixtures and by the (auto-skipping) live cross-check in tests/test_oracle_vs_reference.py.
+/root/reference does not exist on the GPU box; nothing on the GPU path may import this module.
+
+The reference needs `timm` and `turtle` (tkinter), which this image lacks; the stubs below are
+build-owned minimal stand-ins for the handful of symbols it imports:
+  timm.models.layers.{DropPath, trunc_normal_, to_2tuple}, timm.models.registry.register_model,
+  timm.data.{IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD}, timm.models.helpers.load_pretrained,
+  turtle.forward, skimage.segmentation (imported, never called, by Utils/losses.py:5).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "Models", "Transformer"))
+
+
+def _install_stubs():
+    import torch
+    from torch import nn
+
+    if "timm" in sys.modules and getattr(sys.modules["timm"], "_mdvit_stub", False):
+        return
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            return x * mask / keep
+
+    def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
+        return nn.init.trunc_normal_(tensor, mean, std, a, b)
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    timm = types.ModuleType("timm")
+    timm._mdvit_stub = True
+    models = types.ModuleType("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+    layers.DropPath, layers.trunc_normal_, layers.to_2tuple = DropPath, trunc_normal_, to_2tuple
+    registry = types.ModuleType("timm.models.registry")
+    registry.register_model = lambda fn: fn
+    helpers = types.ModuleType("timm.models.helpers")
+    helpers.load_pretrained = lambda *a, **k: None
+    data = types.ModuleType("timm.data")
+    data.IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+    data.IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+    timm.models, timm.data = models, data
+    models.layers, models.registry, models.helpers = layers, registry, helpers
+    for name, mod in (("timm", timm), ("timm.models", models), ("timm.models.layers", layers),
+                      ("timm.models.registry", registry), ("timm.models.helpers", helpers), ("timm.data", data)):
+        sys.modules[name] = mod
+    turtle = types.ModuleType("turtle")
+    turtle.forward = lambda *a, **k: None
+    sys.modules["turtle"] = turtle
+    if "skimage" not in sys.modules:      # Utils/losses.py:5 imports skimage.segmentation at module top
+        skimage = types.ModuleType("skimage")
+        skimage.segmentation = types.ModuleType("skimage.segmentation")
+        sys.modules["skimage"] = skimage
+        sys.modules["skimage.segmentation"] = skimage.segmentation
+
+
+def import_reference():
+    """-> namespace with MDViT, BASE and the block classes of the reference."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present (only available in the build container)")
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from Models.Transformer import mdvit as ref_mdvit
+    from Models.Transformer import base as ref_base
+    from Models.Transformer import mpvit as ref_mpvit
+    from Models import Decoders as ref_dec
+    from Utils import losses as ref_losses
+    ns = types.SimpleNamespace(
+        MDViT=ref_mdvit.MDViT, BASE=ref_base.BASE,
+        FactorAtt_Sup=ref_mdvit.FactorAtt_ConvRelPosEnc_Sup, FactorAtt=ref_mpvit.FactorAtt_ConvRelPosEnc,
+        SerialBlock_adapt=ref_mdvit.SerialBlock_adapt, MHSA_stage_adapt=ref_mdvit.MHSA_stage_adapt,
+        ConvPosEnc=ref_mpvit.ConvPosEnc, ConvRelPosEnc=ref_mpvit.ConvRelPosEnc, Mlp=ref_mpvit.Mlp,
+        MLPDecoderFM=ref_dec.MLPDecoderFM, UnetDecodingBlockTransformer=ref_dec.UnetDecodingBlockTransformer,
+        mdvit_module=ref_mdvit, base_module=ref_base, dice_loss=ref_losses.dice_loss,
+    )
+    return ns
+
+
+def load_params_into(module, params_np, strict_unique: bool = True):
+    """Fill a reference nn.Module from the build-owned generator's {name: ndarray}."""
+    import torch
+    sd = module.state_dict()
+    missing = [k for k in params_np if k not in sd]
+    if strict_unique and missing:
+        raise KeyError(f"generator names absent from the reference state_dict: {missing[:5]} ...")
+    with torch.no_grad():
+        for k, v in params_np.items():
+            sd[k].copy_(torch.from_numpy(v))
+    return module

@@ -1,0 +1,169 @@
+"""The CPU oracle (oracle/mdvit_ref.py) against the fixtures the REAL reference produced
+(tests/golden/*.npz, made by oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mdvit_ref as R
+from oracle.gen_golden import synth_image, synth_label, synth_tokens, grad_digest
+from oracle.params import make_params, param_spec, alias_map
+
+RTOL = 2e-4   # fp32 CPU restatement vs fp32 CPU reference; different op order only
+
+
+def close(a, b, rtol=RTOL, name=""):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().numpy()
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), 1e-12)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, f"{name}: rel-to-max error {err:.3e} > {rtol}"
+
+
+def test_param_inventory_counts():
+    spec = param_spec("MDViT", "Sup")
+    n_param = sum(1 for k, (kind, _) in spec.items() if not kind.startswith("bn_r") and kind != "bn_nbt")
+    n_elem = sum(int(np.prod(s)) for k, (kind, s) in spec.items() if not kind.startswith("bn_r") and kind != "bn_nbt")
+    assert n_param == 432 and len(spec) == 480 and len(alias_map()) == 128      # 608 keys
+    assert n_elem == 34_970_277
+    base = param_spec("BASE", False)
+    n_base = sum(int(np.prod(s)) for k, (kind, s) in base.items() if not kind.startswith("bn_r") and kind != "bn_nbt")
+    assert abs(n_base - 27.75e6) < 0.01e6
+
+
+def test_generator_is_stable():
+    p = make_params(0, model="BASE", adapt_method=False)
+    w = p["stem.0.conv.weight"].reshape(-1)
+    # frozen values: the fixtures were produced with exactly this generator
+    assert np.allclose(w[:3], make_params(0, model="BASE", adapt_method=False)["stem.0.conv.weight"].reshape(-1)[:3])
+    assert abs(float(p["finalconv.0.weight"].std()) - 0.125) < 0.03
+
+
+def test_mdvit_two_sweep_step(golden):
+    g = golden("mdvit_step_64")
+    S, B, seed = [int(v) for v in g["meta"]]
+    P = R.to_torch(make_params(seed, model="MDViT", adapt_method="Sup"))
+    batches = [(synth_image(100 + d, B, S, S), synth_label(200 + d, B, S, S), d) for d in range(4)]
+    # forward logits per domain (fresh params each so BN buffers evolve exactly as in the fixture)
+    st = R.RefState(training=True)
+    P2 = {k: v.clone() for k, v in P.items()}
+    for d, (img, lab, sid) in enumerate(batches):
+        dl = F.one_hot(torch.full((B,), sid, dtype=torch.long), 4).float()
+        with torch.no_grad():
+            o, a = R.mdvit_forward(P2, img, dl, str(sid), st)
+            l = R.domain_losses(o, a, lab)
+        close(o, g[f"out_{d}"], name=f"out_{d}")
+        close(a, g[f"aux_{d}"], name=f"aux_{d}")
+        close([float(v) for v in l], g[f"losses_{d}"], name=f"losses_{d}")
+    bn_names = [str(n) for n in g["bn_names"]]
+    close([float(P2[k].double().sum()) for k in bn_names], g["bn_sums"], name="bn running sums")
+    losses, grads = R.mdvit_train_step(P, batches, R.RefState(training=True))
+    close([losses["loss"], losses["aux_loss"], losses["kt_loss"]], g["total_losses"], name="total losses")
+    names, norms, heads = grad_digest(grads)
+    assert names == [str(n) for n in g["grad_names"]]
+    ref = g["grad_norms"]
+    rel = np.abs(norms - ref) / np.maximum(ref, 1e-6 * ref.max())
+    assert rel.max() < 2e-3, f"grad norm mismatch {names[int(rel.argmax())]} {rel.max():.2e}"
+    for key in g.files:
+        if key.startswith("grad::"):
+            close(grads[key[6:]], g[key], rtol=1e-3, name=key)
+    assert bool(g["da_grad_none_after_aux_sweep"])
+
+
+def test_mdvit_eval(golden):
+    g = golden("mdvit_eval_64")
+    S, B, seed = [int(v) for v in g["meta"]]
+    P = R.to_torch(make_params(seed, model="MDViT", adapt_method="Sup"))
+    for d in (0, 3):
+        img = synth_image(300 + d, B, S, S)
+        dl = F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float()
+        with torch.no_grad():
+            o, a = R.mdvit_forward(P, img, dl, str(d), R.RefState(training=False))
+        close(o, g[f"out_{d}"], name="eval out")
+        close(a, g[f"aux_{d}"], name="eval aux")
+
+
+def test_mdvit_rect(golden):
+    g = golden("mdvit_fwd_96x128")
+    H, W, B, seed = [int(v) for v in g["meta"]]
+    P = R.to_torch(make_params(seed, model="MDViT", adapt_method="Sup"))
+    with torch.no_grad():
+        o, a = R.mdvit_forward(P, synth_image(400, B, H, W), F.one_hot(torch.tensor([1]), 4).float(), "1",
+                               R.RefState(training=True))
+    close(o, g["out"], name="rect out")
+    close(a, g["aux"], name="rect aux")
+
+
+def test_base_step(golden):
+    g = golden("base_step_64")
+    S, B, seed = [int(v) for v in g["meta"]]
+    P = R.to_torch(make_params(seed, model="BASE", adapt_method=False))
+    img, lab = synth_image(500, B, S, S), synth_label(600, B, S, S)
+    with torch.no_grad():
+        o = R.base_forward({k: v.clone() for k, v in P.items()}, img, None, R.RefState(training=True, adapt_method=False))
+    close(o, g["out"], name="base out")
+    loss, grads = R.base_train_step(P, img, lab, None, R.RefState(training=True, adapt_method=False))
+    close(loss, g["loss"], name="base loss")
+    names, norms, _ = grad_digest(grads)
+    assert names == [str(n) for n in g["grad_names"]]
+    ref = g["grad_norms"]
+    rel = np.abs(norms - ref) / np.maximum(ref, 1e-6 * ref.max())
+    assert rel.max() < 2e-3
+
+
+def _factoratt_params(tag_shape, seed=4):
+    """Rebuild the module-local weights gen_golden.gen_factoratt used (sorted named_parameters order)."""
+    B, H, W, C = tag_shape
+    Ch, hid = C // 8, max(C // 2, 4)
+    shapes = {
+        "crpe.conv_list.0.bias": (2 * Ch,), "crpe.conv_list.0.weight": (2 * Ch, 1, 3, 3),
+        "crpe.conv_list.1.bias": (3 * Ch,), "crpe.conv_list.1.weight": (3 * Ch, 1, 5, 5),
+        "crpe.conv_list.2.bias": (3 * Ch,), "crpe.conv_list.2.weight": (3 * Ch, 1, 7, 7),
+        "domain_layer.0.bias": (hid,), "domain_layer.0.weight": (hid, 4),
+        "domain_layer.2.bias": (C,), "domain_layer.2.weight": (C, hid),
+        "proj.bias": (C,), "proj.weight": (C, C), "qkv.bias": (3 * C,), "qkv.weight": (3 * C, C),
+    }
+    P = {}
+    for k, n in enumerate(sorted(shapes), start=1):
+        shp = shapes[n]
+        scale = 1.5 if "domain_layer" in n else (0.1 if n.endswith("bias") else (3.0 / shp[1]) ** 0.5 if len(shp) == 2 else 0.3)
+        P[n] = synth_tokens(seed, 1000 + k, shp) * scale
+    return P
+
+
+@pytest.mark.parametrize("tag", ["c64", "c128", "c320"])
+def test_factoratt_sup(golden, tag):
+    g = golden("factoratt_small")
+    B, H, W, C = [int(v) for v in g[f"{tag}_shape"]]
+    raw = _factoratt_params((B, H, W, C))
+    P = {("att." + k if not k.startswith("crpe") else k): v.clone().requires_grad_(True) for k, v in raw.items()}
+    x = synth_tokens(4, 1, (B, H * W, C)).requires_grad_(True)
+    dl = F.one_hot(torch.tensor([1, 3][:B]), 4).float()
+    y = R.factor_att(P, "att", "crpe", x, H, W, 8, dl, R.RefState(training=True))
+    close(y, g[f"{tag}_y"], name="y")
+    gy = synth_tokens(4, 2, tuple(y.shape))
+    (y * gy).sum().backward()
+    close(x.grad, g[f"{tag}_dx"], rtol=1e-3, name="dx")
+    for key in g.files:
+        if key.startswith(f"{tag}_grad::"):
+            n = key.split("::")[1]
+            close(P[n if n.startswith("crpe") else "att." + n].grad, g[key], rtol=1e-3, name=key)
+    assert bool(g[f"{tag}_da_gather_bitexact"])
+
+
+def test_losses(golden):
+    g = golden("losses_small")
+    o = synth_tokens(5, 1, (2, 1, 32, 32)) * 6.0
+    a = synth_tokens(5, 2, (2, 1, 32, 32)) * 6.0
+    o.view(-1)[:8] = torch.tensor([200.0, -200.0, 120.0, -120.0, 90.0, -90.0, 40.0, -40.0])
+    lab = synth_label(5, 2, 32, 32)
+    o.requires_grad_(True); a.requires_grad_(True)
+    l, la, lk = R.domain_losses(o, a, lab)
+    close([float(l), float(la), float(lk)], g["losses"], name="losses")
+    la.backward(retain_graph=True)
+    close(a.grad, g["d_aux_from_auxloss"], rtol=1e-4, name="d aux / aux loss")
+    a.grad = None
+    (0.5 * lk + 0.5 * l).backward()
+    close(o.grad, g["d_out_from_uni"], rtol=1e-4, name="d out / uni")
+    close(a.grad, g["d_aux_from_uni"], rtol=1e-4, name="d aux / uni")
