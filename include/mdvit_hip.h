@@ -1,0 +1,160 @@
+/* libmdvit_hip.so -- C ABI of the MI355X-native MDViT forward/backward path.
+ *
+ * Conventions:
+ *  - every function ENQUEUES work on `stream` (a hipStream_t passed as void*) and returns
+ *    immediately; no internal device synchronisation; no allocation -- the caller owns every
+ *    buffer including workspaces; pointers are borrowed for the duration of the enqueue.
+ *  - return 0 (MDVIT_OK) or an MDVIT_E_* code; the message is in mdvit_last_error() (thread-local).
+ *  - all tensors are fp32, activations in token-major NHWC: [B, H*W, C] row-major ("tokens").
+ *    Weights keep the layouts PyTorch's modules store (Linear [out,in], Conv [out,in/g,kh,kw]),
+ *    so a reference state_dict is consumed without repacking.
+ *  - file:line citations are into the reference tree (siyi-wind/MDViT) the entry point replaces.
+ */
+#ifndef MDVIT_HIP_H
+#define MDVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDVIT_ABI_VERSION 1
+
+enum {
+    MDVIT_OK = 0,
+    MDVIT_E_SHAPE = 1,
+    MDVIT_E_DTYPE = 2,
+    MDVIT_E_ALIGN = 3,
+    MDVIT_E_WORKSPACE = 4,
+    MDVIT_E_HIP = 5
+};
+
+enum { MDVIT_EPI_NONE = 0, MDVIT_EPI_GELU_DUAL = 1, MDVIT_EPI_DGELU = 2 };
+enum { MDVIT_ACT_NONE = 0, MDVIT_ACT_HSWISH = 1, MDVIT_ACT_RELU = 2 };
+
+const char* mdvit_last_error(void);
+int mdvit_version(void);
+
+/* ---- GEMM family -------------------------------------------------------------------------
+ * C[M,N] = op(A)[M,K] * op(B)[K,N] (+bias[N]) with fused neighbours.
+ *   trans_a = 0: A is [M,K] row-major (lda);   1: A is stored [K,M] row-major (wgrad, A = dY^T).
+ *   trans_b = 1: B is [N,K] row-major (an nn.Linear / 1x1-conv weight); 0: B is [K,N] row-major.
+ * A prologue (backward of `res + DropPath(Dropout(.))`, mdvit.py:311,354 / mpvit.py:73-78):
+ *   A[token][f] *= a_rowscale[token / a_rows_per_scale] * dropmask(a_key, token*F + f).
+ * Epilogues:
+ *   NONE      : C = acc + bias; then optional dropout(e_drop_p), row scale (DropPath), + residual.
+ *   GELU_DUAL : C = acc + bias (pre-activation u), C2 = dropout(gelu_erf(u))       (mpvit.py:73-75)
+ *   DGELU     : C = acc * gelu'(gelu_u) * dropmask(e_key)                          (backward of the above)
+ * allow_split: the reduction may be split across workgroups (fp32 atomics; C is zeroed first).
+ * Replaces: nn.Linear mdvit.py:288,310  mpvit.py:73,76; 1x1 nn.Conv2d mdvit.py:98,589
+ *           Decoders.py:185,300-311; their autograd backward. */
+typedef struct MdvitGemmDesc {
+    const float* A; const float* B; float* C; float* C2;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t trans_a, trans_b;
+    const float* bias;
+    float a_drop_p; uint32_t a_key0, a_key1;
+    const float* a_rowscale; int32_t a_rows_per_scale;
+    int32_t epi;
+    float e_drop_p; uint32_t e_key0, e_key1;
+    const float* e_rowscale; int32_t e_rows_per_scale;
+    const float* residual; int64_t ldr;
+    const float* gelu_u; int64_t ldu;
+    int32_t allow_split;
+} MdvitGemmDesc;
+int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
+
+/* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,
+ * linear_out Decoders.py:311).  bwd: dx[m,k] = dy[m] w[k]; dw[k] = sum_m dy[m] x[m,k]; db = sum dy. */
+int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y,
+                     int32_t M, int32_t K, int32_t accumulate, void* stream);
+int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, const float* dy, float* dx, int64_t lddx,
+                     float* dw, float* db, int32_t M, int32_t K, void* stream);
+
+/* out[n] = sum_m A[m][n] * (optional dropmask x rowscale, as the GEMM A prologue): bias gradients. */
+int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N,
+                     float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale,
+                     void* stream);
+
+/* ---- LayerNorm over C (nn.LayerNorm eps=1e-6, mdvit.py:327,342,498) ------------------------- */
+int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int32_t M, int32_t C, float eps, void* stream);
+int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+
+/* ---- 3x3 convolutions on NHWC ------------------------------------------------------------------
+ * dwconv3x3: depthwise, pad 1, stride 1|2, optional bias, optional "+ input" (ConvPosEnc,
+ * mpvit.py:239-248; DWCPatchEmbed dwconv mdvit.py:90-97).  w is [C,1,3,3]. */
+int mdvit_dwconv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
+                        int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream);
+int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                        int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream);
+/* gconv2: Conv2d(2C, C, 3, groups=C, bias=False) applied to cat(skip, up) WITHOUT materialising the
+ * concat (Decoders.py:30-38,198-199).  w is [C,2,3,3]; output channel g reads concat channels 2g, 2g+1. */
+int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const float* w, float* y,
+                         int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const float* up, const float* w,
+                         float* dskip, float* dup, float* dw, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* Dense 3x3 (pad 1) as im2col + GEMM: col is [B*Ho*Wo, Cin*9], column order (cin,kh,kw) == weight.view(Cout,-1)
+ * (stem.1 mpvit.py:104-111, bridge mdvit.py:557-564). */
+int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream);
+int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream);
+/* stem.0: NCHW image [B,Cin,H,W] -> NHWC [B,H/2,W/2,Cout], 3x3 s2 p1, no bias (mdvit.py:509-517). */
+int mdvit_stemconv_fwd(const float* img, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
+int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
+
+/* ---- BatchNorm2d (train: batch stats, biased var; running stats momentum, unbiased var) + activation
+ * on NHWC [M,C]  (mpvit.py:112-123, mdvit.py:99-122,559-563, Decoders.py:39-62,304-306).
+ * ws: 2*C doubles of scratch.  drop2d: nn.Dropout2d on (sample, channel) planes (Decoders.py:309,333). */
+int mdvit_bn_stats(const float* y, double* ws, float* mean, float* rstd, float* running_mean, float* running_var,
+                   int64_t* num_batches_tracked, int32_t M, int32_t C, float eps, float momentum, void* stream);
+int mdvit_bn_eval_prep(const float* running_mean, const float* running_var, float* mean, float* rstd, int32_t C, float eps, void* stream);
+int mdvit_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, float* z,
+                   int32_t M, int32_t C, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream);
+int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                 float* dy, float* dgamma, float* dbeta, double* ws, int32_t M, int32_t C, int32_t act, int32_t training,
+                 float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream);
+
+/* ---- bilinear resize, align_corners=False, NHWC (F.interpolate call sites mdvit.py:699,
+ * Decoders.py:196,320-329,336) ------------------------------------------------------------------ */
+int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C,
+                       int32_t accumulate, void* stream);
+int mdvit_upsample_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+
+/* ---- Domain Adapter: a = softmax_heads(W2 relu(W1 label + b1) + b2), [B,C] (mdvit.py:272-276,301-303) */
+int mdvit_da_fwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, float* a,
+                 int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream);
+int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,
+                 const float* da, float* dW1, float* db1, float* dW2, float* db2,
+                 int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream);
+
+/* ---- factorized attention core (mdvit.py:293-304, mpvit.py:296-318) -------------------------
+ * qkv: [B,N,3C] as produced by the qkv Linear (q | k | v, channel = head*Ch + ch).
+ * out[b,n,c] = a[b,c] * ( Ch^-0.5 * sum_j q[n,head,j] M[b,head,j,ch] + q[n,c] * (dwconv_win(v)[n,c] + bias[c]) )
+ * with M = softmax_over_tokens(k)^T v.  crpe weights: [s3*Ch,1,3,3], [s5*Ch,1,5,5], [s7*Ch,1,7,7] (+bias).
+ * a == NULL: no domain adapter (mpvit.py:347-373).  kmax/ksum [B,C] and Mmat [B,C,Ch] are saved for backward. */
+size_t mdvit_factoratt_ws_bytes(int32_t B, int32_t N, int32_t C, int32_t heads);
+int mdvit_factoratt_fwd(const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
+                        const float* w7, const float* b7, const float* a, float* out, float* kmax, float* ksum, float* Mmat,
+                        void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
+                        int32_t s3, int32_t s5, int32_t s7, void* stream);
+int mdvit_factoratt_bwd(const float* dout, const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
+                        const float* w7, const float* b7, const float* a, const float* kmax, const float* ksum, const float* Mmat,
+                        float* dqkv, float* da, float* dw3, float* db3, float* dw5, float* db5, float* dw7, float* db7,
+                        void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
+                        int32_t s3, int32_t s5, int32_t s7, void* stream);
+
+/* ---- step losses on logits (multi_train_MDViT.py:147-169, Utils/losses.py:8-16, nn.BCELoss) ---
+ * losses[0] = BCE(s(out),y)+Dice(s(out),y); [1] = same for aux; [2] = Dice(s(aux), s(out)).  aux may be NULL.
+ * sums: 16 doubles of scratch kept for backward.  g: 3 upstream gradients (device memory). */
+int mdvit_seg_losses_fwd(const float* out, const float* aux, const float* label, double* sums, float* losses, int64_t n, void* stream);
+int mdvit_seg_losses_bwd(const float* out, const float* aux, const float* label, const double* sums, const float* g,
+                         float* dout, float* daux, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDVIT_HIP_H */

@@ -1,0 +1,121 @@
+"""ctypes binding of libmdvit_hip.so (the C ABI declared in include/mdvit_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, the op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmdvit_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "mdvit_hip.h")
+
+EPI_NONE, EPI_GELU_DUAL, EPI_DGELU = 0, 1, 2
+ACT_NONE, ACT_HSWISH, ACT_RELU = 0, 1, 2
+
+f32p = C.c_void_p
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+u32 = C.c_uint32
+f32 = C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp), ("C2", vp),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("trans_a", i32), ("trans_b", i32),
+        ("bias", vp),
+        ("a_drop_p", f32), ("a_key0", u32), ("a_key1", u32),
+        ("a_rowscale", vp), ("a_rows_per_scale", i32),
+        ("epi", i32),
+        ("e_drop_p", f32), ("e_key0", u32), ("e_key1", u32),
+        ("e_rowscale", vp), ("e_rows_per_scale", i32),
+        ("residual", vp), ("ldr", i64),
+        ("gelu_u", vp), ("ldu", i64),
+        ("allow_split", i32),
+    ]
+
+
+_SIGS = {
+    "mdvit_gemm_f32": [C.POINTER(GemmDesc), vp],
+    "mdvit_rowdot_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
+    "mdvit_rowdot_bwd": [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, vp],
+    "mdvit_colsum_f32": [vp, i64, vp, i32, i32, f32, u32, u32, vp, i32, vp],
+    "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "mdvit_dwconv3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_gconv2_3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_gconv2_3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_im2col3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_col2im3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_stemconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_stemconv_wgrad": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_bn_stats": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp],
+    "mdvit_bn_eval_prep": [vp, vp, vp, vp, i32, f32, vp],
+    "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, i32, vp],
+    "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32, i32, vp],
+    "mdvit_upsample_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_upsample_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_da_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_factoratt_fwd": [vp] * 12 + [vp, C.c_size_t] + [i32] * 8 + [vp],
+    "mdvit_factoratt_bwd": [vp] * 20 + [vp, C.c_size_t] + [i32] * 8 + [vp],
+    "mdvit_seg_losses_fwd": [vp, vp, vp, vp, vp, i64, vp],
+    "mdvit_seg_losses_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, vp],
+}
+
+_lib = None
+
+
+class MdvitHipError(RuntimeError):
+    pass
+
+
+def declared_symbols() -> List[str]:
+    """Every function the public header declares (used by the symbol-export test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdvit_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """dlopen the library (works without a GPU) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MdvitHipError(
+            f"{LIB_PATH} is missing: build it with `python -m mdvit_amd.build` (hipcc, gfx950). "
+            "mdvit_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mdvit_last_error.restype = C.c_char_p
+    lib.mdvit_last_error.argtypes = []
+    lib.mdvit_version.restype = C.c_int
+    lib.mdvit_version.argtypes = []
+    lib.mdvit_factoratt_ws_bytes.restype = C.c_size_t
+    lib.mdvit_factoratt_ws_bytes.argtypes = [i32, i32, i32, i32]
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = sig
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().mdvit_last_error().decode(errors="replace")
+        raise MdvitHipError(f"{what} failed (code {code}): {msg}")
+
+
+def call(name: str, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,337 @@
+"""Building blocks of the MDViT path as nn.Modules whose forward runs HIP kernels (mdvit_amd.ops).
+
+Class names, constructor arguments, parameter names and shapes mirror the reference so its
+state_dict loads unchanged:
+  Conv2d_BN, ConvPosEnc, ConvRelPosEnc, Mlp, FactorAtt_ConvRelPosEnc   <- Models/Transformer/mpvit.py
+  DWConv2d_BN, DWCPatchEmbed, FactorAtt_ConvRelPosEnc_Sup, SerialBlock_adapt, MHSA_stage_adapt
+                                                                      <- Models/Transformer/mdvit.py
+Internally every activation is NHWC: images [B,H,W,C], tokens [B,H*W,C] (the same memory).
+Parameters live in plain containers (no torch forward exists to fall back to).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import ACT_HSWISH, ACT_NONE, ACT_RELU
+
+
+# ---- parameter containers (state_dict-compatible with nn.Conv2d / nn.Linear / nn.LayerNorm / nn.BatchNorm2d)
+class ConvParams(nn.Module):
+    def __init__(self, out_ch, in_per_group, kh, kw, bias=True, groups=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_ch, in_per_group, kh, kw))
+        self.bias = nn.Parameter(torch.empty(out_ch)) if bias else None
+        self.kernel_size, self.out_channels, self.groups = (kh, kw), out_ch, groups
+
+    def forward(self, *a, **k):
+        raise RuntimeError("ConvParams only holds parameters; compute goes through mdvit_amd.ops (HIP)")
+
+
+class LinearParams(nn.Module):
+    def __init__(self, in_f, out_f, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        self.bias = nn.Parameter(torch.empty(out_f)) if bias else None
+
+    def forward(self, *a, **k):
+        raise RuntimeError("LinearParams only holds parameters; compute goes through mdvit_amd.ops (HIP)")
+
+
+class LayerNormParams(nn.Module):
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class BatchNormAct(nn.Module):
+    """nn.BatchNorm2d state (weight, bias, running_mean, running_var, num_batches_tracked) + fused activation."""
+
+    def __init__(self, ch, act=ACT_NONE, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(ch))
+        self.bias = nn.Parameter(torch.zeros(ch))
+        self.register_buffer("running_mean", torch.zeros(ch))
+        self.register_buffer("running_var", torch.ones(ch))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.act, self.eps, self.momentum = act, eps, momentum
+
+    def forward(self, y, drop2d_p: float = 0.0):
+        return ops.bn_act(y, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked,
+                          self.training, self.act, self.eps, self.momentum, drop2d_p if self.training else 0.0)
+
+
+def _check_norm(conv_norm):
+    if conv_norm is not nn.BatchNorm2d:
+        raise NotImplementedError("only conv_norm=nn.BatchNorm2d is built (the reference's train scripts use nothing else)")
+
+
+class _NoParams(nn.Module):
+    """placeholder keeping nn.Sequential indices aligned with the reference (ReLU / Identity slots)."""
+
+    def forward(self, x):
+        return x
+
+
+# ---- conv blocks -----------------------------------------------------------------------------------
+class Conv2d_BN(nn.Module):
+    """stem conv: 3x3 s2 p1 (no bias) -> BN -> Hardswish (mpvit.py:81-124).  First stem conv reads the
+    NCHW image directly; the second goes im2col + MFMA GEMM."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish, norm_layer=nn.BatchNorm2d, from_image=False):
+        super().__init__()
+        _check_norm(norm_layer)
+        assert kernel_size == 3 and pad == 1
+        self.conv = ConvParams(out_ch, in_ch, 3, 3, bias=False)
+        self.bn = BatchNormAct(out_ch, ACT_HSWISH if act_layer is nn.Hardswish else ACT_NONE)
+        self.stride, self.from_image = stride, from_image
+
+    def forward(self, x):
+        if self.from_image:
+            assert self.stride == 2
+            y = ops.stem_conv(x, self.conv.weight)
+        else:
+            y = ops.conv3x3_dense(x, self.conv.weight, None, self.stride)
+        return self.bn(y)
+
+
+class DWConv2d_BN(nn.Module):
+    """dw3x3(groups=in) -> pw1x1 -> BN -> Hardswish (mdvit.py:74-123)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, norm_layer=nn.BatchNorm2d, act_layer=nn.Hardswish):
+        super().__init__()
+        _check_norm(norm_layer)
+        assert kernel_size == 3
+        self.dwconv = ConvParams(in_ch, 1, 3, 3, bias=False, groups=in_ch)
+        self.pwconv = ConvParams(out_ch, in_ch, 1, 1, bias=False)
+        self.bn = BatchNormAct(out_ch, ACT_HSWISH)
+        self.stride = stride
+
+    def forward(self, x):
+        t = ops.dwconv3x3(x, self.dwconv.weight, None, self.stride, False)
+        return self.bn(ops.linear(t, self.pwconv.weight))
+
+
+class DWCPatchEmbed(nn.Module):
+    """mdvit.py:183-208."""
+
+    def __init__(self, in_chans=3, embed_dim=768, patch_size=16, stride=1, conv_norm=nn.BatchNorm2d, act_layer=nn.Hardswish):
+        super().__init__()
+        self.patch_conv = DWConv2d_BN(in_chans, embed_dim, kernel_size=patch_size, stride=stride, norm_layer=conv_norm, act_layer=act_layer)
+
+    def forward(self, x):
+        return self.patch_conv(x)
+
+
+class DecoderDWConv2d_BN(nn.Module):
+    """Decoders.py flavour (:15-63): Conv2d(in=2*out, out, 3, groups=out) -> pw(out,out) -> BN -> Hardswish,
+    applied to cat(skip, up) without materialising the concat."""
+
+    def __init__(self, in_ch, out_ch, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        _check_norm(norm_layer)
+        assert in_ch == 2 * out_ch
+        self.dwconv = ConvParams(out_ch, 2, 3, 3, bias=False, groups=out_ch)
+        self.pwconv = ConvParams(out_ch, out_ch, 1, 1, bias=False)
+        self.bn = BatchNormAct(out_ch, ACT_HSWISH)
+
+    def forward(self, skip, up):
+        t = ops.gconv2_3x3(skip, up, self.dwconv.weight)
+        return self.bn(ops.linear(t, self.pwconv.weight))
+
+
+# ---- transformer block ------------------------------------------------------------------------------
+class ConvPosEnc(nn.Module):
+    """x + dwconv3x3_bias(x)  (mpvit.py:229-248)."""
+
+    def __init__(self, dim, k=3):
+        super().__init__()
+        assert k == 3
+        self.proj = ConvParams(dim, 1, 3, 3, bias=True, groups=dim)
+
+    def forward(self, x, size: Tuple[int, int]):
+        B, N, Cn = x.shape
+        H, W = size
+        return ops.dwconv3x3(x.view(B, H, W, Cn), self.proj.weight, self.proj.bias, 1, True).view(B, N, Cn)
+
+
+class ConvRelPosEnc(nn.Module):
+    """Holds the 3/5/7 depthwise windows (mpvit.py:251-318); applied inside ops.factor_att."""
+
+    def __init__(self, Ch, h, window):
+        super().__init__()
+        if isinstance(window, int):
+            window = {window: h}
+        if sorted(window) != [3, 5, 7] or sum(window.values()) != h:
+            raise NotImplementedError("the HIP attention kernel is built for the reference's {3:2, 5:3, 7:3}-style windows")
+        self.window = dict(window)
+        self.head_splits = [window[3], window[5], window[7]]
+        self.conv_list = nn.ModuleList([ConvParams(window[k] * Ch, 1, k, k, bias=True, groups=window[k] * Ch) for k in (3, 5, 7)])
+
+    def params(self):
+        c = self.conv_list
+        return (c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[2].weight, c[2].bias)
+
+
+class _FactorAttBase(nn.Module):
+    def _attend(self, x, size, a, res, rowscale):
+        B, N, Cn = x.shape
+        H, W = size
+        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
+        y = ops.factor_att(qkv, self.crpe.params(), a, H, W, self.num_heads, self.crpe.head_splits)
+        # proj + proj_drop (+ DropPath + residual when the caller hands them in)
+        return ops.linear(y, self.proj.weight, self.proj.bias, residual=res, rowscale=rowscale,
+                          drop_p=self.proj_drop_p if self.training else 0.0, rows_per_scale=N)
+
+
+class FactorAtt_ConvRelPosEnc(_FactorAttBase):
+    """mpvit.py:321-373 (no domain adapter)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0, shared_crpe=None):
+        super().__init__()
+        if qk_scale is not None:
+            raise NotImplementedError("qk_scale override is not built")
+        self.num_heads = num_heads
+        self.qkv = LinearParams(dim, dim * 3, bias=qkv_bias)
+        self.proj = LinearParams(dim, dim)
+        self.proj_drop_p = proj_drop
+        self.crpe = shared_crpe
+
+    def forward(self, x, size, _res=None, _rowscale=None):
+        return self._attend(x, size, None, _res, _rowscale)
+
+
+class FactorAtt_ConvRelPosEnc_Sup(_FactorAttBase):
+    """mdvit.py:243-313 (domain adapter: softmax over heads of MLP(one_hot))."""
+
+    def __init__(self, seq_length, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0,
+                 shared_crpe=None, r=2, num_domains=4):
+        super().__init__()
+        if qk_scale is not None:
+            raise NotImplementedError("qk_scale override is not built")
+        self.num_heads = num_heads
+        hidden = max(dim // r, 4)
+        self.qkv = LinearParams(dim, dim * 3, bias=qkv_bias)
+        self.proj = LinearParams(dim, dim)
+        self.proj_drop_p = proj_drop
+        self.domain_layer = nn.Sequential(LinearParams(num_domains, hidden), _NoParams(), LinearParams(hidden, dim))
+        self.crpe = shared_crpe
+
+    def forward(self, x, size, domain_label, _res=None, _rowscale=None):
+        d0, d2 = self.domain_layer[0], self.domain_layer[2]
+        a = ops.domain_adapter(domain_label, d0.weight, d0.bias, d2.weight, d2.bias, self.num_heads)
+        return self._attend(x, size, a, _res, _rowscale)
+
+
+class Mlp(nn.Module):
+    """mpvit.py:51-78."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        assert out_features == in_features and act_layer is nn.GELU
+        self.fc1 = LinearParams(in_features, hidden_features)
+        self.fc2 = LinearParams(hidden_features, out_features)
+        self.drop_p = drop
+
+    def forward(self, x, _res=None, _rowscale=None):
+        N = x.shape[1]
+        res = _res if _res is not None else torch.zeros_like(x)
+        return ops.mlp_residual(x, res, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, _rowscale,
+                                self.drop_p if self.training else 0.0, N)
+
+
+class SerialBlock_adapt(nn.Module):
+    """mdvit.py:316-361: cpe -> LN -> attention(+DA) -> DropPath+res -> LN -> MLP -> DropPath+res."""
+
+    def __init__(self, seq_length, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, act_layer=nn.GELU, norm_layer=None, shared_cpe=None, shared_crpe=None, adapt_method=None,
+                 num_domains=4, base_semantics=False):
+        super().__init__()
+        self.cpe = shared_cpe
+        self.norm1 = LayerNormParams(dim, 1e-6)
+        self.adapt_method = adapt_method
+        self.base_semantics = base_semantics
+        if adapt_method == "Sup":
+            self.factoratt_crpe = FactorAtt_ConvRelPosEnc_Sup(seq_length, dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                                              attn_drop=attn_drop, proj_drop=drop, shared_crpe=shared_crpe, num_domains=num_domains)
+        else:
+            self.factoratt_crpe = FactorAtt_ConvRelPosEnc(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                                          attn_drop=attn_drop, proj_drop=drop, shared_crpe=shared_crpe)
+        self.drop_path_p = drop_path
+        self.norm2 = LayerNormParams(dim, 1e-6)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def _droppath_scales(self, B, device):
+        if not self.training or self.drop_path_p <= 0.0:
+            return None, None
+        keep = 1.0 - self.drop_path_p
+        m = (torch.rand((2, B), device=device) < keep).float() / keep      # per-sample masks for both branches
+        return m[0].contiguous(), m[1].contiguous()
+
+    def forward(self, x, size: Tuple[int, int], domain_label=None):
+        x = self.cpe(x, size)
+        s1, s2 = self._droppath_scales(x.shape[0], x.device)
+        cur = self.norm1(x)
+        use_da = (domain_label is not None) if self.base_semantics else (self.adapt_method is not None and domain_label is not None)
+        if use_da:
+            if not isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
+                raise TypeError("forward() got a domain_label but this block was built without adapt_method='Sup' "
+                                "(the reference raises here too: mdvit.py:350-351)")
+            x = self.factoratt_crpe(cur, size, domain_label, _res=x, _rowscale=s1)
+        else:
+            if isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
+                raise TypeError("adapt_method='Sup' blocks need a domain_label (mdvit.py:281)")
+            x = self.factoratt_crpe(cur, size, _res=x, _rowscale=s1)
+        cur = self.norm2(x)
+        return self.mlp(cur, _res=x, _rowscale=s2)
+
+
+class MHSA_stage_adapt(nn.Module):
+    """mdvit.py:415-440: one shared ConvPosEnc / ConvRelPosEnc per stage, num_layers serial blocks."""
+
+    def __init__(self, seq_length, dim, num_layers, num_heads, mlp_ratio, qkv_bias=True, qk_scale=None, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.0, num_domains=4, norm_layer=None, adapt_method=None,
+                 crpe_window={3: 2, 5: 3, 7: 3}, base_semantics=False):
+        super().__init__()
+        self.cpe = ConvPosEnc(dim, k=3)
+        self.crpe = ConvRelPosEnc(Ch=dim // num_heads, h=num_heads, window=crpe_window)
+        self.mhca_blks = nn.ModuleList([
+            SerialBlock_adapt(seq_length, dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_rate, attn_drop_rate, drop_path_rate,
+                              nn.GELU, norm_layer, self.cpe, self.crpe, adapt_method, num_domains, base_semantics)
+            for _ in range(num_layers)])
+
+    def forward(self, input, H, W, domain_label=None):
+        for blk in self.mhca_blks:
+            input = blk(input, (H, W), domain_label)
+        return input
+
+
+def init_weights_(module: nn.Module):
+    """The reference's `_init_weights` (mdvit.py:648-664): Linear trunc_normal(.02)/0, LayerNorm 1/0,
+    Conv normal(0, sqrt(2/fan_out)) with fan_out = kh*kw*out/groups, BatchNorm 1/0."""
+    for m in module.modules():
+        if isinstance(m, LinearParams):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, LayerNormParams):
+            nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+        elif isinstance(m, ConvParams):
+            out_ch, in_pg, kh, kw = m.weight.shape
+            fan_out = kh * kw * out_ch // m.groups
+            nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / fan_out))
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, BatchNormAct):
+            nn.init.ones_(m.weight); nn.init.zeros_(m.bias)

@@ -1,0 +1,75 @@
+// Shared device/host helpers for libmdvit_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mdvit_hip.h"
+
+#define MDVIT_WAVE 64
+
+// ---- thread-local last-error string --------------------------------------------------------
+extern thread_local char g_mdvit_err[512];
+int mdvit_set_error(int code, const char* fmt, ...);
+
+#define MDVIT_CHECK_ARG(cond, code, ...)                      \
+    do {                                                      \
+        if (!(cond)) return mdvit_set_error(code, __VA_ARGS__); \
+    } while (0)
+
+#define MDVIT_LAUNCH_CHECK()                                                         \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess)                                                       \
+            return mdvit_set_error(MDVIT_E_HIP, "%s:%d launch failed: %s", __FILE__, \
+                                   __LINE__, hipGetErrorString(e__));                \
+    } while (0)
+
+#define MDVIT_ZERO(ptr, bytes, strm)                                                          \
+    do {                                                                                     \
+        hipError_t e__ = hipMemsetAsync((ptr), 0, (bytes), (strm));                          \
+        if (e__ != hipSuccess)                                                               \
+            return mdvit_set_error(MDVIT_E_HIP, "%s:%d memset failed: %s", __FILE__, __LINE__, \
+                                   hipGetErrorString(e__));                                  \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- counter-based dropout RNG (stateless; the backward pass re-derives the mask) ----------
+__device__ __forceinline__ uint32_t mdvit_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// keep-scale for element idx under (k0,k1): 0 or inv_keep.  thresh = round(p * 2^32).
+__device__ __forceinline__ float mdvit_drop_scale(uint32_t k0, uint32_t k1, uint32_t idx, uint32_t thresh, float inv_keep) {
+    uint32_t h = mdvit_hash32(mdvit_hash32(idx ^ k0) + k1);
+    return h >= thresh ? inv_keep : 0.0f;
+}
+
+// ---- wave / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU default)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float hswish_f(float x) { return x * fminf(fmaxf(x + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f); }
+__device__ __forceinline__ float hswish_grad_f(float x) {
+    // d/dx [x * clamp(x+3,0,6)/6]; ATen: 0 for x<-3, 1 for x>3, (2x+3)/6 in between
+    return x < -3.0f ? 0.0f : (x > 3.0f ? 1.0f : (2.0f * x + 3.0f) * (1.0f / 6.0f));
+}

@@ -1,0 +1,627 @@
+// 3x3 convolutions and bilinear resampling on NHWC fp32 (HBM-bound; lanes run along channels so
+// every global access is a contiguous 16 B/lane float4, halo re-reads are served by L1/L2).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 f4_fma(float4 a, float4 w, float4 acc) {
+    acc.x = fmaf(a.x, w.x, acc.x); acc.y = fmaf(a.y, w.y, acc.y); acc.z = fmaf(a.z, w.z, acc.z); acc.w = fmaf(a.w, w.w, acc.w);
+    return acc;
+}
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ---- depthwise 3x3, pad 1, stride 1|2 --------------------------------------------------------
+// thread = (output token, channel quad).  w [C,1,3,3] -> LDS as [9][C] once per block.
+__global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int B, int Hi, int Wi, int C, int stride, int add_input) {
+    extern __shared__ float s_w[];   // [9][C]
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) { const int c = i / 9, t = i % 9; s_w[t * C + c] = w[i]; }
+    __syncthreads();
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1, QC = C >> 2;
+    const long total = (long)B * Ho * Wo * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % QC) * 4;
+        long tkn = e / QC;
+        const int wo = (int)(tkn % Wo); tkn /= Wo;
+        const int ho = (int)(tkn % Ho);
+        const int b = (int)(tkn / Ho);
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * stride + kh - 1;
+            if (hi < 0 || hi >= Hi) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * stride + kw - 1;
+                if (wi < 0 || wi >= Wi) continue;
+                const float4 xv = *reinterpret_cast<const float4*>(x + (((long)b * Hi + hi) * Wi + wi) * C + c);
+                const float4 wv = *reinterpret_cast<const float4*>(&s_w[(kh * 3 + kw) * C + c]);
+                acc = f4_fma(xv, wv, acc);
+            }
+        }
+        if (add_input) acc = f4_add(acc, *reinterpret_cast<const float4*>(x + (((long)b * Hi + ho) * Wi + wo) * C + c));
+        *reinterpret_cast<float4*>(y + (((long)b * Ho + ho) * Wo + wo) * C + c) = acc;
+    }
+}
+
+// dgrad: dx[b,hi,wi,c] = sum_{kh,kw} w[c,kh,kw] * dy[b,ho,wo,c], ho*stride + kh - 1 == hi  (+ dy if add_input)
+__global__ __launch_bounds__(256) void dwconv3x3_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int B, int Hi, int Wi, int C, int stride, int add_input) {
+    extern __shared__ float s_w[];
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) { const int c = i / 9, t = i % 9; s_w[t * C + c] = w[i]; }
+    __syncthreads();
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1, QC = C >> 2;
+    const long total = (long)B * Hi * Wi * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % QC) * 4;
+        long tkn = e / QC;
+        const int wi = (int)(tkn % Wi); tkn /= Wi;
+        const int hi = (int)(tkn % Hi);
+        const int b = (int)(tkn / Hi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hn = hi - kh + 1;
+            if (hn < 0 || (hn % stride) != 0) continue;
+            const int ho = hn / stride;
+            if (ho >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wn = wi - kw + 1;
+                if (wn < 0 || (wn % stride) != 0) continue;
+                const int wo = wn / stride;
+                if (wo >= Wo) continue;
+                const float4 g = *reinterpret_cast<const float4*>(dy + (((long)b * Ho + ho) * Wo + wo) * C + c);
+                const float4 wv = *reinterpret_cast<const float4*>(&s_w[(kh * 3 + kw) * C + c]);
+                acc = f4_fma(g, wv, acc);
+            }
+        }
+        if (add_input) acc = f4_add(acc, *reinterpret_cast<const float4*>(dy + (((long)b * Hi + hi) * Wi + wi) * C + c));
+        *reinterpret_cast<float4*>(dx + (((long)b * Hi + hi) * Wi + wi) * C + c) = acc;
+    }
+}
+
+// wgrad: dw[c,kh,kw] = sum_{b,ho,wo} dy[b,ho,wo,c] * x[b,ho*s+kh-1,wo*s+kw-1,c]; dbias[c] = sum dy.
+// Block = (C/4 quads) x (256/(C/4) token lanes) over a contiguous chunk of output tokens; register
+// partials -> LDS atomics -> one global atomic per (c,tap) per block.
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ dw, float* __restrict__ dbias,
+                                                              int B, int Hi, int Wi, int C, int stride, int tokens_per_block) {
+    extern __shared__ float s_acc[];   // [C][10]
+    for (int i = threadIdx.x; i < C * 10; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1, QC = C >> 2;
+    const long ntok = (long)B * Ho * Wo;
+    const long t_beg = (long)blockIdx.x * tokens_per_block, t_end = min(ntok, t_beg + tokens_per_block);
+    const int nquads_blk = min(QC, 256);
+    const int tl = threadIdx.x / nquads_blk, ntl = blockDim.x / nquads_blk;
+    for (int q = threadIdx.x % nquads_blk; q < QC; q += nquads_blk) {
+        const int c = q * 4;
+        float4 acc[9];
+        float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tl < ntl) {
+            for (long tk = t_beg + tl; tk < t_end; tk += ntl) {
+                long r = tk;
+                const int wo = (int)(r % Wo); r /= Wo;
+                const int ho = (int)(r % Ho);
+                const int b = (int)(r / Ho);
+                const float4 g = *reinterpret_cast<const float4*>(dy + tk * C + c);
+                accb = f4_add(accb, g);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hi = ho * stride + kh - 1;
+                    if (hi < 0 || hi >= Hi) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int wi = wo * stride + kw - 1;
+                        if (wi < 0 || wi >= Wi) continue;
+                        const float4 xv = *reinterpret_cast<const float4*>(x + (((long)b * Hi + hi) * Wi + wi) * C + c);
+                        acc[kh * 3 + kw] = f4_fma(g, xv, acc[kh * 3 + kw]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            atomicAdd(&s_acc[(c + 0) * 10 + t], acc[t].x); atomicAdd(&s_acc[(c + 1) * 10 + t], acc[t].y);
+            atomicAdd(&s_acc[(c + 2) * 10 + t], acc[t].z); atomicAdd(&s_acc[(c + 3) * 10 + t], acc[t].w);
+        }
+        atomicAdd(&s_acc[(c + 0) * 10 + 9], accb.x); atomicAdd(&s_acc[(c + 1) * 10 + 9], accb.y);
+        atomicAdd(&s_acc[(c + 2) * 10 + 9], accb.z); atomicAdd(&s_acc[(c + 3) * 10 + 9], accb.w);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 10; i += blockDim.x) {
+        const int c = i / 10, t = i % 10;
+        if (t < 9) atomicAdd(&dw[c * 9 + t], s_acc[i]);
+        else if (dbias) atomicAdd(&dbias[c], s_acc[i]);
+    }
+}
+
+// ---- grouped conv on the virtual concat(skip, up): out channel g <- concat channels 2g, 2g+1 ---
+// thread = (token, output-channel pair): reads one float4 = concat channels [4p, 4p+4) -> outputs 2p, 2p+1
+__device__ __forceinline__ const float* cat_ptr(const float* skip, const float* up, int C, long tok, int cc) {
+    // cc: concat channel (multiple of 4) in [0, 2C)
+    return cc < C ? skip + tok * C + cc : up + tok * C + (cc - C);
+}
+
+__global__ __launch_bounds__(256) void gconv2_fwd_kernel(const float* __restrict__ skip, const float* __restrict__ up,
+                                                         const float* __restrict__ w, float* __restrict__ y, int B, int H, int W, int C) {
+    extern __shared__ float s_w[];   // [9][2C]: tap-major, concat-channel minor
+    for (int i = threadIdx.x; i < 18 * C; i += blockDim.x) {
+        const int g = i / 18, r = i % 18, j = r / 9, t = r % 9;     // w[g][j][t]
+        s_w[t * 2 * C + 2 * g + j] = w[i];
+    }
+    __syncthreads();
+    const int PC = C >> 1;
+    const long total = (long)B * H * W * PC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % PC);
+        long tkn = e / PC;
+        const int wo = (int)(tkn % W); tkn /= W;
+        const int ho = (int)(tkn % H);
+        const int b = (int)(tkn / H);
+        const int cc = 4 * p;
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho + kh - 1;
+            if (hi < 0 || hi >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo + kw - 1;
+                if (wi < 0 || wi >= W) continue;
+                const float4 xv = *reinterpret_cast<const float4*>(cat_ptr(skip, up, C, ((long)b * H + hi) * W + wi, cc));
+                const float4 wv = *reinterpret_cast<const float4*>(&s_w[(kh * 3 + kw) * 2 * C + cc]);
+                o0 = fmaf(xv.x, wv.x, fmaf(xv.y, wv.y, o0));
+                o1 = fmaf(xv.z, wv.z, fmaf(xv.w, wv.w, o1));
+            }
+        }
+        *reinterpret_cast<float2*>(y + (((long)b * H + ho) * W + wo) * C + 2 * p) = make_float2(o0, o1);
+    }
+}
+
+// dgrad wrt the concat: d cat[b,hi,wi,2g+j] = sum_taps w[g,j,kh,kw] dy[b,hi-kh+1,wi-kw+1,g]
+__global__ __launch_bounds__(256) void gconv2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           float* __restrict__ dskip, float* __restrict__ dup, int B, int H, int W, int C) {
+    extern __shared__ float s_w[];
+    for (int i = threadIdx.x; i < 18 * C; i += blockDim.x) {
+        const int g = i / 18, r = i % 18, j = r / 9, t = r % 9;
+        s_w[t * 2 * C + 2 * g + j] = w[i];
+    }
+    __syncthreads();
+    const int PC = C >> 1;
+    const long total = (long)B * H * W * PC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % PC);
+        long tkn = e / PC;
+        const int wi = (int)(tkn % W); tkn /= W;
+        const int hi = (int)(tkn % H);
+        const int b = (int)(tkn / H);
+        const int cc = 4 * p;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ho = hi - kh + 1;
+            if (ho < 0 || ho >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wo = wi - kw + 1;
+                if (wo < 0 || wo >= W) continue;
+                const float2 g = *reinterpret_cast<const float2*>(dy + (((long)b * H + ho) * W + wo) * C + 2 * p);
+                const float4 wv = *reinterpret_cast<const float4*>(&s_w[(kh * 3 + kw) * 2 * C + cc]);
+                acc.x = fmaf(g.x, wv.x, acc.x); acc.y = fmaf(g.x, wv.y, acc.y);
+                acc.z = fmaf(g.y, wv.z, acc.z); acc.w = fmaf(g.y, wv.w, acc.w);
+            }
+        }
+        const long tok = ((long)b * H + hi) * W + wi;
+        float* dst = cc < C ? dskip + tok * C + cc : dup + tok * C + (cc - C);
+        *reinterpret_cast<float4*>(dst) = acc;
+    }
+}
+
+// wgrad: dw[g,j,kh,kw] = sum dy[b,ho,wo,g] * cat[b,ho+kh-1,wo+kw-1,2g+j]
+__global__ __launch_bounds__(256) void gconv2_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ skip,
+                                                           const float* __restrict__ up, float* __restrict__ dw,
+                                                           int B, int H, int W, int C, int tokens_per_block) {
+    extern __shared__ float s_acc[];   // [C][18]
+    for (int i = threadIdx.x; i < C * 18; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    const int PC = C >> 1;
+    const long ntok = (long)B * H * W;
+    const long t_beg = (long)blockIdx.x * tokens_per_block, t_end = min(ntok, t_beg + tokens_per_block);
+    const int np_blk = min(PC, 256);
+    const int tl = threadIdx.x / np_blk, ntl = blockDim.x / np_blk;
+    for (int p = threadIdx.x % np_blk; p < PC; p += np_blk) {
+        const int cc = 4 * p;
+        float4 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tl < ntl) {
+            for (long tk = t_beg + tl; tk < t_end; tk += ntl) {
+                long r = tk;
+                const int wo = (int)(r % W); r /= W;
+                const int ho = (int)(r % H);
+                const int b = (int)(r / H);
+                const float2 g = *reinterpret_cast<const float2*>(dy + tk * C + 2 * p);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hi = ho + kh - 1;
+                    if (hi < 0 || hi >= H) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int wi = wo + kw - 1;
+                        if (wi < 0 || wi >= W) continue;
+                        const float4 xv = *reinterpret_cast<const float4*>(cat_ptr(skip, up, C, ((long)b * H + hi) * W + wi, cc));
+                        float4& a = acc[kh * 3 + kw];
+                        a.x = fmaf(g.x, xv.x, a.x); a.y = fmaf(g.x, xv.y, a.y);
+                        a.z = fmaf(g.y, xv.z, a.z); a.w = fmaf(g.y, xv.w, a.w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {   // outputs 2p (j=0,1) and 2p+1 (j=0,1)
+            atomicAdd(&s_acc[(2 * p) * 18 + t], acc[t].x);     atomicAdd(&s_acc[(2 * p) * 18 + 9 + t], acc[t].y);
+            atomicAdd(&s_acc[(2 * p + 1) * 18 + t], acc[t].z); atomicAdd(&s_acc[(2 * p + 1) * 18 + 9 + t], acc[t].w);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 18; i += blockDim.x) atomicAdd(&dw[i], s_acc[i]);
+}
+
+// ---- im2col / col2im for dense 3x3 pad 1; column order (cin, kh, kw) ---------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ col,
+                                                        int B, int Hi, int Wi, int Cin, int stride) {
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    const long total = (long)B * Ho * Wo * Cin;
+    const int K = Cin * 9;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % Cin);
+        long m = e / Cin;
+        long r = m;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float* dst = col + m * K + c * 9;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * stride + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * stride + kw - 1;
+                const bool ok = hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+                dst[kh * 3 + kw] = ok ? x[(((long)b * Hi + hi) * Wi + wi) * Cin + c] : 0.f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, float* __restrict__ dx,
+                                                        int B, int Hi, int Wi, int Cin, int stride) {
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    const long total = (long)B * Hi * Wi * Cin;
+    const int K = Cin * 9;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % Cin);
+        long r = e / Cin;
+        const int wi = (int)(r % Wi); r /= Wi;
+        const int hi = (int)(r % Hi);
+        const int b = (int)(r / Hi);
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hn = hi - kh + 1;
+            if (hn < 0 || (hn % stride) != 0) continue;
+            const int ho = hn / stride;
+            if (ho >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wn = wi - kw + 1;
+                if (wn < 0 || (wn % stride) != 0) continue;
+                const int wo = wn / stride;
+                if (wo >= Wo) continue;
+                acc += dcol[(((long)b * Ho + ho) * Wo + wo) * K + c * 9 + kh * 3 + kw];
+            }
+        }
+        dx[e] = acc;
+    }
+}
+
+// ---- stem.0: NCHW image -> NHWC, 3x3 s2 p1; thread = (output pixel, 4 output channels) ----------
+template <int CIN>
+__global__ __launch_bounds__(256) void stemconv_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                           float* __restrict__ y, int B, int H, int W, int Cout) {
+    extern __shared__ float s_w[];   // [CIN*9][Cout]
+    for (int i = threadIdx.x; i < Cout * CIN * 9; i += blockDim.x) { const int co = i / (CIN * 9), k = i % (CIN * 9); s_w[k * Cout + co] = w[i]; }
+    __syncthreads();
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, QC = Cout >> 2;
+    const long total = (long)B * Ho * Wo * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(e % QC) * 4;
+        long r = e / QC;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hi = 2 * ho + kh - 1;
+                if (hi < 0 || hi >= H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int wi = 2 * wo + kw - 1;
+                    if (wi < 0 || wi >= W) continue;
+                    const float xv = img[(((long)b * CIN + ci) * H + hi) * W + wi];
+                    const float4 wv = *reinterpret_cast<const float4*>(&s_w[(ci * 9 + kh * 3 + kw) * Cout + co]);
+                    acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y); acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w);
+                }
+            }
+        *reinterpret_cast<float4*>(y + (((long)b * Ho + ho) * Wo + wo) * Cout + co) = acc;
+    }
+}
+
+// dw[co,ci,kh,kw] = sum_{b,ho,wo} dy[b,ho,wo,co] * img[b,ci,2ho+kh-1,2wo+kw-1]
+// thread = (co, pixel lane); 27 register accumulators; LDS atomics -> global atomics.
+template <int CIN>
+__global__ __launch_bounds__(256) void stemconv_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ dy,
+                                                             float* __restrict__ dw, int B, int H, int W, int Cout, int pix_per_block) {
+    extern __shared__ float s_acc[];   // [Cout][CIN*9]
+    constexpr int KK = CIN * 9;
+    for (int i = threadIdx.x; i < Cout * KK; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long npix = (long)B * Ho * Wo;
+    const long p_beg = (long)blockIdx.x * pix_per_block, p_end = min(npix, p_beg + pix_per_block);
+    const int nco = min(Cout, 256), pl = threadIdx.x / nco, npl = blockDim.x / nco;
+    for (int co = threadIdx.x % nco; co < Cout; co += nco) {
+        float acc[KK];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) acc[k] = 0.f;
+        if (pl < npl) {
+            for (long px = p_beg + pl; px < p_end; px += npl) {
+                long r = px;
+                const int wo = (int)(r % Wo); r /= Wo;
+                const int ho = (int)(r % Ho);
+                const int b = (int)(r / Ho);
+                const float g = dy[px * Cout + co];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int hi = 2 * ho + kh - 1;
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int wi = 2 * wo + kw - 1;
+                            const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+                            const float xv = ok ? img[(((long)b * CIN + ci) * H + hi) * W + wi] : 0.f;
+                            acc[ci * 9 + kh * 3 + kw] = fmaf(g, xv, acc[ci * 9 + kh * 3 + kw]);
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) atomicAdd(&s_acc[co * KK + k], acc[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cout * KK; i += blockDim.x) atomicAdd(&dw[i], s_acc[i]);
+}
+
+// ---- bilinear, align_corners=False (ATen upsample_bilinear2d index rule) ------------------------
+__device__ __forceinline__ void bilin_src(int o, int in_size, float scale, int& i0, int& i1, float& l1) {
+    float src = scale * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int B, int Hi, int Wi, int Ho, int Wo, int C, int accumulate) {
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    const bool vec = (C & 3) == 0;
+    const int QC = vec ? C >> 2 : C;
+    const long total = (long)B * Ho * Wo * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(e % QC);
+        long r = e / QC;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        int h0, h1, w0, w1; float lh, lw;
+        bilin_src(ho, Hi, sh, h0, h1, lh);
+        bilin_src(wo, Wi, sw, w0, w1, lw);
+        const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
+        const long base = (long)b * Hi * Wi;
+        if (vec) {
+            const int c = q * 4;
+            const float4 v00 = *reinterpret_cast<const float4*>(x + (base + (long)h0 * Wi + w0) * C + c);
+            const float4 v01 = *reinterpret_cast<const float4*>(x + (base + (long)h0 * Wi + w1) * C + c);
+            const float4 v10 = *reinterpret_cast<const float4*>(x + (base + (long)h1 * Wi + w0) * C + c);
+            const float4 v11 = *reinterpret_cast<const float4*>(x + (base + (long)h1 * Wi + w1) * C + c);
+            float4 o;
+            o.x = c00 * v00.x + c01 * v01.x + c10 * v10.x + c11 * v11.x;
+            o.y = c00 * v00.y + c01 * v01.y + c10 * v10.y + c11 * v11.y;
+            o.z = c00 * v00.z + c01 * v01.z + c10 * v10.z + c11 * v11.z;
+            o.w = c00 * v00.w + c01 * v01.w + c10 * v10.w + c11 * v11.w;
+            float4* dst = reinterpret_cast<float4*>(y + (((long)b * Ho + ho) * Wo + wo) * C + c);
+            if (accumulate) o = f4_add(o, *dst);
+            *dst = o;
+        } else {
+            const float v = c00 * x[(base + (long)h0 * Wi + w0) * C + q] + c01 * x[(base + (long)h0 * Wi + w1) * C + q] +
+                            c10 * x[(base + (long)h1 * Wi + w0) * C + q] + c11 * x[(base + (long)h1 * Wi + w1) * C + q];
+            float* dst = y + (((long)b * Ho + ho) * Wo + wo) * C + q;
+            *dst = accumulate ? *dst + v : v;
+        }
+    }
+}
+
+// adjoint in gather form: for every input pixel, visit the output pixels whose 2-tap stencil can touch it.
+__device__ __forceinline__ void out_range(int i, int in_size, int out_size, int& lo, int& hi) {
+    // outputs o with floor(src(o)) in {i-1, i}; conservative bounds, exact weights are re-derived per o
+    const float inv = (float)out_size / (float)in_size;
+    lo = (int)floorf(((float)i - 1.0f) * inv) - 1;
+    hi = (int)ceilf(((float)i + 2.0f) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size) hi = out_size;
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                           int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    const bool vec = (C & 3) == 0;
+    const int QC = vec ? C >> 2 : C;
+    const long total = (long)B * Hi * Wi * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(e % QC);
+        long r = e / QC;
+        const int wi = (int)(r % Wi); r /= Wi;
+        const int hi = (int)(r % Hi);
+        const int b = (int)(r / Hi);
+        int olo, ohi, plo, phi;
+        out_range(hi, Hi, Ho, olo, ohi);
+        out_range(wi, Wi, Wo, plo, phi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oh = olo; oh < ohi; ++oh) {
+            int h0, h1; float lh;
+            bilin_src(oh, Hi, sh, h0, h1, lh);
+            const float wh = (h0 == hi ? 1.f - lh : 0.f) + (h1 == hi ? lh : 0.f);
+            if (wh == 0.f) continue;
+            for (int ow = plo; ow < phi; ++ow) {
+                int w0, w1; float lw;
+                bilin_src(ow, Wi, sw, w0, w1, lw);
+                const float ww = (w0 == wi ? 1.f - lw : 0.f) + (w1 == wi ? lw : 0.f);
+                if (ww == 0.f) continue;
+                const float cf = wh * ww;
+                const long off = (((long)b * Ho + oh) * Wo + ow) * C;
+                if (vec) {
+                    const float4 g = *reinterpret_cast<const float4*>(dy + off + q * 4);
+                    acc.x = fmaf(cf, g.x, acc.x); acc.y = fmaf(cf, g.y, acc.y); acc.z = fmaf(cf, g.z, acc.z); acc.w = fmaf(cf, g.w, acc.w);
+                } else {
+                    acc.x = fmaf(cf, dy[off + q], acc.x);
+                }
+            }
+        }
+        if (vec) *reinterpret_cast<float4*>(dx + (((long)b * Hi + hi) * Wi + wi) * C + q * 4) = acc;
+        else dx[(((long)b * Hi + hi) * Wi + wi) * C + q] = acc.x;
+    }
+}
+
+inline int ew_grid(long total) { return (int)min((total + 255) / 256, 16384L); }
+
+}  // namespace
+
+extern "C" int mdvit_dwconv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Hi, int32_t Wi,
+                                   int32_t C, int32_t stride, int32_t add_input, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "dwconv3x3_fwd: bad shape B=%d H=%d W=%d C=%d", B, Hi, Wi, C);
+    MDVIT_CHECK_ARG(stride == 1 || stride == 2, MDVIT_E_SHAPE, "dwconv3x3_fwd: stride must be 1 or 2");
+    MDVIT_CHECK_ARG(!(add_input && stride != 1), MDVIT_E_SHAPE, "dwconv3x3_fwd: add_input needs stride 1");
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    const long total = (long)B * Ho * Wo * C / 4;
+    hipLaunchKernelGGL(dwconv3x3_fwd_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 9 * C, (hipStream_t)stream,
+                       x, w, bias, y, B, Hi, Wi, C, stride, add_input);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                                   int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "dwconv3x3_bwd: bad shape B=%d H=%d W=%d C=%d", B, Hi, Wi, C);
+    MDVIT_CHECK_ARG(stride == 1 || stride == 2, MDVIT_E_SHAPE, "dwconv3x3_bwd: stride must be 1 or 2");
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    if (dx) {
+        const long total = (long)B * Hi * Wi * C / 4;
+        hipLaunchKernelGGL(dwconv3x3_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 9 * C, s, dy, w, dx, B, Hi, Wi, C, stride, add_input);
+    }
+    if (dw) {
+        MDVIT_ZERO(dw, sizeof(float) * 9 * C, s);
+        if (dbias) MDVIT_ZERO(dbias, sizeof(float) * C, s);
+        const long ntok = (long)B * Ho * Wo;
+        int tpb = (int)max(64L, (ntok + 1023) / 1024);
+        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(cdiv(ntok, tpb)), dim3(256), sizeof(float) * 10 * C, s, dy, x, dw, dbias, B, Hi, Wi, C, stride, tpb);
+    }
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, MDVIT_E_SHAPE, "gconv2_fwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+    const long total = (long)B * H * W * C / 2;
+    hipLaunchKernelGGL(gconv2_fwd_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, (hipStream_t)stream, skip, up, w, y, B, H, W, C);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const float* up, const float* w, float* dskip, float* dup, float* dw,
+                                    int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "gconv2_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
+    const long total = (long)B * H * W * C / 2;
+    hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
+    MDVIT_ZERO(dw, sizeof(float) * 18 * C, s);
+    const long ntok = (long)B * H * W;
+    int tpb = (int)max(64L, (ntok + 1023) / 1024);
+    hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(cdiv(ntok, tpb)), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, dw, B, H, W, C, tpb);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && (stride == 1 || stride == 2), MDVIT_E_SHAPE, "im2col3x3: bad shape");
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(ew_grid((long)B * Ho * Wo * Cin)), dim3(256), 0, (hipStream_t)stream, x, col, B, Hi, Wi, Cin, stride);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && (stride == 1 || stride == 2), MDVIT_E_SHAPE, "col2im3x3: bad shape");
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(ew_grid((long)B * Hi * Wi * Cin)), dim3(256), 0, (hipStream_t)stream, dcol, dx, B, Hi, Wi, Cin, stride);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_stemconv_fwd(const float* img, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+    MDVIT_CHECK_ARG(Cin == 3, MDVIT_E_SHAPE, "stemconv_fwd: only in_chans == 3 is built (got %d)", Cin);
+    MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0 && Cout <= 256, MDVIT_E_SHAPE, "stemconv_fwd: bad shape");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL((stemconv_fwd_kernel<3>), dim3(ew_grid((long)B * Ho * Wo * Cout / 4)), dim3(256), sizeof(float) * 27 * Cout, (hipStream_t)stream,
+                       img, w, y, B, H, W, Cout);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(Cin == 3, MDVIT_E_SHAPE, "stemconv_wgrad: only in_chans == 3 is built (got %d)", Cin);
+    MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout <= 256, MDVIT_E_SHAPE, "stemconv_wgrad: bad shape");
+    MDVIT_ZERO(dw, sizeof(float) * 27 * Cout, s);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long npix = (long)B * Ho * Wo;
+    int ppb = (int)max(64L, (npix + 2047) / 2048);
+    hipLaunchKernelGGL((stemconv_wgrad_kernel<3>), dim3(cdiv(npix, ppb)), dim3(256), sizeof(float) * 27 * Cout, s, img, dy, dw, B, H, W, Cout, ppb);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, int32_t accumulate, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, MDVIT_E_SHAPE, "upsample_fwd: bad shape");
+    const long total = (long)B * Ho * Wo * ((C & 3) == 0 ? C / 4 : C);
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hi, Wi, Ho, Wo, C, accumulate);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_upsample_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, MDVIT_E_SHAPE, "upsample_bwd: bad shape");
+    const long total = (long)B * Hi * Wi * ((C & 3) == 0 ? C / 4 : C);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hi, Wi, Ho, Wo, C);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}

@@ -1,0 +1,439 @@
+// LayerNorm, BatchNorm(+activation, +Dropout2d), 1-output linear ("rowdot") and column sums.
+// All HBM-bound streaming kernels over token-major [M, C] fp32: lanes run along C (coalesced),
+// row statistics by wavefront shuffle reductions, channel statistics by per-thread partials ->
+// LDS -> one double atomic per channel per workgroup.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per token row, row held in registers (C <= 64*VPT).
+// ------------------------------------------------------------------------------------------------
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < M; row += nw) {
+        const float* xr = x + (long)row * C;
+        float v[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < C ? xr[c] : 0.f;
+            s += v[j];
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = lane + 64 * j;
+            const float d = c < C ? v[j] - mu : 0.f;
+            q += d * d;
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        float* yr = y + (long)row * C;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) yr[c] = (v[j] - mu) * rs * gamma[c] + beta[c];
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
+    __shared__ float s_dg[4][64 * VPT];
+    __shared__ float s_db[4][64 * VPT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    float adg[VPT], adb[VPT], g[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        adg[j] = 0.f; adb[j] = 0.f;
+        const int c = lane + 64 * j;
+        g[j] = c < C ? gamma[c] : 0.f;
+    }
+    for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < M; row += nw) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[VPT], d[VPT];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = lane + 64 * j;
+            const bool ok = c < C;
+            const float dv = ok ? dy[(long)row * C + c] : 0.f;
+            xh[j] = ok ? (x[(long)row * C + c] - mu) * rs : 0.f;
+            d[j] = dv * g[j];
+            c1 += d[j];
+            c2 += d[j] * xh[j];
+            adg[j] += dv * xh[j];
+            adb[j] += dv;
+        }
+        c1 = wave_sum(c1) / (float)C;
+        c2 = wave_sum(c2) / (float)C;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) dx[(long)row * C + c] = rs * (d[j] - c1 - xh[j] * c2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) { s_dg[wave][lane + 64 * j] = adg[j]; s_db[wave][lane + 64 * j] = adb[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        atomicAdd(&dgamma[c], s_dg[0][c] + s_dg[1][c] + s_dg[2][c] + s_dg[3][c]);
+        atomicAdd(&dbeta[c], s_db[0][c] + s_db[1][c] + s_db[2][c] + s_db[3][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel reductions over [M,C] viewed as float4 quads: total thread count is a multiple of C/4 so
+// every thread owns ONE channel quad.  MODE 0: sum & sumsq of y (BN stats).  MODE 1: BN backward
+// sums (sum g, sum g*xhat) with g = dz * drop2d * act'(pre).  MODE 2: plain column sum with the
+// GEMM A-prologue (dropout mask x row scale).
+// ------------------------------------------------------------------------------------------------
+struct ChanArgs {
+    const float* a; const float* b;          // MODE0: a=y.  MODE1: a=dz, b=y.  MODE2: a=A
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    double* ws; float* out;                   // ws [2C] doubles (MODE0/1); out [C] floats (MODE2)
+    long lda; int M, C; int act;
+    float drop_p; uint32_t k0, k1, thresh; float inv_keep; int rows_per_sample;
+    const float* rowscale; int rows_per_scale;
+};
+
+__device__ __forceinline__ float act_grad(int act, float pre) {
+    return act == MDVIT_ACT_HSWISH ? hswish_grad_f(pre) : (act == MDVIT_ACT_RELU ? (pre > 0.f ? 1.f : 0.f) : 1.f);
+}
+__device__ __forceinline__ float act_fwd(int act, float pre) {
+    return act == MDVIT_ACT_HSWISH ? hswish_f(pre) : (act == MDVIT_ACT_RELU ? fmaxf(pre, 0.f) : pre);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
+    extern __shared__ float s_acc[];          // [2*C]
+    const int QC = p.C >> 2;
+    for (int i = threadIdx.x; i < 2 * p.C; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    const long T = (long)gridDim.x * blockDim.x;
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(t0 % QC), c = q * 4;
+    const long total = (long)p.M * QC;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu[4], rs[4], ga[4], be[4];
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu[j] = p.mean[c + j]; rs[j] = p.rstd[c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; }
+    }
+    for (long e = t0; e < total; e += T) {
+        const long row = e / QC;
+        const float4 av = *reinterpret_cast<const float4*>(p.a + row * p.lda + c);
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += a4[j]; s2[j] += a4[j] * a4[j]; }
+        } else if (MODE == 1) {
+            const float4 yv = *reinterpret_cast<const float4*>(p.b + row * p.C + c);
+            const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (y4[j] - mu[j]) * rs[j];
+                float g = a4[j] * act_grad(p.act, xh * ga[j] + be[j]);
+                if (p.drop_p > 0.f)
+                    g *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+                s1[j] += g; s2[j] += g * xh;
+            }
+        } else {
+            float r = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = a4[j] * r;
+                if (p.drop_p > 0.f) v *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)(row * p.C + c + j), p.thresh, p.inv_keep);
+                s1[j] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        atomicAdd(&s_acc[c + j], s1[j]);
+        if (MODE != 2) atomicAdd(&s_acc[p.C + c + j], s2[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.C; i += blockDim.x) {
+        if (MODE == 2) atomicAdd(&p.out[i], s_acc[i]);
+        else { atomicAdd(&p.ws[i], (double)s_acc[i]); atomicAdd(&p.ws[p.C + i], (double)s_acc[p.C + i]); }
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, float* mean, float* rstd, float* rmean, float* rvar,
+                                   int64_t* nbt, int M, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const double m = ws[c] / M;
+        double var = ws[C + c] / M - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+    if (c == 0 && nbt) *nbt += 1;
+}
+
+__global__ void bn_eval_prep_kernel(const float* rm, const float* rv, float* mean, float* rstd, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { mean[c] = rm[c]; rstd[c] = 1.0f / sqrtf(rv[c] + eps); }
+}
+
+// z = act((y-mean)*rstd*gamma+beta) * drop2d     (float4 over [M,C])
+__global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __restrict__ z) {
+    const int QC = p.C >> 2;
+    const long total = (long)p.M * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / QC;
+        const int c = (int)(e % QC) * 4;
+        const float4 yv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
+        const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pre = (y4[j] - p.mean[c + j]) * p.rstd[c + j] * p.gamma[c + j] + p.beta[c + j];
+            o[j] = act_fwd(p.act, pre);
+            if (p.drop_p > 0.f)
+                o[j] *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+        }
+        *reinterpret_cast<float4*>(z + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)   (training)   |   gamma*rstd*g   (eval)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __restrict__ dy, float* dgamma, float* dbeta, int training) {
+    const int QC = p.C >> 2;
+    const long total = (long)p.M * QC;
+    const double invM = 1.0 / (double)p.M;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / QC;
+        const int c = (int)(e % QC) * 4;
+        const float4 dv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
+        const float4 yv = *reinterpret_cast<const float4*>(p.b + row * p.C + c);
+        const float d4[4] = {dv.x, dv.y, dv.z, dv.w}, y4[4] = {yv.x, yv.y, yv.z, yv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float rs = p.rstd[c + j], ga = p.gamma[c + j];
+            const float xh = (y4[j] - p.mean[c + j]) * rs;
+            float g = d4[j] * act_grad(p.act, xh * ga + p.beta[c + j]);
+            if (p.drop_p > 0.f)
+                g *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+            if (training) {
+                const float sg = (float)(p.ws[c + j] * invM), sgx = (float)(p.ws[p.C + c + j] * invM);
+                o[j] = ga * rs * (g - sg - xh * sgx);
+            } else {
+                o[j] = ga * rs * g;
+            }
+        }
+        *reinterpret_cast<float4*>(dy + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) { dbeta[c] = (float)p.ws[c]; dgamma[c] = (float)p.ws[p.C + c]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rowdot: y[m] = x[m,:].w + b    (wave per row)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int M, int K, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < M; row += nw) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += x[(long)row * ldx + k] * w[k];
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (b) s += b[0];
+            y[row] = accumulate ? y[row] + s : s;
+        }
+    }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ dy, float* __restrict__ dx, long lddx,
+                                                         float* __restrict__ dw, float* __restrict__ db, int M, int K) {
+    __shared__ float s_dw[4][64 * VPT];
+    __shared__ float s_db[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    float adw[VPT], wv[VPT];
+    float adb = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) { adw[j] = 0.f; const int k = lane + 64 * j; wv[j] = k < K ? w[k] : 0.f; }
+    for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < M; row += nw) {
+        const float g = dy[row];
+        adb += g;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int k = lane + 64 * j;
+            if (k < K) {
+                adw[j] += g * x[(long)row * ldx + k];
+                if (dx) dx[(long)row * lddx + k] = g * wv[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) s_dw[wave][lane + 64 * j] = adw[j];
+    if (lane == 0) s_db[wave] = adb;     // every lane of a wave holds the same adb
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) atomicAdd(&dw[k], s_dw[0][k] + s_dw[1][k] + s_dw[2][k] + s_dw[3][k]);
+    if (threadIdx.x == 0 && db) atomicAdd(db, s_db[0] + s_db[1] + s_db[2] + s_db[3]);
+}
+
+int chan_grid(long M, int C, int max_blocks) {
+    // grid*256 must be a multiple of C/4
+    const int QC = C / 4;
+    int g = 1;
+    {
+        int a = QC, b = 256;
+        while (b) { int t = a % b; a = b; b = t; }
+        g = QC / a;                       // smallest grid with (grid*256) % QC == 0
+    }
+    long want = ((long)M * QC + 256L * 8 - 1) / (256L * 8);
+    if (want > max_blocks) want = max_blocks;
+    if (want < 1) want = 1;
+    long grid = (want + g - 1) / g * g;
+    return (int)grid;
+}
+
+void fill_drop(ChanArgs& a, float p, uint32_t k0, uint32_t k1, int rows_per_sample) {
+    a.drop_p = p; a.k0 = k0; a.k1 = k1;
+    a.thresh = (uint32_t)((double)p * 4294967296.0);
+    a.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+}
+
+}  // namespace
+
+#define LN_DISPATCH(KERN, C, ...)                                                                    \
+    do {                                                                                             \
+        if (C <= 64) hipLaunchKernelGGL((KERN<1>), grid, dim3(256), 0, s, __VA_ARGS__);              \
+        else if (C <= 128) hipLaunchKernelGGL((KERN<2>), grid, dim3(256), 0, s, __VA_ARGS__);        \
+        else if (C <= 256) hipLaunchKernelGGL((KERN<4>), grid, dim3(256), 0, s, __VA_ARGS__);        \
+        else if (C <= 512) hipLaunchKernelGGL((KERN<8>), grid, dim3(256), 0, s, __VA_ARGS__);        \
+        else hipLaunchKernelGGL((KERN<16>), grid, dim3(256), 0, s, __VA_ARGS__);                     \
+    } while (0)
+
+extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                   int32_t M, int32_t C, float eps, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_fwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
+    dim3 grid(min(cdiv(M, 4), 4096));
+    LN_DISPATCH(ln_fwd_kernel, C, x, gamma, beta, y, mean, rstd, M, C, eps);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                   float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
+    MDVIT_ZERO(dgamma, sizeof(float) * C, s);
+    MDVIT_ZERO(dbeta, sizeof(float) * C, s);
+    dim3 grid(min(cdiv(M, 16), 1024));
+    LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_bn_stats(const float* y, double* ws, float* mean, float* rstd, float* running_mean, float* running_var,
+                              int64_t* nbt, int32_t M, int32_t C, float eps, float momentum, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_stats: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
+    MDVIT_ZERO(ws, sizeof(double) * 2 * C, s);
+    ChanArgs a; memset(&a, 0, sizeof(a));
+    a.a = y; a.lda = C; a.M = M; a.C = C; a.ws = ws;
+    const int grid = chan_grid(M, C, 2048);
+    hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid), dim3(256), sizeof(float) * 2 * C, s, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, mean, rstd, running_mean, running_var, nbt, M, C, eps, momentum);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_bn_eval_prep(const float* rm, const float* rv, float* mean, float* rstd, int32_t C, float eps, void* stream) {
+    hipLaunchKernelGGL(bn_eval_prep_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rm, rv, mean, rstd, C, eps);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, float* z,
+                              int32_t M, int32_t C, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample,
+                              void* stream) {
+    MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, MDVIT_E_SHAPE, "bn_apply: need C %% 4 == 0 (M=%d C=%d)", M, C);
+    ChanArgs a; memset(&a, 0, sizeof(a));
+    a.a = y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
+    fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
+    const long total = (long)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, (hipStream_t)stream, a, z);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            float* dy, float* dgamma, float* dbeta, double* ws, int32_t M, int32_t C, int32_t act, int32_t training,
+                            float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_bwd: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
+    MDVIT_ZERO(ws, sizeof(double) * 2 * C, s);
+    ChanArgs a; memset(&a, 0, sizeof(a));
+    a.a = dz; a.b = y; a.lda = C; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ws = ws; a.M = M; a.C = C; a.act = act;
+    fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
+    hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(chan_grid(M, C, 2048)), dim3(256), sizeof(float) * 2 * C, s, a);
+    const long total = (long)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, s, a, dy, dgamma, dbeta, training);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N, float drop_p, uint32_t key0, uint32_t key1,
+                                const float* rowscale, int32_t rows_per_scale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && N <= 8192 && lda % 4 == 0, MDVIT_E_SHAPE, "colsum: need N %% 4 == 0 (M=%d N=%d)", M, N);
+    MDVIT_ZERO(out, sizeof(float) * N, s);
+    ChanArgs a; memset(&a, 0, sizeof(a));
+    a.a = A; a.lda = lda; a.M = M; a.C = N; a.out = out;
+    fill_drop(a, drop_p, key0, key1, 1);
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(chan_grid(M, N, 1024)), dim3(256), sizeof(float) * 2 * N, s, a);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y, int32_t M, int32_t K,
+                                int32_t accumulate, void* stream) {
+    MDVIT_CHECK_ARG(M > 0 && K > 0, MDVIT_E_SHAPE, "rowdot_fwd: bad shape M=%d K=%d", M, K);
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(min(cdiv(M, 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, w, b, y, M, K, accumulate);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, const float* dy, float* dx, int64_t lddx, float* dw, float* db,
+                                int32_t M, int32_t K, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(M > 0 && K > 0 && K <= 1024, MDVIT_E_SHAPE, "rowdot_bwd: need K <= 1024 (M=%d K=%d)", M, K);
+    MDVIT_ZERO(dw, sizeof(float) * K, s);
+    if (db) MDVIT_ZERO(db, sizeof(float), s);
+    dim3 grid(min(cdiv(M, 64), 1024));
+    const int C = K;
+    LN_DISPATCH(rowdot_bwd_kernel, C, x, (long)ldx, w, dy, dx, (long)lddx, dw, db, M, K);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}

@@ -1,0 +1,82 @@
+"""Decoder-side modules: U-Net decoding block with a transformer stage, the auxiliary "peer" head.
+
+  UnetDecodingBlockTransformer  <- Models/Decoders.py:174-214
+  MLPDecoderFM                  <- Models/Decoders.py:289-339
+
+Two exact algebraic restructurings (both linear maps commute; bilinear weights sum to 1, so biases
+commute too) keep the 512-channel full-resolution tensors of the reference out of HBM:
+  * conv1x1(upsample(x)) == upsample(conv1x1(x))           (conv_before, finalconv, linear_out)
+  * linear_fuse(cat_q upsample(linear_q(x_q))) == sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)
+The composed weights Wf_q W_q are formed by a GEMM on the autograd tape each call, so every
+parameter still receives its exact gradient.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import ACT_RELU
+from .blocks import BatchNormAct, ConvParams, DecoderDWConv2d_BN, _NoParams, _check_norm
+
+
+class UnetDecodingBlockTransformer(nn.Module):
+    def __init__(self, in_channel, out_channel, mhsa_block, use_res=False, conv_norm=nn.BatchNorm2d):
+        super().__init__()
+        if use_res:
+            raise NotImplementedError("use_res=True is never used by the reference's models")
+        self.use_res = use_res
+        self.conv_before = ConvParams(out_channel, in_channel, 1, 1, bias=True)
+        self.conv_after = DecoderDWConv2d_BN(out_channel * 2, out_channel, norm_layer=conv_norm)
+        self.mhsa_block = mhsa_block
+
+    def forward(self, input, skip, domain_label=None):
+        """input NHWC [B,h,w,Cin], skip NHWC [B,H,W,Cout] -> NHWC [B,H,W,Cout]."""
+        B, H, W, Cout = skip.shape
+        low = ops.linear(input, self.conv_before.weight, self.conv_before.bias)       # 1x1 conv at the LOW resolution
+        up = ops.upsample_bilinear(low, H, W)
+        z = self.conv_after(skip, up)
+        t = self.mhsa_block(z.view(B, H * W, Cout), H, W, domain_label)
+        return t.view(B, H, W, Cout)
+
+
+class MLPDecoderFM(nn.Module):
+    def __init__(self, in_channels, out_channel, hidden_channel=256, outfeature_channel=64, dropout_ratio=0.1, conv_norm=nn.BatchNorm2d):
+        super().__init__()
+        _check_norm(conv_norm)
+        assert out_channel == 1
+        self.linear1 = ConvParams(hidden_channel, in_channels[0], 1, 1)
+        self.linear2 = ConvParams(hidden_channel, in_channels[1], 1, 1)
+        self.linear3 = ConvParams(hidden_channel, in_channels[2], 1, 1)
+        self.linear4 = ConvParams(hidden_channel, in_channels[3], 1, 1)
+        self.linear_fuse = nn.Sequential(ConvParams(hidden_channel, hidden_channel * 4 + outfeature_channel, 1, 1),
+                                         BatchNormAct(hidden_channel, ACT_RELU), _NoParams())
+        self.dropout = nn.Dropout2d(dropout_ratio)      # holds p only; the mask is applied inside the BN+ReLU kernel
+        self.linear_out = ConvParams(out_channel, hidden_channel, 1, 1)
+        self.hidden = hidden_channel
+
+    def forward(self, features, img_size, out_feat=False):
+        if out_feat:
+            raise NotImplementedError("out_feat=True of the aux head is unused by the train path")
+        x1 = features[0]
+        B, h, w, _ = x1.shape
+        hid = self.hidden
+        Wf = self.linear_fuse[0].weight.view(hid, -1)          # [hid, 4*hid + C5]
+        bias = self.linear_fuse[0].bias
+        lins = (self.linear1, self.linear2, self.linear3, self.linear4)
+        # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)
+        acc = ops.linear(features[4], Wf[:, 4 * hid:], bias)                                  # [B,h,w,hid]
+        for q, lin in enumerate(lins):
+            Wf_q = Wf[:, q * hid:(q + 1) * hid]
+            Wc = ops.matmul(Wf_q, lin.weight.view(hid, -1))                                    # [hid, C_q]
+            bc = ops.rowdot(Wf_q, lin.bias)                                                    # [hid]
+            fq = features[q]
+            if fq.shape[1] == h and fq.shape[2] == w:
+                acc = ops.linear(fq, Wc, bc, residual=acc)
+            else:
+                acc = ops.upsample_bilinear(ops.linear(fq, Wc, bc), h, w, base=acc)
+        p = self.dropout.p if self.training else 0.0
+        y = self.linear_fuse[1](acc, drop2d_p=p)                                              # BN + ReLU + Dropout2d
+        low = ops.rowdot(y, self.linear_out.weight, self.linear_out.bias)                     # [B,h,w]
+        out = ops.upsample_bilinear(low.view(B, h, w, 1), int(img_size[0]), int(img_size[1]))
+        return out.view(B, 1, int(img_size[0]), int(img_size[1]))

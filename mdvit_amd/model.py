@@ -1,0 +1,152 @@
+"""MDViT and BASE with the reference's constructor / forward / state_dict surface, computing on
+hand-written HIP kernels (mdvit_amd.ops -> libmdvit_hip.so).
+
+  MDViT <- Models/Transformer/mdvit.py:474-730      BASE <- Models/Transformer/base.py:340-512
+Call surface kept (multi_train_MDViT.py:57-60,140-146; multi_train_BASE.py:66-68,168):
+  MDViT(img_size=..., drop_rate=0.1, drop_path_rate=0.1, conv_norm=nn.BatchNorm2d, adapt_method='Sup',
+        num_domains=4, decoder_name='MLPFM');  out, aux = model(img, domain_label, d)  |  model(img, d=d)
+  BASE(drop_rate, drop_path_rate, conv_norm, adapt_method);  out = model(img)
+Inputs NCHW fp32 on the GPU; outputs (B,1,H,W) fp32 logits.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import ACT_RELU
+from .blocks import (BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
+                     init_weights_)
+from .decode import MLPDecoderFM, UnetDecodingBlockTransformer
+
+
+class _EncoderDecoder(nn.Module):
+    _base_semantics = False
+
+    def _build_trunk(self, img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
+                     drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains):
+        _check_norm(conv_norm)
+        if num_stages != 4:
+            raise NotImplementedError("num_stages must be 4")
+        self.num_stages = num_stages
+        E = list(embed_dims)
+        self.stem = nn.Sequential(
+            Conv2d_BN(in_chans, E[0] // 2, kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish, from_image=True),
+            Conv2d_BN(E[0] // 2, E[0], kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish),
+        )
+        self.patch_embed_stages = nn.ModuleList([
+            DWCPatchEmbed(in_chans=E[i] if i == 0 else E[i - 1], embed_dim=E[i], patch_size=3, stride=1 if i == 0 else 2, conv_norm=conv_norm)
+            for i in range(num_stages)])
+
+        def stage(i):
+            return MHSA_stage_adapt((img_size // 2 ** (i + 2)) ** 2, E[i], num_layers=num_layers[i], num_heads=num_heads[i],
+                                    mlp_ratio=mlp_ratios[i], qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate,
+                                    attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate, norm_layer=norm_layer,
+                                    adapt_method=adapt_method, num_domains=num_domains, base_semantics=self._base_semantics)
+
+        self.mhsa_stages = nn.ModuleList([stage(i) for i in range(num_stages)])
+        self.bridge = nn.Sequential(ConvParams(E[3], E[3], 3, 3), BatchNormAct(E[3], ACT_RELU), _NoParams(),
+                                    ConvParams(E[3] * 2, E[3], 3, 3), BatchNormAct(E[3] * 2, ACT_RELU), _NoParams())
+        self.mhsa_list = [stage(i) for i in range(num_stages)]          # plain list, as in the reference (mdvit.py:568)
+        self.decoder1 = UnetDecodingBlockTransformer(E[3] * 2, E[3], self.mhsa_list[3], conv_norm=conv_norm)
+        self.decoder2 = UnetDecodingBlockTransformer(E[3], E[2], self.mhsa_list[2], conv_norm=conv_norm)
+        self.decoder3 = UnetDecodingBlockTransformer(E[2], E[1], self.mhsa_list[1], conv_norm=conv_norm)
+        self.decoder4 = UnetDecodingBlockTransformer(E[1], E[0], self.mhsa_list[0], conv_norm=conv_norm)
+        self.finalconv = nn.Sequential(ConvParams(1, E[0], 1, 1))
+
+    def _trunk(self, x, domain_label):
+        """x NCHW image -> (logits (B,1,H,W), encoder_outs NHWC list, decoder4 output NHWC)."""
+        if x.dim() != 4:
+            raise ValueError("expected a (B,C,H,W) image batch")
+        B, _, Hi, Wi = x.shape
+        x = self.stem[1](self.stem[0](x.float()))
+        enc = []
+        for idx in range(self.num_stages):
+            x = self.patch_embed_stages[idx](x)
+            _, H, W, Cn = x.shape
+            x = self.mhsa_stages[idx](x.view(B, H * W, Cn), H, W, domain_label).view(B, H, W, Cn)
+            enc.append(x)
+        out = ops.conv3x3_dense(enc[3], self.bridge[0].weight, self.bridge[0].bias, 1)
+        out = self.bridge[1](out)
+        out = ops.conv3x3_dense(out, self.bridge[3].weight, self.bridge[3].bias, 1)
+        out = self.bridge[4](out)
+        out = self.decoder1(out, enc[3], domain_label)
+        out = self.decoder2(out, enc[2], domain_label)
+        out = self.decoder3(out, enc[1], domain_label)
+        out = self.decoder4(out, enc[0], domain_label)
+        dec4 = out
+        _, h, w, _ = dec4.shape
+        low = ops.rowdot(dec4, self.finalconv[0].weight, self.finalconv[0].bias)          # 1x1 conv (1 channel) at H/4
+        logits = ops.upsample_bilinear(low.view(B, h, w, 1), Hi, Wi).view(B, 1, Hi, Wi)
+        return logits, enc, dec4, (Hi, Wi)
+
+    @staticmethod
+    def _pooled_feat(enc3):
+        """adaptive_avg_pool2d(encoder_outs[3], 1) -- token mean via the column-sum kernel (not differentiable)."""
+        B, H, W, Cn = enc3.shape
+        feat = torch.empty((B, Cn), device=enc3.device, dtype=torch.float32)
+        with torch.no_grad():
+            for b in range(B):
+                ops.call("mdvit_colsum_f32", ops._p(enc3[b]), Cn, ops._p(feat[b]), H * W, Cn, 0.0, 0, 0, None, 1, ops._stream())
+        return feat / float(H * W)
+
+
+class MDViT(_EncoderDecoder):
+    def __init__(self, img_size=512, in_chans=3, num_stages=4, num_layers=[2, 2, 2, 2], embed_dims=[64, 128, 320, 512],
+                 mlp_ratios=[8, 8, 4, 4], num_heads=[8, 8, 8, 8], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=None, conv_norm=nn.BatchNorm2d, adapt_method=None, num_domains=4,
+                 decoder_name="MLPFM", **kwargs):
+        super().__init__()
+        if decoder_name != "MLPFM":
+            raise NotImplementedError(f"decoder_name={decoder_name!r}: only the default 'MLPFM' peer heads are built")
+        self.decoder_name = decoder_name
+        self.adapt_method = adapt_method
+        self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
+                          drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains)
+        self.debranch1 = MLPDecoderFM(embed_dims, 1, 512)
+        self.debranch2 = MLPDecoderFM(embed_dims, 1, 512)
+        self.debranch3 = MLPDecoderFM(embed_dims, 1, 512)
+        self.debranch4 = MLPDecoderFM(embed_dims, 1, 512)
+        init_weights_(self)
+
+    def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
+        logits, enc, dec4, img_size = self._trunk(x, domain_label)
+        if not out_seg:
+            return {"seg": None, "feat": self._pooled_feat(enc[3])}
+        feats = enc + [dec4]
+        if d == "0":
+            aux_out = self.debranch1(feats, img_size=img_size)
+        elif d == "1":
+            aux_out = self.debranch2(feats, img_size=img_size)
+        elif d == "2":
+            aux_out = self.debranch3(feats, img_size=img_size)
+        elif d == "3":
+            aux_out = self.debranch4(feats, img_size=img_size)
+        else:
+            aux_out = None
+        if out_feat:
+            return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}
+        return [logits, aux_out]
+
+
+class BASE(_EncoderDecoder):
+    _base_semantics = True          # base.py:216 applies the adapter whenever a domain_label is given
+
+    def __init__(self, img_size=512, in_chans=3, num_stages=4, num_layers=[2, 2, 2, 2], embed_dims=[64, 128, 320, 512],
+                 mlp_ratios=[8, 8, 4, 4], num_heads=[8, 8, 8, 8], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=None, conv_norm=nn.BatchNorm2d, adapt_method=None, num_domains=4, **kwargs):
+        super().__init__()
+        self.adapt_method = adapt_method
+        self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
+                          drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains)
+        init_weights_(self)
+
+    def forward(self, x, domain_label=None, out_feat=False, out_seg=True):
+        logits, enc, dec4, _ = self._trunk(x, domain_label)
+        if not out_seg:
+            return {"seg": None, "feat": self._pooled_feat(enc[3])}
+        if out_feat:
+            return {"seg": logits, "feat": self._pooled_feat(enc[3])}
+        return logits

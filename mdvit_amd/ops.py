@@ -1,0 +1,590 @@
+"""torch.autograd.Function wrappers over the C ABI (libmdvit_hip.so).
+
+PyTorch is used here for device memory (caching allocator), streams and the autograd tape only;
+every arithmetic op below is a HIP kernel.  Tensors are fp32, contiguous, on a CUDA(HIP) device,
+activations token-major NHWC.  Saved tensors are never modified in place, so a graph can be
+back-propagated twice (`retain_graph=True`, multi_train_MDViT.py:201-207).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, call
+
+_key_counter = itertools.count(1)
+
+
+def _next_key() -> Tuple[int, int]:
+    """A fresh (key0, key1) pair for one dropout site; derived from torch's seed so that
+    torch.manual_seed makes runs repeatable."""
+    n = next(_key_counter)
+    seed = torch.initial_seed() & 0xFFFFFFFF
+    k0 = (seed * 2654435761 + n * 0x9E3779B1) & 0xFFFFFFFF
+    k1 = ((n * 0x85EBCA6B) ^ (seed >> 3) ^ 0xC2B2AE35) & 0xFFFFFFFF
+    return k0, k1
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.MdvitHipError("mdvit_amd ops need CUDA(HIP) tensors; there is no CPU path")
+        if t.dtype != torch.float32:
+            raise _lib.MdvitHipError(f"mdvit_amd ops are fp32 (got {t.dtype})")
+        if not t.is_contiguous():
+            raise _lib.MdvitHipError("mdvit_amd ops need contiguous tensors")
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# raw GEMM helper
+# ------------------------------------------------------------------------------------------------
+def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
+         a_drop=0.0, a_key=(0, 0), a_rowscale=None, a_rows_per_scale=1,
+         e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
+         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False):
+    d = GemmDesc()
+    d.A, d.B, d.C, d.C2 = A, B, out, out2
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.M, d.N, d.K = M, N, K
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+    d.bias = bias
+    d.a_drop_p, d.a_key0, d.a_key1 = a_drop, a_key[0], a_key[1]
+    d.a_rowscale, d.a_rows_per_scale = a_rowscale, a_rows_per_scale
+    d.epi = epi
+    d.e_drop_p, d.e_key0, d.e_key1 = e_drop, e_key[0], e_key[1]
+    d.e_rowscale, d.e_rows_per_scale = e_rowscale, e_rows_per_scale
+    d.residual, d.ldr = residual, ldr
+    d.gelu_u, d.ldu = gelu_u, ldu
+    d.allow_split = int(allow_split)
+    call("mdvit_gemm_f32", C.byref(d), _stream())
+
+
+def _ld_view(t: torch.Tensor) -> Tuple[int, int, int]:
+    """(rows, cols, leading dim) of a 2-D tensor whose rows are contiguous (column slices allowed)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.MdvitHipError("expected a 2-D row-contiguous tensor")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear / 1x1 conv:  y = x W^T + b  [+ dropout, DropPath row scale, residual]
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, residual, rowscale, drop_p, rows_per_scale):
+        # x [M,K] ; W [N,K] (may be a column slice: stride(0) >= K) ; residual [M,N]
+        _chk(x, b, residual, rowscale)
+        M, K = x.shape
+        N, K2, ldb = _ld_view(W)
+        assert K == K2
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        key = _next_key() if drop_p > 0 else (0, 0)
+        gemm(_p(x), _p(W), _p(y), M, N, K, lda=K, ldb=ldb, ldc=N, bias=_p(b),
+             e_drop=drop_p, e_key=key, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale,
+             residual=_p(residual), ldr=N)
+        ctx.save_for_backward(x, W, rowscale)
+        ctx.meta = (drop_p, key, rows_per_scale, b is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, rowscale = ctx.saved_tensors
+        drop_p, key, rps, has_b, has_res = ctx.meta
+        g = _c(g)
+        M, K = x.shape
+        N, _, ldb = _ld_view(W)
+        pro = dict(a_drop=drop_p, a_key=key, a_rowscale=_p(rowscale), a_rows_per_scale=rps)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, **pro)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty((N, K), device=x.device, dtype=torch.float32)
+            gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
+        if has_b and ctx.needs_input_grad[2]:
+            db = torch.empty((N,), device=x.device, dtype=torch.float32)
+            call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, _stream())
+        return dx, dW, db, (g if has_res else None), None, None, None
+
+
+def linear(x, W, b=None, residual=None, rowscale=None, drop_p: float = 0.0, rows_per_scale: int = 1):
+    """x: [..., K] -> [..., N].  W [N,K] may be a view with W.stride(1)==1 (column slice of a wider matrix)."""
+    shp = x.shape
+    x2 = _c(x).view(-1, shp[-1])
+    if W.dim() == 4:
+        W = W.view(W.shape[0], -1)
+    r2 = None if residual is None else _c(residual).view(-1, W.shape[0])
+    y = _Linear.apply(x2, W, b, r2, rowscale, float(drop_p), int(rows_per_scale))
+    return y.view(*shp[:-1], W.shape[0])
+
+
+class _MatMul(torch.autograd.Function):
+    """C[M,N] = A[M,K] @ B[K,N] for weight composition (both operands row-contiguous 2-D views)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        M, K, lda = _ld_view(A)
+        K2, N, ldb = _ld_view(B)
+        assert K == K2
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+        gemm(_p(A), _p(B), _p(out), M, N, K, lda=lda, ldb=ldb, ldc=N, trans_b=False)
+        ctx.save_for_backward(A, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        g = _c(g)
+        M, K, lda = _ld_view(A)
+        _, N, ldb = _ld_view(B)
+        dA = dB = None
+        if ctx.needs_input_grad[0]:      # dA = g @ B^T : B stored [K,N] row-major == "weight [N'=K, K'=N]"
+            dA = torch.empty((M, K), device=A.device, dtype=torch.float32)
+            gemm(_p(g), _p(B), _p(dA), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=True)
+        if ctx.needs_input_grad[1]:      # dB = A^T @ g
+            dB = torch.empty((K, N), device=A.device, dtype=torch.float32)
+            gemm(_p(A), _p(g), _p(dB), K, N, M, lda=lda, ldb=N, ldc=N, trans_a=True, trans_b=False)
+        return dA, dB
+
+
+def matmul(A, B):
+    return _MatMul.apply(A, B)
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP with residual:  out = res + DropPath(Dropout(fc2(Dropout(GELU(fc1(x))))))      mpvit.py:71-78
+# ------------------------------------------------------------------------------------------------
+class _MlpResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, W1, b1, W2, b2, rowscale, drop_p, rows_per_scale):
+        _chk(x, res, W1, b1, W2, b2, rowscale)
+        M, Cin = x.shape
+        Hd = W1.shape[0]
+        u = torch.empty((M, Hd), device=x.device, dtype=torch.float32)
+        h = torch.empty_like(u)
+        k1 = _next_key() if drop_p > 0 else (0, 0)
+        k2 = _next_key() if drop_p > 0 else (0, 0)
+        gemm(_p(x), _p(W1), _p(u), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), out2=_p(h),
+             epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
+        out = torch.empty((M, Cin), device=x.device, dtype=torch.float32)
+        gemm(_p(h), _p(W2), _p(out), M, Cin, Hd, lda=Hd, ldb=Hd, ldc=Cin, bias=_p(b2),
+             e_drop=drop_p, e_key=k2, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale, residual=_p(res), ldr=Cin)
+        ctx.save_for_backward(x, u, h, W1, W2, rowscale)
+        ctx.meta = (drop_p, k1, k2, rows_per_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, u, h, W1, W2, rowscale = ctx.saved_tensors
+        drop_p, k1, k2, rps = ctx.meta
+        g = _c(g)
+        M, Cin = x.shape
+        Hd = W1.shape[0]
+        dev = x.device
+        pro = dict(a_drop=drop_p, a_key=k2, a_rowscale=_p(rowscale), a_rows_per_scale=rps)
+        # du = (dy W2) * gelu'(u) * mask1
+        du = torch.empty_like(u)
+        gemm(_p(g), _p(W2), _p(du), M, Hd, Cin, lda=Cin, ldb=Hd, ldc=Hd, trans_b=False,
+             epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1, **pro)
+        dW2 = torch.empty_like(W2)
+        gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
+        db2 = torch.empty((Cin,), device=dev, dtype=torch.float32)
+        call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, _stream())
+        dW1 = torch.empty_like(W1)
+        gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
+        db1 = torch.empty((Hd,), device=dev, dtype=torch.float32)
+        call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, _stream())
+        dx = torch.empty_like(x)
+        gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False)
+        return dx, g, dW1, db1, dW2, db2, None, None, None
+
+
+def mlp_residual(x, res, W1, b1, W2, b2, rowscale=None, drop_p=0.0, rows_per_scale=1):
+    shp = res.shape
+    out = _MlpResidual.apply(_c(x).view(-1, shp[-1]), _c(res).view(-1, shp[-1]), W1, b1, W2, b2, rowscale,
+                             float(drop_p), int(rows_per_scale))
+    return out.view(shp)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _chk(x, gamma, beta)
+        M, Cn = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call("mdvit_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cn, eps, _stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        g = _c(g)
+        M, Cn = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, Cn, _stream())
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    shp = x.shape
+    return _LayerNorm.apply(_c(x).view(-1, shp[-1]), gamma, beta, float(eps)).view(shp)
+
+
+# ------------------------------------------------------------------------------------------------
+# depthwise / grouped 3x3 convolutions (NHWC)
+# ------------------------------------------------------------------------------------------------
+class _DwConv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, add_input):
+        _chk(x, w, bias)
+        B, H, W_, Cn = x.shape
+        Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+        y = torch.empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
+        call("mdvit_dwconv3x3_fwd", _p(x), _p(w), _p(bias), _p(y), B, H, W_, Cn, stride, int(add_input), _stream())
+        ctx.save_for_backward(x, w)
+        ctx.meta = (stride, add_input, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, add_input, has_b = ctx.meta
+        g = _c(g)
+        B, H, W_, Cn = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty((Cn,), device=x.device, dtype=torch.float32) if has_b else None
+        call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_, Cn, stride, int(add_input), _stream())
+        return dx, dw, db, None, None
+
+
+def dwconv3x3(x, w, bias=None, stride=1, add_input=False):
+    return _DwConv3x3.apply(_c(x), w, bias, int(stride), bool(add_input))
+
+
+class _GConv2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, up, w):
+        _chk(skip, up, w)
+        B, H, W_, Cn = skip.shape
+        y = torch.empty_like(skip)
+        call("mdvit_gconv2_3x3_fwd", _p(skip), _p(up), _p(w), _p(y), B, H, W_, Cn, _stream())
+        ctx.save_for_backward(skip, up, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        skip, up, w = ctx.saved_tensors
+        g = _c(g)
+        B, H, W_, Cn = skip.shape
+        dskip, dup, dw = torch.empty_like(skip), torch.empty_like(up), torch.empty_like(w)
+        call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), _p(dskip), _p(dup), _p(dw), B, H, W_, Cn, _stream())
+        return dskip, dup, dw
+
+
+def gconv2_3x3(skip, up, w):
+    return _GConv2.apply(_c(skip), _c(up), w)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense 3x3 conv = im2col + GEMM; stem.0 direct
+# ------------------------------------------------------------------------------------------------
+class _Im2col(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        _chk(x)
+        B, H, W_, Cn = x.shape
+        Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+        col = torch.empty((B * Ho * Wo, Cn * 9), device=x.device, dtype=torch.float32)
+        call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cn, stride, _stream())
+        ctx.meta = (B, H, W_, Cn, stride)
+        return col
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W_, Cn, stride = ctx.meta
+        g = _c(g)
+        dx = torch.empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
+        call("mdvit_col2im3x3", _p(g), _p(dx), B, H, W_, Cn, stride, _stream())
+        return dx, None
+
+
+def conv3x3_dense(x, w, bias=None, stride=1):
+    """x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] -> [B,Ho,Wo,Cout]."""
+    B, H, W_, Cn = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+    col = _Im2col.apply(_c(x), int(stride))
+    y = _Linear.apply(col, w.view(w.shape[0], -1), bias, None, None, 0.0, 1)
+    return y.view(B, Ho, Wo, w.shape[0])
+
+
+class _StemConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, w):
+        _chk(img, w)
+        B, Cin, H, W_ = img.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cout), device=img.device, dtype=torch.float32)
+        call("mdvit_stemconv_fwd", _p(img), _p(w), _p(y), B, H, W_, Cin, Cout, _stream())
+        ctx.save_for_backward(img, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        img, w = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise _lib.MdvitHipError("gradient w.r.t. the input image is not built (the train path never needs it)")
+        g = _c(g)
+        B, Cin, H, W_ = img.shape
+        dw = torch.empty_like(w)
+        call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(dw), B, H, W_, Cin, w.shape[0], _stream())
+        return None, dw
+
+
+def stem_conv(img, w):
+    return _StemConv.apply(_c(img), w)
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm2d (+activation, +Dropout2d) on NHWC
+# ------------------------------------------------------------------------------------------------
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, drop2d_p, rows_per_sample):
+        _chk(y, gamma, beta, running_mean, running_var)
+        Cn = y.shape[-1]
+        M = y.numel() // Cn
+        dev = y.device
+        mean = torch.empty((Cn,), device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        if training:
+            ws = torch.empty((2 * Cn,), device=dev, dtype=torch.float64)
+            call("mdvit_bn_stats", _p(y), _p(ws), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                 C.c_void_p(nbt.data_ptr()) if nbt is not None else None, M, Cn, eps, momentum, _stream())
+        else:
+            call("mdvit_bn_eval_prep", _p(running_mean), _p(running_var), _p(mean), _p(rstd), Cn, eps, _stream())
+        key = _next_key() if drop2d_p > 0 else (0, 0)
+        z = torch.empty_like(y)
+        call("mdvit_bn_apply", _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), M, Cn, act, drop2d_p, key[0], key[1],
+             rows_per_sample, _stream())
+        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        ctx.meta = (training, act, drop2d_p, key, rows_per_sample)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, act, drop2d_p, key, rps = ctx.meta
+        g = _c(g)
+        Cn = y.shape[-1]
+        M = y.numel() // Cn
+        dy = torch.empty_like(y)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty((2 * Cn,), device=y.device, dtype=torch.float64)
+        call("mdvit_bn_bwd", _p(g), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dg), _p(db), _p(ws),
+             M, Cn, act, int(training), drop2d_p, key[0], key[1], rps, _stream())
+        return dy, dg, db, None, None, None, None, None, None, None, None, None
+
+
+def bn_act(y, gamma, beta, running_mean, running_var, nbt, training, act, eps=1e-5, momentum=0.1, drop2d_p=0.0):
+    rows_per_sample = y.numel() // (y.shape[0] * y.shape[-1])
+    return _BNAct.apply(_c(y), gamma, beta, running_mean, running_var, nbt, bool(training), float(eps), float(momentum),
+                        int(act), float(drop2d_p), int(rows_per_sample))
+
+
+# ------------------------------------------------------------------------------------------------
+# bilinear resize (align_corners=False), optionally accumulated onto a base tensor
+# ------------------------------------------------------------------------------------------------
+class _Upsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, base):
+        _chk(x, base)
+        B, H, W_, Cn = x.shape
+        if base is None:
+            y = torch.empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
+        else:
+            y = base.clone()
+        call("mdvit_upsample_fwd", _p(x), _p(y), B, H, W_, Ho, Wo, Cn, int(base is not None), _stream())
+        ctx.meta = (B, H, W_, Ho, Wo, Cn, base is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W_, Ho, Wo, Cn, has_base = ctx.meta
+        g = _c(g)
+        dx = torch.empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
+        call("mdvit_upsample_bwd", _p(g), _p(dx), B, H, W_, Ho, Wo, Cn, _stream())
+        return dx, None, None, (g if has_base else None)
+
+
+def upsample_bilinear(x, Ho, Wo, base=None):
+    """NHWC x -> [B,Ho,Wo,C] (+ base)."""
+    if base is None and x.shape[1] == Ho and x.shape[2] == Wo:
+        return x
+    return _Upsample.apply(_c(x), int(Ho), int(Wo), None if base is None else _c(base))
+
+
+# ------------------------------------------------------------------------------------------------
+# 1-output linear (finalconv / linear_out)
+# ------------------------------------------------------------------------------------------------
+class _RowDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _chk(w, b)
+        M, K, ldx = _ld_view(x)
+        y = torch.empty((M,), device=x.device, dtype=torch.float32)
+        call("mdvit_rowdot_fwd", _p(x), ldx, _p(w), _p(b), _p(y), M, K, 0, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _c(g)
+        M, K, ldx = _ld_view(x)
+        dx = torch.empty((M, K), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = torch.empty((K,), device=x.device, dtype=torch.float32)
+        db = torch.empty((1,), device=x.device, dtype=torch.float32) if ctx.has_b else None
+        call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, _p(dw), _p(db), M, K, _stream())
+        return dx, dw.view_as(w), db
+
+
+def rowdot(x, w, b=None):
+    """x [..., K] . w (any shape with K elements) + b[1] -> [...].  A 2-D x may be a column-slice view."""
+    if x.dim() == 2:
+        return _RowDot.apply(x, w, b)
+    shp = x.shape
+    return _RowDot.apply(_c(x).view(-1, shp[-1]), w, b).view(shp[:-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# Domain adapter + factorized attention core
+# ------------------------------------------------------------------------------------------------
+class _DomainAdapter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, label, W1, b1, W2, b2, heads):
+        _chk(label, W1, b1, W2, b2)
+        B, D = label.shape
+        hid, Cn = W1.shape[0], W2.shape[0]
+        a = torch.empty((B, Cn), device=label.device, dtype=torch.float32)
+        call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, D, hid, Cn, heads, _stream())
+        ctx.save_for_backward(label, W1, b1, W2, b2, a)
+        ctx.heads = heads
+        return a
+
+    @staticmethod
+    def backward(ctx, g):
+        label, W1, b1, W2, b2, a = ctx.saved_tensors
+        g = _c(g)
+        B, D = label.shape
+        hid, Cn = W1.shape[0], W2.shape[0]
+        dW1, db1, dW2, db2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
+        call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(g), _p(dW1), _p(db1), _p(dW2), _p(db2),
+             B, D, hid, Cn, ctx.heads, _stream())
+        return None, dW1, db1, dW2, db2, None
+
+
+def domain_adapter(label, W1, b1, W2, b2, heads):
+    return _DomainAdapter.apply(_c(label.float()), W1, b1, W2, b2, int(heads))
+
+
+class _FactorAtt(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, w3, b3, w5, b5, w7, b7, a, H, W_, heads, splits):
+        _chk(qkv, w3, b3, w5, b5, w7, b7, a)
+        B, N, C3 = qkv.shape
+        Cn = C3 // 3
+        Ch = Cn // heads
+        dev = qkv.device
+        out = torch.empty((B, N, Cn), device=dev, dtype=torch.float32)
+        kmax = torch.empty((B, Cn), device=dev, dtype=torch.float32)
+        ksum = torch.empty_like(kmax)
+        Mmat = torch.empty((B, Cn, Ch), device=dev, dtype=torch.float32)
+        wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
+        ws = torch.empty((wsb // 4,), device=dev, dtype=torch.float32)
+        call("mdvit_factoratt_fwd", _p(qkv), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(out), _p(kmax), _p(ksum),
+             _p(Mmat), _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2], _stream())
+        ctx.save_for_backward(qkv, w3, b3, w5, b5, w7, b7, a, kmax, ksum, Mmat)
+        ctx.meta = (H, W_, heads, splits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, w3, b3, w5, b5, w7, b7, a, kmax, ksum, Mmat = ctx.saved_tensors
+        H, W_, heads, splits = ctx.meta
+        g = _c(g)
+        B, N, C3 = qkv.shape
+        Cn = C3 // 3
+        dev = qkv.device
+        dqkv = torch.empty_like(qkv)
+        da = torch.empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
+        dws = [torch.empty_like(t) for t in (w3, b3, w5, b5, w7, b7)]
+        wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
+        ws = torch.empty((wsb // 4,), device=dev, dtype=torch.float32)
+        call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
+             _p(Mmat), _p(dqkv), _p(da), *[_p(t) for t in dws], _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2],
+             _stream())
+        return (dqkv, *dws, da, None, None, None, None)
+
+
+def factor_att(qkv, crpe_params, a, H, W_, heads, splits=(2, 3, 3)):
+    """qkv [B,N,3C]; crpe_params = (w3,b3,w5,b5,w7,b7); a [B,C] or None -> [B,N,C]."""
+    w3, b3, w5, b5, w7, b7 = crpe_params
+    return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, a, int(H), int(W_), int(heads), tuple(splits))
+
+
+# ------------------------------------------------------------------------------------------------
+# fused step losses on logits
+# ------------------------------------------------------------------------------------------------
+class _SegLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, aux, label):
+        _chk(out, aux, label)
+        n = out.numel()
+        sums = torch.empty((16,), device=out.device, dtype=torch.float64)
+        losses = torch.empty((3,), device=out.device, dtype=torch.float32)
+        call("mdvit_seg_losses_fwd", _p(out), _p(aux), _p(label), _p(sums), _p(losses), n, _stream())
+        ctx.save_for_backward(out, aux, label, sums)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        out, aux, label, sums = ctx.saved_tensors
+        g = _c(g.float())
+        n = out.numel()
+        dout = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        daux = torch.empty_like(aux) if (aux is not None and ctx.needs_input_grad[1]) else None
+        call("mdvit_seg_losses_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(g), _p(dout), _p(daux), n, _stream())
+        return dout, daux, None
+
+
+def seg_losses(out, aux, label):
+    """logits -> tensor[3] = (BCE+Dice(out), BCE+Dice(aux), Dice(sigmoid(aux), sigmoid(out)))."""
+    return _SegLosses.apply(_c(out), None if aux is None else _c(aux), _c(label.float()))

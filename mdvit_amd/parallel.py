@@ -1,0 +1,110 @@
+"""Data parallelism for the MDViT step: one process per GPU, replicated weights, ONE bucketed
+all-reduce of the gradients per optimisation step over RCCL (xGMI), overlapped with the last
+backward sweep.  Replaces nn.DataParallel's per-forward parameter broadcast + per-backward
+reduce-to-GPU0 (multi_train_MDViT.py:72-74) -- no per-forward traffic at all.
+
+Gradients live as views into a few flat buckets (allocated once), filled in place by autograd.
+Buckets are ordered in REVERSE registration order (heads first, stem last) so that they complete
+early in the backward sweep; when the last gradient of a bucket has been accumulated during the
+final sweep of the step, its all-reduce is issued asynchronously on the process group's stream.
+xGMI is point-to-point (7 links/GPU): bucket size defaults to 32 MiB, large enough that RCCL's
+reduce-scatter+all-gather stripes every bucket over all links.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradBucketReducer:
+    def __init__(self, params, bucket_bytes: int = 32 << 20, process_group=None, average: bool = True):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.average = average
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self._armed = False
+        self._handles = []
+        self._pending: List[int] = []
+        # reverse order: parameters used last in forward get their gradients first in backward
+        order = list(reversed(self.params))
+        self.buckets: List[torch.Tensor] = []
+        self._bucket_of = {}
+        self._bucket_sizes: List[int] = []
+        cur, cur_elems = [], 0
+        groups = []
+        limit = max(1, bucket_bytes // 4)
+        for p in order:
+            if cur and cur_elems + p.numel() > limit:
+                groups.append(cur); cur, cur_elems = [], 0
+            cur.append(p); cur_elems += p.numel()
+        if cur:
+            groups.append(cur)
+        for bi, grp in enumerate(groups):
+            n = sum(p.numel() for p in grp)
+            flat = torch.zeros(n, dtype=grp[0].dtype, device=grp[0].device)
+            off = 0
+            for p in grp:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                self._bucket_of[p] = bi
+                off += p.numel()
+            self.buckets.append(flat)
+            self._bucket_sizes.append(len(grp))
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    # ---- step protocol --------------------------------------------------------------------------
+    def zero_grad(self):
+        for b in self.buckets:
+            b.zero_()
+
+    def arm(self):
+        """Call right before the LAST backward() of the step: from now on a bucket is reduced as soon
+        as each of its gradients has been accumulated once more."""
+        self._armed = True
+        self._pending = list(self._bucket_sizes)
+        self._handles = []
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        if self.world > 1:
+            self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Wait for the in-flight reductions; reduce buckets whose parameters got no gradient in the
+        last sweep (e.g. unused heads); apply the 1/world average."""
+        if self._armed:
+            for bi, left in enumerate(self._pending):
+                if left > 0:
+                    self._launch(bi)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._armed = False
+        if self.world > 1 and self.average:
+            for b in self.buckets:
+                b.div_(self.world)
+
+    def check_views(self):
+        """autograd must keep accumulating into the bucket views (it does as long as .grad is never re-bound)."""
+        for p in self.params:
+            bi = self._bucket_of[p]
+            b = self.buckets[bi]
+            if p.grad is None or p.grad.data_ptr() < b.data_ptr() or p.grad.data_ptr() >= b.data_ptr() + b.numel() * b.element_size():
+                return False
+        return True
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):
+    """One-off weight/buffer sync at start-up (replicas are seeded identically; this makes it certain)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=process_group)

@@ -1,0 +1,99 @@
+"""The optimisation step of multi_train_MDViT.py:129-213 (and multi_train_BASE.py:150-200) for the
+HIP-backed models: per domain forward -> fused losses -> the "det_Sup" two-sweep backward
+(aux loss with every `domain_layer` parameter frozen, then alpha*kt + (1-alpha)*loss into everything),
+gradients accumulated over the domains, optional data-parallel all-reduce, optimizer step.
+
+Because the step loss is a sum over domains, back-propagating each domain right after its forward
+gives the same gradients as the reference's "4 forwards, then 2 sweeps" while keeping only one
+domain's activations alive; `per_domain_backward=False` reproduces the reference's
+order exactly.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .losses import domain_losses, seg_loss
+from .parallel import GradBucketReducer
+
+
+def _da_params(model):
+    return [p for n, p in model.named_parameters() if "domain_layer" in n]
+
+
+def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: float = 0.5, num_domains: int = 4,
+                     reducer: Optional[GradBucketReducer] = None, per_domain_backward: bool = True,
+                     use_domain_label: bool = True) -> Dict[str, torch.Tensor]:
+    """batches: [(img (B,3,H,W), label (B,1,H,W), set_id (B,) int64)] one per domain.
+    Returns the summed losses as device tensors (no host sync inside the step)."""
+    da = _da_params(model)
+    if reducer is not None:
+        reducer.zero_grad()
+    elif optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    else:
+        model.zero_grad(set_to_none=True)
+
+    def two_sweeps(aux_sum, uni, last):
+        for p in da:
+            p.requires_grad = False
+        aux_sum.backward(retain_graph=True)
+        for p in da:
+            p.requires_grad = True
+        if last and reducer is not None:
+            reducer.arm()
+        uni.backward()
+
+    tot = tot_aux = tot_kt = None
+    stash = []
+    for i, (img, label, set_id) in enumerate(batches):
+        d = str(int(set_id[0]))      # set_id is created on the host side of the loader (multi_train_MDViT.py:137-138)
+        if use_domain_label:
+            domain_label = F.one_hot(set_id, num_domains).float()
+            out, aux = model(img, domain_label, d)
+        else:
+            out, aux = model(img, d=d)
+        l, la, lk = domain_losses(out, aux, label)
+        tot = l.detach() if tot is None else tot + l.detach()
+        tot_aux = la.detach() if tot_aux is None else tot_aux + la.detach()
+        tot_kt = lk.detach() if tot_kt is None else tot_kt + lk.detach()
+        if per_domain_backward:
+            two_sweeps(la, alpha * lk + (1 - alpha) * l, last=(i == len(batches) - 1))
+        else:
+            stash.append((l, la, lk))
+    if not per_domain_backward:
+        two_sweeps(sum(s[1] for s in stash), alpha * sum(s[2] for s in stash) + (1 - alpha) * sum(s[0] for s in stash), last=True)
+    if reducer is not None:
+        reducer.finish()
+    if optimizer is not None:
+        optimizer.step()
+    return {"loss": tot, "aux_loss": tot_aux, "kt_loss": tot_kt}
+
+
+def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Optional[GradBucketReducer] = None,
+                    num_domains: int = 4, use_domain_label: bool = False) -> Dict[str, torch.Tensor]:
+    """multi_train_BASE.py:150-200: per domain loss = BCE + Dice, one backward of the sum."""
+    if reducer is not None:
+        reducer.zero_grad()
+    elif optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    else:
+        model.zero_grad(set_to_none=True)
+    tot = None
+    for i, (img, label, set_id) in enumerate(batches):
+        if use_domain_label:
+            out = model(img, F.one_hot(set_id, num_domains).float())
+        else:
+            out = model(img)
+        l = seg_loss(out, label)
+        if reducer is not None and i == len(batches) - 1:
+            reducer.arm()
+        l.backward()
+        tot = l.detach() if tot is None else tot + l.detach()
+    if reducer is not None:
+        reducer.finish()
+    if optimizer is not None:
+        optimizer.step()
+    return {"loss": tot}

@@ -1,0 +1,433 @@
+"""Per-kernel parity: each HIP entry point (through the C ABI, via mdvit_amd.ops) against a plain
+torch CPU reference of the same op on the same seeded inputs.  fp32 tolerance: 1e-4 relative to the
+tensor's max magnitude unless stated (north_star bar: 1e-3 rel)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+def check(a, b, tol=TOL, name=""):
+    assert a.shape == b.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = relerr(a, b)
+    assert math.isfinite(e) and e <= tol, f"{name}: rel-to-max error {e:.3e} > {tol}"
+
+
+def grads_of(fn, inputs, gout):
+    ins = [t.clone().requires_grad_(True) for t in inputs]
+    out = fn(*ins)
+    out.backward(gout.to(out.device))
+    return out, [t.grad for t in ins]
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(70, 192, 64), (1000, 64, 512), (300, 320, 128), (257, 1024, 320), (8, 64, 64), (4096, 2048, 512), (33, 36, 28)])
+def test_linear_fwd_bwd(M, N, K):
+    from mdvit_amd import ops
+    x, W, b, g = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref, gr = grads_of(lambda x, W, b: F.linear(x.double(), W.double(), b.double()), [x, W, b], g.double())
+    out, go = grads_of(lambda x, W, b: ops.linear(x, W, b), [x.to(dev()), W.to(dev()), b.to(dev())], g)
+    check(out, ref, name="y")
+    for n, a, r in zip(("dx", "dW", "db"), go, gr):
+        check(a, r, name=n)
+
+
+def test_linear_big_token_axis_split():
+    """wgrad reduces over 65536 tokens -> split-K + atomics path."""
+    from mdvit_amd import ops
+    M, N, K = 65536, 64, 64
+    x, W, g = rnd(M, K, seed=5), rnd(N, K, seed=6, scale=0.125), rnd(M, N, seed=7)
+    ref, gr = grads_of(lambda x, W: F.linear(x.double(), W.double()), [x, W], g.double())
+    out, go = grads_of(lambda x, W: ops.linear(x, W, None), [x.to(dev()), W.to(dev())], g)
+    check(out, ref, name="y")
+    check(go[0], gr[0], name="dx")
+    check(go[1], gr[1], tol=2e-4, name="dW")
+
+
+def test_linear_weight_slice_and_residual():
+    from mdvit_amd import ops
+    M, N, K = 200, 128, 64
+    Wfull, x, res, g = rnd(N, 320, seed=8, scale=0.1), rnd(M, K, seed=9), rnd(M, N, seed=10), rnd(M, N, seed=11)
+
+    def ref_fn(x, Wf, res):
+        return res.double() + F.linear(x.double(), Wf.double()[:, 128:192])
+
+    def hip_fn(x, Wf, res):
+        return ops.linear(x, Wf[:, 128:192], None, residual=res)
+
+    ref, gr = grads_of(ref_fn, [x, Wfull, res], g.double())
+    out, go = grads_of(hip_fn, [x.to(dev()), Wfull.to(dev()), res.to(dev())], g)
+    check(out, ref, name="y")
+    for n, a, r in zip(("dx", "dWfull", "dres"), go, gr):
+        check(a, r, name=n)
+
+
+def test_matmul_composition():
+    from mdvit_amd import ops
+    A, B, g = rnd(512, 2112, seed=12, scale=0.05), rnd(512, 320, seed=13, scale=0.05), rnd(512, 320, seed=14)
+    ref, gr = grads_of(lambda A, B: A.double()[:, 512:1024] @ B.double(), [A, B], g.double())
+    out, go = grads_of(lambda A, B: ops.matmul(A[:, 512:1024], B), [A.to(dev()), B.to(dev())], g)
+    check(out, ref, name="C")
+    check(go[0], gr[0], name="dA")
+    check(go[1], gr[1], name="dB")
+
+
+def test_linear_dropout_droppath_statistics_and_backward_mask():
+    from mdvit_amd import ops
+    torch.manual_seed(0)
+    B_, Ntok, K, N = 8, 128, 64, 256
+    M = B_ * Ntok
+    x, W, b = rnd(M, K, seed=15).to(dev()), rnd(N, K, seed=16, scale=0.2).to(dev()), rnd(N, seed=17).to(dev())
+    res = torch.zeros(M, N, device=dev())
+    rs = torch.tensor([0, 1 / 0.9, 1 / 0.9, 0, 1 / 0.9, 1 / 0.9, 1 / 0.9, 1 / 0.9], device=dev())
+    xr, Wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    y = ops.linear(xr, Wr, b, residual=res, rowscale=rs, drop_p=0.1, rows_per_scale=Ntok)
+    plain = F.linear(x, W, b)
+    ratio = (y / plain).detach()
+    live = rs.repeat_interleave(Ntok) > 0
+    kept = (ratio[live].abs() > 1e-6)
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.9) < 0.01, f"keep rate {frac}"
+    assert (y[~live] == 0).all(), "DropPath-ed samples must be exactly zero"
+    exp_scale = (1 / 0.9) * (1 / 0.9)
+    assert torch.allclose(ratio[live][kept], torch.full_like(ratio[live][kept], exp_scale), rtol=1e-4)
+    # backward must use the SAME mask
+    g = rnd(M, N, seed=18).to(dev())
+    y.backward(g)
+    mask = torch.zeros_like(y)
+    mask[live] = kept.float() * exp_scale
+    gm = g * mask
+    check(xr.grad, gm @ W, name="dx under dropout")
+    check(Wr.grad, gm.t() @ x, tol=2e-4, name="dW under dropout")
+    # a second call draws a different mask
+    y2 = ops.linear(x, W, b, residual=res, rowscale=rs, drop_p=0.1, rows_per_scale=Ntok)
+    assert (y2 != y.detach()).any()
+
+
+@pytest.mark.parametrize("M,C,r", [(512, 64, 8), (130, 128, 8), (64, 320, 4), (16, 512, 4)])
+def test_mlp_residual(M, C, r):
+    from mdvit_amd import ops
+    Hd = C * r
+    x, res = rnd(M, C, seed=20), rnd(M, C, seed=21)
+    W1, b1, W2, b2 = rnd(Hd, C, seed=22, scale=C ** -0.5), rnd(Hd, seed=23, scale=0.1), rnd(C, Hd, seed=24, scale=Hd ** -0.5), rnd(C, seed=25, scale=0.1)
+    g = rnd(M, C, seed=26)
+
+    def ref_fn(x, res, W1, b1, W2, b2):
+        return res.double() + F.linear(F.gelu(F.linear(x.double(), W1.double(), b1.double())), W2.double(), b2.double())
+
+    ref, gr = grads_of(ref_fn, [x, res, W1, b1, W2, b2], g.double())
+    out, go = grads_of(lambda *a: ops.mlp_residual(*a), [t.to(dev()) for t in (x, res, W1, b1, W2, b2)], g)
+    check(out, ref, name="y")
+    for n, a, r_ in zip(("dx", "dres", "dW1", "db1", "dW2", "db2"), go, gr):
+        check(a, r_, name=n)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 64), (77, 128), (300, 320), (64, 512), (5, 1024)])
+def test_layernorm(M, C):
+    from mdvit_amd import ops
+    x, ga, be, g = rnd(M, C, seed=30, scale=2.0) + 0.5, 1 + 0.5 * rnd(C, seed=31), rnd(C, seed=32, scale=0.1), rnd(M, C, seed=33)
+    ref, gr = grads_of(lambda x, ga, be: F.layer_norm(x.double(), (C,), ga.double(), be.double(), 1e-6), [x, ga, be], g.double())
+    out, go = grads_of(lambda x, ga, be: ops.layer_norm(x, ga, be, 1e-6), [x.to(dev()), ga.to(dev()), be.to(dev())], g)
+    check(out, ref, name="y")
+    for n, a, r in zip(("dx", "dgamma", "dbeta"), go, gr):
+        check(a, r, name=n)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,C,stride,bias,add", [(2, 16, 16, 64, 1, True, True), (2, 17, 13, 128, 2, False, False), (1, 8, 8, 320, 2, False, False),
+                                                     (3, 5, 7, 64, 1, False, False), (2, 4, 4, 512, 1, True, True)])
+def test_dwconv3x3(B, H, W, C, stride, bias, add):
+    from mdvit_amd import ops
+    x, w, b = rnd(B, C, H, W, seed=40), rnd(C, 1, 3, 3, seed=41, scale=0.3), (rnd(C, seed=42, scale=0.1) if bias else None)
+
+    def ref_fn(x, w, *bb):
+        y = F.conv2d(x.double(), w.double(), bb[0].double() if bb else None, stride, 1, 1, C)
+        return y + x.double() if add else y
+
+    ins = [x, w] + ([b] if bias else [])
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    g = rnd(B, C, Ho, Wo, seed=43)
+    ref, gr = grads_of(ref_fn, ins, g.double())
+
+    def hip_fn(x, w, *bb):
+        return ops.dwconv3x3(x, w, bb[0] if bb else None, stride, add)
+
+    hin = [nhwc(x).to(dev()), w.to(dev())] + ([b.to(dev())] if bias else [])
+    out, go = grads_of(hip_fn, hin, nhwc(g))
+    check(nchw(out), ref, name="y")
+    check(nchw(go[0]), gr[0], name="dx")
+    check(go[1], gr[1], name="dw")
+    if bias:
+        check(go[2], gr[2], name="dbias")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 9, 7, 128), (2, 4, 4, 320), (1, 2, 2, 512)])
+def test_gconv2(B, H, W, C):
+    from mdvit_amd import ops
+    skip, up, w, g = rnd(B, C, H, W, seed=50), rnd(B, C, H, W, seed=51), rnd(C, 2, 3, 3, seed=52, scale=0.3), rnd(B, C, H, W, seed=53)
+    ref, gr = grads_of(lambda s, u, w: F.conv2d(torch.cat((s, u), 1).double(), w.double(), None, 1, 1, 1, C), [skip, up, w], g.double())
+    out, go = grads_of(lambda s, u, w: ops.gconv2_3x3(s, u, w), [nhwc(skip).to(dev()), nhwc(up).to(dev()), w.to(dev())], nhwc(g))
+    check(nchw(out), ref, name="y")
+    check(nchw(go[0]), gr[0], name="dskip")
+    check(nchw(go[1]), gr[1], name="dup")
+    check(go[2], gr[2], name="dw")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,bias", [(2, 16, 16, 32, 64, 2, False), (1, 8, 8, 512, 512, 1, True), (2, 5, 6, 64, 128, 1, True), (1, 9, 9, 32, 64, 2, False)])
+def test_conv3x3_dense(B, H, W, Cin, Cout, stride, bias):
+    from mdvit_amd import ops
+    x, w = rnd(B, Cin, H, W, seed=60), rnd(Cout, Cin, 3, 3, seed=61, scale=(Cin * 9) ** -0.5)
+    b = rnd(Cout, seed=62, scale=0.1) if bias else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    g = rnd(B, Cout, Ho, Wo, seed=63)
+    ins = [x, w] + ([b] if bias else [])
+    ref, gr = grads_of(lambda x, w, *bb: F.conv2d(x.double(), w.double(), bb[0].double() if bb else None, stride, 1), ins, g.double())
+    hin = [nhwc(x).to(dev()), w.to(dev())] + ([b.to(dev())] if bias else [])
+    out, go = grads_of(lambda x, w, *bb: ops.conv3x3_dense(x, w, bb[0] if bb else None, stride), hin, nhwc(g))
+    check(nchw(out), ref, name="y")
+    check(nchw(go[0]), gr[0], name="dx")
+    check(go[1], gr[1], name="dw")
+    if bias:
+        check(go[2], gr[2], name="db")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 17, 23), (3, 64, 48)])
+def test_stem_conv(B, H, W):
+    from mdvit_amd import ops
+    img, w = rnd(B, 3, H, W, seed=70, scale=2.0), rnd(32, 3, 3, 3, seed=71, scale=0.2)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = rnd(B, 32, Ho, Wo, seed=72)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(img.double(), wr.double(), None, 2, 1)
+    ref.backward(g.double())
+    wh = w.to(dev()).requires_grad_(True)
+    out = ops.stem_conv(img.to(dev()), wh)
+    out.backward(nhwc(g).to(dev()))
+    check(nchw(out), ref, name="y")
+    check(wh.grad, wr.grad, name="dw")
+
+
+@pytest.mark.parametrize("act", ["hswish", "relu"])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (4, 3, 5, 320), (1, 8, 8, 1024)])
+def test_bn_act_train(act, B, H, W, C):
+    from mdvit_amd import ops, _lib
+    a = _lib.ACT_HSWISH if act == "hswish" else _lib.ACT_RELU
+    fn = F.hardswish if act == "hswish" else F.relu
+    y, ga, be, g = rnd(B, C, H, W, seed=80, scale=2.0) + 0.3, 1 + 0.5 * rnd(C, seed=81), rnd(C, seed=82, scale=0.2), rnd(B, C, H, W, seed=83)
+    rm0, rv0 = rnd(C, seed=84, scale=0.1), 1 + 0.5 * rnd(C, seed=85)
+    rm, rv = rm0.clone().double(), rv0.clone().double()
+    ref, gr = grads_of(lambda y, ga, be: fn(F.batch_norm(y.double(), rm, rv, ga.double(), be.double(), True, 0.1, 1e-5)), [y, ga, be], g.double())
+    rmh, rvh, nbt = rm0.to(dev()), rv0.to(dev()), torch.tensor(3, device=dev())
+    out, go = grads_of(lambda y, ga, be: ops.bn_act(y, ga, be, rmh, rvh, nbt, True, a), [nhwc(y).to(dev()), ga.to(dev()), be.to(dev())], nhwc(g))
+    check(nchw(out), ref, name="z")
+    check(nchw(go[0]), gr[0], tol=3e-4, name="dy")
+    check(go[1], gr[1], tol=3e-4, name="dgamma")
+    check(go[2], gr[2], tol=3e-4, name="dbeta")
+    check(rmh, rm, name="running_mean")
+    check(rvh, rv, name="running_var")
+    assert int(nbt) == 4
+
+
+def test_bn_act_eval_and_dropout2d():
+    from mdvit_amd import ops, _lib
+    B, H, W, C = 4, 8, 8, 64
+    y, ga, be = rnd(B, C, H, W, seed=90), 1 + 0.5 * rnd(C, seed=91), rnd(C, seed=92, scale=0.2)
+    rm, rv = rnd(C, seed=93, scale=0.3), 1 + 0.5 * rnd(C, seed=94)
+    ref = F.relu(F.batch_norm(y.double(), rm.double(), rv.double(), ga.double(), be.double(), False, 0.1, 1e-5))
+    rmh, rvh = rm.to(dev()), rv.to(dev())
+    out = ops.bn_act(nhwc(y).to(dev()), ga.to(dev()), be.to(dev()), rmh, rvh, None, False, _lib.ACT_RELU)
+    check(nchw(out), ref, name="eval z")
+    check(rmh, rm, tol=0, name="running_mean untouched")
+    # Dropout2d: whole (sample, channel) planes are zeroed, survivors scaled by 1/keep
+    B, H, W, C = 16, 4, 4, 512
+    yy = (rnd(B, H, W, C, seed=95).abs() + 0.5).to(dev())
+    one, zero = torch.ones(C, device=dev()), torch.zeros(C, device=dev())
+    z_plain = ops.bn_act(yy, one, zero, zero.clone(), one.clone(), None, False, _lib.ACT_NONE)
+    z = ops.bn_act(yy, one, zero, zero.clone(), one.clone(), None, True, _lib.ACT_NONE, drop2d_p=0.25)
+    # training-mode BN normalises, so compare plane-wise zero pattern only
+    planes = (z.abs().sum(dim=(1, 2)) == 0)
+    frac = planes.float().mean().item()
+    assert abs(frac - 0.25) < 0.03, f"dropped plane fraction {frac}"
+    partial = ((z == 0).float().mean(dim=(1, 2)) > 0) & ~planes
+    assert not partial.any(), "Dropout2d must drop whole planes"
+    assert z_plain.abs().min() > 0
+
+
+@pytest.mark.parametrize("B,Hi,Wi,Ho,Wo,C", [(2, 8, 8, 16, 16, 64), (1, 4, 4, 32, 32, 128), (2, 16, 16, 64, 64, 1), (1, 3, 4, 24, 32, 512), (2, 5, 7, 11, 13, 8), (1, 6, 8, 6, 8, 64)])
+def test_upsample(B, Hi, Wi, Ho, Wo, C):
+    from mdvit_amd.ops import _Upsample
+    x, g = rnd(B, C, Hi, Wi, seed=100), rnd(B, C, Ho, Wo, seed=101)
+    ref, gr = grads_of(lambda x: F.interpolate(x.double(), size=(Ho, Wo), mode="bilinear", align_corners=False), [x], g.double())
+    out, go = grads_of(lambda x: _Upsample.apply(x, Ho, Wo, None), [nhwc(x).to(dev())], nhwc(g))
+    check(nchw(out), ref, name="y")
+    check(nchw(go[0]), gr[0], name="dx")
+    base = rnd(B, Ho, Wo, C, seed=102).to(dev())
+    out2 = _Upsample.apply(nhwc(x).to(dev()), Ho, Wo, base)
+    check(out2, out.detach() + base, name="accumulate")
+
+
+def test_rowdot():
+    from mdvit_amd import ops
+    x, w, b, g = rnd(3000, 64, seed=110), rnd(1, 64, 1, 1, seed=111), rnd(1, seed=112), rnd(3000, seed=113)
+    ref, gr = grads_of(lambda x, w, b: x.double() @ w.double().view(-1) + b.double(), [x, w, b], g.double())
+    out, go = grads_of(lambda x, w, b: ops.rowdot(x, w, b), [x.to(dev()), w.to(dev()), b.to(dev())], g)
+    check(out, ref, name="y")
+    for n, a, r in zip(("dx", "dw", "db"), go, gr):
+        check(a, r, name=n)
+    # strided rows (a column slice of a wider matrix), K = 512
+    Wf, v = rnd(512, 2112, seed=114), rnd(512, seed=115)
+    ref2, gr2 = grads_of(lambda Wf, v: Wf.double()[:, 1024:1536] @ v.double(), [Wf, v], rnd(512, seed=116).double())
+    out2, go2 = grads_of(lambda Wf, v: ops.rowdot(Wf[:, 1024:1536], v), [Wf.to(dev()), v.to(dev())], rnd(512, seed=116))
+    check(out2, ref2, name="y slice")
+    check(go2[0], gr2[0], name="dWf slice")
+    check(go2[1], gr2[1], name="dv slice")
+
+
+@pytest.mark.parametrize("C", [64, 128, 320, 512])
+def test_domain_adapter(C):
+    from mdvit_amd import ops
+    B, hid, heads = 5, max(C // 2, 4), 8
+    lab = F.one_hot(torch.tensor([0, 3, 1, 2, 3]), 4).float()
+    W1, b1, W2, b2 = rnd(hid, 4, seed=120, scale=1.5), rnd(hid, seed=121, scale=0.1), rnd(C, hid, seed=122, scale=3 / hid ** 0.5), rnd(C, seed=123, scale=0.1)
+    g = rnd(B, C, seed=124)
+
+    def ref_fn(W1, b1, W2, b2):
+        z = F.linear(torch.relu(F.linear(lab.double(), W1.double(), b1.double())), W2.double(), b2.double())
+        return torch.softmax(z.view(B, heads, C // heads), dim=1).reshape(B, C)
+
+    ref, gr = grads_of(ref_fn, [W1, b1, W2, b2], g.double())
+    out, go = grads_of(lambda *p: ops.domain_adapter(lab.to(dev()), *p, heads), [t.to(dev()) for t in (W1, b1, W2, b2)], g)
+    check(out, ref, name="a")
+    for n, a, r in zip(("dW1", "db1", "dW2", "db2"), go, gr):
+        check(a, r, name=n)
+    # domain-id routing is exact: one_hot(d) @ W1^T == the gathered column W1[:, d] (bit-for-bit)
+    with torch.no_grad():
+        for d in range(4):
+            a_onehot = ops.domain_adapter(F.one_hot(torch.tensor([d]), 4).float().to(dev()), *[t.to(dev()) for t in (W1, b1, W2, b2)], heads)
+            W1g = torch.zeros_like(W1); W1g[:, 0] = W1[:, d]
+            a_gather = ops.domain_adapter(torch.tensor([[1.0, 0, 0, 0]], device=dev()), W1g.to(dev()), b1.to(dev()), W2.to(dev()), b2.to(dev()), heads)
+            assert torch.equal(a_onehot, a_gather), f"domain {d}: gather not bit-exact"
+
+
+def _attn_ref(qkv, crpe, a, H, W, heads):
+    """double-precision restatement of the attention core on (B,N,3C) qkv (mdvit.py:293-304)."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    Ch = C // heads
+    q, k, v = [t.reshape(B, N, heads, Ch).permute(0, 2, 1, 3) for t in qkv.split(C, dim=2)]
+    M = torch.softmax(k, dim=2).transpose(2, 3) @ v
+    fa = q @ M
+    vimg = v.permute(0, 1, 3, 2).reshape(B, C, H, W)
+    w3, b3, w5, b5, w7, b7 = crpe
+    c1, c2 = 2 * Ch, 5 * Ch
+    conv = torch.cat([F.conv2d(vimg[:, :c1], w3, b3, 1, 1, 1, c1), F.conv2d(vimg[:, c1:c2], w5, b5, 1, 2, 1, c2 - c1),
+                      F.conv2d(vimg[:, c2:], w7, b7, 1, 3, 1, C - c2)], 1)
+    conv = conv.reshape(B, heads, Ch, N).permute(0, 1, 3, 2)
+    y = Ch ** -0.5 * fa + q * conv
+    if a is not None:
+        y = a.view(B, heads, 1, Ch) * y
+    return y.permute(0, 2, 1, 3).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("B,H,W,C,use_a", [(2, 16, 16, 64, True), (1, 9, 14, 128, True), (2, 8, 8, 320, True), (2, 4, 4, 512, True), (2, 12, 12, 64, False), (1, 40, 40, 64, True)])
+def test_factor_att_core(B, H, W, C, use_a):
+    from mdvit_amd import ops
+    heads, Ch, N = 8, C // 8, H * W
+    qkv = rnd(B, N, 3 * C, seed=130, scale=1.5)
+    crpe = [rnd(2 * Ch, 1, 3, 3, seed=131, scale=0.3), rnd(2 * Ch, seed=132, scale=0.1), rnd(3 * Ch, 1, 5, 5, seed=133, scale=0.2), rnd(3 * Ch, seed=134, scale=0.1),
+            rnd(3 * Ch, 1, 7, 7, seed=135, scale=0.15), rnd(3 * Ch, seed=136, scale=0.1)]
+    a = torch.softmax(rnd(B, heads, Ch, seed=137, scale=2.0), dim=1).reshape(B, C) if use_a else None
+    g = rnd(B, N, C, seed=138)
+    ins = [qkv] + crpe + ([a] if use_a else [])
+
+    def ref_fn(qkv, *rest):
+        cr = [t.double() for t in rest[:6]]
+        return _attn_ref(qkv.double(), cr, rest[6].double() if use_a else None, H, W, heads)
+
+    def hip_fn(qkv, *rest):
+        return ops.factor_att(qkv, tuple(rest[:6]), rest[6] if use_a else None, H, W, heads)
+
+    ref, gr = grads_of(ref_fn, ins, g.double())
+    out, go = grads_of(hip_fn, [t.to(dev()) for t in ins], g)
+    check(out, ref, name="y")
+    names = ["dqkv", "dw3", "db3", "dw5", "db5", "dw7", "db7"] + (["da"] if use_a else [])
+    for n, x, r in zip(names, go, gr):
+        check(x, r, tol=3e-4, name=n)
+
+
+def test_factor_att_softmax_is_shift_invariant_and_stable():
+    """column softmax over tokens with a large offset on K must not overflow (online max handling)."""
+    from mdvit_amd import ops
+    B, H, W, C, heads = 1, 16, 16, 64, 8
+    Ch = C // heads
+    qkv = rnd(B, H * W, 3 * C, seed=140)
+    crpe = [rnd(2 * Ch, 1, 3, 3, seed=141, scale=0.3), rnd(2 * Ch, seed=142), rnd(3 * Ch, 1, 5, 5, seed=143, scale=0.2), rnd(3 * Ch, seed=144),
+            rnd(3 * Ch, 1, 7, 7, seed=145, scale=0.1), rnd(3 * Ch, seed=146)]
+    crd = tuple(t.to(dev()) for t in crpe)
+    y0 = ops.factor_att(qkv.to(dev()), crd, None, H, W, heads)
+    q2 = qkv.clone(); q2[:, :, C:2 * C] += 300.0     # exp(300) overflows fp32 without max subtraction
+    y1 = ops.factor_att(q2.to(dev()), crd, None, H, W, heads)
+    assert torch.isfinite(y1).all()
+    check(y1, y0, tol=2e-4, name="shift invariance")
+
+
+def test_seg_losses(golden):
+    from mdvit_amd import ops
+    from oracle import mdvit_ref as R
+    from oracle.gen_golden import synth_label, synth_tokens
+    gd = golden("losses_small")
+    o = synth_tokens(5, 1, (2, 1, 32, 32)) * 6.0
+    a = synth_tokens(5, 2, (2, 1, 32, 32)) * 6.0
+    o.view(-1)[:8] = torch.tensor([200.0, -200.0, 120.0, -120.0, 90.0, -90.0, 40.0, -40.0])
+    lab = synth_label(5, 2, 32, 32)
+    oh, ah = o.to(dev()).requires_grad_(True), a.to(dev()).requires_grad_(True)
+    l = ops.seg_losses(oh, ah, lab.to(dev()))
+    check(l.cpu(), torch.tensor(gd["losses"], dtype=torch.float32), tol=1e-5, name="losses vs golden")
+    l[1].backward(retain_graph=True)
+    assert oh.grad is None or float(oh.grad.abs().max()) == 0.0
+    check(ah.grad, torch.from_numpy(gd["d_aux_from_auxloss"]), tol=2e-4, name="d aux (aux sweep)")
+    ah.grad = None; oh.grad = None
+    (0.5 * l[2] + 0.5 * l[0]).backward()
+    check(oh.grad, torch.from_numpy(gd["d_out_from_uni"]), tol=2e-4, name="d out (uni sweep)")
+    check(ah.grad, torch.from_numpy(gd["d_aux_from_uni"]), tol=2e-4, name="d aux (uni sweep)")
+    # BASE flavour (no aux)
+    l0 = ops.seg_losses(o.to(dev()), None, lab.to(dev()))
+    ref0 = R.bce_loss(torch.sigmoid(o.double()), lab.double()) + R.dice_loss(torch.sigmoid(o.double()), lab.double())
+    assert abs(float(l0[0]) - float(ref0)) < 1e-5 * abs(float(ref0))
+
+
+def test_abi_error_reporting():
+    from mdvit_amd import ops, _lib
+    x = torch.zeros(4, 6, device=dev())        # K = 6 is not a multiple of 4 -> MDVIT_E_ALIGN, not a crash
+    W = torch.zeros(8, 6, device=dev())
+    with pytest.raises(_lib.MdvitHipError, match="gemm"):
+        ops.linear(x, W, None)
+    with pytest.raises(_lib.MdvitHipError):
+        ops.linear(torch.zeros(4, 8), torch.zeros(8, 8), None)      # CPU tensors: no CPU path
