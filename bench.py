@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MDViT (adapt_method='Sup', MLPFM peer heads) train step at 512x512 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--size S] [--model mdvit|base]
+
+One step = for each of the 4 domains a forward of B synthetic images, the fused BCE/Dice/KT losses and
+the reference's two-sweep backward (multi_train_MDViT.py:129-207), gradient all-reduce across ranks,
+AdamW update.  drop_rate = drop_path_rate = 0.1 as in multi_train_MDViT.py:59.  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line (see README/DESIGN for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--model", default="mdvit", choices=["mdvit", "base"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--detail", default="", help="write the per-kernel table to this JSON file")
+    return ap.parse_args()
+
+
+def cpu_baseline(size: int):
+    """The CPU oracle (oracle/mdvit_ref.py, pure torch fp32) timed on the host cores on a bounded sample of the
+    same workload: one domain, one 512x512 image, forward + losses + two-sweep backward."""
+    import torch
+    from oracle import mdvit_ref as R
+    from oracle.params import make_params
+    from mdvit_amd.synthetic import make_domain_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = R.to_torch(make_params(0, model="MDViT", adapt_method="Sup"))
+    img, lab, _ = make_domain_batch(1, size, 0, 1234)
+    st = R.RefState(training=True, drop_rate=0.1, drop_path_rate=0.1, aux_drop=0.1)
+    t0 = time.perf_counter()
+    R.mdvit_train_step(P, [(img, lab, 0)], st)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 domain x 1 image {size}x{size}, fwd + BCE/Dice/KT + two-sweep bwd, fp32 torch CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mdvit_amd
+    from mdvit_amd import ops
+    from mdvit_amd.parallel import GradBucketReducer, broadcast_parameters
+    from mdvit_amd.synthetic import make_step_batches
+    from mdvit_amd.train import base_train_step, mdvit_train_step
+
+    torch.manual_seed(0)
+    if args.model == "mdvit":
+        model = mdvit_amd.MDViT(img_size=args.size, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d,
+                                adapt_method="Sup", num_domains=4, decoder_name="MLPFM").to(dev).train()
+        domains, flop_per_img = (0, 1, 2, 3), 251.0e9
+    else:
+        model = mdvit_amd.BASE(drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method=False).to(dev).train()
+        domains, flop_per_img = (0,), 137.7e9
+    broadcast_parameters(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    reducer = GradBucketReducer(model.parameters()) if world > 1 else None
+    # a small pool of distinct synthetic steps, resident in HBM before timing
+    pool = [make_step_batches(args.batch, args.size, rank=rank, step=s, device=dev, domains=domains) for s in range(2)]
+
+    def step(i):
+        b = pool[i % len(pool)]
+        if args.model == "mdvit":
+            return mdvit_train_step(model, b, optimizer=opt, reducer=reducer)
+        return base_train_step(model, b, optimizer=opt, reducer=reducer)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    if not args.no_kernel_events:
+        ops.kernel_events_begin()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    table = ops.kernel_events_end() if not args.no_kernel_events else {}
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    imgs_per_step = len(domains) * args.batch * world
+    value = imgs_per_step * args.steps / dt
+    loss_val = float(last["loss"]) if last is not None else float("nan")
+
+    if rank == 0:
+        roof = None
+        if table:
+            name, rec = max(table.items(), key=lambda kv: kv[1]["ms"])
+            tf = rec["flop"] / (rec["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
+                    "flop_per_launch": round(rec["flop"] / rec["n"]),
+                    "share_of_step": round(rec["ms"] / (dt * 1e3), 4)}
+            if args.detail:
+                with open(args.detail, "w") as f:
+                    json.dump({"step_ms": dt * 1e3 / args.steps, "kernels": table}, f, indent=1)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline(args.size)
+            except Exception as e:           # the baseline is a report, never a reason to lose the GPU number
+                cpu = {"error": repr(e)}
+        line = {
+            "metric": "512x512 images/sec MDViT train step (fwd+bwd, two-sweep, AdamW)" if args.model == "mdvit" else "512x512 images/sec BASE train step",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{'MDViT Sup+MLPFM' if args.model == 'mdvit' else 'BASE'} train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
+                                   f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, fp32 MFMA, data-parallel x{world}",
+                       "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
+            "model_flops_util": round(value / world * flop_per_img / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,26 +124,32 @@ int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t 
                        int32_t accumulate, void* stream);
 int mdvit_upsample_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
 
-/* ---- Domain Adapter: a = softmax_heads(W2 relu(W1 label + b1) + b2), [B,C] (mdvit.py:272-276,301-303) */
+/* ---- Domain Adapter: a = softmax_heads(W2 relu(W1 label + b1) + b2), [B,C] (mdvit.py:272-276,301-303).
+ * Backward takes e[b,c] = a[b,c] * dL/da[b,c] (what mdvit_factoratt_bwd emits -- it needs no division by a):
+ * dz = e - a * sum_heads(e).  ws: mdvit_da_ws_bytes(B, hid, C) bytes of scratch. */
 int mdvit_da_fwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, float* a,
                  int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream);
+size_t mdvit_da_ws_bytes(int32_t B, int32_t hid, int32_t C);
 int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,
-                 const float* da, float* dW1, float* db1, float* dW2, float* db2,
+                 const float* e, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,
                  int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream);
 
 /* ---- factorized attention core (mdvit.py:293-304, mpvit.py:296-318) -------------------------
  * qkv: [B,N,3C] as produced by the qkv Linear (q | k | v, channel = head*Ch + ch).
- * out[b,n,c] = a[b,c] * ( Ch^-0.5 * sum_j q[n,head,j] M[b,head,j,ch] + q[n,c] * (dwconv_win(v)[n,c] + bias[c]) )
+ * U[b,n,c]   = dwconv_win(v)[n,c] + bias[c]                       (saved for backward)
+ * out[b,n,c] = a[b,c] * ( Ch^-0.5 * sum_j q[n,head,j] M[b,head,j,ch] + q[n,c] * U[b,n,c] )
  * with M = softmax_over_tokens(k)^T v.  crpe weights: [s3*Ch,1,3,3], [s5*Ch,1,5,5], [s7*Ch,1,7,7] (+bias).
- * a == NULL: no domain adapter (mpvit.py:347-373).  kmax/ksum [B,C] and Mmat [B,C,Ch] are saved for backward. */
+ * a == NULL: no domain adapter (mpvit.py:347-373).  kmax/ksum [B,C] and Mmat [B,C,Ch] are saved for backward.
+ * Backward returns dqkv, the crpe gradients and e = a * dL/da (NULL when a is NULL). */
 size_t mdvit_factoratt_ws_bytes(int32_t B, int32_t N, int32_t C, int32_t heads);
 int mdvit_factoratt_fwd(const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
-                        const float* w7, const float* b7, const float* a, float* out, float* kmax, float* ksum, float* Mmat,
+                        const float* w7, const float* b7, const float* a, float* out, float* U, float* kmax, float* ksum, float* Mmat,
                         void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
                         int32_t s3, int32_t s5, int32_t s7, void* stream);
-int mdvit_factoratt_bwd(const float* dout, const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
-                        const float* w7, const float* b7, const float* a, const float* kmax, const float* ksum, const float* Mmat,
-                        float* dqkv, float* da, float* dw3, float* db3, float* dw5, float* db5, float* dw7, float* db7,
+int mdvit_factoratt_bwd(const float* dout, const float* qkv, const float* out, const float* U,
+                        const float* w3, const float* b3, const float* w5, const float* b5, const float* w7, const float* b7,
+                        const float* a, const float* kmax, const float* ksum, const float* Mmat,
+                        float* dqkv, float* e, float* dw3, float* db3, float* dw5, float* db5, float* dw7, float* db7,
                         void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
                         int32_t s3, int32_t s5, int32_t s7, void* stream);
 

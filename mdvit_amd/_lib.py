@@ -64,9 +64,9 @@ _SIGS = {
     "mdvit_upsample_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_upsample_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mdvit_da_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mdvit_factoratt_fwd": [vp] * 12 + [vp, C.c_size_t] + [i32] * 8 + [vp],
-    "mdvit_factoratt_bwd": [vp] * 20 + [vp, C.c_size_t] + [i32] * 8 + [vp],
+    "mdvit_da_bwd": [vp] * 11 + [vp, C.c_size_t] + [i32] * 5 + [vp],
+    "mdvit_factoratt_fwd": [vp] * 13 + [vp, C.c_size_t] + [i32] * 8 + [vp],
+    "mdvit_factoratt_bwd": [vp] * 22 + [vp, C.c_size_t] + [i32] * 8 + [vp],
     "mdvit_seg_losses_fwd": [vp, vp, vp, vp, vp, i64, vp],
     "mdvit_seg_losses_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, vp],
 }
@@ -102,6 +102,8 @@ def load():
     lib.mdvit_version.argtypes = []
     lib.mdvit_factoratt_ws_bytes.restype = C.c_size_t
     lib.mdvit_factoratt_ws_bytes.argtypes = [i32, i32, i32, i32]
+    lib.mdvit_da_ws_bytes.restype = C.c_size_t
+    lib.mdvit_da_ws_bytes.argtypes = [i32, i32, i32]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int

@@ -183,11 +183,11 @@ class ConvRelPosEnc(nn.Module):
 
 
 class _FactorAttBase(nn.Module):
-    def _attend(self, x, size, a, res, rowscale):
+    def _attend(self, x, size, domain_label, da_params, res, rowscale):
         B, N, Cn = x.shape
         H, W = size
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
-        y = ops.factor_att(qkv, self.crpe.params(), a, H, W, self.num_heads, self.crpe.head_splits)
+        y = ops.factor_att(qkv, self.crpe.params(), H, W, self.num_heads, self.crpe.head_splits, domain_label, da_params)
         # proj + proj_drop (+ DropPath + residual when the caller hands them in)
         return ops.linear(y, self.proj.weight, self.proj.bias, residual=res, rowscale=rowscale,
                           drop_p=self.proj_drop_p if self.training else 0.0, rows_per_scale=N)
@@ -207,7 +207,7 @@ class FactorAtt_ConvRelPosEnc(_FactorAttBase):
         self.crpe = shared_crpe
 
     def forward(self, x, size, _res=None, _rowscale=None):
-        return self._attend(x, size, None, _res, _rowscale)
+        return self._attend(x, size, None, None, _res, _rowscale)
 
 
 class FactorAtt_ConvRelPosEnc_Sup(_FactorAttBase):
@@ -228,8 +228,7 @@ class FactorAtt_ConvRelPosEnc_Sup(_FactorAttBase):
 
     def forward(self, x, size, domain_label, _res=None, _rowscale=None):
         d0, d2 = self.domain_layer[0], self.domain_layer[2]
-        a = ops.domain_adapter(domain_label, d0.weight, d0.bias, d2.weight, d2.bias, self.num_heads)
-        return self._attend(x, size, a, _res, _rowscale)
+        return self._attend(x, size, domain_label, (d0.weight, d0.bias, d2.weight, d2.bias), _res, _rowscale)
 
 
 class Mlp(nn.Module):

@@ -5,21 +5,24 @@
 //
 //   fwd  A: per (token tile, head chunk, batch): tile column max / exp-sum / partial K^T V    -> ws
 //        B: combine tiles (rescale by exp(m_t - m)) -> M [B,C,Ch], column stats kmax/ksum [B,C]
-//        C: out = a * (Ch^-0.5 * q.M + q * (dwconv_{3|5|7}(v) + bias))
-//   bwd  1: token-axis reductions da, dM, d(crpe weights)      2: t = sum dM*M     3: dq,dk,dv
+//        C: U = dwconv_{3|5|7}(v) + bias (saved);  out = a * (Ch^-0.5 * q.M + q * U)
+//   bwd  1: dU = a*G*q (stored), e[b,c] = sum_n G*out          (e = a * dL/da, needs no division)
+//        2: dM = Q^T dFA via the same tile-partial / combine scheme as fwd A/B (no softmax)
+//        3: crpe weight/bias gradients: depthwise-window wgrad of (dU, V), one launch per window size
+//        4: t = sum_e dM*M          5: dq, dk, dv per token with the head rows staged in LDS
+// All HBM/L2-bound VALU kernels: lanes run along channels (coalesced), token-axis reductions are
+// two-stage (tile partials in a workspace, then a combine) so every launch has >= hundreds of workgroups.
 #include "common.h"
 
 namespace {
 
-constexpr int FA_T = 64;      // tokens per tile in fwd pass A
-constexpr int FA_TCHUNK = 8;  // tokens exchanged through LDS per step in bwd pass 1
+constexpr int FA_T = 64;      // tokens per tile in the partial (K^T V / Q^T dFA) kernels
 
 struct FaGeom {
     int B, H, W, N, C, heads, Ch, s3, s5, s7;
     float scale;
 };
 
-// window radius and weight pointer of channel c
 struct CrpeW { const float* w3; const float* b3; const float* w5; const float* b5; const float* w7; const float* b7; };
 
 __device__ __forceinline__ int crpe_radius(const FaGeom& g, int c) {
@@ -37,62 +40,83 @@ __device__ __forceinline__ float crpe_bias(const FaGeom& g, const CrpeW& cw, int
     return cw.b7[c - (g.s3 + g.s5) * g.Ch];
 }
 
-// ---- fwd A --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fa_kv_partial_kernel(const float* __restrict__ qkv, float* __restrict__ ws_m,
-                                                            float* __restrict__ ws_s, float* __restrict__ ws_P, FaGeom g, int CW, int NT) {
-    extern __shared__ float sm[];          // ks[FA_T][CW], vs[FA_T][CW]
-    float* ks = sm;
-    float* vs = sm + FA_T * CW;
+// ---- tile partials: P[c][e] = sum_{n in tile} f(X[n,c]) * Y[n, head(c)*Ch + e] ----------------------
+// SOFTMAX: f = exp(x - tile max), also emits tile max / exp-sum (fwd A, X = k, Y = v).
+// !SOFTMAX: f = identity, Y scaled per channel by ysc[b,c]*yscale (bwd 2, X = q, Y = G).
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
+                                                         const float* __restrict__ ysc, float yscale,
+                                                         float* __restrict__ ws_m, float* __restrict__ ws_s, float* __restrict__ ws_P,
+                                                         FaGeom g, int CW, int NT) {
+    extern __shared__ float sm[];          // xs[FA_T][CW], ys[FA_T][CW]
+    float* xs = sm;
+    float* ys = sm + FA_T * CW;
     const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
     const int c0 = chunk * CW, n0 = tile * FA_T, nt = min(FA_T, g.N - n0);
-    const int C3 = 3 * g.C;
     for (int i = threadIdx.x; i < nt * CW; i += blockDim.x) {
         const int n = i / CW, c = i % CW;
-        const float* row = qkv + ((long)b * g.N + n0 + n) * C3;
-        ks[n * CW + c] = row[g.C + c0 + c];
-        vs[n * CW + c] = row[2 * g.C + c0 + c];
+        const long tok = (long)b * g.N + n0 + n;
+        xs[n * CW + c] = X[tok * ldx + c0 + c];
+        float yv = Y[tok * ldy + c0 + c];
+        if (!SOFTMAX) yv *= yscale * (ysc ? ysc[(long)b * g.C + c0 + c] : 1.f);
+        ys[n * CW + c] = yv;
     }
     __syncthreads();
-    if (threadIdx.x < CW) {
-        const int c = threadIdx.x;
+    if (SOFTMAX) {
+        // column max / exp: 4 threads per column (256 threads, CW <= 64), 2 (CW <= 128) or 1
+        const int per = CW <= 64 ? 4 : (CW <= 128 ? 2 : 1);
+        const int c = threadIdx.x / per, sub = threadIdx.x % per;
         float m = -INFINITY;
-        for (int n = 0; n < nt; ++n) m = fmaxf(m, ks[n * CW + c]);
+        if (c < CW)
+            for (int n = sub; n < nt; n += per) m = fmaxf(m, xs[n * CW + c]);
+        for (int o = 1; o < per; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         float s = 0.f;
-        for (int n = 0; n < nt; ++n) { const float e = expf(ks[n * CW + c] - m); ks[n * CW + c] = e; s += e; }
-        const long o = ((long)b * NT + tile) * g.C + c0 + c;
-        ws_m[o] = m; ws_s[o] = s;
+        if (c < CW)
+            for (int n = sub; n < nt; n += per) { const float e = expf(xs[n * CW + c] - m); xs[n * CW + c] = e; s += e; }
+        for (int o = 1; o < per; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (c < CW && sub == 0) {
+            const long o = ((long)b * NT + tile) * g.C + c0 + c;
+            ws_m[o] = m; ws_s[o] = s;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int o = threadIdx.x; o < CW * g.Ch; o += blockDim.x) {
         const int c = o / g.Ch, e = o % g.Ch, hb = (c / g.Ch) * g.Ch;
         float acc = 0.f;
-        for (int n = 0; n < nt; ++n) acc = fmaf(ks[n * CW + c], vs[n * CW + hb + e], acc);
+#pragma unroll 8
+        for (int n = 0; n < nt; ++n) acc = fmaf(xs[n * CW + c], ys[n * CW + hb + e], acc);
         ws_P[(((long)b * NT + tile) * g.C + c0 + c) * g.Ch + e] = acc;
     }
 }
 
-// ---- fwd B --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fa_kv_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_s,
-                                                            const float* __restrict__ ws_P, float* __restrict__ kmax, float* __restrict__ ksum,
-                                                            float* __restrict__ Mmat, FaGeom g, int NT) {
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void fa_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_s,
+                                                         const float* __restrict__ ws_P, float* __restrict__ kmax, float* __restrict__ ksum,
+                                                         float* __restrict__ Mout, FaGeom g, int NT) {
     const int b = blockIdx.y;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= g.C * g.Ch) return;
     const int c = o / g.Ch, e = o % g.Ch;
-    float m = -INFINITY;
-    for (int t = 0; t < NT; ++t) m = fmaxf(m, ws_m[((long)b * NT + t) * g.C + c]);
-    float s = 0.f, acc = 0.f;
-    for (int t = 0; t < NT; ++t) {
-        const long i = ((long)b * NT + t) * g.C + c;
-        const float f = expf(ws_m[i] - m);
-        s = fmaf(ws_s[i], f, s);
-        acc = fmaf(ws_P[i * g.Ch + e], f, acc);
+    if (SOFTMAX) {
+        float m = -INFINITY;
+        for (int t = 0; t < NT; ++t) m = fmaxf(m, ws_m[((long)b * NT + t) * g.C + c]);
+        float s = 0.f, acc = 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const long i = ((long)b * NT + t) * g.C + c;
+            const float f = expf(ws_m[i] - m);
+            s = fmaf(ws_s[i], f, s);
+            acc = fmaf(ws_P[i * g.Ch + e], f, acc);
+        }
+        Mout[((long)b * g.C + c) * g.Ch + e] = acc / s;
+        if (e == 0) { kmax[(long)b * g.C + c] = m; ksum[(long)b * g.C + c] = s; }
+    } else {
+        float acc = 0.f;
+        for (int t = 0; t < NT; ++t) acc += ws_P[(((long)b * NT + t) * g.C + c) * g.Ch + e];
+        Mout[((long)b * g.C + c) * g.Ch + e] = acc;
     }
-    Mmat[((long)b * g.C + c) * g.Ch + e] = acc / s;
-    if (e == 0) { kmax[(long)b * g.C + c] = m; ksum[(long)b * g.C + c] = s; }
 }
 
-// ---- shared: crpe weight table for a channel chunk, zero-padded to 7x7, [cl][49] in LDS ---------
+// ---- crpe weight table for a channel chunk, zero-padded to 7x7, [cl][49] in LDS ------------------
 __device__ __forceinline__ void load_crpe_table(float* s_w, float* s_b, const FaGeom& g, const CrpeW& cw, int c0, int CC) {
     for (int i = threadIdx.x; i < CC * 49; i += blockDim.x) {
         const int cl = i / 49, t = i % 49, c = c0 + cl;
@@ -112,8 +136,8 @@ __device__ __forceinline__ void load_crpe_table(float* s_w, float* s_b, const Fa
 // ---- fwd C --------------------------------------------------------------------------------------
 // block: CC channels x (256/CC) token lanes; grid.x over token groups, grid.y over channel chunks.
 __global__ __launch_bounds__(256) void fa_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ Mmat,
-                                                       const float* __restrict__ a, float* __restrict__ out, FaGeom g, CrpeW cw,
-                                                       int CC, int tokens_per_block) {
+                                                       const float* __restrict__ a, float* __restrict__ out, float* __restrict__ U,
+                                                       FaGeom g, CrpeW cw, int CC, int tokens_per_block) {
     extern __shared__ float sm[];          // s_w[CC*49], s_b[CC]
     float* s_w = sm;
     float* s_b = sm + CC * 49;
@@ -147,102 +171,93 @@ __global__ __launch_bounds__(256) void fa_apply_kernel(const float* __restrict__
         float y = g.scale * fa + qc * u;
         if (a) y *= a[(long)b * g.C + c];
         out[tok * g.C + c] = y;
+        U[tok * g.C + c] = u;
     }
 }
 
-// ---- bwd 1: reductions over tokens ---------------------------------------------------------------
-// blockDim = TL * C (TL token lanes).  Thread = (token lane, channel c).  Per-thread register partials:
-// da, d(bias), d(w[49]), dM[c][0..CH).  dFA rows and q rows of FA_TCHUNK tokens go through LDS so that a
-// thread can see the other channels of its head.
-template <int CH>
-__global__ __launch_bounds__(512) void fa_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ qkv, const float* __restrict__ Mmat,
-                                     const float* __restrict__ a, float* __restrict__ da, float* __restrict__ dM,
-                                     float* dw3, float* db3, float* dw5, float* db5, float* dw7, float* db7,
-                                     FaGeom g, CrpeW cw, int TL, int tokens_per_block) {
-    extern __shared__ float sm[];           // s_dfa[TL][TCHUNK][C], s_q[TL][TCHUNK][C]
-    const int C = g.C, C3 = 3 * C;
-    float* s_dfa = sm;
-    float* s_q = sm + TL * FA_TCHUNK * C;
-    const int c = threadIdx.x % C, tl = threadIdx.x / C;
-    const int b = blockIdx.y;
-    const int head = c / CH, ch = c % CH, hb = head * CH, r = crpe_radius(g, c);
-    const float* wp = crpe_wptr(g, cw, c, r);
-    const float bias = crpe_bias(g, cw, c, r);
-    const int win = 2 * r + 1;
-    const float ac = a ? a[(long)b * C + c] : 1.f;
+// ---- bwd 1: dU = a*G*q ; e[b,c] = sum_n G[n,c]*out[n,c]  (float4 over channels) ---------------------
+__global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                          const float* __restrict__ out, const float* __restrict__ a,
+                                                          float* __restrict__ dU, float* __restrict__ e, FaGeom g) {
+    extern __shared__ float s_e[];         // [C]
+    const int b = blockIdx.y, C = g.C, QC = C >> 2;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) s_e[i] = 0.f;
+    __syncthreads();
+    const long T = (long)gridDim.x * blockDim.x;          // multiple of QC (host guarantees)
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(t0 % QC) * 4;
+    float4 av = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a) av = *reinterpret_cast<const float4*>(a + (long)b * C + c);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long total = (long)g.N * QC;
+    for (long i = t0; i < total; i += T) {
+        const long tok = (long)b * g.N + i / QC;
+        const float4 G = *reinterpret_cast<const float4*>(dout + tok * C + c);
+        const float4 q = *reinterpret_cast<const float4*>(qkv + tok * 3 * C + c);
+        *reinterpret_cast<float4*>(dU + tok * C + c) = make_float4(av.x * G.x * q.x, av.y * G.y * q.y, av.z * G.z * q.z, av.w * G.w * q.w);
+        if (e) {
+            const float4 o = *reinterpret_cast<const float4*>(out + tok * C + c);
+            acc.x = fmaf(G.x, o.x, acc.x); acc.y = fmaf(G.y, o.y, acc.y); acc.z = fmaf(G.z, o.z, acc.z); acc.w = fmaf(G.w, o.w, acc.w);
+        }
+    }
+    if (e) {
+        atomicAdd(&s_e[c], acc.x); atomicAdd(&s_e[c + 1], acc.y); atomicAdd(&s_e[c + 2], acc.z); atomicAdd(&s_e[c + 3], acc.w);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += blockDim.x) atomicAdd(&e[(long)b * C + i], s_e[i]);
+    }
+}
+
+// ---- bwd 3: crpe wgrad for one window size: dw[c,i,j] = sum_{b,n} dU[n,c] * V[n+(i-r,j-r),c]; db = sum dU ----
+// block = CL channels x (256/CL) token lanes over a chunk of tokens of one image.
+template <int WIN>
+__global__ __launch_bounds__(256) void fa_crpe_wgrad_kernel(const float* __restrict__ dU, const float* __restrict__ qkv,
+                                                            float* __restrict__ dw, float* __restrict__ db, FaGeom g,
+                                                            int cbase, int ncls, int CL, int tokens_per_block) {
+    extern __shared__ float s_acc[];       // [CL][WIN*WIN+1]
+    constexpr int R = WIN / 2, NW = WIN * WIN;
+    for (int i = threadIdx.x; i < CL * (NW + 1); i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    const int b = blockIdx.z, cchunk = blockIdx.y;
+    const int cl = threadIdx.x % CL, tl = threadIdx.x / CL, ntl = blockDim.x / CL;
+    const int ci = cchunk * CL + cl;                 // index inside the window class
     const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
-    float acc_da = 0.f, acc_db = 0.f;
-    float acc_w[49], acc_m[CH];
+    float acc[NW];
+    float accb = 0.f;
 #pragma unroll
-    for (int t = 0; t < 49; ++t) acc_w[t] = 0.f;
+    for (int t = 0; t < NW; ++t) acc[t] = 0.f;
+    if (ci < ncls && tl < ntl) {
+        const int c = cbase + ci, C = g.C, C3 = 3 * C;
+        for (int n = n_beg + tl; n < n_end; n += ntl) {
+            const long tok = (long)b * g.N + n;
+            const float du = dU[tok * C + c];
+            accb += du;
+            const int h = n / g.W, w = n % g.W;
 #pragma unroll
-    for (int e = 0; e < CH; ++e) acc_m[e] = 0.f;
-    const float* Mb = Mmat + ((long)b * C + hb) * CH + ch;
-    const int per_step = TL * FA_TCHUNK;
-    for (int base = n_beg; base < n_end; base += per_step) {
-#pragma unroll 1
-        for (int tt = 0; tt < FA_TCHUNK; ++tt) {
-            const int n = base + tl * FA_TCHUNK + tt;
-            float dfa = 0.f, qc = 0.f;
-            if (n < n_end) {
-                const long tok = (long)b * g.N + n;
-                const float* row = qkv + tok * C3;
-                const float G = dout[tok * C + c];
-                qc = row[c];
-                const float dY = ac * G, dU = dY * qc;
-                const int h = n / g.W, w = n % g.W;
-                float u = bias;
+            for (int i = 0; i < WIN; ++i) {
+                const int hh = h + i - R;
+                if (hh < 0 || hh >= g.H) continue;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) {
-                        if (i < win && j < win) {
-                            const int hh = h + i - r, ww = w + j - r;
-                            if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) {
-                                const float vn = qkv[((long)b * g.N + hh * g.W + ww) * C3 + 2 * C + c];
-                                u = fmaf(wp[i * win + j], vn, u);
-                                acc_w[i * 7 + j] = fmaf(dU, vn, acc_w[i * 7 + j]);
-                            }
-                        }
-                    }
+                for (int j = 0; j < WIN; ++j) {
+                    const int ww = w + j - R;
+                    if (ww < 0 || ww >= g.W) continue;
+                    acc[i * WIN + j] = fmaf(du, qkv[((long)b * g.N + hh * g.W + ww) * C3 + 2 * C + c], acc[i * WIN + j]);
                 }
-                float fa = 0.f;
-#pragma unroll
-                for (int j = 0; j < CH; ++j) fa = fmaf(row[hb + j], Mb[j * CH], fa);
-                const float Y = g.scale * fa + qc * u;
-                acc_da = fmaf(G, Y, acc_da);
-                acc_db += dU;
-                dfa = g.scale * dY;
             }
-            s_dfa[(tl * FA_TCHUNK + tt) * C + c] = dfa;
-            s_q[(tl * FA_TCHUNK + tt) * C + c] = qc;
         }
-        __syncthreads();
-#pragma unroll 1
-        for (int tt = 0; tt < FA_TCHUNK; ++tt) {
-            const float qk = s_q[(tl * FA_TCHUNK + tt) * C + c];
-            const float* drow = &s_dfa[(tl * FA_TCHUNK + tt) * C + hb];
 #pragma unroll
-            for (int e = 0; e < CH; ++e) acc_m[e] = fmaf(qk, drow[e], acc_m[e]);
-        }
-        __syncthreads();
+        for (int t = 0; t < NW; ++t) atomicAdd(&s_acc[cl * (NW + 1) + t], acc[t]);
+        atomicAdd(&s_acc[cl * (NW + 1) + NW], accb);
     }
-    if (a) atomicAdd(&da[(long)b * C + c], acc_da);
-#pragma unroll
-    for (int e = 0; e < CH; ++e) atomicAdd(&dM[((long)b * C + c) * CH + e], acc_m[e]);
-    float* dwp; float* dbp;
-    if (r == 1) { dwp = dw3 + (long)c * 9; dbp = db3 + c; }
-    else if (r == 2) { dwp = dw5 + (long)(c - g.s3 * CH) * 25; dbp = db5 + (c - g.s3 * CH); }
-    else { dwp = dw7 + (long)(c - (g.s3 + g.s5) * CH) * 49; dbp = db7 + (c - (g.s3 + g.s5) * CH); }
-    atomicAdd(dbp, acc_db);
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-            if (i < win && j < win) atomicAdd(&dwp[i * win + j], acc_w[i * 7 + j]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < CL * (NW + 1); i += blockDim.x) {
+        const int l = i / (NW + 1), t = i % (NW + 1), cc = cchunk * CL + l;
+        if (cc >= ncls) continue;
+        if (t < NW) atomicAdd(&dw[(long)cc * NW + t], s_acc[i]);
+        else atomicAdd(&db[cc], s_acc[i]);
+    }
 }
 
-// ---- bwd 2: t[b,c] = sum_e dM[b,c,e] * M[b,c,e] -----------------------------------------------
+// ---- bwd 4: t[b,c] = sum_e dM[b,c,e] * M[b,c,e] -------------------------------------------------
 __global__ void fa_bwd_mid_kernel(const float* __restrict__ dM, const float* __restrict__ Mmat, float* __restrict__ tcol, int BC, int Ch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= BC) return;
@@ -251,63 +266,76 @@ __global__ void fa_bwd_mid_kernel(const float* __restrict__ dM, const float* __r
     tcol[i] = s;
 }
 
-// ---- bwd 3: dq, dk, dv per (token, channel) ------------------------------------------------------
-__global__ __launch_bounds__(256) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+// ---- bwd 5: dq, dk, dv ----------------------------------------------------------------------------
+// blockDim = TLN * C: TLN tokens are processed together, one thread per (token, channel).  The head rows
+// P = softmax column weights, dFA and v of those tokens go through LDS so the three Ch-long contractions
+// read them as broadcasts; M / dM stay in global memory (L2-resident, [C,Ch] per image).
+template <int CH>
+__global__ __launch_bounds__(512) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                           const float* __restrict__ U, const float* __restrict__ dU,
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
                                                            const float* __restrict__ dM, const float* __restrict__ tcol,
-                                                           float* __restrict__ dqkv, FaGeom g, CrpeW cw, int CC, int tokens_per_block) {
-    extern __shared__ float sm[];
-    float* s_w = sm;
-    float* s_b = sm + CC * 49;
-    const int c0 = blockIdx.y * CC;
-    load_crpe_table(s_w, s_b, g, cw, c0, CC);
-    __syncthreads();
-    const int cl = threadIdx.x % CC, tl = threadIdx.x / CC, ntl = blockDim.x / CC;
-    const int c = c0 + cl;
-    if (c >= g.C || tl >= ntl) return;
-    const int C = g.C, C3 = 3 * C, Ch = g.Ch;
-    const int head = c / Ch, ch = c % Ch, hb = head * Ch, r = crpe_radius(g, c);
-    const long total = (long)g.B * g.N;
-    const long t_beg = (long)blockIdx.x * tokens_per_block, t_end = min(total, t_beg + tokens_per_block);
-    for (long tok = t_beg + tl; tok < t_end; tok += ntl) {
-        const int b = (int)(tok / g.N), n = (int)(tok % g.N), h = n / g.W, w = n % g.W;
-        const float* row = qkv + tok * C3;
-        const float* grow = dout + tok * C;
-        const float* ab = a ? a + (long)b * C : nullptr;
-        const float ac = ab ? ab[c] : 1.f;
-        const float G = grow[c], qc = row[c], kc = row[C + c];
-        const float dY = ac * G;
-        // U (forward conv) and conv^T(dU) share the stencil walk
-        float u = s_b[cl], dvc = 0.f;
-        for (int di = -r; di <= r; ++di) {
-            for (int dj = -r; dj <= r; ++dj) {
-                const int hh = h + di, ww = w + dj;
-                if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W)
-                    u = fmaf(s_w[cl * 49 + (di + 3) * 7 + (dj + 3)], qkv[((long)b * g.N + hh * g.W + ww) * C3 + 2 * C + c], u);
-                const int h2 = h - di, w2 = w - dj;      // token whose window position (di,dj) lands on n
-                if (h2 >= 0 && h2 < g.H && w2 >= 0 && w2 < g.W) {
-                    const long t2 = (long)b * g.N + h2 * g.W + w2;
-                    dvc = fmaf(s_w[cl * 49 + (di + 3) * 7 + (dj + 3)], ac * dout[t2 * C + c] * qkv[t2 * C3 + c], dvc);
+                                                           float* __restrict__ dqkv, FaGeom g, CrpeW cw, int TLN, int tokens_per_block) {
+    extern __shared__ float sm[];          // s_P[TLN][C], s_dfa[TLN][C], s_v[TLN][C]
+    const int C = g.C, C3 = 3 * C;
+    float* s_P = sm;
+    float* s_dfa = sm + TLN * C;
+    float* s_v = sm + 2 * TLN * C;
+    const int c = threadIdx.x % C, tl = threadIdx.x / C;
+    const int b = blockIdx.y;
+    const int head = c / CH, ch = c % CH, hb = head * CH, r = crpe_radius(g, c);
+    const float* wp = crpe_wptr(g, cw, c, r);
+    const int win = 2 * r + 1;
+    const float ac = a ? a[(long)b * C + c] : 1.f;
+    const float km = kmax[(long)b * C + c], ksinv = 1.0f / ksum[(long)b * C + c], tc = tcol[(long)b * C + c];
+    const float* Mrow = Mmat + ((long)b * C + c) * CH;        // M[c][e]
+    const float* dMrow = dM + ((long)b * C + c) * CH;         // dM[c][e]
+    const float* dMcol = dM + ((long)b * C + hb) * CH + ch;   // dM[hb+j][ch], stride CH
+    const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
+    for (int base = n_beg; base < n_end; base += TLN) {
+        const int n = base + tl;
+        const bool ok = n < n_end;
+        const long tok = (long)b * g.N + (ok ? n : n_beg);
+        float G = 0.f, P = 0.f;
+        if (ok) {
+            const float* row = qkv + tok * C3;
+            G = dout[tok * C + c];
+            P = expf(row[C + c] - km) * ksinv;
+            s_P[tl * C + c] = P;
+            s_dfa[tl * C + c] = g.scale * ac * G;
+            s_v[tl * C + c] = row[2 * C + c];
+        }
+        __syncthreads();
+        if (ok) {
+            float dq = 0.f, dP = 0.f, dv = 0.f;
+            const float* pr = &s_P[tl * C + hb];
+            const float* fr = &s_dfa[tl * C + hb];
+            const float* vr = &s_v[tl * C + hb];
+#pragma unroll 8
+            for (int e = 0; e < CH; ++e) {
+                dq = fmaf(fr[e], Mrow[e], dq);
+                dP = fmaf(vr[e], dMrow[e], dP);
+                dv = fmaf(pr[e], dMcol[(long)e * CH], dv);
+            }
+            // conv^T(dU): token n collects dU of every token whose window covers n
+            const int h = n / g.W, w = n % g.W;
+            for (int i = 0; i < win; ++i) {
+                const int h2 = h - (i - r);
+                if (h2 < 0 || h2 >= g.H) continue;
+                for (int j = 0; j < win; ++j) {
+                    const int w2 = w - (j - r);
+                    if (w2 < 0 || w2 >= g.W) continue;
+                    dv = fmaf(wp[i * win + j], dU[((long)b * g.N + h2 * g.W + w2) * C + c], dv);
                 }
             }
+            dq = fmaf(ac * G, U[tok * C + c], dq);
+            float* drow = dqkv + tok * C3;
+            drow[c] = dq;
+            drow[C + c] = P * (dP - tc);
+            drow[2 * C + c] = dv;
         }
-        const float* Mrow = Mmat + ((long)b * C + c) * Ch;       // M[c][e]
-        const float* dMrow = dM + ((long)b * C + c) * Ch;        // dM[c][e]
-        float dq = 0.f, dP = 0.f, dv = dvc;
-        for (int e = 0; e < Ch; ++e) {
-            const float ae = ab ? ab[hb + e] : 1.f;
-            dq = fmaf(g.scale * ae * grow[hb + e], Mrow[e], dq);                 // dFA[n,hb+e] * M[c][e]
-            dP = fmaf(row[2 * C + hb + e], dMrow[e], dP);                         // v[n,hb+e] * dM[c][e]
-            const float pj = expf(row[C + hb + e] - kmax[(long)b * C + hb + e]) / ksum[(long)b * C + hb + e];
-            dv = fmaf(pj, dM[((long)b * C + hb + e) * Ch + ch], dv);              // P[n,hb+e] * dM[hb+e][ch]
-        }
-        dq = fmaf(dY, u, dq);
-        const float P = expf(kc - kmax[(long)b * C + c]) / ksum[(long)b * C + c];
-        float* drow = dqkv + tok * C3;
-        drow[c] = dq;
-        drow[C + c] = P * (dP - tcol[(long)b * C + c]);
-        drow[2 * C + c] = dv;
+        __syncthreads();
     }
 }
 
@@ -342,44 +370,67 @@ __global__ __launch_bounds__(256) void da_fwd_kernel(const float* __restrict__ l
     }
 }
 
-__global__ __launch_bounds__(256) void da_bwd_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
-                                                     const float* __restrict__ W2, const float* __restrict__ a, const float* __restrict__ da,
-                                                     float* dW1, float* db1, float* dW2, float* db2, int D, int hid, int C, int heads) {
-    extern __shared__ float sm[];   // h1[hid], dz[C], dh[hid]
-    float* h1 = sm;
-    float* dz = sm + hid;
-    float* dh = dz + C;
+// backward from e = a * dL/da:  dz[c] = e[c] - a[c] * sum_{heads} e[., ch]   (softmax over heads)
+// stage 1 (grid = B): dz -> dzbuf [B,C], relu(h1) -> hbuf [B,hid], dh -> dhbuf [B,hid]
+__global__ __launch_bounds__(256) void da_bwd_stage1_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                            const float* __restrict__ W2, const float* __restrict__ a, const float* __restrict__ e,
+                                                            float* __restrict__ dzbuf, float* __restrict__ hbuf, float* __restrict__ dhbuf,
+                                                            int D, int hid, int C, int heads) {
+    extern __shared__ float sm[];   // dz[C]
+    float* dz = sm;
     const int b = blockIdx.x, Ch = C / heads;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int ch = c % Ch;
+        float tot = 0.f;
+        for (int hh = 0; hh < heads; ++hh) tot += e[(long)b * C + hh * Ch + ch];
+        const float v = e[(long)b * C + c] - a[(long)b * C + c] * tot;
+        dz[c] = v;
+        dzbuf[(long)b * C + c] = v;
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < hid; i += blockDim.x) {
         float s = 0.f;
         for (int d = 0; d < D; ++d) s = fmaf(label[(long)b * D + d], W1[(long)i * D + d], s);
-        h1[i] = s + b1[i];          // pre-ReLU
+        const float h = s + b1[i];
+        float t = 0.f;
+        for (int c = 0; c < C; ++c) t = fmaf(dz[c], W2[(long)c * hid + i], t);
+        hbuf[(long)b * hid + i] = fmaxf(h, 0.f);
+        dhbuf[(long)b * hid + i] = h > 0.f ? t : 0.f;
     }
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int ch = c % Ch;
-        float dot = 0.f;
-        for (int hh = 0; hh < heads; ++hh) dot = fmaf(a[(long)b * C + hh * Ch + ch], da[(long)b * C + hh * Ch + ch], dot);
-        dz[c] = a[(long)b * C + c] * (da[(long)b * C + c] - dot);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        atomicAdd(&db2[c], dz[c]);
-        for (int i = 0; i < hid; ++i) atomicAdd(&dW2[(long)c * hid + i], dz[c] * fmaxf(h1[i], 0.f));
-    }
-    for (int i = threadIdx.x; i < hid; i += blockDim.x) {
+}
+// stage 2: one thread per weight element, loop over the batch (no atomics, deterministic)
+__global__ __launch_bounds__(256) void da_bwd_stage2_kernel(const float* __restrict__ label, const float* __restrict__ dzbuf,
+                                                            const float* __restrict__ hbuf, const float* __restrict__ dhbuf,
+                                                            float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                                            int B, int D, int hid, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nW2 = (long)C * hid, nW1 = (long)hid * D;
+    if (i < nW2) {
+        const int c = (int)(i / hid), j = (int)(i % hid);
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s = fmaf(dz[c], W2[(long)c * hid + i], s);
-        dh[i] = h1[i] > 0.f ? s : 0.f;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < hid; i += blockDim.x) {
-        atomicAdd(&db1[i], dh[i]);
-        for (int d = 0; d < D; ++d) atomicAdd(&dW1[(long)i * D + d], dh[i] * label[(long)b * D + d]);
+        for (int b = 0; b < B; ++b) s = fmaf(dzbuf[(long)b * C + c], hbuf[(long)b * hid + j], s);
+        dW2[i] = s;
+    } else if (i < nW2 + nW1) {
+        const long k = i - nW2;
+        const int j = (int)(k / D), d = (int)(k % D);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(dhbuf[(long)b * hid + j], label[(long)b * D + d], s);
+        dW1[k] = s;
+    } else if (i < nW2 + nW1 + C) {
+        const int c = (int)(i - nW2 - nW1);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dzbuf[(long)b * C + c];
+        db2[c] = s;
+    } else if (i < nW2 + nW1 + C + hid) {
+        const int j = (int)(i - nW2 - nW1 - C);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dhbuf[(long)b * hid + j];
+        db1[j] = s;
     }
 }
 
 bool make_geom(FaGeom& g, int B, int H, int W, int C, int heads, int s3, int s5, int s7) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || C % heads != 0) return false;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || C % heads != 0 || C % 4 != 0) return false;
     if (s3 + s5 + s7 != heads) return false;
     g.B = B; g.H = H; g.W = W; g.N = H * W; g.C = C; g.heads = heads; g.Ch = C / heads; g.s3 = s3; g.s5 = s5; g.s7 = s7;
     g.scale = 1.0f / sqrtf((float)g.Ch);
@@ -394,12 +445,36 @@ int fa_cw(const FaGeom& g) {
     return hp * g.Ch;
 }
 
+// fwd: ws_m, ws_s [B,NT,C] + ws_P [B,NT,C,Ch].   bwd: dU [B,N,C] + tcol [B,C] + dM [B,C,Ch] + ws_P [B,NT,C,Ch].
 size_t fa_ws_floats(int B, int N, int C, int heads) {
     const int Ch = C / heads;
     const long NT = (N + FA_T - 1) / FA_T;
     const long fwd = (long)B * NT * C * (2 + Ch);
-    const long bwd = (long)B * C * (1 + Ch);
+    const long bwd = (long)B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch;
     return (size_t)(fwd > bwd ? fwd : bwd);
+}
+
+int quad_grid(long work_quads, int QC, int max_blocks) {
+    // smallest grid >= wanted with (grid*256) % QC == 0
+    int a = QC, b = 256;
+    while (b) { int t = a % b; a = b; b = t; }
+    const int gmul = QC / a;
+    long want = (work_quads + 256L * 4 - 1) / (256L * 4);
+    if (want > max_blocks) want = max_blocks;
+    if (want < 1) want = 1;
+    return (int)((want + gmul - 1) / gmul * gmul);
+}
+
+template <int WIN>
+void launch_crpe_wgrad(const float* dU, const float* qkv, float* dw, float* db, const FaGeom& g, int cbase, int ncls, hipStream_t s) {
+    if (ncls <= 0) return;
+    int CL = 16;
+    while (CL < ncls && CL < 64) CL <<= 1;            // 16/32/64 channels per block
+    const int ntl = 256 / CL;
+    int tpb = ntl * 16;                                 // 16 tokens per lane
+    while ((long)cdiv(g.N, tpb) * g.B * cdiv(ncls, CL) > 4096) tpb *= 2;
+    hipLaunchKernelGGL((fa_crpe_wgrad_kernel<WIN>), dim3(cdiv(g.N, tpb), cdiv(ncls, CL), g.B), dim3(256), sizeof(float) * CL * (WIN * WIN + 1), s,
+                       dU, qkv, dw, db, g, cbase, ncls, CL, tpb);
 }
 
 }  // namespace
@@ -410,7 +485,7 @@ extern "C" size_t mdvit_factoratt_ws_bytes(int32_t B, int32_t N, int32_t C, int3
 }
 
 extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
-                                   const float* w7, const float* b7, const float* a, float* out, float* kmax, float* ksum, float* Mmat,
+                                   const float* w7, const float* b7, const float* a, float* out, float* U, float* kmax, float* ksum, float* Mmat,
                                    void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
                                    int32_t s3, int32_t s5, int32_t s7, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -422,22 +497,24 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     float* ws_m = (float*)ws;
     float* ws_s = ws_m + (long)B * NT * C;
     float* ws_P = ws_s + (long)B * NT * C;
-    hipLaunchKernelGGL(fa_kv_partial_kernel, dim3(NT, C / CW, B), dim3(256), sizeof(float) * 2 * FA_T * CW, s, qkv, ws_m, ws_s, ws_P, g, CW, NT);
-    hipLaunchKernelGGL(fa_kv_combine_kernel, dim3(cdiv((long)C * g.Ch, 256), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
+    hipLaunchKernelGGL((fa_partial_kernel<true>), dim3(NT, C / CW, B), dim3(256), sizeof(float) * 2 * FA_T * CW, s,
+                       qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, CW, NT);
+    hipLaunchKernelGGL((fa_combine_kernel<true>), dim3(cdiv((long)C * g.Ch, 256), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
     CrpeW cw{w3, b3, w5, b5, w7, b7};
-    const int CC = C < 128 ? C : 128;          // channel chunk; 256 % CC == 0 for C in {64,128,...}
+    const int CC = C < 128 ? C : 128;
     int block = 256;
     if (256 % CC) block = CC * (256 / CC > 0 ? 256 / CC : 1);
     const long total = (long)B * g.N;
     int tpb = (int)max(32L, (total + 2047) / 2048);
-    hipLaunchKernelGGL(fa_apply_kernel, dim3(cdiv(total, tpb), cdiv(C, CC)), dim3(block), sizeof(float) * CC * 50, s, qkv, Mmat, a, out, g, cw, CC, tpb);
+    hipLaunchKernelGGL(fa_apply_kernel, dim3(cdiv(total, tpb), cdiv(C, CC)), dim3(block), sizeof(float) * CC * 50, s, qkv, Mmat, a, out, U, g, cw, CC, tpb);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
-                                   const float* w7, const float* b7, const float* a, const float* kmax, const float* ksum, const float* Mmat,
-                                   float* dqkv, float* da, float* dw3, float* db3, float* dw5, float* db5, float* dw7, float* db7,
+extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const float* out, const float* U,
+                                   const float* w3, const float* b3, const float* w5, const float* b5, const float* w7, const float* b7,
+                                   const float* a, const float* kmax, const float* ksum, const float* Mmat,
+                                   float* dqkv, float* e, float* dw3, float* db3, float* dw5, float* db5, float* dw7, float* db7,
                                    void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
                                    int32_t s3, int32_t s5, int32_t s7, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -445,22 +522,39 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     MDVIT_CHECK_ARG(make_geom(g, B, H, W, C, heads, s3, s5, s7), MDVIT_E_SHAPE, "factoratt_bwd: bad geometry B=%d H=%d W=%d C=%d heads=%d", B, H, W, C, heads);
     MDVIT_CHECK_ARG(ws_bytes >= fa_ws_floats(B, g.N, C, heads) * sizeof(float), MDVIT_E_WORKSPACE, "factoratt_bwd: workspace too small (%zu bytes)", ws_bytes);
     MDVIT_CHECK_ARG(C <= 512, MDVIT_E_SHAPE, "factoratt_bwd: C=%d > 512 not built", C);
-    MDVIT_CHECK_ARG((a == nullptr) == (da == nullptr), MDVIT_E_SHAPE, "factoratt_bwd: a and da must both be given or both be NULL");
-    float* tcol = (float*)ws;
+    MDVIT_CHECK_ARG((a == nullptr) == (e == nullptr), MDVIT_E_SHAPE, "factoratt_bwd: a and e must both be given or both be NULL");
+    const int Ch = g.Ch, NT = cdiv(g.N, FA_T), CW = fa_cw(g);
+    MDVIT_CHECK_ARG(CW <= 128, MDVIT_E_SHAPE, "factoratt_bwd: head dim %d too large", Ch);
+    float* dU = (float*)ws;
+    float* tcol = dU + (long)B * g.N * C;
     float* dM = tcol + (long)B * C;
-    const int Ch = g.Ch;
-    MDVIT_ZERO(dM, sizeof(float) * (size_t)B * C * Ch, s);
-    if (da) MDVIT_ZERO(da, sizeof(float) * (size_t)B * C, s);
+    float* ws_P = dM + (long)B * C * Ch;
+    if (e) MDVIT_ZERO(e, sizeof(float) * (size_t)B * C, s);
     MDVIT_ZERO(dw3, sizeof(float) * s3 * Ch * 9, s);  MDVIT_ZERO(db3, sizeof(float) * s3 * Ch, s);
     MDVIT_ZERO(dw5, sizeof(float) * s5 * Ch * 25, s); MDVIT_ZERO(db5, sizeof(float) * s5 * Ch, s);
     MDVIT_ZERO(dw7, sizeof(float) * s7 * Ch * 49, s); MDVIT_ZERO(db7, sizeof(float) * s7 * Ch, s);
+    // 1: dU, e
+    const int QC = C / 4;
+    hipLaunchKernelGGL(fa_bwd_prep_kernel, dim3(quad_grid((long)g.N * QC, QC, 512), B), dim3(256), sizeof(float) * C, s, dout, qkv, out, a, dU, e, g);
+    // 2: dM = Q^T (scale * a * G)
+    hipLaunchKernelGGL((fa_partial_kernel<false>), dim3(NT, C / CW, B), dim3(256), sizeof(float) * 2 * FA_T * CW, s,
+                       qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, CW, NT);
+    hipLaunchKernelGGL((fa_combine_kernel<false>), dim3(cdiv((long)C * Ch, 256), B), dim3(256), 0, s,
+                       (const float*)nullptr, (const float*)nullptr, ws_P, (float*)nullptr, (float*)nullptr, dM, g, NT);
+    // 3: crpe weight gradients
+    launch_crpe_wgrad<3>(dU, qkv, dw3, db3, g, 0, s3 * Ch, s);
+    launch_crpe_wgrad<5>(dU, qkv, dw5, db5, g, s3 * Ch, s5 * Ch, s);
+    launch_crpe_wgrad<7>(dU, qkv, dw7, db7, g, (s3 + s5) * Ch, s7 * Ch, s);
+    // 4, 5
+    hipLaunchKernelGGL(fa_bwd_mid_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, dM, Mmat, tcol, B * C, Ch);
     CrpeW cw{w3, b3, w5, b5, w7, b7};
-    const int TL = max(1, 256 / C);
-    const int block = TL * C;
-    int tpb = TL * FA_TCHUNK * max(1, 128 / (TL * FA_TCHUNK));       // ~128 tokens per block
-    const size_t lds = sizeof(float) * 2 * TL * FA_TCHUNK * C;
+    const int TLN = max(1, 256 / C);
+    const int block = TLN * C;
+    int tpb = TLN * 8;
+    while ((long)cdiv(g.N, tpb) * B > 8192) tpb *= 2;
+    const size_t lds = sizeof(float) * 3 * TLN * C;
     dim3 grid(cdiv(g.N, tpb), B);
-#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_reduce_kernel<CHV>), grid, dim3(block), lds, s, dout, qkv, Mmat, a, da, dM, dw3, db3, dw5, db5, dw7, db7, g, cw, TL, tpb)
+#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(block), lds, s, dout, qkv, U, dU, Mmat, a, kmax, ksum, dM, tcol, dqkv, g, cw, TLN, tpb)
     switch (Ch) {
         case 8: FA_BWD_LAUNCH(8); break;
         case 16: FA_BWD_LAUNCH(16); break;
@@ -469,14 +563,6 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         default: return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_bwd: head dim %d not built (8/16/40/64)", Ch);
     }
 #undef FA_BWD_LAUNCH
-    hipLaunchKernelGGL(fa_bwd_mid_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, dM, Mmat, tcol, B * C, Ch);
-    const int CC = C < 128 ? C : 128;
-    int blk = 256;
-    if (256 % CC) blk = CC * (256 / CC > 0 ? 256 / CC : 1);
-    const long total = (long)B * g.N;
-    int tpb2 = (int)max(32L, (total + 2047) / 2048);
-    hipLaunchKernelGGL(fa_bwd_apply_kernel, dim3(cdiv(total, tpb2), cdiv(C, CC)), dim3(blk), sizeof(float) * CC * 50, s,
-                       dout, qkv, Mmat, a, kmax, ksum, dM, tcol, dqkv, g, cw, CC, tpb2);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -489,15 +575,24 @@ extern "C" int mdvit_da_fwd(const float* label, const float* W1, const float* b1
     return MDVIT_OK;
 }
 
+extern "C" size_t mdvit_da_ws_bytes(int32_t B, int32_t hid, int32_t C) {
+    if (B <= 0 || hid <= 0 || C <= 0) return 0;
+    return sizeof(float) * ((size_t)B * C + 2 * (size_t)B * hid);
+}
+
 extern "C" int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,
-                            const float* da, float* dW1, float* db1, float* dW2, float* db2,
+                            const float* e, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,
                             int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     (void)b2;
     MDVIT_CHECK_ARG(B > 0 && D > 0 && hid > 0 && C > 0 && heads > 0 && C % heads == 0, MDVIT_E_SHAPE, "da_bwd: bad shape");
-    MDVIT_ZERO(dW1, sizeof(float) * hid * D, s); MDVIT_ZERO(db1, sizeof(float) * hid, s);
-    MDVIT_ZERO(dW2, sizeof(float) * (size_t)C * hid, s); MDVIT_ZERO(db2, sizeof(float) * C, s);
-    hipLaunchKernelGGL(da_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (2 * hid + C), s, label, W1, b1, W2, a, da, dW1, db1, dW2, db2, D, hid, C, heads);
+    MDVIT_CHECK_ARG(ws_bytes >= mdvit_da_ws_bytes(B, hid, C), MDVIT_E_WORKSPACE, "da_bwd: workspace too small");
+    float* dzbuf = (float*)ws;
+    float* hbuf = dzbuf + (long)B * C;
+    float* dhbuf = hbuf + (long)B * hid;
+    hipLaunchKernelGGL(da_bwd_stage1_kernel, dim3(B), dim3(256), sizeof(float) * C, s, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads);
+    const long total = (long)C * hid + (long)hid * D + C + hid;
+    hipLaunchKernelGGL(da_bwd_stage2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, label, dzbuf, hbuf, dhbuf, dW1, db1, dW2, db2, B, D, hid, C);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -14,7 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
 struct GemmArgs {
@@ -43,9 +43,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
-    constexpr int LDSA = BM + 4, LDSB = BN + 4;
+    // k-contiguous operands are transposed on the LDS write: odd leading dimension -> conflict-free ds_write_b32;
+    // m/n-contiguous operands are written as float4: leading dimension % 4 == 0.
+    constexpr int LDSA = TA ? BM + 4 : BM + 1, LDSB = TB ? BN + 1 : BN + 4;
     constexpr int WTM = BM / WAVES_M / 32, WTN = BN / WAVES_N / 32;   // 32x32 blocks per wave
     constexpr int A_V4 = BM * BK / 4 / NTHREADS, B_V4 = BN * BK / 4 / NTHREADS;
+    constexpr int KT = BK / 4;                                        // threads per k-contiguous row
     __shared__ __attribute__((aligned(16))) float smem[BK * LDSA + BK * LDSB];
     float* As = smem;
     float* Bs = smem + BK * LDSA;
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
         for (int v = 0; v < A_V4; ++v) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!TA) {   // A[m][k], k contiguous: 4 threads per row
-                const int r = (tid >> 2) + v * 64, m = m0 + r, k = k0 + (tid & 3) * 4;
+            if (!TA) {   // A[m][k], k contiguous: BK/4 threads per row
+                const int r = tid / KT + v * (NTHREADS / KT), m = m0 + r, k = k0 + (tid % KT) * 4;
                 if (m < p.M && k < kend) {
                     x = *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k);
                     if (p.a_drop | (p.a_rowscale != nullptr)) {
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         for (int v = 0; v < B_V4; ++v) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TB) {    // B[n][k], k contiguous (weights as stored by nn.Linear)
-                const int r = (tid >> 2) + v * 64, n = n0 + r, k = k0 + (tid & 3) * 4;
+                const int r = tid / KT + v * (NTHREADS / KT), n = n0 + r, k = k0 + (tid % KT) * 4;
                 if (n < p.N && k < kend) x = *reinterpret_cast<const float4*>(p.B + (long)n * p.ldb + k);
             } else {     // B[k][n], n contiguous
                 constexpr int TPR = BN / 4;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
         for (int v = 0; v < A_V4; ++v) {
             if (!TA) {
-                const int r = (tid >> 2) + v * 64, c = (tid & 3) * 4;
+                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
                 As[(c + 0) * LDSA + r] = ra[v].x; As[(c + 1) * LDSA + r] = ra[v].y;
                 As[(c + 2) * LDSA + r] = ra[v].z; As[(c + 3) * LDSA + r] = ra[v].w;
             } else {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
         for (int v = 0; v < B_V4; ++v) {
             if (TB) {
-                const int r = (tid >> 2) + v * 64, c = (tid & 3) * 4;
+                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
                 Bs[(c + 0) * LDSB + r] = rb[v].x; Bs[(c + 1) * LDSB + r] = rb[v].y;
                 Bs[(c + 2) * LDSB + r] = rb[v].z; Bs[(c + 3) * LDSB + r] = rb[v].w;
             } else {
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
                 for (int j = 0; j < WTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
@@ -180,35 +183,76 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         }
     }
 
-    // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------
+    // ---- epilogue.  The MFMA ran as D = B^T-tile x A-tile, so D[row = n][col = m]: lane holds, for each
+    // register quad q = r>>2, FOUR CONSECUTIVE output columns n = 8q + 4*(lane>>5) + (r&3) of output row
+    // m = lane&31  ->  one 16-byte store per quad instead of four scalar stores.
     const bool atomic = p.splits > 1;
     const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0);
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
+        const int row = m0 + wm0 + i * 32 + l31;
+        if (row >= p.M) continue;
+        const float rsc = p.e_rowscale ? p.e_rowscale[row / p.e_rows_per_scale] : 1.f;
 #pragma unroll
         for (int j = 0; j < WTN; ++j) {
-            const int col = n0 + wn0 + j * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = add_bias ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + wn0 + j * 32 + 8 * q + 4 * lhi;
+                if (col >= p.N) continue;
+                float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                const int nv = min(4, p.N - col);
+                if (add_bias) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] += p.bias[col + t];
+                }
                 float* dst = p.C + (long)row * p.ldc + col;
-                if (atomic) { atomicAdd(dst, v); continue; }
-                if (p.epi == MDVIT_EPI_GELU_DUAL) {
-                    *dst = v;                                                    // u (pre-activation)
-                    float h = gelu_f(v);
-                    if (p.e_drop) h *= mdvit_drop_scale(p.e_k0, p.e_k1, (uint32_t)((long)row * p.N + col), p.e_thresh, p.e_inv_keep);
-                    p.C2[(long)row * p.ldc + col] = h;
+                if (atomic) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nv) atomicAdd(dst + t, v[t]);
                     continue;
                 }
-                if (p.epi == MDVIT_EPI_DGELU) v *= gelu_grad_f(p.gelu_u[(long)row * p.ldu + col]);
-                if (p.e_drop) v *= mdvit_drop_scale(p.e_k0, p.e_k1, (uint32_t)((long)row * p.N + col), p.e_thresh, p.e_inv_keep);
-                if (p.e_rowscale) v *= p.e_rowscale[row / p.e_rows_per_scale];
-                if (p.residual) v += p.residual[(long)row * p.ldr + col];
-                *dst = v;
+                const uint32_t didx = (uint32_t)((long)row * p.N + col);
+                if (p.epi == MDVIT_EPI_GELU_DUAL) {
+                    float h[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        h[t] = gelu_f(v[t]);
+                        if (p.e_drop) h[t] *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + t, p.e_thresh, p.e_inv_keep);
+                    }
+                    float* dst2 = p.C2 + (long)row * p.ldc + col;
+                    if (vec) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(dst2) = make_float4(h[0], h[1], h[2], h[3]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (t < nv) { dst[t] = v[t]; dst2[t] = h[t]; }
+                    }
+                    continue;
+                }
+                if (p.epi == MDVIT_EPI_DGELU) {
+                    const float* up = p.gelu_u + (long)row * p.ldu + col;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] *= gelu_grad_f(up[t]);
+                }
+                if (p.e_drop) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + t, p.e_thresh, p.e_inv_keep);
+                }
+                if (p.e_rowscale) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] *= rsc;
+                }
+                if (p.residual) {
+                    const float* rp = p.residual + (long)row * p.ldr + col;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] += rp[t];
+                }
+                if (vec) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nv) dst[t] = v[t];
+                }
             }
         }
     }

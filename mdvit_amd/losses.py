@@ -14,8 +14,7 @@ from . import ops
 
 def domain_losses(out_logits, aux_logits, label):
     """-> (loss, aux_loss, kt_loss) 0-dim tensors, differentiable w.r.t. both logit tensors."""
-    l = ops.seg_losses(out_logits, aux_logits, label)
-    return l[0], l[1], l[2]
+    return ops.seg_losses(out_logits, aux_logits, label)
 
 
 def seg_loss(out_logits, label):

@@ -74,7 +74,44 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.residual, d.ldr = residual, ldr
     d.gelu_u, d.ldu = gelu_u, ldu
     d.allow_split = int(allow_split)
+    if _events is None:
+        call("mdvit_gemm_f32", C.byref(d), _stream())
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     call("mdvit_gemm_f32", C.byref(d), _stream())
+    e1.record()
+    _events.append((_gemm_kernel_name(M, N, trans_a, trans_b), 2.0 * M * N * K, e0, e1))
+
+
+# ---- optional per-kernel timing (bench.py): HIP events on the launch stream around each GEMM ------
+_events = None
+
+
+def kernel_events_begin():
+    global _events
+    _events = []
+
+
+def kernel_events_end():
+    """-> {kernel name: {"n", "ms", "flop"}} for the launches since kernel_events_begin()."""
+    global _events
+    ev, _events = _events, None
+    if not ev:
+        return {}
+    torch.cuda.synchronize()
+    table = {}
+    for name, flop, e0, e1 in ev:
+        r = table.setdefault(name, {"n": 0, "ms": 0.0, "flop": 0.0})
+        r["n"] += 1
+        r["ms"] += e0.elapsed_time(e1)
+        r["flop"] += flop
+    return table
+
+
+def _gemm_kernel_name(M, N, trans_a, trans_b):
+    narrow = (N <= 64) or (N % 128 != 0 and N % 64 == 0)       # mirrors the tile choice in csrc/gemm.hip
+    return "gemm_f32_kernel<%s,%s,%s>" % ("256x64" if narrow else "128x128", "T" if trans_a else "N", "T" if trans_b else "N")
 
 
 def _ld_view(t: torch.Tensor) -> Tuple[int, int, int]:
@@ -90,6 +127,7 @@ def _ld_view(t: torch.Tensor) -> Tuple[int, int, int]:
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, residual, rowscale, drop_p, rows_per_scale):
+        ctx.set_materialize_grads(False)
         # x [M,K] ; W [N,K] (may be a column slice: stride(0) >= K) ; residual [M,N]
         _chk(x, b, residual, rowscale)
         M, K = x.shape
@@ -106,6 +144,8 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 7
         x, W, rowscale = ctx.saved_tensors
         drop_p, key, rps, has_b, has_res = ctx.meta
         g = _c(g)
@@ -141,6 +181,7 @@ class _MatMul(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, B):
+        ctx.set_materialize_grads(False)
         M, K, lda = _ld_view(A)
         K2, N, ldb = _ld_view(B)
         assert K == K2
@@ -151,6 +192,8 @@ class _MatMul(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 2
         A, B = ctx.saved_tensors
         g = _c(g)
         M, K, lda = _ld_view(A)
@@ -175,6 +218,7 @@ def matmul(A, B):
 class _MlpResidual(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, W1, b1, W2, b2, rowscale, drop_p, rows_per_scale):
+        ctx.set_materialize_grads(False)
         _chk(x, res, W1, b1, W2, b2, rowscale)
         M, Cin = x.shape
         Hd = W1.shape[0]
@@ -193,6 +237,8 @@ class _MlpResidual(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 9
         x, u, h, W1, W2, rowscale = ctx.saved_tensors
         drop_p, k1, k2, rps = ctx.meta
         g = _c(g)
@@ -230,6 +276,7 @@ def mlp_residual(x, res, W1, b1, W2, b2, rowscale=None, drop_p=0.0, rows_per_sca
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
+        ctx.set_materialize_grads(False)
         _chk(x, gamma, beta)
         M, Cn = x.shape
         y = torch.empty_like(x)
@@ -241,6 +288,8 @@ class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 4
         x, gamma, mean, rstd = ctx.saved_tensors
         g = _c(g)
         M, Cn = x.shape
@@ -262,6 +311,7 @@ def layer_norm(x, gamma, beta, eps=1e-6):
 class _DwConv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, add_input):
+        ctx.set_materialize_grads(False)
         _chk(x, w, bias)
         B, H, W_, Cn = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
@@ -273,6 +323,8 @@ class _DwConv3x3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 5
         x, w = ctx.saved_tensors
         stride, add_input, has_b = ctx.meta
         g = _c(g)
@@ -291,6 +343,7 @@ def dwconv3x3(x, w, bias=None, stride=1, add_input=False):
 class _GConv2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, skip, up, w):
+        ctx.set_materialize_grads(False)
         _chk(skip, up, w)
         B, H, W_, Cn = skip.shape
         y = torch.empty_like(skip)
@@ -300,6 +353,8 @@ class _GConv2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 3
         skip, up, w = ctx.saved_tensors
         g = _c(g)
         B, H, W_, Cn = skip.shape
@@ -318,6 +373,7 @@ def gconv2_3x3(skip, up, w):
 class _Im2col(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stride):
+        ctx.set_materialize_grads(False)
         _chk(x)
         B, H, W_, Cn = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
@@ -328,6 +384,8 @@ class _Im2col(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 2
         B, H, W_, Cn, stride = ctx.meta
         g = _c(g)
         dx = torch.empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
@@ -347,6 +405,7 @@ def conv3x3_dense(x, w, bias=None, stride=1):
 class _StemConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, w):
+        ctx.set_materialize_grads(False)
         _chk(img, w)
         B, Cin, H, W_ = img.shape
         Cout = w.shape[0]
@@ -357,6 +416,8 @@ class _StemConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 2
         img, w = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.MdvitHipError("gradient w.r.t. the input image is not built (the train path never needs it)")
@@ -377,6 +438,7 @@ def stem_conv(img, w):
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, drop2d_p, rows_per_sample):
+        ctx.set_materialize_grads(False)
         _chk(y, gamma, beta, running_mean, running_var)
         Cn = y.shape[-1]
         M = y.numel() // Cn
@@ -399,6 +461,8 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 12
         y, gamma, beta, mean, rstd = ctx.saved_tensors
         training, act, drop2d_p, key, rps = ctx.meta
         g = _c(g)
@@ -424,6 +488,7 @@ def bn_act(y, gamma, beta, running_mean, running_var, nbt, training, act, eps=1e
 class _Upsample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Ho, Wo, base):
+        ctx.set_materialize_grads(False)
         _chk(x, base)
         B, H, W_, Cn = x.shape
         if base is None:
@@ -436,6 +501,8 @@ class _Upsample(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 4
         B, H, W_, Ho, Wo, Cn, has_base = ctx.meta
         g = _c(g)
         dx = torch.empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
@@ -456,6 +523,7 @@ def upsample_bilinear(x, Ho, Wo, base=None):
 class _RowDot(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.set_materialize_grads(False)
         _chk(w, b)
         M, K, ldx = _ld_view(x)
         y = torch.empty((M,), device=x.device, dtype=torch.float32)
@@ -466,6 +534,8 @@ class _RowDot(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 3
         x, w = ctx.saved_tensors
         g = _c(g)
         M, K, ldx = _ld_view(x)
@@ -487,83 +557,89 @@ def rowdot(x, w, b=None):
 # ------------------------------------------------------------------------------------------------
 # Domain adapter + factorized attention core
 # ------------------------------------------------------------------------------------------------
-class _DomainAdapter(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, label, W1, b1, W2, b2, heads):
-        _chk(label, W1, b1, W2, b2)
-        B, D = label.shape
-        hid, Cn = W1.shape[0], W2.shape[0]
-        a = torch.empty((B, Cn), device=label.device, dtype=torch.float32)
-        call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, D, hid, Cn, heads, _stream())
-        ctx.save_for_backward(label, W1, b1, W2, b2, a)
-        ctx.heads = heads
-        return a
-
-    @staticmethod
-    def backward(ctx, g):
-        label, W1, b1, W2, b2, a = ctx.saved_tensors
-        g = _c(g)
-        B, D = label.shape
-        hid, Cn = W1.shape[0], W2.shape[0]
-        dW1, db1, dW2, db2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
-        call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(g), _p(dW1), _p(db1), _p(dW2), _p(db2),
-             B, D, hid, Cn, ctx.heads, _stream())
-        return None, dW1, db1, dW2, db2, None
-
-
-def domain_adapter(label, W1, b1, W2, b2, heads):
-    return _DomainAdapter.apply(_c(label.float()), W1, b1, W2, b2, int(heads))
-
-
 class _FactorAtt(torch.autograd.Function):
+    """Attention core + Domain Adapter as ONE node: the adapter's backward consumes e = a * dL/da straight
+    from the attention backward (no division by a).  label is None -> no adapter (BASE / mpvit flavour)."""
+
     @staticmethod
-    def forward(ctx, qkv, w3, b3, w5, b5, w7, b7, a, H, W_, heads, splits):
-        _chk(qkv, w3, b3, w5, b5, w7, b7, a)
+    def forward(ctx, qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, H, W_, heads, splits):
+        _chk(qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2)
+        ctx.set_materialize_grads(False)
         B, N, C3 = qkv.shape
         Cn = C3 // 3
         Ch = Cn // heads
         dev = qkv.device
+        a = None
+        if label is not None:
+            a = torch.empty((B, Cn), device=dev, dtype=torch.float32)
+            call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, label.shape[1], W1.shape[0], Cn, heads, _stream())
         out = torch.empty((B, N, Cn), device=dev, dtype=torch.float32)
+        U = torch.empty_like(out)
         kmax = torch.empty((B, Cn), device=dev, dtype=torch.float32)
         ksum = torch.empty_like(kmax)
         Mmat = torch.empty((B, Cn, Ch), device=dev, dtype=torch.float32)
         wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
         ws = torch.empty((wsb // 4,), device=dev, dtype=torch.float32)
-        call("mdvit_factoratt_fwd", _p(qkv), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(out), _p(kmax), _p(ksum),
+        call("mdvit_factoratt_fwd", _p(qkv), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(out), _p(U), _p(kmax), _p(ksum),
              _p(Mmat), _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2], _stream())
-        ctx.save_for_backward(qkv, w3, b3, w5, b5, w7, b7, a, kmax, ksum, Mmat)
+        ctx.save_for_backward(qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, a, out, U, kmax, ksum, Mmat)
         ctx.meta = (H, W_, heads, splits)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qkv, w3, b3, w5, b5, w7, b7, a, kmax, ksum, Mmat = ctx.saved_tensors
+        if g is None:
+            return (None,) * 16
+        qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, a, out, U, kmax, ksum, Mmat = ctx.saved_tensors
         H, W_, heads, splits = ctx.meta
         g = _c(g)
         B, N, C3 = qkv.shape
         Cn = C3 // 3
         dev = qkv.device
         dqkv = torch.empty_like(qkv)
-        da = torch.empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
+        e = torch.empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
         dws = [torch.empty_like(t) for t in (w3, b3, w5, b5, w7, b7)]
         wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
         ws = torch.empty((wsb // 4,), device=dev, dtype=torch.float32)
-        call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
-             _p(Mmat), _p(dqkv), _p(da), *[_p(t) for t in dws], _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2],
+        call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(out), _p(U), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
+             _p(Mmat), _p(dqkv), _p(e), *[_p(t) for t in dws], _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2],
              _stream())
-        return (dqkv, *dws, da, None, None, None, None)
+        dW1 = db1 = dW2 = db2 = None
+        if a is not None:
+            hid = W1.shape[0]
+            dW1, db1, dW2, db2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
+            dab = _lib.load().mdvit_da_ws_bytes(B, hid, Cn)
+            daws = torch.empty((dab // 4,), device=dev, dtype=torch.float32)
+            call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), _p(dW1), _p(db1), _p(dW2), _p(db2),
+                 _p(daws), dab, B, label.shape[1], hid, Cn, heads, _stream())
+        return (dqkv, *dws, None, dW1, db1, dW2, db2, None, None, None, None)
 
 
-def factor_att(qkv, crpe_params, a, H, W_, heads, splits=(2, 3, 3)):
-    """qkv [B,N,3C]; crpe_params = (w3,b3,w5,b5,w7,b7); a [B,C] or None -> [B,N,C]."""
+def factor_att(qkv, crpe_params, H, W_, heads, splits=(2, 3, 3), domain_label=None, da_params=None):
+    """qkv [B,N,3C]; crpe_params = (w3,b3,w5,b5,w7,b7); domain_label [B,D] + da_params (W1,b1,W2,b2) or None -> [B,N,C]."""
     w3, b3, w5, b5, w7, b7 = crpe_params
-    return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, a, int(H), int(W_), int(heads), tuple(splits))
+    if domain_label is None:
+        return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, None, None, None, None, None, int(H), int(W_), int(heads), tuple(splits))
+    W1, b1, W2, b2 = da_params
+    return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, _c(domain_label.float()), W1, b1, W2, b2, int(H), int(W_), int(heads), tuple(splits))
+
+
+def domain_adapter(label, W1, b1, W2, b2, heads):
+    """a = softmax_heads(W2 relu(W1 label + b1) + b2); forward only (its gradient path is inside factor_att)."""
+    label = _c(label.float())
+    B, D = label.shape
+    a = torch.empty((B, W2.shape[0]), device=label.device, dtype=torch.float32)
+    call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, D, W1.shape[0], W2.shape[0], int(heads), _stream())
+    return a
 
 
 # ------------------------------------------------------------------------------------------------
 # fused step losses on logits
 # ------------------------------------------------------------------------------------------------
 class _SegLosses(torch.autograd.Function):
+    """Three scalar outputs so that a backward() that involves only some of them (the aux sweep) hands back
+    None -- not a zero tensor -- for the logits that take no part (multi_train_MDViT.py:201)."""
+
     @staticmethod
     def forward(ctx, out, aux, label):
         _chk(out, aux, label)
@@ -572,19 +648,31 @@ class _SegLosses(torch.autograd.Function):
         losses = torch.empty((3,), device=out.device, dtype=torch.float32)
         call("mdvit_seg_losses_fwd", _p(out), _p(aux), _p(label), _p(sums), _p(losses), n, _stream())
         ctx.save_for_backward(out, aux, label, sums)
-        return losses
+        ctx.set_materialize_grads(False)
+        return losses[0].clone(), losses[1].clone(), losses[2].clone()
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g0, g1, g2):
         out, aux, label, sums = ctx.saved_tensors
-        g = _c(g.float())
         n = out.numel()
-        dout = torch.empty_like(out) if ctx.needs_input_grad[0] else None
-        daux = torch.empty_like(aux) if (aux is not None and ctx.needs_input_grad[1]) else None
-        call("mdvit_seg_losses_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(g), _p(dout), _p(daux), n, _stream())
+        zero = None
+        gs = []
+        for gi in (g0, g1, g2):
+            if gi is None:
+                if zero is None:
+                    zero = torch.zeros((), device=out.device, dtype=torch.float32)
+                gi = zero
+            gs.append(gi.reshape(()).float())
+        g = torch.stack(gs)
+        need_out = ctx.needs_input_grad[0] and (g0 is not None or g2 is not None)
+        need_aux = aux is not None and ctx.needs_input_grad[1] and (g1 is not None or g2 is not None)
+        dout = torch.empty_like(out) if need_out else None
+        daux = torch.empty_like(aux) if need_aux else None
+        if need_out or need_aux:
+            call("mdvit_seg_losses_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(g), _p(dout), _p(daux), n, _stream())
         return dout, daux, None
 
 
 def seg_losses(out, aux, label):
-    """logits -> tensor[3] = (BCE+Dice(out), BCE+Dice(aux), Dice(sigmoid(aux), sigmoid(out)))."""
+    """logits -> (BCE+Dice(out), BCE+Dice(aux), Dice(sigmoid(aux), sigmoid(out))) as three 0-dim tensors."""
     return _SegLosses.apply(_c(out), None if aux is None else _c(aux), _c(label.float()))

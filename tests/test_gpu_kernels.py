@@ -110,7 +110,7 @@ def test_linear_dropout_droppath_statistics_and_backward_mask():
     assert abs(frac - 0.9) < 0.01, f"keep rate {frac}"
     assert (y[~live] == 0).all(), "DropPath-ed samples must be exactly zero"
     exp_scale = (1 / 0.9) * (1 / 0.9)
-    assert torch.allclose(ratio[live][kept], torch.full_like(ratio[live][kept], exp_scale), rtol=1e-4)
+    assert torch.allclose(y.detach()[live][kept], plain[live][kept] * exp_scale, rtol=1e-4, atol=1e-5)
     # backward must use the SAME mask
     g = rnd(M, N, seed=18).to(dev())
     y.backward(g)
@@ -311,29 +311,21 @@ def test_rowdot():
 
 
 @pytest.mark.parametrize("C", [64, 128, 320, 512])
-def test_domain_adapter(C):
+def test_domain_adapter_forward_and_exact_gather(C):
     from mdvit_amd import ops
     B, hid, heads = 5, max(C // 2, 4), 8
     lab = F.one_hot(torch.tensor([0, 3, 1, 2, 3]), 4).float()
     W1, b1, W2, b2 = rnd(hid, 4, seed=120, scale=1.5), rnd(hid, seed=121, scale=0.1), rnd(C, hid, seed=122, scale=3 / hid ** 0.5), rnd(C, seed=123, scale=0.1)
-    g = rnd(B, C, seed=124)
-
-    def ref_fn(W1, b1, W2, b2):
-        z = F.linear(torch.relu(F.linear(lab.double(), W1.double(), b1.double())), W2.double(), b2.double())
-        return torch.softmax(z.view(B, heads, C // heads), dim=1).reshape(B, C)
-
-    ref, gr = grads_of(ref_fn, [W1, b1, W2, b2], g.double())
-    out, go = grads_of(lambda *p: ops.domain_adapter(lab.to(dev()), *p, heads), [t.to(dev()) for t in (W1, b1, W2, b2)], g)
-    check(out, ref, name="a")
-    for n, a, r in zip(("dW1", "db1", "dW2", "db2"), go, gr):
-        check(a, r, name=n)
+    z = F.linear(torch.relu(F.linear(lab.double(), W1.double(), b1.double())), W2.double(), b2.double())
+    ref = torch.softmax(z.view(B, heads, C // heads), dim=1).reshape(B, C)
+    P = [t.to(dev()) for t in (W1, b1, W2, b2)]
+    check(ops.domain_adapter(lab.to(dev()), *P, heads), ref, name="a")
     # domain-id routing is exact: one_hot(d) @ W1^T == the gathered column W1[:, d] (bit-for-bit)
-    with torch.no_grad():
-        for d in range(4):
-            a_onehot = ops.domain_adapter(F.one_hot(torch.tensor([d]), 4).float().to(dev()), *[t.to(dev()) for t in (W1, b1, W2, b2)], heads)
-            W1g = torch.zeros_like(W1); W1g[:, 0] = W1[:, d]
-            a_gather = ops.domain_adapter(torch.tensor([[1.0, 0, 0, 0]], device=dev()), W1g.to(dev()), b1.to(dev()), W2.to(dev()), b2.to(dev()), heads)
-            assert torch.equal(a_onehot, a_gather), f"domain {d}: gather not bit-exact"
+    for d in range(4):
+        a_onehot = ops.domain_adapter(F.one_hot(torch.tensor([d]), 4).float().to(dev()), *P, heads)
+        W1g = torch.zeros_like(W1); W1g[:, 0] = W1[:, d]
+        a_gather = ops.domain_adapter(torch.tensor([[1.0, 0, 0, 0]], device=dev()), W1g.to(dev()), P[1], P[2], P[3], heads)
+        assert torch.equal(a_onehot, a_gather), f"domain {d}: gather not bit-exact"
 
 
 def _attn_ref(qkv, crpe, a, H, W, heads):
@@ -358,26 +350,35 @@ def _attn_ref(qkv, crpe, a, H, W, heads):
 
 @pytest.mark.parametrize("B,H,W,C,use_a", [(2, 16, 16, 64, True), (1, 9, 14, 128, True), (2, 8, 8, 320, True), (2, 4, 4, 512, True), (2, 12, 12, 64, False), (1, 40, 40, 64, True)])
 def test_factor_att_core(B, H, W, C, use_a):
+    """attention core + domain adapter node: forward, dqkv, crpe gradients and the adapter's parameter gradients"""
     from mdvit_amd import ops
-    heads, Ch, N = 8, C // 8, H * W
+    heads, Ch, N, hid = 8, C // 8, H * W, max(C // 2, 4)
     qkv = rnd(B, N, 3 * C, seed=130, scale=1.5)
     crpe = [rnd(2 * Ch, 1, 3, 3, seed=131, scale=0.3), rnd(2 * Ch, seed=132, scale=0.1), rnd(3 * Ch, 1, 5, 5, seed=133, scale=0.2), rnd(3 * Ch, seed=134, scale=0.1),
             rnd(3 * Ch, 1, 7, 7, seed=135, scale=0.15), rnd(3 * Ch, seed=136, scale=0.1)]
-    a = torch.softmax(rnd(B, heads, Ch, seed=137, scale=2.0), dim=1).reshape(B, C) if use_a else None
-    g = rnd(B, N, C, seed=138)
-    ins = [qkv] + crpe + ([a] if use_a else [])
+    da = [rnd(hid, 4, seed=137, scale=1.5), rnd(hid, seed=138, scale=0.1), rnd(C, hid, seed=139, scale=3 / hid ** 0.5), rnd(C, seed=140, scale=0.1)]
+    lab = F.one_hot(torch.tensor([2, 0][:B]), 4).float()
+    g = rnd(B, N, C, seed=141)
+    ins = [qkv] + crpe + (da if use_a else [])
 
     def ref_fn(qkv, *rest):
         cr = [t.double() for t in rest[:6]]
-        return _attn_ref(qkv.double(), cr, rest[6].double() if use_a else None, H, W, heads)
+        a = None
+        if use_a:
+            W1, b1, W2, b2 = [t.double() for t in rest[6:]]
+            z = F.linear(torch.relu(F.linear(lab.double(), W1, b1)), W2, b2)
+            a = torch.softmax(z.view(B, heads, Ch), dim=1).reshape(B, C)
+        return _attn_ref(qkv.double(), cr, a, H, W, heads)
 
     def hip_fn(qkv, *rest):
-        return ops.factor_att(qkv, tuple(rest[:6]), rest[6] if use_a else None, H, W, heads)
+        if use_a:
+            return ops.factor_att(qkv, tuple(rest[:6]), H, W, heads, (2, 3, 3), lab.to(dev()), tuple(rest[6:]))
+        return ops.factor_att(qkv, tuple(rest[:6]), H, W, heads)
 
     ref, gr = grads_of(ref_fn, ins, g.double())
     out, go = grads_of(hip_fn, [t.to(dev()) for t in ins], g)
     check(out, ref, name="y")
-    names = ["dqkv", "dw3", "db3", "dw5", "db5", "dw7", "db7"] + (["da"] if use_a else [])
+    names = ["dqkv", "dw3", "db3", "dw5", "db5", "dw7", "db7"] + (["dW1", "db1", "dW2", "db2"] if use_a else [])
     for n, x, r in zip(names, go, gr):
         check(x, r, tol=3e-4, name=n)
 
@@ -391,9 +392,9 @@ def test_factor_att_softmax_is_shift_invariant_and_stable():
     crpe = [rnd(2 * Ch, 1, 3, 3, seed=141, scale=0.3), rnd(2 * Ch, seed=142), rnd(3 * Ch, 1, 5, 5, seed=143, scale=0.2), rnd(3 * Ch, seed=144),
             rnd(3 * Ch, 1, 7, 7, seed=145, scale=0.1), rnd(3 * Ch, seed=146)]
     crd = tuple(t.to(dev()) for t in crpe)
-    y0 = ops.factor_att(qkv.to(dev()), crd, None, H, W, heads)
+    y0 = ops.factor_att(qkv.to(dev()), crd, H, W, heads)
     q2 = qkv.clone(); q2[:, :, C:2 * C] += 300.0     # exp(300) overflows fp32 without max subtraction
-    y1 = ops.factor_att(q2.to(dev()), crd, None, H, W, heads)
+    y1 = ops.factor_att(q2.to(dev()), crd, H, W, heads)
     assert torch.isfinite(y1).all()
     check(y1, y0, tol=2e-4, name="shift invariance")
 
@@ -409,9 +410,9 @@ def test_seg_losses(golden):
     lab = synth_label(5, 2, 32, 32)
     oh, ah = o.to(dev()).requires_grad_(True), a.to(dev()).requires_grad_(True)
     l = ops.seg_losses(oh, ah, lab.to(dev()))
-    check(l.cpu(), torch.tensor(gd["losses"], dtype=torch.float32), tol=1e-5, name="losses vs golden")
+    check(torch.stack(l).cpu(), torch.tensor(gd["losses"], dtype=torch.float32), tol=1e-5, name="losses vs golden")
     l[1].backward(retain_graph=True)
-    assert oh.grad is None or float(oh.grad.abs().max()) == 0.0
+    assert oh.grad is None, "the aux sweep must not touch the main logits"
     check(ah.grad, torch.from_numpy(gd["d_aux_from_auxloss"]), tol=2e-4, name="d aux (aux sweep)")
     ah.grad = None; oh.grad = None
     (0.5 * l[2] + 0.5 * l[0]).backward()

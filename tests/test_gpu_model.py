@@ -22,9 +22,17 @@ def relerr(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
 
 
-def check(a, b, tol=TOL, name=""):
+def check(a, b, tol=TOL, name="", floor=0.0):
     e = relerr(a, b)
+    if floor > 0.0:      # tensors that are analytically zero (e.g. a conv bias in front of train-mode BN) hold only round-off
+        a_ = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a)).double()
+        b_ = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b)).double()
+        if float(a_.abs().max()) <= floor and float(b_.abs().max()) <= floor:
+            return
     assert np.isfinite(e) and e <= tol, f"{name}: rel-to-max error {e:.3e} > {tol}"
+
+
+GRAD_FLOOR = 1e-7       # |grad| below this in BOTH implementations == "zero up to round-off"
 
 
 def load_params(model, params_np):
@@ -219,7 +227,7 @@ def test_mdvit_vs_oracle_128():
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         e = relerr(p.grad, ref)
-        if not (e <= 5e-3):
+        if not (e <= 5e-3) and max(float(p.grad.abs().max()), float(ref.abs().max())) > GRAD_FLOOR:
             bad.append((n, e))
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:6]}"
 
@@ -257,4 +265,4 @@ def test_train_step_harness_matches_reference_order():
     for k in ("loss", "aux_loss", "kt_loss"):
         check(res[0][0][k], res[1][0][k], tol=1e-5, name=k)
     for n in res[0][1]:
-        check(res[0][1][n], res[1][1][n], tol=2e-3, name=n)
+        check(res[0][1][n], res[1][1][n], tol=2e-3, name=n, floor=GRAD_FLOOR)
