@@ -45,7 +45,7 @@ def cpu_baseline(size: int):
     from oracle import mdvit_ref as R
     from oracle.params import make_params
     from mdvit_amd.synthetic import make_domain_batch
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)       # oneDNN stops scaling (and collapses when oversubscribed) past ~32 threads here
     torch.set_num_threads(cores)
     P = R.to_torch(make_params(0, model="MDViT", adapt_method="Sup"))
     img, lab, _ = make_domain_batch(1, size, 0, 1234)

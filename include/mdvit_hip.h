@@ -108,14 +108,17 @@ int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, int32_t B
 
 /* ---- BatchNorm2d (train: batch stats, biased var; running stats momentum, unbiased var) + activation
  * on NHWC [M,C]  (mpvit.py:112-123, mdvit.py:99-122,559-563, Decoders.py:39-62,304-306).
- * ws: 2*C doubles of scratch.  drop2d: nn.Dropout2d on (sample, channel) planes (Decoders.py:309,333). */
-int mdvit_bn_stats(const float* y, double* ws, float* mean, float* rstd, float* running_mean, float* running_var,
+ * ws: mdvit_bn_ws_bytes(M, C) bytes of scratch.  Channel sums are reduced in a fixed order (per-block partial
+ * rows, then a block-ordered double sum), so results are bitwise reproducible run to run.
+ * drop2d: nn.Dropout2d on (sample, channel) planes (Decoders.py:309,333). */
+size_t mdvit_bn_ws_bytes(int32_t M, int32_t C);
+int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* mean, float* rstd, float* running_mean, float* running_var,
                    int64_t* num_batches_tracked, int32_t M, int32_t C, float eps, float momentum, void* stream);
 int mdvit_bn_eval_prep(const float* running_mean, const float* running_var, float* mean, float* rstd, int32_t C, float eps, void* stream);
 int mdvit_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, float* z,
                    int32_t M, int32_t C, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream);
 int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                 float* dy, float* dgamma, float* dbeta, double* ws, int32_t M, int32_t C, int32_t act, int32_t training,
+                 float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t act, int32_t training,
                  float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream);
 
 /* ---- bilinear resize, align_corners=False, NHWC (F.interpolate call sites mdvit.py:699,

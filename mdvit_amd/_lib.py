@@ -57,10 +57,10 @@ _SIGS = {
     "mdvit_col2im3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_wgrad": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mdvit_bn_stats": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp],
+    "mdvit_bn_stats": [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp],
     "mdvit_bn_eval_prep": [vp, vp, vp, vp, i32, f32, vp],
     "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, i32, vp],
-    "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32, i32, vp],
+    "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, f32, u32, u32, i32, vp],
     "mdvit_upsample_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_upsample_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -102,6 +102,8 @@ def load():
     lib.mdvit_version.argtypes = []
     lib.mdvit_factoratt_ws_bytes.restype = C.c_size_t
     lib.mdvit_factoratt_ws_bytes.argtypes = [i32, i32, i32, i32]
+    lib.mdvit_bn_ws_bytes.restype = C.c_size_t
+    lib.mdvit_bn_ws_bytes.argtypes = [i32, i32]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t
     lib.mdvit_da_ws_bytes.argtypes = [i32, i32, i32]
     for name, sig in _SIGS.items():

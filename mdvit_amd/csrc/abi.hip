@@ -15,3 +15,32 @@ int mdvit_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* mdvit_last_error(void) { return g_mdvit_err; }
 extern "C" int mdvit_version(void) { return MDVIT_ABI_VERSION; }
+
+namespace {
+__global__ __launch_bounds__(256) void zero_u32_kernel(uint32_t* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void zero_u128_kernel(uint4* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+}  // namespace
+
+int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return MDVIT_OK;
+    if (ptr == nullptr || (bytes & 3) || (reinterpret_cast<uintptr_t>(ptr) & 3))
+        return mdvit_set_error(MDVIT_E_ALIGN, "zero fill needs a 4-byte aligned buffer and size (ptr=%p bytes=%zu)", ptr, bytes);
+    if (((reinterpret_cast<uintptr_t>(ptr) | bytes) & 15) == 0) {
+        const size_t n = bytes / 16;
+        const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(zero_u128_kernel, dim3(grid), dim3(256), 0, stream, (uint4*)ptr, n);
+    } else {
+        const size_t n = bytes / 4;
+        const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(zero_u32_kernel, dim3(grid), dim3(256), 0, stream, (uint32_t*)ptr, n);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "zero fill launch failed: %s", hipGetErrorString(e));
+    return MDVIT_OK;
+}

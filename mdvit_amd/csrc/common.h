@@ -26,12 +26,12 @@ int mdvit_set_error(int code, const char* fmt, ...);
                                    __LINE__, hipGetErrorString(e__));                \
     } while (0)
 
-#define MDVIT_ZERO(ptr, bytes, strm)                                                          \
-    do {                                                                                     \
-        hipError_t e__ = hipMemsetAsync((ptr), 0, (bytes), (strm));                          \
-        if (e__ != hipSuccess)                                                               \
-            return mdvit_set_error(MDVIT_E_HIP, "%s:%d memset failed: %s", __FILE__, __LINE__, \
-                                   hipGetErrorString(e__));                                  \
+// Zero-fill as an ordinary kernel on the launch stream (strictly stream-ordered with the kernels around it).
+int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream);
+#define MDVIT_ZERO(ptr, bytes, strm)                                   \
+    do {                                                               \
+        int rc__ = mdvit_zero_async((ptr), (bytes), (strm));           \
+        if (rc__ != MDVIT_OK) return rc__;                             \
     } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -314,8 +314,8 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     splits = cdiv(d->K, kps);
     a.splits = splits; a.k_per_split = kps;
     if (splits > 1) {
-        hipError_t e = hipMemset2DAsync(d->C, d->ldc * sizeof(float), 0, (size_t)d->N * sizeof(float), d->M, s);
-        if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "gemm: memset failed: %s", hipGetErrorString(e));
+        MDVIT_CHECK_ARG(d->ldc == d->N, MDVIT_E_SHAPE, "gemm: split reduction needs a dense output (ldc == N)");
+        MDVIT_ZERO(d->C, sizeof(float) * (size_t)d->M * d->N, s);
     }
     if (narrow) launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, s);
     else launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, s);

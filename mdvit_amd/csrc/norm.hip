@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 struct ChanArgs {
     const float* a; const float* b;          // MODE0: a=y.  MODE1: a=dz, b=y.  MODE2: a=A
     const float* mean; const float* rstd; const float* gamma; const float* beta;
-    double* ws; float* out;                   // ws [2C] doubles (MODE0/1); out [C] floats (MODE2)
+    double* ws; float* out; float* part;      // ws [2C] doubles + part [grid][2C] floats (MODE0/1); out [C] floats (MODE2)
     long lda; int M, C; int act;
     float drop_p; uint32_t k0, k1, thresh; float inv_keep; int rows_per_sample;
     const float* rowscale; int rows_per_scale;
@@ -159,16 +159,40 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
             }
         }
     }
+    if (MODE == 2) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        atomicAdd(&s_acc[c + j], s1[j]);
-        if (MODE != 2) atomicAdd(&s_acc[p.C + c + j], s2[j]);
+        for (int j = 0; j < 4; ++j) atomicAdd(&s_acc[c + j], s1[j]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.C; i += blockDim.x) atomicAdd(&p.out[i], s_acc[i]);
+        return;
     }
+    // MODE 0/1: bitwise-reproducible reduction.  Every thread parks its 8 partials in LDS; the partials of one
+    // channel quad are then added in increasing thread order, and each block writes ONE partial row
+    // part[block][2C]; chan_finalize_kernel adds the rows in block order (double).
+    float* s_part = s_acc + 2 * p.C;          // [blockDim][8]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_part[threadIdx.x * 8 + j] = s1[j]; s_part[threadIdx.x * 8 + 4 + j] = s2[j]; }
     __syncthreads();
-    for (int i = threadIdx.x; i < p.C; i += blockDim.x) {
-        if (MODE == 2) atomicAdd(&p.out[i], s_acc[i]);
-        else { atomicAdd(&p.ws[i], (double)s_acc[i]); atomicAdd(&p.ws[p.C + i], (double)s_acc[p.C + i]); }
+    const int blk_q0 = (int)(((long)blockIdx.x * blockDim.x) % QC);      // quad owned by thread 0 of this block
+    for (int qq = threadIdx.x; qq < QC; qq += blockDim.x) {
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int tt = (qq - blk_q0 + QC) % QC; tt < (int)blockDim.x; tt += QC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a1[j] += s_part[tt * 8 + j]; a2[j] += s_part[tt * 8 + 4 + j]; }
+        }
+        float* dst = p.part + (long)blockIdx.x * 2 * p.C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[qq * 4 + j] = a1[j]; dst[p.C + qq * 4 + j] = a2[j]; }
     }
+}
+
+// ws[i] = sum over blocks (in block order) of part[block][i], i < 2C, in double
+__global__ __launch_bounds__(256) void chan_finalize_kernel(const float* __restrict__ part, double* __restrict__ ws, int nblk, int C2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C2) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * C2 + i];
+    ws[i] = s;
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* mean, float* rstd, float* rmean, float* rvar,
@@ -354,16 +378,28 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_bn_stats(const float* y, double* ws, float* mean, float* rstd, float* running_mean, float* running_var,
+constexpr int CHAN_MAX_BLOCKS = 1024;
+
+static size_t bn_ws_bytes(int M, int C) {
+    return sizeof(double) * 2 * (size_t)C + sizeof(float) * 2 * (size_t)C * (size_t)chan_grid(M, C, CHAN_MAX_BLOCKS);
+}
+
+extern "C" size_t mdvit_bn_ws_bytes(int32_t M, int32_t C) {
+    if (M <= 0 || C <= 0 || C % 4) return 0;
+    return bn_ws_bytes(M, C);
+}
+
+extern "C" int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* mean, float* rstd, float* running_mean, float* running_var,
                               int64_t* nbt, int32_t M, int32_t C, float eps, float momentum, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_stats: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
-    MDVIT_ZERO(ws, sizeof(double) * 2 * C, s);
+    MDVIT_CHECK_ARG(ws_bytes >= bn_ws_bytes(M, C), MDVIT_E_WORKSPACE, "bn_stats: workspace too small");
     ChanArgs a; memset(&a, 0, sizeof(a));
-    a.a = y; a.lda = C; a.M = M; a.C = C; a.ws = ws;
-    const int grid = chan_grid(M, C, 2048);
-    hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid), dim3(256), sizeof(float) * 2 * C, s, a);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, mean, rstd, running_mean, running_var, nbt, M, C, eps, momentum);
+    a.a = y; a.lda = C; a.M = M; a.C = C; a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * C);
+    const int grid = chan_grid(M, C, CHAN_MAX_BLOCKS);
+    hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, a.ws, mean, rstd, running_mean, running_var, nbt, M, C, eps, momentum);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -388,15 +424,18 @@ extern "C" int mdvit_bn_apply(const float* y, const float* mean, const float* rs
 }
 
 extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                            float* dy, float* dgamma, float* dbeta, double* ws, int32_t M, int32_t C, int32_t act, int32_t training,
+                            float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t act, int32_t training,
                             float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_bwd: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
-    MDVIT_ZERO(ws, sizeof(double) * 2 * C, s);
+    MDVIT_CHECK_ARG(ws_bytes >= bn_ws_bytes(M, C), MDVIT_E_WORKSPACE, "bn_bwd: workspace too small");
     ChanArgs a; memset(&a, 0, sizeof(a));
-    a.a = dz; a.b = y; a.lda = C; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ws = ws; a.M = M; a.C = C; a.act = act;
+    a.a = dz; a.b = y; a.lda = C; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
+    a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * C);
     fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
-    hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(chan_grid(M, C, 2048)), dim3(256), sizeof(float) * 2 * C, s, a);
+    const int grid = chan_grid(M, C, CHAN_MAX_BLOCKS);
+    hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(grid), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
     const long total = (long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, s, a, dy, dgamma, dbeta, training);
     MDVIT_LAUNCH_CHECK();

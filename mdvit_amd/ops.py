@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -17,6 +18,21 @@ from . import _lib
 from ._lib import GemmDesc, call
 
 _key_counter = itertools.count(1)
+_POISON = os.environ.get("MDVIT_POISON", "0") == "1"      # debug: NaN-fill every buffer an op allocates
+
+
+def _empty(*a, **k):
+    t = torch.empty(*a, **k)
+    if _POISON and t.is_floating_point():
+        t.fill_(float("nan"))
+    return t
+
+
+def _empty_like(x):
+    t = torch.empty_like(x)
+    if _POISON and t.is_floating_point():
+        t.fill_(float("nan"))
+    return t
 
 
 def _next_key() -> Tuple[int, int]:
@@ -133,7 +149,7 @@ class _Linear(torch.autograd.Function):
         M, K = x.shape
         N, K2, ldb = _ld_view(W)
         assert K == K2
-        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        y = _empty((M, N), device=x.device, dtype=torch.float32)
         key = _next_key() if drop_p > 0 else (0, 0)
         gemm(_p(x), _p(W), _p(y), M, N, K, lda=K, ldb=ldb, ldc=N, bias=_p(b),
              e_drop=drop_p, e_key=key, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale,
@@ -154,13 +170,13 @@ class _Linear(torch.autograd.Function):
         pro = dict(a_drop=drop_p, a_key=key, a_rowscale=_p(rowscale), a_rows_per_scale=rps)
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = _empty_like(x)
             gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, **pro)
         if ctx.needs_input_grad[1]:
-            dW = torch.empty((N, K), device=x.device, dtype=torch.float32)
+            dW = _empty((N, K), device=x.device, dtype=torch.float32)
             gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
         if has_b and ctx.needs_input_grad[2]:
-            db = torch.empty((N,), device=x.device, dtype=torch.float32)
+            db = _empty((N,), device=x.device, dtype=torch.float32)
             call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, _stream())
         return dx, dW, db, (g if has_res else None), None, None, None
 
@@ -185,7 +201,7 @@ class _MatMul(torch.autograd.Function):
         M, K, lda = _ld_view(A)
         K2, N, ldb = _ld_view(B)
         assert K == K2
-        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+        out = _empty((M, N), device=A.device, dtype=torch.float32)
         gemm(_p(A), _p(B), _p(out), M, N, K, lda=lda, ldb=ldb, ldc=N, trans_b=False)
         ctx.save_for_backward(A, B)
         return out
@@ -200,10 +216,10 @@ class _MatMul(torch.autograd.Function):
         _, N, ldb = _ld_view(B)
         dA = dB = None
         if ctx.needs_input_grad[0]:      # dA = g @ B^T : B stored [K,N] row-major == "weight [N'=K, K'=N]"
-            dA = torch.empty((M, K), device=A.device, dtype=torch.float32)
+            dA = _empty((M, K), device=A.device, dtype=torch.float32)
             gemm(_p(g), _p(B), _p(dA), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=True)
         if ctx.needs_input_grad[1]:      # dB = A^T @ g
-            dB = torch.empty((K, N), device=A.device, dtype=torch.float32)
+            dB = _empty((K, N), device=A.device, dtype=torch.float32)
             gemm(_p(A), _p(g), _p(dB), K, N, M, lda=lda, ldb=N, ldc=N, trans_a=True, trans_b=False)
         return dA, dB
 
@@ -222,13 +238,13 @@ class _MlpResidual(torch.autograd.Function):
         _chk(x, res, W1, b1, W2, b2, rowscale)
         M, Cin = x.shape
         Hd = W1.shape[0]
-        u = torch.empty((M, Hd), device=x.device, dtype=torch.float32)
-        h = torch.empty_like(u)
+        u = _empty((M, Hd), device=x.device, dtype=torch.float32)
+        h = _empty_like(u)
         k1 = _next_key() if drop_p > 0 else (0, 0)
         k2 = _next_key() if drop_p > 0 else (0, 0)
         gemm(_p(x), _p(W1), _p(u), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), out2=_p(h),
              epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
-        out = torch.empty((M, Cin), device=x.device, dtype=torch.float32)
+        out = _empty((M, Cin), device=x.device, dtype=torch.float32)
         gemm(_p(h), _p(W2), _p(out), M, Cin, Hd, lda=Hd, ldb=Hd, ldc=Cin, bias=_p(b2),
              e_drop=drop_p, e_key=k2, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale, residual=_p(res), ldr=Cin)
         ctx.save_for_backward(x, u, h, W1, W2, rowscale)
@@ -247,18 +263,18 @@ class _MlpResidual(torch.autograd.Function):
         dev = x.device
         pro = dict(a_drop=drop_p, a_key=k2, a_rowscale=_p(rowscale), a_rows_per_scale=rps)
         # du = (dy W2) * gelu'(u) * mask1
-        du = torch.empty_like(u)
+        du = _empty_like(u)
         gemm(_p(g), _p(W2), _p(du), M, Hd, Cin, lda=Cin, ldb=Hd, ldc=Hd, trans_b=False,
              epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1, **pro)
-        dW2 = torch.empty_like(W2)
+        dW2 = _empty_like(W2)
         gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
-        db2 = torch.empty((Cin,), device=dev, dtype=torch.float32)
+        db2 = _empty((Cin,), device=dev, dtype=torch.float32)
         call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, _stream())
-        dW1 = torch.empty_like(W1)
+        dW1 = _empty_like(W1)
         gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
-        db1 = torch.empty((Hd,), device=dev, dtype=torch.float32)
+        db1 = _empty((Hd,), device=dev, dtype=torch.float32)
         call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, _stream())
-        dx = torch.empty_like(x)
+        dx = _empty_like(x)
         gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False)
         return dx, g, dW1, db1, dW2, db2, None, None, None
 
@@ -279,9 +295,9 @@ class _LayerNorm(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         _chk(x, gamma, beta)
         M, Cn = x.shape
-        y = torch.empty_like(x)
-        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
+        y = _empty_like(x)
+        mean = _empty((M,), device=x.device, dtype=torch.float32)
+        rstd = _empty_like(mean)
         call("mdvit_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cn, eps, _stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
@@ -293,9 +309,9 @@ class _LayerNorm(torch.autograd.Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         g = _c(g)
         M, Cn = x.shape
-        dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(gamma)
+        dx = _empty_like(x)
+        dg = _empty_like(gamma)
+        db = _empty_like(gamma)
         call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, Cn, _stream())
         return dx, dg, db, None
 
@@ -315,7 +331,7 @@ class _DwConv3x3(torch.autograd.Function):
         _chk(x, w, bias)
         B, H, W_, Cn = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
-        y = torch.empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
+        y = _empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
         call("mdvit_dwconv3x3_fwd", _p(x), _p(w), _p(bias), _p(y), B, H, W_, Cn, stride, int(add_input), _stream())
         ctx.save_for_backward(x, w)
         ctx.meta = (stride, add_input, bias is not None)
@@ -329,9 +345,9 @@ class _DwConv3x3(torch.autograd.Function):
         stride, add_input, has_b = ctx.meta
         g = _c(g)
         B, H, W_, Cn = x.shape
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w)
-        db = torch.empty((Cn,), device=x.device, dtype=torch.float32) if has_b else None
+        dx = _empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = _empty_like(w)
+        db = _empty((Cn,), device=x.device, dtype=torch.float32) if has_b else None
         call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_, Cn, stride, int(add_input), _stream())
         return dx, dw, db, None, None
 
@@ -346,7 +362,7 @@ class _GConv2(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         _chk(skip, up, w)
         B, H, W_, Cn = skip.shape
-        y = torch.empty_like(skip)
+        y = _empty_like(skip)
         call("mdvit_gconv2_3x3_fwd", _p(skip), _p(up), _p(w), _p(y), B, H, W_, Cn, _stream())
         ctx.save_for_backward(skip, up, w)
         return y
@@ -358,7 +374,7 @@ class _GConv2(torch.autograd.Function):
         skip, up, w = ctx.saved_tensors
         g = _c(g)
         B, H, W_, Cn = skip.shape
-        dskip, dup, dw = torch.empty_like(skip), torch.empty_like(up), torch.empty_like(w)
+        dskip, dup, dw = _empty_like(skip), _empty_like(up), _empty_like(w)
         call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), _p(dskip), _p(dup), _p(dw), B, H, W_, Cn, _stream())
         return dskip, dup, dw
 
@@ -377,7 +393,7 @@ class _Im2col(torch.autograd.Function):
         _chk(x)
         B, H, W_, Cn = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
-        col = torch.empty((B * Ho * Wo, Cn * 9), device=x.device, dtype=torch.float32)
+        col = _empty((B * Ho * Wo, Cn * 9), device=x.device, dtype=torch.float32)
         call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cn, stride, _stream())
         ctx.meta = (B, H, W_, Cn, stride)
         return col
@@ -388,7 +404,7 @@ class _Im2col(torch.autograd.Function):
             return (None,) * 2
         B, H, W_, Cn, stride = ctx.meta
         g = _c(g)
-        dx = torch.empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
+        dx = _empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
         call("mdvit_col2im3x3", _p(g), _p(dx), B, H, W_, Cn, stride, _stream())
         return dx, None
 
@@ -409,7 +425,7 @@ class _StemConv(torch.autograd.Function):
         _chk(img, w)
         B, Cin, H, W_ = img.shape
         Cout = w.shape[0]
-        y = torch.empty((B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cout), device=img.device, dtype=torch.float32)
+        y = _empty((B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cout), device=img.device, dtype=torch.float32)
         call("mdvit_stemconv_fwd", _p(img), _p(w), _p(y), B, H, W_, Cin, Cout, _stream())
         ctx.save_for_backward(img, w)
         return y
@@ -423,7 +439,7 @@ class _StemConv(torch.autograd.Function):
             raise _lib.MdvitHipError("gradient w.r.t. the input image is not built (the train path never needs it)")
         g = _c(g)
         B, Cin, H, W_ = img.shape
-        dw = torch.empty_like(w)
+        dw = _empty_like(w)
         call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(dw), B, H, W_, Cin, w.shape[0], _stream())
         return None, dw
 
@@ -443,16 +459,17 @@ class _BNAct(torch.autograd.Function):
         Cn = y.shape[-1]
         M = y.numel() // Cn
         dev = y.device
-        mean = torch.empty((Cn,), device=dev, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
+        mean = _empty((Cn,), device=dev, dtype=torch.float32)
+        rstd = _empty_like(mean)
         if training:
-            ws = torch.empty((2 * Cn,), device=dev, dtype=torch.float64)
-            call("mdvit_bn_stats", _p(y), _p(ws), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+            wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn)
+            ws = _empty((wsb // 8 + 1,), device=dev, dtype=torch.float64)
+            call("mdvit_bn_stats", _p(y), _p(ws), wsb, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
                  C.c_void_p(nbt.data_ptr()) if nbt is not None else None, M, Cn, eps, momentum, _stream())
         else:
             call("mdvit_bn_eval_prep", _p(running_mean), _p(running_var), _p(mean), _p(rstd), Cn, eps, _stream())
         key = _next_key() if drop2d_p > 0 else (0, 0)
-        z = torch.empty_like(y)
+        z = _empty_like(y)
         call("mdvit_bn_apply", _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), M, Cn, act, drop2d_p, key[0], key[1],
              rows_per_sample, _stream())
         ctx.save_for_backward(y, gamma, beta, mean, rstd)
@@ -468,10 +485,11 @@ class _BNAct(torch.autograd.Function):
         g = _c(g)
         Cn = y.shape[-1]
         M = y.numel() // Cn
-        dy = torch.empty_like(y)
-        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
-        ws = torch.empty((2 * Cn,), device=y.device, dtype=torch.float64)
-        call("mdvit_bn_bwd", _p(g), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dg), _p(db), _p(ws),
+        dy = _empty_like(y)
+        dg, db = _empty_like(gamma), _empty_like(gamma)
+        wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn)
+        ws = _empty((wsb // 8 + 1,), device=y.device, dtype=torch.float64)
+        call("mdvit_bn_bwd", _p(g), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dg), _p(db), _p(ws), wsb,
              M, Cn, act, int(training), drop2d_p, key[0], key[1], rps, _stream())
         return dy, dg, db, None, None, None, None, None, None, None, None, None
 
@@ -492,7 +510,7 @@ class _Upsample(torch.autograd.Function):
         _chk(x, base)
         B, H, W_, Cn = x.shape
         if base is None:
-            y = torch.empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
+            y = _empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
         else:
             y = base.clone()
         call("mdvit_upsample_fwd", _p(x), _p(y), B, H, W_, Ho, Wo, Cn, int(base is not None), _stream())
@@ -505,7 +523,7 @@ class _Upsample(torch.autograd.Function):
             return (None,) * 4
         B, H, W_, Ho, Wo, Cn, has_base = ctx.meta
         g = _c(g)
-        dx = torch.empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
+        dx = _empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
         call("mdvit_upsample_bwd", _p(g), _p(dx), B, H, W_, Ho, Wo, Cn, _stream())
         return dx, None, None, (g if has_base else None)
 
@@ -526,7 +544,7 @@ class _RowDot(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         _chk(w, b)
         M, K, ldx = _ld_view(x)
-        y = torch.empty((M,), device=x.device, dtype=torch.float32)
+        y = _empty((M,), device=x.device, dtype=torch.float32)
         call("mdvit_rowdot_fwd", _p(x), ldx, _p(w), _p(b), _p(y), M, K, 0, _stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -539,9 +557,9 @@ class _RowDot(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = _c(g)
         M, K, ldx = _ld_view(x)
-        dx = torch.empty((M, K), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dw = torch.empty((K,), device=x.device, dtype=torch.float32)
-        db = torch.empty((1,), device=x.device, dtype=torch.float32) if ctx.has_b else None
+        dx = _empty((M, K), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = _empty((K,), device=x.device, dtype=torch.float32)
+        db = _empty((1,), device=x.device, dtype=torch.float32) if ctx.has_b else None
         call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, _p(dw), _p(db), M, K, _stream())
         return dx, dw.view_as(w), db
 
@@ -571,15 +589,15 @@ class _FactorAtt(torch.autograd.Function):
         dev = qkv.device
         a = None
         if label is not None:
-            a = torch.empty((B, Cn), device=dev, dtype=torch.float32)
+            a = _empty((B, Cn), device=dev, dtype=torch.float32)
             call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, label.shape[1], W1.shape[0], Cn, heads, _stream())
-        out = torch.empty((B, N, Cn), device=dev, dtype=torch.float32)
-        U = torch.empty_like(out)
-        kmax = torch.empty((B, Cn), device=dev, dtype=torch.float32)
-        ksum = torch.empty_like(kmax)
-        Mmat = torch.empty((B, Cn, Ch), device=dev, dtype=torch.float32)
+        out = _empty((B, N, Cn), device=dev, dtype=torch.float32)
+        U = _empty_like(out)
+        kmax = _empty((B, Cn), device=dev, dtype=torch.float32)
+        ksum = _empty_like(kmax)
+        Mmat = _empty((B, Cn, Ch), device=dev, dtype=torch.float32)
         wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
-        ws = torch.empty((wsb // 4,), device=dev, dtype=torch.float32)
+        ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
         call("mdvit_factoratt_fwd", _p(qkv), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(out), _p(U), _p(kmax), _p(ksum),
              _p(Mmat), _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2], _stream())
         ctx.save_for_backward(qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, a, out, U, kmax, ksum, Mmat)
@@ -596,20 +614,20 @@ class _FactorAtt(torch.autograd.Function):
         B, N, C3 = qkv.shape
         Cn = C3 // 3
         dev = qkv.device
-        dqkv = torch.empty_like(qkv)
-        e = torch.empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
-        dws = [torch.empty_like(t) for t in (w3, b3, w5, b5, w7, b7)]
+        dqkv = _empty_like(qkv)
+        e = _empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
+        dws = [_empty_like(t) for t in (w3, b3, w5, b5, w7, b7)]
         wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
-        ws = torch.empty((wsb // 4,), device=dev, dtype=torch.float32)
+        ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
         call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(out), _p(U), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
              _p(Mmat), _p(dqkv), _p(e), *[_p(t) for t in dws], _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2],
              _stream())
         dW1 = db1 = dW2 = db2 = None
         if a is not None:
             hid = W1.shape[0]
-            dW1, db1, dW2, db2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b2)
+            dW1, db1, dW2, db2 = _empty_like(W1), _empty_like(b1), _empty_like(W2), _empty_like(b2)
             dab = _lib.load().mdvit_da_ws_bytes(B, hid, Cn)
-            daws = torch.empty((dab // 4,), device=dev, dtype=torch.float32)
+            daws = _empty((dab // 4,), device=dev, dtype=torch.float32)
             call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), _p(dW1), _p(db1), _p(dW2), _p(db2),
                  _p(daws), dab, B, label.shape[1], hid, Cn, heads, _stream())
         return (dqkv, *dws, None, dW1, db1, dW2, db2, None, None, None, None)
@@ -628,7 +646,7 @@ def domain_adapter(label, W1, b1, W2, b2, heads):
     """a = softmax_heads(W2 relu(W1 label + b1) + b2); forward only (its gradient path is inside factor_att)."""
     label = _c(label.float())
     B, D = label.shape
-    a = torch.empty((B, W2.shape[0]), device=label.device, dtype=torch.float32)
+    a = _empty((B, W2.shape[0]), device=label.device, dtype=torch.float32)
     call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, D, W1.shape[0], W2.shape[0], int(heads), _stream())
     return a
 
@@ -644,8 +662,8 @@ class _SegLosses(torch.autograd.Function):
     def forward(ctx, out, aux, label):
         _chk(out, aux, label)
         n = out.numel()
-        sums = torch.empty((16,), device=out.device, dtype=torch.float64)
-        losses = torch.empty((3,), device=out.device, dtype=torch.float32)
+        sums = _empty((16,), device=out.device, dtype=torch.float64)
+        losses = _empty((3,), device=out.device, dtype=torch.float32)
         call("mdvit_seg_losses_fwd", _p(out), _p(aux), _p(label), _p(sums), _p(losses), n, _stream())
         ctx.save_for_backward(out, aux, label, sums)
         ctx.set_materialize_grads(False)
@@ -666,8 +684,8 @@ class _SegLosses(torch.autograd.Function):
         g = torch.stack(gs)
         need_out = ctx.needs_input_grad[0] and (g0 is not None or g2 is not None)
         need_aux = aux is not None and ctx.needs_input_grad[1] and (g1 is not None or g2 is not None)
-        dout = torch.empty_like(out) if need_out else None
-        daux = torch.empty_like(aux) if need_aux else None
+        dout = _empty_like(out) if need_out else None
+        daux = _empty_like(aux) if need_aux else None
         if need_out or need_aux:
             call("mdvit_seg_losses_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(g), _p(dout), _p(daux), n, _stream())
         return dout, daux, None
