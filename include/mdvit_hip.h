@@ -47,7 +47,8 @@ int mdvit_version(void);
  *   NONE      : C = acc + bias; then optional dropout(e_drop_p), row scale (DropPath), + residual.
  *   GELU_DUAL : C = acc + bias (pre-activation u), C2 = dropout(gelu_erf(u))       (mpvit.py:73-75)
  *   DGELU     : C = acc * gelu'(gelu_u) * dropmask(e_key)                          (backward of the above)
- * allow_split: the reduction may be split across workgroups (fp32 atomics; C is zeroed first).
+ * allow_split: the reduction may be split across workgroups: every split writes a dense [M,N] slab into `ws`,
+ * a second kernel adds the slabs in a fixed order (deterministic; no atomics).
  * Replaces: nn.Linear mdvit.py:288,310  mpvit.py:73,76; 1x1 nn.Conv2d mdvit.py:98,589
  *           Decoders.py:185,300-311; their autograd backward. */
 typedef struct MdvitGemmDesc {
@@ -64,7 +65,9 @@ typedef struct MdvitGemmDesc {
     const float* residual; int64_t ldr;
     const float* gelu_u; int64_t ldu;
     int32_t allow_split;
+    void* ws; uint64_t ws_bytes;      /* scratch for split reductions: mdvit_gemm_ws_bytes(desc) (0 = none needed) */
 } MdvitGemmDesc;
+size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,

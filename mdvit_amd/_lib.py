@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("residual", vp), ("ldr", i64),
         ("gelu_u", vp), ("ldu", i64),
         ("allow_split", i32),
+        ("ws", vp), ("ws_bytes", C.c_uint64),
     ]
 
 
@@ -102,6 +103,8 @@ def load():
     lib.mdvit_version.argtypes = []
     lib.mdvit_factoratt_ws_bytes.restype = C.c_size_t
     lib.mdvit_factoratt_ws_bytes.argtypes = [i32, i32, i32, i32]
+    lib.mdvit_gemm_ws_bytes.restype = C.c_size_t
+    lib.mdvit_gemm_ws_bytes.argtypes = [C.POINTER(GemmDesc)]
     lib.mdvit_bn_ws_bytes.restype = C.c_size_t
     lib.mdvit_bn_ws_bytes.argtypes = [i32, i32]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t

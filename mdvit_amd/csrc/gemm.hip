@@ -31,7 +31,8 @@ struct GemmArgs {
     const float* e_rowscale; int e_rows_per_scale;
     const float* residual; long ldr;
     const float* gelu_u; long ldu;
-    int splits; int k_per_split;   // split along K (atomics) when splits > 1
+    int splits; int k_per_split;   // split along K: each split writes a dense [M,N] slab, reduced by a second kernel
+    float* slab;
     int tiles_m, tiles_n;
 };
 
@@ -186,9 +187,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     // ---- epilogue.  The MFMA ran as D = B^T-tile x A-tile, so D[row = n][col = m]: lane holds, for each
     // register quad q = r>>2, FOUR CONSECUTIVE output columns n = 8q + 4*(lane>>5) + (r&3) of output row
     // m = lane&31  ->  one 16-byte store per quad instead of four scalar stores.
-    const bool atomic = p.splits > 1;
-    const bool add_bias = p.bias != nullptr && blockIdx.y == 0;
+    const bool split = p.splits > 1;
+    const bool add_bias = p.bias != nullptr && !split;
     const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0);
+    float* slab = split ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
         const int row = m0 + wm0 + i * 32 + l31;
@@ -201,17 +203,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 const int col = n0 + wn0 + j * 32 + 8 * q + 4 * lhi;
                 if (col >= p.N) continue;
                 float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                const int nv = min(4, p.N - col);
-                if (add_bias) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] += p.bias[col + t];
-                }
-                float* dst = p.C + (long)row * p.ldc + col;
-                if (atomic) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (t < nv) atomicAdd(dst + t, v[t]);
+                if (split) {          // N % 4 == 0 is guaranteed by the planner for split launches
+                    *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = make_float4(v[0], v[1], v[2], v[3]);
                     continue;
                 }
+                const int nv = min(4, p.N - col);
+                if (add_bias) {
+                    if (vec) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (t < nv) v[t] += p.bias[col + t];
+                    }
+                }
+                float* dst = p.C + (long)row * p.ldc + col;
                 const uint32_t didx = (uint32_t)((long)row * p.N + col);
                 if (p.epi == MDVIT_EPI_GELU_DUAL) {
                     float h[4];
@@ -232,8 +236,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 }
                 if (p.epi == MDVIT_EPI_DGELU) {
                     const float* up = p.gelu_u + (long)row * p.ldu + col;
+                    if (vec && ((p.ldu & 3) == 0)) {
+                        const float4 u4 = *reinterpret_cast<const float4*>(up);
+                        v[0] *= gelu_grad_f(u4.x); v[1] *= gelu_grad_f(u4.y); v[2] *= gelu_grad_f(u4.z); v[3] *= gelu_grad_f(u4.w);
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] *= gelu_grad_f(up[t]);
+                        for (int t = 0; t < 4; ++t) if (t < nv) v[t] *= gelu_grad_f(up[t]);
+                    }
                 }
                 if (p.e_drop) {
 #pragma unroll
@@ -245,8 +254,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 }
                 if (p.residual) {
                     const float* rp = p.residual + (long)row * p.ldr + col;
+                    if (vec && ((p.ldr & 3) == 0)) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] += rp[t];
+                        for (int t = 0; t < 4; ++t) if (t < nv) v[t] += rp[t];
+                    }
                 }
                 if (vec) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 else {
@@ -258,6 +272,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
+// C[m][n] = sum_s slab[s][m][n] (+ bias[n]); fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                                 float* __restrict__ C, long ldc, int M, int N, int splits) {
+    const int NQ = N >> 2;
+    const long total = (long)M * NQ, MN = (long)M * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / NQ;
+        const int n = (int)(e % NQ) * 4;
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = slab + m * N + n;
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)sidx * MN);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float* dst = C + m * ldc + n;
+        if ((ldc & 3) == 0) *reinterpret_cast<float4*>(dst) = acc;
+        else { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& a, int ta, int tb, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(NTHREADS);
@@ -266,6 +300,35 @@ int launch_cfg(const GemmArgs& a, int ta, int tb, hipStream_t s) {
     else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, a);
     return 0;
+}
+
+struct GemmPlan { int cfg, tiles_m, tiles_n, splits, kps; };
+
+// Tile shape and K-split so that the launch has enough workgroups for 256 CUs:
+//   cfg 0: 128x128 (default)   1: 256x64 (narrow outputs, N an odd multiple of 64)   2: 64x64 (few tiles)
+GemmPlan plan_gemm(const MdvitGemmDesc* d) {
+    GemmPlan pl;
+    const bool narrow = (d->N <= 64) || (d->N % 128 != 0 && d->N % 64 == 0);
+    pl.cfg = narrow ? 1 : 0;
+    int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
+    long tiles = (long)cdiv(d->M, BM) * cdiv(d->N, BN);
+    if (tiles < 192) {
+        const long t64 = (long)cdiv(d->M, 64) * cdiv(d->N, 64);
+        if (t64 > tiles) { pl.cfg = 2; BM = 64; BN = 64; tiles = t64; }
+    }
+    pl.tiles_m = cdiv(d->M, BM); pl.tiles_n = cdiv(d->N, BN);
+    int splits = 1;
+    const bool plain = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual;
+    if (d->allow_split && plain && tiles < 384 && d->K >= 512 && (d->N % 4 == 0)) {
+        splits = (int)((768 + tiles - 1) / tiles);
+        const int max_splits = d->K / 256;
+        if (splits > max_splits) splits = max_splits;
+        if (splits > 256) splits = 256;
+        if (splits < 1) splits = 1;
+    }
+    pl.kps = cdiv(cdiv(d->K, splits), BK) * BK;
+    pl.splits = cdiv(d->K, pl.kps);
+    return pl;
 }
 
 }  // namespace
@@ -297,28 +360,28 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
 
-    // tile shape: 256x64 when the output is narrow or N is an odd multiple of 64, else 128x128
-    const bool narrow = (d->N <= 64) || (d->N % 128 != 0 && d->N % 64 == 0);
-    const int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
-    a.tiles_m = cdiv(d->M, BM); a.tiles_n = cdiv(d->N, BN);
-    const long tiles = (long)a.tiles_m * a.tiles_n;
-    int splits = 1;
-    const bool plain = d->epi == MDVIT_EPI_NONE && !a.e_drop && !d->e_rowscale && !d->residual;
-    if (d->allow_split && plain && tiles < 512 && d->K >= 2048) {
-        splits = (int)((1024 + tiles - 1) / tiles);
-        const int max_splits = d->K / 512;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
+    const GemmPlan pl = plan_gemm(d);
+    a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;
+    if (pl.splits > 1) {
+        const size_t need = sizeof(float) * (size_t)pl.splits * d->M * d->N;
+        MDVIT_CHECK_ARG(d->ws != nullptr && d->ws_bytes >= need, MDVIT_E_WORKSPACE,
+                        "gemm: split reduction needs %zu bytes of workspace (mdvit_gemm_ws_bytes), got %zu", need, (size_t)d->ws_bytes);
+        a.slab = (float*)d->ws;
     }
-    int kps = cdiv(cdiv(d->K, splits), BK) * BK;
-    splits = cdiv(d->K, kps);
-    a.splits = splits; a.k_per_split = kps;
-    if (splits > 1) {
-        MDVIT_CHECK_ARG(d->ldc == d->N, MDVIT_E_SHAPE, "gemm: split reduction needs a dense output (ldc == N)");
-        MDVIT_ZERO(d->C, sizeof(float) * (size_t)d->M * d->N, s);
+    if (pl.cfg == 0) launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, s);
+    else if (pl.cfg == 1) launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, s);
+    else launch_cfg<64, 64, 2, 2>(a, d->trans_a, d->trans_b, s);
+    if (pl.splits > 1) {
+        const long total = (long)d->M * d->N / 4;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)min((total + 255) / 256, 4096L)), dim3(256), 0, s,
+                           a.slab, d->bias, d->C, (long)d->ldc, d->M, d->N, pl.splits);
     }
-    if (narrow) launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, s);
-    else launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, s);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
+}
+
+extern "C" size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* d) {
+    if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    const GemmPlan pl = plan_gemm(d);
+    return pl.splits > 1 ? sizeof(float) * (size_t)pl.splits * d->M * d->N : 0;
 }

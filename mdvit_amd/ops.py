@@ -90,6 +90,12 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.residual, d.ldr = residual, ldr
     d.gelu_u, d.ldu = gelu_u, ldu
     d.allow_split = int(allow_split)
+    ws = None
+    if allow_split:
+        need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
+        if need:
+            ws = _empty((need // 4,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+            d.ws, d.ws_bytes = _p(ws), need
     if _events is None:
         call("mdvit_gemm_f32", C.byref(d), _stream())
         return
@@ -126,8 +132,7 @@ def kernel_events_end():
 
 
 def _gemm_kernel_name(M, N, trans_a, trans_b):
-    narrow = (N <= 64) or (N % 128 != 0 and N % 64 == 0)       # mirrors the tile choice in csrc/gemm.hip
-    return "gemm_f32_kernel<%s,%s,%s>" % ("256x64" if narrow else "128x128", "T" if trans_a else "N", "T" if trans_b else "N")
+    return "gemm_f32_kernel<%s,%s>" % ("T" if trans_a else "N", "T" if trans_b else "N")
 
 
 def _ld_view(t: torch.Tensor) -> Tuple[int, int, int]:
@@ -153,7 +158,7 @@ class _Linear(torch.autograd.Function):
         key = _next_key() if drop_p > 0 else (0, 0)
         gemm(_p(x), _p(W), _p(y), M, N, K, lda=K, ldb=ldb, ldc=N, bias=_p(b),
              e_drop=drop_p, e_key=key, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale,
-             residual=_p(residual), ldr=N)
+             residual=_p(residual), ldr=N, allow_split=True)
         ctx.save_for_backward(x, W, rowscale)
         ctx.meta = (drop_p, key, rows_per_scale, b is not None, residual is not None)
         return y
@@ -171,7 +176,7 @@ class _Linear(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = _empty_like(x)
-            gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, **pro)
+            gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, allow_split=True, **pro)
         if ctx.needs_input_grad[1]:
             dW = _empty((N, K), device=x.device, dtype=torch.float32)
             gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
@@ -202,7 +207,7 @@ class _MatMul(torch.autograd.Function):
         K2, N, ldb = _ld_view(B)
         assert K == K2
         out = _empty((M, N), device=A.device, dtype=torch.float32)
-        gemm(_p(A), _p(B), _p(out), M, N, K, lda=lda, ldb=ldb, ldc=N, trans_b=False)
+        gemm(_p(A), _p(B), _p(out), M, N, K, lda=lda, ldb=ldb, ldc=N, trans_b=False, allow_split=True)
         ctx.save_for_backward(A, B)
         return out
 
@@ -217,10 +222,10 @@ class _MatMul(torch.autograd.Function):
         dA = dB = None
         if ctx.needs_input_grad[0]:      # dA = g @ B^T : B stored [K,N] row-major == "weight [N'=K, K'=N]"
             dA = _empty((M, K), device=A.device, dtype=torch.float32)
-            gemm(_p(g), _p(B), _p(dA), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=True)
+            gemm(_p(g), _p(B), _p(dA), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=True, allow_split=True)
         if ctx.needs_input_grad[1]:      # dB = A^T @ g
             dB = _empty((K, N), device=A.device, dtype=torch.float32)
-            gemm(_p(A), _p(g), _p(dB), K, N, M, lda=lda, ldb=N, ldc=N, trans_a=True, trans_b=False)
+            gemm(_p(A), _p(g), _p(dB), K, N, M, lda=lda, ldb=N, ldc=N, trans_a=True, trans_b=False, allow_split=True)
         return dA, dB
 
 
@@ -275,7 +280,7 @@ class _MlpResidual(torch.autograd.Function):
         db1 = _empty((Hd,), device=dev, dtype=torch.float32)
         call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, _stream())
         dx = _empty_like(x)
-        gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False)
+        gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False, allow_split=True)
         return dx, g, dW1, db1, dW2, db2, None, None, None
 
 
