@@ -116,62 +116,146 @@ __global__ __launch_bounds__(256) void fa_combine_kernel(const float* __restrict
     }
 }
 
-// ---- crpe weight table for a channel chunk, zero-padded to 7x7, [cl][49] in LDS ------------------
-__device__ __forceinline__ void load_crpe_table(float* s_w, float* s_b, const FaGeom& g, const CrpeW& cw, int c0, int CC) {
-    for (int i = threadIdx.x; i < CC * 49; i += blockDim.x) {
-        const int cl = i / 49, t = i % 49, c = c0 + cl;
-        float v = 0.f;
-        if (c < g.C) {
-            const int r = crpe_radius(g, c), di = t / 7 - 3, dj = t % 7 - 3;
-            if (abs(di) <= r && abs(dj) <= r) v = crpe_wptr(g, cw, c, r)[(di + r) * (2 * r + 1) + (dj + r)];
-        }
-        s_w[i] = v;
+// ---- LDS-tiled depthwise window convolution over the token image -----------------------------------
+// y[b,n,cy] = bias[ci] + sum_{i,j} w[ci][i][j] * x[b, n + (i-R, j-R), cx]      (FLIP: w[ci][WIN-1-i][WIN-1-j], no bias)
+// for the ncls channels of ONE window class (ci = class-local index).  Block = 8 x 16 token tile x 32 channels:
+// the tile plus halo sits in LDS ([row][col][channel], channel fastest -> conflict-free), thread (channel, row)
+// produces 16 outputs along w from WIN input rows held in registers (16*WIN FMAs per TW+WIN-1 LDS reads).
+constexpr int CT_TH = 8, CT_TW = 16, CT_CL = 32;
+
+template <int WIN, bool FLIP>
+__global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restrict__ x, long ldx, int xoff,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, long ldy, int yoff,
+                                                           int H, int W, int ncls, int tiles_w) {
+    constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
+    __shared__ float sx[LH * LW * CT_CL];
+    __shared__ float sw[CT_CL * WIN * WIN];
+    const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
+    const int th0 = (blockIdx.x / tiles_w) * CT_TH, tw0 = (blockIdx.x % tiles_w) * CT_TW;
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const long img = (long)b * H * W;
+    for (int i = threadIdx.x; i < CT_CL * WIN * WIN; i += 256) {
+        const int c = i / (WIN * WIN), t = i % (WIN * WIN);
+        sw[i] = (c0 + c < ncls) ? w[(long)(c0 + c) * WIN * WIN + (FLIP ? WIN * WIN - 1 - t : t)] : 0.f;
     }
-    for (int cl = threadIdx.x; cl < CC; cl += blockDim.x) {
-        const int c = c0 + cl;
-        s_b[cl] = c < g.C ? crpe_bias(g, cw, c, crpe_radius(g, c)) : 0.f;
+    for (int p = rl; p < LH * LW; p += 8) {
+        const int hh = th0 + p / LW - R, ww = tw0 + p % LW - R;
+        float v = 0.f;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W && c0 + cl < ncls) v = x[(img + (long)hh * W + ww) * ldx + xoff + c0 + cl];
+        sx[p * CT_CL + cl] = v;
+    }
+    __syncthreads();
+    const int h = th0 + rl;
+    if (c0 + cl >= ncls || h >= H) return;
+    float acc[CT_TW];
+    const float b0 = (!FLIP && bias) ? bias[c0 + cl] : 0.f;
+#pragma unroll
+    for (int t = 0; t < CT_TW; ++t) acc[t] = b0;
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {
+        float row[LW], wr[WIN];
+#pragma unroll
+        for (int t = 0; t < LW; ++t) row[t] = sx[((rl + i) * LW + t) * CT_CL + cl];
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) wr[j] = sw[cl * WIN * WIN + i * WIN + j];
+#pragma unroll
+        for (int t = 0; t < CT_TW; ++t)
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) acc[t] = fmaf(wr[j], row[t + j], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < CT_TW; ++t)
+        if (tw0 + t < W) y[(img + (long)h * W + tw0 + t) * ldy + yoff + c0 + cl] = acc[t];
+}
+
+// dw[ci][i][j] += sum_tokens g[n,cg] * x[n + (i-R, j-R), cx];  db[ci] += sum g.   Thread (channel, window row i)
+// slides along w with the x row in registers; every (channel, tap) is owned by one thread -> one global atomic
+// per tap per block, no LDS reduction.
+template <int WIN>
+__global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __restrict__ g, long ldg, int goff,
+                                                                 const float* __restrict__ x, long ldx, int xoff,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 int H, int W, int ncls, int tiles_w, int tiles_total, int tiles_per_block) {
+    constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
+    __shared__ float sx[LH * LW * CT_CL];
+    __shared__ float sg[CT_TH * CT_TW * CT_CL];
+    const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;          // rl = window row i (threads with rl >= WIN only help loading)
+    const long img = (long)b * H * W;
+    const bool chan_ok = c0 + cl < ncls;
+    float acc[WIN];
+    float accb = 0.f;
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) acc[j] = 0.f;
+    const int t_beg = blockIdx.x * tiles_per_block, t_end = min(tiles_total, t_beg + tiles_per_block);
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int th0 = (tile / tiles_w) * CT_TH, tw0 = (tile % tiles_w) * CT_TW;
+        for (int p = rl; p < LH * LW; p += 8) {
+            const int hh = th0 + p / LW - R, ww = tw0 + p % LW - R;
+            float v = 0.f;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W && chan_ok) v = x[(img + (long)hh * W + ww) * ldx + xoff + c0 + cl];
+            sx[p * CT_CL + cl] = v;
+        }
+        for (int p = rl; p < CT_TH * CT_TW; p += 8) {
+            const int hh = th0 + p / CT_TW, ww = tw0 + p % CT_TW;
+            float v = 0.f;
+            if (hh < H && ww < W && chan_ok) v = g[(img + (long)hh * W + ww) * ldg + goff + c0 + cl];
+            sg[p * CT_CL + cl] = v;
+        }
+        __syncthreads();
+        if (rl < WIN && chan_ok) {
+#pragma unroll 2
+            for (int h = 0; h < CT_TH; ++h) {
+                float row[LW], gr[CT_TW];
+#pragma unroll
+                for (int t = 0; t < LW; ++t) row[t] = sx[((h + rl) * LW + t) * CT_CL + cl];
+#pragma unroll
+                for (int t = 0; t < CT_TW; ++t) gr[t] = sg[(h * CT_TW + t) * CT_CL + cl];
+#pragma unroll
+                for (int t = 0; t < CT_TW; ++t) {
+                    if (rl == 0) accb += gr[t];
+#pragma unroll
+                    for (int j = 0; j < WIN; ++j) acc[j] = fmaf(gr[t], row[t + j], acc[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (rl < WIN && chan_ok) {
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) atomicAdd(&dw[(long)(c0 + cl) * WIN * WIN + rl * WIN + j], acc[j]);
+        if (rl == 0) atomicAdd(&db[c0 + cl], accb);
     }
 }
 
-// ---- fwd C --------------------------------------------------------------------------------------
-// block: CC channels x (256/CC) token lanes; grid.x over token groups, grid.y over channel chunks.
-__global__ __launch_bounds__(256) void fa_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ Mmat,
-                                                       const float* __restrict__ a, float* __restrict__ out, float* __restrict__ U,
-                                                       FaGeom g, CrpeW cw, int CC, int tokens_per_block) {
-    extern __shared__ float sm[];          // s_w[CC*49], s_b[CC]
-    float* s_w = sm;
-    float* s_b = sm + CC * 49;
-    const int c0 = blockIdx.y * CC;
-    load_crpe_table(s_w, s_b, g, cw, c0, CC);
-    __syncthreads();
-    const int cl = threadIdx.x % CC, tl = threadIdx.x / CC, ntl = blockDim.x / CC;
-    const int c = c0 + cl;
-    if (c >= g.C || tl >= ntl) return;
-    const int head = c / g.Ch, ch = c % g.Ch, hb = head * g.Ch, r = crpe_radius(g, c);
-    const int C3 = 3 * g.C;
-    const long total = (long)g.B * g.N;
-    const long t_beg = (long)blockIdx.x * tokens_per_block, t_end = min(total, t_beg + tokens_per_block);
-    for (long tok = t_beg + tl; tok < t_end; tok += ntl) {
-        const int b = (int)(tok / g.N), n = (int)(tok % g.N), h = n / g.W, w = n % g.W;
-        const float* row = qkv + tok * C3;
-        const float qc = row[c];
-        float fa = 0.f;
-        const float* Mb = Mmat + ((long)b * g.C + hb) * g.Ch + ch;
-        for (int j = 0; j < g.Ch; ++j) fa = fmaf(row[hb + j], Mb[(long)j * g.Ch], fa);
-        float u = s_b[cl];
-        for (int di = -r; di <= r; ++di) {
-            const int hh = h + di;
-            if (hh < 0 || hh >= g.H) continue;
-            for (int dj = -r; dj <= r; ++dj) {
-                const int ww = w + dj;
-                if (ww < 0 || ww >= g.W) continue;
-                u = fmaf(s_w[cl * 49 + (di + 3) * 7 + (dj + 3)], qkv[((long)b * g.N + hh * g.W + ww) * C3 + 2 * g.C + c], u);
-            }
+// ---- fwd C': out = a * (Ch^-0.5 * q.M + q * U)    (U from the tiled conv; q rows staged in LDS) -----------
+template <int CH>
+__global__ __launch_bounds__(512) void fa_out_kernel(const float* __restrict__ qkv, const float* __restrict__ U,
+                                                     const float* __restrict__ Mmat, const float* __restrict__ a,
+                                                     float* __restrict__ out, FaGeom g, int TLN, int tokens_per_block) {
+    extern __shared__ float s_q[];         // [TLN][C]
+    const int C = g.C, C3 = 3 * C;
+    const int c = threadIdx.x % C, tl = threadIdx.x / C, b = blockIdx.y;
+    const int head = c / CH, ch = c % CH, hb = head * CH;
+    const float ac = a ? a[(long)b * C + c] : 1.f;
+    const float* Mb = Mmat + ((long)b * C + hb) * CH + ch;       // M[hb+j][ch], stride CH
+    const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
+    for (int base = n_beg; base < n_end; base += TLN) {
+        const int n = base + tl;
+        const bool ok = n < n_end;
+        const long tok = (long)b * g.N + (ok ? n : n_beg);
+        float qc = 0.f;
+        if (ok) { qc = qkv[tok * C3 + c]; s_q[tl * C + c] = qc; }
+        __syncthreads();
+        if (ok) {
+            float fa = 0.f;
+            const float* qr = &s_q[tl * C + hb];
+#pragma unroll 8
+            for (int j = 0; j < CH; ++j) fa = fmaf(qr[j], Mb[(long)j * CH], fa);
+            out[tok * C + c] = ac * (g.scale * fa + qc * U[tok * C + c]);
         }
-        float y = g.scale * fa + qc * u;
-        if (a) y *= a[(long)b * g.C + c];
-        out[tok * g.C + c] = y;
-        U[tok * g.C + c] = u;
+        __syncthreads();
     }
 }
 
@@ -207,56 +291,6 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restric
     }
 }
 
-// ---- bwd 3: crpe wgrad for one window size: dw[c,i,j] = sum_{b,n} dU[n,c] * V[n+(i-r,j-r),c]; db = sum dU ----
-// block = CL channels x (256/CL) token lanes over a chunk of tokens of one image.
-template <int WIN>
-__global__ __launch_bounds__(256) void fa_crpe_wgrad_kernel(const float* __restrict__ dU, const float* __restrict__ qkv,
-                                                            float* __restrict__ dw, float* __restrict__ db, FaGeom g,
-                                                            int cbase, int ncls, int CL, int tokens_per_block) {
-    extern __shared__ float s_acc[];       // [CL][WIN*WIN+1]
-    constexpr int R = WIN / 2, NW = WIN * WIN;
-    for (int i = threadIdx.x; i < CL * (NW + 1); i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
-    const int b = blockIdx.z, cchunk = blockIdx.y;
-    const int cl = threadIdx.x % CL, tl = threadIdx.x / CL, ntl = blockDim.x / CL;
-    const int ci = cchunk * CL + cl;                 // index inside the window class
-    const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
-    float acc[NW];
-    float accb = 0.f;
-#pragma unroll
-    for (int t = 0; t < NW; ++t) acc[t] = 0.f;
-    if (ci < ncls && tl < ntl) {
-        const int c = cbase + ci, C = g.C, C3 = 3 * C;
-        for (int n = n_beg + tl; n < n_end; n += ntl) {
-            const long tok = (long)b * g.N + n;
-            const float du = dU[tok * C + c];
-            accb += du;
-            const int h = n / g.W, w = n % g.W;
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) {
-                const int hh = h + i - R;
-                if (hh < 0 || hh >= g.H) continue;
-#pragma unroll
-                for (int j = 0; j < WIN; ++j) {
-                    const int ww = w + j - R;
-                    if (ww < 0 || ww >= g.W) continue;
-                    acc[i * WIN + j] = fmaf(du, qkv[((long)b * g.N + hh * g.W + ww) * C3 + 2 * C + c], acc[i * WIN + j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NW; ++t) atomicAdd(&s_acc[cl * (NW + 1) + t], acc[t]);
-        atomicAdd(&s_acc[cl * (NW + 1) + NW], accb);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < CL * (NW + 1); i += blockDim.x) {
-        const int l = i / (NW + 1), t = i % (NW + 1), cc = cchunk * CL + l;
-        if (cc >= ncls) continue;
-        if (t < NW) atomicAdd(&dw[(long)cc * NW + t], s_acc[i]);
-        else atomicAdd(&db[cc], s_acc[i]);
-    }
-}
-
 // ---- bwd 4: t[b,c] = sum_e dM[b,c,e] * M[b,c,e] -------------------------------------------------
 __global__ void fa_bwd_mid_kernel(const float* __restrict__ dM, const float* __restrict__ Mmat, float* __restrict__ tcol, int BC, int Ch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,11 +306,11 @@ __global__ void fa_bwd_mid_kernel(const float* __restrict__ dM, const float* __r
 // read them as broadcasts; M / dM stay in global memory (L2-resident, [C,Ch] per image).
 template <int CH>
 __global__ __launch_bounds__(512) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
-                                                           const float* __restrict__ U, const float* __restrict__ dU,
+                                                           const float* __restrict__ U, const float* __restrict__ dVc,
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
                                                            const float* __restrict__ dM, const float* __restrict__ tcol,
-                                                           float* __restrict__ dqkv, FaGeom g, CrpeW cw, int TLN, int tokens_per_block) {
+                                                           float* __restrict__ dqkv, FaGeom g, int TLN, int tokens_per_block) {
     extern __shared__ float sm[];          // s_P[TLN][C], s_dfa[TLN][C], s_v[TLN][C]
     const int C = g.C, C3 = 3 * C;
     float* s_P = sm;
@@ -284,9 +318,7 @@ __global__ __launch_bounds__(512) void fa_bwd_apply_kernel(const float* __restri
     float* s_v = sm + 2 * TLN * C;
     const int c = threadIdx.x % C, tl = threadIdx.x / C;
     const int b = blockIdx.y;
-    const int head = c / CH, ch = c % CH, hb = head * CH, r = crpe_radius(g, c);
-    const float* wp = crpe_wptr(g, cw, c, r);
-    const int win = 2 * r + 1;
+    const int head = c / CH, ch = c % CH, hb = head * CH;
     const float ac = a ? a[(long)b * C + c] : 1.f;
     const float km = kmax[(long)b * C + c], ksinv = 1.0f / ksum[(long)b * C + c], tc = tcol[(long)b * C + c];
     const float* Mrow = Mmat + ((long)b * C + c) * CH;        // M[c][e]
@@ -318,17 +350,7 @@ __global__ __launch_bounds__(512) void fa_bwd_apply_kernel(const float* __restri
                 dP = fmaf(vr[e], dMrow[e], dP);
                 dv = fmaf(pr[e], dMcol[(long)e * CH], dv);
             }
-            // conv^T(dU): token n collects dU of every token whose window covers n
-            const int h = n / g.W, w = n % g.W;
-            for (int i = 0; i < win; ++i) {
-                const int h2 = h - (i - r);
-                if (h2 < 0 || h2 >= g.H) continue;
-                for (int j = 0; j < win; ++j) {
-                    const int w2 = w - (j - r);
-                    if (w2 < 0 || w2 >= g.W) continue;
-                    dv = fmaf(wp[i * win + j], dU[((long)b * g.N + h2 * g.W + w2) * C + c], dv);
-                }
-            }
+            dv += dVc[tok * C + c];                       // conv^T(dU), from the tiled (flipped-window) conv
             dq = fmaf(ac * G, U[tok * C + c], dq);
             float* drow = dqkv + tok * C3;
             drow[c] = dq;
@@ -445,12 +467,12 @@ int fa_cw(const FaGeom& g) {
     return hp * g.Ch;
 }
 
-// fwd: ws_m, ws_s [B,NT,C] + ws_P [B,NT,C,Ch].   bwd: dU [B,N,C] + tcol [B,C] + dM [B,C,Ch] + ws_P [B,NT,C,Ch].
+// fwd: ws_m, ws_s [B,NT,C] + ws_P [B,NT,C,Ch].   bwd: dU, dVc [B,N,C] each + tcol [B,C] + dM [B,C,Ch] + ws_P [B,NT,C,Ch].
 size_t fa_ws_floats(int B, int N, int C, int heads) {
     const int Ch = C / heads;
     const long NT = (N + FA_T - 1) / FA_T;
     const long fwd = (long)B * NT * C * (2 + Ch);
-    const long bwd = (long)B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch;
+    const long bwd = 2L * B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch;
     return (size_t)(fwd > bwd ? fwd : bwd);
 }
 
@@ -465,16 +487,24 @@ int quad_grid(long work_quads, int QC, int max_blocks) {
     return (int)((want + gmul - 1) / gmul * gmul);
 }
 
-template <int WIN>
-void launch_crpe_wgrad(const float* dU, const float* qkv, float* dw, float* db, const FaGeom& g, int cbase, int ncls, hipStream_t s) {
+template <int WIN, bool FLIP>
+void launch_conv_tile(const float* x, long ldx, int xoff, const float* w, const float* bias, float* y, long ldy, int yoff,
+                      const FaGeom& g, int ncls, hipStream_t s) {
     if (ncls <= 0) return;
-    int CL = 16;
-    while (CL < ncls && CL < 64) CL <<= 1;            // 16/32/64 channels per block
-    const int ntl = 256 / CL;
-    int tpb = ntl * 16;                                 // 16 tokens per lane
-    while ((long)cdiv(g.N, tpb) * g.B * cdiv(ncls, CL) > 4096) tpb *= 2;
-    hipLaunchKernelGGL((fa_crpe_wgrad_kernel<WIN>), dim3(cdiv(g.N, tpb), cdiv(ncls, CL), g.B), dim3(256), sizeof(float) * CL * (WIN * WIN + 1), s,
-                       dU, qkv, dw, db, g, cbase, ncls, CL, tpb);
+    const int tiles_w = cdiv(g.W, CT_TW), tiles_h = cdiv(g.H, CT_TH);
+    hipLaunchKernelGGL((fa_conv_tile_kernel<WIN, FLIP>), dim3(tiles_w * tiles_h, cdiv(ncls, CT_CL), g.B), dim3(256), 0, s,
+                       x, ldx, xoff, w, bias, y, ldy, yoff, g.H, g.W, ncls, tiles_w);
+}
+
+template <int WIN>
+void launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x, long ldx, int xoff, float* dw, float* db,
+                            const FaGeom& g, int ncls, hipStream_t s) {
+    if (ncls <= 0) return;
+    const int tiles_w = cdiv(g.W, CT_TW), tiles_h = cdiv(g.H, CT_TH), tiles = tiles_w * tiles_h;
+    int tpb = 1;                                   // tiles per block: keep >= ~512 blocks, cut the atomics otherwise
+    while ((long)cdiv(tiles, tpb * 2) * cdiv(ncls, CT_CL) * g.B >= 512) tpb *= 2;
+    hipLaunchKernelGGL((fa_conv_tile_wgrad_kernel<WIN>), dim3(cdiv(tiles, tpb), cdiv(ncls, CT_CL), g.B), dim3(256), 0, s,
+                       gsrc, ldg, goff, x, ldx, xoff, dw, db, g.H, g.W, ncls, tiles_w, tiles, tpb);
 }
 
 }  // namespace
@@ -500,13 +530,27 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     hipLaunchKernelGGL((fa_partial_kernel<true>), dim3(NT, C / CW, B), dim3(256), sizeof(float) * 2 * FA_T * CW, s,
                        qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, CW, NT);
     hipLaunchKernelGGL((fa_combine_kernel<true>), dim3(cdiv((long)C * g.Ch, 256), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
-    CrpeW cw{w3, b3, w5, b5, w7, b7};
-    const int CC = C < 128 ? C : 128;
-    int block = 256;
-    if (256 % CC) block = CC * (256 / CC > 0 ? 256 / CC : 1);
-    const long total = (long)B * g.N;
-    int tpb = (int)max(32L, (total + 2047) / 2048);
-    hipLaunchKernelGGL(fa_apply_kernel, dim3(cdiv(total, tpb), cdiv(C, CC)), dim3(block), sizeof(float) * CC * 50, s, qkv, Mmat, a, out, U, g, cw, CC, tpb);
+    MDVIT_CHECK_ARG(C <= 512, MDVIT_E_SHAPE, "factoratt_fwd: C=%d > 512 not built", C);
+    // U = dwconv_win(v) + bias, one tiled launch per window class (channels [0,s3*Ch) | [..) | [..))
+    const int Ch = g.Ch, c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
+    launch_conv_tile<3, false>(qkv, 3L * C, 2 * C, w3, b3, U, (long)C, 0, g, s3 * Ch, s);
+    launch_conv_tile<5, false>(qkv, 3L * C, 2 * C + c5, w5, b5, U, (long)C, c5, g, s5 * Ch, s);
+    launch_conv_tile<7, false>(qkv, 3L * C, 2 * C + c7, w7, b7, U, (long)C, c7, g, s7 * Ch, s);
+    {
+        const int TLN = max(1, 256 / C), block = TLN * C;
+        int tpb = TLN * 8;
+        while ((long)cdiv(g.N, tpb) * B > 8192) tpb *= 2;
+        dim3 grid(cdiv(g.N, tpb), B);
+#define FA_OUT_LAUNCH(CHV) hipLaunchKernelGGL((fa_out_kernel<CHV>), grid, dim3(block), sizeof(float) * TLN * C, s, qkv, U, Mmat, a, out, g, TLN, tpb)
+        switch (Ch) {
+            case 8: FA_OUT_LAUNCH(8); break;
+            case 16: FA_OUT_LAUNCH(16); break;
+            case 40: FA_OUT_LAUNCH(40); break;
+            case 64: FA_OUT_LAUNCH(64); break;
+            default: return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_fwd: head dim %d not built (8/16/40/64)", Ch);
+        }
+#undef FA_OUT_LAUNCH
+    }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -526,7 +570,8 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     const int Ch = g.Ch, NT = cdiv(g.N, FA_T), CW = fa_cw(g);
     MDVIT_CHECK_ARG(CW <= 128, MDVIT_E_SHAPE, "factoratt_bwd: head dim %d too large", Ch);
     float* dU = (float*)ws;
-    float* tcol = dU + (long)B * g.N * C;
+    float* dVc = dU + (long)B * g.N * C;
+    float* tcol = dVc + (long)B * g.N * C;
     float* dM = tcol + (long)B * C;
     float* ws_P = dM + (long)B * C * Ch;
     if (e) MDVIT_ZERO(e, sizeof(float) * (size_t)B * C, s);
@@ -542,19 +587,23 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     hipLaunchKernelGGL((fa_combine_kernel<false>), dim3(cdiv((long)C * Ch, 256), B), dim3(256), 0, s,
                        (const float*)nullptr, (const float*)nullptr, ws_P, (float*)nullptr, (float*)nullptr, dM, g, NT);
     // 3: crpe weight gradients
-    launch_crpe_wgrad<3>(dU, qkv, dw3, db3, g, 0, s3 * Ch, s);
-    launch_crpe_wgrad<5>(dU, qkv, dw5, db5, g, s3 * Ch, s5 * Ch, s);
-    launch_crpe_wgrad<7>(dU, qkv, dw7, db7, g, (s3 + s5) * Ch, s7 * Ch, s);
+    const int c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
+    launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, g, s3 * Ch, s);
+    launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, g, s5 * Ch, s);
+    launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, g, s7 * Ch, s);
+    // conv^T(dU) = correlation with the flipped window
+    launch_conv_tile<3, true>(dU, (long)C, 0, w3, nullptr, dVc, (long)C, 0, g, s3 * Ch, s);
+    launch_conv_tile<5, true>(dU, (long)C, c5, w5, nullptr, dVc, (long)C, c5, g, s5 * Ch, s);
+    launch_conv_tile<7, true>(dU, (long)C, c7, w7, nullptr, dVc, (long)C, c7, g, s7 * Ch, s);
     // 4, 5
     hipLaunchKernelGGL(fa_bwd_mid_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, dM, Mmat, tcol, B * C, Ch);
-    CrpeW cw{w3, b3, w5, b5, w7, b7};
     const int TLN = max(1, 256 / C);
     const int block = TLN * C;
     int tpb = TLN * 8;
     while ((long)cdiv(g.N, tpb) * B > 8192) tpb *= 2;
     const size_t lds = sizeof(float) * 3 * TLN * C;
     dim3 grid(cdiv(g.N, tpb), B);
-#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(block), lds, s, dout, qkv, U, dU, Mmat, a, kmax, ksum, dM, tcol, dqkv, g, cw, TLN, tpb)
+#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(block), lds, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, dM, tcol, dqkv, g, TLN, tpb)
     switch (Ch) {
         case 8: FA_BWD_LAUNCH(8); break;
         case 16: FA_BWD_LAUNCH(16); break;

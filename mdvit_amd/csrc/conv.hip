@@ -29,15 +29,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const float* __restr
         float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int hi = ho * stride + kh - 1;
-            if (hi < 0 || hi >= Hi) continue;
+            const int hi = ho * stride + kh - 1, hc = min(max(hi, 0), Hi - 1);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int wi = wo * stride + kw - 1;
-                if (wi < 0 || wi >= Wi) continue;
-                const float4 xv = *reinterpret_cast<const float4*>(x + (((long)b * Hi + hi) * Wi + wi) * C + c);
+                const int wi = wo * stride + kw - 1, wc = min(max(wi, 0), Wi - 1);
+                const float m = (hi == hc && wi == wc) ? 1.f : 0.f;
+                const float4 xv = *reinterpret_cast<const float4*>(x + (((long)b * Hi + hc) * Wi + wc) * C + c);
                 const float4 wv = *reinterpret_cast<const float4*>(&s_w[(kh * 3 + kw) * C + c]);
-                acc = f4_fma(xv, wv, acc);
+                acc = f4_fma(xv, make_float4(wv.x * m, wv.y * m, wv.z * m, wv.w * m), acc);
             }
         }
         if (add_input) acc = f4_add(acc, *reinterpret_cast<const float4*>(x + (((long)b * Hi + ho) * Wi + wo) * C + c));
@@ -112,14 +111,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
                 accb = f4_add(accb, g);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
-                    const int hi = ho * stride + kh - 1;
-                    if (hi < 0 || hi >= Hi) continue;
+                    const int hi = ho * stride + kh - 1, hc = min(max(hi, 0), Hi - 1);
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        const int wi = wo * stride + kw - 1;
-                        if (wi < 0 || wi >= Wi) continue;
-                        const float4 xv = *reinterpret_cast<const float4*>(x + (((long)b * Hi + hi) * Wi + wi) * C + c);
-                        acc[kh * 3 + kw] = f4_fma(g, xv, acc[kh * 3 + kw]);
+                        const int wi = wo * stride + kw - 1, wc = min(max(wi, 0), Wi - 1);
+                        const float m = (hi == hc && wi == wc) ? 1.f : 0.f;
+                        const float4 xv = *reinterpret_cast<const float4*>(x + (((long)b * Hi + hc) * Wi + wc) * C + c);
+                        acc[kh * 3 + kw] = f4_fma(make_float4(g.x * m, g.y * m, g.z * m, g.w * m), xv, acc[kh * 3 + kw]);
                     }
                 }
             }

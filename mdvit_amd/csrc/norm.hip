@@ -186,13 +186,30 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
     }
 }
 
-// ws[i] = sum over blocks (in block order) of part[block][i], i < 2C, in double
+// ws[i] = sum over blocks of part[block][i], i < 2C, in double and in a FIXED order:
+// 32 columns x 8 row lanes per workgroup; lane r adds rows r, r+8, ... then the 8 lane sums are added 0..7.
 __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* __restrict__ part, double* __restrict__ ws, int nblk, int C2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C2) return;
+    __shared__ double s_sum[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * C2 + i];
-    ws[i] = s;
+    if (i < C2) {
+        int b = rl;
+        for (; b + 24 < nblk; b += 32) {        // 4 independent loads in flight
+            const float v0 = part[(long)b * C2 + i], v1 = part[(long)(b + 8) * C2 + i];
+            const float v2 = part[(long)(b + 16) * C2 + i], v3 = part[(long)(b + 24) * C2 + i];
+            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        }
+        for (; b < nblk; b += 8) s += (double)part[(long)b * C2 + i];
+    }
+    s_sum[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && i < C2) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
+        ws[i] = t;
+    }
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* mean, float* rstd, float* rmean, float* rvar,
@@ -378,7 +395,7 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
     return MDVIT_OK;
 }
 
-constexpr int CHAN_MAX_BLOCKS = 1024;
+constexpr int CHAN_MAX_BLOCKS = 512;
 
 static size_t bn_ws_bytes(int M, int C) {
     return sizeof(double) * 2 * (size_t)C + sizeof(float) * 2 * (size_t)C * (size_t)chan_grid(M, C, CHAN_MAX_BLOCKS);
@@ -398,7 +415,7 @@ extern "C" int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* 
     a.a = y; a.lda = C; a.M = M; a.C = C; a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * C);
     const int grid = chan_grid(M, C, CHAN_MAX_BLOCKS);
     hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, a.ws, mean, rstd, running_mean, running_var, nbt, M, C, eps, momentum);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
@@ -435,7 +452,7 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
     fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
     const int grid = chan_grid(M, C, CHAN_MAX_BLOCKS);
     hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(grid), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
     const long total = (long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, s, a, dy, dgamma, dbeta, training);
     MDVIT_LAUNCH_CHECK();
