@@ -76,7 +76,7 @@ def main():
 
     import mdvit_amd
     from mdvit_amd import ops
-    from mdvit_amd.parallel import GradBucketReducer, broadcast_parameters
+    from mdvit_amd.parallel import GradAccumulator, broadcast_parameters
     from mdvit_amd.synthetic import make_step_batches
     from mdvit_amd.train import base_train_step, mdvit_train_step
 
@@ -90,15 +90,15 @@ def main():
         domains, flop_per_img = (0,), 137.7e9
     broadcast_parameters(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
-    reducer = GradBucketReducer(model.parameters()) if world > 1 else None
+    accum = GradAccumulator(model.parameters())       # fused accumulation; overlapped bucketed all-reduce when world > 1
     # a small pool of distinct synthetic steps, resident in HBM before timing
     pool = [make_step_batches(args.batch, args.size, rank=rank, step=s, device=dev, domains=domains) for s in range(2)]
 
     def step(i):
         b = pool[i % len(pool)]
         if args.model == "mdvit":
-            return mdvit_train_step(model, b, optimizer=opt, reducer=reducer)
-        return base_train_step(model, b, optimizer=opt, reducer=reducer)
+            return mdvit_train_step(model, b, optimizer=opt, accumulator=accum)
+        return base_train_step(model, b, optimizer=opt, accumulator=accum)
 
     def fence():
         if world > 1:

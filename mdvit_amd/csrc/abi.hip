@@ -44,3 +44,18 @@ int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
     if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "zero fill launch failed: %s", hipGetErrorString(e));
     return MDVIT_OK;
 }
+
+int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream) {
+    int i = 0;
+    while (i < n) {
+        if (items[i].p == nullptr || items[i].bytes == 0) { ++i; continue; }
+        char* beg = (char*)items[i].p;
+        size_t len = items[i].bytes;
+        int j = i + 1;
+        while (j < n && items[j].p != nullptr && (char*)items[j].p == beg + len) { len += items[j].bytes; ++j; }
+        const int rc = mdvit_zero_async(beg, len, stream);
+        if (rc != MDVIT_OK) return rc;
+        i = j;
+    }
+    return MDVIT_OK;
+}

@@ -574,10 +574,13 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     float* tcol = dVc + (long)B * g.N * C;
     float* dM = tcol + (long)B * C;
     float* ws_P = dM + (long)B * C * Ch;
-    if (e) MDVIT_ZERO(e, sizeof(float) * (size_t)B * C, s);
-    MDVIT_ZERO(dw3, sizeof(float) * s3 * Ch * 9, s);  MDVIT_ZERO(db3, sizeof(float) * s3 * Ch, s);
-    MDVIT_ZERO(dw5, sizeof(float) * s5 * Ch * 25, s); MDVIT_ZERO(db5, sizeof(float) * s5 * Ch, s);
-    MDVIT_ZERO(dw7, sizeof(float) * s7 * Ch * 49, s); MDVIT_ZERO(db7, sizeof(float) * s7 * Ch, s);
+    {
+        const MdvitZeroItem z[7] = {{e, e ? sizeof(float) * (size_t)B * C : 0}, {dw3, sizeof(float) * s3 * Ch * 9}, {db3, sizeof(float) * s3 * Ch},
+                                    {dw5, sizeof(float) * s5 * Ch * 25}, {db5, sizeof(float) * s5 * Ch},
+                                    {dw7, sizeof(float) * s7 * Ch * 49}, {db7, sizeof(float) * s7 * Ch}};
+        const int rc = mdvit_zero_many(z, 7, s);
+        if (rc != MDVIT_OK) return rc;
+    }
     // 1: dU, e
     const int QC = C / 4;
     hipLaunchKernelGGL(fa_bwd_prep_kernel, dim3(quad_grid((long)g.N * QC, QC, 512), B), dim3(256), sizeof(float) * C, s, dout, qkv, out, a, dU, e, g);

@@ -28,6 +28,10 @@ int mdvit_set_error(int code, const char* fmt, ...);
 
 // Zero-fill as an ordinary kernel on the launch stream (strictly stream-ordered with the kernels around it).
 int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream);
+// Zero several buffers; runs of buffers that are adjacent in memory are cleared by one launch (callers allocate
+// the small gradient outputs of one op as slices of a single buffer).
+struct MdvitZeroItem { void* p; size_t bytes; };
+int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream);
 #define MDVIT_ZERO(ptr, bytes, strm)                                   \
     do {                                                               \
         int rc__ = mdvit_zero_async((ptr), (bytes), (strm));           \

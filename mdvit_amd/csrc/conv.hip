@@ -538,8 +538,11 @@ extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float*
         hipLaunchKernelGGL(dwconv3x3_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 9 * C, s, dy, w, dx, B, Hi, Wi, C, stride, add_input);
     }
     if (dw) {
-        MDVIT_ZERO(dw, sizeof(float) * 9 * C, s);
-        if (dbias) MDVIT_ZERO(dbias, sizeof(float) * C, s);
+        {
+            const MdvitZeroItem z[2] = {{dw, sizeof(float) * 9 * C}, {dbias, dbias ? sizeof(float) * C : 0}};
+            const int rc = mdvit_zero_many(z, 2, s);
+            if (rc != MDVIT_OK) return rc;
+        }
         const long ntok = (long)B * Ho * Wo;
         int tpb = (int)max(64L, (ntok + 1023) / 1024);
         hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(cdiv(ntok, tpb)), dim3(256), sizeof(float) * 10 * C, s, dy, x, dw, dbias, B, Hi, Wi, C, stride, tpb);

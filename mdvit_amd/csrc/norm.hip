@@ -387,8 +387,11 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
                                    float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
-    MDVIT_ZERO(dgamma, sizeof(float) * C, s);
-    MDVIT_ZERO(dbeta, sizeof(float) * C, s);
+    {
+        const MdvitZeroItem z[2] = {{dgamma, sizeof(float) * C}, {dbeta, sizeof(float) * C}};
+        const int rc = mdvit_zero_many(z, 2, s);
+        if (rc != MDVIT_OK) return rc;
+    }
     dim3 grid(min(cdiv(M, 16), 1024));
     LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C);
     MDVIT_LAUNCH_CHECK();
@@ -485,8 +488,11 @@ extern "C" int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, con
                                 int32_t M, int32_t K, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && K > 0 && K <= 1024, MDVIT_E_SHAPE, "rowdot_bwd: need K <= 1024 (M=%d K=%d)", M, K);
-    MDVIT_ZERO(dw, sizeof(float) * K, s);
-    if (db) MDVIT_ZERO(db, sizeof(float), s);
+    {
+        const MdvitZeroItem z[2] = {{dw, sizeof(float) * K}, {db, db ? sizeof(float) : 0}};
+        const int rc = mdvit_zero_many(z, 2, s);
+        if (rc != MDVIT_OK) return rc;
+    }
     dim3 grid(min(cdiv(M, 64), 1024));
     const int C = K;
     LN_DISPATCH(rowdot_bwd_kernel, C, x, (long)ldx, w, dy, dx, (long)lddx, dw, db, M, K);

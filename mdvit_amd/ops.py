@@ -65,6 +65,20 @@ def _chk(*ts):
             raise _lib.MdvitHipError("mdvit_amd ops need contiguous tensors")
 
 
+def _flat_like(*protos):
+    """Allocate the (small) outputs of one op as slices of ONE buffer, in order, so the library can clear them
+    with a single zero-fill launch.  protos: tensors (shape donors) or shapes; None entries pass through."""
+    shapes = [None if t is None else (tuple(t.shape) if isinstance(t, torch.Tensor) else tuple(t)) for t in protos]
+    dev = next(t.device for t in protos if isinstance(t, torch.Tensor))
+    sizes = [0 if sh is None else int(torch.Size(sh).numel()) for sh in shapes]
+    flat = _empty((max(sum(sizes), 1),), device=dev, dtype=torch.float32)
+    out, off = [], 0
+    for sh, n in zip(shapes, sizes):
+        out.append(None if sh is None else flat[off:off + n].view(sh))
+        off += n
+    return out
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -315,8 +329,7 @@ class _LayerNorm(torch.autograd.Function):
         g = _c(g)
         M, Cn = x.shape
         dx = _empty_like(x)
-        dg = _empty_like(gamma)
-        db = _empty_like(gamma)
+        dg, db = _flat_like(gamma, gamma)
         call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, Cn, _stream())
         return dx, dg, db, None
 
@@ -351,8 +364,7 @@ class _DwConv3x3(torch.autograd.Function):
         g = _c(g)
         B, H, W_, Cn = x.shape
         dx = _empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = _empty_like(w)
-        db = _empty((Cn,), device=x.device, dtype=torch.float32) if has_b else None
+        dw, db = _flat_like(w, (Cn,) if has_b else None)
         call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_, Cn, stride, int(add_input), _stream())
         return dx, dw, db, None, None
 
@@ -563,8 +575,7 @@ class _RowDot(torch.autograd.Function):
         g = _c(g)
         M, K, ldx = _ld_view(x)
         dx = _empty((M, K), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dw = _empty((K,), device=x.device, dtype=torch.float32)
-        db = _empty((1,), device=x.device, dtype=torch.float32) if ctx.has_b else None
+        dw, db = _flat_like(w.reshape(-1), (1,) if ctx.has_b else None)
         call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, _p(dw), _p(db), M, K, _stream())
         return dx, dw.view_as(w), db
 
@@ -620,8 +631,7 @@ class _FactorAtt(torch.autograd.Function):
         Cn = C3 // 3
         dev = qkv.device
         dqkv = _empty_like(qkv)
-        e = _empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
-        dws = [_empty_like(t) for t in (w3, b3, w5, b5, w7, b7)]
+        e, *dws = _flat_like((B, Cn) if a is not None else None, w3, b3, w5, b5, w7, b7)
         wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
         ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
         call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(out), _p(U), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),

@@ -102,6 +102,54 @@ class GradBucketReducer:
         return True
 
 
+class GradAccumulator:
+    """Gradient accumulation over the 4 domains x 2 sweeps of one step with a handful of kernels.
+
+    autograd's AccumulateGrad issues one small add per parameter per backward() (432 x 7 per step).  Here every
+    sweep but the last runs with p.grad = None, and its fresh gradients are folded into flat buckets by ONE
+    multi-tensor add; for the last sweep p.grad is re-pointed at the bucket views so that (a) autograd adds the
+    last contribution in place and (b) with world_size > 1 the post-accumulate hooks launch each bucket's
+    all-reduce (RCCL) as soon as it is complete, overlapped with the rest of the backward sweep."""
+
+    def __init__(self, params, bucket_bytes: int = 32 << 20, process_group=None, average: bool = True):
+        self.reducer = GradBucketReducer(params, bucket_bytes, process_group, average)
+        self.params = self.reducer.params
+        self.views = [p.grad for p in self.params]          # views into the flat buckets
+        for p in self.params:
+            p.grad = None
+
+    @property
+    def world(self):
+        return self.reducer.world
+
+    def zero(self):
+        self.reducer.zero_grad()
+        for p in self.params:
+            p.grad = None
+
+    def begin_sweep(self, last: bool):
+        if last:
+            for p, v in zip(self.params, self.views):
+                p.grad = v
+            self.reducer.arm()
+        else:
+            for p in self.params:
+                p.grad = None
+
+    def end_sweep(self, last: bool):
+        if last:
+            self.reducer.finish()
+            return
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None:
+                dst.append(v); src.append(p.grad)
+        if dst:
+            torch._foreach_add_(dst, src)
+        for p in self.params:
+            p.grad = None
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):
     """One-off weight/buffer sync at start-up (replicas are seeded identically; this makes it certain)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:

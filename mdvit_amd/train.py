@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from .losses import domain_losses, seg_loss
-from .parallel import GradBucketReducer
+from .parallel import GradAccumulator, GradBucketReducer
 
 
 def _da_params(model):
@@ -25,26 +25,36 @@ def _da_params(model):
 
 def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: float = 0.5, num_domains: int = 4,
                      reducer: Optional[GradBucketReducer] = None, per_domain_backward: bool = True,
-                     use_domain_label: bool = True) -> Dict[str, torch.Tensor]:
+                     use_domain_label: bool = True, accumulator: Optional[GradAccumulator] = None) -> Dict[str, torch.Tensor]:
     """batches: [(img (B,3,H,W), label (B,1,H,W), set_id (B,) int64)] one per domain.
-    Returns the summed losses as device tensors (no host sync inside the step)."""
+    Returns the summed losses as device tensors (no host sync inside the step).
+    accumulator: fused gradient accumulation (+ overlapped all-reduce when world_size > 1), see parallel.GradAccumulator."""
     da = _da_params(model)
-    if reducer is not None:
+    if accumulator is not None:
+        accumulator.zero()
+    elif reducer is not None:
         reducer.zero_grad()
     elif optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
     else:
         model.zero_grad(set_to_none=True)
 
+    def sweep(loss, last, retain=False):
+        if accumulator is not None:
+            accumulator.begin_sweep(last)
+        elif last and reducer is not None:
+            reducer.arm()
+        loss.backward(retain_graph=retain)
+        if accumulator is not None:
+            accumulator.end_sweep(last)
+
     def two_sweeps(aux_sum, uni, last):
         for p in da:
             p.requires_grad = False
-        aux_sum.backward(retain_graph=True)
+        sweep(aux_sum, False, retain=True)
         for p in da:
             p.requires_grad = True
-        if last and reducer is not None:
-            reducer.arm()
-        uni.backward()
+        sweep(uni, last)
 
     tot = tot_aux = tot_kt = None
     stash = []
@@ -65,7 +75,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
             stash.append((l, la, lk))
     if not per_domain_backward:
         two_sweeps(sum(s[1] for s in stash), alpha * sum(s[2] for s in stash) + (1 - alpha) * sum(s[0] for s in stash), last=True)
-    if reducer is not None:
+    if accumulator is None and reducer is not None:
         reducer.finish()
     if optimizer is not None:
         optimizer.step()
@@ -73,9 +83,12 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
 
 
 def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Optional[GradBucketReducer] = None,
-                    num_domains: int = 4, use_domain_label: bool = False) -> Dict[str, torch.Tensor]:
+                    num_domains: int = 4, use_domain_label: bool = False,
+                    accumulator: Optional[GradAccumulator] = None) -> Dict[str, torch.Tensor]:
     """multi_train_BASE.py:150-200: per domain loss = BCE + Dice, one backward of the sum."""
-    if reducer is not None:
+    if accumulator is not None:
+        accumulator.zero()
+    elif reducer is not None:
         reducer.zero_grad()
     elif optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
@@ -88,11 +101,16 @@ def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Op
         else:
             out = model(img)
         l = seg_loss(out, label)
-        if reducer is not None and i == len(batches) - 1:
+        last = i == len(batches) - 1
+        if accumulator is not None:
+            accumulator.begin_sweep(last)
+        elif reducer is not None and last:
             reducer.arm()
         l.backward()
+        if accumulator is not None:
+            accumulator.end_sweep(last)
         tot = l.detach() if tot is None else tot + l.detach()
-    if reducer is not None:
+    if accumulator is None and reducer is not None:
         reducer.finish()
     if optimizer is not None:
         optimizer.step()

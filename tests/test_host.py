@@ -129,6 +129,17 @@ for p, q in zip(model.parameters(), ref.parameters()):
     assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
 for p in extra.parameters():
     assert float(p.grad.abs().max()) == 0.0
+# ---- fused accumulator: sweeps 1..n-1 folded by one multi-tensor add, the last sweep armed for all-reduce ----
+from mdvit_amd.parallel import GradAccumulator
+model2 = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 3))
+model2.load_state_dict(ref.state_dict())
+acc = GradAccumulator(list(model2.parameters()), bucket_bytes=4096)
+for step in range(2):
+    acc.zero()
+    acc.begin_sweep(False); ((model2(xs) - ys) ** 2).mean().backward(); acc.end_sweep(False)
+    acc.begin_sweep(True); model2(xs).abs().mean().backward(); acc.end_sweep(True)
+for p, q in zip(model2.parameters(), ref.parameters()):
+    assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
