@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="mdvit", choices=["mdvit", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-sweeps", action="store_true", help="run the reference's literal two full sweeps instead of the merged (linear-algebra-equivalent) form")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--detail", default="", help="write the per-kernel table to this JSON file")
     return ap.parse_args()
@@ -97,7 +98,7 @@ def main():
     def step(i):
         b = pool[i % len(pool)]
         if args.model == "mdvit":
-            return mdvit_train_step(model, b, optimizer=opt, accumulator=accum)
+            return mdvit_train_step(model, b, optimizer=opt, accumulator=accum, merged_sweeps=not args.reference_sweeps)
         return base_train_step(model, b, optimizer=opt, accumulator=accum)
 
     def fence():

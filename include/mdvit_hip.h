@@ -132,12 +132,13 @@ int mdvit_upsample_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_
 
 /* ---- Domain Adapter: a = softmax_heads(W2 relu(W1 label + b1) + b2), [B,C] (mdvit.py:272-276,301-303).
  * Backward takes e[b,c] = a[b,c] * dL/da[b,c] (what mdvit_factoratt_bwd emits -- it needs no division by a):
- * dz = e - a * sum_heads(e).  ws: mdvit_da_ws_bytes(B, hid, C) bytes of scratch. */
+ * dz = scale * (e - a * sum_heads(e)).  ws: mdvit_da_ws_bytes(B, hid, C) bytes of scratch.  scale = -1 lets a
+ * dgrad-only aux sweep pre-subtract its adapter gradient (mdvit_amd/train.py, multi_train_MDViT.py:198-207). */
 int mdvit_da_fwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, float* a,
                  int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream);
 size_t mdvit_da_ws_bytes(int32_t B, int32_t hid, int32_t C);
 int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,
-                 const float* e, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,
+                 const float* e, float scale, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,
                  int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream);
 
 /* ---- factorized attention core (mdvit.py:293-304, mpvit.py:296-318) -------------------------
@@ -146,7 +147,7 @@ int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const flo
  * out[b,n,c] = a[b,c] * ( Ch^-0.5 * sum_j q[n,head,j] M[b,head,j,ch] + q[n,c] * U[b,n,c] )
  * with M = softmax_over_tokens(k)^T v.  crpe weights: [s3*Ch,1,3,3], [s5*Ch,1,5,5], [s7*Ch,1,7,7] (+bias).
  * a == NULL: no domain adapter (mpvit.py:347-373).  kmax/ksum [B,C] and Mmat [B,C,Ch] are saved for backward.
- * Backward returns dqkv, the crpe gradients and e = a * dL/da (NULL when a is NULL). */
+ * Backward returns dqkv, the crpe gradients (all six may be NULL: dgrad only) and e = a * dL/da (NULL when a is NULL). */
 size_t mdvit_factoratt_ws_bytes(int32_t B, int32_t N, int32_t C, int32_t heads);
 int mdvit_factoratt_fwd(const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
                         const float* w7, const float* b7, const float* a, float* out, float* U, float* kmax, float* ksum, float* Mmat,

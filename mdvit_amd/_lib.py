@@ -65,7 +65,7 @@ _SIGS = {
     "mdvit_upsample_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_upsample_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mdvit_da_bwd": [vp] * 11 + [vp, C.c_size_t] + [i32] * 5 + [vp],
+    "mdvit_da_bwd": [vp] * 7 + [f32] + [vp] * 4 + [vp, C.c_size_t] + [i32] * 5 + [vp],
     "mdvit_factoratt_fwd": [vp] * 13 + [vp, C.c_size_t] + [i32] * 8 + [vp],
     "mdvit_factoratt_bwd": [vp] * 22 + [vp, C.c_size_t] + [i32] * 8 + [vp],
     "mdvit_seg_losses_fwd": [vp, vp, vp, vp, vp, i64, vp],

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void da_fwd_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(256) void da_bwd_stage1_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ a, const float* __restrict__ e,
                                                             float* __restrict__ dzbuf, float* __restrict__ hbuf, float* __restrict__ dhbuf,
-                                                            int D, int hid, int C, int heads) {
+                                                            int D, int hid, int C, int heads, float scale) {
     extern __shared__ float sm[];   // dz[C]
     float* dz = sm;
     const int b = blockIdx.x, Ch = C / heads;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void da_bwd_stage1_kernel(const float* __restr
         const int ch = c % Ch;
         float tot = 0.f;
         for (int hh = 0; hh < heads; ++hh) tot += e[(long)b * C + hh * Ch + ch];
-        const float v = e[(long)b * C + c] - a[(long)b * C + c] * tot;
+        const float v = scale * (e[(long)b * C + c] - a[(long)b * C + c] * tot);
         dz[c] = v;
         dzbuf[(long)b * C + c] = v;
     }
@@ -574,7 +574,12 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     float* tcol = dVc + (long)B * g.N * C;
     float* dM = tcol + (long)B * C;
     float* ws_P = dM + (long)B * C * Ch;
-    {
+    const bool want_wgrad = dw3 != nullptr;
+    MDVIT_CHECK_ARG(want_wgrad ? (db3 && dw5 && db5 && dw7 && db7) : !(db3 || dw5 || db5 || dw7 || db7), MDVIT_E_SHAPE,
+                    "factoratt_bwd: the six crpe gradient outputs must be all given or all NULL");
+    if (!want_wgrad) {
+        if (e) MDVIT_ZERO(e, sizeof(float) * (size_t)B * C, s);
+    } else {
         const MdvitZeroItem z[7] = {{e, e ? sizeof(float) * (size_t)B * C : 0}, {dw3, sizeof(float) * s3 * Ch * 9}, {db3, sizeof(float) * s3 * Ch},
                                     {dw5, sizeof(float) * s5 * Ch * 25}, {db5, sizeof(float) * s5 * Ch},
                                     {dw7, sizeof(float) * s7 * Ch * 49}, {db7, sizeof(float) * s7 * Ch}};
@@ -591,9 +596,11 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
                        (const float*)nullptr, (const float*)nullptr, ws_P, (float*)nullptr, (float*)nullptr, dM, g, NT);
     // 3: crpe weight gradients
     const int c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
-    launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, g, s3 * Ch, s);
-    launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, g, s5 * Ch, s);
-    launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, g, s7 * Ch, s);
+    if (want_wgrad) {
+        launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, g, s3 * Ch, s);
+        launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, g, s5 * Ch, s);
+        launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, g, s7 * Ch, s);
+    }
     // conv^T(dU) = correlation with the flipped window
     launch_conv_tile<3, true>(dU, (long)C, 0, w3, nullptr, dVc, (long)C, 0, g, s3 * Ch, s);
     launch_conv_tile<5, true>(dU, (long)C, c5, w5, nullptr, dVc, (long)C, c5, g, s5 * Ch, s);
@@ -633,7 +640,7 @@ extern "C" size_t mdvit_da_ws_bytes(int32_t B, int32_t hid, int32_t C) {
 }
 
 extern "C" int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,
-                            const float* e, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,
+                            const float* e, float scale, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,
                             int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     (void)b2;
@@ -642,7 +649,7 @@ extern "C" int mdvit_da_bwd(const float* label, const float* W1, const float* b1
     float* dzbuf = (float*)ws;
     float* hbuf = dzbuf + (long)B * C;
     float* dhbuf = hbuf + (long)B * hid;
-    hipLaunchKernelGGL(da_bwd_stage1_kernel, dim3(B), dim3(256), sizeof(float) * C, s, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads);
+    hipLaunchKernelGGL(da_bwd_stage1_kernel, dim3(B), dim3(256), sizeof(float) * C, s, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads, scale);
     const long total = (long)C * hid + (long)hid * D + C + hid;
     hipLaunchKernelGGL(da_bwd_stage2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, label, dzbuf, hbuf, dhbuf, dW1, db1, dW2, db2, B, D, hid, C);
     MDVIT_LAUNCH_CHECK();

@@ -565,10 +565,12 @@ extern "C" int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const fl
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "gconv2_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     const long total = (long)B * H * W * C / 2;
     hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
-    MDVIT_ZERO(dw, sizeof(float) * 18 * C, s);
-    const long ntok = (long)B * H * W;
-    int tpb = (int)max(64L, (ntok + 1023) / 1024);
-    hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(cdiv(ntok, tpb)), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, dw, B, H, W, C, tpb);
+    if (dw) {
+        MDVIT_ZERO(dw, sizeof(float) * 18 * C, s);
+        const long ntok = (long)B * H * W;
+        int tpb = (int)max(64L, (ntok + 1023) / 1024);
+        hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(cdiv(ntok, tpb)), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, dw, B, H, W, C, tpb);
+    }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

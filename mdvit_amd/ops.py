@@ -65,6 +65,19 @@ def _chk(*ts):
             raise _lib.MdvitHipError("mdvit_amd ops need contiguous tensors")
 
 
+# ---- backward mode ----------------------------------------------------------------------------------
+# 0: every gradient.   1: "aux sweep" of the merged two-sweep step (mdvit_amd/train.py): data gradients only;
+#    parameters get no gradient EXCEPT the domain-adapter weights, which receive MINUS their gradient, so that a
+#    following full backward of (aux + uni) leaves them with the uni-only gradient the reference computes by
+#    freezing them during the aux sweep (multi_train_MDViT.py:198-207).
+_dgrad_only = False
+
+
+def set_dgrad_only(flag: bool):
+    global _dgrad_only
+    _dgrad_only = bool(flag)
+
+
 def _flat_like(*protos):
     """Allocate the (small) outputs of one op as slices of ONE buffer, in order, so the library can clear them
     with a single zero-fill launch.  protos: tensors (shape donors) or shapes; None entries pass through."""
@@ -191,10 +204,10 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _empty_like(x)
             gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, allow_split=True, **pro)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _dgrad_only:
             dW = _empty((N, K), device=x.device, dtype=torch.float32)
             gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
-        if has_b and ctx.needs_input_grad[2]:
+        if has_b and ctx.needs_input_grad[2] and not _dgrad_only:
             db = _empty((N,), device=x.device, dtype=torch.float32)
             call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, _stream())
         return dx, dW, db, (g if has_res else None), None, None, None
@@ -229,6 +242,8 @@ class _MatMul(torch.autograd.Function):
     def backward(ctx, g):
         if g is None:
             return (None,) * 2
+        if _dgrad_only:          # both operands are weights
+            return None, None
         A, B = ctx.saved_tensors
         g = _c(g)
         M, K, lda = _ld_view(A)
@@ -285,14 +300,16 @@ class _MlpResidual(torch.autograd.Function):
         du = _empty_like(u)
         gemm(_p(g), _p(W2), _p(du), M, Hd, Cin, lda=Cin, ldb=Hd, ldc=Hd, trans_b=False,
              epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1, **pro)
-        dW2 = _empty_like(W2)
-        gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
-        db2 = _empty((Cin,), device=dev, dtype=torch.float32)
-        call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, _stream())
-        dW1 = _empty_like(W1)
-        gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
-        db1 = _empty((Hd,), device=dev, dtype=torch.float32)
-        call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, _stream())
+        dW1 = db1 = dW2 = db2 = None
+        if not _dgrad_only:
+            dW2 = _empty_like(W2)
+            gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
+            db2 = _empty((Cin,), device=dev, dtype=torch.float32)
+            call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, _stream())
+            dW1 = _empty_like(W1)
+            gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
+            db1 = _empty((Hd,), device=dev, dtype=torch.float32)
+            call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, _stream())
         dx = _empty_like(x)
         gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False, allow_split=True)
         return dx, g, dW1, db1, dW2, db2, None, None, None
@@ -331,6 +348,8 @@ class _LayerNorm(torch.autograd.Function):
         dx = _empty_like(x)
         dg, db = _flat_like(gamma, gamma)
         call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, Cn, _stream())
+        if _dgrad_only:
+            return dx, None, None, None
         return dx, dg, db, None
 
 
@@ -364,7 +383,7 @@ class _DwConv3x3(torch.autograd.Function):
         g = _c(g)
         B, H, W_, Cn = x.shape
         dx = _empty_like(x) if ctx.needs_input_grad[0] else None
-        dw, db = _flat_like(w, (Cn,) if has_b else None)
+        dw, db = (None, None) if _dgrad_only else _flat_like(w, (Cn,) if has_b else None)
         call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_, Cn, stride, int(add_input), _stream())
         return dx, dw, db, None, None
 
@@ -391,7 +410,7 @@ class _GConv2(torch.autograd.Function):
         skip, up, w = ctx.saved_tensors
         g = _c(g)
         B, H, W_, Cn = skip.shape
-        dskip, dup, dw = _empty_like(skip), _empty_like(up), _empty_like(w)
+        dskip, dup, dw = _empty_like(skip), _empty_like(up), (None if _dgrad_only else _empty_like(w))
         call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), _p(dskip), _p(dup), _p(dw), B, H, W_, Cn, _stream())
         return dskip, dup, dw
 
@@ -454,6 +473,8 @@ class _StemConv(torch.autograd.Function):
         img, w = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.MdvitHipError("gradient w.r.t. the input image is not built (the train path never needs it)")
+        if _dgrad_only:
+            return None, None
         g = _c(g)
         B, Cin, H, W_ = img.shape
         dw = _empty_like(w)
@@ -508,6 +529,8 @@ class _BNAct(torch.autograd.Function):
         ws = _empty((wsb // 8 + 1,), device=y.device, dtype=torch.float64)
         call("mdvit_bn_bwd", _p(g), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dg), _p(db), _p(ws), wsb,
              M, Cn, act, int(training), drop2d_p, key[0], key[1], rps, _stream())
+        if _dgrad_only:
+            dg = db = None
         return dy, dg, db, None, None, None, None, None, None, None, None, None
 
 
@@ -577,6 +600,8 @@ class _RowDot(torch.autograd.Function):
         dx = _empty((M, K), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         dw, db = _flat_like(w.reshape(-1), (1,) if ctx.has_b else None)
         call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, _p(dw), _p(db), M, K, _stream())
+        if _dgrad_only:
+            return dx, None, None
         return dx, dw.view_as(w), db
 
 
@@ -631,7 +656,11 @@ class _FactorAtt(torch.autograd.Function):
         Cn = C3 // 3
         dev = qkv.device
         dqkv = _empty_like(qkv)
-        e, *dws = _flat_like((B, Cn) if a is not None else None, w3, b3, w5, b5, w7, b7)
+        if _dgrad_only:
+            e = _empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
+            dws = [None] * 6
+        else:
+            e, *dws = _flat_like((B, Cn) if a is not None else None, w3, b3, w5, b5, w7, b7)
         wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
         ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
         call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(out), _p(U), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
@@ -643,8 +672,9 @@ class _FactorAtt(torch.autograd.Function):
             dW1, db1, dW2, db2 = _empty_like(W1), _empty_like(b1), _empty_like(W2), _empty_like(b2)
             dab = _lib.load().mdvit_da_ws_bytes(B, hid, Cn)
             daws = _empty((dab // 4,), device=dev, dtype=torch.float32)
-            call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), _p(dW1), _p(db1), _p(dW2), _p(db2),
-                 _p(daws), dab, B, label.shape[1], hid, Cn, heads, _stream())
+            # dgrad-only (aux) sweep: MINUS the adapter gradient, cancelled against the merged sweep's (see set_dgrad_only)
+            call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), -1.0 if _dgrad_only else 1.0,
+                 _p(dW1), _p(db1), _p(dW2), _p(db2), _p(daws), dab, B, label.shape[1], hid, Cn, heads, _stream())
         return (dqkv, *dws, None, dW1, db1, dW2, db2, None, None, None, None)
 
 

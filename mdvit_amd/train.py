@@ -15,6 +15,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .losses import domain_losses, seg_loss
 from .parallel import GradAccumulator, GradBucketReducer
 
@@ -25,10 +26,15 @@ def _da_params(model):
 
 def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: float = 0.5, num_domains: int = 4,
                      reducer: Optional[GradBucketReducer] = None, per_domain_backward: bool = True,
-                     use_domain_label: bool = True, accumulator: Optional[GradAccumulator] = None) -> Dict[str, torch.Tensor]:
+                     use_domain_label: bool = True, accumulator: Optional[GradAccumulator] = None,
+                     merged_sweeps: bool = False) -> Dict[str, torch.Tensor]:
     """batches: [(img (B,3,H,W), label (B,1,H,W), set_id (B,) int64)] one per domain.
     Returns the summed losses as device tensors (no host sync inside the step).
-    accumulator: fused gradient accumulation (+ overlapped all-reduce when world_size > 1), see parallel.GradAccumulator."""
+    accumulator: fused gradient accumulation (+ overlapped all-reduce when world_size > 1), see parallel.GradAccumulator.
+    merged_sweeps: same gradients as the reference's two sweeps with half the weight-gradient work.  Back-propagation
+      is linear in the upstream gradient, so  grad(aux, adapters frozen) + grad(uni)  ==  grad(aux + uni) - [adapter part of
+      grad(aux)].  Sweep 1 therefore runs data-gradients-only (no wgrad GEMMs / reductions) and hands every domain adapter
+      MINUS its aux gradient; sweep 2 is one ordinary backward of aux + uni."""
     da = _da_params(model)
     if accumulator is not None:
         accumulator.zero()
@@ -49,6 +55,14 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
             accumulator.end_sweep(last)
 
     def two_sweeps(aux_sum, uni, last):
+        if merged_sweeps:
+            ops.set_dgrad_only(True)
+            try:
+                sweep(aux_sum, False, retain=True)
+            finally:
+                ops.set_dgrad_only(False)
+            sweep(aux_sum + uni, last)
+            return
         for p in da:
             p.requires_grad = False
         sweep(aux_sum, False, retain=True)

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_sessionstart(session):
+    # the CPU oracle runs inside GPU tests too; several xdist workers x all host cores oversubscribe badly
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // 4)))
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
 

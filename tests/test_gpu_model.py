@@ -301,3 +301,22 @@ def test_forward_is_bitwise_reproducible():
         outs.append((o.clone(), a.clone(), m.stem[0].bn.running_var.clone()))
     for o, a, rv in outs[1:]:
         assert torch.equal(o, outs[0][0]) and torch.equal(a, outs[0][1]) and torch.equal(rv, outs[0][2])
+
+
+def test_merged_sweeps_equal_reference_two_sweeps():
+    """dgrad-only aux sweep + one merged sweep == the reference's two full sweeps (every parameter, incl. the
+    domain adapters that the reference freezes during the aux sweep)"""
+    from mdvit_amd.train import mdvit_train_step
+    from oracle.gen_golden import synth_image, synth_label
+    batches = [(synth_image(960 + d, 2, 64, 64).to(dev()), synth_label(970 + d, 2, 64, 64).to(dev()),
+                torch.full((2,), d, dtype=torch.long, device=dev())) for d in range(4)]
+    res = []
+    for merged in (False, True):
+        m = build_mdvit(9, 64).train()
+        out = mdvit_train_step(m, batches, optimizer=None, merged_sweeps=merged)
+        res.append((out, {n: p.grad.clone() for n, p in m.named_parameters()}))
+        assert all(p.requires_grad for p in m.parameters())
+    for k in ("loss", "aux_loss", "kt_loss"):
+        check(res[0][0][k], res[1][0][k], tol=1e-6, name=k)
+    for n in res[0][1]:
+        check_grad(res[1][1][n], res[0][1][n], name=n, l2_tol=2e-4, max_tol=2e-3)
