@@ -130,12 +130,24 @@ def main():
         roof = None
         if table:
             name, rec = max(table.items(), key=lambda kv: kv[1]["ms"])
-            tf = rec["flop"] / (rec["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
-                    "flop_per_launch": round(rec["flop"] / rec["n"]),
-                    "share_of_step": round(rec["ms"] / (dt * 1e3), 4)}
+            secs = rec["ms"] * 1e-3
+            tf, gbs = rec["flop"] / secs / 1e12, rec["bytes"] / secs / 1e9
+            # the dominant GEMM variant is priced against BOTH roofs; "bound" is the one that is closer
+            frac_mfma, frac_hbm = tf / PEAK_F32_MFMA_TFLOPS, gbs / PEAK_HBM_GBS
+            pmc = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pmc = json.load(f).get("kernels", {})
+            except Exception:
+                pass
+            traffic = pmc.get(name.split("+")[0], {}).get("hbm_bytes_per_launch")
+            if frac_hbm > frac_mfma:
+                roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+            else:
+                roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
+            roof.update({"traffic": traffic, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
+                         "flop_per_launch": round(rec["flop"] / rec["n"]), "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]),
+                         "mfma_tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "share_of_step": round(rec["ms"] / (dt * 1e3), 4)})
             if args.detail:
                 with open(args.detail, "w") as f:
                     json.dump({"step_ms": dt * 1e3 / args.steps, "kernels": table}, f, indent=1)

@@ -68,6 +68,8 @@ typedef struct MdvitGemmDesc {
     void* ws; uint64_t ws_bytes;      /* scratch for split reductions: mdvit_gemm_ws_bytes(desc) (0 = none needed) */
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
+/* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
+int mdvit_gemm_plan(const MdvitGemmDesc* desc, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,

@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
 
 _SIGS = {
     "mdvit_gemm_f32": [C.POINTER(GemmDesc), vp],
+    "mdvit_gemm_plan": [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_rowdot_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mdvit_rowdot_bwd": [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, vp],
     "mdvit_colsum_f32": [vp, i64, vp, i32, i32, f32, u32, u32, vp, i32, vp],

@@ -380,6 +380,15 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     return MDVIT_OK;
 }
 
+extern "C" int mdvit_gemm_plan(const MdvitGemmDesc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits) {
+    MDVIT_CHECK_ARG(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0, MDVIT_E_SHAPE, "gemm_plan: bad descriptor");
+    const GemmPlan pl = plan_gemm(d);
+    if (tile_m) *tile_m = pl.cfg == 0 ? 128 : (pl.cfg == 1 ? 256 : 64);
+    if (tile_n) *tile_n = pl.cfg == 0 ? 128 : 64;
+    if (splits) *splits = pl.splits;
+    return MDVIT_OK;
+}
+
 extern "C" size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* d) {
     if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     const GemmPlan pl = plan_gemm(d);

@@ -126,11 +126,18 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     if _events is None:
         call("mdvit_gemm_f32", C.byref(d), _stream())
         return
+    tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+    call("mdvit_gemm_plan", C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     call("mdvit_gemm_f32", C.byref(d), _stream())
     e1.record()
-    _events.append((_gemm_kernel_name(M, N, trans_a, trans_b), 2.0 * M * N * K, e0, e1))
+    waves = {128: "2, 2", 256: "4, 1", 64: "2, 2"}[tm.value]       # kernel symbol as rocprofv3 prints it
+    name = "gemm_f32_kernel<%d, %d, %s, %s, %s>%s" % (tm.value, tn.value, waves, "true" if trans_a else "false",
+                                                     "true" if trans_b else "false", "+splitk_reduce" if sp.value > 1 else "")
+    # algorithmic HBM bytes of the launch: A, B read once, C (and C2 / residual / gelu_u) once
+    nbytes = 4.0 * (M * K + N * K + M * N * (1 + (out2 is not None) + (residual is not None) + (gelu_u is not None)))
+    _events.append((name, 2.0 * M * N * K, nbytes, e0, e1))
 
 
 # ---- optional per-kernel timing (bench.py): HIP events on the launch stream around each GEMM ------
@@ -150,16 +157,13 @@ def kernel_events_end():
         return {}
     torch.cuda.synchronize()
     table = {}
-    for name, flop, e0, e1 in ev:
-        r = table.setdefault(name, {"n": 0, "ms": 0.0, "flop": 0.0})
+    for name, flop, nbytes, e0, e1 in ev:
+        r = table.setdefault(name, {"n": 0, "ms": 0.0, "flop": 0.0, "bytes": 0.0})
         r["n"] += 1
         r["ms"] += e0.elapsed_time(e1)
         r["flop"] += flop
+        r["bytes"] += nbytes
     return table
-
-
-def _gemm_kernel_name(M, N, trans_a, trans_b):
-    return "gemm_f32_kernel<%s,%s>" % ("T" if trans_a else "N", "T" if trans_b else "N")
 
 
 def _ld_view(t: torch.Tensor) -> Tuple[int, int, int]:
