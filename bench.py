@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="mdvit", choices=["mdvit", "base"])
+    ap.add_argument("--no-side-stream", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-sweeps", action="store_true", help="run the reference's literal two full sweeps instead of the merged (linear-algebra-equivalent) form")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -91,7 +92,10 @@ def main():
         domains, flop_per_img = (0,), 137.7e9
     broadcast_parameters(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    if world == 1 and not args.no_side_stream:
+        ops.enable_side_stream(True)      # wgrad kernels overlap the dgrad chain (DP ranks keep in-place hooks for the all-reduce overlap)
     accum = GradAccumulator(model.parameters())       # fused accumulation; overlapped bucketed all-reduce when world > 1
+    accum.attach_sinks()                              # wgrad GEMMs add straight into the gradient buckets
     # a small pool of distinct synthetic steps, resident in HBM before timing
     pool = [make_step_batches(args.batch, args.size, rank=rank, step=s, device=dev, domains=domains) for s in range(2)]
 

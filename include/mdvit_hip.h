@@ -66,6 +66,7 @@ typedef struct MdvitGemmDesc {
     const float* gelu_u; int64_t ldu;
     int32_t allow_split;
     void* ws; uint64_t ws_bytes;      /* scratch for split reductions: mdvit_gemm_ws_bytes(desc) (0 = none needed) */
+    int32_t accumulate;               /* C += result (gradient accumulation straight into a persistent buffer) */
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
@@ -82,7 +83,7 @@ int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, const float* d
 /* out[n] = sum_m A[m][n] * (optional dropmask x rowscale, as the GEMM A prologue): bias gradients. */
 int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N,
                      float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale,
-                     void* stream);
+                     int32_t accumulate, void* stream);
 
 /* ---- LayerNorm over C (nn.LayerNorm eps=1e-6, mdvit.py:327,342,498) ------------------------- */
 int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

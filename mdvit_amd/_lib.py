@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("gelu_u", vp), ("ldu", i64),
         ("allow_split", i32),
         ("ws", vp), ("ws_bytes", C.c_uint64),
+        ("accumulate", i32),
     ]
 
 
@@ -48,7 +49,7 @@ _SIGS = {
     "mdvit_gemm_plan": [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_rowdot_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mdvit_rowdot_bwd": [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, vp],
-    "mdvit_colsum_f32": [vp, i64, vp, i32, i32, f32, u32, u32, vp, i32, vp],
+    "mdvit_colsum_f32": [vp, i64, vp, i32, i32, f32, u32, u32, vp, i32, i32, vp],
     "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "mdvit_dwconv3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

@@ -33,6 +33,7 @@ struct GemmArgs {
     const float* gelu_u; long ldu;
     int splits; int k_per_split;   // split along K: each split writes a dense [M,N] slab, reduced by a second kernel
     float* slab;
+    int accumulate;
     int tiles_m, tiles_n;
 };
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     // m = lane&31  ->  one 16-byte store per quad instead of four scalar stores.
     const bool split = p.splits > 1;
     const bool add_bias = p.bias != nullptr && !split;
-    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0);
+    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
     float* slab = split ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
@@ -262,6 +263,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                         for (int t = 0; t < 4; ++t) if (t < nv) v[t] += rp[t];
                     }
                 }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] += dst[t];
+                }
                 if (vec) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 else {
 #pragma unroll
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
 
 // C[m][n] = sum_s slab[s][m][n] (+ bias[n]); fixed summation order -> deterministic
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
-                                                                 float* __restrict__ C, long ldc, int M, int N, int splits) {
+                                                                 float* __restrict__ C, long ldc, int M, int N, int splits, int accumulate) {
     const int NQ = N >> 2;
     const long total = (long)M * NQ, MN = (long)M * N;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         float* dst = C + m * ldc + n;
-        if ((ldc & 3) == 0) *reinterpret_cast<float4*>(dst) = acc;
+        if (accumulate) { acc.x += dst[0]; acc.y += dst[1]; acc.z += dst[2]; acc.w += dst[3]; }
+        if (((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) *reinterpret_cast<float4*>(dst) = acc;
         else { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
     }
 }
@@ -359,6 +365,8 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.e_thresh = (uint32_t)((double)d->e_drop_p * 4294967296.0); a.e_inv_keep = 1.f / (1.f - d->e_drop_p);
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
+    a.accumulate = d->accumulate;
+    MDVIT_CHECK_ARG(!(d->accumulate && d->epi == MDVIT_EPI_GELU_DUAL), MDVIT_E_SHAPE, "gemm: accumulate is not defined for GELU_DUAL");
 
     const GemmPlan pl = plan_gemm(d);
     a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;
@@ -374,7 +382,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     if (pl.splits > 1) {
         const long total = (long)d->M * d->N / 4;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)min((total + 255) / 256, 4096L)), dim3(256), 0, s,
-                           a.slab, d->bias, d->C, (long)d->ldc, d->M, d->N, pl.splits);
+                           a.slab, d->bias, d->C, (long)d->ldc, d->M, d->N, pl.splits, d->accumulate);
     }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;

@@ -463,10 +463,10 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
 }
 
 extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N, float drop_p, uint32_t key0, uint32_t key1,
-                                const float* rowscale, int32_t rows_per_scale, void* stream) {
+                                const float* rowscale, int32_t rows_per_scale, int32_t accumulate, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && N <= 8192 && lda % 4 == 0, MDVIT_E_SHAPE, "colsum: need N %% 4 == 0 (M=%d N=%d)", M, N);
-    MDVIT_ZERO(out, sizeof(float) * N, s);
+    if (!accumulate) MDVIT_ZERO(out, sizeof(float) * N, s);
     ChanArgs a; memset(&a, 0, sizeof(a));
     a.a = A; a.lda = lda; a.M = M; a.C = N; a.out = out;
     fill_drop(a, drop_p, key0, key1, 1);

@@ -78,6 +78,72 @@ def set_dgrad_only(flag: bool):
     _dgrad_only = bool(flag)
 
 
+# ---- second stream for weight gradients ---------------------------------------------------------------
+# wgrad GEMMs / reductions are leaves of the backward graph: nothing in the sweep consumes them.  At small batch
+# they use a fraction of the 256 CUs, so they are issued on a side HIP stream and overlap with the dgrad chain on
+# the main stream.  Whoever consumes the gradients calls join_side_stream() first (mdvit_amd.train does).
+_side_stream = None
+
+
+def enable_side_stream(flag: bool = True):
+    global _side_stream
+    _side_stream = torch.cuda.Stream() if flag else None
+
+
+# ---- gradient sinks: leaf parameter -> persistent accumulation buffer ---------------------------------------
+# When a sink is registered for a weight (mdvit_amd.parallel.GradAccumulator does it), its gradient is ADDED into
+# the sink by the wgrad kernel itself -- on the side stream when enabled -- and autograd receives None for it:
+# no gradient tensor ever crosses streams, and there is no per-parameter accumulation kernel.
+_sinks = {}
+
+
+def set_grad_sinks(sinks):
+    """sinks: {parameter: tensor of the same shape to accumulate into}, or None/{} to disable."""
+    global _sinks
+    _sinks = {} if not sinks else {(p.data_ptr(), p.numel()): v for p, v in sinks.items()}
+
+
+def _sink_of(t):
+    if not _sinks or t is None or t.grad_fn is not None or not t.is_contiguous():
+        return None
+    return _sinks.get((t.data_ptr(), t.numel()))
+
+
+_side_keepalive = []     # tensors the side stream still reads; holding a reference also stops autograd from
+                         # accumulating into them IN PLACE on the main stream (it only does so when it is the sole owner)
+
+
+def join_side_stream():
+    if _side_stream is not None:
+        torch.cuda.current_stream().wait_stream(_side_stream)
+        _side_keepalive.clear()
+
+
+class _on_side:
+    """with _on_side(t1, t2, ...): launches go to the side stream, ordered after everything already enqueued on the
+    main stream; the listed main-stream tensors are protected from reuse until the side work is done."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        if _side_stream is None:
+            return self
+        _side_stream.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            t.record_stream(_side_stream)
+        _side_keepalive.extend(self.tensors)
+        self.ctx = torch.cuda.stream(_side_stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _flat_like(*protos):
     """Allocate the (small) outputs of one op as slices of ONE buffer, in order, so the library can clear them
     with a single zero-fill launch.  protos: tensors (shape donors) or shapes; None entries pass through."""
@@ -102,7 +168,7 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
          a_drop=0.0, a_key=(0, 0), a_rowscale=None, a_rows_per_scale=1,
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
-         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False):
+         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False):
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = A, B, out, out2
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
@@ -117,6 +183,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.residual, d.ldr = residual, ldr
     d.gelu_u, d.ldu = gelu_u, ldu
     d.allow_split = int(allow_split)
+    d.accumulate = int(accumulate)
     ws = None
     if allow_split:
         need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
@@ -167,7 +234,10 @@ def kernel_events_end():
 
 
 def _ld_view(t: torch.Tensor) -> Tuple[int, int, int]:
-    """(rows, cols, leading dim) of a 2-D tensor whose rows are contiguous (column slices allowed)."""
+    """(rows, cols, leading dim) of a 2-D tensor whose rows are contiguous (column slices allowed); a contiguous
+    conv weight [out, in, kh, kw] is read as [out, in*kh*kw] (so leaf conv weights reach the op un-viewed)."""
+    if t.dim() == 4 and t.is_contiguous():
+        return t.shape[0], t.numel() // t.shape[0], t.numel() // t.shape[0]
     if t.dim() != 2 or t.stride(1) != 1:
         raise _lib.MdvitHipError("expected a 2-D row-contiguous tensor")
     return t.shape[0], t.shape[1], t.stride(0)
@@ -192,6 +262,7 @@ class _Linear(torch.autograd.Function):
              residual=_p(residual), ldr=N, allow_split=True)
         ctx.save_for_backward(x, W, rowscale)
         ctx.meta = (drop_p, key, rows_per_scale, b is not None, residual is not None)
+        ctx.bias_ref = b if (b is not None and b.grad_fn is None) else None      # leaf bias: only to look up its gradient sink
         return y
 
     @staticmethod
@@ -208,12 +279,25 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _empty_like(x)
             gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, allow_split=True, **pro)
-        if ctx.needs_input_grad[1] and not _dgrad_only:
-            dW = _empty((N, K), device=x.device, dtype=torch.float32)
-            gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
-        if has_b and ctx.needs_input_grad[2] and not _dgrad_only:
-            db = _empty((N,), device=x.device, dtype=torch.float32)
-            call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, _stream())
+        if not _dgrad_only and (ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2])):
+            sW = _sink_of(W)
+            sb = _sink_of(ctx.bias_ref) if has_b else None
+            if sW is not None and (not has_b or sb is not None):
+                # accumulate straight into the gradient buckets (side stream if enabled); autograd gets None
+                with _on_side(g, x, rowscale):
+                    gemm(_p(g), _p(x), _p(sW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, accumulate=True, **pro)
+                    if has_b:
+                        db, acc_b = sb, True
+                        call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _stream())
+                        db = None
+            else:
+                acc_b = False
+                if ctx.needs_input_grad[1]:
+                    dW = _empty(tuple(W.shape) if W.dim() == 4 else (N, K), device=x.device, dtype=torch.float32)
+                    gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
+                if has_b and ctx.needs_input_grad[2]:
+                    db = _empty((N,), device=x.device, dtype=torch.float32)
+                    call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _stream())
         return dx, dW, db, (g if has_res else None), None, None, None
 
 
@@ -221,8 +305,8 @@ def linear(x, W, b=None, residual=None, rowscale=None, drop_p: float = 0.0, rows
     """x: [..., K] -> [..., N].  W [N,K] may be a view with W.stride(1)==1 (column slice of a wider matrix)."""
     shp = x.shape
     x2 = _c(x).view(-1, shp[-1])
-    if W.dim() == 4:
-        W = W.view(W.shape[0], -1)
+    if W.dim() == 4 and not W.is_contiguous():
+        W = W.reshape(W.shape[0], -1)
     r2 = None if residual is None else _c(residual).view(-1, W.shape[0])
     y = _Linear.apply(x2, W, b, r2, rowscale, float(drop_p), int(rows_per_scale))
     return y.view(*shp[:-1], W.shape[0])
@@ -287,6 +371,7 @@ class _MlpResidual(torch.autograd.Function):
              e_drop=drop_p, e_key=k2, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale, residual=_p(res), ldr=Cin)
         ctx.save_for_backward(x, u, h, W1, W2, rowscale)
         ctx.meta = (drop_p, k1, k2, rows_per_scale)
+        ctx.b1_ref, ctx.b2_ref = b1, b2           # leaf biases: only to look up their gradient sinks
         return out
 
     @staticmethod
@@ -305,17 +390,28 @@ class _MlpResidual(torch.autograd.Function):
         gemm(_p(g), _p(W2), _p(du), M, Hd, Cin, lda=Cin, ldb=Hd, ldc=Hd, trans_b=False,
              epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1, **pro)
         dW1 = db1 = dW2 = db2 = None
-        if not _dgrad_only:
-            dW2 = _empty_like(W2)
-            gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
-            db2 = _empty((Cin,), device=dev, dtype=torch.float32)
-            call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, _stream())
-            dW1 = _empty_like(W1)
-            gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
-            db1 = _empty((Hd,), device=dev, dtype=torch.float32)
-            call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, _stream())
         dx = _empty_like(x)
         gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False, allow_split=True)
+        if not _dgrad_only:
+            sinks = [_sink_of(t) for t in (W1, ctx.b1_ref, W2, ctx.b2_ref)]
+            sunk = all(t is not None for t in sinks)
+            if sunk:
+                dW1_, db1, dW2_, db2 = sinks
+                with _on_side(g, h, du, x, rowscale):
+                    gemm(_p(g), _p(h), _p(dW2_), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, accumulate=True, **pro)
+                    call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _stream())
+                    gemm(_p(du), _p(x), _p(dW1_), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
+                    call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), _stream())
+                dW1 = db1 = dW2 = db2 = None
+            else:
+                dW2 = _empty_like(W2)
+                gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
+                db2 = _empty((Cin,), device=dev, dtype=torch.float32)
+                call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _stream())
+                dW1 = _empty_like(W1)
+                gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
+                db1 = _empty((Hd,), device=dev, dtype=torch.float32)
+                call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), _stream())
         return dx, g, dW1, db1, dW2, db2, None, None, None
 
 
@@ -387,8 +483,12 @@ class _DwConv3x3(torch.autograd.Function):
         g = _c(g)
         B, H, W_, Cn = x.shape
         dx = _empty_like(x) if ctx.needs_input_grad[0] else None
-        dw, db = (None, None) if _dgrad_only else _flat_like(w, (Cn,) if has_b else None)
-        call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), _p(dw), _p(db), B, H, W_, Cn, stride, int(add_input), _stream())
+        dw = db = None
+        if dx is not None:
+            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), None, None, B, H, W_, Cn, stride, int(add_input), _stream())
+        if not _dgrad_only:
+            dw, db = _flat_like(w, (Cn,) if has_b else None)
+            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), None, _p(dw), _p(db), B, H, W_, Cn, stride, int(add_input), _stream())
         return dx, dw, db, None, None
 
 
@@ -454,7 +554,7 @@ def conv3x3_dense(x, w, bias=None, stride=1):
     B, H, W_, Cn = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
     col = _Im2col.apply(_c(x), int(stride))
-    y = _Linear.apply(col, w.view(w.shape[0], -1), bias, None, None, 0.0, 1)
+    y = _Linear.apply(col, w if w.is_contiguous() else w.reshape(w.shape[0], -1), bias, None, None, 0.0, 1)
     return y.view(B, Ho, Wo, w.shape[0])
 
 

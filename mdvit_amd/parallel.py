@@ -35,20 +35,23 @@ class GradBucketReducer:
         cur, cur_elems = [], 0
         groups = []
         limit = max(1, bucket_bytes // 4)
+        def slot(p):                      # every gradient view starts on a 64-byte boundary (kernels store 16 B vectors)
+            return (p.numel() + 15) // 16 * 16
+
         for p in order:
-            if cur and cur_elems + p.numel() > limit:
+            if cur and cur_elems + slot(p) > limit:
                 groups.append(cur); cur, cur_elems = [], 0
-            cur.append(p); cur_elems += p.numel()
+            cur.append(p); cur_elems += slot(p)
         if cur:
             groups.append(cur)
         for bi, grp in enumerate(groups):
-            n = sum(p.numel() for p in grp)
+            n = sum(slot(p) for p in grp)
             flat = torch.zeros(n, dtype=grp[0].dtype, device=grp[0].device)
             off = 0
             for p in grp:
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 self._bucket_of[p] = bi
-                off += p.numel()
+                off += slot(p)
             self.buckets.append(flat)
             self._bucket_sizes.append(len(grp))
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
@@ -117,6 +120,12 @@ class GradAccumulator:
         self.views = [p.grad for p in self.params]          # views into the flat buckets
         for p in self.params:
             p.grad = None
+        self.sinks = {p: v for p, v in zip(self.params, self.views) if p.is_cuda}
+
+    def attach_sinks(self, flag: bool = True):
+        """Let the HIP wgrad kernels add weight gradients straight into the buckets (mdvit_amd.ops.set_grad_sinks)."""
+        from . import ops
+        ops.set_grad_sinks(self.sinks if flag else None)
 
     @property
     def world(self):
@@ -128,7 +137,10 @@ class GradAccumulator:
             p.grad = None
 
     def begin_sweep(self, last: bool):
-        if last:
+        # With a single rank there is nothing to overlap: every sweep (the last one too) is folded in by one
+        # multi-tensor add, which also lets weight gradients be produced on a side stream (ops.enable_side_stream).
+        self._hooked = last and self.world > 1
+        if self._hooked:
             for p, v in zip(self.params, self.views):
                 p.grad = v
             self.reducer.arm()
@@ -137,7 +149,7 @@ class GradAccumulator:
                 p.grad = None
 
     def end_sweep(self, last: bool):
-        if last:
+        if self._hooked:
             self.reducer.finish()
             return
         dst, src = [], []
@@ -146,8 +158,12 @@ class GradAccumulator:
                 dst.append(v); src.append(p.grad)
         if dst:
             torch._foreach_add_(dst, src)
-        for p in self.params:
-            p.grad = None
+        if last:                      # hand the accumulated gradients to the optimizer
+            for p, v in zip(self.params, self.views):
+                p.grad = v
+        else:
+            for p in self.params:
+                p.grad = None
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):

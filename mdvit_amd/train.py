@@ -51,6 +51,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
         elif last and reducer is not None:
             reducer.arm()
         loss.backward(retain_graph=retain)
+        ops.join_side_stream()          # weight gradients may have been produced on the side stream
         if accumulator is not None:
             accumulator.end_sweep(last)
 
@@ -121,6 +122,7 @@ def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Op
         elif reducer is not None and last:
             reducer.arm()
         l.backward()
+        ops.join_side_stream()
         if accumulator is not None:
             accumulator.end_sweep(last)
         tot = l.detach() if tot is None else tot + l.detach()

@@ -320,3 +320,29 @@ def test_merged_sweeps_equal_reference_two_sweeps():
         check(res[0][0][k], res[1][0][k], tol=1e-6, name=k)
     for n in res[0][1]:
         check_grad(res[1][1][n], res[0][1][n], name=n, l2_tol=2e-4, max_tol=2e-3)
+
+
+def test_side_stream_wgrad_matches_single_stream():
+    """weight gradients issued on the side HIP stream (joined before use) == everything on one stream"""
+    from mdvit_amd import ops
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.train import mdvit_train_step
+    from oracle.gen_golden import synth_image, synth_label
+    batches = [(synth_image(980 + d, 2, 64, 64).to(dev()), synth_label(990 + d, 2, 64, 64).to(dev()),
+                torch.full((2,), d, dtype=torch.long, device=dev())) for d in range(4)]
+    res = []
+    try:
+        for side in (False, True):
+            ops.enable_side_stream(side)
+            m = build_mdvit(13, 64).train()
+            acc = GradAccumulator(m.parameters())
+            acc.attach_sinks(side)      # side run: wgrad GEMMs accumulate straight into the buckets on the side stream
+            for _ in range(2):          # twice: exercises buffer reuse across steps
+                mdvit_train_step(m, batches, optimizer=None, accumulator=acc, merged_sweeps=True)
+            torch.cuda.synchronize()
+            res.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        ops.enable_side_stream(False)
+        ops.set_grad_sinks(None)
+    for n in res[0]:
+        check_grad(res[1][n], res[0][n], name=n, l2_tol=2e-4, max_tol=2e-3)
