@@ -34,6 +34,7 @@ struct GemmArgs {
     int splits; int k_per_split;   // split along K: each split writes a dense [M,N] slab, reduced by a second kernel
     float* slab;
     int accumulate;
+    int vec;                       // output rows can take 16-byte vector accesses
     int tiles_m, tiles_n;
 };
 
@@ -43,7 +44,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+// EPI (compile time, so every instantiation carries only its own epilogue -- the unrolled epilogue of a single
+// do-everything kernel was ~20k instructions, far beyond the instruction cache):
+//   0 PLAIN  : (+bias) | split slab | accumulate        1 GELU_DUAL    2 DGELU (x dropout mask)
+//   3 FULL   : +bias, dropout, DropPath row scale, +residual
+// APRO: dropout-mask x row-scale prologue on the A operand (backward GEMMs).
+enum { EPI_PLAIN = 0, EPI_GELU2 = 1, EPI_DGELU = 2, EPI_FULL = 3 };
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI, bool APRO>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     // k-contiguous operands are transposed on the LDS write: odd leading dimension -> conflict-free ds_write_b32;
     // m/n-contiguous operands are written as float4: leading dimension % 4 == 0.
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 const int r = tid / KT + v * (NTHREADS / KT), m = m0 + r, k = k0 + (tid % KT) * 4;
                 if (m < p.M && k < kend) {
                     x = *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k);
-                    if (p.a_drop | (p.a_rowscale != nullptr)) {
+                    if (APRO) {
                         float rs = p.a_rowscale ? p.a_rowscale[m / p.a_rows_per_scale] : 1.f;
                         if (p.a_drop) {
                             const uint32_t idx = (uint32_t)((long)m * p.K + k);
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, m = m0 + (tid % TPR) * 4;
                 if (k < kend && m < p.M) {
                     x = *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m);
-                    if (p.a_drop | (p.a_rowscale != nullptr)) {
+                    if (APRO) {
                         // the stored tensor is [k][m] = dY[token k][feature m]; mask index = k*M + m
                         float rs = p.a_rowscale ? p.a_rowscale[k / p.a_rows_per_scale] : 1.f;
                         if (p.a_drop) {
@@ -188,90 +196,73 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     // ---- epilogue.  The MFMA ran as D = B^T-tile x A-tile, so D[row = n][col = m]: lane holds, for each
     // register quad q = r>>2, FOUR CONSECUTIVE output columns n = 8q + 4*(lane>>5) + (r&3) of output row
     // m = lane&31  ->  one 16-byte store per quad instead of four scalar stores.
-    const bool split = p.splits > 1;
-    const bool add_bias = p.bias != nullptr && !split;
-    const bool vec = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    const bool split = (EPI == EPI_PLAIN) && p.splits > 1;
     float* slab = split ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
         const int row = m0 + wm0 + i * 32 + l31;
         if (row >= p.M) continue;
-        const float rsc = p.e_rowscale ? p.e_rowscale[row / p.e_rows_per_scale] : 1.f;
+        float rsc = 1.f;
+        if (EPI == EPI_FULL) rsc = p.e_rowscale ? p.e_rowscale[row / p.e_rows_per_scale] : 1.f;
 #pragma unroll
         for (int j = 0; j < WTN; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = n0 + wn0 + j * 32 + 8 * q + 4 * lhi;
                 if (col >= p.N) continue;
-                float v[4] = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (split) {          // N % 4 == 0 is guaranteed by the planner for split launches
-                    *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    continue;
-                }
-                const int nv = min(4, p.N - col);
-                if (add_bias) {
-                    if (vec) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
-                    else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) if (t < nv) v[t] += p.bias[col + t];
-                    }
-                }
+                float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 float* dst = p.C + (long)row * p.ldc + col;
-                const uint32_t didx = (uint32_t)((long)row * p.N + col);
-                if (p.epi == MDVIT_EPI_GELU_DUAL) {
-                    float h[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        h[t] = gelu_f(v[t]);
-                        if (p.e_drop) h[t] *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + t, p.e_thresh, p.e_inv_keep);
-                    }
-                    float* dst2 = p.C2 + (long)row * p.ldc + col;
-                    if (vec) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(dst2) = make_float4(h[0], h[1], h[2], h[3]);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) if (t < nv) { dst[t] = v[t]; dst2[t] = h[t]; }
+                if (EPI == EPI_PLAIN) {
+                    if (split) { *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = v; continue; }
+                    if (p.vec) {
+                        if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                        if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                        *reinterpret_cast<float4*>(dst) = v;
+                    } else {                 // generic (unaligned / N % 4 != 0) path, deliberately not unrolled
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+                        const int nv = min(4, p.N - col);
+#pragma unroll 1
+                        for (int t = 0; t < nv; ++t) {
+                            float o = vv[t] + (p.bias ? p.bias[col + t] : 0.f);
+                            if (p.accumulate) o += dst[t];
+                            dst[t] = o;
+                        }
                     }
                     continue;
                 }
-                if (p.epi == MDVIT_EPI_DGELU) {
-                    const float* up = p.gelu_u + (long)row * p.ldu + col;
-                    if (vec && ((p.ldu & 3) == 0)) {
-                        const float4 u4 = *reinterpret_cast<const float4*>(up);
-                        v[0] *= gelu_grad_f(u4.x); v[1] *= gelu_grad_f(u4.y); v[2] *= gelu_grad_f(u4.z); v[3] *= gelu_grad_f(u4.w);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) if (t < nv) v[t] *= gelu_grad_f(up[t]);
+                // EPI 1..3 require the vector layout (host-checked)
+                if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                const uint32_t didx = (uint32_t)((long)row * p.N + col);
+                if (EPI == EPI_GELU2) {
+                    float4 h = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                    if (p.e_drop) {
+                        h.x *= mdvit_drop_scale(p.e_k0, p.e_k1, didx, p.e_thresh, p.e_inv_keep);
+                        h.y *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 1, p.e_thresh, p.e_inv_keep);
+                        h.z *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 2, p.e_thresh, p.e_inv_keep);
+                        h.w *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 3, p.e_thresh, p.e_inv_keep);
                     }
+                    *reinterpret_cast<float4*>(dst) = v;
+                    *reinterpret_cast<float4*>(p.C2 + (long)row * p.ldc + col) = h;
+                    continue;
+                }
+                if (EPI == EPI_DGELU) {
+                    const float4 u4 = *reinterpret_cast<const float4*>(p.gelu_u + (long)row * p.ldu + col);
+                    v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
                 }
                 if (p.e_drop) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + t, p.e_thresh, p.e_inv_keep);
+                    v.x *= mdvit_drop_scale(p.e_k0, p.e_k1, didx, p.e_thresh, p.e_inv_keep);
+                    v.y *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 1, p.e_thresh, p.e_inv_keep);
+                    v.z *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 2, p.e_thresh, p.e_inv_keep);
+                    v.w *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 3, p.e_thresh, p.e_inv_keep);
                 }
-                if (p.e_rowscale) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] *= rsc;
-                }
-                if (p.residual) {
-                    const float* rp = p.residual + (long)row * p.ldr + col;
-                    if (vec && ((p.ldr & 3) == 0)) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(rp);
-                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) if (t < nv) v[t] += rp[t];
+                if (EPI == EPI_FULL) {
+                    v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+                    if (p.residual) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col);
+                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                     }
                 }
-                if (p.accumulate) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (t < nv) v[t] += dst[t];
-                }
-                if (vec) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (t < nv) dst[t] = v[t];
-                }
+                *reinterpret_cast<float4*>(dst) = v;
             }
         }
     }
@@ -299,12 +290,28 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_cfg(const GemmArgs& a, int ta, int tb, hipStream_t s) {
+int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, bool apro, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(NTHREADS);
-    if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, a);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, a);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, a);
+#define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_, APRO_) \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_, APRO_>), grid, block, 0, s, a)
+    if (!ta && tb) {                                   // forward (weights [N,K])
+        if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2, false);
+        else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL, false);
+        else if (epi == EPI_PLAIN && !apro) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, false);
+        else if (epi == EPI_PLAIN && apro) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, true);
+        else return 1;
+    } else if (!ta && !tb) {                           // dgrad
+        if (epi == EPI_DGELU) { if (apro) MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU, true); else MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU, false); }
+        else if (epi == EPI_PLAIN) { if (apro) MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN, true); else MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN, false); }
+        else if (epi == EPI_FULL && !apro) MDVIT_GEMM_LAUNCH(false, false, EPI_FULL, false);
+        else return 1;
+    } else if (ta && !tb) {                            // wgrad
+        if (epi != EPI_PLAIN) return 1;
+        if (apro) MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN, true); else MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN, false);
+    } else {
+        return 1;
+    }
+#undef MDVIT_GEMM_LAUNCH
     return 0;
 }
 
@@ -366,7 +373,6 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
     a.accumulate = d->accumulate;
-    MDVIT_CHECK_ARG(!(d->accumulate && d->epi == MDVIT_EPI_GELU_DUAL), MDVIT_E_SHAPE, "gemm: accumulate is not defined for GELU_DUAL");
 
     const GemmPlan pl = plan_gemm(d);
     a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;
@@ -375,10 +381,28 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
         MDVIT_CHECK_ARG(d->ws != nullptr && d->ws_bytes >= need, MDVIT_E_WORKSPACE,
                         "gemm: split reduction needs %zu bytes of workspace (mdvit_gemm_ws_bytes), got %zu", need, (size_t)d->ws_bytes);
         a.slab = (float*)d->ws;
+        a.bias = nullptr;                 // the reduce kernel adds the bias
     }
-    if (pl.cfg == 0) launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, s);
-    else if (pl.cfg == 1) launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, s);
-    else launch_cfg<64, 64, 2, 2>(a, d->trans_a, d->trans_b, s);
+    // epilogue kind
+    int epi = EPI_PLAIN;
+    if (d->epi == MDVIT_EPI_GELU_DUAL) epi = EPI_GELU2;
+    else if (d->epi == MDVIT_EPI_DGELU) epi = EPI_DGELU;
+    else if (a.e_drop || d->e_rowscale || d->residual) epi = EPI_FULL;
+    const bool apro = a.a_drop || d->a_rowscale != nullptr;
+    a.vec = ((d->N & 3) == 0) && ((d->ldc & 3) == 0) && aligned16(d->C);
+    if (epi != EPI_PLAIN) {
+        MDVIT_CHECK_ARG(a.vec && (!d->bias || aligned16(d->bias)) && (!d->C2 || aligned16(d->C2)) &&
+                        (!d->residual || (aligned16(d->residual) && d->ldr % 4 == 0)) && (!d->gelu_u || (aligned16(d->gelu_u) && d->ldu % 4 == 0)),
+                        MDVIT_E_ALIGN, "gemm: fused epilogues need N %% 4 == 0 and 16-byte aligned C / bias / residual / gelu_u rows");
+        MDVIT_CHECK_ARG(!d->accumulate, MDVIT_E_SHAPE, "gemm: accumulate is only defined for the plain epilogue");
+    } else if (d->bias && !aligned16(d->bias)) {
+        a.vec = 0;
+    }
+    int rc;
+    if (pl.cfg == 0) rc = launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, epi, apro, s);
+    else if (pl.cfg == 1) rc = launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, epi, apro, s);
+    else rc = launch_cfg<64, 64, 2, 2>(a, d->trans_a, d->trans_b, epi, apro, s);
+    MDVIT_CHECK_ARG(rc == 0, MDVIT_E_SHAPE, "gemm: this (trans_a=%d, trans_b=%d, epilogue=%d, a_prologue=%d) combination is not built", d->trans_a, d->trans_b, epi, (int)apro);
     if (pl.splits > 1) {
         const long total = (long)d->M * d->N / 4;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)min((total + 255) / 256, 4096L)), dim3(256), 0, s,

@@ -24,8 +24,8 @@ def make_domain_batch(B: int, S: int, domain: int, seed: int, device="cpu") -> T
     xx = torch.arange(S).view(1, 1, S).float()
     lab = ((((yy - cy.view(B, 1, 1)) / ry.view(B, 1, 1)) ** 2 + ((xx - cx.view(B, 1, 1)) / rx.view(B, 1, 1)) ** 2) <= 1.0)
     lab = lab.float().view(B, 1, S, S)
-    set_id = torch.full((B,), domain, dtype=torch.long)
-    return img.to(device), lab.to(device), set_id.to(device)
+    set_id = torch.full((B,), domain, dtype=torch.long)      # stays on the host, as batch['set_id'] from the DataLoader does
+    return img.to(device), lab.to(device), set_id
 
 
 def make_step_batches(B: int, S: int, rank: int = 0, step: int = 0, device="cpu", domains=(0, 1, 2, 3)) -> List[tuple]:

@@ -74,9 +74,13 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
     tot = tot_aux = tot_kt = None
     stash = []
     for i, (img, label, set_id) in enumerate(batches):
-        d = str(int(set_id[0]))      # set_id is created on the host side of the loader (multi_train_MDViT.py:137-138)
+        # set_id is a HOST tensor, as from the DataLoader (multi_train_MDViT.py:137-139): reading set_id[0] must not
+        # synchronise the GPU stream -- the host keeps enqueueing the next domain while the GPU works on this one
+        if set_id.is_cuda:
+            set_id = set_id.cpu()
+        d = str(int(set_id[0]))
         if use_domain_label:
-            domain_label = F.one_hot(set_id, num_domains).float()
+            domain_label = F.one_hot(set_id, num_domains).float().to(img.device, non_blocking=True)
             out, aux = model(img, domain_label, d)
         else:
             out, aux = model(img, d=d)
@@ -112,7 +116,7 @@ def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Op
     tot = None
     for i, (img, label, set_id) in enumerate(batches):
         if use_domain_label:
-            out = model(img, F.one_hot(set_id, num_domains).float())
+            out = model(img, F.one_hot(set_id.cpu(), num_domains).float().to(img.device, non_blocking=True))
         else:
             out = model(img)
         l = seg_loss(out, label)
