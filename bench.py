@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="mdvit", choices=["mdvit", "base"])
     ap.add_argument("--no-side-stream", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
+    ap.add_argument("--fuse-images", type=int, default=32,
+                    help="domain batches are fused into one domain-batched forward while the fused batch stays <= this many images (0: one forward per domain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-sweeps", action="store_true", help="run the reference's literal two full sweeps instead of the merged (linear-algebra-equivalent) form")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -91,7 +94,7 @@ def main():
         model = mdvit_amd.BASE(drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method=False).to(dev).train()
         domains, flop_per_img = (0,), 137.7e9
     broadcast_parameters(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True, capturable=args.graph)
     if world == 1 and not args.no_side_stream:
         ops.enable_side_stream(True)      # wgrad kernels overlap the dgrad chain (DP ranks keep in-place hooks for the all-reduce overlap)
     accum = GradAccumulator(model.parameters())       # fused accumulation; overlapped bucketed all-reduce when world > 1
@@ -99,11 +102,25 @@ def main():
     # a small pool of distinct synthetic steps, resident in HBM before timing
     pool = [make_step_batches(args.batch, args.size, rank=rank, step=s, device=dev, domains=domains) for s in range(2)]
 
+    fuse = max(1, min(len(domains), args.fuse_images // max(1, args.batch))) if args.model == "mdvit" else 1
+
+    def step_batches(b):
+        if args.model == "mdvit":
+            return mdvit_train_step(model, b, optimizer=opt, accumulator=accum, merged_sweeps=not args.reference_sweeps, fuse_domains=fuse)
+        return base_train_step(model, b, optimizer=opt, accumulator=accum)
+
     def step(i):
         b = pool[i % len(pool)]
-        if args.model == "mdvit":
-            return mdvit_train_step(model, b, optimizer=opt, accumulator=accum, merged_sweeps=not args.reference_sweeps)
-        return base_train_step(model, b, optimizer=opt, accumulator=accum)
+        return graphed(b) if graphed is not None else step_batches(b)
+
+    graphed = None
+    if args.graph:
+        from mdvit_amd.graph import GraphedStep
+        try:
+            graphed = GraphedStep(lambda b: step_batches(b), pool[0], warmup=2, fuse_domains=fuse)
+        except Exception as e:                     # report and continue eagerly: the numbers stay valid, just host-bound
+            print(f"[bench] HIP-graph capture failed, running eagerly: {e!r}", file=sys.stderr, flush=True)
+            graphed = None
 
     def fence():
         if world > 1:
@@ -113,7 +130,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    if not args.no_kernel_events:
+    use_events = not args.no_kernel_events and not args.graph
+    if use_events:
         ops.kernel_events_begin()
     t0 = time.perf_counter()
     last = None
@@ -121,7 +139,7 @@ def main():
         last = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    table = ops.kernel_events_end() if not args.no_kernel_events else {}
+    table = ops.kernel_events_end() if use_events else {}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

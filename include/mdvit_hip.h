@@ -67,6 +67,8 @@ typedef struct MdvitGemmDesc {
     int32_t allow_split;
     void* ws; uint64_t ws_bytes;      /* scratch for split reductions: mdvit_gemm_ws_bytes(desc) (0 = none needed) */
     int32_t accumulate;               /* C += result (gradient accumulation straight into a persistent buffer) */
+    const uint32_t* drop_seed;        /* optional device {s0,s1}: effective keys (key0 ^ s0, key1 + s1) -- lets a captured
+                                         HIP graph draw fresh dropout masks on every replay */
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
@@ -83,7 +85,7 @@ int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, const float* d
 /* out[n] = sum_m A[m][n] * (optional dropmask x rowscale, as the GEMM A prologue): bias gradients. */
 int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N,
                      float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale,
-                     int32_t accumulate, void* stream);
+                     int32_t accumulate, const uint32_t* drop_seed, void* stream);
 
 /* ---- LayerNorm over C (nn.LayerNorm eps=1e-6, mdvit.py:327,342,498) ------------------------- */
 int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -114,18 +116,24 @@ int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, int32_t B
 
 /* ---- BatchNorm2d (train: batch stats, biased var; running stats momentum, unbiased var) + activation
  * on NHWC [M,C]  (mpvit.py:112-123, mdvit.py:99-122,559-563, Decoders.py:39-62,304-306).
- * ws: mdvit_bn_ws_bytes(M, C) bytes of scratch.  Channel sums are reduced in a fixed order (per-block partial
+ * ws: mdvit_bn_ws_bytes(M, C, groups) bytes of scratch.  Channel sums are reduced in a fixed order (per-block partial
  * rows, then a block-ordered double sum), so results are bitwise reproducible run to run.
+ * groups: the M rows are `groups` equal consecutive row groups (one per domain batch, multi_train_MDViT.py:137-153
+ * runs one forward per domain); statistics, normalisation and the backward sums are per group -- mean/rstd are
+ * [groups, C] -- and the running statistics receive the groups' momentum updates in order, i.e. exactly what
+ * `groups` consecutive forwards of M/groups rows each produce.  dgamma/dbeta are summed over the groups.
  * drop2d: nn.Dropout2d on (sample, channel) planes (Decoders.py:309,333). */
-size_t mdvit_bn_ws_bytes(int32_t M, int32_t C);
+size_t mdvit_bn_ws_bytes(int32_t M, int32_t C, int32_t groups);
 int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* mean, float* rstd, float* running_mean, float* running_var,
-                   int64_t* num_batches_tracked, int32_t M, int32_t C, float eps, float momentum, void* stream);
+                   int64_t* num_batches_tracked, int32_t M, int32_t C, int32_t groups, float eps, float momentum, void* stream);
 int mdvit_bn_eval_prep(const float* running_mean, const float* running_var, float* mean, float* rstd, int32_t C, float eps, void* stream);
 int mdvit_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, float* z,
-                   int32_t M, int32_t C, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream);
+                   int32_t M, int32_t C, int32_t groups, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1,
+                   const uint32_t* drop_seed, int32_t rows_per_sample, void* stream);
 int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                 float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t act, int32_t training,
-                 float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream);
+                 float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t groups, int32_t act,
+                 int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, int32_t rows_per_sample,
+                 void* stream);
 
 /* ---- bilinear resize, align_corners=False, NHWC (F.interpolate call sites mdvit.py:699,
  * Decoders.py:196,320-329,336) ------------------------------------------------------------------ */

@@ -35,6 +35,7 @@ struct GemmArgs {
     float* slab;
     int accumulate;
     int vec;                       // output rows can take 16-byte vector accesses
+    const uint32_t* seed;          // optional device-side dropout seed {s0, s1}: key0 ^= s0, key1 += s1 (graph replays draw fresh masks)
     int tiles_m, tiles_n;
 };
 
@@ -64,6 +65,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     float* Bs = smem + BK * LDSA;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t ak0 = p.a_k0 ^ s0, ak1 = p.a_k1 + s1, ek0 = p.e_k0 ^ s0, ek1 = p.e_k1 + s1;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
@@ -94,10 +98,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                         float rs = p.a_rowscale ? p.a_rowscale[m / p.a_rows_per_scale] : 1.f;
                         if (p.a_drop) {
                             const uint32_t idx = (uint32_t)((long)m * p.K + k);
-                            x.x *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx, p.a_thresh, p.a_inv_keep);
-                            x.y *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx + 1, p.a_thresh, p.a_inv_keep);
-                            x.z *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx + 2, p.a_thresh, p.a_inv_keep);
-                            x.w *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx + 3, p.a_thresh, p.a_inv_keep);
+                            x.x *= rs * mdvit_drop_scale(ak0, ak1, idx, p.a_thresh, p.a_inv_keep);
+                            x.y *= rs * mdvit_drop_scale(ak0, ak1, idx + 1, p.a_thresh, p.a_inv_keep);
+                            x.z *= rs * mdvit_drop_scale(ak0, ak1, idx + 2, p.a_thresh, p.a_inv_keep);
+                            x.w *= rs * mdvit_drop_scale(ak0, ak1, idx + 3, p.a_thresh, p.a_inv_keep);
                         } else { x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs; }
                     }
                 }
@@ -111,10 +115,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                         float rs = p.a_rowscale ? p.a_rowscale[k / p.a_rows_per_scale] : 1.f;
                         if (p.a_drop) {
                             const uint32_t idx = (uint32_t)((long)k * p.M + m);
-                            x.x *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx, p.a_thresh, p.a_inv_keep);
-                            x.y *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx + 1, p.a_thresh, p.a_inv_keep);
-                            x.z *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx + 2, p.a_thresh, p.a_inv_keep);
-                            x.w *= rs * mdvit_drop_scale(p.a_k0, p.a_k1, idx + 3, p.a_thresh, p.a_inv_keep);
+                            x.x *= rs * mdvit_drop_scale(ak0, ak1, idx, p.a_thresh, p.a_inv_keep);
+                            x.y *= rs * mdvit_drop_scale(ak0, ak1, idx + 1, p.a_thresh, p.a_inv_keep);
+                            x.z *= rs * mdvit_drop_scale(ak0, ak1, idx + 2, p.a_thresh, p.a_inv_keep);
+                            x.w *= rs * mdvit_drop_scale(ak0, ak1, idx + 3, p.a_thresh, p.a_inv_keep);
                         } else { x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs; }
                     }
                 }
@@ -236,10 +240,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 if (EPI == EPI_GELU2) {
                     float4 h = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
                     if (p.e_drop) {
-                        h.x *= mdvit_drop_scale(p.e_k0, p.e_k1, didx, p.e_thresh, p.e_inv_keep);
-                        h.y *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 1, p.e_thresh, p.e_inv_keep);
-                        h.z *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 2, p.e_thresh, p.e_inv_keep);
-                        h.w *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 3, p.e_thresh, p.e_inv_keep);
+                        h.x *= mdvit_drop_scale(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
+                        h.y *= mdvit_drop_scale(ek0, ek1, didx + 1, p.e_thresh, p.e_inv_keep);
+                        h.z *= mdvit_drop_scale(ek0, ek1, didx + 2, p.e_thresh, p.e_inv_keep);
+                        h.w *= mdvit_drop_scale(ek0, ek1, didx + 3, p.e_thresh, p.e_inv_keep);
                     }
                     *reinterpret_cast<float4*>(dst) = v;
                     *reinterpret_cast<float4*>(p.C2 + (long)row * p.ldc + col) = h;
@@ -250,10 +254,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                     v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
                 }
                 if (p.e_drop) {
-                    v.x *= mdvit_drop_scale(p.e_k0, p.e_k1, didx, p.e_thresh, p.e_inv_keep);
-                    v.y *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 1, p.e_thresh, p.e_inv_keep);
-                    v.z *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 2, p.e_thresh, p.e_inv_keep);
-                    v.w *= mdvit_drop_scale(p.e_k0, p.e_k1, didx + 3, p.e_thresh, p.e_inv_keep);
+                    v.x *= mdvit_drop_scale(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
+                    v.y *= mdvit_drop_scale(ek0, ek1, didx + 1, p.e_thresh, p.e_inv_keep);
+                    v.z *= mdvit_drop_scale(ek0, ek1, didx + 2, p.e_thresh, p.e_inv_keep);
+                    v.w *= mdvit_drop_scale(ek0, ek1, didx + 3, p.e_thresh, p.e_inv_keep);
                 }
                 if (EPI == EPI_FULL) {
                     v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
@@ -373,6 +377,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
     a.accumulate = d->accumulate;
+    a.seed = d->drop_seed;
 
     const GemmPlan pl = plan_gemm(d);
     a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;

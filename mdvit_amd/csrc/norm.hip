@@ -106,6 +106,10 @@ struct ChanArgs {
     long lda; int M, C; int act;
     float drop_p; uint32_t k0, k1, thresh; float inv_keep; int rows_per_sample;
     const float* rowscale; int rows_per_scale;
+    const uint32_t* seed;                     // optional device-side dropout seed (see gemm.hip)
+    int groups;                               // BN over `groups` consecutive row groups of M rows each (MODE0/1: grid.y = group;
+                                              // mean/rstd/ws/part are per group); apply kernels: M = all rows, rows_per_group below
+    long rows_per_group;
 };
 
 __device__ __forceinline__ float act_grad(int act, float pre) {
@@ -118,6 +122,7 @@ __device__ __forceinline__ float act_fwd(int act, float pre) {
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
     extern __shared__ float s_acc[];          // [2*C]
+    const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
     const int QC = p.C >> 2;
     for (int i = threadIdx.x; i < 2 * p.C; i += blockDim.x) s_acc[i] = 0.f;
     __syncthreads();
@@ -125,14 +130,16 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
     const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int q = (int)(t0 % QC), c = q * 4;
     const long total = (long)p.M * QC;
+    const int grp = MODE == 2 ? 0 : (int)blockIdx.y;        // BN group: rows [grp*M, (grp+1)*M)
+    const long row0 = (long)grp * p.M;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     float mu[4], rs[4], ga[4], be[4];
     if (MODE == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { mu[j] = p.mean[c + j]; rs[j] = p.rstd[c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; }
+        for (int j = 0; j < 4; ++j) { mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; }
     }
     for (long e = t0; e < total; e += T) {
-        const long row = e / QC;
+        const long row = row0 + e / QC;
         const float4 av = *reinterpret_cast<const float4*>(p.a + row * p.lda + c);
         const float a4[4] = {av.x, av.y, av.z, av.w};
         if (MODE == 0) {
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
                 const float xh = (y4[j] - mu[j]) * rs[j];
                 float g = a4[j] * act_grad(p.act, xh * ga[j] + be[j]);
                 if (p.drop_p > 0.f)
-                    g *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+                    g *= mdvit_drop_scale(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
                 s1[j] += g; s2[j] += g * xh;
             }
         } else {
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = a4[j] * r;
-                if (p.drop_p > 0.f) v *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)(row * p.C + c + j), p.thresh, p.inv_keep);
+                if (p.drop_p > 0.f) v *= mdvit_drop_scale(k0e, k1e, (uint32_t)(row * p.C + c + j), p.thresh, p.inv_keep);
                 s1[j] += v;
             }
         }
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { a1[j] += s_part[tt * 8 + j]; a2[j] += s_part[tt * 8 + 4 + j]; }
         }
-        float* dst = p.part + (long)blockIdx.x * 2 * p.C;
+        float* dst = p.part + ((long)grp * gridDim.x + blockIdx.x) * 2 * p.C;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dst[qq * 4 + j] = a1[j]; dst[p.C + qq * 4 + j] = a2[j]; }
     }
@@ -190,6 +197,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
 // 32 columns x 8 row lanes per workgroup; lane r adds rows r, r+8, ... then the 8 lane sums are added 0..7.
 __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* __restrict__ part, double* __restrict__ ws, int nblk, int C2) {
     __shared__ double s_sum[8][33];
+    part += (long)blockIdx.y * nblk * C2;          // one BN group per grid.y
+    ws += (long)blockIdx.y * C2;
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cl;
     double s = 0.0;
@@ -213,21 +222,23 @@ __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* __restr
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* mean, float* rstd, float* rmean, float* rvar,
-                                   int64_t* nbt, int M, int C, float eps, float momentum) {
+                                   int64_t* nbt, int M, int C, float eps, float momentum, int groups) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
-        const double m = ws[c] / M;
-        double var = ws[C + c] / M - m * m;
-        if (var < 0.0) var = 0.0;
-        mean[c] = (float)m;
-        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (rmean) {
+        float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+        for (int g = 0; g < groups; ++g) {      // running statistics: the same update sequence as `groups` consecutive forwards
+            const double m = ws[(long)g * 2 * C + c] / M;
+            double var = ws[(long)g * 2 * C + C + c] / M - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[g * C + c] = (float)m;
+            rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
             const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+            rm = (1.f - momentum) * rm + momentum * (float)m;
+            rv = (1.f - momentum) * rv + momentum * (float)unb;
         }
+        if (rmean) { rmean[c] = rm; rvar[c] = rv; }
     }
-    if (c == 0 && nbt) *nbt += 1;
+    if (c == 0 && nbt) *nbt += groups;
 }
 
 __global__ void bn_eval_prep_kernel(const float* rm, const float* rv, float* mean, float* rstd, int C, float eps) {
@@ -237,6 +248,7 @@ __global__ void bn_eval_prep_kernel(const float* rm, const float* rv, float* mea
 
 // z = act((y-mean)*rstd*gamma+beta) * drop2d     (float4 over [M,C])
 __global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __restrict__ z) {
+    const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
     const int QC = p.C >> 2;
     const long total = (long)p.M * QC;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -244,13 +256,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __rest
         const int c = (int)(e % QC) * 4;
         const float4 yv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
         const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+        const int gc = (int)(row / p.rows_per_group) * p.C + c;
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float pre = (y4[j] - p.mean[c + j]) * p.rstd[c + j] * p.gamma[c + j] + p.beta[c + j];
+            const float pre = (y4[j] - p.mean[gc + j]) * p.rstd[gc + j] * p.gamma[c + j] + p.beta[c + j];
             o[j] = act_fwd(p.act, pre);
             if (p.drop_p > 0.f)
-                o[j] *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+                o[j] *= mdvit_drop_scale(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
         }
         *reinterpret_cast<float4*>(z + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -258,25 +271,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __rest
 
 // dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)   (training)   |   gamma*rstd*g   (eval)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __restrict__ dy, float* dgamma, float* dbeta, int training) {
+    const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
     const int QC = p.C >> 2;
     const long total = (long)p.M * QC;
-    const double invM = 1.0 / (double)p.M;
+    const double invM = 1.0 / (double)p.rows_per_group;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long row = e / QC;
         const int c = (int)(e % QC) * 4;
         const float4 dv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
         const float4 yv = *reinterpret_cast<const float4*>(p.b + row * p.C + c);
         const float d4[4] = {dv.x, dv.y, dv.z, dv.w}, y4[4] = {yv.x, yv.y, yv.z, yv.w};
+        const int grp = (int)(row / p.rows_per_group);
+        const int gc = grp * p.C + c;
+        const double* wsg = p.ws + (long)grp * 2 * p.C;
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float rs = p.rstd[c + j], ga = p.gamma[c + j];
-            const float xh = (y4[j] - p.mean[c + j]) * rs;
+            const float rs = p.rstd[gc + j], ga = p.gamma[c + j];
+            const float xh = (y4[j] - p.mean[gc + j]) * rs;
             float g = d4[j] * act_grad(p.act, xh * ga + p.beta[c + j]);
             if (p.drop_p > 0.f)
-                g *= mdvit_drop_scale(p.k0, p.k1, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+                g *= mdvit_drop_scale(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
             if (training) {
-                const float sg = (float)(p.ws[c + j] * invM), sgx = (float)(p.ws[p.C + c + j] * invM);
+                const float sg = (float)(wsg[c + j] * invM), sgx = (float)(wsg[p.C + c + j] * invM);
                 o[j] = ga * rs * (g - sg - xh * sgx);
             } else {
                 o[j] = ga * rs * g;
@@ -285,7 +302,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __
         *reinterpret_cast<float4*>(dy + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < p.C; c += blockDim.x) { dbeta[c] = (float)p.ws[c]; dgamma[c] = (float)p.ws[p.C + c]; }
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            double sb = 0.0, sg = 0.0;
+            for (int g = 0; g < p.groups; ++g) { sb += p.ws[(long)g * 2 * p.C + c]; sg += p.ws[(long)g * 2 * p.C + p.C + c]; }
+            dbeta[c] = (float)sb; dgamma[c] = (float)sg;
+        }
     }
 }
 
@@ -400,26 +421,30 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
 
 constexpr int CHAN_MAX_BLOCKS = 512;
 
-static size_t bn_ws_bytes(int M, int C) {
-    return sizeof(double) * 2 * (size_t)C + sizeof(float) * 2 * (size_t)C * (size_t)chan_grid(M, C, CHAN_MAX_BLOCKS);
+// M = rows of ONE group
+static size_t bn_ws_bytes(int M, int C, int groups) {
+    return (size_t)groups * (sizeof(double) * 2 * (size_t)C + sizeof(float) * 2 * (size_t)C * (size_t)chan_grid(M, C, CHAN_MAX_BLOCKS));
 }
 
-extern "C" size_t mdvit_bn_ws_bytes(int32_t M, int32_t C) {
-    if (M <= 0 || C <= 0 || C % 4) return 0;
-    return bn_ws_bytes(M, C);
+extern "C" size_t mdvit_bn_ws_bytes(int32_t M, int32_t C, int32_t groups) {
+    if (M <= 0 || C <= 0 || C % 4 || groups <= 0 || M % groups) return 0;
+    return bn_ws_bytes(M / groups, C, groups);
 }
 
 extern "C" int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* mean, float* rstd, float* running_mean, float* running_var,
-                              int64_t* nbt, int32_t M, int32_t C, float eps, float momentum, void* stream) {
+                              int64_t* nbt, int32_t M, int32_t C, int32_t groups, float eps, float momentum, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_stats: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
-    MDVIT_CHECK_ARG(ws_bytes >= bn_ws_bytes(M, C), MDVIT_E_WORKSPACE, "bn_stats: workspace too small");
+    MDVIT_CHECK_ARG(groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "bn_stats: M=%d is not a multiple of groups=%d", M, groups);
+    const int Mg = M / groups;
+    MDVIT_CHECK_ARG(ws_bytes >= bn_ws_bytes(Mg, C, groups), MDVIT_E_WORKSPACE, "bn_stats: workspace too small");
     ChanArgs a; memset(&a, 0, sizeof(a));
-    a.a = y; a.lda = C; a.M = M; a.C = C; a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * C);
-    const int grid = chan_grid(M, C, CHAN_MAX_BLOCKS);
-    hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, a.ws, mean, rstd, running_mean, running_var, nbt, M, C, eps, momentum);
+    a.a = y; a.lda = C; a.M = Mg; a.C = C; a.groups = groups; a.rows_per_group = Mg;
+    a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * (size_t)C * groups);
+    const int grid = chan_grid(Mg, C, CHAN_MAX_BLOCKS);
+    hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid, groups), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32), groups), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, a.ws, mean, rstd, running_mean, running_var, nbt, Mg, C, eps, momentum, groups);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -431,12 +456,15 @@ extern "C" int mdvit_bn_eval_prep(const float* rm, const float* rv, float* mean,
 }
 
 extern "C" int mdvit_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, float* z,
-                              int32_t M, int32_t C, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample,
-                              void* stream) {
+                              int32_t M, int32_t C, int32_t groups, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* seed,
+                              int32_t rows_per_sample, void* stream) {
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, MDVIT_E_SHAPE, "bn_apply: need C %% 4 == 0 (M=%d C=%d)", M, C);
+    MDVIT_CHECK_ARG(groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "bn_apply: M=%d is not a multiple of groups=%d", M, groups);
     ChanArgs a; memset(&a, 0, sizeof(a));
     a.a = y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
+    a.groups = groups; a.rows_per_group = M / groups;
     fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
+    a.seed = seed;
     const long total = (long)M * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, (hipStream_t)stream, a, z);
     MDVIT_LAUNCH_CHECK();
@@ -444,18 +472,24 @@ extern "C" int mdvit_bn_apply(const float* y, const float* mean, const float* rs
 }
 
 extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                            float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t act, int32_t training,
-                            float drop2d_p, uint32_t key0, uint32_t key1, int32_t rows_per_sample, void* stream) {
+                            float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t groups, int32_t act,
+                            int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* seed, int32_t rows_per_sample,
+                            void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_bwd: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
-    MDVIT_CHECK_ARG(ws_bytes >= bn_ws_bytes(M, C), MDVIT_E_WORKSPACE, "bn_bwd: workspace too small");
+    MDVIT_CHECK_ARG(groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "bn_bwd: M=%d is not a multiple of groups=%d", M, groups);
+    const int Mg = M / groups;
+    MDVIT_CHECK_ARG(ws_bytes >= bn_ws_bytes(Mg, C, groups), MDVIT_E_WORKSPACE, "bn_bwd: workspace too small");
     ChanArgs a; memset(&a, 0, sizeof(a));
-    a.a = dz; a.b = y; a.lda = C; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
-    a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * C);
+    a.a = dz; a.b = y; a.lda = C; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = Mg; a.C = C; a.act = act;
+    a.groups = groups; a.rows_per_group = Mg;
+    a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * (size_t)C * groups);
     fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
-    const int grid = chan_grid(M, C, CHAN_MAX_BLOCKS);
-    hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(grid), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
+    a.seed = seed;
+    const int grid = chan_grid(Mg, C, CHAN_MAX_BLOCKS);
+    hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(grid, groups), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32), groups), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
+    a.M = M;                                   // the apply pass runs over all rows
     const long total = (long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, s, a, dy, dgamma, dbeta, training);
     MDVIT_LAUNCH_CHECK();
@@ -463,13 +497,14 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
 }
 
 extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N, float drop_p, uint32_t key0, uint32_t key1,
-                                const float* rowscale, int32_t rows_per_scale, int32_t accumulate, void* stream) {
+                                const float* rowscale, int32_t rows_per_scale, int32_t accumulate, const uint32_t* seed, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && N <= 8192 && lda % 4 == 0, MDVIT_E_SHAPE, "colsum: need N %% 4 == 0 (M=%d N=%d)", M, N);
     if (!accumulate) MDVIT_ZERO(out, sizeof(float) * N, s);
     ChanArgs a; memset(&a, 0, sizeof(a));
     a.a = A; a.lda = lda; a.M = M; a.C = N; a.out = out;
     fill_drop(a, drop_p, key0, key1, 1);
+    a.seed = seed;
     a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(chan_grid(M, N, 1024)), dim3(256), sizeof(float) * 2 * N, s, a);
     MDVIT_LAUNCH_CHECK();

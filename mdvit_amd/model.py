@@ -56,8 +56,13 @@ class _EncoderDecoder(nn.Module):
         self.decoder4 = UnetDecodingBlockTransformer(E[1], E[0], self.mhsa_list[0], conv_norm=conv_norm)
         self.finalconv = nn.Sequential(ConvParams(1, E[0], 1, 1))
 
-    def _trunk(self, x, domain_label):
-        """x NCHW image -> (logits (B,1,H,W), encoder_outs NHWC list, decoder4 output NHWC)."""
+    def _trunk(self, x, domain_label, groups: int = 1):
+        """x NCHW image -> (logits (B,1,H,W), encoder_outs NHWC list, decoder4 output NHWC).
+        groups > 1: x is `groups` equal consecutive domain batches; BatchNorm statistics stay per domain batch."""
+        with ops.bn_groups(groups):
+            return self._trunk_impl(x, domain_label)
+
+    def _trunk_impl(self, x, domain_label):
         if x.dim() != 4:
             raise ValueError("expected a (B,C,H,W) image batch")
         B, _, Hi, Wi = x.shape
@@ -89,7 +94,7 @@ class _EncoderDecoder(nn.Module):
         feat = torch.empty((B, Cn), device=enc3.device, dtype=torch.float32)
         with torch.no_grad():
             for b in range(B):
-                ops.call("mdvit_colsum_f32", ops._p(enc3[b]), Cn, ops._p(feat[b]), H * W, Cn, 0.0, 0, 0, None, 1, 0, ops._stream())
+                ops.call("mdvit_colsum_f32", ops._p(enc3[b]), Cn, ops._p(feat[b]), H * W, Cn, 0.0, 0, 0, None, 1, 0, None, ops._stream())
         return feat / float(H * W)
 
 
@@ -112,6 +117,12 @@ class MDViT(_EncoderDecoder):
         init_weights_(self)
 
     def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
+        """d: the reference's domain id string ('0'..'3').  Extension: a list/tuple of G domain ids runs a DOMAIN-BATCHED
+        forward -- x (and domain_label) hold G equal consecutive domain batches; BatchNorm statistics are kept per
+        domain batch and each batch goes through its own peer head, so the result equals G separate forwards
+        (multi_train_MDViT.py:137-153) concatenated along the batch axis."""
+        if isinstance(d, (list, tuple)):
+            return self._forward_domains(x, domain_label, [str(v) for v in d], out_feat, out_seg)
         logits, enc, dec4, img_size = self._trunk(x, domain_label)
         if not out_seg:
             return {"seg": None, "feat": self._pooled_feat(enc[3])}
@@ -126,6 +137,22 @@ class MDViT(_EncoderDecoder):
             aux_out = self.debranch4(feats, img_size=img_size)
         else:
             aux_out = None
+        if out_feat:
+            return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}
+        return [logits, aux_out]
+
+
+    def _forward_domains(self, x, domain_label, ds, out_feat, out_seg):
+        G = len(ds)
+        if x.shape[0] % G:
+            raise ValueError(f"batch {x.shape[0]} is not {G} equal domain batches")
+        logits, enc, dec4, img_size = self._trunk(x, domain_label, groups=G)
+        if not out_seg:
+            return {"seg": None, "feat": self._pooled_feat(enc[3])}
+        heads = {"0": self.debranch1, "1": self.debranch2, "2": self.debranch3, "3": self.debranch4}
+        parts = [ops.split_groups(f, G) for f in enc + [dec4]]          # per feature: G batch views
+        aux = [heads[dd]([pf[g] for pf in parts], img_size=img_size) if dd in heads else None for g, dd in enumerate(ds)]
+        aux_out = None if any(a is None for a in aux) else torch.cat(aux, 0)
         if out_feat:
             return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}
         return [logits, aux_out]

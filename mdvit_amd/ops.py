@@ -45,6 +45,32 @@ def _next_key() -> Tuple[int, int]:
     return k0, k1
 
 
+# ---- device-side dropout seed -------------------------------------------------------------------------
+# Dropout keys are baked into kernel arguments; under HIP-graph replay they would repeat.  With the device seed
+# enabled every dropout-capable kernel also mixes in two words read from device memory, and bump_seed() (one tiny
+# in-graph kernel) advances them once per step.
+_seed_buf = None
+
+
+def enable_device_seed(flag: bool = True):
+    global _seed_buf
+    global _SEED_STEP
+    _seed_buf = torch.tensor([0x1234567, 0x89ABCDE], dtype=torch.int32, device="cuda") if flag else None
+    _SEED_STEP = torch.tensor([-1640531527, 2135587861], dtype=torch.int32, device="cuda") if flag else None
+
+
+def bump_seed():
+    if _seed_buf is not None:
+        _seed_buf.add_(_SEED_STEP)          # int32 wrap-around add
+
+
+_SEED_STEP = None
+
+
+def _seed_ptr():
+    return None if _seed_buf is None else C.c_void_p(_seed_buf.data_ptr())
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -184,6 +210,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.gelu_u, d.ldu = gelu_u, ldu
     d.allow_split = int(allow_split)
     d.accumulate = int(accumulate)
+    d.drop_seed = _seed_ptr() if (a_drop > 0 or e_drop > 0) else None
     ws = None
     if allow_split:
         need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
@@ -288,7 +315,7 @@ class _Linear(torch.autograd.Function):
                     gemm(_p(g), _p(x), _p(sW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, accumulate=True, **pro)
                     if has_b:
                         db, acc_b = sb, True
-                        call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _stream())
+                        call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _seed_ptr() if drop_p > 0 else None, _stream())
                         db = None
             else:
                 acc_b = False
@@ -297,7 +324,7 @@ class _Linear(torch.autograd.Function):
                     gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
                 if has_b and ctx.needs_input_grad[2]:
                     db = _empty((N,), device=x.device, dtype=torch.float32)
-                    call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _stream())
+                    call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _seed_ptr() if drop_p > 0 else None, _stream())
         return dx, dW, db, (g if has_res else None), None, None, None
 
 
@@ -399,19 +426,19 @@ class _MlpResidual(torch.autograd.Function):
                 dW1_, db1, dW2_, db2 = sinks
                 with _on_side(g, h, du, x, rowscale):
                     gemm(_p(g), _p(h), _p(dW2_), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, accumulate=True, **pro)
-                    call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _stream())
+                    call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
                     gemm(_p(du), _p(x), _p(dW1_), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
-                    call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), _stream())
+                    call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), None, _stream())
                 dW1 = db1 = dW2 = db2 = None
             else:
                 dW2 = _empty_like(W2)
                 gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
                 db2 = _empty((Cin,), device=dev, dtype=torch.float32)
-                call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _stream())
+                call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
                 dW1 = _empty_like(W1)
                 gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
                 db1 = _empty((Hd,), device=dev, dtype=torch.float32)
-                call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), _stream())
+                call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), None, _stream())
         return dx, g, dW1, db1, dW2, db2, None, None, None
 
 
@@ -595,53 +622,109 @@ def stem_conv(img, w):
 # ------------------------------------------------------------------------------------------------
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, drop2d_p, rows_per_sample):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, eps, momentum, act, drop2d_p, rows_per_sample, groups):
         ctx.set_materialize_grads(False)
         _chk(y, gamma, beta, running_mean, running_var)
         Cn = y.shape[-1]
         M = y.numel() // Cn
         dev = y.device
-        mean = _empty((Cn,), device=dev, dtype=torch.float32)
+        if not training:
+            groups = 1                 # eval normalises every sample with the shared running statistics
+        mean = _empty((groups, Cn), device=dev, dtype=torch.float32)
         rstd = _empty_like(mean)
         if training:
-            wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn)
+            wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn, groups)
             ws = _empty((wsb // 8 + 1,), device=dev, dtype=torch.float64)
             call("mdvit_bn_stats", _p(y), _p(ws), wsb, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
-                 C.c_void_p(nbt.data_ptr()) if nbt is not None else None, M, Cn, eps, momentum, _stream())
+                 C.c_void_p(nbt.data_ptr()) if nbt is not None else None, M, Cn, groups, eps, momentum, _stream())
         else:
             call("mdvit_bn_eval_prep", _p(running_mean), _p(running_var), _p(mean), _p(rstd), Cn, eps, _stream())
         key = _next_key() if drop2d_p > 0 else (0, 0)
         z = _empty_like(y)
-        call("mdvit_bn_apply", _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), M, Cn, act, drop2d_p, key[0], key[1],
-             rows_per_sample, _stream())
+        call("mdvit_bn_apply", _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), M, Cn, groups, act, drop2d_p, key[0], key[1],
+             _seed_ptr() if drop2d_p > 0 else None, rows_per_sample, _stream())
         ctx.save_for_backward(y, gamma, beta, mean, rstd)
-        ctx.meta = (training, act, drop2d_p, key, rows_per_sample)
+        ctx.meta = (training, act, drop2d_p, key, rows_per_sample, groups)
         return z
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 12
+            return (None,) * 13
         y, gamma, beta, mean, rstd = ctx.saved_tensors
-        training, act, drop2d_p, key, rps = ctx.meta
+        training, act, drop2d_p, key, rps, groups = ctx.meta
         g = _c(g)
         Cn = y.shape[-1]
         M = y.numel() // Cn
         dy = _empty_like(y)
         dg, db = _empty_like(gamma), _empty_like(gamma)
-        wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn)
+        wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn, groups)
         ws = _empty((wsb // 8 + 1,), device=y.device, dtype=torch.float64)
         call("mdvit_bn_bwd", _p(g), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dg), _p(db), _p(ws), wsb,
-             M, Cn, act, int(training), drop2d_p, key[0], key[1], rps, _stream())
+             M, Cn, groups, act, int(training), drop2d_p, key[0], key[1], _seed_ptr() if drop2d_p > 0 else None, rps, _stream())
         if _dgrad_only:
             dg = db = None
-        return dy, dg, db, None, None, None, None, None, None, None, None, None
+        return dy, dg, db, None, None, None, None, None, None, None, None, None, None
+
+
+# ---- domain-batched forward: the batch is `groups` equal consecutive domain batches -----------------------------
+# The reference runs one forward per domain (multi_train_MDViT.py:137-153); the only op on the trunk that couples the
+# samples of a forward is BatchNorm (batch statistics).  With bn_groups(G) active every train-mode BatchNorm keeps
+# per-group statistics, so ONE forward over the concatenated G domain batches is the same function as G forwards --
+# with 1/G of the kernel launches and G-times larger (better filled) kernels.
+_bn_groups = 1
+
+
+class bn_groups:
+    def __init__(self, groups: int):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        global _bn_groups
+        self.prev, _bn_groups = _bn_groups, self.groups
+
+    def __exit__(self, *exc):
+        global _bn_groups
+        _bn_groups = self.prev
+
+
+class _SplitGroups(torch.autograd.Function):
+    """x [G*B, ...] -> G views [B, ...] (no copy); backward concatenates the G gradients once."""
+
+    @staticmethod
+    def forward(ctx, x, groups):
+        ctx.set_materialize_grads(False)
+        ctx.shape = (groups, x.shape[0] // groups) + tuple(x.shape[1:])
+        return tuple(x.view(ctx.shape).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None, None
+        ref = next(g for g in gs if g is not None)
+        out = torch.empty(ctx.shape, device=ref.device, dtype=ref.dtype)
+        for i, g in enumerate(gs):
+            if g is None:
+                out[i].zero_()
+            else:
+                out[i].copy_(g)
+        return out.view((ctx.shape[0] * ctx.shape[1],) + ctx.shape[2:]), None
+
+
+def split_groups(x, groups: int):
+    if groups == 1:
+        return (x,)
+    assert x.shape[0] % groups == 0
+    return _SplitGroups.apply(_c(x), int(groups))
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, nbt, training, act, eps=1e-5, momentum=0.1, drop2d_p=0.0):
     rows_per_sample = y.numel() // (y.shape[0] * y.shape[-1])
+    groups = _bn_groups if training else 1
+    if groups > 1 and y.shape[0] % groups:
+        raise ValueError(f"bn_groups({groups}) needs a batch that is a multiple of it, got {y.shape[0]}")
     return _BNAct.apply(_c(y), gamma, beta, running_mean, running_var, nbt, bool(training), float(eps), float(momentum),
-                        int(act), float(drop2d_p), int(rows_per_sample))
+                        int(act), float(drop2d_p), int(rows_per_sample), int(groups))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def _da_params(model):
 def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: float = 0.5, num_domains: int = 4,
                      reducer: Optional[GradBucketReducer] = None, per_domain_backward: bool = True,
                      use_domain_label: bool = True, accumulator: Optional[GradAccumulator] = None,
-                     merged_sweeps: bool = False) -> Dict[str, torch.Tensor]:
+                     merged_sweeps: bool = False, fuse_domains: int = 1) -> Dict[str, torch.Tensor]:
     """batches: [(img (B,3,H,W), label (B,1,H,W), set_id (B,) int64)] one per domain.
     Returns the summed losses as device tensors (no host sync inside the step).
     accumulator: fused gradient accumulation (+ overlapped all-reduce when world_size > 1), see parallel.GradAccumulator.
@@ -44,6 +44,8 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
         optimizer.zero_grad(set_to_none=True)
     else:
         model.zero_grad(set_to_none=True)
+    if fuse_domains > 1:
+        batches = _fuse_batches(batches, fuse_domains, num_domains, use_domain_label)
 
     def sweep(loss, last, retain=False):
         if accumulator is not None:
@@ -73,18 +75,28 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
 
     tot = tot_aux = tot_kt = None
     stash = []
-    for i, (img, label, set_id) in enumerate(batches):
+    for i, batch in enumerate(batches):
+        img, label, set_id = batch[0], batch[1], batch[2]
         # set_id is a HOST tensor, as from the DataLoader (multi_train_MDViT.py:137-139): reading set_id[0] must not
         # synchronise the GPU stream -- the host keeps enqueueing the next domain while the GPU works on this one
         if set_id.is_cuda:
             set_id = set_id.cpu()
-        d = str(int(set_id[0]))
+        G = batch[4] if len(batch) > 4 else 1         # domain batches fused into this forward (see _fuse_batches)
+        Bd = img.shape[0] // G
+        d = str(int(set_id[0])) if G == 1 else [str(int(set_id[g * Bd])) for g in range(G)]
         if use_domain_label:
-            domain_label = F.one_hot(set_id, num_domains).float().to(img.device, non_blocking=True)
+            # an optional 4th entry carries the one-hot label already on the device (needed under HIP-graph capture)
+            domain_label = batch[3] if len(batch) > 3 and batch[3] is not None else \
+                F.one_hot(set_id, num_domains).float().to(img.device, non_blocking=True)
             out, aux = model(img, domain_label, d)
         else:
             out, aux = model(img, d=d)
-        l, la, lk = domain_losses(out, aux, label)
+        if G == 1:
+            l, la, lk = domain_losses(out, aux, label)
+        else:       # per-domain BCE/Dice/KT (each a mean over ITS batch, multi_train_MDViT.py:147-153), then summed
+            og, ag = ops.split_groups(out, G), ops.split_groups(aux, G)
+            per = [domain_losses(og[g], ag[g], label[g * Bd:(g + 1) * Bd]) for g in range(G)]
+            l, la, lk = (sum(t[j] for t in per) for j in range(3))
         tot = l.detach() if tot is None else tot + l.detach()
         tot_aux = la.detach() if tot_aux is None else tot_aux + la.detach()
         tot_kt = lk.detach() if tot_kt is None else tot_kt + lk.detach()
@@ -99,6 +111,40 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
     if optimizer is not None:
         optimizer.step()
     return {"loss": tot, "aux_loss": tot_aux, "kt_loss": tot_kt}
+
+
+def _fuse_batches(batches, fuse_domains, num_domains, use_domain_label):
+    """Concatenate runs of up to `fuse_domains` equally shaped domain batches into one domain-batched forward
+    (model(img, label, [d0, d1, ...])): same losses and gradients as separate forwards (BatchNorm statistics are kept
+    per domain batch), a quarter of the kernel launches and better-filled kernels at small per-domain batch sizes.
+    A batch that is already fused (5-tuple) passes through."""
+    out, run = [], []
+
+    def flush():
+        if not run:
+            return
+        if len(run) == 1:
+            out.append(run[0])
+        else:
+            img = torch.cat([b[0] for b in run], 0)
+            lab = torch.cat([b[1] for b in run], 0)
+            sid = torch.cat([b[2].cpu() for b in run], 0)
+            dl = None
+            if use_domain_label:
+                dl = torch.cat([b[3] for b in run], 0) if all(len(b) > 3 and b[3] is not None for b in run) else \
+                    F.one_hot(sid, num_domains).float().to(img.device, non_blocking=True)
+            out.append((img, lab, sid, dl, len(run)))
+        run.clear()
+
+    for b in batches:
+        if len(b) > 4 or (run and (b[0].shape != run[0][0].shape or len(run) >= fuse_domains)):
+            flush()
+        if len(b) > 4:
+            out.append(b)
+        else:
+            run.append(b)
+    flush()
+    return out
 
 
 def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Optional[GradBucketReducer] = None,

@@ -14,7 +14,8 @@ def pytest_sessionstart(session):
     # the CPU oracle runs inside GPU tests too; several xdist workers x all host cores oversubscribe badly
     try:
         import torch
-        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // 4)))
+        n = os.cpu_count() or 8
+        torch.set_num_threads(max(1, min(8, n // 4 if os.environ.get("PYTEST_XDIST_WORKER") else n)))
     except Exception:
         pass
 

@@ -255,6 +255,50 @@ def test_bn_act_train(act, B, H, W, C):
     assert int(nbt) == 4
 
 
+@pytest.mark.parametrize("G,Bg,H,W,C", [(4, 2, 8, 8, 64), (2, 3, 5, 3, 320), (4, 1, 16, 16, 32)])
+def test_bn_act_grouped_equals_consecutive_forwards(G, Bg, H, W, C):
+    """bn_groups(G): per-domain-batch statistics in ONE call == G consecutive BatchNorm forwards (outputs, all
+    gradients, and the running statistics after G momentum updates in order)"""
+    from mdvit_amd import ops, _lib
+    y, ga, be, g = rnd(G * Bg, C, H, W, seed=86, scale=2.0) + 0.3, 1 + 0.5 * rnd(C, seed=87), rnd(C, seed=88, scale=0.2), rnd(G * Bg, C, H, W, seed=89)
+    y = y + torch.arange(G).repeat_interleave(Bg).view(-1, 1, 1, 1).float()        # groups with different statistics
+    rm0, rv0 = rnd(C, seed=84, scale=0.1), 1 + 0.5 * rnd(C, seed=85)
+    rm, rv = rm0.clone().double(), rv0.clone().double()
+
+    def ref_fn(y, ga, be):
+        return torch.cat([F.hardswish(F.batch_norm(y[i * Bg:(i + 1) * Bg].double(), rm, rv, ga.double(), be.double(), True, 0.1, 1e-5))
+                          for i in range(G)], 0)
+    ref, gr = grads_of(ref_fn, [y, ga, be], g.double())
+    rmh, rvh, nbt = rm0.to(dev()), rv0.to(dev()), torch.tensor(0, device=dev())
+
+    def our_fn(y, ga, be):
+        with ops.bn_groups(G):
+            return ops.bn_act(y, ga, be, rmh, rvh, nbt, True, _lib.ACT_HSWISH)
+    out, go = grads_of(our_fn, [nhwc(y).to(dev()), ga.to(dev()), be.to(dev())], nhwc(g))
+    check(nchw(out), ref, name="z")
+    check(nchw(go[0]), gr[0], tol=3e-4, name="dy")
+    check(go[1], gr[1], tol=3e-4, name="dgamma")
+    check(go[2], gr[2], tol=3e-4, name="dbeta")
+    check(rmh, rm, name="running_mean")
+    check(rvh, rv, name="running_var")
+    assert int(nbt) == G
+    # and it is bit-identical to calling the same kernels group by group
+    rm2, rv2, nbt2 = rm0.to(dev()), rv0.to(dev()), torch.tensor(0, device=dev())
+    yd = nhwc(y).to(dev())
+    sep = torch.cat([ops.bn_act(yd[i * Bg:(i + 1) * Bg].contiguous(), ga.to(dev()), be.to(dev()), rm2, rv2, nbt2, True, _lib.ACT_HSWISH)
+                     for i in range(G)], 0)
+    assert torch.equal(sep, out.detach()) and torch.equal(rm2, rmh) and torch.equal(rv2, rvh)
+
+
+def test_split_groups_backward_handles_missing_gradients():
+    from mdvit_amd import ops
+    x = rnd(6, 5, 4, seed=120).to(dev()).requires_grad_(True)
+    a, b, c = ops.split_groups(x, 3)
+    (a.sum() * 2 + c.sum() * 3).backward()
+    want = torch.cat([torch.full((2, 5, 4), 2.0), torch.zeros(2, 5, 4), torch.full((2, 5, 4), 3.0)]).to(dev())
+    assert torch.equal(x.grad, want)
+
+
 def test_bn_act_eval_and_dropout2d():
     from mdvit_amd import ops, _lib
     B, H, W, C = 4, 8, 8, 64

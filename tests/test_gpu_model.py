@@ -346,3 +346,112 @@ def test_side_stream_wgrad_matches_single_stream():
         ops.set_grad_sinks(None)
     for n in res[0]:
         check_grad(res[1][n], res[0][n], name=n, l2_tol=2e-4, max_tol=2e-3)
+
+
+def _four_domain_batches(seed, B=2, size=64):
+    from oracle.gen_golden import synth_image, synth_label
+    return [(synth_image(seed + d, B, size, size).to(dev()), synth_label(seed + 10 + d, B, size, size).to(dev()),
+             torch.full((B,), d, dtype=torch.long)) for d in range(4)]
+
+
+@pytest.mark.parametrize("fuse", [2, 4])
+def test_domain_batched_step_equals_per_domain_forwards(fuse):
+    """ONE forward over the concatenated domain batches (per-domain BatchNorm statistics, per-domain peer heads and
+    losses) == the reference's one forward per domain: logits, the three losses, every gradient, BN running stats"""
+    from mdvit_amd.train import mdvit_train_step
+    batches = _four_domain_batches(1100)
+    res = []
+    for f in (1, fuse):
+        m = build_mdvit(17, 64).train()
+        out = mdvit_train_step(m, batches, optimizer=None, merged_sweeps=True, fuse_domains=f)
+        res.append((out, {n: p.grad.clone() for n, p in m.named_parameters()}, {n: b.clone() for n, b in m.named_buffers()}))
+    for k in ("loss", "aux_loss", "kt_loss"):
+        check(res[0][0][k], res[1][0][k], tol=1e-5, name=k)
+    for n in res[0][1]:
+        check_grad(res[1][1][n], res[0][1][n], name=n, l2_tol=3e-4, max_tol=3e-3)
+    for n in res[0][2]:
+        check(res[1][2][n].double(), res[0][2][n].double(), tol=1e-5, name=n)
+
+
+def test_domain_batched_forward_matches_oracle_per_domain():
+    """model(x, label, ['0','1','2','3']) vs the oracle run once per domain"""
+    from oracle import mdvit_ref as R
+    from oracle.params import make_params
+    P = make_params(21, model="MDViT", adapt_method="Sup")
+    m = build_mdvit(21, 64).train()
+    batches = _four_domain_batches(1200)
+    img = torch.cat([b[0] for b in batches]); sid = torch.cat([b[2] for b in batches])
+    lab = F.one_hot(sid, 4).float().to(dev())
+    out, aux = m(img, lab, ["0", "1", "2", "3"])
+    Pt = R.to_torch(P)
+    for d, b in enumerate(batches):
+        st = R.RefState(training=True)          # running statistics advance domain by domain, as in the fused forward
+        with torch.no_grad():
+            o_ref, a_ref = R.mdvit_forward(Pt, b[0].cpu(), F.one_hot(b[2], 4).float(), str(d), st)
+        check(out[2 * d:2 * d + 2].cpu(), o_ref, tol=1e-3, name=f"logits d{d}")
+        check(aux[2 * d:2 * d + 2].cpu(), a_ref, tol=1e-3, name=f"aux d{d}")
+    sd = m.state_dict()
+    for k in ("stem.0.bn.running_mean", "bridge.1.running_var", "decoder4.conv1.1.running_mean"):
+        if k in sd and k in Pt:
+            check(sd[k].cpu(), Pt[k], tol=1e-4, name=k)
+
+
+def test_device_seed_redraws_dropout_masks(monkeypatch):
+    """with the device-side seed enabled the SAME host keys (as baked into a captured graph) give a new mask after
+    bump_seed(), the same mask without it, and the backward re-derives the mask of its forward"""
+    from mdvit_amd import ops
+    monkeypatch.setattr(ops, "_next_key", lambda: (123, 456))
+    ops.enable_device_seed(True)
+    try:
+        x = torch.ones(512, 256, device=dev())
+        w = torch.eye(256, device=dev()).requires_grad_(True)
+        y0 = ops.linear(x, w, None, drop_p=0.5)
+        y0b = ops.linear(x, w, None, drop_p=0.5)
+        assert torch.equal(y0, y0b)
+        ops.bump_seed()
+        y1 = ops.linear(x, w, None, drop_p=0.5)
+        for y in (y0, y1):
+            assert abs((y != 0).float().mean().item() - 0.5) < 0.02
+        assert (y0.detach() != y1.detach()).float().mean().item() > 0.3
+        # backward of y1 uses y1's mask: d(sum y1)/dx is 2 where kept, 0 where dropped (w = I)
+        xg = x.clone().requires_grad_(True)
+        y2 = ops.linear(xg, w, None, drop_p=0.5)
+        y2.sum().backward()
+        assert torch.equal(xg.grad, y2.detach())
+    finally:
+        ops.enable_device_seed(False)
+
+
+def test_graphed_step_matches_eager_step():
+    """HIP-graph replay of the whole optimisation step (dropout off) == the eager step: same losses and weights after
+    three steps"""
+    from mdvit_amd import ops
+    from mdvit_amd.graph import GraphedStep
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.train import mdvit_train_step
+    batches = _four_domain_batches(1300)
+    res = []
+    try:
+        for graphed in (False, True):
+            m = build_mdvit(23, 64).train()
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.05, fused=True, capturable=True)
+            acc = GradAccumulator(m.parameters())
+            acc.attach_sinks()
+            fn = lambda b: mdvit_train_step(m, b, optimizer=opt, accumulator=acc, merged_sweeps=True, fuse_domains=4)
+            losses = []
+            if graphed:
+                g = GraphedStep(fn, batches, warmup=0, fuse_domains=4)
+                for _ in range(3):
+                    losses.append(float(g(batches)["loss"]))
+            else:
+                for _ in range(3):
+                    losses.append(float(fn(batches)["loss"]))
+            torch.cuda.synchronize()
+            res.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
+    finally:
+        ops.set_grad_sinks(None)
+        ops.enable_device_seed(False)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 2e-4 * abs(a), (res[0][0], res[1][0])
+    for n in res[0][1]:
+        check(res[1][1][n], res[0][1][n], tol=2e-3, name=n)

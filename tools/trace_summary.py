@@ -1,0 +1,48 @@
+"""Summarise a rocprofv3 --kernel-trace csv: per-kernel totals per step, per-stream busy time, idle gaps.
+usage: python tools/trace_summary.py <dir or *_kernel_trace.csv> [--steps K] [--skip-frac F]"""
+import csv, glob, os, sys, collections
+
+def main():
+    path = sys.argv[1]
+    steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 1
+    skip = float(sys.argv[sys.argv.index("--skip-frac") + 1]) if "--skip-frac" in sys.argv else 0.0
+    if os.path.isdir(path):
+        path = sorted(glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True))[-1]
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
+    cut = t0 + skip * (t1 - t0)
+    if "--last-ms" in sys.argv:
+        cut = t1 - float(sys.argv[sys.argv.index("--last-ms") + 1]) * 1e6
+    rows = [r for r in rows if int(r["Start_Timestamp"]) >= cut]
+    t0 = int(rows[0]["Start_Timestamp"])
+    span = (t1 - t0) / 1e6
+    per = collections.defaultdict(lambda: [0.0, 0])
+    streams = collections.defaultdict(float)
+    for r in rows:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        name = name.split("(")[0] if "<" not in name else name[:name.rfind(">") + 1] if name.rfind(">") > 0 else name
+        per[name][0] += d; per[name][1] += 1
+        streams[r.get("Stream_Id", r.get("Queue_Id", "?"))] += d
+    # union busy time
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+    busy, cur_s, cur_e = 0, ev[0][0], ev[0][1]
+    gaps = []
+    for s, e in ev[1:]:
+        if s > cur_e:
+            busy += cur_e - cur_s; gaps.append(s - cur_e); cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += cur_e - cur_s
+    print(f"span {span:.1f} ms  busy(union) {busy/1e6:.1f} ms  idle {span-busy/1e6:.1f} ms  kernels {len(rows)}  steps {steps}")
+    print("per-stream kernel time (ms):", {k: round(v, 1) for k, v in streams.items()})
+    if gaps:
+        gaps.sort()
+        print(f"gaps: n={len(gaps)} median {gaps[len(gaps)//2]/1e3:.1f} us  p90 {gaps[int(len(gaps)*0.9)]/1e3:.1f} us  sum {sum(gaps)/1e6:.1f} ms")
+    tot = sum(v[0] for v in per.values())
+    print(f"sum of kernel durations {tot:.1f} ms  ({tot/steps:.1f} ms/step)")
+    for name, (d, n) in sorted(per.items(), key=lambda kv: -kv[1][0])[:60]:
+        print(f"{d/steps:8.2f} ms/step {n//steps:6d}/step {d/n*1e3:8.1f} us  {100*d/tot:5.1f}%  {name[:110]}")
+
+main()
