@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-sweeps", action="store_true", help="run the reference's literal two full sweeps instead of the merged (linear-algebra-equivalent) form")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--by-shape", action="store_true", help="key the GEMM event table by (variant, M, N, K) -- for tools/gemm_shapes.py")
     ap.add_argument("--detail", default="", help="write the per-kernel table to this JSON file")
     return ap.parse_args()
 
@@ -132,7 +133,7 @@ def main():
     fence()
     use_events = not args.no_kernel_events and not args.graph
     if use_events:
-        ops.kernel_events_begin()
+        ops.kernel_events_begin(by_shape=args.by_shape)
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):

@@ -41,8 +41,8 @@ int mdvit_version(void);
  * C[M,N] = op(A)[M,K] * op(B)[K,N] (+bias[N]) with fused neighbours.
  *   trans_a = 0: A is [M,K] row-major (lda);   1: A is stored [K,M] row-major (wgrad, A = dY^T).
  *   trans_b = 1: B is [N,K] row-major (an nn.Linear / 1x1-conv weight); 0: B is [K,N] row-major.
- * A prologue (backward of `res + DropPath(Dropout(.))`, mdvit.py:311,354 / mpvit.py:73-78):
- *   A[token][f] *= a_rowscale[token / a_rows_per_scale] * dropmask(a_key, token*F + f).
+ * (The backward of `res + DropPath(Dropout(.))`, mdvit.py:311,354 / mpvit.py:73-78, masks the upstream gradient once
+ *  with mdvit_colsum_f32 and feeds the masked tensor to the dgrad / wgrad GEMMs.)
  * Epilogues:
  *   NONE      : C = acc + bias; then optional dropout(e_drop_p), row scale (DropPath), + residual.
  *   GELU_DUAL : C = acc + bias (pre-activation u), C2 = dropout(gelu_erf(u))       (mpvit.py:73-75)
@@ -57,8 +57,6 @@ typedef struct MdvitGemmDesc {
     int32_t M, N, K;
     int32_t trans_a, trans_b;
     const float* bias;
-    float a_drop_p; uint32_t a_key0, a_key1;
-    const float* a_rowscale; int32_t a_rows_per_scale;
     int32_t epi;
     float e_drop_p; uint32_t e_key0, e_key1;
     const float* e_rowscale; int32_t e_rows_per_scale;
@@ -73,6 +71,9 @@ typedef struct MdvitGemmDesc {
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
 int mdvit_gemm_plan(const MdvitGemmDesc* desc, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
+/* Tuning hook for tools/gemm_sweep.py: pin the tile configuration (0: 128x128, 1: 256x64, 2: 64x64; -1: planner) and the
+ * requested K-split (one of the planner's candidates; 0: planner) of every following mdvit_gemm_f32 call. */
+int mdvit_gemm_force_plan(int32_t cfg, int32_t splits);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,
@@ -82,8 +83,11 @@ int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b
 int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, const float* dy, float* dx, int64_t lddx,
                      float* dw, float* db, int32_t M, int32_t K, void* stream);
 
-/* out[n] = sum_m A[m][n] * (optional dropmask x rowscale, as the GEMM A prologue): bias gradients. */
-int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N,
+/* Masked upstream gradient + bias gradient in one pass over dY [M,N] (the backward of  y = drop(x W^T + b) * droppath,
+ * mdvit.py:306-309,343-346):  masked[m][n] = A[m][n] * dropmask(m*N+n) * rowscale[m / rows_per_scale]  (optional) and
+ * out[n] (+)= sum_m masked[m][n]  (optional).  The mask is re-derived from (key0,key1[,drop_seed]) exactly as the forward
+ * GEMM epilogue drew it; the dgrad/wgrad GEMMs then read `masked` with no prologue of their own. */
+int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, int32_t M, int32_t N,
                      float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale,
                      int32_t accumulate, const uint32_t* drop_seed, void* stream);
 

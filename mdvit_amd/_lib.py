@@ -31,8 +31,6 @@ class GemmDesc(C.Structure):
         ("M", i32), ("N", i32), ("K", i32),
         ("trans_a", i32), ("trans_b", i32),
         ("bias", vp),
-        ("a_drop_p", f32), ("a_key0", u32), ("a_key1", u32),
-        ("a_rowscale", vp), ("a_rows_per_scale", i32),
         ("epi", i32),
         ("e_drop_p", f32), ("e_key0", u32), ("e_key1", u32),
         ("e_rowscale", vp), ("e_rows_per_scale", i32),
@@ -48,9 +46,10 @@ class GemmDesc(C.Structure):
 _SIGS = {
     "mdvit_gemm_f32": [C.POINTER(GemmDesc), vp],
     "mdvit_gemm_plan": [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+    "mdvit_gemm_force_plan": [i32, i32],
     "mdvit_rowdot_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mdvit_rowdot_bwd": [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, vp],
-    "mdvit_colsum_f32": [vp, i64, vp, i32, i32, f32, u32, u32, vp, i32, i32, vp, vp],
+    "mdvit_colsum_f32": [vp, i64, vp, vp, i32, i32, f32, u32, u32, vp, i32, i32, vp, vp],
     "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "mdvit_dwconv3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],

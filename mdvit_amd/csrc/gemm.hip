@@ -23,8 +23,6 @@ struct GemmArgs {
     int M, N, K;
     const float* bias;
     // A prologue
-    int a_drop; uint32_t a_k0, a_k1, a_thresh; float a_inv_keep;
-    const float* a_rowscale; int a_rows_per_scale;
     // epilogue
     int epi;                       // MDVIT_EPI_*
     int e_drop; uint32_t e_k0, e_k1, e_thresh; float e_inv_keep;
@@ -49,10 +47,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // do-everything kernel was ~20k instructions, far beyond the instruction cache):
 //   0 PLAIN  : (+bias) | split slab | accumulate        1 GELU_DUAL    2 DGELU (x dropout mask)
 //   3 FULL   : +bias, dropout, DropPath row scale, +residual
-// APRO: dropout-mask x row-scale prologue on the A operand (backward GEMMs).
 enum { EPI_PLAIN = 0, EPI_GELU2 = 1, EPI_DGELU = 2, EPI_FULL = 3 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI, bool APRO>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     // k-contiguous operands are transposed on the LDS write: odd leading dimension -> conflict-free ds_write_b32;
     // m/n-contiguous operands are written as float4: leading dimension % 4 == 0.
@@ -67,7 +64,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t s0 = 0, s1 = 0;
     if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
-    const uint32_t ak0 = p.a_k0 ^ s0, ak1 = p.a_k1 + s1, ek0 = p.e_k0 ^ s0, ek1 = p.e_k1 + s1;
+    const uint32_t ek0 = p.e_k0 ^ s0, ek1 = p.e_k1 + s1;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
@@ -92,36 +89,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TA) {   // A[m][k], k contiguous: BK/4 threads per row
                 const int r = tid / KT + v * (NTHREADS / KT), m = m0 + r, k = k0 + (tid % KT) * 4;
-                if (m < p.M && k < kend) {
-                    x = *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k);
-                    if (APRO) {
-                        float rs = p.a_rowscale ? p.a_rowscale[m / p.a_rows_per_scale] : 1.f;
-                        if (p.a_drop) {
-                            const uint32_t idx = (uint32_t)((long)m * p.K + k);
-                            x.x *= rs * mdvit_drop_scale(ak0, ak1, idx, p.a_thresh, p.a_inv_keep);
-                            x.y *= rs * mdvit_drop_scale(ak0, ak1, idx + 1, p.a_thresh, p.a_inv_keep);
-                            x.z *= rs * mdvit_drop_scale(ak0, ak1, idx + 2, p.a_thresh, p.a_inv_keep);
-                            x.w *= rs * mdvit_drop_scale(ak0, ak1, idx + 3, p.a_thresh, p.a_inv_keep);
-                        } else { x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs; }
-                    }
-                }
+                if (m < p.M && k < kend) x = *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k);
             } else {     // A stored [k][m], m contiguous (wgrad: A = dY^T)
                 constexpr int TPR = BM / 4;                 // threads per k-row
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, m = m0 + (tid % TPR) * 4;
-                if (k < kend && m < p.M) {
-                    x = *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m);
-                    if (APRO) {
-                        // the stored tensor is [k][m] = dY[token k][feature m]; mask index = k*M + m
-                        float rs = p.a_rowscale ? p.a_rowscale[k / p.a_rows_per_scale] : 1.f;
-                        if (p.a_drop) {
-                            const uint32_t idx = (uint32_t)((long)k * p.M + m);
-                            x.x *= rs * mdvit_drop_scale(ak0, ak1, idx, p.a_thresh, p.a_inv_keep);
-                            x.y *= rs * mdvit_drop_scale(ak0, ak1, idx + 1, p.a_thresh, p.a_inv_keep);
-                            x.z *= rs * mdvit_drop_scale(ak0, ak1, idx + 2, p.a_thresh, p.a_inv_keep);
-                            x.w *= rs * mdvit_drop_scale(ak0, ak1, idx + 3, p.a_thresh, p.a_inv_keep);
-                        } else { x.x *= rs; x.y *= rs; x.z *= rs; x.w *= rs; }
-                    }
-                }
+                if (k < kend && m < p.M) x = *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m);
             }
             ra[v] = x;
         }
@@ -272,46 +244,57 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
-// C[m][n] = sum_s slab[s][m][n] (+ bias[n]); fixed summation order -> deterministic
+// C[m][n] = sum_s slab[s][m][n] (+ bias[n]).  R lanes share one output quad: lane r adds slabs r, r+R, ... and the R
+// partial sums are folded by a shuffle tree -- a fixed order for a given shape, so the result is deterministic.
+template <int R>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                                                  float* __restrict__ C, long ldc, int M, int N, int splits, int accumulate) {
     const int NQ = N >> 2;
     const long total = (long)M * NQ, MN = (long)M * N;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = threadIdx.x % R;
+    const long stride = (long)gridDim.x * blockDim.x / R;
+    for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) / R; e < total; e += stride) {
         const long m = e / NQ;
         const int n = (int)(e % NQ) * 4;
-        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* src = slab + m * N + n;
-        for (int sidx = 0; sidx < splits; ++sidx) {
+        for (int sidx = r; sidx < splits; sidx += R) {
             const float4 v = *reinterpret_cast<const float4*>(src + (long)sidx * MN);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        float* dst = C + m * ldc + n;
-        if (accumulate) { acc.x += dst[0]; acc.y += dst[1]; acc.z += dst[2]; acc.w += dst[3]; }
-        if (((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) *reinterpret_cast<float4*>(dst) = acc;
-        else { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
+#pragma unroll
+        for (int off = R / 2; off > 0; off >>= 1) {
+            acc.x += __shfl_down(acc.x, off, R); acc.y += __shfl_down(acc.y, off, R);
+            acc.z += __shfl_down(acc.z, off, R); acc.w += __shfl_down(acc.w, off, R);
+        }
+        if (r == 0) {
+            if (bias) { acc.x += bias[n]; acc.y += bias[n + 1]; acc.z += bias[n + 2]; acc.w += bias[n + 3]; }
+            float* dst = C + m * ldc + n;
+            if (accumulate) { acc.x += dst[0]; acc.y += dst[1]; acc.z += dst[2]; acc.w += dst[3]; }
+            if (((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) *reinterpret_cast<float4*>(dst) = acc;
+            else { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
+        }
     }
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, bool apro, hipStream_t s) {
+int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(NTHREADS);
-#define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_, APRO_) \
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_, APRO_>), grid, block, 0, s, a)
+#define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_) \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_>), grid, block, 0, s, a)
     if (!ta && tb) {                                   // forward (weights [N,K])
-        if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2, false);
-        else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL, false);
-        else if (epi == EPI_PLAIN && !apro) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, false);
-        else if (epi == EPI_PLAIN && apro) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, true);
+        if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2);
+        else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL);
+        else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN);
         else return 1;
     } else if (!ta && !tb) {                           // dgrad
-        if (epi == EPI_DGELU) { if (apro) MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU, true); else MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU, false); }
-        else if (epi == EPI_PLAIN) { if (apro) MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN, true); else MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN, false); }
-        else if (epi == EPI_FULL && !apro) MDVIT_GEMM_LAUNCH(false, false, EPI_FULL, false);
+        if (epi == EPI_DGELU) MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU);
+        else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN);
+        else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, false, EPI_FULL);
         else return 1;
     } else if (ta && !tb) {                            // wgrad
         if (epi != EPI_PLAIN) return 1;
-        if (apro) MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN, true); else MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN, false);
+        MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN);
     } else {
         return 1;
     }
@@ -321,31 +304,45 @@ int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, bool apro, hipStream_
 
 struct GemmPlan { int cfg, tiles_m, tiles_n, splits, kps; };
 
-// Tile shape and K-split so that the launch has enough workgroups for 256 CUs:
-//   cfg 0: 128x128 (default)   1: 256x64 (narrow outputs, N an odd multiple of 64)   2: 64x64 (few tiles)
+// Tile shape and K-split from a small cost model (CU cycles):
+//   cfg 0: 128x128 (2 workgroups / CU)   1: 256x64 (narrow outputs)   2: 64x64 (4 workgroups / CU; few or ragged tiles)
+// cost = rounds over the chip x workgroups sharing a CU x padded tile work / tile efficiency, plus -- when the K range
+// is split into slabs -- the fixed-order slab reduction (a second, HBM-bound kernel).
+int g_force_cfg = -1, g_force_splits = 0;      // tuning hook (mdvit_gemm_force_plan); -1 / 0 = planner decides
+
 GemmPlan plan_gemm(const MdvitGemmDesc* d) {
-    GemmPlan pl;
-    const bool narrow = (d->N <= 64) || (d->N % 128 != 0 && d->N % 64 == 0);
-    pl.cfg = narrow ? 1 : 0;
-    int BM = narrow ? 256 : 128, BN = narrow ? 64 : 128;
-    long tiles = (long)cdiv(d->M, BM) * cdiv(d->N, BN);
-    if (tiles < 192) {
-        const long t64 = (long)cdiv(d->M, 64) * cdiv(d->N, 64);
-        if (t64 > tiles) { pl.cfg = 2; BM = 64; BN = 64; tiles = t64; }
-    }
-    pl.tiles_m = cdiv(d->M, BM); pl.tiles_n = cdiv(d->N, BN);
-    int splits = 1;
+    static const int BMs[3] = {128, 256, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 2, 4};
+    static const double EFF[3] = {0.8, 0.8, 1.0};       // measured (tools/gemm_sweep.py): the 64x64 tile at 4 workgroups / CU wins almost everywhere
+    static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
     const bool plain = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual;
-    if (d->allow_split && plain && tiles < 384 && d->K >= 512 && (d->N % 4 == 0)) {
-        splits = (int)((768 + tiles - 1) / tiles);
-        const int max_splits = d->K / 256;
-        if (splits > max_splits) splits = max_splits;
-        if (splits > 256) splits = 256;
-        if (splits < 1) splits = 1;
+    const bool can_split = d->allow_split && plain && d->K >= 512 && (d->N % 4 == 0);
+    GemmPlan best; best.cfg = 0; best.tiles_m = cdiv(d->M, 128); best.tiles_n = cdiv(d->N, 128); best.splits = 1;
+    best.kps = cdiv(d->K, BK) * BK;
+    double best_cost = 1e300;
+    for (int c = 0; c < 3; ++c) {
+        if (g_force_cfg >= 0 && c != g_force_cfg) continue;
+        const long tm = cdiv(d->M, BMs[c]), tn = cdiv(d->N, BNs[c]);
+        const long tiles = tm * tn;
+        for (int si = 0; si < (int)(sizeof(SPLITS) / sizeof(int)); ++si) {
+            const int want = SPLITS[si];
+            if (want > 1 && (!can_split || want > d->K / 256)) break;
+            if (g_force_splits > 0 && can_split && want != g_force_splits) continue;
+            const int kps = cdiv(cdiv(d->K, want), BK) * BK;
+            const int splits = cdiv(d->K, kps);
+            const long wgs = tiles * splits;
+            const long slots = 256L * OCC[c];
+            const double rounds = wgs <= slots ? 1.0 : (double)wgs / (double)slots;   // workgroups do not run in lockstep: no ceil
+            // one workgroup alone on a CU: 2*BM*BN*kps flop at ~180 flop/clk; plus a fixed prologue/epilogue cost per workgroup
+            const double wg_cycles = 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 1500.0 + 6.0 * BMs[c] * BNs[c] / 64.0;
+            double cost = rounds * OCC[c] * wg_cycles;
+            if (splits > 1) cost += 12000.0 + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best.cfg = c; best.tiles_m = (int)tm; best.tiles_n = (int)tn; best.splits = splits; best.kps = kps;
+            }
+        }
     }
-    pl.kps = cdiv(cdiv(d->K, splits), BK) * BK;
-    pl.splits = cdiv(d->K, pl.kps);
-    return pl;
+    return best;
 }
 
 }  // namespace
@@ -361,16 +358,13 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     MDVIT_CHECK_ARG(d->trans_b ? (d->K % 4 == 0) : (d->N % 4 == 0), MDVIT_E_ALIGN, "gemm: contiguous extent of B must be %% 4 (N=%d K=%d tb=%d)", d->N, d->K, d->trans_b);
     MDVIT_CHECK_ARG(d->epi != MDVIT_EPI_GELU_DUAL || d->C2, MDVIT_E_SHAPE, "gemm: GELU_DUAL needs C2");
     MDVIT_CHECK_ARG(d->epi != MDVIT_EPI_DGELU || d->gelu_u, MDVIT_E_SHAPE, "gemm: DGELU needs gelu_u");
-    MDVIT_CHECK_ARG((long)d->M * d->N < (1L << 32) && (long)d->M * d->K < (1L << 32), MDVIT_E_SHAPE, "gemm: dropout index space exceeds 2^32");
+    MDVIT_CHECK_ARG(!(d->e_drop_p > 0.f) || (long)d->M * d->N < (1L << 32), MDVIT_E_SHAPE, "gemm: dropout index space exceeds 2^32");
 
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = d->A; a.B = d->B; a.C = d->C; a.C2 = d->C2;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K;
     a.bias = d->bias;
-    a.a_drop = d->a_drop_p > 0.f; a.a_k0 = d->a_key0; a.a_k1 = d->a_key1;
-    a.a_thresh = (uint32_t)((double)d->a_drop_p * 4294967296.0); a.a_inv_keep = 1.f / (1.f - d->a_drop_p);
-    a.a_rowscale = d->a_rowscale; a.a_rows_per_scale = d->a_rows_per_scale > 0 ? d->a_rows_per_scale : 1;
     a.epi = d->epi;
     a.e_drop = d->e_drop_p > 0.f; a.e_k0 = d->e_key0; a.e_k1 = d->e_key1;
     a.e_thresh = (uint32_t)((double)d->e_drop_p * 4294967296.0); a.e_inv_keep = 1.f / (1.f - d->e_drop_p);
@@ -393,7 +387,6 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     if (d->epi == MDVIT_EPI_GELU_DUAL) epi = EPI_GELU2;
     else if (d->epi == MDVIT_EPI_DGELU) epi = EPI_DGELU;
     else if (a.e_drop || d->e_rowscale || d->residual) epi = EPI_FULL;
-    const bool apro = a.a_drop || d->a_rowscale != nullptr;
     a.vec = ((d->N & 3) == 0) && ((d->ldc & 3) == 0) && aligned16(d->C);
     if (epi != EPI_PLAIN) {
         MDVIT_CHECK_ARG(a.vec && (!d->bias || aligned16(d->bias)) && (!d->C2 || aligned16(d->C2)) &&
@@ -404,16 +397,28 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
         a.vec = 0;
     }
     int rc;
-    if (pl.cfg == 0) rc = launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, epi, apro, s);
-    else if (pl.cfg == 1) rc = launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, epi, apro, s);
-    else rc = launch_cfg<64, 64, 2, 2>(a, d->trans_a, d->trans_b, epi, apro, s);
-    MDVIT_CHECK_ARG(rc == 0, MDVIT_E_SHAPE, "gemm: this (trans_a=%d, trans_b=%d, epilogue=%d, a_prologue=%d) combination is not built", d->trans_a, d->trans_b, epi, (int)apro);
+    if (pl.cfg == 0) rc = launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, epi, s);
+    else if (pl.cfg == 1) rc = launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, epi, s);
+    else rc = launch_cfg<64, 64, 2, 2>(a, d->trans_a, d->trans_b, epi, s);
+    MDVIT_CHECK_ARG(rc == 0, MDVIT_E_SHAPE, "gemm: this (trans_a=%d, trans_b=%d, epilogue=%d) combination is not built", d->trans_a, d->trans_b, epi);
     if (pl.splits > 1) {
         const long total = (long)d->M * d->N / 4;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)min((total + 255) / 256, 4096L)), dim3(256), 0, s,
-                           a.slab, d->bias, d->C, (long)d->ldc, d->M, d->N, pl.splits, d->accumulate);
+#define MDVIT_REDUCE_LAUNCH(R_) \
+    hipLaunchKernelGGL((gemm_splitk_reduce_kernel<R_>), dim3((int)min((total * R_ + 255) / 256, 4096L)), dim3(256), 0, s, \
+                       a.slab, d->bias, d->C, (long)d->ldc, d->M, d->N, pl.splits, d->accumulate)
+        if (total >= 65536 || pl.splits < 4) MDVIT_REDUCE_LAUNCH(1);
+        else if (total >= 16384 || pl.splits < 16) MDVIT_REDUCE_LAUNCH(4);
+        else if (total >= 4096 || pl.splits < 64) MDVIT_REDUCE_LAUNCH(16);
+        else MDVIT_REDUCE_LAUNCH(64);
+#undef MDVIT_REDUCE_LAUNCH
     }
     MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_gemm_force_plan(int32_t cfg, int32_t splits) {
+    g_force_cfg = (cfg >= 0 && cfg <= 2) ? cfg : -1;
+    g_force_splits = splits > 0 ? splits : 0;
     return MDVIT_OK;
 }
 

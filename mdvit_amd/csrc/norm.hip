@@ -103,6 +103,7 @@ struct ChanArgs {
     const float* a; const float* b;          // MODE0: a=y.  MODE1: a=dz, b=y.  MODE2: a=A
     const float* mean; const float* rstd; const float* gamma; const float* beta;
     double* ws; float* out; float* part;      // ws [2C] doubles + part [grid][2C] floats (MODE0/1); out [C] floats (MODE2)
+    float* masked;                            // MODE2: optional [M,C] copy of a x dropmask x rowscale (the masked upstream gradient)
     long lda; int M, C; int act;
     float drop_p; uint32_t k0, k1, thresh; float inv_keep; int rows_per_sample;
     const float* rowscale; int rows_per_scale;
@@ -158,15 +159,18 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
             }
         } else {
             float r = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
+            float v4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = a4[j] * r;
                 if (p.drop_p > 0.f) v *= mdvit_drop_scale(k0e, k1e, (uint32_t)(row * p.C + c + j), p.thresh, p.inv_keep);
-                s1[j] += v;
+                s1[j] += v; v4[j] = v;
             }
+            if (p.masked) *reinterpret_cast<float4*>(p.masked + row * p.C + c) = make_float4(v4[0], v4[1], v4[2], v4[3]);
         }
     }
     if (MODE == 2) {
+        if (!p.out) return;                   // masked copy only
 #pragma unroll
         for (int j = 0; j < 4; ++j) atomicAdd(&s_acc[c + j], s1[j]);
         __syncthreads();
@@ -496,17 +500,20 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, int32_t M, int32_t N, float drop_p, uint32_t key0, uint32_t key1,
-                                const float* rowscale, int32_t rows_per_scale, int32_t accumulate, const uint32_t* seed, void* stream) {
+extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, int32_t M, int32_t N, float drop_p, uint32_t key0,
+                                uint32_t key1, const float* rowscale, int32_t rows_per_scale, int32_t accumulate, const uint32_t* seed,
+                                void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && N <= 8192 && lda % 4 == 0, MDVIT_E_SHAPE, "colsum: need N %% 4 == 0 (M=%d N=%d)", M, N);
-    if (!accumulate) MDVIT_ZERO(out, sizeof(float) * N, s);
+    MDVIT_CHECK_ARG(out || masked, MDVIT_E_SHAPE, "colsum: nothing to produce (out and masked are both NULL)");
+    MDVIT_CHECK_ARG((long)M * N < (1L << 32), MDVIT_E_SHAPE, "colsum: dropout index space exceeds 2^32");
+    if (out && !accumulate) MDVIT_ZERO(out, sizeof(float) * N, s);
     ChanArgs a; memset(&a, 0, sizeof(a));
-    a.a = A; a.lda = lda; a.M = M; a.C = N; a.out = out;
+    a.a = A; a.lda = lda; a.M = M; a.C = N; a.out = out; a.masked = masked;
     fill_drop(a, drop_p, key0, key1, 1);
     a.seed = seed;
     a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-    hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(chan_grid(M, N, 1024)), dim3(256), sizeof(float) * 2 * N, s, a);
+    hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(chan_grid(M, N, out ? 1024 : 4096)), dim3(256), sizeof(float) * 2 * N, s, a);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

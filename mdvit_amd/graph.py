@@ -46,6 +46,9 @@ class GraphedStep:
             ops.bump_seed()
             return step_fn(self.static)
 
+        if warmup < 1:
+            raise ValueError("GraphedStep needs >= 1 eager warm-up step: lazily created state (AdamW moments, workspaces) "
+                             "must exist before capture or the graph would re-initialise it on every replay")
         if warmup > 0:                       # eager warm-up steps (they DO update the weights) on a side stream, as torch asks
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -192,7 +192,6 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # raw GEMM helper
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
-         a_drop=0.0, a_key=(0, 0), a_rowscale=None, a_rows_per_scale=1,
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
          residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False):
     d = GemmDesc()
@@ -201,8 +200,6 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.M, d.N, d.K = M, N, K
     d.trans_a, d.trans_b = int(trans_a), int(trans_b)
     d.bias = bias
-    d.a_drop_p, d.a_key0, d.a_key1 = a_drop, a_key[0], a_key[1]
-    d.a_rowscale, d.a_rows_per_scale = a_rowscale, a_rows_per_scale
     d.epi = epi
     d.e_drop_p, d.e_key0, d.e_key1 = e_drop, e_key[0], e_key[1]
     d.e_rowscale, d.e_rows_per_scale = e_rowscale, e_rows_per_scale
@@ -210,7 +207,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.gelu_u, d.ldu = gelu_u, ldu
     d.allow_split = int(allow_split)
     d.accumulate = int(accumulate)
-    d.drop_seed = _seed_ptr() if (a_drop > 0 or e_drop > 0) else None
+    d.drop_seed = _seed_ptr() if e_drop > 0 else None
     ws = None
     if allow_split:
         need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
@@ -227,8 +224,13 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     call("mdvit_gemm_f32", C.byref(d), _stream())
     e1.record()
     waves = {128: "2, 2", 256: "4, 1", 64: "2, 2"}[tm.value]       # kernel symbol as rocprofv3 prints it
-    name = "gemm_f32_kernel<%d, %d, %s, %s, %s>%s" % (tm.value, tn.value, waves, "true" if trans_a else "false",
-                                                     "true" if trans_b else "false", "+splitk_reduce" if sp.value > 1 else "")
+    kepi = 1 if epi == _lib.EPI_GELU_DUAL else 2 if epi == _lib.EPI_DGELU else \
+        3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
+    name = "gemm_f32_kernel<%d, %d, %s, %s, %s, %d>%s" % (
+        tm.value, tn.value, waves, "true" if trans_a else "false", "true" if trans_b else "false", kepi,
+        "+splitk_reduce" if sp.value > 1 else "")
+    if _events_by_shape:
+        name += " M=%d N=%d K=%d sp=%d" % (M, N, K, sp.value)
     # algorithmic HBM bytes of the launch: A, B read once, C (and C2 / residual / gelu_u) once
     nbytes = 4.0 * (M * K + N * K + M * N * (1 + (out2 is not None) + (residual is not None) + (gelu_u is not None)))
     _events.append((name, 2.0 * M * N * K, nbytes, e0, e1))
@@ -236,11 +238,13 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
 
 # ---- optional per-kernel timing (bench.py): HIP events on the launch stream around each GEMM ------
 _events = None
+_events_by_shape = False
 
 
-def kernel_events_begin():
-    global _events
+def kernel_events_begin(by_shape: bool = False):
+    global _events, _events_by_shape
     _events = []
+    _events_by_shape = bool(by_shape)
 
 
 def kernel_events_end():
@@ -301,30 +305,35 @@ class _Linear(torch.autograd.Function):
         g = _c(g)
         M, K = x.shape
         N, _, ldb = _ld_view(W)
-        pro = dict(a_drop=drop_p, a_key=key, a_rowscale=_p(rowscale), a_rows_per_scale=rps)
         dx = dW = db = None
-        if ctx.needs_input_grad[0]:
-            dx = _empty_like(x)
-            gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, allow_split=True, **pro)
-        if not _dgrad_only and (ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2])):
+        want_w = not _dgrad_only and (ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]))
+        sW = sb = None
+        if want_w:
             sW = _sink_of(W)
             sb = _sink_of(ctx.bias_ref) if has_b else None
-            if sW is not None and (not has_b or sb is not None):
+        sunk = want_w and sW is not None and (not has_b or sb is not None)
+        want_b = want_w and has_b and (sunk or ctx.needs_input_grad[2])
+        if want_b and not sunk:
+            db = _empty((N,), device=x.device, dtype=torch.float32)
+        # ONE pass over the upstream gradient: gm = g * dropmask * droppath scale (only if there is a mask) and the bias
+        # gradient (column sums of gm); the dgrad / wgrad GEMMs below read gm with no prologue of their own
+        masked = drop_p > 0 or rowscale is not None
+        gm = _empty_like(g) if masked else g
+        if masked or want_b:
+            call("mdvit_colsum_f32", _p(g), N, _p(sb if sunk else db) if want_b else None, _p(gm) if masked else None, M, N,
+                 drop_p, key[0], key[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
+        if ctx.needs_input_grad[0]:
+            dx = _empty_like(x)
+            gemm(_p(gm), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, allow_split=True)
+        if want_w:
+            if sunk:
                 # accumulate straight into the gradient buckets (side stream if enabled); autograd gets None
-                with _on_side(g, x, rowscale):
-                    gemm(_p(g), _p(x), _p(sW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, accumulate=True, **pro)
-                    if has_b:
-                        db, acc_b = sb, True
-                        call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _seed_ptr() if drop_p > 0 else None, _stream())
-                        db = None
-            else:
-                acc_b = False
-                if ctx.needs_input_grad[1]:
-                    dW = _empty(tuple(W.shape) if W.dim() == 4 else (N, K), device=x.device, dtype=torch.float32)
-                    gemm(_p(g), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, **pro)
-                if has_b and ctx.needs_input_grad[2]:
-                    db = _empty((N,), device=x.device, dtype=torch.float32)
-                    call("mdvit_colsum_f32", _p(g), N, _p(db), M, N, drop_p, key[0], key[1], _p(rowscale), rps, int(acc_b), _seed_ptr() if drop_p > 0 else None, _stream())
+                with _on_side(gm, x):
+                    gemm(_p(gm), _p(x), _p(sW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
+                db = None
+            elif ctx.needs_input_grad[1]:
+                dW = _empty(tuple(W.shape) if W.dim() == 4 else (N, K), device=x.device, dtype=torch.float32)
+                gemm(_p(gm), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True)
         return dx, dW, db, (g if has_res else None), None, None, None
 
 
@@ -411,34 +420,38 @@ class _MlpResidual(torch.autograd.Function):
         M, Cin = x.shape
         Hd = W1.shape[0]
         dev = x.device
-        pro = dict(a_drop=drop_p, a_key=k2, a_rowscale=_p(rowscale), a_rows_per_scale=rps)
-        # du = (dy W2) * gelu'(u) * mask1
-        du = _empty_like(u)
-        gemm(_p(g), _p(W2), _p(du), M, Hd, Cin, lda=Cin, ldb=Hd, ldc=Hd, trans_b=False,
-             epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1, **pro)
         dW1 = db1 = dW2 = db2 = None
+        sinks = [_sink_of(t) for t in (W1, ctx.b1_ref, W2, ctx.b2_ref)] if not _dgrad_only else [None] * 4
+        sunk = not _dgrad_only and all(t is not None for t in sinks)
+        if not _dgrad_only and not sunk:
+            db2 = _empty((Cin,), device=dev, dtype=torch.float32)
+        # gm = g * dropmask2 * droppath scale, and db2 = column sums of gm, in one pass
+        masked = drop_p > 0 or rowscale is not None
+        gm = _empty_like(g) if masked else g
+        if masked or not _dgrad_only:
+            call("mdvit_colsum_f32", _p(g), Cin, None if _dgrad_only else _p(sinks[3] if sunk else db2), _p(gm) if masked else None, M, Cin,
+                 drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
+        # du = (gm W2) * gelu'(u) * mask1
+        du = _empty_like(u)
+        gemm(_p(gm), _p(W2), _p(du), M, Hd, Cin, lda=Cin, ldb=Hd, ldc=Hd, trans_b=False,
+             epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)
         dx = _empty_like(x)
         gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False, allow_split=True)
         if not _dgrad_only:
-            sinks = [_sink_of(t) for t in (W1, ctx.b1_ref, W2, ctx.b2_ref)]
-            sunk = all(t is not None for t in sinks)
             if sunk:
-                dW1_, db1, dW2_, db2 = sinks
-                with _on_side(g, h, du, x, rowscale):
-                    gemm(_p(g), _p(h), _p(dW2_), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, accumulate=True, **pro)
-                    call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
+                dW1_, db1_, dW2_, _ = sinks
+                with _on_side(gm, h, du, x):
+                    gemm(_p(gm), _p(h), _p(dW2_), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
                     gemm(_p(du), _p(x), _p(dW1_), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
-                    call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), None, _stream())
-                dW1 = db1 = dW2 = db2 = None
+                    call("mdvit_colsum_f32", _p(du), Hd, _p(db1_), None, M, Hd, 0.0, 0, 0, None, 1, 1, None, _stream())
+                db2 = None
             else:
                 dW2 = _empty_like(W2)
-                gemm(_p(g), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, **pro)
-                db2 = _empty((Cin,), device=dev, dtype=torch.float32)
-                call("mdvit_colsum_f32", _p(g), Cin, _p(db2), M, Cin, drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
+                gemm(_p(gm), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True)
                 dW1 = _empty_like(W1)
                 gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
                 db1 = _empty((Hd,), device=dev, dtype=torch.float32)
-                call("mdvit_colsum_f32", _p(du), Hd, _p(db1), M, Hd, 0.0, 0, 0, None, 1, int(sunk), None, _stream())
+                call("mdvit_colsum_f32", _p(du), Hd, _p(db1), None, M, Hd, 0.0, 0, 0, None, 1, 0, None, _stream())
         return dx, g, dW1, db1, dW2, db2, None, None, None
 
 

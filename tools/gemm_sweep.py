@@ -1,0 +1,61 @@
+"""Ground truth for the GEMM planner: time every (tile config, K-split) of the shapes a bench step uses and compare
+with the planner's pick.  usage: python tools/gemm_sweep.py shapes.json [top]   (shapes.json from bench.py --by-shape --detail)"""
+import ctypes as C, json, re, sys
+import torch
+from mdvit_amd import _lib, ops
+
+lib = _lib.load()
+SPLITS = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256]
+CFG = {0: "128x128", 1: "256x64", 2: "64x64"}
+
+
+def timed(fn, n=6):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    d = json.load(open(sys.argv[1]))
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    seen, total_pl, total_best = set(), 0.0, 0.0
+    for name, r in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms"])[:top]:
+        m = re.search(r"<\d+, \d+, \d, \d, (\w+), (\w+), (\d)(?:, \w+)?>.* M=(\d+) N=(\d+) K=(\d+)", name)
+        ta, tb, epi, M, N, K = m.groups()
+        ta, tb, M, N, K = ta == "true", tb == "true", int(M), int(N), int(K)
+        if int(epi) != 0 or (M, N, K, ta, tb) in seen:
+            continue                      # fused-epilogue GEMMs cannot split; their tile choice is swept via the plain twin
+        seen.add((M, N, K, ta, tb))
+        A = torch.randn((K, M) if ta else (M, K), device="cuda")
+        B = torch.randn((N, K) if tb else (K, N), device="cuda")
+        out = torch.empty((M, N), device="cuda")
+
+        def run():
+            ops.gemm(ops._p(A), ops._p(B), ops._p(out), M, N, K, lda=A.stride(0), ldb=B.stride(0), ldc=N, trans_a=ta, trans_b=tb, allow_split=True)
+        lib.mdvit_gemm_force_plan(-1, 0)
+        t_pl = timed(run)
+        g = _lib.GemmDesc(); g.M, g.N, g.K, g.trans_a, g.trans_b, g.allow_split = M, N, K, int(ta), int(tb), 1
+        tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+        lib.mdvit_gemm_plan(C.byref(g), C.byref(tm), C.byref(tn), C.byref(sp))
+        res = []
+        for cfg in range(3):
+            for s in SPLITS:
+                if s > 1 and (K < 512 or s > K // 256):
+                    break
+                lib.mdvit_gemm_force_plan(cfg, s)
+                res.append((timed(run, 4), cfg, s))
+        lib.mdvit_gemm_force_plan(-1, 0)
+        res.sort()
+        bt, bc, bs = res[0]
+        total_pl += t_pl * r["n"]; total_best += bt * r["n"]
+        fl = 2.0 * M * N * K
+        print(f"M={M:>7} N={N:>5} K={K:>7} {'T' if ta else 'N'}{'T' if tb else 'N'} x{r['n']:3d}  planner {tm.value}x{tn.value} sp={sp.value:<4d} {t_pl:8.1f} us ({fl/t_pl/1e6:5.1f} TF)"
+              f" | best {CFG[bc]} sp={bs:<4d} {bt:8.1f} us ({fl/bt/1e6:5.1f} TF) | next {CFG[res[1][1]]} sp={res[1][2]} {res[1][0]:.1f}", flush=True)
+    print(f"weighted: planner {total_pl/1e3:.2f} ms, best {total_best/1e3:.2f} ms")
+
+
+main()

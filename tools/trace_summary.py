@@ -42,7 +42,7 @@ def main():
         print(f"gaps: n={len(gaps)} median {gaps[len(gaps)//2]/1e3:.1f} us  p90 {gaps[int(len(gaps)*0.9)]/1e3:.1f} us  sum {sum(gaps)/1e6:.1f} ms")
     tot = sum(v[0] for v in per.values())
     print(f"sum of kernel durations {tot:.1f} ms  ({tot/steps:.1f} ms/step)")
-    for name, (d, n) in sorted(per.items(), key=lambda kv: -kv[1][0])[:60]:
+    for name, (d, n) in sorted(per.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[sys.argv.index('--top') + 1]) if '--top' in sys.argv else 60]:
         print(f"{d/steps:8.2f} ms/step {n//steps:6d}/step {d/n*1e3:8.1f} us  {100*d/tot:5.1f}%  {name[:110]}")
 
 main()
