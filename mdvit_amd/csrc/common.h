@@ -47,10 +47,24 @@ __device__ __forceinline__ uint32_t mdvit_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-// keep-scale for element idx under (k0,k1): 0 or inv_keep.  thresh = round(p * 2^32).
+// Dropout keep-scales (0 or inv_keep), thresh = round(p * 2^32).  ONE 32-bit hash per aligned group of four elements,
+// rotated by a byte per element: each element still sees a uniform 32-bit value (exact drop probability), the four
+// decisions hang on disjoint top bytes, and the two quarter-rate v_mul_lo_u32 rounds are paid once per float4 instead
+// of once per element (they dominated the VALU time of the K=64/128 MLP GEMM epilogues).
+__device__ __forceinline__ uint32_t mdvit_drop_bits(uint32_t k0, uint32_t k1, uint32_t idx) {
+    return mdvit_hash32(mdvit_hash32((idx >> 2) ^ k0) + k1);
+}
 __device__ __forceinline__ float mdvit_drop_scale(uint32_t k0, uint32_t k1, uint32_t idx, uint32_t thresh, float inv_keep) {
-    uint32_t h = mdvit_hash32(mdvit_hash32(idx ^ k0) + k1);
+    const uint32_t h = __builtin_rotateright32(mdvit_drop_bits(k0, k1, idx), 8u * (idx & 3u));
     return h >= thresh ? inv_keep : 0.0f;
+}
+// idx4 % 4 == 0: scales of elements idx4 .. idx4+3
+__device__ __forceinline__ float4 mdvit_drop_scale4(uint32_t k0, uint32_t k1, uint32_t idx4, uint32_t thresh, float inv_keep) {
+    const uint32_t h = mdvit_drop_bits(k0, k1, idx4);
+    return make_float4(h >= thresh ? inv_keep : 0.0f,
+                       __builtin_rotateright32(h, 8) >= thresh ? inv_keep : 0.0f,
+                       __builtin_rotateright32(h, 16) >= thresh ? inv_keep : 0.0f,
+                       __builtin_rotateright32(h, 24) >= thresh ? inv_keep : 0.0f);
 }
 
 // ---- wave / block reductions -----------------------------------------------------------------

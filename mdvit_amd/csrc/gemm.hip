@@ -212,10 +212,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 if (EPI == EPI_GELU2) {
                     float4 h = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
                     if (p.e_drop) {
-                        h.x *= mdvit_drop_scale(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
-                        h.y *= mdvit_drop_scale(ek0, ek1, didx + 1, p.e_thresh, p.e_inv_keep);
-                        h.z *= mdvit_drop_scale(ek0, ek1, didx + 2, p.e_thresh, p.e_inv_keep);
-                        h.w *= mdvit_drop_scale(ek0, ek1, didx + 3, p.e_thresh, p.e_inv_keep);
+                        const float4 ds = mdvit_drop_scale4(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
+                        h.x *= ds.x; h.y *= ds.y; h.z *= ds.z; h.w *= ds.w;
                     }
                     *reinterpret_cast<float4*>(dst) = v;
                     *reinterpret_cast<float4*>(p.C2 + (long)row * p.ldc + col) = h;
@@ -226,10 +224,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                     v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
                 }
                 if (p.e_drop) {
-                    v.x *= mdvit_drop_scale(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
-                    v.y *= mdvit_drop_scale(ek0, ek1, didx + 1, p.e_thresh, p.e_inv_keep);
-                    v.z *= mdvit_drop_scale(ek0, ek1, didx + 2, p.e_thresh, p.e_inv_keep);
-                    v.w *= mdvit_drop_scale(ek0, ek1, didx + 3, p.e_thresh, p.e_inv_keep);
+                    const float4 ds = mdvit_drop_scale4(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
+                    v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
                 }
                 if (EPI == EPI_FULL) {
                     v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
@@ -333,7 +329,7 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
             const long slots = 256L * OCC[c];
             const double rounds = wgs <= slots ? 1.0 : (double)wgs / (double)slots;   // workgroups do not run in lockstep: no ceil
             // one workgroup alone on a CU: 2*BM*BN*kps flop at ~180 flop/clk; plus a fixed prologue/epilogue cost per workgroup
-            const double wg_cycles = 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 1500.0 + 6.0 * BMs[c] * BNs[c] / 64.0;
+            const double wg_cycles = 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0;
             double cost = rounds * OCC[c] * wg_cycles;
             if (splits > 1) cost += 12000.0 + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;
             if (cost < best_cost) {

@@ -149,21 +149,28 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
         } else if (MODE == 1) {
             const float4 yv = *reinterpret_cast<const float4*>(p.b + row * p.C + c);
             const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+            float ds[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop_p > 0.f) {
+                const float4 d4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c), p.thresh, p.inv_keep);
+                ds[0] = d4.x; ds[1] = d4.y; ds[2] = d4.z; ds[3] = d4.w;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float xh = (y4[j] - mu[j]) * rs[j];
-                float g = a4[j] * act_grad(p.act, xh * ga[j] + be[j]);
-                if (p.drop_p > 0.f)
-                    g *= mdvit_drop_scale(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+                const float g = a4[j] * act_grad(p.act, xh * ga[j] + be[j]) * ds[j];
                 s1[j] += g; s2[j] += g * xh;
             }
         } else {
             float r = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
             float v4[4];
+            float ds[4] = {r, r, r, r};
+            if (p.drop_p > 0.f) {
+                const float4 d4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)(row * p.C + c), p.thresh, p.inv_keep);
+                ds[0] *= d4.x; ds[1] *= d4.y; ds[2] *= d4.z; ds[3] *= d4.w;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = a4[j] * r;
-                if (p.drop_p > 0.f) v *= mdvit_drop_scale(k0e, k1e, (uint32_t)(row * p.C + c + j), p.thresh, p.inv_keep);
+                const float v = a4[j] * ds[j];
                 s1[j] += v; v4[j] = v;
             }
             if (p.masked) *reinterpret_cast<float4*>(p.masked + row * p.C + c) = make_float4(v4[0], v4[1], v4[2], v4[3]);
@@ -262,12 +269,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __rest
         const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
         const int gc = (int)(row / p.rows_per_group) * p.C + c;
         float o[4];
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop_p > 0.f) {
+            const float4 d4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c), p.thresh, p.inv_keep);
+            ds[0] = d4.x; ds[1] = d4.y; ds[2] = d4.z; ds[3] = d4.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float pre = (y4[j] - p.mean[gc + j]) * p.rstd[gc + j] * p.gamma[c + j] + p.beta[c + j];
-            o[j] = act_fwd(p.act, pre);
-            if (p.drop_p > 0.f)
-                o[j] *= mdvit_drop_scale(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+            o[j] = act_fwd(p.act, pre) * ds[j];
         }
         *reinterpret_cast<float4*>(z + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -289,13 +299,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __
         const int gc = grp * p.C + c;
         const double* wsg = p.ws + (long)grp * 2 * p.C;
         float o[4];
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop_p > 0.f) {
+            const float4 q4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c), p.thresh, p.inv_keep);
+            ds[0] = q4.x; ds[1] = q4.y; ds[2] = q4.z; ds[3] = q4.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float rs = p.rstd[gc + j], ga = p.gamma[c + j];
             const float xh = (y4[j] - p.mean[gc + j]) * rs;
-            float g = d4[j] * act_grad(p.act, xh * ga + p.beta[c + j]);
-            if (p.drop_p > 0.f)
-                g *= mdvit_drop_scale(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c + j), p.thresh, p.inv_keep);
+            const float g = d4[j] * act_grad(p.act, xh * ga + p.beta[c + j]) * ds[j];
             if (training) {
                 const float sg = (float)(wsg[c + j] * invM), sgx = (float)(wsg[p.C + c + j] * invM);
                 o[j] = ga * rs * (g - sg - xh * sgx);

@@ -27,15 +27,28 @@ def main():
         m = re.search(r"<\d+, \d+, \d, \d, (\w+), (\w+), (\d)(?:, \w+)?>.* M=(\d+) N=(\d+) K=(\d+)", name)
         ta, tb, epi, M, N, K = m.groups()
         ta, tb, M, N, K = ta == "true", tb == "true", int(M), int(N), int(K)
-        if int(epi) != 0 or (M, N, K, ta, tb) in seen:
-            continue                      # fused-epilogue GEMMs cannot split; their tile choice is swept via the plain twin
-        seen.add((M, N, K, ta, tb))
+        epi = int(epi)
+        if (M, N, K, ta, tb, epi) in seen:
+            continue
+        seen.add((M, N, K, ta, tb, epi))
         A = torch.randn((K, M) if ta else (M, K), device="cuda")
         B = torch.randn((N, K) if tb else (K, N), device="cuda")
         out = torch.empty((M, N), device="cuda")
 
+        extra = {}
+        if epi == 1:
+            out2 = torch.empty_like(out); bias = torch.randn(N, device="cuda")
+            extra = dict(out2=ops._p(out2), bias=ops._p(bias), epi=_lib.EPI_GELU_DUAL, e_drop=0.1, e_key=(1, 2))
+        elif epi == 2:
+            u = torch.randn((M, N), device="cuda")
+            extra = dict(epi=_lib.EPI_DGELU, gelu_u=ops._p(u), ldu=N, e_drop=0.1, e_key=(1, 2))
+        elif epi == 3:
+            res = torch.randn((M, N), device="cuda"); bias = torch.randn(N, device="cuda")
+            extra = dict(residual=ops._p(res), ldr=N, bias=ops._p(bias), e_drop=0.1, e_key=(1, 2))
+
         def run():
-            ops.gemm(ops._p(A), ops._p(B), ops._p(out), M, N, K, lda=A.stride(0), ldb=B.stride(0), ldc=N, trans_a=ta, trans_b=tb, allow_split=True)
+            ops.gemm(ops._p(A), ops._p(B), ops._p(out), M, N, K, lda=A.stride(0), ldb=B.stride(0), ldc=N, trans_a=ta, trans_b=tb,
+                     allow_split=epi == 0, **extra)
         lib.mdvit_gemm_force_plan(-1, 0)
         t_pl = timed(run)
         g = _lib.GemmDesc(); g.M, g.N, g.K, g.trans_a, g.trans_b, g.allow_split = M, N, K, int(ta), int(tb), 1
@@ -44,7 +57,7 @@ def main():
         res = []
         for cfg in range(3):
             for s in SPLITS:
-                if s > 1 and (K < 512 or s > K // 256):
+                if s > 1 and (epi != 0 or K < 512 or s > K // 256):
                     break
                 lib.mdvit_gemm_force_plan(cfg, s)
                 res.append((timed(run, 4), cfg, s))
@@ -53,7 +66,7 @@ def main():
         bt, bc, bs = res[0]
         total_pl += t_pl * r["n"]; total_best += bt * r["n"]
         fl = 2.0 * M * N * K
-        print(f"M={M:>7} N={N:>5} K={K:>7} {'T' if ta else 'N'}{'T' if tb else 'N'} x{r['n']:3d}  planner {tm.value}x{tn.value} sp={sp.value:<4d} {t_pl:8.1f} us ({fl/t_pl/1e6:5.1f} TF)"
+        print(f"M={M:>7} N={N:>5} K={K:>7} {'T' if ta else 'N'}{'T' if tb else 'N'} e{epi} x{r['n']:3d}  planner {tm.value}x{tn.value} sp={sp.value:<4d} {t_pl:8.1f} us ({fl/t_pl/1e6:5.1f} TF)"
               f" | best {CFG[bc]} sp={bs:<4d} {bt:8.1f} us ({fl/bt/1e6:5.1f} TF) | next {CFG[res[1][1]]} sp={res[1][2]} {res[1][0]:.1f}", flush=True)
     print(f"weighted: planner {total_pl/1e3:.2f} ms, best {total_best/1e3:.2f} ms")
 
