@@ -123,13 +123,38 @@ __global__ __launch_bounds__(256) void fa_combine_kernel(const float* __restrict
 // produces 16 outputs along w from WIN input rows held in registers (16*WIN FMAs per TW+WIN-1 LDS reads).
 constexpr int CT_TH = 8, CT_TW = 16, CT_CL = 32;
 
+// Stage an LHxLW token window x 32 channels into LDS ([position][channel]); zero outside the image / past `nch` channels.
+// 8 lanes x float4 cover one position, 32 positions per pass; ALL global loads of the window are issued before the
+// first LDS store (a load -> store loop would pay the HBM latency once per iteration).  x already points at the first
+// channel of the block; nch % 4 == 0.
+template <int LH, int LW>
+__device__ __forceinline__ void ct_stage_window(float* __restrict__ sx, const float* __restrict__ x, long ldx, long img,
+                                                int h0, int w0, int H, int W, int nch) {
+    constexpr int NP = LH * LW, PASSES = (NP + 31) / 32;
+    const int q4 = (threadIdx.x & 7) * 4, pl = threadIdx.x >> 3;
+    float4 v[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int p = pl + 32 * i;
+        const int hh = h0 + p / LW, ww = w0 + p % LW;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < NP && hh >= 0 && hh < H && ww >= 0 && ww < W && q4 < nch)
+            v[i] = *reinterpret_cast<const float4*>(x + (img + (long)hh * W + ww) * ldx + q4);
+    }
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int p = pl + 32 * i;
+        if (p < NP) *reinterpret_cast<float4*>(sx + p * CT_CL + q4) = v[i];
+    }
+}
+
 template <int WIN, bool FLIP>
 __global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restrict__ x, long ldx, int xoff,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            float* __restrict__ y, long ldy, int yoff,
                                                            int H, int W, int ncls, int tiles_w) {
     constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
-    __shared__ float sx[LH * LW * CT_CL];
+    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
     __shared__ float sw[CT_CL * WIN * WIN];
     const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
     const int th0 = (blockIdx.x / tiles_w) * CT_TH, tw0 = (blockIdx.x % tiles_w) * CT_TW;
@@ -139,12 +164,7 @@ __global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restri
         const int c = i / (WIN * WIN), t = i % (WIN * WIN);
         sw[i] = (c0 + c < ncls) ? w[(long)(c0 + c) * WIN * WIN + (FLIP ? WIN * WIN - 1 - t : t)] : 0.f;
     }
-    for (int p = rl; p < LH * LW; p += 8) {
-        const int hh = th0 + p / LW - R, ww = tw0 + p % LW - R;
-        float v = 0.f;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W && c0 + cl < ncls) v = x[(img + (long)hh * W + ww) * ldx + xoff + c0 + cl];
-        sx[p * CT_CL + cl] = v;
-    }
+    ct_stage_window<LH, LW>(sx, x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
     __syncthreads();
     const int h = th0 + rl;
     if (c0 + cl >= ncls || h >= H) return;
@@ -178,8 +198,8 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
                                                                  float* __restrict__ dw, float* __restrict__ db,
                                                                  int H, int W, int ncls, int tiles_w, int tiles_total, int tiles_per_block) {
     constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
-    __shared__ float sx[LH * LW * CT_CL];
-    __shared__ float sg[CT_TH * CT_TW * CT_CL];
+    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
+    __shared__ __attribute__((aligned(16))) float sg[CT_TH * CT_TW * CT_CL];
     const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;          // rl = window row i (threads with rl >= WIN only help loading)
     const long img = (long)b * H * W;
@@ -191,18 +211,8 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
     const int t_beg = blockIdx.x * tiles_per_block, t_end = min(tiles_total, t_beg + tiles_per_block);
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int th0 = (tile / tiles_w) * CT_TH, tw0 = (tile % tiles_w) * CT_TW;
-        for (int p = rl; p < LH * LW; p += 8) {
-            const int hh = th0 + p / LW - R, ww = tw0 + p % LW - R;
-            float v = 0.f;
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W && chan_ok) v = x[(img + (long)hh * W + ww) * ldx + xoff + c0 + cl];
-            sx[p * CT_CL + cl] = v;
-        }
-        for (int p = rl; p < CT_TH * CT_TW; p += 8) {
-            const int hh = th0 + p / CT_TW, ww = tw0 + p % CT_TW;
-            float v = 0.f;
-            if (hh < H && ww < W && chan_ok) v = g[(img + (long)hh * W + ww) * ldg + goff + c0 + cl];
-            sg[p * CT_CL + cl] = v;
-        }
+        ct_stage_window<LH, LW>(sx, x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
+        ct_stage_window<CT_TH, CT_TW>(sg, g + goff + c0, ldg, img, th0, tw0, H, W, ncls - c0);
         __syncthreads();
         if (rl < WIN && chan_ok) {
 #pragma unroll 2
