@@ -311,63 +311,117 @@ __global__ void fa_bwd_mid_kernel(const float* __restrict__ dM, const float* __r
 }
 
 // ---- bwd 5: dq, dk, dv ----------------------------------------------------------------------------
-// blockDim = TLN * C: TLN tokens are processed together, one thread per (token, channel).  The head rows
-// P = softmax column weights, dFA and v of those tokens go through LDS so the three Ch-long contractions
-// read them as broadcasts; M / dM stay in global memory (L2-resident, [C,Ch] per image).
+// Per image and head three token x Ch x Ch products (dq = dFA.KV^T, dP = v.dKV^T, dv = P.dKV) plus element-wise terms.
+// They run on v_mfma_f32_32x32x2_f32 as D[channel][token] = W[channel][k] . X[k][token]:
+//   * a wavefront owns 32 tokens of one channel GROUP (GW = max(Ch, 32) channels = 4/2/1/1 heads for Ch = 8/16/40/64);
+//     for Ch < 32 the small matrices are staged block-diagonally in LDS so one 32-wide MFMA tile serves several heads;
+//   * lane (token = lane % 32, half = lane / 32) holds its token's channels as the quads {32*(q/4) + 8*(q%4) + 4*half},
+//     and the k index of MFMA step kk is mapped to exactly those channels -- so the values a lane loads (float4, once)
+//     are both its MFMA operands and the element-wise terms of the 4-consecutive-channel quads the MFMA hands back to it;
+//   * W elements come from LDS (row stride GW + 1: conflict-free for row- and column-wise walks).
+// The kernel is HBM-bound: reads dout, k, v, U, dVc, writes dq|dk|dv, each exactly once.
+typedef float fa_f32x16 __attribute__((ext_vector_type(16)));
+
 template <int CH>
-__global__ __launch_bounds__(512) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+__global__ __launch_bounds__(256) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
                                                            const float* __restrict__ U, const float* __restrict__ dVc,
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
                                                            const float* __restrict__ dM, const float* __restrict__ tcol,
-                                                           float* __restrict__ dqkv, FaGeom g, int TLN, int tokens_per_block) {
-    extern __shared__ float sm[];          // s_P[TLN][C], s_dfa[TLN][C], s_v[TLN][C]
+                                                           float* __restrict__ dqkv, FaGeom g, int tiles_per_block) {
+    constexpr int GW = CH < 32 ? 32 : CH;          // channels per group
+    constexpr int NB = (GW + 31) / 32;             // 32-channel MFMA row blocks
+    constexpr int NQ = GW / 8;                     // float4 quads per lane
+    constexpr int KS = GW / 2;                     // MFMA k-steps
+    constexpr int LD = GW + 1;
+    __shared__ float sKV[GW * LD], sD[GW * LD];
+    __shared__ __attribute__((aligned(16))) float s_a[GW], s_km[GW], s_ks[GW], s_tc[GW];
     const int C = g.C, C3 = 3 * C;
-    float* s_P = sm;
-    float* s_dfa = sm + TLN * C;
-    float* s_v = sm + 2 * TLN * C;
-    const int c = threadIdx.x % C, tl = threadIdx.x / C;
-    const int b = blockIdx.y;
-    const int head = c / CH, ch = c % CH, hb = head * CH;
-    const float ac = a ? a[(long)b * C + c] : 1.f;
-    const float km = kmax[(long)b * C + c], ksinv = 1.0f / ksum[(long)b * C + c], tc = tcol[(long)b * C + c];
-    const float* Mrow = Mmat + ((long)b * C + c) * CH;        // M[c][e]
-    const float* dMrow = dM + ((long)b * C + c) * CH;         // dM[c][e]
-    const float* dMcol = dM + ((long)b * C + hb) * CH + ch;   // dM[hb+j][ch], stride CH
-    const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
-    for (int base = n_beg; base < n_end; base += TLN) {
-        const int n = base + tl;
-        const bool ok = n < n_end;
-        const long tok = (long)b * g.N + (ok ? n : n_beg);
-        float G = 0.f, P = 0.f;
-        if (ok) {
-            const float* row = qkv + tok * C3;
-            G = dout[tok * C + c];
-            P = expf(row[C + c] - km) * ksinv;
-            s_P[tl * C + c] = P;
-            s_dfa[tl * C + c] = g.scale * ac * G;
-            s_v[tl * C + c] = row[2 * C + c];
+    const int b = blockIdx.z, g0 = blockIdx.y * GW;
+    for (int i = threadIdx.x; i < GW * GW; i += 256) {
+        const int r = i / GW, cc = i % GW;
+        const bool same = (r / CH) == (cc / CH);
+        const long src = ((long)b * C + g0 + r) * CH + (cc % CH);
+        sKV[r * LD + cc] = same ? Mmat[src] : 0.f;
+        sD[r * LD + cc] = same ? dM[src] : 0.f;
+    }
+    for (int i = threadIdx.x; i < GW; i += 256) {
+        const long ci = (long)b * C + g0 + i;
+        s_a[i] = a ? a[ci] : 1.f; s_km[i] = kmax[ci]; s_ks[i] = 1.0f / ksum[ci]; s_tc[i] = tcol[ci];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane & 31, half = lane >> 5;
+    const int ntiles = (g.N + 31) / 32;
+    const int tile_beg = blockIdx.x * tiles_per_block, tile_end = min(ntiles, tile_beg + tiles_per_block);
+    const float inv_scale = 1.0f / g.scale;
+    for (int tile = tile_beg + wave; tile < tile_end; tile += 4) {
+        const int n = tile * 32 + t;
+        const bool ok = n < g.N;
+        const long tok = (long)b * g.N + (ok ? n : g.N - 1);
+        const float* grow = dout + tok * C + g0;
+        const float* krow = qkv + tok * C3 + C + g0;
+        float dfa[NQ][4], vv[NQ][4], pp[NQ][4];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
+            const float4 g4 = *reinterpret_cast<const float4*>(grow + cq);
+            const float4 k4 = *reinterpret_cast<const float4*>(krow + cq);
+            const float4 v4 = *reinterpret_cast<const float4*>(krow + C + cq);
+            const float4 a4 = *reinterpret_cast<const float4*>(s_a + cq);
+            const float4 m4 = *reinterpret_cast<const float4*>(s_km + cq);
+            const float4 i4 = *reinterpret_cast<const float4*>(s_ks + cq);
+            const float z = ok ? 1.f : 0.f;          // out-of-range tokens contribute zeros (their results are not stored)
+            dfa[q][0] = z * g.scale * a4.x * g4.x; dfa[q][1] = z * g.scale * a4.y * g4.y;
+            dfa[q][2] = z * g.scale * a4.z * g4.z; dfa[q][3] = z * g.scale * a4.w * g4.w;
+            vv[q][0] = z * v4.x; vv[q][1] = z * v4.y; vv[q][2] = z * v4.z; vv[q][3] = z * v4.w;
+            pp[q][0] = z * expf(k4.x - m4.x) * i4.x; pp[q][1] = z * expf(k4.y - m4.y) * i4.y;
+            pp[q][2] = z * expf(k4.z - m4.z) * i4.z; pp[q][3] = z * expf(k4.w - m4.w) * i4.w;
         }
-        __syncthreads();
-        if (ok) {
-            float dq = 0.f, dP = 0.f, dv = 0.f;
-            const float* pr = &s_P[tl * C + hb];
-            const float* fr = &s_dfa[tl * C + hb];
-            const float* vr = &s_v[tl * C + hb];
-#pragma unroll 8
-            for (int e = 0; e < CH; ++e) {
-                dq = fmaf(fr[e], Mrow[e], dq);
-                dP = fmaf(vr[e], dMrow[e], dP);
-                dv = fmaf(pr[e], dMcol[(long)e * CH], dv);
+        fa_f32x16 acc1[NB], acc2[NB], acc3[NB];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc1[ob][r] = 0.f; acc2[ob][r] = 0.f; acc3[ob][r] = 0.f; }
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            const int orow = 32 * ob + t;                       // W row (output channel) this lane feeds
+            const bool rok = orow < GW;
+            const int orc = rok ? orow : 0;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int q = kk / 4, j = kk % 4;
+                const int kc = 32 * (q / 4) + 8 * (q % 4) + 4 * half + j;      // channel of this lane's k slot
+                float w1 = sKV[orc * LD + kc], w2 = sD[orc * LD + kc], w3 = sD[kc * LD + orc];
+                if (!rok) { w1 = 0.f; w2 = 0.f; w3 = 0.f; }
+                acc1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, dfa[q][j], acc1[ob], 0, 0, 0);
+                acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2, vv[q][j], acc2[ob], 0, 0, 0);
+                acc3[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w3, pp[q][j], acc3[ob], 0, 0, 0);
             }
-            dv += dVc[tok * C + c];                       // conv^T(dU), from the tiled (flipped-window) conv
-            dq = fmaf(ac * G, U[tok * C + c], dq);
-            float* drow = dqkv + tok * C3;
-            drow[c] = dq;
-            drow[C + c] = P * (dP - tc);
-            drow[2 * C + c] = dv;
         }
-        __syncthreads();
+        if (ok) {
+            const float* urow = U + tok * C + g0;
+            const float* crow = dVc + tok * C + g0;
+            float* drow = dqkv + tok * C3 + g0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ob = q / 4, r0 = 4 * (q % 4);
+                const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
+                const float4 u4 = *reinterpret_cast<const float4*>(urow + cq);
+                const float4 c4 = *reinterpret_cast<const float4*>(crow + cq);
+                const float4 t4 = *reinterpret_cast<const float4*>(s_tc + cq);
+                float4 dq, dk, dv;
+                dq.x = fmaf(dfa[q][0] * inv_scale, u4.x, acc1[ob][r0 + 0]); dq.y = fmaf(dfa[q][1] * inv_scale, u4.y, acc1[ob][r0 + 1]);
+                dq.z = fmaf(dfa[q][2] * inv_scale, u4.z, acc1[ob][r0 + 2]); dq.w = fmaf(dfa[q][3] * inv_scale, u4.w, acc1[ob][r0 + 3]);
+                dk.x = pp[q][0] * (acc2[ob][r0 + 0] - t4.x); dk.y = pp[q][1] * (acc2[ob][r0 + 1] - t4.y);
+                dk.z = pp[q][2] * (acc2[ob][r0 + 2] - t4.z); dk.w = pp[q][3] * (acc2[ob][r0 + 3] - t4.w);
+                dv.x = acc3[ob][r0 + 0] + c4.x; dv.y = acc3[ob][r0 + 1] + c4.y;
+                dv.z = acc3[ob][r0 + 2] + c4.z; dv.w = acc3[ob][r0 + 3] + c4.w;
+                *reinterpret_cast<float4*>(drow + cq) = dq;
+                *reinterpret_cast<float4*>(drow + C + cq) = dk;
+                *reinterpret_cast<float4*>(drow + 2 * C + cq) = dv;
+            }
+        }
     }
 }
 
@@ -617,13 +671,13 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     launch_conv_tile<7, true>(dU, (long)C, c7, w7, nullptr, dVc, (long)C, c7, g, s7 * Ch, s);
     // 4, 5
     hipLaunchKernelGGL(fa_bwd_mid_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, dM, Mmat, tcol, B * C, Ch);
-    const int TLN = max(1, 256 / C);
-    const int block = TLN * C;
-    int tpb = TLN * 8;
-    while ((long)cdiv(g.N, tpb) * B > 8192) tpb *= 2;
-    const size_t lds = sizeof(float) * 3 * TLN * C;
-    dim3 grid(cdiv(g.N, tpb), B);
-#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(block), lds, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, dM, tcol, dqkv, g, TLN, tpb)
+    const int GW = Ch < 32 ? 32 : Ch;
+    MDVIT_CHECK_ARG(C % GW == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GW);
+    const int ntiles = cdiv(g.N, 32);
+    int tpb = 4;                                   // 32-token tiles per block (one per wavefront), doubled while the grid stays large
+    while (tpb < 64 && (long)cdiv(ntiles, tpb * 2) * (C / GW) * B >= 2048) tpb *= 2;
+    dim3 grid(cdiv(ntiles, tpb), C / GW, B);
+#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, dM, tcol, dqkv, g, tpb)
     switch (Ch) {
         case 8: FA_BWD_LAUNCH(8); break;
         case 16: FA_BWD_LAUNCH(16); break;
