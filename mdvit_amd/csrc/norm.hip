@@ -94,6 +94,113 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm for C = 64*VPL (the model's 64/128/320/512): 16 lanes per token row (4 rows per wavefront), each lane
+// VPL float4 quads strided by 16 -> 16-byte coalesced loads, 4-step 16-lane shuffle reductions, 4 independent rows
+// in flight per wavefront (the wave-per-row kernels above move 4 bytes per lane and serialise on 6-step reductions).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_fwd16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int M, float eps) {
+    constexpr int C = 64 * VPL;
+    const int sub = threadIdx.x & 15;
+    const long r0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, nr = ((long)gridDim.x * blockDim.x) >> 4;
+    float4 ga[VPL], be[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        ga[j] = *reinterpret_cast<const float4*>(gamma + 4 * (sub + 16 * j));
+        be[j] = *reinterpret_cast<const float4*>(beta + 4 * (sub + 16 * j));
+    }
+    for (long row = r0; row < M; row += nr) {
+        const float* xr = x + row * C;
+        float4 v[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) { v[j] = *reinterpret_cast<const float4*>(xr + 4 * (sub + 16 * j)); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+        const float mu = sum16(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+        }
+        const float rs = 1.0f / sqrtf(sum16(q) * (1.0f / C) + eps);
+        float* yr = y + row * C;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+            *reinterpret_cast<float4*>(yr + 4 * (sub + 16 * j)) =
+                make_float4(v[j].x * rs * ga[j].x + be[j].x, v[j].y * rs * ga[j].y + be[j].y, v[j].z * rs * ga[j].z + be[j].z, v[j].w * rs * ga[j].w + be[j].w);
+        if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ dx,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+    constexpr int C = 64 * VPL;
+    __shared__ float s_dg[4][C], s_db[4][C];
+    const int sub = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, nr = ((long)gridDim.x * blockDim.x) >> 4;
+    float4 ga[VPL], adg[VPL], adb[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        ga[j] = *reinterpret_cast<const float4*>(gamma + 4 * (sub + 16 * j));
+        adg[j] = make_float4(0.f, 0.f, 0.f, 0.f); adb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long row = r0; row < M; row += nr) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[VPL], d[VPL];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dy + row * C + 4 * (sub + 16 * j));
+            const float4 x4 = *reinterpret_cast<const float4*>(x + row * C + 4 * (sub + 16 * j));
+            xh[j] = make_float4((x4.x - mu) * rs, (x4.y - mu) * rs, (x4.z - mu) * rs, (x4.w - mu) * rs);
+            d[j] = make_float4(g4.x * ga[j].x, g4.y * ga[j].y, g4.z * ga[j].z, g4.w * ga[j].w);
+            c1 += (d[j].x + d[j].y) + (d[j].z + d[j].w);
+            c2 += (d[j].x * xh[j].x + d[j].y * xh[j].y) + (d[j].z * xh[j].z + d[j].w * xh[j].w);
+            adg[j].x += g4.x * xh[j].x; adg[j].y += g4.y * xh[j].y; adg[j].z += g4.z * xh[j].z; adg[j].w += g4.w * xh[j].w;
+            adb[j].x += g4.x; adb[j].y += g4.y; adb[j].z += g4.z; adb[j].w += g4.w;
+        }
+        c1 = sum16(c1) * (1.0f / C);
+        c2 = sum16(c2) * (1.0f / C);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+            *reinterpret_cast<float4*>(dx + row * C + 4 * (sub + 16 * j)) =
+                make_float4(rs * (d[j].x - c1 - xh[j].x * c2), rs * (d[j].y - c1 - xh[j].y * c2),
+                            rs * (d[j].z - c1 - xh[j].z * c2), rs * (d[j].w - c1 - xh[j].w * c2));
+    }
+    // fold the 4 row slots of the wavefront (lanes sub, sub+16, sub+32, sub+48), then the 4 wavefronts through LDS
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            adg[j].x += __shfl_xor(adg[j].x, o, 64); adg[j].y += __shfl_xor(adg[j].y, o, 64);
+            adg[j].z += __shfl_xor(adg[j].z, o, 64); adg[j].w += __shfl_xor(adg[j].w, o, 64);
+            adb[j].x += __shfl_xor(adb[j].x, o, 64); adb[j].y += __shfl_xor(adb[j].y, o, 64);
+            adb[j].z += __shfl_xor(adb[j].z, o, 64); adb[j].w += __shfl_xor(adb[j].w, o, 64);
+        }
+        if (lane < 16) {
+            *reinterpret_cast<float4*>(&s_dg[wave][4 * (sub + 16 * j)]) = adg[j];
+            *reinterpret_cast<float4*>(&s_db[wave][4 * (sub + 16 * j)]) = adb[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        atomicAdd(&dgamma[c], (s_dg[0][c] + s_dg[1][c]) + (s_dg[2][c] + s_dg[3][c]));
+        atomicAdd(&dbeta[c], (s_db[0][c] + s_db[1][c]) + (s_db[2][c] + s_db[3][c]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Channel reductions over [M,C] viewed as float4 quads: total thread count is a multiple of C/4 so
 // every thread owns ONE channel quad.  MODE 0: sum & sumsq of y (BN stats).  MODE 1: BN backward
 // sums (sum g, sum g*xhat) with g = dz * drop2d * act'(pre).  MODE 2: plain column sum with the
@@ -257,17 +364,22 @@ __global__ void bn_eval_prep_kernel(const float* rm, const float* rv, float* mea
     if (c < C) { mean[c] = rm[c]; rstd[c] = 1.0f / sqrtf(rv[c] + eps); }
 }
 
-// z = act((y-mean)*rstd*gamma+beta) * drop2d     (float4 over [M,C])
+// z = act((y-mean)*rstd*gamma+beta) * drop2d.  grid = (x, groups); the thread count along x is a multiple of C/4, so a
+// thread keeps ONE channel quad of ONE statistics group: its 16 normalisation constants live in registers and the row
+// loop is pure streaming (no per-element parameter loads, no 64-bit divisions).  p.M = rows per group.
 __global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __restrict__ z) {
     const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
     const int QC = p.C >> 2;
-    const long total = (long)p.M * QC;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long row = e / QC;
-        const int c = (int)(e % QC) * 4;
+    const long T = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(t0 % QC) * 4, grp = blockIdx.y;
+    const long row0 = (long)grp * p.M, rstep = T / QC;
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; }
+    for (long r = t0 / QC; r < p.M; r += rstep) {
+        const long row = row0 + r;
         const float4 yv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
         const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
-        const int gc = (int)(row / p.rows_per_group) * p.C + c;
         float o[4];
         float ds[4] = {1.f, 1.f, 1.f, 1.f};
         if (p.drop_p > 0.f) {
@@ -275,29 +387,32 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __rest
             ds[0] = d4.x; ds[1] = d4.y; ds[2] = d4.z; ds[3] = d4.w;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float pre = (y4[j] - p.mean[gc + j]) * p.rstd[gc + j] * p.gamma[c + j] + p.beta[c + j];
-            o[j] = act_fwd(p.act, pre) * ds[j];
-        }
+        for (int j = 0; j < 4; ++j) o[j] = act_fwd(p.act, (y4[j] - mu[j]) * rs[j] * ga[j] + be[j]) * ds[j];
         *reinterpret_cast<float4*>(z + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
-// dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)   (training)   |   gamma*rstd*g   (eval)
+// dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M)   (training)   |   gamma*rstd*g   (eval);  same thread layout as bn_apply
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __restrict__ dy, float* dgamma, float* dbeta, int training) {
     const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
     const int QC = p.C >> 2;
-    const long total = (long)p.M * QC;
-    const double invM = 1.0 / (double)p.rows_per_group;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long row = e / QC;
-        const int c = (int)(e % QC) * 4;
+    const long T = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(t0 % QC) * 4, grp = blockIdx.y;
+    const long row0 = (long)grp * p.M, rstep = T / QC;
+    const double invM = 1.0 / (double)p.M;
+    const double* wsg = p.ws + (long)grp * 2 * p.C;
+    float mu[4], rs[4], ga[4], be[4], sg[4], sgx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j];
+        sg[j] = training ? (float)(wsg[c + j] * invM) : 0.f;
+        sgx[j] = training ? (float)(wsg[p.C + c + j] * invM) : 0.f;
+    }
+    for (long r = t0 / QC; r < p.M; r += rstep) {
+        const long row = row0 + r;
         const float4 dv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
         const float4 yv = *reinterpret_cast<const float4*>(p.b + row * p.C + c);
         const float d4[4] = {dv.x, dv.y, dv.z, dv.w}, y4[4] = {yv.x, yv.y, yv.z, yv.w};
-        const int grp = (int)(row / p.rows_per_group);
-        const int gc = grp * p.C + c;
-        const double* wsg = p.ws + (long)grp * 2 * p.C;
         float o[4];
         float ds[4] = {1.f, 1.f, 1.f, 1.f};
         if (p.drop_p > 0.f) {
@@ -306,23 +421,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float rs = p.rstd[gc + j], ga = p.gamma[c + j];
-            const float xh = (y4[j] - p.mean[gc + j]) * rs;
-            const float g = d4[j] * act_grad(p.act, xh * ga + p.beta[c + j]) * ds[j];
-            if (training) {
-                const float sg = (float)(wsg[c + j] * invM), sgx = (float)(wsg[p.C + c + j] * invM);
-                o[j] = ga * rs * (g - sg - xh * sgx);
-            } else {
-                o[j] = ga * rs * g;
-            }
+            const float xh = (y4[j] - mu[j]) * rs[j];
+            const float g = d4[j] * act_grad(p.act, xh * ga[j] + be[j]) * ds[j];
+            o[j] = ga[j] * rs[j] * (g - sg[j] - xh * sgx[j]);
         }
         *reinterpret_cast<float4*>(dy + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-            double sb = 0.0, sg = 0.0;
-            for (int g = 0; g < p.groups; ++g) { sb += p.ws[(long)g * 2 * p.C + c]; sg += p.ws[(long)g * 2 * p.C + p.C + c]; }
-            dbeta[c] = (float)sb; dgamma[c] = (float)sg;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int cc = threadIdx.x; cc < p.C; cc += blockDim.x) {
+            double sb = 0.0, sgm = 0.0;
+            for (int g = 0; g < p.groups; ++g) { sb += p.ws[(long)g * 2 * p.C + cc]; sgm += p.ws[(long)g * 2 * p.C + p.C + cc]; }
+            dbeta[cc] = (float)sb; dgamma[cc] = (float)sgm;
         }
     }
 }
@@ -415,6 +524,15 @@ extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const flo
                                    int32_t M, int32_t C, float eps, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_fwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
+    if (C == 64 || C == 128 || C == 320 || C == 512) {
+        dim3 grid16(min(cdiv(M, 16), 4096));
+        if (C == 64) hipLaunchKernelGGL((ln_fwd16_kernel<1>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
+        else if (C == 128) hipLaunchKernelGGL((ln_fwd16_kernel<2>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
+        else if (C == 320) hipLaunchKernelGGL((ln_fwd16_kernel<5>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
+        else hipLaunchKernelGGL((ln_fwd16_kernel<8>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
+        MDVIT_LAUNCH_CHECK();
+        return MDVIT_OK;
+    }
     dim3 grid(min(cdiv(M, 4), 4096));
     LN_DISPATCH(ln_fwd_kernel, C, x, gamma, beta, y, mean, rstd, M, C, eps);
     MDVIT_LAUNCH_CHECK();
@@ -429,6 +547,15 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
         const MdvitZeroItem z[2] = {{dgamma, sizeof(float) * C}, {dbeta, sizeof(float) * C}};
         const int rc = mdvit_zero_many(z, 2, s);
         if (rc != MDVIT_OK) return rc;
+    }
+    if (C == 64 || C == 128 || C == 320 || C == 512) {
+        dim3 grid16(min(cdiv(M, 64), 1024));
+        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
+        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
+        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
+        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
+        MDVIT_LAUNCH_CHECK();
+        return MDVIT_OK;
     }
     dim3 grid(min(cdiv(M, 16), 1024));
     LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C);
@@ -480,10 +607,10 @@ extern "C" int mdvit_bn_apply(const float* y, const float* mean, const float* rs
     ChanArgs a; memset(&a, 0, sizeof(a));
     a.a = y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
     a.groups = groups; a.rows_per_group = M / groups;
+    a.M = M / groups;                          // rows per statistics group (grid.y = group)
     fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
     a.seed = seed;
-    const long total = (long)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, (hipStream_t)stream, a, z);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(chan_grid(a.M, C, max(1, 4096 / groups)), groups), dim3(256), 0, (hipStream_t)stream, a, z);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -506,9 +633,7 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
     const int grid = chan_grid(Mg, C, CHAN_MAX_BLOCKS);
     hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(grid, groups), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32), groups), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
-    a.M = M;                                   // the apply pass runs over all rows
-    const long total = (long)M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)min((total + 255) / 256, 8192L)), dim3(256), 0, s, a, dy, dgamma, dbeta, training);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chan_grid(Mg, C, max(1, 4096 / groups)), groups), dim3(256), 0, s, a, dy, dgamma, dbeta, training);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

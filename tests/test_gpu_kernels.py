@@ -142,7 +142,7 @@ def test_mlp_residual(M, C, r):
         check(a, r_, name=n)
 
 
-@pytest.mark.parametrize("M,C", [(1000, 64), (77, 128), (300, 320), (64, 512), (5, 1024)])
+@pytest.mark.parametrize("M,C", [(1000, 64), (77, 128), (300, 320), (64, 512), (5, 1024), (33, 96), (4099, 64)])
 def test_layernorm(M, C):
     from mdvit_amd import ops
     x, ga, be, g = rnd(M, C, seed=30, scale=2.0) + 0.5, 1 + 0.5 * rnd(C, seed=31), rnd(C, seed=32, scale=0.1), rnd(M, C, seed=33)
