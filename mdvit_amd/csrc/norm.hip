@@ -673,7 +673,7 @@ extern "C" int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, con
         const int rc = mdvit_zero_many(z, 2, s);
         if (rc != MDVIT_OK) return rc;
     }
-    dim3 grid(min(cdiv(M, 64), 1024));
+    dim3 grid(min(cdiv(M, 4), 1024));          // one row per wavefront per pass: small M (weight composition) still fills the chip
     const int C = K;
     LN_DISPATCH(rowdot_bwd_kernel, C, x, (long)ldx, w, dy, dx, (long)lddx, dw, db, M, K);
     MDVIT_LAUNCH_CHECK();
