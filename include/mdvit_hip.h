@@ -65,12 +65,18 @@ typedef struct MdvitGemmDesc {
     int32_t allow_split;
     void* ws; uint64_t ws_bytes;      /* scratch for split reductions: mdvit_gemm_ws_bytes(desc) (0 = none needed) */
     int32_t accumulate;               /* C += result (gradient accumulation straight into a persistent buffer) */
+    int32_t precision;                /* 0: fp32 MFMA (bit-for-bit an fmaf chain).  1: "bf16x3" -- operands split hi+lo into two bf16
+                                       * planes while staged, hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
+                                       * accumulation (~1e-5 relative); built for trans_a = 0, trans_b = 1 only */
     const uint32_t* drop_seed;        /* optional device {s0,s1}: effective keys (key0 ^ s0, key1 + s1) -- lets a captured
                                          HIP graph draw fresh dropout masks on every replay */
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
 int mdvit_gemm_plan(const MdvitGemmDesc* desc, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
+/* out[cols, rows] = in[rows, cols]^T (row-major, in may be a column slice with leading dimension ld_in).  Used on WEIGHTS
+ * only: with precision = 1 the data-gradient GEMM  dX = dY W  reads W^T so that both operands are k-contiguous. */
+int mdvit_transpose_f32(const float* in, int64_t ld_in, float* out, int32_t rows, int32_t cols, void* stream);
 /* Tuning hook for tools/gemm_sweep.py: pin the tile configuration (0: 128x128, 1: 256x64, 2: 64x64; -1: planner) and the
  * requested K-split (one of the planner's candidates; 0: planner) of every following mdvit_gemm_f32 call. */
 int mdvit_gemm_force_plan(int32_t cfg, int32_t splits);

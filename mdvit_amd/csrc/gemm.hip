@@ -11,6 +11,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -49,17 +52,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   3 FULL   : +bias, dropout, DropPath row scale, +residual
 enum { EPI_PLAIN = 0, EPI_GELU2 = 1, EPI_DGELU = 2, EPI_FULL = 3 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI>
+// BF3 ("bf16x3", NT layout only): every fp32 operand is split as x = hi + lo (two RNE bf16 values, |x - hi - lo| <= 2^-18 |x|)
+// while it is staged into LDS, and each product runs as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation -- three 32-cycle MFMAs per K=16 instead of eight 64-cycle fp32 MFMAs (5.3x less matrix-core time),
+// ~1e-5 relative accuracy.  LDS holds [row][k] bf16 planes (80-byte rows: conflict-free ds_read_b128 fragments).
+__device__ __forceinline__ void split_bf16x3(const float4 x, uint2& hi, uint2& lo) {
+    f32x2_t a = {x.x, x.y}, b = {x.z, x.w};
+    const bf16x2_t ha = __builtin_convertvector(a, bf16x2_t), hb = __builtin_convertvector(b, bf16x2_t);
+    const uint32_t hau = __builtin_bit_cast(uint32_t, ha), hbu = __builtin_bit_cast(uint32_t, hb);
+    f32x2_t la = {x.x - __uint_as_float(hau << 16), x.y - __uint_as_float(hau & 0xffff0000u)};
+    f32x2_t lb = {x.z - __uint_as_float(hbu << 16), x.w - __uint_as_float(hbu & 0xffff0000u)};
+    const bf16x2_t lab = __builtin_convertvector(la, bf16x2_t), lbb = __builtin_convertvector(lb, bf16x2_t);
+    hi = make_uint2(hau, hbu);
+    lo = make_uint2(__builtin_bit_cast(uint32_t, lab), __builtin_bit_cast(uint32_t, lbb));
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI, bool BF3>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
+    static_assert(!BF3 || (!TA && TB), "the bf16x3 path stages k-contiguous operands only (NT)");
     // k-contiguous operands are transposed on the LDS write: odd leading dimension -> conflict-free ds_write_b32;
     // m/n-contiguous operands are written as float4: leading dimension % 4 == 0.
     constexpr int LDSA = TA ? BM + 4 : BM + 1, LDSB = TB ? BN + 1 : BN + 4;
+    constexpr int LDKB = 80;                                            // BF3: bytes per [row][32 x bf16] LDS row (64 + 16 pad)
+    constexpr int SMEM_FLOATS = BF3 ? (BM + BN) * 2 * LDKB / 4 : BK * LDSA + BK * LDSB;
     constexpr int WTM = BM / WAVES_M / 32, WTN = BN / WAVES_N / 32;   // 32x32 blocks per wave
     constexpr int A_V4 = BM * BK / 4 / NTHREADS, B_V4 = BN * BK / 4 / NTHREADS;
     constexpr int KT = BK / 4;                                        // threads per k-contiguous row
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDSA + BK * LDSB];
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + BK * LDSA;
+    // BF3 planes (bytes): A hi | A lo | B hi | B lo
+    char* sb = reinterpret_cast<char*>(smem);
+    char* Ahi = sb; char* Alo = sb + BM * LDKB; char* Bhi = sb + 2 * BM * LDKB; char* Blo = Bhi + BN * LDKB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t s0 = 0, s1 = 0;
@@ -114,6 +138,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         }
     };
     auto store_smem = [&]() {
+        if (BF3) {
+#pragma unroll
+            for (int v = 0; v < A_V4; ++v) {
+                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
+                uint2 hi, lo;
+                split_bf16x3(ra[v], hi, lo);
+                *reinterpret_cast<uint2*>(Ahi + r * LDKB + c * 2) = hi;
+                *reinterpret_cast<uint2*>(Alo + r * LDKB + c * 2) = lo;
+            }
+#pragma unroll
+            for (int v = 0; v < B_V4; ++v) {
+                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
+                uint2 hi, lo;
+                split_bf16x3(rb[v], hi, lo);
+                *reinterpret_cast<uint2*>(Bhi + r * LDKB + c * 2) = hi;
+                *reinterpret_cast<uint2*>(Blo + r * LDKB + c * 2) = lo;
+            }
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < A_V4; ++v) {
             if (!TA) {
@@ -148,6 +191,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
         if (more) { load_a(k0 + BK); load_b(k0 + BK); }
+        if (BF3) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int koff = (2 * ks + lhi) * 16;                   // byte offset of this lane's 8 bf16 in the row
+                bf16x8_t ah[WTM], al[WTM], bh[WTN], bl[WTN];
+#pragma unroll
+                for (int i = 0; i < WTM; ++i) {
+                    const int r = wm0 + i * 32 + l31;
+                    ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ahi + r * LDKB + koff));
+                    al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Alo + r * LDKB + koff));
+                }
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) {
+                    const int r = wn0 + j * 32 + l31;
+                    bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bhi + r * LDKB + koff));
+                    bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Blo + r * LDKB + koff));
+                }
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int krow = 2 * kk + lhi;
@@ -274,23 +344,33 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, hipStream_t s) {
+int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, int bf3, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(NTHREADS);
-#define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_) \
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_>), grid, block, 0, s, a)
-    if (!ta && tb) {                                   // forward (weights [N,K])
-        if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2);
-        else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL);
-        else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN);
-        else return 1;
+#define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_, BF3_) \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_, BF3_>), grid, block, 0, s, a)
+    if (!ta && tb) {                                   // forward (weights [N,K]); with transposed weights also dgrad
+        if (bf3) {
+            if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2, true);
+            else if (epi == EPI_DGELU) MDVIT_GEMM_LAUNCH(false, true, EPI_DGELU, true);
+            else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL, true);
+            else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, true);
+            else return 1;
+        } else {
+            if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2, false);
+            else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL, false);
+            else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, false);
+            else return 1;
+        }
+    } else if (bf3) {
+        return 1;
     } else if (!ta && !tb) {                           // dgrad
-        if (epi == EPI_DGELU) MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU);
-        else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN);
-        else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, false, EPI_FULL);
+        if (epi == EPI_DGELU) MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU, false);
+        else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN, false);
+        else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, false, EPI_FULL, false);
         else return 1;
     } else if (ta && !tb) {                            // wgrad
         if (epi != EPI_PLAIN) return 1;
-        MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN);
+        MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN, false);
     } else {
         return 1;
     }
@@ -329,7 +409,10 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
             const long slots = 256L * OCC[c];
             const double rounds = wgs <= slots ? 1.0 : (double)wgs / (double)slots;   // workgroups do not run in lockstep: no ceil
             // one workgroup alone on a CU: 2*BM*BN*kps flop at ~180 flop/clk; plus a fixed prologue/epilogue cost per workgroup
-            const double wg_cycles = 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0;
+            // bf16x3: 3 x 32-cycle MFMAs per 32x32x16 on 4 SIMDs, plus the hi/lo split of every staged element (VALU)
+            const double wg_cycles = d->precision == 1
+                ? 0.0015 * BMs[c] * BNs[c] * (double)kps + 0.06 * (BMs[c] + BNs[c]) * (double)kps + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0
+                : 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0;
             double cost = rounds * OCC[c] * wg_cycles;
             if (splits > 1) cost += 12000.0 + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;
             if (cost < best_cost) {
@@ -393,10 +476,10 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
         a.vec = 0;
     }
     int rc;
-    if (pl.cfg == 0) rc = launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, epi, s);
-    else if (pl.cfg == 1) rc = launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, epi, s);
-    else rc = launch_cfg<64, 64, 2, 2>(a, d->trans_a, d->trans_b, epi, s);
-    MDVIT_CHECK_ARG(rc == 0, MDVIT_E_SHAPE, "gemm: this (trans_a=%d, trans_b=%d, epilogue=%d) combination is not built", d->trans_a, d->trans_b, epi);
+    if (pl.cfg == 0) rc = launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, epi, d->precision, s);
+    else if (pl.cfg == 1) rc = launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, epi, d->precision, s);
+    else rc = launch_cfg<64, 64, 2, 2>(a, d->trans_a, d->trans_b, epi, d->precision, s);
+    MDVIT_CHECK_ARG(rc == 0, MDVIT_E_SHAPE, "gemm: this (trans_a=%d, trans_b=%d, epilogue=%d, precision=%d) combination is not built", d->trans_a, d->trans_b, epi, d->precision);
     if (pl.splits > 1) {
         const long total = (long)d->M * d->N / 4;
 #define MDVIT_REDUCE_LAUNCH(R_) \
@@ -408,6 +491,31 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
         else MDVIT_REDUCE_LAUNCH(64);
 #undef MDVIT_REDUCE_LAUNCH
     }
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+// out[c][r] = in[r][c]  (weights only: the bf16x3 dgrad reads W^T so that both GEMM operands are k-contiguous)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long ld_in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) out[(long)c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int mdvit_transpose_f32(const float* in, int64_t ld_in, float* out, int32_t rows, int32_t cols, void* stream) {
+    MDVIT_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_in >= cols, MDVIT_E_SHAPE, "transpose: bad shape rows=%d cols=%d ld=%ld", rows, cols, (long)ld_in);
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, out, rows, cols);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

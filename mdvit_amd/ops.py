@@ -193,7 +193,9 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
-         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False):
+         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None):
+    if precision is None:
+        precision = _gemm_precision if (trans_b and not trans_a) else 0
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = A, B, out, out2
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
@@ -207,6 +209,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.gelu_u, d.ldu = gelu_u, ldu
     d.allow_split = int(allow_split)
     d.accumulate = int(accumulate)
+    d.precision = int(precision)
     d.drop_seed = _seed_ptr() if e_drop > 0 else None
     ws = None
     if allow_split:
@@ -226,14 +229,59 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     waves = {128: "2, 2", 256: "4, 1", 64: "2, 2"}[tm.value]       # kernel symbol as rocprofv3 prints it
     kepi = 1 if epi == _lib.EPI_GELU_DUAL else 2 if epi == _lib.EPI_DGELU else \
         3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
-    name = "gemm_f32_kernel<%d, %d, %s, %s, %s, %d>%s" % (
+    name = "gemm_f32_kernel<%d, %d, %s, %s, %s, %d, %s>%s" % (
         tm.value, tn.value, waves, "true" if trans_a else "false", "true" if trans_b else "false", kepi,
-        "+splitk_reduce" if sp.value > 1 else "")
+        "true" if precision else "false", "+splitk_reduce" if sp.value > 1 else "")
     if _events_by_shape:
         name += " M=%d N=%d K=%d sp=%d" % (M, N, K, sp.value)
     # algorithmic HBM bytes of the launch: A, B read once, C (and C2 / residual / gelu_u) once
     nbytes = 4.0 * (M * K + N * K + M * N * (1 + (out2 is not None) + (residual is not None) + (gelu_u is not None)))
     _events.append((name, 2.0 * M * N * K, nbytes, e0, e1))
+
+
+# ---- GEMM arithmetic ---------------------------------------------------------------------------------------
+# 0 "fp32": fp32-input MFMA, bit-for-bit an fmaf chain.  1 "bf16x3": operands split hi+lo into bf16 while staged,
+# hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate (~1e-5 relative).  The bf16x3 kernel wants both
+# operands k-contiguous, so the data-gradient GEMMs read a transposed copy of the weight (wt()).
+_PRECISIONS = {"fp32": 0, "bf16x3": 1}
+_gemm_precision = _PRECISIONS[os.environ.get("MDVIT_GEMM_PRECISION", "fp32")]
+
+
+def set_gemm_precision(name: str):
+    global _gemm_precision
+    _gemm_precision = _PRECISIONS[name]
+
+
+def gemm_precision() -> str:
+    return "bf16x3" if _gemm_precision else "fp32"
+
+
+_wt_cache = {}       # leaf weight data_ptr -> (version, rows, cols, ld, W^T)
+
+
+def wt(W):
+    """W [N,K] (2-D view, or a contiguous conv weight read as [out, in*kh*kw]) -> contiguous W^T [K,N].  Cached per leaf
+    parameter and refreshed when the parameter's version counter moves (optimizer step, load_state_dict)."""
+    N, K, ld = _ld_view(W)
+    leaf = W.grad_fn is None and W.requires_grad
+    key = W.data_ptr()
+    if leaf:
+        hit = _wt_cache.get(key)
+        if hit is not None and hit[:4] == (W._version, N, K, ld):
+            return hit[4]
+    out = torch.empty((K, N), device=W.device, dtype=torch.float32)
+    call("mdvit_transpose_f32", _p(W), ld, _p(out), N, K, _stream())
+    if leaf:
+        _wt_cache[key] = (W._version, N, K, ld, out)
+    return out
+
+
+def _dgrad(g, W, dx, M, K, N, ldb, **kw):
+    """dx[M,K] = g[M,N] @ W[N,K]: NN on the fp32 path; NT against the cached W^T on the bf16x3 path."""
+    if _gemm_precision:
+        gemm(_p(g), _p(wt(W)), _p(dx), M, K, N, lda=N, ldb=N, ldc=K, trans_b=True, **kw)
+    else:
+        gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, **kw)
 
 
 # ---- optional per-kernel timing (bench.py): HIP events on the launch stream around each GEMM ------
@@ -324,7 +372,7 @@ class _Linear(torch.autograd.Function):
                  drop_p, key[0], key[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         if ctx.needs_input_grad[0]:
             dx = _empty_like(x)
-            gemm(_p(gm), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, allow_split=True)
+            _dgrad(gm, W, dx, M, K, N, ldb, allow_split=True)
         if want_w:
             if sunk:
                 # accumulate straight into the gradient buckets (side stream if enabled); autograd gets None
@@ -433,10 +481,9 @@ class _MlpResidual(torch.autograd.Function):
                  drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         # du = (gm W2) * gelu'(u) * mask1
         du = _empty_like(u)
-        gemm(_p(gm), _p(W2), _p(du), M, Hd, Cin, lda=Cin, ldb=Hd, ldc=Hd, trans_b=False,
-             epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)
+        _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)
         dx = _empty_like(x)
-        gemm(_p(du), _p(W1), _p(dx), M, Cin, Hd, lda=Hd, ldb=Cin, ldc=Cin, trans_b=False, allow_split=True)
+        _dgrad(du, W1, dx, M, Cin, Hd, Cin, allow_split=True)
         if not _dgrad_only:
             if sunk:
                 dW1_, db1_, dW2_, _ = sinks

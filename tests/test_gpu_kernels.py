@@ -52,6 +52,51 @@ def test_linear_fwd_bwd(M, N, K):
         check(a, r, name=n)
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 192, 64), (333, 512, 320), (4096, 64, 512), (77, 1280, 320)])
+def test_linear_and_mlp_bf16x3_vs_fp64(M, N, K):
+    """bf16x3 GEMMs (hi/lo bf16 split, three bf16 MFMAs, fp32 accumulate): forward, dgrad through the transposed-weight
+    cache, and the fused GELU / GELU' epilogues, against fp64 -- error class 1e-5, checked at 1e-4 of the tensor max"""
+    from mdvit_amd import ops
+    x, W, b, g = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref, gr = grads_of(lambda x, W, b: F.linear(x.double(), W.double(), b.double()), [x, W, b], g.double())
+    W2, b2, res = rnd(K, N, seed=5, scale=N ** -0.5), rnd(K, seed=6), rnd(M, K, seed=7)
+    g2 = rnd(M, K, seed=8)
+    mref, mgr = grads_of(lambda x, W, b, W2, b2: res.double() + F.linear(F.gelu(F.linear(x.double(), W.double(), b.double())), W2.double(), b2.double()),
+                         [x, W, b, W2, b2], g2.double())
+    ops.set_gemm_precision("bf16x3")
+    try:
+        assert ops.gemm_precision() == "bf16x3"
+        out, go = grads_of(lambda x, W, b: ops.linear(x, W, b), [x.to(dev()), W.to(dev()), b.to(dev())], g)
+        mout, mgo = grads_of(lambda x, W, b, W2, b2: ops.mlp_residual(x, res.to(dev()), W, b, W2, b2),
+                             [x.to(dev()), W.to(dev()), b.to(dev()), W2.to(dev()), b2.to(dev())], g2)
+        ops.kernel_events_begin()
+        ops.linear(x.to(dev()), W.to(dev()), b.to(dev()))
+        names = list(ops.kernel_events_end())
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert names and all(n.split(">")[0].endswith("true") for n in names), names        # the bf16x3 instantiation really ran
+    check(out, ref, name="y")
+    for n, a, r in zip(("dx", "dW", "db"), go, gr):
+        check(a, r, name=n)
+    check(mout, mref, name="mlp y")
+    for n, a, r in zip(("dx", "dW1", "db1", "dW2", "db2"), mgo, mgr):
+        check(a, r, name="mlp " + n)
+
+
+def test_weight_transpose_cache_follows_updates():
+    from mdvit_amd import ops
+    W = torch.nn.Parameter(rnd(96, 200, seed=9).to(dev()))
+    t1 = ops.wt(W)
+    assert torch.equal(t1, W.detach().t().contiguous())
+    assert ops.wt(W) is t1                              # cached while the parameter is unchanged
+    with torch.no_grad():
+        W.add_(1.0)                                     # an optimizer step bumps the version counter
+    t2 = ops.wt(W)
+    assert t2 is not t1 and torch.equal(t2, W.detach().t().contiguous())
+    Wv = torch.nn.Parameter(rnd(64, 320, seed=10).to(dev()))
+    assert torch.equal(ops.wt(Wv[:, 128:192]), Wv.detach()[:, 128:192].t().contiguous())   # column-slice view
+
+
 def test_linear_big_token_axis_split():
     """wgrad reduces over 65536 tokens -> split-K + atomics path."""
     from mdvit_amd import ops

@@ -51,6 +51,16 @@ def main():
                      allow_split=epi == 0, **extra)
         lib.mdvit_gemm_force_plan(-1, 0)
         t_pl = timed(run)
+        t_bf = None
+        if not ta and tb:
+            extra["precision"] = 1
+            t_bf = timed(run)
+            bres = []
+            for cfg in range(3):
+                lib.mdvit_gemm_force_plan(cfg, 1)
+                bres.append((timed(run, 4), cfg))
+            lib.mdvit_gemm_force_plan(-1, 0)
+            extra["precision"] = 0
         g = _lib.GemmDesc(); g.M, g.N, g.K, g.trans_a, g.trans_b, g.allow_split = M, N, K, int(ta), int(tb), 1
         tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
         lib.mdvit_gemm_plan(C.byref(g), C.byref(tm), C.byref(tn), C.byref(sp))
@@ -67,7 +77,8 @@ def main():
         total_pl += t_pl * r["n"]; total_best += bt * r["n"]
         fl = 2.0 * M * N * K
         print(f"M={M:>7} N={N:>5} K={K:>7} {'T' if ta else 'N'}{'T' if tb else 'N'} e{epi} x{r['n']:3d}  planner {tm.value}x{tn.value} sp={sp.value:<4d} {t_pl:8.1f} us ({fl/t_pl/1e6:5.1f} TF)"
-              f" | best {CFG[bc]} sp={bs:<4d} {bt:8.1f} us ({fl/bt/1e6:5.1f} TF) | next {CFG[res[1][1]]} sp={res[1][2]} {res[1][0]:.1f}", flush=True)
+              f" | best {CFG[bc]} sp={bs:<4d} {bt:8.1f} us ({fl/bt/1e6:5.1f} TF) | next {CFG[res[1][1]]} sp={res[1][2]} {res[1][0]:.1f}"
+              + ("" if t_bf is None else f" | bf16x3 planner {t_bf:.1f} us ({fl/t_bf/1e6:.1f} TF) per cfg " + " ".join(f"{CFG[c]}:{t:.1f}" for t, c in bres)), flush=True)
     print(f"weighted: planner {total_pl/1e3:.2f} ms, best {total_best/1e3:.2f} ms")
 
 
