@@ -21,6 +21,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak; a bf16x3 GEMM issues 3 bf16 MFMAs per product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -33,6 +34,9 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="mdvit", choices=["mdvit", "base"])
     ap.add_argument("--no-side-stream", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel); "
+                         "fp32 = fp32-input MFMA")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
     ap.add_argument("--fuse-images", type=int, default=32,
                     help="domain batches are fused into one domain-batched forward while the fused batch stays <= this many images (0: one forward per domain)")
@@ -86,6 +90,9 @@ def main():
     from mdvit_amd.synthetic import make_step_batches
     from mdvit_amd.train import base_train_step, mdvit_train_step
 
+    ops.set_gemm_precision(args.precision)
+    # useful-flop roof of the GEMM arithmetic in use: fp32 MFMA peak, or a third of the bf16 peak (3 MFMAs per product)
+    peak_mfma = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
     torch.manual_seed(0)
     if args.model == "mdvit":
         model = mdvit_amd.MDViT(img_size=args.size, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d,
@@ -156,7 +163,7 @@ def main():
             secs = rec["ms"] * 1e-3
             tf, gbs = rec["flop"] / secs / 1e12, rec["bytes"] / secs / 1e9
             # the dominant GEMM variant is priced against BOTH roofs; "bound" is the one that is closer
-            frac_mfma, frac_hbm = tf / PEAK_F32_MFMA_TFLOPS, gbs / PEAK_HBM_GBS
+            frac_mfma, frac_hbm = tf / peak_mfma, gbs / PEAK_HBM_GBS
             pmc = {}
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -167,7 +174,7 @@ def main():
             if frac_hbm > frac_mfma:
                 roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
             else:
-                roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
+                roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak_mfma, 1), "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
             roof.update({"traffic": traffic, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
                          "flop_per_launch": round(rec["flop"] / rec["n"]), "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]),
                          "mfma_tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "share_of_step": round(rec["ms"] / (dt * 1e3), 4)})
@@ -184,11 +191,11 @@ def main():
             "metric": "512x512 images/sec MDViT train step (fwd+bwd, two-sweep, AdamW)" if args.model == "mdvit" else "512x512 images/sec BASE train step",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 storage; GEMM operands split hi+lo bf16, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{'MDViT Sup+MLPFM' if args.model == 'mdvit' else 'BASE'} train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
-                                   f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, fp32 MFMA, data-parallel x{world}",
+                                   f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
-            "model_flops_util": round(value / world * flop_per_img / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

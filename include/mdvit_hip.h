@@ -67,7 +67,7 @@ typedef struct MdvitGemmDesc {
     int32_t accumulate;               /* C += result (gradient accumulation straight into a persistent buffer) */
     int32_t precision;                /* 0: fp32 MFMA (bit-for-bit an fmaf chain).  1: "bf16x3" -- operands split hi+lo into two bf16
                                        * planes while staged, hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
-                                       * accumulation (~1e-5 relative); built for trans_a = 0, trans_b = 1 only */
+                                       * accumulation (~1e-5 relative); built for NT (all epilogues) and TN (plain) */
     const uint32_t* drop_seed;        /* optional device {s0,s1}: effective keys (key0 ^ s0, key1 + s1) -- lets a captured
                                          HIP graph draw fresh dropout masks on every replay */
 } MdvitGemmDesc;

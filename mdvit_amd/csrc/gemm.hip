@@ -67,9 +67,23 @@ __device__ __forceinline__ void split_bf16x3(const float4 x, uint2& hi, uint2& l
     lo = make_uint2(__builtin_bit_cast(uint32_t, lab), __builtin_bit_cast(uint32_t, lbb));
 }
 
+// (x0, x1) = the same column at k and k+1 -> packed bf16 pairs {hi(x0), hi(x1)} and {lo(x0), lo(x1)}
+__device__ __forceinline__ void split_pair_bf16x3(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    f32x2_t a = {x0, x1};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t));
+    f32x2_t l = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
+    hi = h;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(l, bf16x2_t));
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI, bool BF3>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
-    static_assert(!BF3 || (!TA && TB), "the bf16x3 path stages k-contiguous operands only (NT)");
+    // bf16x3 staging: a k-contiguous operand (A of NT/NN, B of NT) is split float4-wise into [row][k] bf16 planes; an
+    // m/n-contiguous operand (A and B of the TN wgrad) is loaded as PAIRS of consecutive k rows, so that each
+    // (row, k..k+1) bf16 pair is one v_cvt_pk_bf16_f32 and one ds_write_b32 -- with lanes running along k the writes
+    // are conflict-free (row stride 20 words, 16 k-pairs + 16-word offset between the two row quads of a 32-lane group).
+    constexpr bool A_PAIR = BF3 && TA, B_PAIR = BF3 && !TB;
+    static_assert(!BF3 || !(TA && TB), "bf16x3: TT is not a layout of this model");
     // k-contiguous operands are transposed on the LDS write: odd leading dimension -> conflict-free ds_write_b32;
     // m/n-contiguous operands are written as float4: leading dimension % 4 == 0.
     constexpr int LDSA = TA ? BM + 4 : BM + 1, LDSB = TB ? BN + 1 : BN + 4;
@@ -108,6 +122,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     float4 ra[A_V4], rb[B_V4];
 
     auto load_a = [&](int k0) {
+        if (A_PAIR) {           // rows k = k0 + 2*kp, +1 ; columns m0 + 4*mq .. +3
+#pragma unroll
+            for (int v = 0; v < A_V4 / 2; ++v) {
+                const int kp = tid & 15, mq = (tid >> 4) + 16 * v;
+                const int k = k0 + 2 * kp, m = m0 + 4 * mq;
+                float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+                if (m < p.M) {
+                    if (k < kend) x0 = *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m);
+                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(p.A + (long)(k + 1) * p.lda + m);
+                }
+                ra[2 * v] = x0; ra[2 * v + 1] = x1;
+            }
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < A_V4; ++v) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -123,6 +151,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         }
     };
     auto load_b = [&](int k0) {
+        if (B_PAIR) {
+#pragma unroll
+            for (int v = 0; v < B_V4 / 2; ++v) {
+                const int kp = tid & 15, nq = (tid >> 4) + 16 * v;
+                const int k = k0 + 2 * kp, n = n0 + 4 * nq;
+                float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+                if (n < p.N) {
+                    if (k < kend) x0 = *reinterpret_cast<const float4*>(p.B + (long)k * p.ldb + n);
+                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(p.B + (long)(k + 1) * p.ldb + n);
+                }
+                rb[2 * v] = x0; rb[2 * v + 1] = x1;
+            }
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < B_V4; ++v) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -139,21 +181,53 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     };
     auto store_smem = [&]() {
         if (BF3) {
+            if (A_PAIR) {
 #pragma unroll
-            for (int v = 0; v < A_V4; ++v) {
-                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                uint2 hi, lo;
-                split_bf16x3(ra[v], hi, lo);
-                *reinterpret_cast<uint2*>(Ahi + r * LDKB + c * 2) = hi;
-                *reinterpret_cast<uint2*>(Alo + r * LDKB + c * 2) = lo;
+                for (int v = 0; v < A_V4 / 2; ++v) {
+                    const int kp = tid & 15, mq = (tid >> 4) + 16 * v;
+                    const float x0[4] = {ra[2 * v].x, ra[2 * v].y, ra[2 * v].z, ra[2 * v].w};
+                    const float x1[4] = {ra[2 * v + 1].x, ra[2 * v + 1].y, ra[2 * v + 1].z, ra[2 * v + 1].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t hi, lo;
+                        split_pair_bf16x3(x0[i], x1[i], hi, lo);
+                        *reinterpret_cast<uint32_t*>(Ahi + (4 * mq + i) * LDKB + kp * 4) = hi;
+                        *reinterpret_cast<uint32_t*>(Alo + (4 * mq + i) * LDKB + kp * 4) = lo;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < A_V4; ++v) {
+                    const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
+                    uint2 hi, lo;
+                    split_bf16x3(ra[v], hi, lo);
+                    *reinterpret_cast<uint2*>(Ahi + r * LDKB + c * 2) = hi;
+                    *reinterpret_cast<uint2*>(Alo + r * LDKB + c * 2) = lo;
+                }
             }
+            if (B_PAIR) {
 #pragma unroll
-            for (int v = 0; v < B_V4; ++v) {
-                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                uint2 hi, lo;
-                split_bf16x3(rb[v], hi, lo);
-                *reinterpret_cast<uint2*>(Bhi + r * LDKB + c * 2) = hi;
-                *reinterpret_cast<uint2*>(Blo + r * LDKB + c * 2) = lo;
+                for (int v = 0; v < B_V4 / 2; ++v) {
+                    const int kp = tid & 15, nq = (tid >> 4) + 16 * v;
+                    const float x0[4] = {rb[2 * v].x, rb[2 * v].y, rb[2 * v].z, rb[2 * v].w};
+                    const float x1[4] = {rb[2 * v + 1].x, rb[2 * v + 1].y, rb[2 * v + 1].z, rb[2 * v + 1].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t hi, lo;
+                        split_pair_bf16x3(x0[i], x1[i], hi, lo);
+                        *reinterpret_cast<uint32_t*>(Bhi + (4 * nq + i) * LDKB + kp * 4) = hi;
+                        *reinterpret_cast<uint32_t*>(Blo + (4 * nq + i) * LDKB + kp * 4) = lo;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < B_V4; ++v) {
+                    const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
+                    uint2 hi, lo;
+                    split_bf16x3(rb[v], hi, lo);
+                    *reinterpret_cast<uint2*>(Bhi + r * LDKB + c * 2) = hi;
+                    *reinterpret_cast<uint2*>(Blo + r * LDKB + c * 2) = lo;
+                }
             }
             return;
         }
@@ -362,7 +436,8 @@ int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, int bf3, hipStream_t 
             else return 1;
         }
     } else if (bf3) {
-        return 1;
+        if (ta && !tb && epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(true, false, EPI_PLAIN, true);     // wgrad, pair-staged operands
+        else return 1;
     } else if (!ta && !tb) {                           // dgrad
         if (epi == EPI_DGELU) MDVIT_GEMM_LAUNCH(false, false, EPI_DGELU, false);
         else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, false, EPI_PLAIN, false);
@@ -411,7 +486,7 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
             // one workgroup alone on a CU: 2*BM*BN*kps flop at ~180 flop/clk; plus a fixed prologue/epilogue cost per workgroup
             // bf16x3: 3 x 32-cycle MFMAs per 32x32x16 on 4 SIMDs, plus the hi/lo split of every staged element (VALU)
             const double wg_cycles = d->precision == 1
-                ? 0.0015 * BMs[c] * BNs[c] * (double)kps + 0.06 * (BMs[c] + BNs[c]) * (double)kps + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0
+                ? 0.0015 * BMs[c] * BNs[c] * (double)kps + (d->trans_a ? 0.12 : 0.06) * (BMs[c] + BNs[c]) * (double)kps + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0
                 : 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0;
             double cost = rounds * OCC[c] * wg_cycles;
             if (splits > 1) cost += 12000.0 + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;

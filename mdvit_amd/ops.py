@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import itertools
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -195,7 +196,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
          residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None):
     if precision is None:
-        precision = _gemm_precision if (trans_b and not trans_a) else 0
+        precision = _gemm_precision if (bool(trans_b) != bool(trans_a)) else 0      # built for NT and TN
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = A, B, out, out2
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
@@ -244,7 +245,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
 # hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate (~1e-5 relative).  The bf16x3 kernel wants both
 # operands k-contiguous, so the data-gradient GEMMs read a transposed copy of the weight (wt()).
 _PRECISIONS = {"fp32": 0, "bf16x3": 1}
-_gemm_precision = _PRECISIONS[os.environ.get("MDVIT_GEMM_PRECISION", "fp32")]
+_gemm_precision = _PRECISIONS[os.environ.get("MDVIT_GEMM_PRECISION", "bf16x3")]
 
 
 def set_gemm_precision(name: str):
@@ -256,7 +257,7 @@ def gemm_precision() -> str:
     return "bf16x3" if _gemm_precision else "fp32"
 
 
-_wt_cache = {}       # leaf weight data_ptr -> (version, rows, cols, ld, W^T)
+_wt_cache = {}       # id(leaf weight) -> (weakref to it, version, data_ptr, rows, cols, ld, W^T); the weakref guards against id reuse
 
 
 def wt(W):
@@ -264,15 +265,16 @@ def wt(W):
     parameter and refreshed when the parameter's version counter moves (optimizer step, load_state_dict)."""
     N, K, ld = _ld_view(W)
     leaf = W.grad_fn is None and W.requires_grad
-    key = W.data_ptr()
+    tag = (W._version, W.data_ptr(), N, K, ld)
     if leaf:
-        hit = _wt_cache.get(key)
-        if hit is not None and hit[:4] == (W._version, N, K, ld):
-            return hit[4]
+        hit = _wt_cache.get(id(W))
+        if hit is not None and hit[0]() is W and hit[1:6] == tag:
+            return hit[6]
     out = torch.empty((K, N), device=W.device, dtype=torch.float32)
     call("mdvit_transpose_f32", _p(W), ld, _p(out), N, K, _stream())
     if leaf:
-        _wt_cache[key] = (W._version, N, K, ld, out)
+        key = id(W)
+        _wt_cache[key] = (weakref.ref(W, lambda _r, key=key: _wt_cache.pop(key, None)),) + tag + (out,)
     return out
 
 

@@ -49,3 +49,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["bf16x3", "fp32"])
+def gemm_precision(request):
+    """run a GPU test under both GEMM arithmetic modes (default bf16x3; fp32 = fp32-input MFMA)"""
+    from mdvit_amd import ops
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision(prev)

@@ -123,7 +123,7 @@ def test_factoratt_module_vs_golden(golden, tag):
             check(named[key.split("::")[1]].grad.reshape(-1)[::29], g[key], name=key)
 
 
-def test_mdvit_two_sweep_step_vs_golden(golden):
+def test_mdvit_two_sweep_step_vs_golden(golden, gemm_precision):
     """4-domain step, multi_train_MDViT.py:129-207: logits, the three losses, BN running stats and every
     parameter gradient after the aux sweep (domain_layer frozen) + uni sweep."""
     from mdvit_amd.losses import domain_losses
@@ -215,7 +215,7 @@ def test_base_step_vs_golden(golden):
     assert rel.max() < 5e-3, f"{names[int(rel.argmax())]} {rel.max():.2e}"
 
 
-def test_mdvit_vs_oracle_128():
+def test_mdvit_vs_oracle_128(gemm_precision):
     """same seeded inputs, larger image (128x128), HIP path vs the CPU oracle incl. input-side gradients of
     every parameter (full tensors, not digests)."""
     from mdvit_amd.losses import domain_losses
@@ -244,8 +244,13 @@ def test_mdvit_vs_oracle_128():
         if ref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
+        # B = 1 at 128x128: the deepest BatchNorms normalise over 16 samples, the worst-conditioned case in the suite.
+        # fp32 GEMMs: 3e-3 (mask flips only).  bf16x3 GEMMs perturb the forward by ~1e-5, i.e. a few more flips: 1e-2.
+        # The bridge sits at 4x4 tokens x 1 image: its BatchNorms see 16 samples, so ONE flipped ReLU moves a channel's
+        # gradient by ~1/16 -- under bf16x3 a couple of such flips happen; bound them separately (fp32: no exception).
+        l2_tol, max_tol = (3e-3, 6e-2) if gemm_precision == "fp32" else ((5e-2, 0.5) if n.startswith("bridge.") else (1e-2, 6e-2))
         try:
-            check_grad(p.grad, ref, name=n)
+            check_grad(p.grad, ref, name=n, l2_tol=l2_tol, max_tol=max_tol)
         except AssertionError as exc:
             bad.append(str(exc))
     assert not bad, f"{len(bad)} gradient tensors off: {bad[:6]}"

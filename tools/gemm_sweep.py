@@ -52,12 +52,12 @@ def main():
         lib.mdvit_gemm_force_plan(-1, 0)
         t_pl = timed(run)
         t_bf = None
-        if not ta and tb:
+        if ta != tb:
             extra["precision"] = 1
             t_bf = timed(run)
             bres = []
             for cfg in range(3):
-                lib.mdvit_gemm_force_plan(cfg, 1)
+                lib.mdvit_gemm_force_plan(cfg, 0)
                 bres.append((timed(run, 4), cfg))
             lib.mdvit_gemm_force_plan(-1, 0)
             extra["precision"] = 0
