@@ -100,8 +100,10 @@ int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, int
 /* ---- LayerNorm over C (nn.LayerNorm eps=1e-6, mdvit.py:327,342,498) ------------------------- */
 int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int32_t M, int32_t C, float eps, void* stream);
+/* add (optional, [M,C]): gradient arriving at x along the residual branch that forked off before the norm
+ * (x + f(LN(x)), mdvit.py:353-360) -- dx = LN-backward(dy) + add in the same pass. */
 int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                        float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+                        const float* add, float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
 
 /* ---- 3x3 convolutions on NHWC ------------------------------------------------------------------
  * dwconv3x3: depthwise, pad 1, stride 1|2, optional bias, optional "+ input" (ConvPosEnc,

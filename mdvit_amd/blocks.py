@@ -52,6 +52,10 @@ class LayerNormParams(nn.Module):
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def fork(self, x):
+        """(LN(x), x) with the residual-branch gradient folded into the LayerNorm backward (ops._LayerNorm)."""
+        return ops.layer_norm_fork(x, self.weight, self.bias, self.eps)
+
 
 class BatchNormAct(nn.Module):
     """nn.BatchNorm2d state (weight, bias, running_mean, running_var, num_batches_tracked) + fused activation."""
@@ -281,7 +285,7 @@ class SerialBlock_adapt(nn.Module):
     def forward(self, x, size: Tuple[int, int], domain_label=None):
         x = self.cpe(x, size)
         s1, s2 = self._droppath_scales(x.shape[0], x.device)
-        cur = self.norm1(x)
+        cur, x = self.norm1.fork(x)
         use_da = (domain_label is not None) if self.base_semantics else (self.adapt_method is not None and domain_label is not None)
         if use_da:
             if not isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
@@ -292,7 +296,7 @@ class SerialBlock_adapt(nn.Module):
             if isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
                 raise TypeError("adapt_method='Sup' blocks need a domain_label (mdvit.py:281)")
             x = self.factoratt_crpe(cur, size, _res=x, _rowscale=s1)
-        cur = self.norm2(x)
+        cur, x = self.norm2.fork(x)
         return self.mlp(cur, _res=x, _rowscale=s2)
 
 

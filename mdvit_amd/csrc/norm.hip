@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 template <int VPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     const float* __restrict__ rstd, const float* __restrict__ add, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
     __shared__ float s_dg[4][64 * VPT];
     __shared__ float s_db[4][64 * VPT];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             const int c = lane + 64 * j;
-            if (c < C) dx[(long)row * C + c] = rs * (d[j] - c1 - xh[j] * c2);
+            if (c < C) dx[(long)row * C + c] = rs * (d[j] - c1 - xh[j] * c2) + (add ? add[(long)row * C + c] : 0.f);
         }
     }
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const float* __restrict__
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, float* __restrict__ dx,
+                                                       const float* __restrict__ rstd, const float* __restrict__ add, float* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
     constexpr int C = 64 * VPL;
     __shared__ float s_dg[4][C], s_db[4][C];
@@ -173,10 +173,15 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__
         c1 = sum16(c1) * (1.0f / C);
         c2 = sum16(c2) * (1.0f / C);
 #pragma unroll
-        for (int j = 0; j < VPL; ++j)
-            *reinterpret_cast<float4*>(dx + row * C + 4 * (sub + 16 * j)) =
-                make_float4(rs * (d[j].x - c1 - xh[j].x * c2), rs * (d[j].y - c1 - xh[j].y * c2),
-                            rs * (d[j].z - c1 - xh[j].z * c2), rs * (d[j].w - c1 - xh[j].w * c2));
+        for (int j = 0; j < VPL; ++j) {
+            float4 o = make_float4(rs * (d[j].x - c1 - xh[j].x * c2), rs * (d[j].y - c1 - xh[j].y * c2),
+                                   rs * (d[j].z - c1 - xh[j].z * c2), rs * (d[j].w - c1 - xh[j].w * c2));
+            if (add) {           // gradient of the residual branch that forked off the LayerNorm input
+                const float4 a4 = *reinterpret_cast<const float4*>(add + row * C + 4 * (sub + 16 * j));
+                o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+            }
+            *reinterpret_cast<float4*>(dx + row * C + 4 * (sub + 16 * j)) = o;
+        }
     }
     // fold the 4 row slots of the wavefront (lanes sub, sub+16, sub+32, sub+48), then the 4 wavefronts through LDS
 #pragma unroll
@@ -540,7 +545,7 @@ extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const flo
 }
 
 extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                   float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
+                                   const float* add, float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
     {
@@ -550,15 +555,15 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
     }
     if (C == 64 || C == 128 || C == 320 || C == 512) {
         dim3 grid16(min(cdiv(M, 64), 1024));
-        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
-        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
-        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
-        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M);
+        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
+        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
+        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
+        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
         MDVIT_LAUNCH_CHECK();
         return MDVIT_OK;
     }
     dim3 grid(min(cdiv(M, 16), 1024));
-    LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C);
+    LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M, C);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -515,8 +515,12 @@ def mlp_residual(x, res, W1, b1, W2, b2, rowscale=None, drop_p=0.0, rows_per_sca
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
+    """fork=True returns (LN(x), x): the second output is x itself, handed to the residual consumer, so that the
+    gradient of the residual branch comes back HERE and is added inside the LayerNorm backward kernel (otherwise
+    autograd sums the two branches of  x + f(LN(x))  with an extra full-tensor add per block and sweep)."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, fork):
         ctx.set_materialize_grads(False)
         _chk(x, gamma, beta)
         M, Cn = x.shape
@@ -525,26 +529,36 @@ class _LayerNorm(torch.autograd.Function):
         rstd = _empty_like(mean)
         call("mdvit_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cn, eps, _stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
+        if fork:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_pass=None):
         if g is None:
-            return (None,) * 4
+            return g_pass, None, None, None, None
         x, gamma, mean, rstd = ctx.saved_tensors
         g = _c(g)
         M, Cn = x.shape
         dx = _empty_like(x)
         dg, db = _flat_like(gamma, gamma)
-        call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), M, Cn, _stream())
+        gp = None if g_pass is None else _c(g_pass)
+        call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(gp), _p(dx), _p(dg), _p(db), M, Cn, _stream())
         if _dgrad_only:
-            return dx, None, None, None
-        return dx, dg, db, None
+            return dx, None, None, None, None
+        return dx, dg, db, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-6):
     shp = x.shape
-    return _LayerNorm.apply(_c(x).view(-1, shp[-1]), gamma, beta, float(eps)).view(shp)
+    return _LayerNorm.apply(_c(x).view(-1, shp[-1]), gamma, beta, float(eps), False).view(shp)
+
+
+def layer_norm_fork(x, gamma, beta, eps=1e-6):
+    """-> (LN(x), x_res): use x_res (same values as x) for the residual branch; see _LayerNorm."""
+    shp = x.shape
+    y, xr = _LayerNorm.apply(_c(x).view(-1, shp[-1]), gamma, beta, float(eps), True)
+    return y.view(shp), xr.view(shp)
 
 
 # ------------------------------------------------------------------------------------------------
