@@ -65,6 +65,9 @@ typedef struct MdvitGemmDesc {
     int32_t allow_split;
     void* ws; uint64_t ws_bytes;      /* scratch for split reductions: mdvit_gemm_ws_bytes(desc) (0 = none needed) */
     int32_t accumulate;               /* C += result (gradient accumulation straight into a persistent buffer) */
+    float* colsum_a;                  /* TN only, optional: colsum_a[m] += sum_k A[k][m] -- the bias gradient (column sums of dY) taken
+                                       * from the wgrad's own A stream instead of a second pass over dY; the caller zeroes it
+                                       * (or passes a gradient bucket to accumulate into) */
     int32_t precision;                /* 0: fp32 MFMA (bit-for-bit an fmaf chain).  1: "bf16x3" -- operands split hi+lo into two bf16
                                        * planes while staged, hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32
                                        * accumulation (~1e-5 relative); built for NT (all epilogues) and TN (plain) */

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("allow_split", i32),
         ("ws", vp), ("ws_bytes", C.c_uint64),
         ("accumulate", i32),
+        ("colsum_a", vp),
         ("precision", i32),
         ("drop_seed", vp),
     ]

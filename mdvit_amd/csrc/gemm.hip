@@ -35,6 +35,7 @@ struct GemmArgs {
     int splits; int k_per_split;   // split along K: each split writes a dense [M,N] slab, reduced by a second kernel
     float* slab;
     int accumulate;
+    float* colsum;                 // TN only: colsum[m] += sum_k A[k][m] (the bias gradient rides on the wgrad's A stream)
     int vec;                       // output rows can take 16-byte vector accesses
     const uint32_t* seed;          // optional device-side dropout seed {s0, s1}: key0 ^= s0, key1 += s1 (graph replays draw fresh masks)
     int tiles_m, tiles_n;
@@ -120,6 +121,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[A_V4], rb[B_V4];
+    constexpr int NCS = A_PAIR ? A_V4 / 2 : 1;             // column-sum partials (TN + colsum, tile column 0 only)
+    float4 cs[NCS];
+#pragma unroll
+    for (int v = 0; v < NCS; ++v) cs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_cs = TA && p.colsum != nullptr && tn == 0;
 
     auto load_a = [&](int k0) {
         if (A_PAIR) {           // rows k = k0 + 2*kp, +1 ; columns m0 + 4*mq .. +3
@@ -180,6 +186,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         }
     };
     auto store_smem = [&]() {
+        if (TA && do_cs) {          // raw fp32 values of the staged A slab (zeros outside the matrix)
+            if (A_PAIR) {
+#pragma unroll
+                for (int v = 0; v < A_V4 / 2; ++v) {
+                    cs[v].x += ra[2 * v].x + ra[2 * v + 1].x; cs[v].y += ra[2 * v].y + ra[2 * v + 1].y;
+                    cs[v].z += ra[2 * v].z + ra[2 * v + 1].z; cs[v].w += ra[2 * v].w + ra[2 * v + 1].w;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < A_V4; ++v) { cs[0].x += ra[v].x; cs[0].y += ra[v].y; cs[0].z += ra[v].z; cs[0].w += ra[v].w; }
+            }
+        }
         if (BF3) {
             if (A_PAIR) {
 #pragma unroll
@@ -311,6 +329,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             store_smem();
             __syncthreads();
         }
+    }
+
+    if (TA && do_cs) {              // (the main loop ended with a barrier: the staging LDS is free)
+        float* s_cs = smem;
+        for (int i = tid; i < BM; i += NTHREADS) s_cs[i] = 0.f;
+        __syncthreads();
+        if (A_PAIR) {
+#pragma unroll
+            for (int v = 0; v < A_V4 / 2; ++v) {
+                const int mq = (tid >> 4) + 16 * v;
+                atomicAdd(&s_cs[4 * mq + 0], cs[v].x); atomicAdd(&s_cs[4 * mq + 1], cs[v].y);
+                atomicAdd(&s_cs[4 * mq + 2], cs[v].z); atomicAdd(&s_cs[4 * mq + 3], cs[v].w);
+            }
+        } else {
+            const int c = (tid % (BM / 4)) * 4;
+            atomicAdd(&s_cs[c + 0], cs[0].x); atomicAdd(&s_cs[c + 1], cs[0].y);
+            atomicAdd(&s_cs[c + 2], cs[0].z); atomicAdd(&s_cs[c + 3], cs[0].w);
+        }
+        __syncthreads();
+        for (int i = tid; i < BM; i += NTHREADS)
+            if (m0 + i < p.M) atomicAdd(&p.colsum[m0 + i], s_cs[i]);
     }
 
     // ---- epilogue.  The MFMA ran as D = B^T-tile x A-tile, so D[row = n][col = m]: lane holds, for each
@@ -525,6 +564,8 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
     a.accumulate = d->accumulate;
+    a.colsum = d->colsum_a;
+    MDVIT_CHECK_ARG(!d->colsum_a || (d->trans_a && !d->trans_b), MDVIT_E_SHAPE, "gemm: colsum_a rides on the TN (wgrad) layout only");
     a.seed = d->drop_seed;
 
     const GemmPlan pl = plan_gemm(d);

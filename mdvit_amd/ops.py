@@ -194,7 +194,7 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
-         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None):
+         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None):
     if precision is None:
         precision = _gemm_precision if (bool(trans_b) != bool(trans_a)) else 0      # built for NT and TN
     d = GemmDesc()
@@ -211,6 +211,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.allow_split = int(allow_split)
     d.accumulate = int(accumulate)
     d.precision = int(precision)
+    d.colsum_a = colsum_a
     d.drop_seed = _seed_ptr() if e_drop > 0 else None
     ws = None
     if allow_split:
@@ -369,7 +370,11 @@ class _Linear(torch.autograd.Function):
         # gradient (column sums of gm); the dgrad / wgrad GEMMs below read gm with no prologue of their own
         masked = drop_p > 0 or rowscale is not None
         gm = _empty_like(g) if masked else g
-        if masked or want_b:
+        # unmasked: the bias gradient rides on the wgrad GEMM's own pass over g (colsum_a); masked: it is fused into the mask pass
+        ride = want_b and not masked and (sunk or ctx.needs_input_grad[1])
+        if want_b and not sunk and ride:
+            db.zero_()
+        if masked or (want_b and not ride):
             call("mdvit_colsum_f32", _p(g), N, _p(sb if sunk else db) if want_b else None, _p(gm) if masked else None, M, N,
                  drop_p, key[0], key[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         if ctx.needs_input_grad[0]:
@@ -379,11 +384,13 @@ class _Linear(torch.autograd.Function):
             if sunk:
                 # accumulate straight into the gradient buckets (side stream if enabled); autograd gets None
                 with _on_side(gm, x):
-                    gemm(_p(gm), _p(x), _p(sW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
+                    gemm(_p(gm), _p(x), _p(sW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, accumulate=True,
+                         colsum_a=_p(sb) if ride else None)
                 db = None
             elif ctx.needs_input_grad[1]:
                 dW = _empty(tuple(W.shape) if W.dim() == 4 else (N, K), device=x.device, dtype=torch.float32)
-                gemm(_p(gm), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True)
+                gemm(_p(gm), _p(x), _p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True,
+                     colsum_a=_p(db) if ride else None)
         return dx, dW, db, (g if has_res else None), None, None, None
 
 
@@ -491,16 +498,15 @@ class _MlpResidual(torch.autograd.Function):
                 dW1_, db1_, dW2_, _ = sinks
                 with _on_side(gm, h, du, x):
                     gemm(_p(gm), _p(h), _p(dW2_), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
-                    gemm(_p(du), _p(x), _p(dW1_), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
-                    call("mdvit_colsum_f32", _p(du), Hd, _p(db1_), None, M, Hd, 0.0, 0, 0, None, 1, 1, None, _stream())
+                    gemm(_p(du), _p(x), _p(dW1_), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, accumulate=True,
+                         colsum_a=_p(db1_))          # db1 = column sums of du, taken from the wgrad's A stream
                 db2 = None
             else:
                 dW2 = _empty_like(W2)
                 gemm(_p(gm), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True)
                 dW1 = _empty_like(W1)
-                gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True)
-                db1 = _empty((Hd,), device=dev, dtype=torch.float32)
-                call("mdvit_colsum_f32", _p(du), Hd, _p(db1), None, M, Hd, 0.0, 0, 0, None, 1, 0, None, _stream())
+                db1 = torch.zeros((Hd,), device=dev, dtype=torch.float32)
+                gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, colsum_a=_p(db1))
         return dx, g, dW1, db1, dW2, db2, None, None, None
 
 
