@@ -45,6 +45,41 @@ int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
     return MDVIT_OK;
 }
 
+namespace {
+// 32 columns x 8 row lanes per workgroup; lane r adds rows r, r+8, ... and the 8 lane sums are added 0..7
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, long stride, int n,
+                                                              float* __restrict__ out, int accumulate) {
+    __shared__ float s_sum[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (i < n) {
+        int b = rl;
+        for (; b + 24 < nblk; b += 32) {
+            const float v0 = part[(long)b * stride + i], v1 = part[(long)(b + 8) * stride + i];
+            const float v2 = part[(long)(b + 16) * stride + i], v3 = part[(long)(b + 24) * stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < nblk; b += 8) s += part[(long)b * stride + i];
+    }
+    s_sum[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
+        out[i] = accumulate ? out[i] + t : t;
+    }
+}
+}  // namespace
+
+int mdvit_reduce_partials(const float* part, int nblk, long stride, int n, float* out, int accumulate, hipStream_t stream) {
+    if (n <= 0 || nblk <= 0) return MDVIT_OK;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, part, nblk, stride, n, out, accumulate);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
 int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream) {
     int i = 0;
     while (i < n) {

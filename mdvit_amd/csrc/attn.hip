@@ -189,13 +189,14 @@ __global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restri
         if (tw0 + t < W) y[(img + (long)h * W + tw0 + t) * ldy + yoff + c0 + cl] = acc[t];
 }
 
-// dw[ci][i][j] += sum_tokens g[n,cg] * x[n + (i-R, j-R), cx];  db[ci] += sum g.   Thread (channel, window row i)
-// slides along w with the x row in registers; every (channel, tap) is owned by one thread -> one global atomic
-// per tap per block, no LDS reduction.
+// dw[ci][i][j] = sum_tokens g[n,cg] * x[n + (i-R, j-R), cx];  db[ci] = sum g.   Thread (channel, window row i)
+// slides along w with the x row in registers; every (channel, tap) of the block's 32 channels is owned by one thread,
+// which writes its partial into the block's row of `part` ([y][z*x][32*(WIN*WIN+1)]); mdvit_reduce_partials adds the
+// rows in a fixed order (deterministic; ~1000 same-address float atomics per tap cost more than the whole kernel).
 template <int WIN>
 __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __restrict__ g, long ldg, int goff,
                                                                  const float* __restrict__ x, long ldx, int xoff,
-                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 float* __restrict__ part,
                                                                  int H, int W, int ncls, int tiles_w, int tiles_total, int tiles_per_block) {
     constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
     __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
@@ -232,10 +233,12 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
         }
         __syncthreads();
     }
-    if (rl < WIN && chan_ok) {
+    constexpr int ROW = CT_CL * (WIN * WIN + 1);
+    float* prow = part + ((long)blockIdx.y * gridDim.z * gridDim.x + (long)blockIdx.z * gridDim.x + blockIdx.x) * ROW + cl * (WIN * WIN + 1);
+    if (rl < WIN) {              // channels past ncls hold zeros
 #pragma unroll
-        for (int j = 0; j < WIN; ++j) atomicAdd(&dw[(long)(c0 + cl) * WIN * WIN + rl * WIN + j], acc[j]);
-        if (rl == 0) atomicAdd(&db[c0 + cl], accb);
+        for (int j = 0; j < WIN; ++j) prow[rl * WIN + j] = acc[j];
+        if (rl == 0) prow[WIN * WIN] = accb;
     }
 }
 
@@ -536,7 +539,9 @@ size_t fa_ws_floats(int B, int N, int C, int heads) {
     const int Ch = C / heads;
     const long NT = (N + FA_T - 1) / FA_T;
     const long fwd = (long)B * NT * C * (2 + Ch);
-    const long bwd = 2L * B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch;
+    // + the partial rows of the window-weight gradients: <= max(1024, C/32 * B) workgroups x 32 channels x (49 taps + bias)
+    const long wg_rows = (long)cdiv(C, 32) * B > 1024 ? (long)cdiv(C, 32) * B : 1024;
+    const long bwd = 2L * B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch + wg_rows * 32 * 50;
     return (size_t)(fwd > bwd ? fwd : bwd);
 }
 
@@ -560,15 +565,54 @@ void launch_conv_tile(const float* x, long ldx, int xoff, const float* w, const 
                        x, ldx, xoff, w, bias, y, ldy, yoff, g.H, g.W, ncls, tiles_w);
 }
 
+// fixed-order sum of the partial rows of one 32-channel block: 32 columns x 8 row lanes per workgroup
 template <int WIN>
-void launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x, long ldx, int xoff, float* dw, float* db,
-                            const FaGeom& g, int ncls, hipStream_t s) {
-    if (ncls <= 0) return;
+__global__ __launch_bounds__(256) void fa_conv_wgrad_finish_kernel(const float* __restrict__ part, int nrows, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int ncls) {
+    constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
+    __shared__ float s_sum[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
+    const float* base = part + (long)blockIdx.y * nrows * ROW;
+    float sacc = 0.f;
+    if (i < ROW)
+        for (int b = rl; b < nrows; b += 8) sacc += base[(long)b * ROW + i];
+    s_sum[rl][cl] = sacc;
+    __syncthreads();
+    if (rl == 0 && i < ROW) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
+        const int c = blockIdx.y * CT_CL + i / T, tap = i % T;
+        if (c < ncls) {
+            if (tap < WIN * WIN) dw[(long)c * WIN * WIN + tap] = t;
+            else db[c] = t;
+        }
+    }
+}
+
+// tiles per block: keep >= ~512 blocks while halving the number of partial rows
+void conv_wgrad_plan(const FaGeom& g, int ncls, int& tpb, long& nblk) {
+    const int tiles = cdiv(g.W, CT_TW) * cdiv(g.H, CT_TH);
+    tpb = 1;
+    while (tpb < tiles && (long)cdiv(tiles, tpb * 2) * cdiv(ncls, CT_CL) * g.B >= 512) tpb *= 2;
+    nblk = (long)cdiv(tiles, tpb) * cdiv(ncls, CT_CL) * g.B;
+}
+
+template <int WIN>
+int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x, long ldx, int xoff, float* dw, float* db, float* part,
+                           const FaGeom& g, int ncls, hipStream_t s) {
+    if (ncls <= 0) return MDVIT_OK;
     const int tiles_w = cdiv(g.W, CT_TW), tiles_h = cdiv(g.H, CT_TH), tiles = tiles_w * tiles_h;
-    int tpb = 1;                                   // tiles per block: keep >= ~512 blocks, cut the atomics otherwise
-    while ((long)cdiv(tiles, tpb * 2) * cdiv(ncls, CT_CL) * g.B >= 512) tpb *= 2;
-    hipLaunchKernelGGL((fa_conv_tile_wgrad_kernel<WIN>), dim3(cdiv(tiles, tpb), cdiv(ncls, CT_CL), g.B), dim3(256), 0, s,
-                       gsrc, ldg, goff, x, ldx, xoff, dw, db, g.H, g.W, ncls, tiles_w, tiles, tpb);
+    int tpb; long nblk;
+    conv_wgrad_plan(g, ncls, tpb, nblk);
+    const int gx = cdiv(tiles, tpb), gy = cdiv(ncls, CT_CL);
+    hipLaunchKernelGGL((fa_conv_tile_wgrad_kernel<WIN>), dim3(gx, gy, g.B), dim3(256), 0, s,
+                       gsrc, ldg, goff, x, ldx, xoff, part, g.H, g.W, ncls, tiles_w, tiles, tpb);
+    // second stage, per 32-channel block y: rows [y][gx*B] of 32*(WIN^2+1) floats -> dw [c][WIN^2], db [c]
+    constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
+    hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<WIN>), dim3(cdiv(ROW, 32), gy), dim3(256), 0, s, part, gx * g.B, dw, db, ncls);
+    return MDVIT_OK;
 }
 
 }  // namespace
@@ -641,15 +685,7 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     const bool want_wgrad = dw3 != nullptr;
     MDVIT_CHECK_ARG(want_wgrad ? (db3 && dw5 && db5 && dw7 && db7) : !(db3 || dw5 || db5 || dw7 || db7), MDVIT_E_SHAPE,
                     "factoratt_bwd: the six crpe gradient outputs must be all given or all NULL");
-    if (!want_wgrad) {
-        if (e) MDVIT_ZERO(e, sizeof(float) * (size_t)B * C, s);
-    } else {
-        const MdvitZeroItem z[7] = {{e, e ? sizeof(float) * (size_t)B * C : 0}, {dw3, sizeof(float) * s3 * Ch * 9}, {db3, sizeof(float) * s3 * Ch},
-                                    {dw5, sizeof(float) * s5 * Ch * 25}, {db5, sizeof(float) * s5 * Ch},
-                                    {dw7, sizeof(float) * s7 * Ch * 49}, {db7, sizeof(float) * s7 * Ch}};
-        const int rc = mdvit_zero_many(z, 7, s);
-        if (rc != MDVIT_OK) return rc;
-    }
+    if (e) MDVIT_ZERO(e, sizeof(float) * (size_t)B * C, s);       // (the window-weight gradients are written, not accumulated)
     // 1: dU, e
     const int QC = C / 4;
     hipLaunchKernelGGL(fa_bwd_prep_kernel, dim3(quad_grid((long)g.N * QC, QC, 512), B), dim3(256), sizeof(float) * C, s, dout, qkv, out, a, dU, e, g);
@@ -661,9 +697,10 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     // 3: crpe weight gradients
     const int c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
     if (want_wgrad) {
-        launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, g, s3 * Ch, s);
-        launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, g, s5 * Ch, s);
-        launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, g, s7 * Ch, s);
+        float* wg_part = ws_P + (long)B * NT * C * Ch;          // partial rows, reduced by the finish kernel of each class
+        launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, wg_part, g, s3 * Ch, s);
+        launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, wg_part, g, s5 * Ch, s);
+        launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, wg_part, g, s7 * Ch, s);
     }
     // conv^T(dU) = correlation with the flipped window
     launch_conv_tile<3, true>(dU, (long)C, 0, w3, nullptr, dVc, (long)C, 0, g, s3 * Ch, s);

@@ -38,6 +38,11 @@ int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream);
         if (rc__ != MDVIT_OK) return rc__;                             \
     } while (0)
 
+// out[i] (+)= sum_{b < nblk} part[b * stride + i], i < n, added in a FIXED order (deterministic): the second stage of
+// "every workgroup writes one row of partial sums".  Same-address float atomics from ~1000 workgroups serialise in the
+// L2 (a reduction's atomic tail cost 30-100 us); a partial row per workgroup plus this ~5 us pass does not.
+int mdvit_reduce_partials(const float* part, int nblk, long stride, int n, float* out, int accumulate, hipStream_t stream);
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
