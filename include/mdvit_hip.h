@@ -37,6 +37,12 @@ enum { MDVIT_ACT_NONE = 0, MDVIT_ACT_HSWISH = 1, MDVIT_ACT_RELU = 2 };
 const char* mdvit_last_error(void);
 int mdvit_version(void);
 
+/* Reductions over the token axis (weight / bias gradients, column sums) write ONE row of partial sums per workgroup into
+ * the caller's workspace and add the rows in a fixed order in a second tiny launch -- deterministic, and much faster than
+ * ~1000 same-address float atomics.  `ws` of those entry points: mdvit_partials_ws_bytes(n) bytes, n = number of floats
+ * the reduction produces (the entry point's comment says which). */
+size_t mdvit_partials_ws_bytes(int32_t n_outputs);
+
 /* ---- GEMM family -------------------------------------------------------------------------
  * C[M,N] = op(A)[M,K] * op(B)[K,N] (+bias[N]) with fused neighbours.
  *   trans_a = 0: A is [M,K] row-major (lda);   1: A is stored [K,M] row-major (wgrad, A = dY^T).
@@ -90,13 +96,13 @@ int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y,
                      int32_t M, int32_t K, int32_t accumulate, void* stream);
 int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, const float* dy, float* dx, int64_t lddx,
-                     float* dw, float* db, int32_t M, int32_t K, void* stream);
+                     float* dw, float* db, void* ws /* n = K + 1 */, size_t ws_bytes, int32_t M, int32_t K, void* stream);
 
 /* Masked upstream gradient + bias gradient in one pass over dY [M,N] (the backward of  y = drop(x W^T + b) * droppath,
  * mdvit.py:306-309,343-346):  masked[m][n] = A[m][n] * dropmask(m*N+n) * rowscale[m / rows_per_scale]  (optional) and
  * out[n] (+)= sum_m masked[m][n]  (optional).  The mask is re-derived from (key0,key1[,drop_seed]) exactly as the forward
  * GEMM epilogue drew it; the dgrad/wgrad GEMMs then read `masked` with no prologue of their own. */
-int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, int32_t M, int32_t N,
+int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, void* ws /* n = N; unused if out == NULL */, size_t ws_bytes, int32_t M, int32_t N,
                      float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale,
                      int32_t accumulate, const uint32_t* drop_seed, void* stream);
 
@@ -106,7 +112,8 @@ int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 /* add (optional, [M,C]): gradient arriving at x along the residual branch that forked off before the norm
  * (x + f(LN(x)), mdvit.py:353-360) -- dx = LN-backward(dy) + add in the same pass. */
 int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                        const float* add, float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream);
+                        const float* add, float* dx, float* dgamma, float* dbeta, void* ws /* n = 2C */, size_t ws_bytes,
+                        int32_t M, int32_t C, void* stream);
 
 /* ---- 3x3 convolutions on NHWC ------------------------------------------------------------------
  * dwconv3x3: depthwise, pad 1, stride 1|2, optional bias, optional "+ input" (ConvPosEnc,
@@ -114,20 +121,23 @@ int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, con
 int mdvit_dwconv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
                         int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream);
 int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                        void* ws /* n = 10C; unused if dw == NULL */, size_t ws_bytes,
                         int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream);
 /* gconv2: Conv2d(2C, C, 3, groups=C, bias=False) applied to cat(skip, up) WITHOUT materialising the
  * concat (Decoders.py:30-38,198-199).  w is [C,2,3,3]; output channel g reads concat channels 2g, 2g+1. */
 int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const float* w, float* y,
                          int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const float* up, const float* w,
-                         float* dskip, float* dup, float* dw, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+                         float* dskip, float* dup, float* dw, void* ws /* n = 18C; unused if dw == NULL */, size_t ws_bytes,
+                         int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 /* Dense 3x3 (pad 1) as im2col + GEMM: col is [B*Ho*Wo, Cin*9], column order (cin,kh,kw) == weight.view(Cout,-1)
  * (stem.1 mpvit.py:104-111, bridge mdvit.py:557-564). */
 int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream);
 int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream);
 /* stem.0: NCHW image [B,Cin,H,W] -> NHWC [B,H/2,W/2,Cout], 3x3 s2 p1, no bias (mdvit.py:509-517). */
 int mdvit_stemconv_fwd(const float* img, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
-int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
+int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, void* ws /* n = 27*Cout */, size_t ws_bytes,
+                         int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 
 /* ---- BatchNorm2d (train: batch stats, biased var; running stats momentum, unbiased var) + activation
  * on NHWC [M,C]  (mpvit.py:112-123, mdvit.py:99-122,559-563, Decoders.py:39-62,304-306).

@@ -51,18 +51,18 @@ _SIGS = {
     "mdvit_gemm_force_plan": [i32, i32],
     "mdvit_transpose_f32": [vp, i64, vp, i32, i32, vp],
     "mdvit_rowdot_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
-    "mdvit_rowdot_bwd": [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, vp],
-    "mdvit_colsum_f32": [vp, i64, vp, vp, i32, i32, f32, u32, u32, vp, i32, i32, vp, vp],
+    "mdvit_rowdot_bwd": [vp, i64, vp, vp, vp, i64, vp, vp, vp, C.c_size_t, i32, i32, vp],
+    "mdvit_colsum_f32": [vp, i64, vp, vp, vp, C.c_size_t, i32, i32, f32, u32, u32, vp, i32, i32, vp, vp],
     "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
-    "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, vp],
     "mdvit_dwconv3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_gconv2_3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mdvit_gconv2_3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_gconv2_3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp],
     "mdvit_im2col3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_col2im3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mdvit_stemconv_wgrad": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_stemconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp],
     "mdvit_bn_stats": [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
     "mdvit_bn_eval_prep": [vp, vp, vp, vp, i32, f32, vp],
     "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
@@ -112,6 +112,8 @@ def load():
     lib.mdvit_gemm_ws_bytes.argtypes = [C.POINTER(GemmDesc)]
     lib.mdvit_bn_ws_bytes.restype = C.c_size_t
     lib.mdvit_bn_ws_bytes.argtypes = [i32, i32, i32]
+    lib.mdvit_partials_ws_bytes.restype = C.c_size_t
+    lib.mdvit_partials_ws_bytes.argtypes = [i32]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t
     lib.mdvit_da_ws_bytes.argtypes = [i32, i32, i32]
     for name, sig in _SIGS.items():

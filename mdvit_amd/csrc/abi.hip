@@ -47,8 +47,9 @@ int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
 
 namespace {
 // 32 columns x 8 row lanes per workgroup; lane r adds rows r, r+8, ... and the 8 lane sums are added 0..7
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, long stride, int n,
-                                                              float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, long stride, int n0,
+                                                              float* __restrict__ out0, int n1, float* __restrict__ out1, int accumulate) {
+    const int n = n0 + n1;
     __shared__ float s_sum[8][33];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cl;
@@ -68,16 +69,21 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
-        out[i] = accumulate ? out[i] + t : t;
+        float* dst = i < n0 ? out0 + i : (out1 ? out1 + (i - n0) : nullptr);
+        if (dst) *dst = accumulate ? *dst + t : t;
     }
 }
 }  // namespace
 
-int mdvit_reduce_partials(const float* part, int nblk, long stride, int n, float* out, int accumulate, hipStream_t stream) {
-    if (n <= 0 || nblk <= 0) return MDVIT_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, part, nblk, stride, n, out, accumulate);
+int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream) {
+    if (n0 + n1 <= 0 || nblk <= 0) return MDVIT_OK;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n0 + n1 + 31) / 32), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
+}
+
+extern "C" size_t mdvit_partials_ws_bytes(int32_t n_outputs) {
+    return n_outputs > 0 ? sizeof(float) * (size_t)MDVIT_MAX_PARTIAL_ROWS * (size_t)n_outputs : 0;
 }
 
 int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream) {

@@ -41,7 +41,13 @@ int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream);
 // out[i] (+)= sum_{b < nblk} part[b * stride + i], i < n, added in a FIXED order (deterministic): the second stage of
 // "every workgroup writes one row of partial sums".  Same-address float atomics from ~1000 workgroups serialise in the
 // L2 (a reduction's atomic tail cost 30-100 us); a partial row per workgroup plus this ~5 us pass does not.
-int mdvit_reduce_partials(const float* part, int nblk, long stride, int n, float* out, int accumulate, hipStream_t stream);
+// Row layout [out0 (n0) | out1 (n1)]; out1 may be NULL (then n1 entries are skipped).
+int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream);
+constexpr int MDVIT_MAX_PARTIAL_ROWS = 2048;        // every partial-row reduction launches at most this many workgroups
+#define MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, n, what)                                                              \
+    MDVIT_CHECK_ARG((ws) != nullptr && (ws_bytes) >= sizeof(float) * (size_t)(nblk) * (size_t)(n), MDVIT_E_WORKSPACE,    \
+                    what ": workspace too small: need %zu bytes (mdvit_partials_ws_bytes), got %zu",                      \
+                    sizeof(float) * (size_t)(nblk) * (size_t)(n), (size_t)(ws_bytes))
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_dgrad_kernel(const float* __res
 // Block = (C/4 quads) x (256/(C/4) token lanes) over a contiguous chunk of output tokens; register
 // partials -> LDS atomics -> one global atomic per (c,tap) per block.
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                              float* __restrict__ dw, float* __restrict__ dbias,
+                                                              float* __restrict__ part,
                                                               int B, int Hi, int Wi, int C, int stride, int tokens_per_block) {
     extern __shared__ float s_acc[];   // [C][10]
     for (int i = threadIdx.x; i < C * 10; i += blockDim.x) s_acc[i] = 0.f;
@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
         atomicAdd(&s_acc[(c + 2) * 10 + 9], accb.z); atomicAdd(&s_acc[(c + 3) * 10 + 9], accb.w);
     }
     __syncthreads();
+    float* row = part + (long)blockIdx.x * C * 10;       // [dw (C*9) | dbias (C)], summed over workgroups by mdvit_reduce_partials
     for (int i = threadIdx.x; i < C * 10; i += blockDim.x) {
         const int c = i / 10, t = i % 10;
-        if (t < 9) atomicAdd(&dw[c * 9 + t], s_acc[i]);
-        else if (dbias) atomicAdd(&dbias[c], s_acc[i]);
+        row[t < 9 ? c * 9 + t : C * 9 + c] = s_acc[i];
     }
 }
 
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gconv2_dgrad_kernel(const float* __restri
 
 // wgrad: dw[g,j,kh,kw] = sum dy[b,ho,wo,g] * cat[b,ho+kh-1,wo+kw-1,2g+j]
 __global__ __launch_bounds__(256) void gconv2_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ skip,
-                                                           const float* __restrict__ up, float* __restrict__ dw,
+                                                           const float* __restrict__ up, float* __restrict__ part,
                                                            int B, int H, int W, int C, int tokens_per_block) {
     extern __shared__ float s_acc[];   // [C][18]
     for (int i = threadIdx.x; i < C * 18; i += blockDim.x) s_acc[i] = 0.f;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void gconv2_wgrad_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * 18; i += blockDim.x) atomicAdd(&dw[i], s_acc[i]);
+    for (int i = threadIdx.x; i < C * 18; i += blockDim.x) part[(long)blockIdx.x * C * 18 + i] = s_acc[i];
 }
 
 // ---- im2col / col2im for dense 3x3 pad 1; column order (cin, kh, kw) ---------------------------
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void stemconv_fwd_kernel(const float* __restri
 // thread = (co, pixel lane); 27 register accumulators; LDS atomics -> global atomics.
 template <int CIN>
 __global__ __launch_bounds__(256) void stemconv_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ dy,
-                                                             float* __restrict__ dw, int B, int H, int W, int Cout, int pix_per_block) {
+                                                             float* __restrict__ part, int B, int H, int W, int Cout, int pix_per_block) {
     extern __shared__ float s_acc[];   // [Cout][CIN*9]
     constexpr int KK = CIN * 9;
     for (int i = threadIdx.x; i < Cout * KK; i += blockDim.x) s_acc[i] = 0.f;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void stemconv_wgrad_kernel(const float* __rest
         for (int k = 0; k < KK; ++k) atomicAdd(&s_acc[co * KK + k], acc[k]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < Cout * KK; i += blockDim.x) atomicAdd(&dw[i], s_acc[i]);
+    for (int i = threadIdx.x; i < Cout * KK; i += blockDim.x) part[(long)blockIdx.x * Cout * KK + i] = s_acc[i];
 }
 
 // ---- bilinear, align_corners=False (ATen upsample_bilinear2d index rule) ------------------------
@@ -527,7 +527,7 @@ extern "C" int mdvit_dwconv3x3_fwd(const float* x, const float* w, const float* 
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
                                    int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "dwconv3x3_bwd: bad shape B=%d H=%d W=%d C=%d", B, Hi, Wi, C);
@@ -538,14 +538,13 @@ extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float*
         hipLaunchKernelGGL(dwconv3x3_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 9 * C, s, dy, w, dx, B, Hi, Wi, C, stride, add_input);
     }
     if (dw) {
-        {
-            const MdvitZeroItem z[2] = {{dw, sizeof(float) * 9 * C}, {dbias, dbias ? sizeof(float) * C : 0}};
-            const int rc = mdvit_zero_many(z, 2, s);
-            if (rc != MDVIT_OK) return rc;
-        }
         const long ntok = (long)B * Ho * Wo;
         int tpb = (int)max(64L, (ntok + 1023) / 1024);
-        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(cdiv(ntok, tpb)), dim3(256), sizeof(float) * 10 * C, s, dy, x, dw, dbias, B, Hi, Wi, C, stride, tpb);
+        const int nblk = cdiv(ntok, tpb);
+        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 10 * C, "dwconv3x3_bwd");
+        hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nblk), dim3(256), sizeof(float) * 10 * C, s, dy, x, (float*)ws, B, Hi, Wi, C, stride, tpb);
+        const int rc = mdvit_reduce_partials((const float*)ws, nblk, 10L * C, 9 * C, dw, C, dbias, 0, s);
+        if (rc != MDVIT_OK) return rc;
     }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
@@ -560,16 +559,19 @@ extern "C" int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const fl
 }
 
 extern "C" int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const float* up, const float* w, float* dskip, float* dup, float* dw,
-                                    int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+                                    void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "gconv2_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     const long total = (long)B * H * W * C / 2;
     hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
     if (dw) {
-        MDVIT_ZERO(dw, sizeof(float) * 18 * C, s);
         const long ntok = (long)B * H * W;
         int tpb = (int)max(64L, (ntok + 1023) / 1024);
-        hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(cdiv(ntok, tpb)), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, dw, B, H, W, C, tpb);
+        const int nblk = cdiv(ntok, tpb);
+        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 18 * C, "gconv2_bwd");
+        hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(nblk), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, (float*)ws, B, H, W, C, tpb);
+        const int rc = mdvit_reduce_partials((const float*)ws, nblk, 18L * C, 18 * C, dw, 0, nullptr, 0, s);
+        if (rc != MDVIT_OK) return rc;
     }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
@@ -600,17 +602,19 @@ extern "C" int mdvit_stemconv_fwd(const float* img, const float* w, float* y, in
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+extern "C" int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W,
+                                    int32_t Cin, int32_t Cout, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(Cin == 3, MDVIT_E_SHAPE, "stemconv_wgrad: only in_chans == 3 is built (got %d)", Cin);
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout <= 256, MDVIT_E_SHAPE, "stemconv_wgrad: bad shape");
-    MDVIT_ZERO(dw, sizeof(float) * 27 * Cout, s);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long npix = (long)B * Ho * Wo;
     int ppb = (int)max(64L, (npix + 2047) / 2048);
-    hipLaunchKernelGGL((stemconv_wgrad_kernel<3>), dim3(cdiv(npix, ppb)), dim3(256), sizeof(float) * 27 * Cout, s, img, dy, dw, B, H, W, Cout, ppb);
+    const int nblk = cdiv(npix, ppb);
+    MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 27 * Cout, "stemconv_wgrad");
+    hipLaunchKernelGGL((stemconv_wgrad_kernel<3>), dim3(nblk), dim3(256), sizeof(float) * 27 * Cout, s, img, dy, (float*)ws, B, H, W, Cout, ppb);
     MDVIT_LAUNCH_CHECK();
-    return MDVIT_OK;
+    return mdvit_reduce_partials((const float*)ws, nblk, 27L * Cout, 27 * Cout, dw, 0, nullptr, 0, s);
 }
 
 extern "C" int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, int32_t accumulate, void* stream) {

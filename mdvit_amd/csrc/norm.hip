@@ -48,7 +48,7 @@ template <int VPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ add, float* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
+                                                     float* __restrict__ part, int M, int C) {
     __shared__ float s_dg[4][64 * VPT];
     __shared__ float s_db[4][64 * VPT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int j = 0; j < VPT; ++j) { s_dg[wave][lane + 64 * j] = adg[j]; s_db[wave][lane + 64 * j] = adb[j]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        atomicAdd(&dgamma[c], s_dg[0][c] + s_dg[1][c] + s_dg[2][c] + s_dg[3][c]);
-        atomicAdd(&dbeta[c], s_db[0][c] + s_db[1][c] + s_db[2][c] + s_db[3][c]);
+        part[(long)blockIdx.x * 2 * C + c] = s_dg[0][c] + s_dg[1][c] + s_dg[2][c] + s_dg[3][c];           // [dgamma | dbeta] row
+        part[(long)blockIdx.x * 2 * C + C + c] = s_db[0][c] + s_db[1][c] + s_db[2][c] + s_db[3][c];
     }
 }
 
@@ -144,7 +144,7 @@ template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ add, float* __restrict__ dx,
-                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+                                                       float* __restrict__ part, int M) {
     constexpr int C = 64 * VPL;
     __shared__ float s_dg[4][C], s_db[4][C];
     const int sub = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        atomicAdd(&dgamma[c], (s_dg[0][c] + s_dg[1][c]) + (s_dg[2][c] + s_dg[3][c]));
-        atomicAdd(&dbeta[c], (s_db[0][c] + s_db[1][c]) + (s_db[2][c] + s_db[3][c]));
+        part[(long)blockIdx.x * 2 * C + c] = (s_dg[0][c] + s_dg[1][c]) + (s_dg[2][c] + s_dg[3][c]);       // [dgamma | dbeta] row
+        part[(long)blockIdx.x * 2 * C + C + c] = (s_db[0][c] + s_db[1][c]) + (s_db[2][c] + s_db[3][c]);
     }
 }
 
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) atomicAdd(&s_acc[c + j], s1[j]);
         __syncthreads();
-        for (int i = threadIdx.x; i < p.C; i += blockDim.x) atomicAdd(&p.out[i], s_acc[i]);
+        for (int i = threadIdx.x; i < p.C; i += blockDim.x) p.part[(long)blockIdx.x * p.C + i] = s_acc[i];   // one partial row per workgroup
         return;
     }
     // MODE 0/1: bitwise-reproducible reduction.  Every thread parks its 8 partials in LDS; the partials of one
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
 template <int VPT>
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                          const float* __restrict__ dy, float* __restrict__ dx, long lddx,
-                                                         float* __restrict__ dw, float* __restrict__ db, int M, int K) {
+                                                         float* __restrict__ part, int has_db, int M, int K) {
     __shared__ float s_dw[4][64 * VPT];
     __shared__ float s_db[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -487,8 +487,9 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     for (int j = 0; j < VPT; ++j) s_dw[wave][lane + 64 * j] = adw[j];
     if (lane == 0) s_db[wave] = adb;     // every lane of a wave holds the same adb
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += blockDim.x) atomicAdd(&dw[k], s_dw[0][k] + s_dw[1][k] + s_dw[2][k] + s_dw[3][k]);
-    if (threadIdx.x == 0 && db) atomicAdd(db, s_db[0] + s_db[1] + s_db[2] + s_db[3]);
+    float* row = part + (long)blockIdx.x * (K + 1);          // [dw (K) | db (1)]
+    for (int k = threadIdx.x; k < K; k += blockDim.x) row[k] = s_dw[0][k] + s_dw[1][k] + s_dw[2][k] + s_dw[3][k];
+    if (threadIdx.x == 0) row[K] = has_db ? s_db[0] + s_db[1] + s_db[2] + s_db[3] : 0.f;
 }
 
 int chan_grid(long M, int C, int max_blocks) {
@@ -545,27 +546,28 @@ extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const flo
 }
 
 extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                   const float* add, float* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, void* stream) {
+                                   const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                   int32_t M, int32_t C, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
-    {
-        const MdvitZeroItem z[2] = {{dgamma, sizeof(float) * C}, {dbeta, sizeof(float) * C}};
-        const int rc = mdvit_zero_many(z, 2, s);
-        if (rc != MDVIT_OK) return rc;
-    }
+    float* part = (float*)ws;
+    int nblk;
     if (C == 64 || C == 128 || C == 320 || C == 512) {
-        dim3 grid16(min(cdiv(M, 64), 1024));
-        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
-        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
-        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
-        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M);
-        MDVIT_LAUNCH_CHECK();
-        return MDVIT_OK;
+        nblk = min(cdiv(M, 64), 1024);
+        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 2 * C, "layernorm_bwd");
+        dim3 grid16(nblk);
+        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
+        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
+        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
+        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
+    } else {
+        nblk = min(cdiv(M, 16), 1024);
+        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 2 * C, "layernorm_bwd");
+        dim3 grid(nblk);
+        LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, add, dx, part, M, C);
     }
-    dim3 grid(min(cdiv(M, 16), 1024));
-    LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, M, C);
     MDVIT_LAUNCH_CHECK();
-    return MDVIT_OK;
+    return mdvit_reduce_partials(part, nblk, 2L * C, C, dgamma, C, dbeta, 0, s);      // fixed-order sums of the per-workgroup rows
 }
 
 constexpr int CHAN_MAX_BLOCKS = 512;
@@ -643,22 +645,23 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, int32_t M, int32_t N, float drop_p, uint32_t key0,
-                                uint32_t key1, const float* rowscale, int32_t rows_per_scale, int32_t accumulate, const uint32_t* seed,
-                                void* stream) {
+extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, void* ws, size_t ws_bytes, int32_t M, int32_t N, float drop_p,
+                                uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, int32_t accumulate,
+                                const uint32_t* seed, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && N <= 8192 && lda % 4 == 0, MDVIT_E_SHAPE, "colsum: need N %% 4 == 0 (M=%d N=%d)", M, N);
     MDVIT_CHECK_ARG(out || masked, MDVIT_E_SHAPE, "colsum: nothing to produce (out and masked are both NULL)");
     MDVIT_CHECK_ARG((long)M * N < (1L << 32), MDVIT_E_SHAPE, "colsum: dropout index space exceeds 2^32");
-    if (out && !accumulate) MDVIT_ZERO(out, sizeof(float) * N, s);
+    const int nblk = chan_grid(M, N, out ? 1024 : 4096);
+    if (out) MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, N, "colsum");
     ChanArgs a; memset(&a, 0, sizeof(a));
-    a.a = A; a.lda = lda; a.M = M; a.C = N; a.out = out; a.masked = masked;
+    a.a = A; a.lda = lda; a.M = M; a.C = N; a.out = out; a.masked = masked; a.part = (float*)ws;
     fill_drop(a, drop_p, key0, key1, 1);
     a.seed = seed;
     a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-    hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(chan_grid(M, N, out ? 1024 : 4096)), dim3(256), sizeof(float) * 2 * N, s, a);
+    hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(nblk), dim3(256), sizeof(float) * 2 * N, s, a);
     MDVIT_LAUNCH_CHECK();
-    return MDVIT_OK;
+    return out ? mdvit_reduce_partials((const float*)ws, nblk, (long)N, N, out, 0, nullptr, accumulate, s) : MDVIT_OK;
 }
 
 extern "C" int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y, int32_t M, int32_t K,
@@ -670,17 +673,15 @@ extern "C" int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, con
 }
 
 extern "C" int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, const float* dy, float* dx, int64_t lddx, float* dw, float* db,
-                                int32_t M, int32_t K, void* stream) {
+                                void* ws, size_t ws_bytes, int32_t M, int32_t K, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && K > 0 && K <= 1024, MDVIT_E_SHAPE, "rowdot_bwd: need K <= 1024 (M=%d K=%d)", M, K);
-    {
-        const MdvitZeroItem z[2] = {{dw, sizeof(float) * K}, {db, db ? sizeof(float) : 0}};
-        const int rc = mdvit_zero_many(z, 2, s);
-        if (rc != MDVIT_OK) return rc;
-    }
-    dim3 grid(min(cdiv(M, 4), 1024));          // one row per wavefront per pass: small M (weight composition) still fills the chip
+    const int nblk = min(cdiv(M, 4), 1024);      // one row per wavefront per pass: small M (weight composition) still fills the chip
+    MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, K + 1, "rowdot_bwd");
+    dim3 grid(nblk);
     const int C = K;
-    LN_DISPATCH(rowdot_bwd_kernel, C, x, (long)ldx, w, dy, dx, (long)lddx, dw, db, M, K);
+    float* part = (float*)ws;
+    LN_DISPATCH(rowdot_bwd_kernel, C, x, (long)ldx, w, dy, dx, (long)lddx, part, db != nullptr, M, K);
     MDVIT_LAUNCH_CHECK();
-    return MDVIT_OK;
+    return mdvit_reduce_partials(part, nblk, (long)K + 1, K, dw, 1, db, 0, s);
 }

@@ -93,8 +93,9 @@ class _EncoderDecoder(nn.Module):
         B, H, W, Cn = enc3.shape
         feat = torch.empty((B, Cn), device=enc3.device, dtype=torch.float32)
         with torch.no_grad():
+            wsp, wsb, _keep = ops._partials_ws(Cn, enc3.device)
             for b in range(B):
-                ops.call("mdvit_colsum_f32", ops._p(enc3[b]), Cn, ops._p(feat[b]), None, H * W, Cn, 0.0, 0, 0, None, 1, 0, None, ops._stream())
+                ops.call("mdvit_colsum_f32", ops._p(enc3[b]), Cn, ops._p(feat[b]), None, wsp, wsb, H * W, Cn, 0.0, 0, 0, None, 1, 0, None, ops._stream())
         return feat / float(H * W)
 
 

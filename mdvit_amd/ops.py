@@ -76,6 +76,13 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _partials_ws(n: int, device):
+    """workspace of the partial-row reductions (n floats produced): (ptr, bytes, keep-alive tensor)"""
+    nbytes = _lib.load().mdvit_partials_ws_bytes(int(n))
+    t = torch.empty((nbytes // 4,), device=device, dtype=torch.float32)
+    return C.c_void_p(t.data_ptr()), nbytes, t
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -375,7 +382,8 @@ class _Linear(torch.autograd.Function):
         if want_b and not sunk and ride:
             db.zero_()
         if masked or (want_b and not ride):
-            call("mdvit_colsum_f32", _p(g), N, _p(sb if sunk else db) if want_b else None, _p(gm) if masked else None, M, N,
+            wsp, wsb, _keep = _partials_ws(N, g.device) if want_b else (None, 0, None)
+            call("mdvit_colsum_f32", _p(g), N, _p(sb if sunk else db) if want_b else None, _p(gm) if masked else None, wsp, wsb, M, N,
                  drop_p, key[0], key[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         if ctx.needs_input_grad[0]:
             dx = _empty_like(x)
@@ -486,7 +494,8 @@ class _MlpResidual(torch.autograd.Function):
         masked = drop_p > 0 or rowscale is not None
         gm = _empty_like(g) if masked else g
         if masked or not _dgrad_only:
-            call("mdvit_colsum_f32", _p(g), Cin, None if _dgrad_only else _p(sinks[3] if sunk else db2), _p(gm) if masked else None, M, Cin,
+            wsp, wsb, _keep = (None, 0, None) if _dgrad_only else _partials_ws(Cin, dev)
+            call("mdvit_colsum_f32", _p(g), Cin, None if _dgrad_only else _p(sinks[3] if sunk else db2), _p(gm) if masked else None, wsp, wsb, M, Cin,
                  drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         # du = (gm W2) * gelu'(u) * mask1
         du = _empty_like(u)
@@ -549,7 +558,8 @@ class _LayerNorm(torch.autograd.Function):
         dx = _empty_like(x)
         dg, db = _flat_like(gamma, gamma)
         gp = None if g_pass is None else _c(g_pass)
-        call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(gp), _p(dx), _p(dg), _p(db), M, Cn, _stream())
+        wsp, wsb, _keep = _partials_ws(2 * Cn, x.device)
+        call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(gp), _p(dx), _p(dg), _p(db), wsp, wsb, M, Cn, _stream())
         if _dgrad_only:
             return dx, None, None, None, None
         return dx, dg, db, None, None
@@ -594,10 +604,11 @@ class _DwConv3x3(torch.autograd.Function):
         dx = _empty_like(x) if ctx.needs_input_grad[0] else None
         dw = db = None
         if dx is not None:
-            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), None, None, B, H, W_, Cn, stride, int(add_input), _stream())
+            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), None, None, None, 0, B, H, W_, Cn, stride, int(add_input), _stream())
         if not _dgrad_only:
             dw, db = _flat_like(w, (Cn,) if has_b else None)
-            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), None, _p(dw), _p(db), B, H, W_, Cn, stride, int(add_input), _stream())
+            wsp, wsb, _keep = _partials_ws(10 * Cn, x.device)
+            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), None, _p(dw), _p(db), wsp, wsb, B, H, W_, Cn, stride, int(add_input), _stream())
         return dx, dw, db, None, None
 
 
@@ -624,7 +635,8 @@ class _GConv2(torch.autograd.Function):
         g = _c(g)
         B, H, W_, Cn = skip.shape
         dskip, dup, dw = _empty_like(skip), _empty_like(up), (None if _dgrad_only else _empty_like(w))
-        call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), _p(dskip), _p(dup), _p(dw), B, H, W_, Cn, _stream())
+        wsp, wsb, _keep = _partials_ws(18 * Cn, g.device) if dw is not None else (None, 0, None)
+        call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), _p(dskip), _p(dup), _p(dw), wsp, wsb, B, H, W_, Cn, _stream())
         return dskip, dup, dw
 
 
@@ -691,7 +703,8 @@ class _StemConv(torch.autograd.Function):
         g = _c(g)
         B, Cin, H, W_ = img.shape
         dw = _empty_like(w)
-        call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(dw), B, H, W_, Cin, w.shape[0], _stream())
+        wsp, wsb, _keep = _partials_ws(27 * w.shape[0], g.device)
+        call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(dw), wsp, wsb, B, H, W_, Cin, w.shape[0], _stream())
         return None, dw
 
 
@@ -868,7 +881,8 @@ class _RowDot(torch.autograd.Function):
         M, K, ldx = _ld_view(x)
         dx = _empty((M, K), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         dw, db = _flat_like(w.reshape(-1), (1,) if ctx.has_b else None)
-        call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, _p(dw), _p(db), M, K, _stream())
+        wsp, wsb, _keep = _partials_ws(K + 1, g.device)
+        call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, _p(dw), _p(db), wsp, wsb, M, K, _stream())
         if _dgrad_only:
             return dx, None, None
         return dx, dw.view_as(w), db
