@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void fa_out_kernel(const float* __restrict__ q
     }
 }
 
-// ---- bwd 1: dU = a*G*q ; e[b,c] = sum_n G[n,c]*out[n,c]  (float4 over channels) ---------------------
+// ---- bwd 1: dU = a*G*q ; e[b,c] = sum_n G[n,c]*out[n,c]  (float4 over channels); e as one partial row per workgroup
 __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
                                                           const float* __restrict__ out, const float* __restrict__ a,
                                                           float* __restrict__ dU, float* __restrict__ e, FaGeom g) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restric
     if (e) {
         atomicAdd(&s_e[c], acc.x); atomicAdd(&s_e[c + 1], acc.y); atomicAdd(&s_e[c + 2], acc.z); atomicAdd(&s_e[c + 3], acc.w);
         __syncthreads();
-        for (int i = threadIdx.x; i < C; i += blockDim.x) atomicAdd(&e[(long)b * C + i], s_e[i]);
+        for (int i = threadIdx.x; i < C; i += blockDim.x) e[((long)b * gridDim.x + blockIdx.x) * C + i] = s_e[i];   // part [b][block][C]
     }
 }
 
@@ -541,7 +541,8 @@ size_t fa_ws_floats(int B, int N, int C, int heads) {
     const long fwd = (long)B * NT * C * (2 + Ch);
     // + the partial rows of the window-weight gradients: <= max(1024, C/32 * B) workgroups x 32 channels x (49 taps + bias)
     const long wg_rows = (long)cdiv(C, 32) * B > 1024 ? (long)cdiv(C, 32) * B : 1024;
-    const long bwd = 2L * B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch + wg_rows * 32 * 50;
+    const long part = wg_rows * 32 * 50 > 1024L * B * C ? wg_rows * 32 * 50 : 1024L * B * C;       // ... or the e partial rows [B][<=1024][C]
+    const long bwd = 2L * B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch + part;
     return (size_t)(fwd > bwd ? fwd : bwd);
 }
 
@@ -685,10 +686,17 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     const bool want_wgrad = dw3 != nullptr;
     MDVIT_CHECK_ARG(want_wgrad ? (db3 && dw5 && db5 && dw7 && db7) : !(db3 || dw5 || db5 || dw7 || db7), MDVIT_E_SHAPE,
                     "factoratt_bwd: the six crpe gradient outputs must be all given or all NULL");
-    if (e) MDVIT_ZERO(e, sizeof(float) * (size_t)B * C, s);       // (the window-weight gradients are written, not accumulated)
     // 1: dU, e
     const int QC = C / 4;
-    hipLaunchKernelGGL(fa_bwd_prep_kernel, dim3(quad_grid((long)g.N * QC, QC, 512), B), dim3(256), sizeof(float) * C, s, dout, qkv, out, a, dU, e, g);
+    {
+        const int gx = quad_grid((long)g.N * QC, QC, 512);
+        float* e_part = ws_P + (long)B * NT * C * Ch;               // [B][gx][C] partial rows (the region is reused by the window-weight gradients below)
+        hipLaunchKernelGGL(fa_bwd_prep_kernel, dim3(gx, B), dim3(256), sizeof(float) * C, s, dout, qkv, out, a, dU, e ? e_part : nullptr, g);
+        if (e) {
+            const int rc = mdvit_reduce_partials_batched(e_part, B, gx, C, e, s);
+            if (rc != MDVIT_OK) return rc;
+        }
+    }
     // 2: dM = Q^T (scale * a * G)
     hipLaunchKernelGGL((fa_partial_kernel<false>), dim3(NT, C / CW, B), dim3(256), sizeof(float) * 2 * FA_T * CW, s,
                        qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, CW, NT);

@@ -43,6 +43,8 @@ int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream);
 // L2 (a reduction's atomic tail cost 30-100 us); a partial row per workgroup plus this ~5 us pass does not.
 // Row layout [out0 (n0) | out1 (n1)]; out1 may be NULL (then n1 entries are skipped).
 int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream);
+// `batches` independent reductions: part [batch][nblk][n] -> out [batch][n]
+int mdvit_reduce_partials_batched(const float* part, int batches, int nblk, int n, float* out, hipStream_t stream);
 constexpr int MDVIT_MAX_PARTIAL_ROWS = 2048;        // every partial-row reduction launches at most this many workgroups
 #define MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, n, what)                                                              \
     MDVIT_CHECK_ARG((ws) != nullptr && (ws_bytes) >= sizeof(float) * (size_t)(nblk) * (size_t)(n), MDVIT_E_WORKSPACE,    \
