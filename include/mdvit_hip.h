@@ -164,7 +164,10 @@ int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float
  * Decoders.py:196,320-329,336) ------------------------------------------------------------------ */
 int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C,
                        int32_t accumulate, void* stream);
-int mdvit_upsample_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+size_t mdvit_upsample_bwd_ws_bytes(int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C);
+/* adjoint, separable: dy [B,Ho,Wo,C] -> (width pass) ws [B,Ho,Wi,C] -> (height pass) dx [B,Hi,Wi,C] */
+int mdvit_upsample_bwd(const float* dy, float* dx, void* ws, size_t ws_bytes, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                       int32_t C, void* stream);
 
 /* ---- Domain Adapter: a = softmax_heads(W2 relu(W1 label + b1) + b2), [B,C] (mdvit.py:272-276,301-303).
  * Backward takes e[b,c] = a[b,c] * dL/da[b,c] (what mdvit_factoratt_bwd emits -- it needs no division by a):

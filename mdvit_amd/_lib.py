@@ -68,7 +68,7 @@ _SIGS = {
     "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_upsample_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
-    "mdvit_upsample_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_upsample_bwd": [vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_da_bwd": [vp] * 7 + [f32] + [vp] * 4 + [vp, C.c_size_t] + [i32] * 5 + [vp],
     "mdvit_factoratt_fwd": [vp] * 13 + [vp, C.c_size_t] + [i32] * 8 + [vp],
@@ -112,6 +112,8 @@ def load():
     lib.mdvit_gemm_ws_bytes.argtypes = [C.POINTER(GemmDesc)]
     lib.mdvit_bn_ws_bytes.restype = C.c_size_t
     lib.mdvit_bn_ws_bytes.argtypes = [i32, i32, i32]
+    lib.mdvit_upsample_bwd_ws_bytes.restype = C.c_size_t
+    lib.mdvit_upsample_bwd_ws_bytes.argtypes = [i32] * 6
     lib.mdvit_partials_ws_bytes.restype = C.c_size_t
     lib.mdvit_partials_ws_bytes.argtypes = [i32]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t

@@ -46,47 +46,44 @@ int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
 }
 
 namespace {
-// 32 columns x 8 row lanes per workgroup; lane r adds rows r, r+8, ... and the 8 lane sums are added 0..7
+// 8 columns x 32 row lanes per workgroup: lane r adds rows r, r+32, ... (4 loads in flight), the 32 lane sums are folded by a
+// fixed shuffle tree.  (Few outputs, up to ~1000 rows: the serial row walk, not bandwidth, sets the time.)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, long stride, int n0,
                                                               float* __restrict__ out0, int n1, float* __restrict__ out1, int accumulate) {
     const int n = n0 + n1;
-    __shared__ float s_sum[8][33];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + cl;
+    const int rl = threadIdx.x & 31, cl = threadIdx.x >> 5;      // a 32-lane half-wavefront per column
+    const int i = blockIdx.x * 8 + cl;
     part += (long)blockIdx.y * nblk * stride;        // batched mode (grid.y > 1): one reduction per batch, out0 [batch][n0]
     out0 += (long)blockIdx.y * n0;
     float s = 0.f;
     if (i < n) {
         int b = rl;
-        for (; b + 24 < nblk; b += 32) {
-            const float v0 = part[(long)b * stride + i], v1 = part[(long)(b + 8) * stride + i];
-            const float v2 = part[(long)(b + 16) * stride + i], v3 = part[(long)(b + 24) * stride + i];
+        for (; b + 96 < nblk; b += 128) {
+            const float v0 = part[(long)b * stride + i], v1 = part[(long)(b + 32) * stride + i];
+            const float v2 = part[(long)(b + 64) * stride + i], v3 = part[(long)(b + 96) * stride + i];
             s += v0; s += v1; s += v2; s += v3;
         }
-        for (; b < nblk; b += 8) s += part[(long)b * stride + i];
+        for (; b < nblk; b += 32) s += part[(long)b * stride + i];
     }
-    s_sum[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && i < n) {
-        float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_down(s, o, 32);
+    if (rl == 0 && i < n) {
         float* dst = i < n0 ? out0 + i : (out1 ? out1 + (i - n0) : nullptr);
-        if (dst) *dst = accumulate ? *dst + t : t;
+        if (dst) *dst = accumulate ? *dst + s : s;
     }
 }
 }  // namespace
 
 int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream) {
     if (n0 + n1 <= 0 || nblk <= 0) return MDVIT_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n0 + n1 + 31) / 32), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n0 + n1 + 7) / 8), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
 
 int mdvit_reduce_partials_batched(const float* part, int batches, int nblk, int n, float* out, hipStream_t stream) {
     if (n <= 0 || nblk <= 0 || batches <= 0) return MDVIT_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32, batches), dim3(256), 0, stream, part, nblk, (long)n, n, out, 0, (float*)nullptr, 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 7) / 8, batches), dim3(256), 0, stream, part, nblk, (long)n, n, out, 0, (float*)nullptr, 0);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

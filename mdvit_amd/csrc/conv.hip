@@ -469,44 +469,40 @@ __device__ __forceinline__ void out_range(int i, int in_size, int out_size, int&
     if (hi > out_size) hi = out_size;
 }
 
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
-                                                           int B, int Hi, int Wi, int Ho, int Wo, int C) {
-    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
-    const bool vec = (C & 3) == 0;
-    const int QC = vec ? C >> 2 : C;
-    const long total = (long)B * Hi * Wi * QC;
+// Separable adjoint (bilinear weights factor as wh * ww): pass W folds the output columns into the input columns
+// (tmp [B,Ho,Wi,C]), pass H folds the rows.  2*(2s+1) taps per result instead of (2s+1)^2 (s = scale: the peer heads
+// upsample 512-channel features x2/x4/x8), every tap load unconditional (weight 0 when it does not touch the pixel).
+template <bool ALONG_W>
+__global__ __launch_bounds__(256) void upsample_bwd_pass_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                long outer, int n_in, int n_out, long inner_q, int vec) {
+    // src [outer][n_out][inner], dst [outer][n_in][inner]   (ALONG_W: outer = B*Ho, inner = C;  else outer = B, inner = Wi*C)
+    const float sc = (float)n_in / (float)n_out;
+    const long total = outer * n_in * inner_q;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int q = (int)(e % QC);
-        long r = e / QC;
-        const int wi = (int)(r % Wi); r /= Wi;
-        const int hi = (int)(r % Hi);
-        const int b = (int)(r / Hi);
-        int olo, ohi, plo, phi;
-        out_range(hi, Hi, Ho, olo, ohi);
-        out_range(wi, Wi, Wo, plo, phi);
+        const long q = e % inner_q;
+        long r = e / inner_q;
+        const int i = (int)(r % n_in);
+        const long o = r / n_in;
+        int lo, hi;
+        out_range(i, n_in, n_out, lo, hi);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int oh = olo; oh < ohi; ++oh) {
-            int h0, h1; float lh;
-            bilin_src(oh, Hi, sh, h0, h1, lh);
-            const float wh = (h0 == hi ? 1.f - lh : 0.f) + (h1 == hi ? lh : 0.f);
-            if (wh == 0.f) continue;
-            for (int ow = plo; ow < phi; ++ow) {
-                int w0, w1; float lw;
-                bilin_src(ow, Wi, sw, w0, w1, lw);
-                const float ww = (w0 == wi ? 1.f - lw : 0.f) + (w1 == wi ? lw : 0.f);
-                if (ww == 0.f) continue;
-                const float cf = wh * ww;
-                const long off = (((long)b * Ho + oh) * Wo + ow) * C;
-                if (vec) {
-                    const float4 g = *reinterpret_cast<const float4*>(dy + off + q * 4);
-                    acc.x = fmaf(cf, g.x, acc.x); acc.y = fmaf(cf, g.y, acc.y); acc.z = fmaf(cf, g.z, acc.z); acc.w = fmaf(cf, g.w, acc.w);
-                } else {
-                    acc.x = fmaf(cf, dy[off + q], acc.x);
-                }
+        const long inner = vec ? inner_q * 4 : inner_q;
+        const float* base = src + o * n_out * inner + (vec ? q * 4 : q);
+#pragma unroll 4
+        for (int t = lo; t < hi; ++t) {
+            int i0, i1; float l;
+            bilin_src(t, n_in, sc, i0, i1, l);
+            const float wgt = (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+            if (vec) {
+                const float4 g = *reinterpret_cast<const float4*>(base + (long)t * inner);
+                acc.x = fmaf(wgt, g.x, acc.x); acc.y = fmaf(wgt, g.y, acc.y); acc.z = fmaf(wgt, g.z, acc.z); acc.w = fmaf(wgt, g.w, acc.w);
+            } else {
+                acc.x = fmaf(wgt, base[(long)t * inner], acc.x);
             }
         }
-        if (vec) *reinterpret_cast<float4*>(dx + (((long)b * Hi + hi) * Wi + wi) * C + q * 4) = acc;
-        else dx[(((long)b * Hi + hi) * Wi + wi) * C + q] = acc.x;
+        float* d = dst + (o * n_in + i) * inner + (vec ? q * 4 : q);
+        if (vec) *reinterpret_cast<float4*>(d) = acc;
+        else *d = acc.x;
     }
 }
 
@@ -625,10 +621,30 @@ extern "C" int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t H
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_upsample_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream) {
+extern "C" size_t mdvit_upsample_bwd_ws_bytes(int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C) {
+    if (B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return 0;
+    return sizeof(float) * (size_t)B * Ho * Wi * C;          // tmp [B,Ho,Wi,C] between the two passes
+}
+
+extern "C" int mdvit_upsample_bwd(const float* dy, float* dx, void* ws, size_t ws_bytes, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                  int32_t C, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, MDVIT_E_SHAPE, "upsample_bwd: bad shape");
-    const long total = (long)B * Hi * Wi * ((C & 3) == 0 ? C / 4 : C);
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Hi, Wi, Ho, Wo, C);
+    MDVIT_CHECK_ARG(ws != nullptr && ws_bytes >= mdvit_upsample_bwd_ws_bytes(B, Hi, Wi, Ho, Wo, C), MDVIT_E_WORKSPACE,
+                    "upsample_bwd: workspace too small (mdvit_upsample_bwd_ws_bytes)");
+    float* tmp = (float*)ws;
+    const int vec = (C & 3) == 0 && aligned16(dy) && aligned16(dx) && aligned16(tmp);
+    const long cq = vec ? C / 4 : C;
+    // pass W: dy [B*Ho][Wo][C] -> tmp [B*Ho][Wi][C]
+    {
+        const long total = (long)B * Ho * Wi * cq;
+        hipLaunchKernelGGL((upsample_bwd_pass_kernel<true>), dim3(ew_grid(total)), dim3(256), 0, s, dy, tmp, (long)B * Ho, Wi, Wo, cq, vec);
+    }
+    // pass H: tmp [B][Ho][Wi*C] -> dx [B][Hi][Wi*C]
+    {
+        const long total = (long)B * Hi * Wi * cq;
+        hipLaunchKernelGGL((upsample_bwd_pass_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, s, tmp, dx, (long)B, Hi, Ho, (long)Wi * cq, vec);
+    }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

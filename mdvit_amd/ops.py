@@ -846,7 +846,9 @@ class _Upsample(torch.autograd.Function):
         B, H, W_, Ho, Wo, Cn, has_base = ctx.meta
         g = _c(g)
         dx = _empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
-        call("mdvit_upsample_bwd", _p(g), _p(dx), B, H, W_, Ho, Wo, Cn, _stream())
+        wsb = _lib.load().mdvit_upsample_bwd_ws_bytes(B, H, W_, Ho, Wo, Cn)
+        ws = _empty((wsb // 4,), device=g.device, dtype=torch.float32)
+        call("mdvit_upsample_bwd", _p(g), _p(dx), _p(ws), wsb, B, H, W_, Ho, Wo, Cn, _stream())
         return dx, None, None, (g if has_base else None)
 
 
