@@ -13,6 +13,7 @@
 // All HBM/L2-bound VALU kernels: lanes run along channels (coalesced), token-axis reductions are
 // two-stage (tile partials in a workspace, then a combine) so every launch has >= hundreds of workgroups.
 #include "common.h"
+#include "conv_tile.h"
 
 namespace {
 
@@ -113,132 +114,6 @@ __global__ __launch_bounds__(256) void fa_combine_kernel(const float* __restrict
         float acc = 0.f;
         for (int t = 0; t < NT; ++t) acc += ws_P[(((long)b * NT + t) * g.C + c) * g.Ch + e];
         Mout[((long)b * g.C + c) * g.Ch + e] = acc;
-    }
-}
-
-// ---- LDS-tiled depthwise window convolution over the token image -----------------------------------
-// y[b,n,cy] = bias[ci] + sum_{i,j} w[ci][i][j] * x[b, n + (i-R, j-R), cx]      (FLIP: w[ci][WIN-1-i][WIN-1-j], no bias)
-// for the ncls channels of ONE window class (ci = class-local index).  Block = 8 x 16 token tile x 32 channels:
-// the tile plus halo sits in LDS ([row][col][channel], channel fastest -> conflict-free), thread (channel, row)
-// produces 16 outputs along w from WIN input rows held in registers (16*WIN FMAs per TW+WIN-1 LDS reads).
-constexpr int CT_TH = 8, CT_TW = 16, CT_CL = 32;
-
-// Stage an LHxLW token window x 32 channels into LDS ([position][channel]); zero outside the image / past `nch` channels.
-// 8 lanes x float4 cover one position, 32 positions per pass; ALL global loads of the window are issued before the
-// first LDS store (a load -> store loop would pay the HBM latency once per iteration).  x already points at the first
-// channel of the block; nch % 4 == 0.
-template <int LH, int LW>
-__device__ __forceinline__ void ct_stage_window(float* __restrict__ sx, const float* __restrict__ x, long ldx, long img,
-                                                int h0, int w0, int H, int W, int nch) {
-    constexpr int NP = LH * LW, PASSES = (NP + 31) / 32;
-    const int q4 = (threadIdx.x & 7) * 4, pl = threadIdx.x >> 3;
-    float4 v[PASSES];
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-        const int p = pl + 32 * i;
-        const int hh = h0 + p / LW, ww = w0 + p % LW;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < NP && hh >= 0 && hh < H && ww >= 0 && ww < W && q4 < nch)
-            v[i] = *reinterpret_cast<const float4*>(x + (img + (long)hh * W + ww) * ldx + q4);
-    }
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-        const int p = pl + 32 * i;
-        if (p < NP) *reinterpret_cast<float4*>(sx + p * CT_CL + q4) = v[i];
-    }
-}
-
-template <int WIN, bool FLIP>
-__global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restrict__ x, long ldx, int xoff,
-                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ y, long ldy, int yoff,
-                                                           int H, int W, int ncls, int tiles_w) {
-    constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
-    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
-    __shared__ float sw[CT_CL * WIN * WIN];
-    const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
-    const int th0 = (blockIdx.x / tiles_w) * CT_TH, tw0 = (blockIdx.x % tiles_w) * CT_TW;
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const long img = (long)b * H * W;
-    for (int i = threadIdx.x; i < CT_CL * WIN * WIN; i += 256) {
-        const int c = i / (WIN * WIN), t = i % (WIN * WIN);
-        sw[i] = (c0 + c < ncls) ? w[(long)(c0 + c) * WIN * WIN + (FLIP ? WIN * WIN - 1 - t : t)] : 0.f;
-    }
-    ct_stage_window<LH, LW>(sx, x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
-    __syncthreads();
-    const int h = th0 + rl;
-    if (c0 + cl >= ncls || h >= H) return;
-    float acc[CT_TW];
-    const float b0 = (!FLIP && bias) ? bias[c0 + cl] : 0.f;
-#pragma unroll
-    for (int t = 0; t < CT_TW; ++t) acc[t] = b0;
-#pragma unroll
-    for (int i = 0; i < WIN; ++i) {
-        float row[LW], wr[WIN];
-#pragma unroll
-        for (int t = 0; t < LW; ++t) row[t] = sx[((rl + i) * LW + t) * CT_CL + cl];
-#pragma unroll
-        for (int j = 0; j < WIN; ++j) wr[j] = sw[cl * WIN * WIN + i * WIN + j];
-#pragma unroll
-        for (int t = 0; t < CT_TW; ++t)
-#pragma unroll
-            for (int j = 0; j < WIN; ++j) acc[t] = fmaf(wr[j], row[t + j], acc[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < CT_TW; ++t)
-        if (tw0 + t < W) y[(img + (long)h * W + tw0 + t) * ldy + yoff + c0 + cl] = acc[t];
-}
-
-// dw[ci][i][j] = sum_tokens g[n,cg] * x[n + (i-R, j-R), cx];  db[ci] = sum g.   Thread (channel, window row i)
-// slides along w with the x row in registers; every (channel, tap) of the block's 32 channels is owned by one thread,
-// which writes its partial into the block's row of `part` ([y][z*x][32*(WIN*WIN+1)]); mdvit_reduce_partials adds the
-// rows in a fixed order (deterministic; ~1000 same-address float atomics per tap cost more than the whole kernel).
-template <int WIN>
-__global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __restrict__ g, long ldg, int goff,
-                                                                 const float* __restrict__ x, long ldx, int xoff,
-                                                                 float* __restrict__ part,
-                                                                 int H, int W, int ncls, int tiles_w, int tiles_total, int tiles_per_block) {
-    constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
-    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
-    __shared__ __attribute__((aligned(16))) float sg[CT_TH * CT_TW * CT_CL];
-    const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;          // rl = window row i (threads with rl >= WIN only help loading)
-    const long img = (long)b * H * W;
-    const bool chan_ok = c0 + cl < ncls;
-    float acc[WIN];
-    float accb = 0.f;
-#pragma unroll
-    for (int j = 0; j < WIN; ++j) acc[j] = 0.f;
-    const int t_beg = blockIdx.x * tiles_per_block, t_end = min(tiles_total, t_beg + tiles_per_block);
-    for (int tile = t_beg; tile < t_end; ++tile) {
-        const int th0 = (tile / tiles_w) * CT_TH, tw0 = (tile % tiles_w) * CT_TW;
-        ct_stage_window<LH, LW>(sx, x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
-        ct_stage_window<CT_TH, CT_TW>(sg, g + goff + c0, ldg, img, th0, tw0, H, W, ncls - c0);
-        __syncthreads();
-        if (rl < WIN && chan_ok) {
-#pragma unroll 2
-            for (int h = 0; h < CT_TH; ++h) {
-                float row[LW], gr[CT_TW];
-#pragma unroll
-                for (int t = 0; t < LW; ++t) row[t] = sx[((h + rl) * LW + t) * CT_CL + cl];
-#pragma unroll
-                for (int t = 0; t < CT_TW; ++t) gr[t] = sg[(h * CT_TW + t) * CT_CL + cl];
-#pragma unroll
-                for (int t = 0; t < CT_TW; ++t) {
-                    if (rl == 0) accb += gr[t];
-#pragma unroll
-                    for (int j = 0; j < WIN; ++j) acc[j] = fmaf(gr[t], row[t + j], acc[j]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    constexpr int ROW = CT_CL * (WIN * WIN + 1);
-    float* prow = part + ((long)blockIdx.y * gridDim.z * gridDim.x + (long)blockIdx.z * gridDim.x + blockIdx.x) * ROW + cl * (WIN * WIN + 1);
-    if (rl < WIN) {              // channels past ncls hold zeros
-#pragma unroll
-        for (int j = 0; j < WIN; ++j) prow[rl * WIN + j] = acc[j];
-        if (rl == 0) prow[WIN * WIN] = accb;
     }
 }
 
@@ -557,65 +432,6 @@ int quad_grid(long work_quads, int QC, int max_blocks) {
     return (int)((want + gmul - 1) / gmul * gmul);
 }
 
-template <int WIN, bool FLIP>
-void launch_conv_tile(const float* x, long ldx, int xoff, const float* w, const float* bias, float* y, long ldy, int yoff,
-                      const FaGeom& g, int ncls, hipStream_t s) {
-    if (ncls <= 0) return;
-    const int tiles_w = cdiv(g.W, CT_TW), tiles_h = cdiv(g.H, CT_TH);
-    hipLaunchKernelGGL((fa_conv_tile_kernel<WIN, FLIP>), dim3(tiles_w * tiles_h, cdiv(ncls, CT_CL), g.B), dim3(256), 0, s,
-                       x, ldx, xoff, w, bias, y, ldy, yoff, g.H, g.W, ncls, tiles_w);
-}
-
-// fixed-order sum of the partial rows of one 32-channel block: 32 columns x 8 row lanes per workgroup
-template <int WIN>
-__global__ __launch_bounds__(256) void fa_conv_wgrad_finish_kernel(const float* __restrict__ part, int nrows, float* __restrict__ dw,
-                                                                   float* __restrict__ db, int ncls) {
-    constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
-    __shared__ float s_sum[8][33];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + cl;
-    const float* base = part + (long)blockIdx.y * nrows * ROW;
-    float sacc = 0.f;
-    if (i < ROW)
-        for (int b = rl; b < nrows; b += 8) sacc += base[(long)b * ROW + i];
-    s_sum[rl][cl] = sacc;
-    __syncthreads();
-    if (rl == 0 && i < ROW) {
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
-        const int c = blockIdx.y * CT_CL + i / T, tap = i % T;
-        if (c < ncls) {
-            if (tap < WIN * WIN) dw[(long)c * WIN * WIN + tap] = t;
-            else db[c] = t;
-        }
-    }
-}
-
-// tiles per block: keep >= ~512 blocks while halving the number of partial rows
-void conv_wgrad_plan(const FaGeom& g, int ncls, int& tpb, long& nblk) {
-    const int tiles = cdiv(g.W, CT_TW) * cdiv(g.H, CT_TH);
-    tpb = 1;
-    while (tpb < tiles && (long)cdiv(tiles, tpb * 2) * cdiv(ncls, CT_CL) * g.B >= 512) tpb *= 2;
-    nblk = (long)cdiv(tiles, tpb) * cdiv(ncls, CT_CL) * g.B;
-}
-
-template <int WIN>
-int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x, long ldx, int xoff, float* dw, float* db, float* part,
-                           const FaGeom& g, int ncls, hipStream_t s) {
-    if (ncls <= 0) return MDVIT_OK;
-    const int tiles_w = cdiv(g.W, CT_TW), tiles_h = cdiv(g.H, CT_TH), tiles = tiles_w * tiles_h;
-    int tpb; long nblk;
-    conv_wgrad_plan(g, ncls, tpb, nblk);
-    const int gx = cdiv(tiles, tpb), gy = cdiv(ncls, CT_CL);
-    hipLaunchKernelGGL((fa_conv_tile_wgrad_kernel<WIN>), dim3(gx, gy, g.B), dim3(256), 0, s,
-                       gsrc, ldg, goff, x, ldx, xoff, part, g.H, g.W, ncls, tiles_w, tiles, tpb);
-    // second stage, per 32-channel block y: rows [y][gx*B] of 32*(WIN^2+1) floats -> dw [c][WIN^2], db [c]
-    constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
-    hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<WIN>), dim3(cdiv(ROW, 32), gy), dim3(256), 0, s, part, gx * g.B, dw, db, ncls);
-    return MDVIT_OK;
-}
-
 }  // namespace
 
 extern "C" size_t mdvit_factoratt_ws_bytes(int32_t B, int32_t N, int32_t C, int32_t heads) {
@@ -642,9 +458,10 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     MDVIT_CHECK_ARG(C <= 512, MDVIT_E_SHAPE, "factoratt_fwd: C=%d > 512 not built", C);
     // U = dwconv_win(v) + bias, one tiled launch per window class (channels [0,s3*Ch) | [..) | [..))
     const int Ch = g.Ch, c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
-    launch_conv_tile<3, false>(qkv, 3L * C, 2 * C, w3, b3, U, (long)C, 0, g, s3 * Ch, s);
-    launch_conv_tile<5, false>(qkv, 3L * C, 2 * C + c5, w5, b5, U, (long)C, c5, g, s5 * Ch, s);
-    launch_conv_tile<7, false>(qkv, 3L * C, 2 * C + c7, w7, b7, U, (long)C, c7, g, s7 * Ch, s);
+    const CtGeom cg{B, g.H, g.W};
+    launch_conv_tile<3, false>(qkv, 3L * C, 2 * C, w3, b3, U, (long)C, 0, cg, s3 * Ch, s);
+    launch_conv_tile<5, false>(qkv, 3L * C, 2 * C + c5, w5, b5, U, (long)C, c5, cg, s5 * Ch, s);
+    launch_conv_tile<7, false>(qkv, 3L * C, 2 * C + c7, w7, b7, U, (long)C, c7, cg, s7 * Ch, s);
     {
         const int TLN = max(1, 256 / C), block = TLN * C;
         int tpb = TLN * 8;
@@ -704,16 +521,17 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
                        (const float*)nullptr, (const float*)nullptr, ws_P, (float*)nullptr, (float*)nullptr, dM, g, NT);
     // 3: crpe weight gradients
     const int c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
+    const CtGeom cg{B, g.H, g.W};
     if (want_wgrad) {
         float* wg_part = ws_P + (long)B * NT * C * Ch;          // partial rows, reduced by the finish kernel of each class
-        launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, wg_part, g, s3 * Ch, s);
-        launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, wg_part, g, s5 * Ch, s);
-        launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, wg_part, g, s7 * Ch, s);
+        launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, wg_part, cg, s3 * Ch, s);
+        launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, wg_part, cg, s5 * Ch, s);
+        launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, wg_part, cg, s7 * Ch, s);
     }
     // conv^T(dU) = correlation with the flipped window
-    launch_conv_tile<3, true>(dU, (long)C, 0, w3, nullptr, dVc, (long)C, 0, g, s3 * Ch, s);
-    launch_conv_tile<5, true>(dU, (long)C, c5, w5, nullptr, dVc, (long)C, c5, g, s5 * Ch, s);
-    launch_conv_tile<7, true>(dU, (long)C, c7, w7, nullptr, dVc, (long)C, c7, g, s7 * Ch, s);
+    launch_conv_tile<3, true>(dU, (long)C, 0, w3, nullptr, dVc, (long)C, 0, cg, s3 * Ch, s);
+    launch_conv_tile<5, true>(dU, (long)C, c5, w5, nullptr, dVc, (long)C, c5, cg, s5 * Ch, s);
+    launch_conv_tile<7, true>(dU, (long)C, c7, w7, nullptr, dVc, (long)C, c7, cg, s7 * Ch, s);
     // 4, 5
     hipLaunchKernelGGL(fa_bwd_mid_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, dM, Mmat, tcol, B * C, Ch);
     const int GW = Ch < 32 ? 32 : Ch;

@@ -1,6 +1,7 @@
 // 3x3 convolutions and bilinear resampling on NHWC fp32 (HBM-bound; lanes run along channels so
 // every global access is a contiguous 16 B/lane float4, halo re-reads are served by L1/L2).
 #include "common.h"
+#include "conv_tile.h"
 
 namespace {
 
@@ -516,6 +517,11 @@ extern "C" int mdvit_dwconv3x3_fwd(const float* x, const float* w, const float* 
     MDVIT_CHECK_ARG(stride == 1 || stride == 2, MDVIT_E_SHAPE, "dwconv3x3_fwd: stride must be 1 or 2");
     MDVIT_CHECK_ARG(!(add_input && stride != 1), MDVIT_E_SHAPE, "dwconv3x3_fwd: add_input needs stride 1");
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    if (stride == 1) {          // LDS-tiled path shared with the attention's window convolutions
+        launch_conv_tile<3, false>(x, (long)C, 0, w, bias, y, (long)C, 0, CtGeom{B, Hi, Wi}, C, (hipStream_t)stream, add_input);
+        MDVIT_LAUNCH_CHECK();
+        return MDVIT_OK;
+    }
     const long total = (long)B * Ho * Wo * C / 4;
     hipLaunchKernelGGL(dwconv3x3_fwd_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 9 * C, (hipStream_t)stream,
                        x, w, bias, y, B, Hi, Wi, C, stride, add_input);
@@ -529,6 +535,19 @@ extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float*
     MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "dwconv3x3_bwd: bad shape B=%d H=%d W=%d C=%d", B, Hi, Wi, C);
     MDVIT_CHECK_ARG(stride == 1 || stride == 2, MDVIT_E_SHAPE, "dwconv3x3_bwd: stride must be 1 or 2");
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    if (stride == 1) {
+        const CtGeom cg{B, Hi, Wi};
+        if (dx) launch_conv_tile<3, true>(dy, (long)C, 0, w, nullptr, dx, (long)C, 0, cg, C, s, add_input);
+        if (dw) {
+            int tpb; long nblk;
+            conv_wgrad_plan(cg, C, tpb, nblk);
+            MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, CT_CL * 10, "dwconv3x3_bwd");
+            const int rc = launch_conv_tile_wgrad<3>(dy, (long)C, 0, x, (long)C, 0, dw, dbias, (float*)ws, cg, C, s);
+            if (rc != MDVIT_OK) return rc;
+        }
+        MDVIT_LAUNCH_CHECK();
+        return MDVIT_OK;
+    }
     if (dx) {
         const long total = (long)B * Hi * Wi * C / 4;
         hipLaunchKernelGGL(dwconv3x3_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 9 * C, s, dy, w, dx, B, Hi, Wi, C, stride, add_input);
