@@ -122,14 +122,15 @@ int mdvit_dwconv3x3_fwd(const float* x, const float* w, const float* bias, float
                         int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream);
 int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
                         void* ws /* n = 10C; unused if dw == NULL */, size_t ws_bytes,
-                        int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream);
+                        int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input,
+                        int32_t accumulate /* dw, dbias += (gradient buckets) */, void* stream);
 /* gconv2: Conv2d(2C, C, 3, groups=C, bias=False) applied to cat(skip, up) WITHOUT materialising the
  * concat (Decoders.py:30-38,198-199).  w is [C,2,3,3]; output channel g reads concat channels 2g, 2g+1. */
 int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const float* w, float* y,
                          int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const float* up, const float* w,
                          float* dskip, float* dup, float* dw, void* ws /* n = 18C; unused if dw == NULL */, size_t ws_bytes,
-                         int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+                         int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate /* dw += */, void* stream);
 /* Dense 3x3 (pad 1) as im2col + GEMM: col is [B*Ho*Wo, Cin*9], column order (cin,kh,kw) == weight.view(Cout,-1)
  * (stem.1 mpvit.py:104-111, bridge mdvit.py:557-564). */
 int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream);
@@ -137,7 +138,7 @@ int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t
 /* stem.0: NCHW image [B,Cin,H,W] -> NHWC [B,H/2,W/2,Cout], 3x3 s2 p1, no bias (mdvit.py:509-517). */
 int mdvit_stemconv_fwd(const float* img, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, void* ws /* n = 27*Cout */, size_t ws_bytes,
-                         int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
+                         int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate /* dw += */, void* stream);
 
 /* ---- BatchNorm2d (train: batch stats, biased var; running stats momentum, unbiased var) + activation
  * on NHWC [M,C]  (mpvit.py:112-123, mdvit.py:99-122,559-563, Decoders.py:39-62,304-306).
@@ -198,6 +199,12 @@ int mdvit_factoratt_bwd(const float* dout, const float* qkv, const float* out, c
                         float* dqkv, float* e, float* dw3, float* db3, float* dw5, float* db5, float* dw7, float* db7,
                         void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
                         int32_t s3, int32_t s5, int32_t s7, void* stream);
+/* The six window-weight gradients of the preceding mdvit_factoratt_bwd call (which was given NULL for them): they read
+ * only dU (left in the SAME ws) and v, so the caller may issue them on another stream -- ordered after that backward --
+ * and let them overlap the rest of the data-gradient chain.  accumulate != 0: add into dw/db (gradient buckets). */
+int mdvit_factoratt_wgrad(const float* qkv, void* ws, size_t ws_bytes, float* dw3, float* db3, float* dw5, float* db5,
+                          float* dw7, float* db7, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
+                          int32_t s3, int32_t s5, int32_t s7, int32_t accumulate, void* stream);
 
 /* ---- step losses on logits (multi_train_MDViT.py:147-169, Utils/losses.py:8-16, nn.BCELoss) ---
  * losses[0] = BCE(s(out),y)+Dice(s(out),y); [1] = same for aux; [2] = Dice(s(aux), s(out)).  aux may be NULL.

@@ -56,13 +56,13 @@ _SIGS = {
     "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, vp],
     "mdvit_dwconv3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_gconv2_3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "mdvit_gconv2_3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, vp],
+    "mdvit_gconv2_3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp],
     "mdvit_im2col3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_col2im3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    "mdvit_stemconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp],
+    "mdvit_stemconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_bn_stats": [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
     "mdvit_bn_eval_prep": [vp, vp, vp, vp, i32, f32, vp],
     "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
@@ -72,6 +72,7 @@ _SIGS = {
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_da_bwd": [vp] * 7 + [f32] + [vp] * 4 + [vp, C.c_size_t] + [i32] * 5 + [vp],
     "mdvit_factoratt_fwd": [vp] * 13 + [vp, C.c_size_t] + [i32] * 8 + [vp],
+    "mdvit_factoratt_wgrad": [vp, vp, C.c_size_t] + [vp] * 6 + [i32] * 9 + [vp],
     "mdvit_factoratt_bwd": [vp] * 22 + [vp, C.c_size_t] + [i32] * 8 + [vp],
     "mdvit_seg_losses_fwd": [vp, vp, vp, vp, vp, i64, vp],
     "mdvit_seg_losses_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, vp],

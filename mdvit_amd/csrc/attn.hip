@@ -553,6 +553,29 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     return MDVIT_OK;
 }
 
+/* The window-weight gradients of a preceding mdvit_factoratt_bwd call (same geometry, same `ws`, given dw3 == NULL there):
+ * they only read dU (left in ws) and v, so they may run on ANOTHER stream once the backward's kernels are ordered before
+ * it; accumulate != 0 adds into dw/db (gradient buckets). */
+extern "C" int mdvit_factoratt_wgrad(const float* qkv, void* ws, size_t ws_bytes, float* dw3, float* db3, float* dw5, float* db5,
+                                     float* dw7, float* db7, int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads,
+                                     int32_t s3, int32_t s5, int32_t s7, int32_t accumulate, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    FaGeom g;
+    MDVIT_CHECK_ARG(make_geom(g, B, H, W, C, heads, s3, s5, s7), MDVIT_E_SHAPE, "factoratt_wgrad: bad geometry");
+    MDVIT_CHECK_ARG(ws_bytes >= fa_ws_floats(B, g.N, C, heads) * sizeof(float), MDVIT_E_WORKSPACE, "factoratt_wgrad: workspace too small");
+    MDVIT_CHECK_ARG(dw3 && db3 && dw5 && db5 && dw7 && db7, MDVIT_E_SHAPE, "factoratt_wgrad: all six outputs are required");
+    const int Ch = g.Ch, NT = cdiv(g.N, FA_T);
+    const float* dU = (const float*)ws;
+    float* wg_part = (float*)ws + 2L * B * g.N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch;
+    const int c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
+    const CtGeom cg{B, g.H, g.W};
+    launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, wg_part, cg, s3 * Ch, s, accumulate);
+    launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, wg_part, cg, s5 * Ch, s, accumulate);
+    launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, wg_part, cg, s7 * Ch, s, accumulate);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
 extern "C" int mdvit_da_fwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, float* a,
                             int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream) {
     MDVIT_CHECK_ARG(B > 0 && D > 0 && hid > 0 && C > 0 && heads > 0 && C % heads == 0, MDVIT_E_SHAPE, "da_fwd: bad shape");

@@ -530,7 +530,8 @@ extern "C" int mdvit_dwconv3x3_fwd(const float* x, const float* w, const float* 
 }
 
 extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
-                                   int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, void* stream) {
+                                   int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t stride, int32_t add_input, int32_t accumulate,
+                                   void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "dwconv3x3_bwd: bad shape B=%d H=%d W=%d C=%d", B, Hi, Wi, C);
     MDVIT_CHECK_ARG(stride == 1 || stride == 2, MDVIT_E_SHAPE, "dwconv3x3_bwd: stride must be 1 or 2");
@@ -542,7 +543,7 @@ extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float*
             int tpb; long nblk;
             conv_wgrad_plan(cg, C, tpb, nblk);
             MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, CT_CL * 10, "dwconv3x3_bwd");
-            const int rc = launch_conv_tile_wgrad<3>(dy, (long)C, 0, x, (long)C, 0, dw, dbias, (float*)ws, cg, C, s);
+            const int rc = launch_conv_tile_wgrad<3>(dy, (long)C, 0, x, (long)C, 0, dw, dbias, (float*)ws, cg, C, s, accumulate);
             if (rc != MDVIT_OK) return rc;
         }
         MDVIT_LAUNCH_CHECK();
@@ -558,7 +559,7 @@ extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float*
         const int nblk = cdiv(ntok, tpb);
         MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 10 * C, "dwconv3x3_bwd");
         hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(nblk), dim3(256), sizeof(float) * 10 * C, s, dy, x, (float*)ws, B, Hi, Wi, C, stride, tpb);
-        const int rc = mdvit_reduce_partials((const float*)ws, nblk, 10L * C, 9 * C, dw, C, dbias, 0, s);
+        const int rc = mdvit_reduce_partials((const float*)ws, nblk, 10L * C, 9 * C, dw, C, dbias, accumulate, s);
         if (rc != MDVIT_OK) return rc;
     }
     MDVIT_LAUNCH_CHECK();
@@ -574,18 +575,19 @@ extern "C" int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const fl
 }
 
 extern "C" int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const float* up, const float* w, float* dskip, float* dup, float* dw,
-                                    void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+                                    void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "gconv2_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     const long total = (long)B * H * W * C / 2;
-    hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
+    MDVIT_CHECK_ARG((dskip == nullptr) == (dup == nullptr), MDVIT_E_SHAPE, "gconv2_bwd: dskip and dup go together");
+    if (dskip) hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
     if (dw) {
         const long ntok = (long)B * H * W;
         int tpb = (int)max(64L, (ntok + 1023) / 1024);
         const int nblk = cdiv(ntok, tpb);
         MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 18 * C, "gconv2_bwd");
         hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(nblk), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, (float*)ws, B, H, W, C, tpb);
-        const int rc = mdvit_reduce_partials((const float*)ws, nblk, 18L * C, 18 * C, dw, 0, nullptr, 0, s);
+        const int rc = mdvit_reduce_partials((const float*)ws, nblk, 18L * C, 18 * C, dw, 0, nullptr, accumulate, s);
         if (rc != MDVIT_OK) return rc;
     }
     MDVIT_LAUNCH_CHECK();
@@ -618,7 +620,7 @@ extern "C" int mdvit_stemconv_fwd(const float* img, const float* w, float* y, in
 }
 
 extern "C" int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W,
-                                    int32_t Cin, int32_t Cout, void* stream) {
+                                    int32_t Cin, int32_t Cout, int32_t accumulate, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(Cin == 3, MDVIT_E_SHAPE, "stemconv_wgrad: only in_chans == 3 is built (got %d)", Cin);
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout <= 256, MDVIT_E_SHAPE, "stemconv_wgrad: bad shape");
@@ -629,7 +631,7 @@ extern "C" int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw
     MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 27 * Cout, "stemconv_wgrad");
     hipLaunchKernelGGL((stemconv_wgrad_kernel<3>), dim3(nblk), dim3(256), sizeof(float) * 27 * Cout, s, img, dy, (float*)ws, B, H, W, Cout, ppb);
     MDVIT_LAUNCH_CHECK();
-    return mdvit_reduce_partials((const float*)ws, nblk, 27L * Cout, 27 * Cout, dw, 0, nullptr, 0, s);
+    return mdvit_reduce_partials((const float*)ws, nblk, 27L * Cout, 27 * Cout, dw, 0, nullptr, accumulate, s);
 }
 
 extern "C" int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, int32_t accumulate, void* stream) {

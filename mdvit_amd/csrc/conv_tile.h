@@ -150,7 +150,7 @@ void launch_conv_tile(const float* x, long ldx, int xoff, const float* w, const 
 // fixed-order sum of the partial rows of one 32-channel block: 32 columns x 8 row lanes per workgroup
 template <int WIN>
 __global__ __launch_bounds__(256) void fa_conv_wgrad_finish_kernel(const float* __restrict__ part, int nrows, float* __restrict__ dw,
-                                                                   float* __restrict__ db, int ncls) {
+                                                                   float* __restrict__ db, int ncls, int accumulate) {
     constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
     __shared__ float s_sum[8][33];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void fa_conv_wgrad_finish_kernel(const float* 
         for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
         const int c = blockIdx.y * CT_CL + i / T, tap = i % T;
         if (c < ncls) {
-            if (tap < WIN * WIN) dw[(long)c * WIN * WIN + tap] = t;
-            else if (db) db[c] = t;
+            float* dst = tap < WIN * WIN ? dw + (long)c * WIN * WIN + tap : (db ? db + c : nullptr);
+            if (dst) *dst = accumulate ? *dst + t : t;
         }
     }
 }
@@ -183,7 +183,7 @@ void conv_wgrad_plan(const CtGeom& g, int ncls, int& tpb, long& nblk) {
 
 template <int WIN>
 int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x, long ldx, int xoff, float* dw, float* db, float* part,
-                           const CtGeom& g, int ncls, hipStream_t s) {
+                           const CtGeom& g, int ncls, hipStream_t s, int accumulate = 0) {
     if (ncls <= 0) return MDVIT_OK;
     const int tiles_w = cdiv(g.W, CT_TW), tiles_h = cdiv(g.H, CT_TH), tiles = tiles_w * tiles_h;
     int tpb; long nblk;
@@ -193,7 +193,7 @@ int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x
                        gsrc, ldg, goff, x, ldx, xoff, part, g.H, g.W, ncls, tiles_w, tiles, tpb);
     // second stage, per 32-channel block y: rows [y][gx*B] of 32*(WIN^2+1) floats -> dw [c][WIN^2], db [c]
     constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
-    hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<WIN>), dim3(cdiv(ROW, 32), gy), dim3(256), 0, s, part, gx * g.B, dw, db, ncls);
+    hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<WIN>), dim3(cdiv(ROW, 32), gy), dim3(256), 0, s, part, gx * g.B, dw, db, ncls, accumulate);
     return MDVIT_OK;
 }
 

@@ -591,6 +591,7 @@ class _DwConv3x3(torch.autograd.Function):
         call("mdvit_dwconv3x3_fwd", _p(x), _p(w), _p(bias), _p(y), B, H, W_, Cn, stride, int(add_input), _stream())
         ctx.save_for_backward(x, w)
         ctx.meta = (stride, add_input, bias is not None)
+        ctx.bias_ref = bias if (bias is not None and bias.grad_fn is None) else None
         return y
 
     @staticmethod
@@ -604,11 +605,20 @@ class _DwConv3x3(torch.autograd.Function):
         dx = _empty_like(x) if ctx.needs_input_grad[0] else None
         dw = db = None
         if dx is not None:
-            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), None, None, None, 0, B, H, W_, Cn, stride, int(add_input), _stream())
+            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), _p(dx), None, None, None, 0, B, H, W_, Cn, stride, int(add_input), 0, _stream())
         if not _dgrad_only:
-            dw, db = _flat_like(w, (Cn,) if has_b else None)
-            wsp, wsb, _keep = _partials_ws(10 * Cn, x.device)
-            call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), None, _p(dw), _p(db), wsp, wsb, B, H, W_, Cn, stride, int(add_input), _stream())
+            sw = _sink_of(w) if _side_stream is not None else None
+            sb = _sink_of(ctx.bias_ref) if (has_b and sw is not None) else None
+            if sw is not None and (not has_b or sb is not None):
+                # weight gradient on the side stream, accumulated straight into the gradient buckets
+                with _on_side(g, x) as _:
+                    wsp, wsb, keep = _partials_ws(10 * Cn, x.device)
+                    _side_keepalive.append(keep)
+                    call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), None, _p(sw), _p(sb), wsp, wsb, B, H, W_, Cn, stride, int(add_input), 1, _stream())
+            else:
+                dw, db = _flat_like(w, (Cn,) if has_b else None)
+                wsp, wsb, _keep = _partials_ws(10 * Cn, x.device)
+                call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), None, _p(dw), _p(db), wsp, wsb, B, H, W_, Cn, stride, int(add_input), 0, _stream())
         return dx, dw, db, None, None
 
 
@@ -634,9 +644,16 @@ class _GConv2(torch.autograd.Function):
         skip, up, w = ctx.saved_tensors
         g = _c(g)
         B, H, W_, Cn = skip.shape
-        dskip, dup, dw = _empty_like(skip), _empty_like(up), (None if _dgrad_only else _empty_like(w))
+        dskip, dup = _empty_like(skip), _empty_like(up)
+        sw = _sink_of(w) if (_side_stream is not None and not _dgrad_only) else None
+        dw = None if (_dgrad_only or sw is not None) else _empty_like(w)
         wsp, wsb, _keep = _partials_ws(18 * Cn, g.device) if dw is not None else (None, 0, None)
-        call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), _p(dskip), _p(dup), _p(dw), wsp, wsb, B, H, W_, Cn, _stream())
+        call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), _p(dskip), _p(dup), _p(dw), wsp, wsb, B, H, W_, Cn, 0, _stream())
+        if sw is not None:      # weight gradient on the side stream, into the gradient bucket
+            with _on_side(g, skip, up):
+                wsp, wsb, keep = _partials_ws(18 * Cn, g.device)
+                _side_keepalive.append(keep)
+                call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), None, None, _p(sw), wsp, wsb, B, H, W_, Cn, 1, _stream())
         return dskip, dup, dw
 
 
@@ -702,9 +719,16 @@ class _StemConv(torch.autograd.Function):
             return None, None
         g = _c(g)
         B, Cin, H, W_ = img.shape
+        sw = _sink_of(w) if _side_stream is not None else None
+        if sw is not None:
+            with _on_side(g, img):
+                wsp, wsb, keep = _partials_ws(27 * w.shape[0], g.device)
+                _side_keepalive.append(keep)
+                call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(sw), wsp, wsb, B, H, W_, Cin, w.shape[0], 1, _stream())
+            return None, None
         dw = _empty_like(w)
         wsp, wsb, _keep = _partials_ws(27 * w.shape[0], g.device)
-        call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(dw), wsp, wsb, B, H, W_, Cin, w.shape[0], _stream())
+        call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(dw), wsp, wsb, B, H, W_, Cin, w.shape[0], 0, _stream())
         return None, dw
 
 
@@ -941,7 +965,10 @@ class _FactorAtt(torch.autograd.Function):
         Cn = C3 // 3
         dev = qkv.device
         dqkv = _empty_like(qkv)
-        if _dgrad_only:
+        crpe = (w3, b3, w5, b5, w7, b7)
+        sinks = [_sink_of(t) for t in crpe] if (not _dgrad_only and _side_stream is not None) else [None] * 6
+        deferred = all(t is not None for t in sinks)        # window-weight gradients on the side stream, straight into the buckets
+        if _dgrad_only or deferred:
             e = _empty((B, Cn), device=dev, dtype=torch.float32) if a is not None else None
             dws = [None] * 6
         else:
@@ -951,6 +978,10 @@ class _FactorAtt(torch.autograd.Function):
         call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(out), _p(U), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
              _p(Mmat), _p(dqkv), _p(e), *[_p(t) for t in dws], _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2],
              _stream())
+        if deferred:
+            with _on_side(ws, qkv):
+                call("mdvit_factoratt_wgrad", _p(qkv), _p(ws), wsb, *[_p(t) for t in sinks], B, H, W_, Cn, heads,
+                     splits[0], splits[1], splits[2], 1, _stream())
         dW1 = db1 = dW2 = db2 = None
         if a is not None:
             hid = W1.shape[0]
