@@ -103,8 +103,8 @@ def main():
         domains, flop_per_img = (0,), 137.7e9
     broadcast_parameters(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True, capturable=args.graph)
-    if world == 1 and not args.no_side_stream:
-        ops.enable_side_stream(True)      # wgrad kernels overlap the dgrad chain (DP ranks keep in-place hooks for the all-reduce overlap)
+    if not args.no_side_stream:
+        ops.enable_side_stream(True)      # wgrad kernels overlap the dgrad chain and add straight into the gradient buckets
     accum = GradAccumulator(model.parameters())       # fused accumulation; overlapped bucketed all-reduce when world > 1
     accum.attach_sinks()                              # wgrad GEMMs add straight into the gradient buckets
     # a small pool of distinct synthetic steps, resident in HBM before timing

@@ -109,10 +109,10 @@ class GradAccumulator:
     """Gradient accumulation over the 4 domains x 2 sweeps of one step with a handful of kernels.
 
     autograd's AccumulateGrad issues one small add per parameter per backward() (432 x 7 per step).  Here every
-    sweep but the last runs with p.grad = None, and its fresh gradients are folded into flat buckets by ONE
-    multi-tensor add; for the last sweep p.grad is re-pointed at the bucket views so that (a) autograd adds the
-    last contribution in place and (b) with world_size > 1 the post-accumulate hooks launch each bucket's
-    all-reduce (RCCL) as soon as it is complete, overlapped with the rest of the backward sweep."""
+    sweep runs with p.grad = None and its fresh gradients are folded into flat buckets by ONE multi-tensor add (most
+    weight gradients never reach autograd: the wgrad kernels add them into the buckets directly, see attach_sinks);
+    after the last sweep, with world_size > 1, the buckets are all-reduced (RCCL) and averaged.
+    (GradBucketReducer above is the hook-driven variant that overlaps the all-reduce with a plain autograd backward.)"""
 
     def __init__(self, params, bucket_bytes: int = 32 << 20, process_group=None, average: bool = True):
         self.reducer = GradBucketReducer(params, bucket_bytes, process_group, average)
@@ -137,29 +137,29 @@ class GradAccumulator:
             p.grad = None
 
     def begin_sweep(self, last: bool):
-        # With a single rank there is nothing to overlap: every sweep (the last one too) is folded in by one
-        # multi-tensor add, which also lets weight gradients be produced on a side stream (ops.enable_side_stream).
-        self._hooked = last and self.world > 1
-        if self._hooked:
-            for p, v in zip(self.params, self.views):
-                p.grad = v
-            self.reducer.arm()
-        else:
-            for p in self.params:
-                p.grad = None
+        # Every sweep runs with p.grad = None and is folded into the buckets by one multi-tensor add; weight gradients that
+        # the HIP kernels accumulate straight into the buckets (sinks, possibly on a side stream) never pass through autograd.
+        for p in self.params:
+            p.grad = None
 
     def end_sweep(self, last: bool):
-        if self._hooked:
-            self.reducer.finish()
-            return
         dst, src = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is not None:
                 dst.append(v); src.append(p.grad)
         if dst:
             torch._foreach_add_(dst, src)
-        if last:                      # hand the accumulated gradients to the optimizer
-            for p, v in zip(self.params, self.views):
+        if last:
+            if self.world > 1:
+                # ONE all-reduce per bucket per step over RCCL/xGMI, all in flight together (35 M parameters = 140 MB:
+                # ~1-2 ms on 8 GPUs against a ~60 ms step, so it is not worth giving up the side-stream weight gradients
+                # -- which bypass autograd's hooks -- to overlap it with the backward)
+                handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.reducer.group, async_op=True) for b in self.reducer.buckets]
+                for h in handles:
+                    h.wait()
+                if self.reducer.average:
+                    torch._foreach_div_(self.reducer.buckets, float(self.world))
+            for p, v in zip(self.params, self.views):       # hand the accumulated gradients to the optimizer
                 p.grad = v
         else:
             for p in self.params:
