@@ -44,49 +44,114 @@ __device__ __forceinline__ float crpe_bias(const FaGeom& g, const CrpeW& cw, int
 // ---- tile partials: P[c][e] = sum_{n in tile} f(X[n,c]) * Y[n, head(c)*Ch + e] ----------------------
 // SOFTMAX: f = exp(x - tile max), also emits tile max / exp-sum (fwd A, X = k, Y = v).
 // !SOFTMAX: f = identity, Y scaled per channel by ysc[b,c]*yscale (bwd 2, X = q, Y = G).
-template <bool SOFTMAX>
+// One workgroup = FA_T tokens x one channel group of GW = max(Ch, 32) channels.  Both operand tiles are staged in LDS
+// (float4 loads, all in flight before the first LDS store); the GW x GW product X^T Y runs on v_mfma_f32_32x32x2_f32
+// with the token axis as k -- each wavefront takes a quarter of the tokens, the four partial results meet in LDS in a
+// fixed order -- and only the head-diagonal Ch x Ch blocks are written out.
+typedef float fap_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CH, bool SOFTMAX>
 __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
                                                          const float* __restrict__ ysc, float yscale,
                                                          float* __restrict__ ws_m, float* __restrict__ ws_s, float* __restrict__ ws_P,
-                                                         FaGeom g, int CW, int NT) {
-    extern __shared__ float sm[];          // xs[FA_T][CW], ys[FA_T][CW]
-    float* xs = sm;
-    float* ys = sm + FA_T * CW;
-    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
-    const int c0 = chunk * CW, n0 = tile * FA_T, nt = min(FA_T, g.N - n0);
-    for (int i = threadIdx.x; i < nt * CW; i += blockDim.x) {
-        const int n = i / CW, c = i % CW;
-        const long tok = (long)b * g.N + n0 + n;
-        xs[n * CW + c] = X[tok * ldx + c0 + c];
-        float yv = Y[tok * ldy + c0 + c];
-        if (!SOFTMAX) yv *= yscale * (ysc ? ysc[(long)b * g.C + c0 + c] : 1.f);
-        ys[n * CW + c] = yv;
+                                                         FaGeom g, int NT) {
+    constexpr int GW = CH < 32 ? 32 : CH, NB = (GW + 31) / 32, GQ = GW / 4;
+    constexpr int STAGE = 2 * FA_T * GW, RED = 4 * NB * 32 * NB * 32;
+    __shared__ __attribute__((aligned(16))) float sm[STAGE > RED ? STAGE : RED];
+    float* xs = sm;                        // [FA_T][GW]
+    float* ys = sm + FA_T * GW;            // [FA_T][GW]
+    const int tile = blockIdx.x, c0 = blockIdx.y * GW, b = blockIdx.z;
+    const int n0 = tile * FA_T, nt = min(FA_T, g.N - n0);
+    // ---- stage (rows past the sequence end are zeros)
+    {
+        constexpr int NV = (FA_T * GQ + 255) / 256;
+        float4 xv[NV], yv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
+            xv[v] = make_float4(0.f, 0.f, 0.f, 0.f); yv[v] = xv[v];
+            if (i < FA_T * GQ && n < nt) {
+                const long tok = (long)b * g.N + n0 + n;
+                xv[v] = *reinterpret_cast<const float4*>(X + tok * ldx + c0 + 4 * q);
+                yv[v] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0 + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
+            if (i < FA_T * GQ) {
+                float4 y4 = yv[v];
+                if (!SOFTMAX) {
+                    float4 sc = make_float4(yscale, yscale, yscale, yscale);
+                    if (ysc) { const float4 a4 = *reinterpret_cast<const float4*>(ysc + (long)b * g.C + c0 + 4 * q); sc.x *= a4.x; sc.y *= a4.y; sc.z *= a4.z; sc.w *= a4.w; }
+                    y4.x *= sc.x; y4.y *= sc.y; y4.z *= sc.z; y4.w *= sc.w;
+                }
+                *reinterpret_cast<float4*>(xs + n * GW + 4 * q) = xv[v];
+                *reinterpret_cast<float4*>(ys + n * GW + 4 * q) = y4;
+            }
+        }
     }
     __syncthreads();
     if (SOFTMAX) {
-        // column max / exp: 4 threads per column (256 threads, CW <= 64), 2 (CW <= 128) or 1
-        const int per = CW <= 64 ? 4 : (CW <= 128 ? 2 : 1);
+        // column max / exp over the tile's tokens: `per` threads per column
+        constexpr int per = GW <= 64 ? 4 : 2;
         const int c = threadIdx.x / per, sub = threadIdx.x % per;
         float m = -INFINITY;
-        if (c < CW)
-            for (int n = sub; n < nt; n += per) m = fmaxf(m, xs[n * CW + c]);
+        if (c < GW)
+            for (int n = sub; n < nt; n += per) m = fmaxf(m, xs[n * GW + c]);
         for (int o = 1; o < per; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float s = 0.f;
-        if (c < CW)
-            for (int n = sub; n < nt; n += per) { const float e = expf(xs[n * CW + c] - m); xs[n * CW + c] = e; s += e; }
-        for (int o = 1; o < per; o <<= 1) s += __shfl_xor(s, o, 64);
-        if (c < CW && sub == 0) {
+        float ssum = 0.f;
+        if (c < GW) {
+            for (int n = sub; n < nt; n += per) { const float e = expf(xs[n * GW + c] - m); xs[n * GW + c] = e; ssum += e; }
+            for (int n = nt + sub; n < FA_T; n += per) xs[n * GW + c] = 0.f;          // padded rows must not contribute exp(0 - m)
+        }
+        for (int o = 1; o < per; o <<= 1) ssum += __shfl_xor(ssum, o, 64);
+        if (c < GW && sub == 0) {
             const long o = ((long)b * NT + tile) * g.C + c0 + c;
-            ws_m[o] = m; ws_s[o] = s;
+            ws_m[o] = m; ws_s[o] = ssum;
         }
         __syncthreads();
     }
-    for (int o = threadIdx.x; o < CW * g.Ch; o += blockDim.x) {
-        const int c = o / g.Ch, e = o % g.Ch, hb = (c / g.Ch) * g.Ch;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int n = 0; n < nt; ++n) acc = fmaf(xs[n * CW + c], ys[n * CW + hb + e], acc);
-        ws_P[(((long)b * NT + tile) * g.C + c0 + c) * g.Ch + e] = acc;
+    // ---- D[c][e] += X[n][c] * Y[n][e] over this wavefront's quarter of the tokens
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+    fap_f32x16 acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int TPW = FA_T / 4;
+#pragma unroll
+    for (int kk = 0; kk < TPW / 2; ++kk) {
+        const int n = wave * TPW + 2 * kk + lhi;
+        float xa[NB], yb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { const int c = 32 * i + l31; xa[i] = c < GW ? xs[n * GW + c] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { const int c = 32 * j + l31; yb[j] = c < GW ? ys[n * GW + c] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                       // the operand tiles are dead: reuse the LDS for the four partial results
+    constexpr int RW = NB * 32;            // padded row width of a partial result
+    float* red = sm + wave * RW * RW;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * i + 8 * (r >> 2) + 4 * lhi + (r & 3), e = 32 * j + l31;       // lane holds column e, rows c
+                red[c * RW + e] = acc[i][j][r];
+            }
+    __syncthreads();
+    for (int o = threadIdx.x; o < GW * CH; o += 256) {
+        const int c = o / CH, el = o % CH, e = (c / CH) * CH + el;       // head-diagonal entry (c, e) of the group
+        const float v = (sm[c * RW + e] + sm[RW * RW + c * RW + e]) + (sm[2 * RW * RW + c * RW + e] + sm[3 * RW * RW + c * RW + e]);
+        ws_P[(((long)b * NT + tile) * g.C + c0 + c) * CH + el] = v;
     }
 }
 
@@ -352,12 +417,27 @@ __global__ __launch_bounds__(256) void da_bwd_stage1_kernel(const float* __restr
         dzbuf[(long)b * C + c] = v;
     }
     __syncthreads();
+    // t[i] = sum_c dz[c] W2[c][i]: the C-long walk is split over 256/hid thread groups (a single thread per i paid C
+    // dependent L2 round trips -- 30 us per launch on a B-block grid), partial sums meet in LDS in a fixed order
+    float* tpart = sm + C;                 // [nseg][hid]
+    const int nseg = hid <= 256 ? 256 / hid : 1;
+    for (int i0 = 0; i0 < hid; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x % (hid <= 256 ? hid : 256), seg = hid <= 256 ? (int)threadIdx.x / hid : 0;
+        if (i < hid && seg < nseg) {
+            const int c_beg = (int)((long)C * seg / nseg), c_end = (int)((long)C * (seg + 1) / nseg);
+            float t = 0.f;
+#pragma unroll 4
+            for (int c = c_beg; c < c_end; ++c) t = fmaf(dz[c], W2[(long)c * hid + i], t);
+            tpart[seg * hid + i] = t;
+        }
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < hid; i += blockDim.x) {
         float s = 0.f;
         for (int d = 0; d < D; ++d) s = fmaf(label[(long)b * D + d], W1[(long)i * D + d], s);
         const float h = s + b1[i];
         float t = 0.f;
-        for (int c = 0; c < C; ++c) t = fmaf(dz[c], W2[(long)c * hid + i], t);
+        for (int seg = 0; seg < nseg; ++seg) t += tpart[seg * hid + i];
         hbuf[(long)b * hid + i] = fmaxf(h, 0.f);
         dhbuf[(long)b * hid + i] = h > 0.f ? t : 0.f;
     }
@@ -452,8 +532,20 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     float* ws_m = (float*)ws;
     float* ws_s = ws_m + (long)B * NT * C;
     float* ws_P = ws_s + (long)B * NT * C;
-    hipLaunchKernelGGL((fa_partial_kernel<true>), dim3(NT, C / CW, B), dim3(256), sizeof(float) * 2 * FA_T * CW, s,
-                       qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, CW, NT);
+    {
+        const int GW = g.Ch < 32 ? 32 : g.Ch;
+        MDVIT_CHECK_ARG(C % GW == 0, MDVIT_E_SHAPE, "factoratt_fwd: C=%d is not a multiple of the %d-channel group", C, GW);
+#define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, true>), dim3(NT, C / GW, B), dim3(256), 0, s, \
+                       qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, NT)
+        switch (g.Ch) {
+            case 8: FA_PART_LAUNCH(8); break;
+            case 16: FA_PART_LAUNCH(16); break;
+            case 40: FA_PART_LAUNCH(40); break;
+            case 64: FA_PART_LAUNCH(64); break;
+            default: return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_fwd: head dim %d not built (8/16/40/64)", g.Ch);
+        }
+#undef FA_PART_LAUNCH
+    }
     hipLaunchKernelGGL((fa_combine_kernel<true>), dim3(cdiv((long)C * g.Ch, 256), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
     MDVIT_CHECK_ARG(C <= 512, MDVIT_E_SHAPE, "factoratt_fwd: C=%d > 512 not built", C);
     // U = dwconv_win(v) + bias, one tiled launch per window class (channels [0,s3*Ch) | [..) | [..))
@@ -515,8 +607,20 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         }
     }
     // 2: dM = Q^T (scale * a * G)
-    hipLaunchKernelGGL((fa_partial_kernel<false>), dim3(NT, C / CW, B), dim3(256), sizeof(float) * 2 * FA_T * CW, s,
-                       qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, CW, NT);
+    {
+        const int GWp = Ch < 32 ? 32 : Ch;
+        MDVIT_CHECK_ARG(C % GWp == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GWp);
+#define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, false>), dim3(NT, C / GWp, B), dim3(256), 0, s, \
+                       qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, NT)
+        switch (Ch) {
+            case 8: FA_PART_LAUNCH(8); break;
+            case 16: FA_PART_LAUNCH(16); break;
+            case 40: FA_PART_LAUNCH(40); break;
+            case 64: FA_PART_LAUNCH(64); break;
+            default: return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_bwd: head dim %d not built (8/16/40/64)", Ch);
+        }
+#undef FA_PART_LAUNCH
+    }
     hipLaunchKernelGGL((fa_combine_kernel<false>), dim3(cdiv((long)C * Ch, 256), B), dim3(256), 0, s,
                        (const float*)nullptr, (const float*)nullptr, ws_P, (float*)nullptr, (float*)nullptr, dM, g, NT);
     // 3: crpe weight gradients
@@ -599,7 +703,7 @@ extern "C" int mdvit_da_bwd(const float* label, const float* W1, const float* b1
     float* dzbuf = (float*)ws;
     float* hbuf = dzbuf + (long)B * C;
     float* dhbuf = hbuf + (long)B * hid;
-    hipLaunchKernelGGL(da_bwd_stage1_kernel, dim3(B), dim3(256), sizeof(float) * C, s, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads, scale);
+    hipLaunchKernelGGL(da_bwd_stage1_kernel, dim3(B), dim3(256), sizeof(float) * (C + (size_t)max(hid, 256)), s, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads, scale);
     const long total = (long)C * hid + (long)hid * D + C + hid;
     hipLaunchKernelGGL(da_bwd_stage2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, label, dzbuf, hbuf, dhbuf, dW1, db1, dW2, db2, B, D, hid, C);
     MDVIT_LAUNCH_CHECK();
