@@ -155,30 +155,32 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
     }
 }
 
-template <bool SOFTMAX>
-__global__ __launch_bounds__(256) void fa_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_s,
-                                                         const float* __restrict__ ws_P, float* __restrict__ kmax, float* __restrict__ ksum,
-                                                         float* __restrict__ Mout, FaGeom g, int NT) {
-    const int b = blockIdx.y;
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= g.C * g.Ch) return;
+// Combine the token-tile partials of the softmax(K)^T V product: online-softmax rescale by exp(m_t - m).  8 outputs (c,e)
+// per workgroup, 32 lanes walk the NT tiles of one output (a single thread per output paid NT dependent loads), lane
+// results folded by a fixed shuffle tree.  (The plain sums of the backward use mdvit_reduce_partials_batched.)
+__global__ __launch_bounds__(256) void fa_combine_softmax_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_s,
+                                                                 const float* __restrict__ ws_P, float* __restrict__ kmax, float* __restrict__ ksum,
+                                                                 float* __restrict__ Mout, FaGeom g, int NT) {
+    const int b = blockIdx.y, rl = threadIdx.x & 31;
+    const int o = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (o >= g.C * g.Ch) return;                       // whole 32-lane groups leave together
     const int c = o / g.Ch, e = o % g.Ch;
-    if (SOFTMAX) {
-        float m = -INFINITY;
-        for (int t = 0; t < NT; ++t) m = fmaxf(m, ws_m[((long)b * NT + t) * g.C + c]);
-        float s = 0.f, acc = 0.f;
-        for (int t = 0; t < NT; ++t) {
-            const long i = ((long)b * NT + t) * g.C + c;
-            const float f = expf(ws_m[i] - m);
-            s = fmaf(ws_s[i], f, s);
-            acc = fmaf(ws_P[i * g.Ch + e], f, acc);
-        }
-        Mout[((long)b * g.C + c) * g.Ch + e] = acc / s;
-        if (e == 0) { kmax[(long)b * g.C + c] = m; ksum[(long)b * g.C + c] = s; }
-    } else {
-        float acc = 0.f;
-        for (int t = 0; t < NT; ++t) acc += ws_P[(((long)b * NT + t) * g.C + c) * g.Ch + e];
-        Mout[((long)b * g.C + c) * g.Ch + e] = acc;
+    float m = -INFINITY;
+    for (int t = rl; t < NT; t += 32) m = fmaxf(m, ws_m[((long)b * NT + t) * g.C + c]);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    float ssum = 0.f, acc = 0.f;
+    for (int t = rl; t < NT; t += 32) {
+        const long i = ((long)b * NT + t) * g.C + c;
+        const float f = expf(ws_m[i] - m);
+        ssum = fmaf(ws_s[i], f, ssum);
+        acc = fmaf(ws_P[i * g.Ch + e], f, acc);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { ssum += __shfl_down(ssum, off, 32); acc += __shfl_down(acc, off, 32); }
+    if (rl == 0) {
+        Mout[((long)b * g.C + c) * g.Ch + e] = acc / ssum;
+        if (e == 0) { kmax[(long)b * g.C + c] = m; ksum[(long)b * g.C + c] = ssum; }
     }
 }
 
@@ -546,7 +548,7 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
         }
 #undef FA_PART_LAUNCH
     }
-    hipLaunchKernelGGL((fa_combine_kernel<true>), dim3(cdiv((long)C * g.Ch, 256), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
+    hipLaunchKernelGGL(fa_combine_softmax_kernel, dim3(cdiv((long)C * g.Ch, 8), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
     MDVIT_CHECK_ARG(C <= 512, MDVIT_E_SHAPE, "factoratt_fwd: C=%d > 512 not built", C);
     // U = dwconv_win(v) + bias, one tiled launch per window class (channels [0,s3*Ch) | [..) | [..))
     const int Ch = g.Ch, c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
@@ -621,8 +623,10 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         }
 #undef FA_PART_LAUNCH
     }
-    hipLaunchKernelGGL((fa_combine_kernel<false>), dim3(cdiv((long)C * Ch, 256), B), dim3(256), 0, s,
-                       (const float*)nullptr, (const float*)nullptr, ws_P, (float*)nullptr, (float*)nullptr, dM, g, NT);
+    {       // dM[b] = sum over the token tiles of ws_P[b][tile]  (fixed order)
+        const int rc = mdvit_reduce_partials_batched(ws_P, B, NT, C * Ch, dM, s);
+        if (rc != MDVIT_OK) return rc;
+    }
     // 3: crpe weight gradients
     const int c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
     const CtGeom cg{B, g.H, g.W};
