@@ -38,7 +38,7 @@ def parse():
                     help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel); "
                          "fp32 = fp32-input MFMA")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
-    ap.add_argument("--fuse-images", type=int, default=32,
+    ap.add_argument("--fuse-images", type=int, default=128,
                     help="domain batches are fused into one domain-batched forward while the fused batch stays <= this many images (0: one forward per domain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reference-sweeps", action="store_true", help="run the reference's literal two full sweeps instead of the merged (linear-algebra-equivalent) form")

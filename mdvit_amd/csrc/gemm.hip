@@ -93,12 +93,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     constexpr int WTM = BM / WAVES_M / 32, WTN = BN / WAVES_N / 32;   // 32x32 blocks per wave
     constexpr int A_V4 = BM * BK / 4 / NTHREADS, B_V4 = BN * BK / 4 / NTHREADS;
     constexpr int KT = BK / 4;                                        // threads per k-contiguous row
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    // 64x64 tiles (little MFMA work per K slab) double-buffer the LDS stage: the next slab is written while the current
+    // one is being multiplied, ONE barrier per slab instead of two.  (The larger tiles would exceed the 64 KB static limit.)
+    constexpr bool DB = (BM == 64 && BN == 64);
+    __shared__ __attribute__((aligned(16))) float smem[DB ? 2 * SMEM_FLOATS : SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + BK * LDSA;
     // BF3 planes (bytes): A hi | A lo | B hi | B lo
     char* sb = reinterpret_cast<char*>(smem);
     char* Ahi = sb; char* Alo = sb + BM * LDKB; char* Bhi = sb + 2 * BM * LDKB; char* Blo = Bhi + BN * LDKB;
+    auto stage = [&](int b) {              // point the staging / fragment pointers at LDS buffer b
+        float* base = smem + b * SMEM_FLOATS;
+        As = base; Bs = base + BK * LDSA;
+        sb = reinterpret_cast<char*>(base);
+        Ahi = sb; Alo = sb + BM * LDKB; Bhi = sb + 2 * BM * LDKB; Blo = Bhi + BN * LDKB;
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t s0 = 0, s1 = 0;
@@ -280,9 +289,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     store_smem();
     __syncthreads();
     const int l31 = lane & 31, lhi = lane >> 5;
+    int buf = 0;
+    if (DB && kbeg + BK < kend) { load_a(kbeg + BK); load_b(kbeg + BK); }      // slab 1 in flight before the loop
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
-        if (more) { load_a(k0 + BK); load_b(k0 + BK); }
+        if (DB) {
+            if (more) {                         // registers hold slab k+1 (loaded one iteration ago): park it in the other buffer
+                stage(buf ^ 1);
+                store_smem();
+                stage(buf);
+                if (k0 + 2 * BK < kend) { load_a(k0 + 2 * BK); load_b(k0 + 2 * BK); }
+            }
+        } else if (more) { load_a(k0 + BK); load_b(k0 + BK); }
         if (BF3) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
@@ -325,7 +343,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
-        if (more) {
+        if (DB) {
+            buf ^= 1;
+            stage(buf);
+        } else if (more) {
             store_smem();
             __syncthreads();
         }

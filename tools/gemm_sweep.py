@@ -49,19 +49,15 @@ def main():
         def run():
             ops.gemm(ops._p(A), ops._p(B), ops._p(out), M, N, K, lda=A.stride(0), ldb=B.stride(0), ldc=N, trans_a=ta, trans_b=tb,
                      allow_split=epi == 0, **extra)
+        if ta != tb:
+            extra["precision"] = 1          # the step runs these layouts in bf16x3
         lib.mdvit_gemm_force_plan(-1, 0)
         t_pl = timed(run)
-        t_bf = None
-        if ta != tb:
-            extra["precision"] = 1
-            t_bf = timed(run)
-            bres = []
-            for cfg in range(3):
-                lib.mdvit_gemm_force_plan(cfg, 0)
-                bres.append((timed(run, 4), cfg))
-            lib.mdvit_gemm_force_plan(-1, 0)
-            extra["precision"] = 0
-        g = _lib.GemmDesc(); g.M, g.N, g.K, g.trans_a, g.trans_b, g.allow_split = M, N, K, int(ta), int(tb), 1
+        g = _lib.GemmDesc(); g.M, g.N, g.K, g.trans_a, g.trans_b, g.allow_split = M, N, K, int(ta), int(tb), int(epi == 0)
+        g.precision = extra.get("precision", 0)
+        g.epi = {0: 0, 1: _lib.EPI_GELU_DUAL, 2: _lib.EPI_DGELU, 3: 0}[epi]
+        if epi == 3:
+            g.residual = 1
         tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
         lib.mdvit_gemm_plan(C.byref(g), C.byref(tm), C.byref(tn), C.byref(sp))
         res = []
@@ -75,6 +71,7 @@ def main():
         res.sort()
         bt, bc, bs = res[0]
         total_pl += t_pl * r["n"]; total_best += bt * r["n"]
+        t_bf = None
         fl = 2.0 * M * N * K
         print(f"M={M:>7} N={N:>5} K={K:>7} {'T' if ta else 'N'}{'T' if tb else 'N'} e{epi} x{r['n']:3d}  planner {tm.value}x{tn.value} sp={sp.value:<4d} {t_pl:8.1f} us ({fl/t_pl/1e6:5.1f} TF)"
               f" | best {CFG[bc]} sp={bs:<4d} {bt:8.1f} us ({fl/bt/1e6:5.1f} TF) | next {CFG[res[1][1]]} sp={res[1][2]} {res[1][0]:.1f}"
