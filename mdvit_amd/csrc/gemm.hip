@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     constexpr int KT = BK / 4;                                        // threads per k-contiguous row
     // 64x64 tiles (little MFMA work per K slab) double-buffer the LDS stage: the next slab is written while the current
     // one is being multiplied, ONE barrier per slab instead of two.  (The larger tiles would exceed the 64 KB static limit.)
-    constexpr bool DB = (BM == 64 && BN == 64);
+    constexpr bool DB = (BM == 64 && BN == 64 && !TA);     // (the pair-staged wgrad measured slower with the doubled LDS footprint)
     __shared__ __attribute__((aligned(16))) float smem[DB ? 2 * SMEM_FLOATS : SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + BK * LDSA;

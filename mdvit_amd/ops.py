@@ -226,7 +226,9 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
         if need:
             ws = _empty((need // 4,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
             d.ws, d.ws_bytes = _p(ws), need
-    if _events is None:
+    if _events is None or (_side_stream is not None and torch.cuda.current_stream() == _side_stream):
+        # (side-stream launches are not event-timed: they queue behind, and share the chip with, the main stream's kernels,
+        #  so an event pair around them measures the wait as well; rocprofv3 has their true durations)
         call("mdvit_gemm_f32", C.byref(d), _stream())
         return
     tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
