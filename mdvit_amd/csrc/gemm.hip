@@ -284,11 +284,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
         }
     };
 
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // Epilogue operands that do not depend on the product (gelu_u of the DGELU epilogue, the residual of the FULL one) are
+    // fetched NOW, ahead of the K loop, when the wavefront owns a single 32x32 block (16 registers): loading them in the
+    // epilogue left every wavefront waiting on HBM latency with nothing else to run.
+    constexpr bool EPRE = (WTM * WTN == 1) && (EPI == EPI_DGELU || EPI == EPI_FULL);
+    float4 epre[EPRE ? 4 : 1];
+    if (EPRE) {
+        const float* src = EPI == EPI_DGELU ? p.gelu_u : p.residual;
+        const long lds_ = EPI == EPI_DGELU ? p.ldu : p.ldr;
+        const int row = m0 + wm0 + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = n0 + wn0 + 8 * q + 4 * lhi;
+            epre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src && row < p.M && col < p.N) epre[q] = *reinterpret_cast<const float4*>(src + (long)row * lds_ + col);
+        }
+    }
     load_a(kbeg);
     load_b(kbeg);
     store_smem();
     __syncthreads();
-    const int l31 = lane & 31, lhi = lane >> 5;
     int buf = 0;
     if (DB && kbeg + BK < kend) { load_a(kbeg + BK); load_b(kbeg + BK); }      // slab 1 in flight before the loop
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                     continue;
                 }
                 if (EPI == EPI_DGELU) {
-                    const float4 u4 = *reinterpret_cast<const float4*>(p.gelu_u + (long)row * p.ldu + col);
+                    const float4 u4 = EPRE ? epre[q] : *reinterpret_cast<const float4*>(p.gelu_u + (long)row * p.ldu + col);
                     v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
                 }
                 if (p.e_drop) {
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 if (EPI == EPI_FULL) {
                     v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
                     if (p.residual) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col);
+                        const float4 r4 = EPRE ? epre[q] : *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col);
                         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                     }
                 }
@@ -545,9 +561,13 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
             const double rounds = wgs <= slots ? 1.0 : (double)wgs / (double)slots;   // workgroups do not run in lockstep: no ceil
             // one workgroup alone on a CU: 2*BM*BN*kps flop at ~180 flop/clk; plus a fixed prologue/epilogue cost per workgroup
             // bf16x3: 3 x 32-cycle MFMAs per 32x32x16 on 4 SIMDs, plus the hi/lo split of every staged element (VALU)
+            // epilogue: the 64x64 tile prefetches gelu_u / the residual ahead of the K loop; the larger tiles load them in the
+            // epilogue, exposed to HBM latency at 2 workgroups per CU
+            const bool loads_epi = d->epi == MDVIT_EPI_DGELU || d->residual != nullptr;
+            const double epi_cycles = (loads_epi && c != 2 ? 30.0 : 6.0) * BMs[c] * BNs[c] / 64.0;
             const double wg_cycles = d->precision == 1
-                ? 0.0015 * BMs[c] * BNs[c] * (double)kps + (d->trans_a ? 0.12 : 0.06) * (BMs[c] + BNs[c]) * (double)kps + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0
-                : 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 800.0 + 6.0 * BMs[c] * BNs[c] / 64.0;
+                ? 0.0015 * BMs[c] * BNs[c] * (double)kps + (d->trans_a ? 0.12 : 0.06) * (BMs[c] + BNs[c]) * (double)kps + 800.0 + epi_cycles
+                : 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 800.0 + epi_cycles;
             double cost = rounds * OCC[c] * wg_cycles;
             if (splits > 1) cost += 12000.0 + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;
             if (cost < best_cost) {
