@@ -86,6 +86,9 @@ int mdvit_gemm_plan(const MdvitGemmDesc* desc, int32_t* tile_m, int32_t* tile_n,
 /* out[cols, rows] = in[rows, cols]^T (row-major, in may be a column slice with leading dimension ld_in).  Used on WEIGHTS
  * only: with precision = 1 the data-gradient GEMM  dX = dY W  reads W^T so that both operands are k-contiguous. */
 int mdvit_transpose_f32(const float* in, int64_t ld_in, float* out, int32_t rows, int32_t cols, void* stream);
+/* n transposes in one launch (the per-step refresh of every cached W^T after the optimizer update).  items_dev: device array
+ * [n][5] of int64 {in pointer, out pointer, ld_in, rows, cols}; blocks_per_item workgroups walk each item's 32x32 tiles. */
+int mdvit_transpose_many(const void* items_dev, int32_t n, int32_t blocks_per_item, void* stream);
 /* Tuning hook for tools/gemm_sweep.py: pin the tile configuration (0: 128x128, 1: 256x64, 2: 64x64; -1: planner) and the
  * requested K-split (one of the planner's candidates; 0: planner) of every following mdvit_gemm_f32 call. */
 int mdvit_gemm_force_plan(int32_t cfg, int32_t splits);

@@ -254,6 +254,31 @@ class Mlp(nn.Module):
                                 self.drop_p if self.training else 0.0, N)
 
 
+# DropPath masks of one forward, drawn at once by the model (model._trunk): {"m": [n_blocks,2,B], "keep", "B", "next"}
+_droppath_pool = None
+
+
+class droppath_pool:
+    """with droppath_pool(n_blocks, B, keep, device): the SerialBlocks inside take their per-sample DropPath scales from one
+    pre-drawn tensor (same distribution: an independent Bernoulli(keep)/keep per block, branch and sample)."""
+
+    def __init__(self, n_blocks, B, keep, device, enabled=True):
+        self.args = (n_blocks, B, keep, device, enabled)
+
+    def __enter__(self):
+        global _droppath_pool
+        n, B, keep, device, enabled = self.args
+        self.prev = _droppath_pool
+        if enabled and keep < 1.0:
+            _droppath_pool = {"m": (torch.rand((n, 2, B), device=device) < keep).float() / keep, "keep": keep, "B": B, "next": 0}
+        return self
+
+    def __exit__(self, *exc):
+        global _droppath_pool
+        _droppath_pool = self.prev
+        return False
+
+
 class SerialBlock_adapt(nn.Module):
     """mdvit.py:316-361: cpe -> LN -> attention(+DA) -> DropPath+res -> LN -> MLP -> DropPath+res."""
 
@@ -279,6 +304,11 @@ class SerialBlock_adapt(nn.Module):
         if not self.training or self.drop_path_p <= 0.0:
             return None, None
         keep = 1.0 - self.drop_path_p
+        pool = _droppath_pool
+        if pool is not None and pool["keep"] == keep and pool["B"] == B and pool["next"] < pool["m"].shape[0]:
+            m = pool["m"][pool["next"]]            # pre-drawn for the whole forward (one torch.rand instead of one per block)
+            pool["next"] += 1
+            return m[0], m[1]
         m = (torch.rand((2, B), device=device) < keep).float() / keep      # per-sample masks for both branches
         return m[0].contiguous(), m[1].contiguous()
 

@@ -246,15 +246,6 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restric
     }
 }
 
-// ---- bwd 4: t[b,c] = sum_e dM[b,c,e] * M[b,c,e] -------------------------------------------------
-__global__ void fa_bwd_mid_kernel(const float* __restrict__ dM, const float* __restrict__ Mmat, float* __restrict__ tcol, int BC, int Ch) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BC) return;
-    float s = 0.f;
-    for (int e = 0; e < Ch; ++e) s = fmaf(dM[(long)i * Ch + e], Mmat[(long)i * Ch + e], s);
-    tcol[i] = s;
-}
-
 // ---- bwd 5: dq, dk, dv ----------------------------------------------------------------------------
 // Per image and head three token x Ch x Ch products (dq = dFA.KV^T, dP = v.dKV^T, dv = P.dKV) plus element-wise terms.
 // They run on v_mfma_f32_32x32x2_f32 as D[channel][token] = W[channel][k] . X[k][token]:
@@ -292,7 +283,10 @@ __global__ __launch_bounds__(256) void fa_bwd_apply_kernel(const float* __restri
     }
     for (int i = threadIdx.x; i < GW; i += 256) {
         const long ci = (long)b * C + g0 + i;
-        s_a[i] = a ? a[ci] : 1.f; s_km[i] = kmax[ci]; s_ks[i] = 1.0f / ksum[ci]; s_tc[i] = tcol[ci];
+        s_a[i] = a ? a[ci] : 1.f; s_km[i] = kmax[ci]; s_ks[i] = 1.0f / ksum[ci];
+        float tc = 0.f;                   // t[c] = sum_e dM[c][e] * M[c][e]  (= sum_n P[n,c] dP[n,c], the column-softmax correction)
+        for (int e = 0; e < CH; ++e) tc = fmaf(dM[ci * CH + e], Mmat[ci * CH + e], tc);
+        s_tc[i] = tc;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -641,7 +635,6 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     launch_conv_tile<5, true>(dU, (long)C, c5, w5, nullptr, dVc, (long)C, c5, cg, s5 * Ch, s);
     launch_conv_tile<7, true>(dU, (long)C, c7, w7, nullptr, dVc, (long)C, c7, cg, s7 * Ch, s);
     // 4, 5
-    hipLaunchKernelGGL(fa_bwd_mid_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, s, dM, Mmat, tcol, B * C, Ch);
     const int GW = Ch < 32 ? 32 : Ch;
     MDVIT_CHECK_ARG(C % GW == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GW);
     const int ntiles = cdiv(g.N, 32);

@@ -670,6 +670,40 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// many small transposes in ONE launch: items [n][5] int64 in device memory = {in, out, ld_in, rows, cols}; grid.y = item
+__global__ __launch_bounds__(256) void transpose_many_kernel(const long long* __restrict__ items) {
+    __shared__ float tile[32][33];
+    const long long* it = items + 5 * (long)blockIdx.y;
+    const float* in = reinterpret_cast<const float*>(it[0]);
+    float* out = reinterpret_cast<float*>(it[1]);
+    const long ld_in = (long)it[2];
+    const int rows = (int)it[3], cols = (int)it[4];
+    const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tidx = blockIdx.x; tidx < tiles_x * tiles_y; tidx += gridDim.x) {
+        const int r0 = (tidx / tiles_x) * 32, c0 = (tidx % tiles_x) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ty + 8 * i, c = c0 + tx;
+            tile[ty + 8 * i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;
+            if (c < cols && r < rows) out[(long)c * rows + r] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int mdvit_transpose_many(const void* items_dev, int32_t n, int32_t blocks_per_item, void* stream) {
+    MDVIT_CHECK_ARG(items_dev && n > 0 && blocks_per_item > 0, MDVIT_E_SHAPE, "transpose_many: bad arguments");
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(blocks_per_item, n), dim3(256), 0, (hipStream_t)stream, (const long long*)items_dev);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
 extern "C" int mdvit_transpose_f32(const float* in, int64_t ld_in, float* out, int32_t rows, int32_t cols, void* stream) {
     MDVIT_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_in >= cols, MDVIT_E_SHAPE, "transpose: bad shape rows=%d cols=%d ld=%ld", rows, cols, (long)ld_in);
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, out, rows, cols);

@@ -17,7 +17,7 @@ from torch import nn
 
 from . import ops
 from ._lib import ACT_RELU
-from .blocks import (BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
+from .blocks import (droppath_pool, BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
                      init_weights_)
 from .decode import MLPDecoderFM, UnetDecodingBlockTransformer
 
@@ -59,7 +59,10 @@ class _EncoderDecoder(nn.Module):
     def _trunk(self, x, domain_label, groups: int = 1):
         """x NCHW image -> (logits (B,1,H,W), encoder_outs NHWC list, decoder4 output NHWC).
         groups > 1: x is `groups` equal consecutive domain batches; BatchNorm statistics stay per domain batch."""
-        with ops.bn_groups(groups):
+        blocks = [blk for st in list(self.mhsa_stages) + list(self.mhsa_list) for blk in st.mhca_blks]
+        keep = 1.0 - blocks[0].drop_path_p
+        uniform = all(blk.drop_path_p == blocks[0].drop_path_p for blk in blocks)
+        with ops.bn_groups(groups), droppath_pool(len(blocks), x.shape[0], keep, x.device, enabled=self.training and uniform):
             return self._trunk_impl(x, domain_label)
 
     def _trunk_impl(self, x, domain_label):

@@ -272,20 +272,53 @@ _wt_cache = {}       # id(leaf weight) -> (weakref to it, version, data_ptr, row
 
 def wt(W):
     """W [N,K] (2-D view, or a contiguous conv weight read as [out, in*kh*kw]) -> contiguous W^T [K,N].  Cached per leaf
-    parameter and refreshed when the parameter's version counter moves (optimizer step, load_state_dict)."""
+    parameter; refreshed (into the same buffer) when the parameter's version counter moves -- normally for all weights
+    at once by refresh_transposes() at the start of a step."""
     N, K, ld = _ld_view(W)
     leaf = W.grad_fn is None and W.requires_grad
     tag = (W._version, W.data_ptr(), N, K, ld)
+    out = None
     if leaf:
         hit = _wt_cache.get(id(W))
-        if hit is not None and hit[0]() is W and hit[1:6] == tag:
-            return hit[6]
-    out = torch.empty((K, N), device=W.device, dtype=torch.float32)
+        if hit is not None and hit[0]() is W:
+            if hit[1:6] == tag:
+                return hit[6]
+            if hit[2:6] == tag[1:]:
+                out = hit[6]                  # same storage and shape, new values: transpose into the existing buffer
+    if out is None:
+        out = torch.empty((K, N), device=W.device, dtype=torch.float32)
     call("mdvit_transpose_f32", _p(W), ld, _p(out), N, K, _stream())
     if leaf:
         key = id(W)
         _wt_cache[key] = (weakref.ref(W, lambda _r, key=key: _wt_cache.pop(key, None)),) + tag + (out,)
     return out
+
+
+_wt_table = None     # (signature, device int64 table [n,5], blocks per item)
+
+
+def refresh_transposes():
+    """Re-transpose EVERY cached weight in one launch (call once per step, after the optimizer update): ~100 weights would
+    otherwise each pay their own launch the first time a data-gradient GEMM touches them."""
+    global _wt_table
+    entries = []
+    for key, hit in list(_wt_cache.items()):
+        W = hit[0]()
+        if W is not None and hit[2:6] == (W.data_ptr(),) + tuple(hit[3:6]) and W.data_ptr() == hit[2]:
+            entries.append((key, W, hit))
+    if len(entries) < 2:
+        return
+    sig = tuple((h[2], h[6].data_ptr(), h[5], h[3], h[4]) for _, _, h in entries)       # (in, out, ld, rows, cols)
+    if _wt_table is None or _wt_table[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            return                            # the table is host-built: it must exist before capture (warm-up steps build it)
+        rows = [[i, o, ld, n, k] for (i, o, ld, n, k) in sig]
+        dev = entries[0][1].device
+        tiles = max(((n + 31) // 32) * ((k + 31) // 32) for (_, _, _, n, k) in sig)
+        _wt_table = (sig, torch.tensor(rows, dtype=torch.int64, device=dev), int(min(tiles, 64)))
+    call("mdvit_transpose_many", _p(_wt_table[1]), len(entries), _wt_table[2], _stream())
+    for key, W, hit in entries:
+        _wt_cache[key] = (hit[0], W._version) + tuple(hit[2:])
 
 
 def _dgrad(g, W, dx, M, K, N, ldb, **kw):

@@ -36,6 +36,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
       grad(aux)].  Sweep 1 therefore runs data-gradients-only (no wgrad GEMMs / reductions) and hands every domain adapter
       MINUS its aux gradient; sweep 2 is one ordinary backward of aux + uni."""
     da = _da_params(model)
+    ops.refresh_transposes()          # the W^T copies of the bf16x3 data-gradient GEMMs follow the last optimizer update (one launch)
     if accumulator is not None:
         accumulator.zero()
     elif reducer is not None:

@@ -91,8 +91,15 @@ def test_weight_transpose_cache_follows_updates():
     assert ops.wt(W) is t1                              # cached while the parameter is unchanged
     with torch.no_grad():
         W.add_(1.0)                                     # an optimizer step bumps the version counter
-    t2 = ops.wt(W)
-    assert t2 is not t1 and torch.equal(t2, W.detach().t().contiguous())
+    t2 = ops.wt(W)                                      # refreshed into the same buffer
+    assert t2 is t1 and torch.equal(t2, W.detach().t().contiguous())
+    W2 = torch.nn.Parameter(rnd(40, 72, seed=11).to(dev()))
+    u1 = ops.wt(W2)
+    with torch.no_grad():
+        W.mul_(0.5); W2.sub_(2.0)
+    ops.refresh_transposes()                            # one launch for every cached weight
+    assert torch.equal(t1, W.detach().t().contiguous()) and torch.equal(u1, W2.detach().t().contiguous())
+    assert ops.wt(W) is t1 and ops.wt(W2) is u1
     Wv = torch.nn.Parameter(rnd(64, 320, seed=10).to(dev()))
     assert torch.equal(ops.wt(Wv[:, 128:192]), Wv.detach()[:, 128:192].t().contiguous())   # column-slice view
 
