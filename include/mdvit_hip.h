@@ -213,8 +213,15 @@ int mdvit_factoratt_wgrad(const float* qkv, void* ws, size_t ws_bytes, float* dw
  * losses[0] = BCE(s(out),y)+Dice(s(out),y); [1] = same for aux; [2] = Dice(s(aux), s(out)).  aux may be NULL.
  * sums: 16 doubles of scratch kept for backward.  g: 3 upstream gradients (device memory). */
 int mdvit_seg_losses_fwd(const float* out, const float* aux, const float* label, double* sums, float* losses, int64_t n, void* stream);
+/* The same in two halves, for data parallelism: nn.DataParallel gathers the replicas' outputs and takes BCE / Dice over the
+ * GLOBAL batch (multi_train_MDViT.py:72-74,147-153).  Each rank runs _sums on its n local elements, the 16 doubles are
+ * all-reduced (sum), _final turns them into the global losses with n_total = n * world.  In _bwd, n stays the LOCAL count
+ * and dice_gain = world: local logit gradients are world * dL_global/dlogits, which the gradient AVERAGE over ranks turns
+ * into dL_global/dtheta.  (Single process: dice_gain = 1, n_total = n -- identical to mdvit_seg_losses_fwd.) */
+int mdvit_seg_losses_sums(const float* out, const float* aux, const float* label, double* sums, int64_t n, void* stream);
+int mdvit_seg_losses_final(const double* sums, float* losses, int64_t n_total, int32_t has_aux, void* stream);
 int mdvit_seg_losses_bwd(const float* out, const float* aux, const float* label, const double* sums, const float* g,
-                         float* dout, float* daux, int64_t n, void* stream);
+                         float* dout, float* daux, int64_t n, float dice_gain, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,9 +45,10 @@ __global__ void seg_losses_final_kernel(const double* __restrict__ sums, float* 
 // d/ds Dice(s,t) = -(2 t D - (2I+eps) 2 s) / D^2,  D = sum s^2 + sum t^2 + eps
 __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float* __restrict__ out, const float* __restrict__ aux,
                                                              const float* __restrict__ label, const double* __restrict__ sums,
-                                                             const float* __restrict__ g, float* __restrict__ dout, float* __restrict__ daux, long n) {
+                                                             const float* __restrict__ g, float* __restrict__ dout, float* __restrict__ daux, long n,
+                                                             float dice_gain) {
     const float eps = 1e-5f, invN = 1.0f / (float)n;
-    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float g0 = g[0], g1 = g[1], g2 = g[2] * dice_gain;
     const float D_o = (float)(sums[2] + sums[3]) + eps, I_o = 2.f * (float)sums[1] + eps;
     const float D_a = (float)(sums[6] + sums[3]) + eps, I_a = 2.f * (float)sums[5] + eps;
     const float D_k = (float)(sums[6] + sums[2]) + eps, I_k = 2.f * (float)sums[7] + eps;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float* __rest
         if (aux) a = sigmoid_f(aux[i]);
         if (dout) {
             const float dbce = (o - y) / fmaxf((1.f - o) * o, 1e-12f) * invN;
-            const float ddice = -(2.f * y * D_o - I_o * 2.f * o) / (D_o * D_o);
+            const float ddice = -(2.f * y * D_o - I_o * 2.f * o) / (D_o * D_o) * dice_gain;
             go = g0 * (dbce + ddice);
             if (aux) go += g2 * (-(2.f * a * D_k - I_k * 2.f * o) / (D_k * D_k));
             dout[i] = go * so;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float* __rest
         if (aux && daux) {
             const float sa = a * (1.f - a);
             const float dbce = (a - y) / fmaxf((1.f - a) * a, 1e-12f) * invN;
-            const float ddice = -(2.f * y * D_a - I_a * 2.f * a) / (D_a * D_a);
+            const float ddice = -(2.f * y * D_a - I_a * 2.f * a) / (D_a * D_a) * dice_gain;
             const float dkt = -(2.f * o * D_k - I_k * 2.f * a) / (D_k * D_k);
             daux[i] = (g1 * (dbce + ddice) + g2 * dkt) * sa;
         }
@@ -75,22 +76,43 @@ __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int mdvit_seg_losses_fwd(const float* out, const float* aux, const float* label, double* sums, float* losses, int64_t n, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    MDVIT_CHECK_ARG(out && label && sums && losses && n > 0, MDVIT_E_SHAPE, "seg_losses_fwd: bad arguments");
+static int seg_sums(const float* out, const float* aux, const float* label, double* sums, int64_t n, hipStream_t s) {
     MDVIT_ZERO(sums, sizeof(double) * 16, s);
     const int grid = (int)((n + 256L * 8 - 1) / (256L * 8) < 1024 ? (n + 256L * 8 - 1) / (256L * 8) : 1024);
     hipLaunchKernelGGL(seg_losses_sums_kernel, dim3(grid), dim3(256), 0, s, out, aux, label, sums, (long)n);
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_seg_losses_sums(const float* out, const float* aux, const float* label, double* sums, int64_t n, void* stream) {
+    MDVIT_CHECK_ARG(out && label && sums && n > 0, MDVIT_E_SHAPE, "seg_losses_sums: bad arguments");
+    const int rc = seg_sums(out, aux, label, sums, n, (hipStream_t)stream);
+    if (rc != MDVIT_OK) return rc;
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_seg_losses_final(const double* sums, float* losses, int64_t n_total, int32_t has_aux, void* stream) {
+    MDVIT_CHECK_ARG(sums && losses && n_total > 0, MDVIT_E_SHAPE, "seg_losses_final: bad arguments");
+    hipLaunchKernelGGL(seg_losses_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, losses, (long)n_total, has_aux);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_seg_losses_fwd(const float* out, const float* aux, const float* label, double* sums, float* losses, int64_t n, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(out && label && sums && losses && n > 0, MDVIT_E_SHAPE, "seg_losses_fwd: bad arguments");
+    const int rc = seg_sums(out, aux, label, sums, n, s);
+    if (rc != MDVIT_OK) return rc;
     hipLaunchKernelGGL(seg_losses_final_kernel, dim3(1), dim3(64), 0, s, sums, losses, (long)n, aux != nullptr);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
 
 extern "C" int mdvit_seg_losses_bwd(const float* out, const float* aux, const float* label, const double* sums, const float* g,
-                                    float* dout, float* daux, int64_t n, void* stream) {
+                                    float* dout, float* daux, int64_t n, float dice_gain, void* stream) {
     MDVIT_CHECK_ARG(out && label && sums && g && n > 0, MDVIT_E_SHAPE, "seg_losses_bwd: bad arguments");
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, aux, label, sums, g, dout, daux, (long)n);
+    hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, aux, label, sums, g, dout, daux, (long)n, dice_gain);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

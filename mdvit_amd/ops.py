@@ -1050,6 +1050,27 @@ def domain_adapter(label, W1, b1, W2, b2, heads):
 # ------------------------------------------------------------------------------------------------
 # fused step losses on logits
 # ------------------------------------------------------------------------------------------------
+# Data parallelism: losses over the global batch (see mdvit_seg_losses_sums in the header).  On by default whenever a
+# process group with more than one rank is initialised; set_global_batch_losses(False) gives per-rank losses instead.
+_loss_global = True
+_loss_group = None
+
+
+def set_global_batch_losses(flag: bool = True, group=None):
+    global _loss_global, _loss_group
+    _loss_global, _loss_group = bool(flag), group
+
+
+_force_collectives = False       # tests: take the collective code paths even in a 1-rank process group
+
+
+def _loss_world() -> int:
+    import torch.distributed as dist
+    if not (_loss_global and dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(_loss_group)
+
+
 class _SegLosses(torch.autograd.Function):
     """Three scalar outputs so that a backward() that involves only some of them (the aux sweep) hands back
     None -- not a zero tensor -- for the logits that take no part (multi_train_MDViT.py:201)."""
@@ -1060,7 +1081,15 @@ class _SegLosses(torch.autograd.Function):
         n = out.numel()
         sums = _empty((16,), device=out.device, dtype=torch.float64)
         losses = _empty((3,), device=out.device, dtype=torch.float32)
-        call("mdvit_seg_losses_fwd", _p(out), _p(aux), _p(label), _p(sums), _p(losses), n, _stream())
+        world = _loss_world()
+        if world > 1 or (_force_collectives and torch.distributed.is_initialized()):
+            # nn.DataParallel semantics: BCE / Dice over the GLOBAL batch of the domain (the replicas' outputs gathered)
+            call("mdvit_seg_losses_sums", _p(out), _p(aux), _p(label), _p(sums), n, _stream())
+            torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM, group=_loss_group)
+            call("mdvit_seg_losses_final", _p(sums), _p(losses), n * world, int(aux is not None), _stream())
+        else:
+            call("mdvit_seg_losses_fwd", _p(out), _p(aux), _p(label), _p(sums), _p(losses), n, _stream())
+        ctx.dice_gain = float(world)
         ctx.save_for_backward(out, aux, label, sums)
         ctx.set_materialize_grads(False)
         return losses[0].clone(), losses[1].clone(), losses[2].clone()
@@ -1083,7 +1112,7 @@ class _SegLosses(torch.autograd.Function):
         dout = _empty_like(out) if need_out else None
         daux = _empty_like(aux) if need_aux else None
         if need_out or need_aux:
-            call("mdvit_seg_losses_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(g), _p(dout), _p(daux), n, _stream())
+            call("mdvit_seg_losses_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(g), _p(dout), _p(daux), n, ctx.dice_gain, _stream())
         return dout, daux, None
 
 

@@ -150,7 +150,8 @@ class GradAccumulator:
         if dst:
             torch._foreach_add_(dst, src)
         if last:
-            if self.world > 1:
+            from . import ops as _ops
+            if self.world > 1 or (_ops._force_collectives and dist.is_initialized()):
                 # ONE all-reduce per bucket per step over RCCL/xGMI, all in flight together (35 M parameters = 140 MB:
                 # ~1-2 ms on 8 GPUs against a ~60 ms step, so it is not worth giving up the side-stream weight gradients
                 # -- which bypass autograd's hooks -- to overlap it with the backward)

@@ -522,6 +522,39 @@ def test_seg_losses(golden):
     assert abs(float(l0[0]) - float(ref0)) < 1e-5 * abs(float(ref0))
 
 
+def test_seg_losses_global_batch_two_ranks_emulated():
+    """Data-parallel loss semantics (nn.DataParallel: Dice / BCE over the gathered global batch): two 'ranks' on one GPU --
+    each runs _sums on its half, the 16 doubles are added (the all-reduce), _final / _bwd use the global sums with
+    n_total = 2n and dice_gain = 2.  Losses must equal the full-batch losses; the rank's logit gradients, divided by the
+    world size (the gradient average), must equal the full-batch gradients of its half."""
+    import ctypes as C
+    from mdvit_amd import ops
+    from mdvit_amd._lib import call
+    from oracle.gen_golden import synth_label, synth_tokens
+    o = (synth_tokens(7, 1, (4, 1, 32, 32)) * 4.0).to(dev())
+    a = (synth_tokens(7, 2, (4, 1, 32, 32)) * 4.0).to(dev())
+    lab = synth_label(7, 4, 32, 32).to(dev())
+    of, af = o.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    lf = ops.seg_losses(of, af, lab)
+    (lf[1] + 0.5 * lf[2] + 0.5 * lf[0]).backward()
+    p, st = ops._p, ops._stream()
+    halves = [(o[:2].contiguous(), a[:2].contiguous(), lab[:2].contiguous()), (o[2:].contiguous(), a[2:].contiguous(), lab[2:].contiguous())]
+    n = halves[0][0].numel()
+    sums = [torch.zeros(16, device=dev(), dtype=torch.float64) for _ in halves]
+    for (oh, ah, lh), sm in zip(halves, sums):
+        call("mdvit_seg_losses_sums", p(oh), p(ah), p(lh), p(sm), n, st)
+    glob = sums[0] + sums[1]
+    losses = torch.zeros(3, device=dev())
+    call("mdvit_seg_losses_final", p(glob), p(losses), 2 * n, 1, st)
+    check(losses, torch.stack(lf).detach(), tol=1e-6, name="global losses")
+    g = torch.tensor([0.5, 1.0, 0.5], device=dev())
+    for r, (oh, ah, lh) in enumerate(halves):
+        do, da = torch.empty_like(oh), torch.empty_like(ah)
+        call("mdvit_seg_losses_bwd", p(oh), p(ah), p(lh), p(glob), p(g), p(do), p(da), n, 2.0, st)
+        check(do / 2, of.grad[2 * r:2 * r + 2], tol=1e-5, name=f"d out rank {r}")
+        check(da / 2, af.grad[2 * r:2 * r + 2], tol=1e-5, name=f"d aux rank {r}")
+
+
 def test_abi_error_reporting():
     from mdvit_amd import ops, _lib
     x = torch.zeros(4, 6, device=dev())        # K = 6 is not a multiple of 4 -> MDVIT_E_ALIGN, not a crash

@@ -2,6 +2,8 @@
   (1) the committed golden vectors the real reference produced (tests/golden/*.npz), and
   (2) the CPU oracle on the same seeded inputs,
 plus the drop-in surface (state_dict names, two backward() calls on one graph, requires_grad flips)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -463,3 +465,50 @@ def test_graphed_step_matches_eager_step():
         assert abs(a - b) <= 2e-4 * abs(a), (res[0][0], res[1][0])
     for n in res[0][1]:
         check(res[1][1][n], res[0][1][n], tol=2e-3, name=n)
+
+
+_DP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29581"), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import mdvit_amd
+from mdvit_amd import ops
+from mdvit_amd.parallel import GradAccumulator, broadcast_parameters
+from mdvit_amd.synthetic import make_step_batches
+from mdvit_amd.train import mdvit_train_step
+res = []
+for force in (False, True):
+    ops._force_collectives = force            # RCCL all-reduce of the loss sums and of the gradient buckets, world = 1
+    torch.manual_seed(0)
+    m = mdvit_amd.MDViT(img_size=64, drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup",
+                        num_domains=4, decoder_name="MLPFM").cuda().train()
+    for d in range(1, 5):
+        getattr(m, f"debranch{d}").dropout.p = 0.0
+    broadcast_parameters(m)
+    ops.enable_side_stream(True)
+    acc = GradAccumulator(m.parameters()); acc.attach_sinks()
+    b = make_step_batches(2, 64, rank=0, step=0, device=torch.device("cuda", 0))
+    out = mdvit_train_step(m, b, optimizer=None, accumulator=acc, merged_sweeps=True, fuse_domains=4)
+    torch.cuda.synchronize()
+    res.append(([float(out[k]) for k in ("loss", "aux_loss", "kt_loss")], [p.grad.clone() for p in m.parameters()]))
+    ops.set_grad_sinks(None); ops.enable_side_stream(False)
+for a, b in zip(res[0][0], res[1][0]):
+    assert abs(a - b) <= 1e-5 * abs(a), (res[0][0], res[1][0])
+worst = max(float((x - y).norm() / (y.norm() + 1e-20)) for x, y in zip(res[1][1], res[0][1]))
+assert worst < 2e-3, worst
+dist.barrier(); dist.destroy_process_group()
+print("dp-path ok", worst)
+"""
+
+
+def test_data_parallel_code_path_on_one_gpu(tmp_path):
+    """the collective code paths of the DP step (RCCL all-reduce of the 16 loss sums per domain and of the gradient buckets,
+    side-stream weight gradients into the buckets) run in a 1-rank NCCL group and reproduce the plain step"""
+    import subprocess, sys
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "dp-path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
