@@ -156,6 +156,22 @@ def main():
     value = imgs_per_step * args.steps / dt
     loss_val = float(last["loss"]) if last is not None else float("nan")
 
+    # fwd / bwd / optimizer split (the metric's "fwd+bwd ms"): two extra, untimed, instrumented steps -- each phase ends with an
+    # event on the main stream (the backward's events come after the side stream has been joined)
+    phase_ms = None
+    if args.model == "mdvit" and not args.graph:
+        acc_ms = {"fwd": 0.0, "bwd": 0.0, "opt": 0.0}
+        reps = 2
+        for i in range(reps):
+            evs = []
+            mdvit_train_step(model, pool[i % len(pool)], optimizer=opt, accumulator=accum, merged_sweeps=not args.reference_sweeps,
+                             fuse_domains=fuse, phase_events=evs)
+            torch.cuda.synchronize()
+            for (_, e0), (tag, e1) in zip(evs[:-1], evs[1:]):
+                acc_ms[tag] += e0.elapsed_time(e1)
+        phase_ms = {"fwd_incl_losses": round(acc_ms["fwd"] / reps, 3), "bwd_two_sweeps_incl_grad_accumulation": round(acc_ms["bwd"] / reps, 3),
+                    "optimizer": round(acc_ms["opt"] / reps, 3)}
+
     if rank == 0:
         roof = None
         if table:
@@ -196,7 +212,7 @@ def main():
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
             "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),
-            "roofline": roof, "cpu_baseline": cpu,
+            "phase_ms": phase_ms, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -27,7 +27,7 @@ def _da_params(model):
 def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: float = 0.5, num_domains: int = 4,
                      reducer: Optional[GradBucketReducer] = None, per_domain_backward: bool = True,
                      use_domain_label: bool = True, accumulator: Optional[GradAccumulator] = None,
-                     merged_sweeps: bool = False, fuse_domains: int = 1) -> Dict[str, torch.Tensor]:
+                     merged_sweeps: bool = False, fuse_domains: int = 1, phase_events: Optional[list] = None) -> Dict[str, torch.Tensor]:
     """batches: [(img (B,3,H,W), label (B,1,H,W), set_id (B,) int64)] one per domain.
     Returns the summed losses as device tensors (no host sync inside the step).
     accumulator: fused gradient accumulation (+ overlapped all-reduce when world_size > 1), see parallel.GradAccumulator.
@@ -74,8 +74,15 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
             p.requires_grad = True
         sweep(uni, last)
 
+    def mark(tag):          # optional phase timing (bench.py): an event per phase boundary on the main stream
+        if phase_events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            phase_events.append((tag, e))
+
     tot = tot_aux = tot_kt = None
     stash = []
+    mark("start")
     for i, batch in enumerate(batches):
         img, label, set_id = batch[0], batch[1], batch[2]
         # set_id is a HOST tensor, as from the DataLoader (multi_train_MDViT.py:137-139): reading set_id[0] must not
@@ -101,16 +108,20 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
         tot = l.detach() if tot is None else tot + l.detach()
         tot_aux = la.detach() if tot_aux is None else tot_aux + la.detach()
         tot_kt = lk.detach() if tot_kt is None else tot_kt + lk.detach()
+        mark("fwd")
         if per_domain_backward:
             two_sweeps(la, alpha * lk + (1 - alpha) * l, last=(i == len(batches) - 1))
+            mark("bwd")
         else:
             stash.append((l, la, lk))
     if not per_domain_backward:
         two_sweeps(sum(s[1] for s in stash), alpha * sum(s[2] for s in stash) + (1 - alpha) * sum(s[0] for s in stash), last=True)
+        mark("bwd")
     if accumulator is None and reducer is not None:
         reducer.finish()
     if optimizer is not None:
         optimizer.step()
+        mark("opt")
     return {"loss": tot, "aux_loss": tot_aux, "kt_loss": tot_kt}
 
 
