@@ -223,6 +223,16 @@ int mdvit_seg_losses_final(const double* sums, float* losses, int64_t n_total, i
 int mdvit_seg_losses_bwd(const float* out, const float* aux, const float* label, const double* sums, const float* g,
                          float* dout, float* daux, int64_t n, float dice_gain, void* stream);
 
+/* ---- on-device metrics and input pipeline --------------------------------------------------------------
+ * Dice / IoU of the thresholded outputs, multi_train_MDViT.py:172-179,275-288 (medpy.metric.binary dc / jc, v0.4.0:
+ * dc = 2|A&Y| / (|A|+|Y|), jc = |A&Y| / |A|Y|) with A = sigmoid(logits) > 0.5, Y = label != 0 -- computed where the logits
+ * live instead of `.cpu().numpy()` per domain.  counts: 8 uint64 of scratch (exact integer counts: |A&Y|, |A|, |Y|,
+ * |Aaux&Y|, |Aaux|); metrics: {dice, iou, aux dice, aux iou} (0 where medpy divides 0/0).  aux may be NULL. */
+int mdvit_seg_metrics(const float* out, const float* aux, const float* label, uint64_t* counts, float* metrics, int64_t n, void* stream);
+/* uint8 HWC image [B,H,W,3] -> fp32 CHW [B,3,H,W]:  ((float)(u8 / 255.0) - mean[c]) / std[c]  with the ImageNet mean / std
+ * (create_dataset.py:25-26 norm01, :143-144,165-172 permute + transforms.Normalize), bit-exact with that sequence. */
+int mdvit_image_normalize_u8(const uint8_t* img_nhwc, float* out_nchw, int32_t B, int32_t H, int32_t W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,78 @@ __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float* __rest
 
 }  // namespace
 
+// ---- on-device segmentation metrics (multi_train_MDViT.py:172-179,275-288 with medpy.metric.binary dc / jc) ------------
+// counts (int64): 0 |A&Y|  1 |A|  2 |Y|  3 |Aaux&Y|  4 |Aaux|,  A = sigmoid(out) > 0.5, Y = label != 0
+namespace {
+__global__ __launch_bounds__(256) void seg_metric_counts_kernel(const float* __restrict__ out, const float* __restrict__ aux,
+                                                                const float* __restrict__ label, unsigned long long* __restrict__ counts, long n) {
+    unsigned int c[5] = {0, 0, 0, 0, 0};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const bool y = label[i] != 0.f, a = sigmoid_f(out[i]) > 0.5f;
+        c[0] += a && y; c[1] += a; c[2] += y;
+        if (aux) { const bool b = sigmoid_f(aux[i]) > 0.5f; c[3] += b && y; c[4] += b; }
+    }
+    __shared__ unsigned int s_c[4][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        unsigned int v = c[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_c[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(&counts[threadIdx.x], (unsigned long long)(s_c[0][threadIdx.x] + s_c[1][threadIdx.x] + s_c[2][threadIdx.x] + s_c[3][threadIdx.x]));
+}
+
+// metrics: 0 dice(out)  1 iou(out)  2 dice(aux)  3 iou(aux);  0/0 -> 0 (medpy's dc returns 0.0 there; its jc would raise)
+__global__ void seg_metric_final_kernel(const unsigned long long* __restrict__ counts, float* __restrict__ metrics, int has_aux) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double i0 = (double)counts[0], a0 = (double)counts[1], y = (double)counts[2];
+        metrics[0] = (a0 + y) > 0 ? (float)(2.0 * i0 / (a0 + y)) : 0.f;
+        metrics[1] = (a0 + y - i0) > 0 ? (float)(i0 / (a0 + y - i0)) : 0.f;
+        const double i1 = (double)counts[3], a1 = (double)counts[4];
+        metrics[2] = has_aux && (a1 + y) > 0 ? (float)(2.0 * i1 / (a1 + y)) : 0.f;
+        metrics[3] = has_aux && (a1 + y - i1) > 0 ? (float)(i1 / (a1 + y - i1)) : 0.f;
+    }
+}
+
+// ---- input pipeline: uint8 HWC image -> ImageNet-normalised fp32 CHW (create_dataset.py:25-26,143-144,165-172) --------
+// norm01 divides in float64 and the result is cast to float32; Normalize then subtracts the mean and divides by the std in fp32
+__global__ __launch_bounds__(256) void image_normalize_u8_kernel(const unsigned char* __restrict__ img, float* __restrict__ out, int B, int H, int W) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const long npix = (long)B * H * W;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const long b = p / ((long)H * W), hw = p % ((long)H * W);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)((double)img[p * 3 + c] / 255.0);
+            out[(b * 3 + c) * (long)H * W + hw] = (v - mean[c]) / stdv[c];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mdvit_seg_metrics(const float* out, const float* aux, const float* label, uint64_t* counts, float* metrics, int64_t n, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(out && label && counts && metrics && n > 0, MDVIT_E_SHAPE, "seg_metrics: bad arguments");
+    MDVIT_ZERO(counts, sizeof(uint64_t) * 8, s);
+    const int grid = (int)((n + 256L * 8 - 1) / (256L * 8) < 1024 ? (n + 256L * 8 - 1) / (256L * 8) : 1024);
+    hipLaunchKernelGGL(seg_metric_counts_kernel, dim3(grid), dim3(256), 0, s, out, aux, label, (unsigned long long*)counts, (long)n);
+    hipLaunchKernelGGL(seg_metric_final_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)counts, metrics, aux != nullptr);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_image_normalize_u8(const uint8_t* img_nhwc, float* out_nchw, int32_t B, int32_t H, int32_t W, void* stream) {
+    MDVIT_CHECK_ARG(img_nhwc && out_nchw && B > 0 && H > 0 && W > 0, MDVIT_E_SHAPE, "image_normalize_u8: bad arguments");
+    const long npix = (long)B * H * W;
+    hipLaunchKernelGGL(image_normalize_u8_kernel, dim3((int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream,
+                       img_nhwc, out_nchw, B, H, W);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
 static int seg_sums(const float* out, const float* aux, const float* label, double* sums, int64_t n, hipStream_t s) {
     MDVIT_ZERO(sums, sizeof(double) * 16, s);
     const int grid = (int)((n + 256L * 8 - 1) / (256L * 8) < 1024 ? (n + 256L * 8 - 1) / (256L * 8) : 1024);

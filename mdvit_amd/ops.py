@@ -1119,3 +1119,29 @@ class _SegLosses(torch.autograd.Function):
 def seg_losses(out, aux, label):
     """logits -> (BCE+Dice(out), BCE+Dice(aux), Dice(sigmoid(aux), sigmoid(out))) as three 0-dim tensors."""
     return _SegLosses.apply(_c(out), None if aux is None else _c(aux), _c(label.float()))
+
+
+# ------------------------------------------------------------------------------------------------
+# on-device metrics and input pipeline (no autograd)
+# ------------------------------------------------------------------------------------------------
+def seg_metrics(out, aux, label):
+    """logits, logits | None, label -> (metrics [4] f32 = dice, iou, aux dice, aux iou; counts [8] int64) on the device:
+    the thresholded-output Dice / IoU of multi_train_MDViT.py:172-179 without a device-to-host copy per domain."""
+    out, label = _c(out.detach()), _c(label.detach().float())
+    aux = None if aux is None else _c(aux.detach())
+    _chk(out, aux, label)
+    counts = torch.empty((8,), device=out.device, dtype=torch.int64)
+    metrics = torch.empty((4,), device=out.device, dtype=torch.float32)
+    call("mdvit_seg_metrics", _p(out), _p(aux), _p(label), _p(counts), _p(metrics), out.numel(), _stream())
+    return metrics, counts
+
+
+def image_normalize_u8(img_u8_nhwc):
+    """uint8 [B,H,W,3] on the device -> ImageNet-normalised fp32 [B,3,H,W] (the loader's norm01 + permute + Normalize)."""
+    if img_u8_nhwc.dtype != torch.uint8 or img_u8_nhwc.dim() != 4 or img_u8_nhwc.shape[-1] != 3 or not img_u8_nhwc.is_cuda:
+        raise _lib.MdvitHipError("image_normalize_u8 expects a CUDA uint8 tensor [B,H,W,3]")
+    x = _c(img_u8_nhwc)
+    B, H, W_, _ = x.shape
+    y = torch.empty((B, 3, H, W_), device=x.device, dtype=torch.float32)
+    call("mdvit_image_normalize_u8", _p(x), _p(y), B, H, W_, _stream())
+    return y

@@ -27,7 +27,8 @@ def _da_params(model):
 def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: float = 0.5, num_domains: int = 4,
                      reducer: Optional[GradBucketReducer] = None, per_domain_backward: bool = True,
                      use_domain_label: bool = True, accumulator: Optional[GradAccumulator] = None,
-                     merged_sweeps: bool = False, fuse_domains: int = 1, phase_events: Optional[list] = None) -> Dict[str, torch.Tensor]:
+                     merged_sweeps: bool = False, fuse_domains: int = 1, phase_events: Optional[list] = None,
+                     with_metrics: bool = False) -> Dict[str, torch.Tensor]:
     """batches: [(img (B,3,H,W), label (B,1,H,W), set_id (B,) int64)] one per domain.
     Returns the summed losses as device tensors (no host sync inside the step).
     accumulator: fused gradient accumulation (+ overlapped all-reduce when world_size > 1), see parallel.GradAccumulator.
@@ -82,6 +83,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
 
     tot = tot_aux = tot_kt = None
     stash = []
+    metric_rows = []        # per domain [dice, iou, aux dice, aux iou] of the thresholded outputs, kept on the device
     mark("start")
     for i, batch in enumerate(batches):
         img, label, set_id = batch[0], batch[1], batch[2]
@@ -99,6 +101,10 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
             out, aux = model(img, domain_label, d)
         else:
             out, aux = model(img, d=d)
+        if with_metrics:       # multi_train_MDViT.py:172-179, without the per-domain .cpu().numpy()
+            for g in range(G):
+                metric_rows.append(ops.seg_metrics(out[g * Bd:(g + 1) * Bd], None if aux is None else aux[g * Bd:(g + 1) * Bd],
+                                                   label[g * Bd:(g + 1) * Bd])[0])
         if G == 1:
             l, la, lk = domain_losses(out, aux, label)
         else:       # per-domain BCE/Dice/KT (each a mean over ITS batch, multi_train_MDViT.py:147-153), then summed
@@ -122,7 +128,10 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
     if optimizer is not None:
         optimizer.step()
         mark("opt")
-    return {"loss": tot, "aux_loss": tot_aux, "kt_loss": tot_kt}
+    res = {"loss": tot, "aux_loss": tot_aux, "kt_loss": tot_kt}
+    if with_metrics:
+        res["metrics"] = torch.stack(metric_rows)          # [domains, 4]
+    return res
 
 
 def _fuse_batches(batches, fuse_domains, num_domains, use_domain_label):

@@ -555,6 +555,39 @@ def test_seg_losses_global_batch_two_ranks_emulated():
         check(da / 2, af.grad[2 * r:2 * r + 2], tol=1e-5, name=f"d aux rank {r}")
 
 
+def test_seg_metrics_counts_are_exact():
+    """thresholded Dice / IoU on the device == medpy's dc / jc (restated in oracle/pipeline.py): integer counts bit-exact"""
+    import numpy as np
+    from mdvit_amd import ops
+    from oracle import pipeline as P
+    from oracle.gen_golden import synth_label, synth_tokens
+    o = synth_tokens(11, 1, (3, 1, 40, 56)) * 3.0
+    a = synth_tokens(11, 2, (3, 1, 40, 56)) * 3.0
+    lab = synth_label(11, 3, 40, 56)
+    m, c = ops.seg_metrics(o.to(dev()), a.to(dev()), lab.to(dev()))
+    ob, ab, yb = torch.sigmoid(o).numpy() > 0.5, torch.sigmoid(a).numpy() > 0.5, lab.numpy().astype(bool)
+    want = [np.count_nonzero(ob & yb), np.count_nonzero(ob), np.count_nonzero(yb), np.count_nonzero(ab & yb), np.count_nonzero(ab)]
+    assert c[:5].tolist() == want
+    ref = [P.dc(ob, yb), P.jc(ob, yb), P.dc(ab, yb), P.jc(ab, yb)]
+    assert np.allclose(m.cpu().numpy(), np.array(ref, dtype=np.float32), rtol=1e-6, atol=0)
+    d0, j0 = P.train_metrics(o, lab)
+    assert abs(float(m[0]) - d0) < 1e-6 and abs(float(m[1]) - j0) < 1e-6
+    m2, c2 = ops.seg_metrics(torch.full((1, 1, 8, 8), -5.0, device=dev()), None, torch.zeros(1, 1, 8, 8, device=dev()))
+    assert m2.tolist() == [0.0, 0.0, 0.0, 0.0] and c2[:3].tolist() == [0, 0, 0]
+
+
+def test_image_normalize_u8_bit_exact():
+    """uint8 HWC -> normalised fp32 CHW on the device == the loader's norm01 + permute + Normalize sequence, bit for bit"""
+    from mdvit_amd import ops
+    from oracle import pipeline as P
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (2, 37, 53, 3), generator=g, dtype=torch.uint8)
+    u8[0, 0, 0] = torch.tensor([0, 255, 128], dtype=torch.uint8)
+    got = ops.image_normalize_u8(u8.to(dev())).cpu()
+    want = torch.stack([P.load_image(u8[b].numpy()) for b in range(2)])
+    assert torch.equal(got, want)
+
+
 def test_abi_error_reporting():
     from mdvit_amd import ops, _lib
     x = torch.zeros(4, 6, device=dev())        # K = 6 is not a multiple of 4 -> MDVIT_E_ALIGN, not a crash

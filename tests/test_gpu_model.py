@@ -361,6 +361,25 @@ def _four_domain_batches(seed, B=2, size=64):
              torch.full((B,), d, dtype=torch.long)) for d in range(4)]
 
 
+def test_train_step_metrics_on_device_match_host_restatement():
+    """with_metrics=True: per-domain Dice / IoU of the thresholded logits, computed on the device inside the step, equal
+    medpy's dc / jc (oracle/pipeline.py) of the same logits taken to the host -- for fused and per-domain forwards"""
+    from mdvit_amd.train import mdvit_train_step
+    from oracle import pipeline as P
+    batches = _four_domain_batches(1400)
+    m = build_mdvit(29, 64).eval()                 # eval: the two calls below see identical logits
+    with torch.no_grad():
+        logits = [m(b[0], F.one_hot(b[2], 4).float().to(dev()), str(d))[0] for d, b in enumerate(batches)]
+    want = [P.train_metrics(lg.cpu(), b[1].cpu()) for lg, b in zip(logits, batches)]
+    for fuse in (1, 4):
+        out = mdvit_train_step(m, batches, optimizer=None, fuse_domains=fuse, with_metrics=True)
+        got = out["metrics"].cpu()
+        assert got.shape == (4, 4)
+        for d in range(4):
+            assert abs(float(got[d, 0]) - want[d][0]) < 1e-6 and abs(float(got[d, 1]) - want[d][1]) < 1e-6, (fuse, d, got[d], want[d])
+        m.zero_grad(set_to_none=True)
+
+
 @pytest.mark.parametrize("fuse", [2, 4])
 def test_domain_batched_step_equals_per_domain_forwards(fuse):
     """ONE forward over the concatenated domain batches (per-domain BatchNorm statistics, per-domain peer heads and

@@ -167,3 +167,18 @@ def test_losses(golden):
     (0.5 * lk + 0.5 * l).backward()
     close(o.grad, g["d_out_from_uni"], rtol=1e-4, name="d out / uni")
     close(a.grad, g["d_aux_from_uni"], rtol=1e-4, name="d aux / uni")
+
+
+def test_metric_and_loader_restatements_known_answers():
+    """oracle/pipeline.py (medpy dc / jc, the loader's normalisation) on hand-computed cases"""
+    import numpy as np
+    from oracle import pipeline as P
+    a = np.array([[1, 1, 0, 0], [1, 0, 0, 0]]); b = np.array([[1, 0, 0, 0], [1, 1, 0, 1]])
+    assert P.dc(a, b) == 2 * 2 / (3 + 4) and P.jc(a, b) == 2 / 5
+    z = np.zeros((2, 2))
+    assert P.dc(z, z) == 0.0 and P.jc(z, z) == 0.0
+    img = np.array([[[0, 128, 255]]], dtype=np.uint8)
+    t = P.load_image(img)
+    want = [(np.float32(0 / 255) - np.float32(0.485)) / np.float32(0.229), (np.float32(128 / 255) - np.float32(0.456)) / np.float32(0.224),
+            (np.float32(255 / 255) - np.float32(0.406)) / np.float32(0.225)]
+    assert t.shape == (3, 1, 1) and [float(v) for v in t.view(-1)] == [float(w) for w in want]
