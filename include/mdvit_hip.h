@@ -233,6 +233,14 @@ int mdvit_seg_metrics(const float* out, const float* aux, const float* label, ui
  * (create_dataset.py:25-26 norm01, :143-144,165-172 permute + transforms.Normalize), bit-exact with that sequence. */
 int mdvit_image_normalize_u8(const uint8_t* img_nhwc, float* out_nchw, int32_t B, int32_t H, int32_t W, void* stream);
 
+/* ---- AdamW over all parameters in one launch (optim.AdamW, multi_train_MDViT.py:91-93) --------------------
+ * table_dev: device array [n_tensors][5] of int64 {param, grad, exp_avg, exp_avg_sq (pointers), numel}.  step_dev[0] (float
+ * step count) is incremented first, lr_dev[0] is the current learning rate -- both in device memory so that a captured
+ * HIP graph replays the update unchanged while the host moves the schedule.  zero_grad != 0 clears each gradient after use.
+ * Math: torch.optim.AdamW (decoupled decay, bias-corrected, amsgrad off). */
+int mdvit_adamw_step(const void* table_dev, int32_t n_tensors, int32_t blocks_per_tensor, const float* lr_dev, float* step_dev,
+                     float beta1, float beta2, float eps, float weight_decay, int32_t zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ _SIGS = {
     "mdvit_factoratt_wgrad": [vp, vp, C.c_size_t] + [vp] * 6 + [i32] * 9 + [vp],
     "mdvit_factoratt_bwd": [vp] * 22 + [vp, C.c_size_t] + [i32] * 8 + [vp],
     "mdvit_seg_losses_fwd": [vp, vp, vp, vp, vp, i64, vp],
+    "mdvit_adamw_step": [vp, i32, i32, vp, vp, f32, f32, f32, f32, i32, vp],
     "mdvit_seg_metrics": [vp, vp, vp, vp, vp, i64, vp],
     "mdvit_image_normalize_u8": [vp, vp, i32, i32, i32, vp],
     "mdvit_seg_losses_sums": [vp, vp, vp, vp, i64, vp],

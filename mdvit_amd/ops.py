@@ -231,20 +231,28 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
         #  so an event pair around them measures the wait as well; rocprofv3 has their true durations)
         call("mdvit_gemm_f32", C.byref(d), _stream())
         return
-    tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
-    call("mdvit_gemm_plan", C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp))
+    kepi = 1 if epi == _lib.EPI_GELU_DUAL else 2 if epi == _lib.EPI_DGELU else \
+        3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
+    pkey = (M, N, K, bool(trans_a), bool(trans_b), kepi, int(precision), bool(allow_split))
+    plan = _plan_cache.get(pkey)
+    if plan is None:
+        tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+        call("mdvit_gemm_plan", C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp))
+        plan = _plan_cache[pkey] = (tm.value, tn.value, sp.value)
+    tmv, tnv, spv = plan
+    waves = {128: "2, 2", 256: "4, 1", 64: "2, 2"}[tmv]       # kernel symbol as rocprofv3 prints it
+    name = "gemm_f32_kernel<%d, %d, %s, %s, %s, %d, %s>%s" % (
+        tmv, tnv, waves, "true" if trans_a else "false", "true" if trans_b else "false", kepi,
+        "true" if precision else "false", "+splitk_reduce" if spv > 1 else "")
+    if _events_by_shape:
+        name += " M=%d N=%d K=%d sp=%d" % (M, N, K, spv)
+    if _events_only is not None and name != _events_only:
+        call("mdvit_gemm_f32", C.byref(d), _stream())
+        return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     call("mdvit_gemm_f32", C.byref(d), _stream())
     e1.record()
-    waves = {128: "2, 2", 256: "4, 1", 64: "2, 2"}[tm.value]       # kernel symbol as rocprofv3 prints it
-    kepi = 1 if epi == _lib.EPI_GELU_DUAL else 2 if epi == _lib.EPI_DGELU else \
-        3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
-    name = "gemm_f32_kernel<%d, %d, %s, %s, %s, %d, %s>%s" % (
-        tm.value, tn.value, waves, "true" if trans_a else "false", "true" if trans_b else "false", kepi,
-        "true" if precision else "false", "+splitk_reduce" if sp.value > 1 else "")
-    if _events_by_shape:
-        name += " M=%d N=%d K=%d sp=%d" % (M, N, K, sp.value)
     # algorithmic HBM bytes of the launch: A, B read once, C (and C2 / residual / gelu_u) once
     nbytes = 4.0 * (M * K + N * K + M * N * (1 + (out2 is not None) + (residual is not None) + (gelu_u is not None)))
     _events.append((name, 2.0 * M * N * K, nbytes, e0, e1))
@@ -332,18 +340,24 @@ def _dgrad(g, W, dx, M, K, N, ldb, **kw):
 # ---- optional per-kernel timing (bench.py): HIP events on the launch stream around each GEMM ------
 _events = None
 _events_by_shape = False
+_events_only = None
+_plan_cache = {}
 
 
-def kernel_events_begin(by_shape: bool = False):
-    global _events, _events_by_shape
+def kernel_events_begin(by_shape: bool = False, only: Optional[str] = None):
+    """only: time the launches of ONE kernel name (as a previous full pass reported it) -- two events per GEMM on every
+    launch cost ~4 % of a step, two events on the dominant kernel's ~30 launches cost nothing."""
+    global _events, _events_by_shape, _events_only
     _events = []
     _events_by_shape = bool(by_shape)
+    _events_only = only
 
 
 def kernel_events_end():
     """-> {kernel name: {"n", "ms", "flop"}} for the launches since kernel_events_begin()."""
-    global _events
+    global _events, _events_only
     ev, _events = _events, None
+    _events_only = None
     if not ev:
         return {}
     torch.cuda.synchronize()

@@ -588,6 +588,33 @@ def test_image_normalize_u8_bit_exact():
     assert torch.equal(got, want)
 
 
+def test_fused_adamw_matches_torch_adamw():
+    """one-launch AdamW over the accumulator's buckets == torch.optim.AdamW (the reference's optimizer), 4 steps, odd sizes,
+    a learning-rate change in between (StepLR), step counter and lr on the device"""
+    from mdvit_amd.optim import FusedAdamW, StepLR
+    from mdvit_amd.parallel import GradAccumulator
+    shapes = [(64, 33), (7,), (320, 1, 3, 3), (1,), (513,), (128, 64)]
+    ps = [torch.nn.Parameter(rnd(*sh, seed=200 + i).to(dev())) for i, sh in enumerate(shapes)]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    acc = GradAccumulator(ps, bucket_bytes=4096)
+    opt = FusedAdamW(acc, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    ref = torch.optim.AdamW(qs, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    sch, rsch = StepLR(opt, step_size=2, gamma=0.5), torch.optim.lr_scheduler.StepLR(ref, step_size=2, gamma=0.5)
+    for step in range(4):
+        acc.zero()
+        acc.begin_sweep(True)
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            g = rnd(*p.shape, seed=300 + 10 * step + i).to(dev())
+            p.grad = g.clone(); q.grad = g.clone()
+        acc.end_sweep(True)                      # folds p.grad into the buckets, re-points p.grad at the bucket views
+        opt.step(); ref.step()
+        sch.step(); rsch.step()
+        assert abs(sch.get_last_lr()[0] - rsch.get_last_lr()[0]) < 1e-12
+    assert float(opt.step_dev[0]) == 4.0
+    for i, (p, q) in enumerate(zip(ps, qs)):
+        check(p.detach(), q.detach(), tol=2e-6, name=f"param {i} after 4 steps")
+
+
 def test_abi_error_reporting():
     from mdvit_amd import ops, _lib
     x = torch.zeros(4, 6, device=dev())        # K = 6 is not a multiple of 4 -> MDVIT_E_ALIGN, not a crash
