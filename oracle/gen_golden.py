@@ -123,6 +123,52 @@ def gen_mdvit_step(ns, S=64, B=2, seed=0):
     return out
 
 
+def gen_mdvit_dsn_step(ns, S=64, B=2, seed=4):
+    """MDViT_DSN (domain-specific norms, mdvit.py:735-960): 4-domain two-sweep step, train mode."""
+    pn = make_params(seed, model="MDViT_DSN", adapt_method="Sup")
+    m = ns.MDViT_DSN(img_size=S, drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup",
+                     num_domains=4, decoder_name="MLPFM")
+    load_params_into(m, pn)
+    for d in range(1, 5):
+        getattr(m, f"debranch{d}").dropout.p = 0.0
+    m.train()
+    out = {}
+    tot = tot_aux = tot_kt = 0.0
+    bce = torch.nn.BCELoss()
+    for d in range(4):
+        img, lab = synth_image(500 + d, B, S, S), synth_label(600 + d, B, S, S)
+        dl = F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float()
+        o, a = m(img, dl, str(d))
+        out[f"out_{d}"], out[f"aux_{d}"] = _sample(o, 7), _sample(a, 7)
+        so, sa = torch.sigmoid(o), torch.sigmoid(a)
+        l = bce(so, lab) + ns.dice_loss(so, lab)
+        la = bce(sa, lab) + ns.dice_loss(sa, lab)
+        lk = ns.dice_loss(sa, so)
+        out[f"losses_{d}"] = np.array([float(l), float(la), float(lk)])
+        tot, tot_aux, tot_kt = tot + l, tot_aux + la, tot_kt + lk
+    m.zero_grad()
+    for n, p in m.named_parameters():
+        if "domain_layer" in n:
+            p.requires_grad = False
+    tot_aux.backward(retain_graph=True)
+    for n, p in m.named_parameters():
+        if "domain_layer" in n:
+            p.requires_grad = True
+    (0.5 * tot_kt + 0.5 * tot).backward()
+    grads = {n: p.grad for n, p in m.named_parameters()}
+    names, norms, heads = grad_digest(grads)
+    sd = m.state_dict()
+    bn_names = sorted(k for k, (kind, _) in param_spec("MDViT_DSN", "Sup").items() if kind in ("bn_rm", "bn_rv"))
+    out.update(grad_names=np.array(names), grad_norms=norms, grad_heads=heads,
+               bn_names=np.array(bn_names), bn_sums=np.array([float(sd[k].double().sum()) for k in bn_names]),
+               total_losses=np.array([float(tot), float(tot_aux), float(tot_kt)]),
+               n_state_dict_keys=np.array(len(sd)), meta=np.array([S, B, seed]))
+    for n in ("stem_1.bns.2.weight", "mhsa_stages.1.mhca_blks.0.norm1s.3.weight", "bridge_norms2.1.bias",
+              "decoder3.conv_after.bns.0.weight", "stem_2.conv.weight", "decoder2.conv_before.bias"):
+        out["grad::" + n] = grads[n].numpy().copy()
+    return out
+
+
 def gen_mdvit_eval(ns, S=64, B=2, seed=1):
     """eval-mode forward with non-trivial running stats (mdvit.py:667-730)."""
     pn = make_params(seed, model="MDViT", adapt_method="Sup")
@@ -227,7 +273,7 @@ def main():
     torch.set_num_threads(8)
     ns = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    jobs = {"mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
+    jobs = {"mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
             "base_step_64": gen_base_step, "factoratt_small": gen_factoratt, "losses_small": gen_losses}
     only = set(sys.argv[1:])
     for name, fn in jobs.items():

@@ -262,6 +262,21 @@ def mdvit_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, d
     return [logits, aux]
 
 
+def dsn_view(P: Params, d: int, canonical_names) -> Params:
+    """The MDViT-named view of an MDViT_DSN parameter dict for domain d: norms[d] selected (mdvit.py:63-70,169-178,
+    396-412,911-917, Decoders.py:106-118).  Shares the tensors, so BN running statistics update in place."""
+    from .params import dsn_name
+    return {n: P[dsn_name(n, d)[0]] for n in canonical_names}
+
+
+def mdvit_dsn_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, d: Optional[str] = None,
+                      st: Optional[RefState] = None):
+    """MDViT_DSN.forward, mdvit.py:896-960 (decoder_name='MLPFM'): MDViT.forward on the domain's norms."""
+    from .params import param_spec
+    names = param_spec("MDViT", "Sup").keys()
+    return mdvit_forward(dsn_view(P, int(d), names), x, domain_label, d, st)
+
+
 def base_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, st: Optional[RefState] = None) -> Tensor:
     """BASE.forward, base.py:477-512 -> logits tensor."""
     st = st or RefState()
@@ -306,7 +321,7 @@ def domain_losses(out: Tensor, aux: Tensor, label: Tensor):
     return bce_loss(o, label) + dice_loss(o, label), bce_loss(a, label) + dice_loss(a, label), dice_loss(a, o)
 
 
-def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: float = 0.5):
+def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: float = 0.5, forward=None):
     """One optimisation step's losses and gradients, multi_train_MDViT.py:129-207.
 
     batches: list of (img, label, set_id:int) -- one per domain.  Returns (losses dict, grads dict).
@@ -320,7 +335,7 @@ def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: f
     tot, tot_aux, tot_kt = 0.0, 0.0, 0.0
     for img, label, sid in batches:
         dl = F.one_hot(torch.full((img.shape[0],), sid, dtype=torch.long), 4).to(img.dtype)
-        out, aux = mdvit_forward(P, img, dl, str(sid), st)
+        out, aux = (forward or mdvit_forward)(P, img, dl, str(sid), st)
         l, la, lk = domain_losses(out, aux, label)
         tot, tot_aux, tot_kt = tot + l, tot_aux + la, tot_kt + lk
     da = [v for k, v in leaves.items() if "domain_layer" in k]

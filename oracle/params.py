@@ -66,6 +66,8 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
                embed_dims=EMBED_DIMS, mlp_ratios=MLP_RATIOS, num_heads=NUM_HEADS,
                num_layers=NUM_LAYERS, in_chans: int = 3) -> "OrderedDict[str, tuple]":
     """name -> (kind, shape) for every unique parameter and buffer."""
+    if model == "MDViT_DSN":
+        return _dsn_spec(param_spec("MDViT", adapt_method, num_domains, embed_dims, mlp_ratios, num_heads, num_layers, in_chans), num_domains)
     assert model in ("MDViT", "BASE")
     sup = adapt_method == "Sup"
     E = tuple(embed_dims)
@@ -109,6 +111,40 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
             _bn(spec, f"debranch{d}.linear_fuse.1", AUX_HIDDEN)
             spec[f"debranch{d}.linear_out.weight"] = ("conv", (1, AUX_HIDDEN, 1, 1))
             spec[f"debranch{d}.linear_out.bias"] = ("bias", (1,))
+    return spec
+
+
+# ---------------------------------------------------------------------------------------------
+# MDViT_DSN (mdvit.py:735-960): the MDViT graph with every trunk BatchNorm / LayerNorm replaced by a ModuleList of
+# num_domains norms indexed by int(d) (Conv2d_BN_M :23-70, DWConv2d_BN_M :127-179, SerialBlock_adapt_M :364-412,
+# bridge_norms{1,2} :815-820, Decoders.DWConv2d_BN_M :66-118).  Its parameter names follow from MDViT's by a renaming.
+# ---------------------------------------------------------------------------------------------
+_DSN_RULES = (
+    (r"^stem\.0\.conv\.", "stem_1.conv.", False), (r"^stem\.0\.bn\.", "stem_1.bns.{d}.", True),
+    (r"^stem\.1\.conv\.", "stem_2.conv.", False), (r"^stem\.1\.bn\.", "stem_2.bns.{d}.", True),
+    (r"\.patch_conv\.bn\.", ".patch_conv.bns.{d}.", True),
+    (r"\.norm1\.", ".norm1s.{d}.", True), (r"\.norm2\.", ".norm2s.{d}.", True),
+    (r"^bridge\.0\.", "bridge_conv1.", False), (r"^bridge\.1\.", "bridge_norms1.{d}.", True),
+    (r"^bridge\.3\.", "bridge_conv2.", False), (r"^bridge\.4\.", "bridge_norms2.{d}.", True),
+    (r"\.conv_after\.bn\.", ".conv_after.bns.{d}.", True),
+)
+
+
+def dsn_name(canonical: str, d: int):
+    """MDViT parameter name -> (MDViT_DSN name for domain d, is it domain specific?)"""
+    import re as _re
+    for pat, rep, per_domain in _DSN_RULES:
+        if _re.search(pat, canonical):
+            return _re.sub(pat, rep.format(d=d), canonical), per_domain
+    return canonical, False
+
+
+def _dsn_spec(mdvit_spec, num_domains):
+    spec = OrderedDict()
+    for name, ks in mdvit_spec.items():
+        _, per_domain = dsn_name(name, 0)
+        for d in range(num_domains if per_domain else 1):
+            spec[dsn_name(name, d)[0]] = ks
     return spec
 
 

@@ -182,3 +182,36 @@ def test_metric_and_loader_restatements_known_answers():
     want = [(np.float32(0 / 255) - np.float32(0.485)) / np.float32(0.229), (np.float32(128 / 255) - np.float32(0.456)) / np.float32(0.224),
             (np.float32(255 / 255) - np.float32(0.406)) / np.float32(0.225)]
     assert t.shape == (3, 1, 1) and [float(v) for v in t.view(-1)] == [float(w) for w in want]
+
+
+def test_mdvit_dsn_two_sweep_step(golden):
+    """MDViT_DSN (per-domain norms selected by int(d)): the oracle's renamed-view restatement vs the real reference"""
+    from oracle.params import alias_map, param_spec
+    g = golden("mdvit_dsn_step_64")
+    S, B, seed = [int(v) for v in g["meta"]]
+    pn = make_params(seed, model="MDViT_DSN", adapt_method="Sup")
+    assert len(pn) + len(alias_map("MDViT")) == int(g["n_state_dict_keys"])       # unique + shared cpe/crpe aliases == reference keys
+    P = R.to_torch(pn)
+    batches = [(synth_image(500 + d, B, S, S), synth_label(600 + d, B, S, S), d) for d in range(4)]
+    P2 = {k: v.clone() for k, v in P.items()}
+    st = R.RefState(training=True)
+    for d, (img, lab, sid) in enumerate(batches):
+        dl = F.one_hot(torch.full((B,), sid, dtype=torch.long), 4).float()
+        with torch.no_grad():
+            o, a = R.mdvit_dsn_forward(P2, img, dl, str(sid), st)
+            l = R.domain_losses(o, a, lab)
+        close(o.reshape(-1)[::7], g[f"out_{d}"], name=f"out_{d}")
+        close(a.reshape(-1)[::7], g[f"aux_{d}"], name=f"aux_{d}")
+        close([float(v) for v in l], g[f"losses_{d}"], name=f"losses_{d}")
+    bn_names = [str(n) for n in g["bn_names"]]
+    close([float(P2[k].double().sum()) for k in bn_names], g["bn_sums"], name="bn running sums (only the domain's own norms move)")
+    losses, grads = R.mdvit_train_step(P, batches, R.RefState(training=True), forward=R.mdvit_dsn_forward)
+    close([losses["loss"], losses["aux_loss"], losses["kt_loss"]], g["total_losses"], name="total losses")
+    names, norms, heads = grad_digest(grads)
+    assert names == [str(n) for n in g["grad_names"]]
+    ref = g["grad_norms"]
+    rel = np.abs(norms - ref) / np.maximum(ref, 1e-6 * ref.max())
+    assert rel.max() < 2e-3, f"grad norm mismatch {names[int(rel.argmax())]} {rel.max():.2e}"
+    for key in g.files:
+        if key.startswith("grad::"):
+            close(grads[key[6:]], g[key], rtol=1e-3, name=key)
