@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--model", default="mdvit", choices=["mdvit", "base"])
+    ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base"], default="mdvit", help="mdvit_dsn: MDViT_DSN, domain-specific norms (one forward per domain)")
     ap.add_argument("--no-side-stream", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel); "
@@ -95,9 +95,10 @@ def main():
     # useful-flop roof of the GEMM arithmetic in use: fp32 MFMA peak, or a third of the bf16 peak (3 MFMAs per product)
     peak_mfma = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
     torch.manual_seed(0)
-    if args.model == "mdvit":
-        model = mdvit_amd.MDViT(img_size=args.size, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d,
-                                adapt_method="Sup", num_domains=4, decoder_name="MLPFM").to(dev).train()
+    if args.model in ("mdvit", "mdvit_dsn"):
+        cls = mdvit_amd.MDViT if args.model == "mdvit" else mdvit_amd.MDViT_DSN
+        model = cls(img_size=args.size, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d,
+                    adapt_method="Sup", num_domains=4, decoder_name="MLPFM").to(dev).train()
         domains, flop_per_img = (0, 1, 2, 3), 251.0e9
     else:
         model = mdvit_amd.BASE(drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method=False).to(dev).train()
@@ -115,10 +116,10 @@ def main():
     # a small pool of distinct synthetic steps, resident in HBM before timing
     pool = [make_step_batches(args.batch, args.size, rank=rank, step=s, device=dev, domains=domains) for s in range(2)]
 
-    fuse = max(1, min(len(domains), args.fuse_images // max(1, args.batch))) if args.model == "mdvit" else 1
+    fuse = max(1, min(len(domains), args.fuse_images // max(1, args.batch))) if args.model == "mdvit" else 1      # DSN: norms differ per domain
 
     def step_batches(b):
-        if args.model == "mdvit":
+        if args.model != "base":
             return mdvit_train_step(model, b, optimizer=opt, accumulator=accum, merged_sweeps=not args.reference_sweeps, fuse_domains=fuse)
         return base_train_step(model, b, optimizer=opt, accumulator=accum)
 
@@ -172,7 +173,7 @@ def main():
     # fwd / bwd / optimizer split (the metric's "fwd+bwd ms"): two extra, untimed, instrumented steps -- each phase ends with an
     # event on the main stream (the backward's events come after the side stream has been joined)
     phase_ms = None
-    if args.model == "mdvit" and not args.graph:
+    if args.model != "base" and not args.graph:
         acc_ms = {"fwd": 0.0, "bwd": 0.0, "opt": 0.0}
         reps = 2
         for i in range(reps):
@@ -217,11 +218,12 @@ def main():
             except Exception as e:           # the baseline is a report, never a reason to lose the GPU number
                 cpu = {"error": repr(e)}
         line = {
-            "metric": "512x512 images/sec MDViT train step (fwd+bwd, two-sweep, AdamW)" if args.model == "mdvit" else "512x512 images/sec BASE train step",
+            "metric": "512x512 images/sec MDViT train step (fwd+bwd, two-sweep, AdamW)" if args.model == "mdvit" else
+                      ("512x512 images/sec MDViT_DSN train step" if args.model == "mdvit_dsn" else "512x512 images/sec BASE train step"),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 storage; GEMM operands split hi+lo bf16, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{'MDViT Sup+MLPFM' if args.model == 'mdvit' else 'BASE'} train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
+            "config": {"workload": f"{ {'mdvit': 'MDViT Sup+MLPFM', 'mdvit_dsn': 'MDViT_DSN Sup+MLPFM', 'base': 'BASE'}[args.model] } train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
             "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),

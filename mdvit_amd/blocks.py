@@ -86,17 +86,62 @@ class _NoParams(nn.Module):
         return x
 
 
+# ---- domain-specific norms (the *_M classes of the reference: mdvit.py:23-70,127-179,364-412; Decoders.py:66-118) ------
+# A module built with dsn=D holds D norms in a ModuleList under the reference's name (bns / norm1s / norm2s) and applies
+# the one the model's forward selected with dsn_domain(int(d)); dsn=0 is the ordinary single-norm module.
+_dsn_domain = None
+
+
+class dsn_domain:
+    def __init__(self, d):
+        self.d = d
+
+    def __enter__(self):
+        global _dsn_domain
+        self.prev, _dsn_domain = _dsn_domain, self.d
+        return self
+
+    def __exit__(self, *exc):
+        global _dsn_domain
+        _dsn_domain = self.prev
+        return False
+
+
+def _dsn_domain_index(n: int) -> int:
+    if _dsn_domain is None or not 0 <= _dsn_domain < n:
+        raise ValueError(f"domain-specific norms need the domain id d in 0..{n - 1} (got {_dsn_domain!r})")
+    return _dsn_domain
+
+
+def _bank(make, dsn):
+    return nn.ModuleList([make() for _ in range(dsn)])
+
+
+def _pick(mod, single: str, bank: str):
+    b = getattr(mod, bank, None)
+    if b is None:
+        return getattr(mod, single)
+    if _dsn_domain is None or not 0 <= _dsn_domain < len(b):
+        raise ValueError(f"domain-specific norms need the domain id d in 0..{len(b) - 1} (got {_dsn_domain!r})")
+    return b[_dsn_domain]
+
+
 # ---- conv blocks -----------------------------------------------------------------------------------
 class Conv2d_BN(nn.Module):
     """stem conv: 3x3 s2 p1 (no bias) -> BN -> Hardswish (mpvit.py:81-124).  First stem conv reads the
     NCHW image directly; the second goes im2col + MFMA GEMM."""
 
-    def __init__(self, in_ch, out_ch, kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish, norm_layer=nn.BatchNorm2d, from_image=False):
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish, norm_layer=nn.BatchNorm2d, from_image=False,
+                 dsn=0):
         super().__init__()
         _check_norm(norm_layer)
         assert kernel_size == 3 and pad == 1
         self.conv = ConvParams(out_ch, in_ch, 3, 3, bias=False)
-        self.bn = BatchNormAct(out_ch, ACT_HSWISH if act_layer is nn.Hardswish else ACT_NONE)
+        mk = lambda: BatchNormAct(out_ch, ACT_HSWISH if act_layer is nn.Hardswish else ACT_NONE)
+        if dsn:
+            self.bns = _bank(mk, dsn)
+        else:
+            self.bn = mk()
         self.stride, self.from_image = stride, from_image
 
     def forward(self, x):
@@ -105,32 +150,36 @@ class Conv2d_BN(nn.Module):
             y = ops.stem_conv(x, self.conv.weight)
         else:
             y = ops.conv3x3_dense(x, self.conv.weight, None, self.stride)
-        return self.bn(y)
+        return _pick(self, "bn", "bns")(y)
 
 
 class DWConv2d_BN(nn.Module):
     """dw3x3(groups=in) -> pw1x1 -> BN -> Hardswish (mdvit.py:74-123)."""
 
-    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, norm_layer=nn.BatchNorm2d, act_layer=nn.Hardswish):
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, norm_layer=nn.BatchNorm2d, act_layer=nn.Hardswish, dsn=0):
         super().__init__()
         _check_norm(norm_layer)
         assert kernel_size == 3
         self.dwconv = ConvParams(in_ch, 1, 3, 3, bias=False, groups=in_ch)
         self.pwconv = ConvParams(out_ch, in_ch, 1, 1, bias=False)
-        self.bn = BatchNormAct(out_ch, ACT_HSWISH)
+        if dsn:
+            self.bns = _bank(lambda: BatchNormAct(out_ch, ACT_HSWISH), dsn)
+        else:
+            self.bn = BatchNormAct(out_ch, ACT_HSWISH)
         self.stride = stride
 
     def forward(self, x):
         t = ops.dwconv3x3(x, self.dwconv.weight, None, self.stride, False)
-        return self.bn(ops.linear(t, self.pwconv.weight))
+        return _pick(self, "bn", "bns")(ops.linear(t, self.pwconv.weight))
 
 
 class DWCPatchEmbed(nn.Module):
     """mdvit.py:183-208."""
 
-    def __init__(self, in_chans=3, embed_dim=768, patch_size=16, stride=1, conv_norm=nn.BatchNorm2d, act_layer=nn.Hardswish):
+    def __init__(self, in_chans=3, embed_dim=768, patch_size=16, stride=1, conv_norm=nn.BatchNorm2d, act_layer=nn.Hardswish, dsn=0):
         super().__init__()
-        self.patch_conv = DWConv2d_BN(in_chans, embed_dim, kernel_size=patch_size, stride=stride, norm_layer=conv_norm, act_layer=act_layer)
+        self.patch_conv = DWConv2d_BN(in_chans, embed_dim, kernel_size=patch_size, stride=stride, norm_layer=conv_norm, act_layer=act_layer,
+                                      dsn=dsn)
 
     def forward(self, x):
         return self.patch_conv(x)
@@ -140,17 +189,20 @@ class DecoderDWConv2d_BN(nn.Module):
     """Decoders.py flavour (:15-63): Conv2d(in=2*out, out, 3, groups=out) -> pw(out,out) -> BN -> Hardswish,
     applied to cat(skip, up) without materialising the concat."""
 
-    def __init__(self, in_ch, out_ch, norm_layer=nn.BatchNorm2d):
+    def __init__(self, in_ch, out_ch, norm_layer=nn.BatchNorm2d, dsn=0):
         super().__init__()
         _check_norm(norm_layer)
         assert in_ch == 2 * out_ch
         self.dwconv = ConvParams(out_ch, 2, 3, 3, bias=False, groups=out_ch)
         self.pwconv = ConvParams(out_ch, out_ch, 1, 1, bias=False)
-        self.bn = BatchNormAct(out_ch, ACT_HSWISH)
+        if dsn:
+            self.bns = _bank(lambda: BatchNormAct(out_ch, ACT_HSWISH), dsn)
+        else:
+            self.bn = BatchNormAct(out_ch, ACT_HSWISH)
 
     def forward(self, skip, up):
         t = ops.gconv2_3x3(skip, up, self.dwconv.weight)
-        return self.bn(ops.linear(t, self.pwconv.weight))
+        return _pick(self, "bn", "bns")(ops.linear(t, self.pwconv.weight))
 
 
 # ---- transformer block ------------------------------------------------------------------------------
@@ -284,10 +336,13 @@ class SerialBlock_adapt(nn.Module):
 
     def __init__(self, seq_length, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
                  drop_path=0.0, act_layer=nn.GELU, norm_layer=None, shared_cpe=None, shared_crpe=None, adapt_method=None,
-                 num_domains=4, base_semantics=False):
+                 num_domains=4, base_semantics=False, dsn=0):
         super().__init__()
         self.cpe = shared_cpe
-        self.norm1 = LayerNormParams(dim, 1e-6)
+        if dsn:
+            self.norm1s = _bank(lambda: LayerNormParams(dim, 1e-6), dsn)
+        else:
+            self.norm1 = LayerNormParams(dim, 1e-6)
         self.adapt_method = adapt_method
         self.base_semantics = base_semantics
         if adapt_method == "Sup":
@@ -297,7 +352,10 @@ class SerialBlock_adapt(nn.Module):
             self.factoratt_crpe = FactorAtt_ConvRelPosEnc(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
                                                           attn_drop=attn_drop, proj_drop=drop, shared_crpe=shared_crpe)
         self.drop_path_p = drop_path
-        self.norm2 = LayerNormParams(dim, 1e-6)
+        if dsn:
+            self.norm2s = _bank(lambda: LayerNormParams(dim, 1e-6), dsn)
+        else:
+            self.norm2 = LayerNormParams(dim, 1e-6)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def _droppath_scales(self, B, device):
@@ -315,7 +373,7 @@ class SerialBlock_adapt(nn.Module):
     def forward(self, x, size: Tuple[int, int], domain_label=None):
         x = self.cpe(x, size)
         s1, s2 = self._droppath_scales(x.shape[0], x.device)
-        cur, x = self.norm1.fork(x)
+        cur, x = _pick(self, "norm1", "norm1s").fork(x)
         use_da = (domain_label is not None) if self.base_semantics else (self.adapt_method is not None and domain_label is not None)
         if use_da:
             if not isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
@@ -326,7 +384,7 @@ class SerialBlock_adapt(nn.Module):
             if isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
                 raise TypeError("adapt_method='Sup' blocks need a domain_label (mdvit.py:281)")
             x = self.factoratt_crpe(cur, size, _res=x, _rowscale=s1)
-        cur, x = self.norm2.fork(x)
+        cur, x = _pick(self, "norm2", "norm2s").fork(x)
         return self.mlp(cur, _res=x, _rowscale=s2)
 
 
@@ -335,13 +393,13 @@ class MHSA_stage_adapt(nn.Module):
 
     def __init__(self, seq_length, dim, num_layers, num_heads, mlp_ratio, qkv_bias=True, qk_scale=None, drop_rate=0.0,
                  attn_drop_rate=0.0, drop_path_rate=0.0, num_domains=4, norm_layer=None, adapt_method=None,
-                 crpe_window={3: 2, 5: 3, 7: 3}, base_semantics=False):
+                 crpe_window={3: 2, 5: 3, 7: 3}, base_semantics=False, dsn=0):
         super().__init__()
         self.cpe = ConvPosEnc(dim, k=3)
         self.crpe = ConvRelPosEnc(Ch=dim // num_heads, h=num_heads, window=crpe_window)
         self.mhca_blks = nn.ModuleList([
             SerialBlock_adapt(seq_length, dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_rate, attn_drop_rate, drop_path_rate,
-                              nn.GELU, norm_layer, self.cpe, self.crpe, adapt_method, num_domains, base_semantics)
+                              nn.GELU, norm_layer, self.cpe, self.crpe, adapt_method, num_domains, base_semantics, dsn)
             for _ in range(num_layers)])
 
     def forward(self, input, H, W, domain_label=None):

@@ -21,13 +21,13 @@ from .blocks import BatchNormAct, ConvParams, DecoderDWConv2d_BN, _NoParams, _ch
 
 
 class UnetDecodingBlockTransformer(nn.Module):
-    def __init__(self, in_channel, out_channel, mhsa_block, use_res=False, conv_norm=nn.BatchNorm2d):
+    def __init__(self, in_channel, out_channel, mhsa_block, use_res=False, conv_norm=nn.BatchNorm2d, dsn=0):
         super().__init__()
         if use_res:
             raise NotImplementedError("use_res=True is never used by the reference's models")
         self.use_res = use_res
         self.conv_before = ConvParams(out_channel, in_channel, 1, 1, bias=True)
-        self.conv_after = DecoderDWConv2d_BN(out_channel * 2, out_channel, norm_layer=conv_norm)
+        self.conv_after = DecoderDWConv2d_BN(out_channel * 2, out_channel, norm_layer=conv_norm, dsn=dsn)
         self.mhsa_block = mhsa_block
 
     def forward(self, input, skip, domain_label=None):

@@ -17,43 +17,54 @@ from torch import nn
 
 from . import ops
 from ._lib import ACT_RELU
-from .blocks import (droppath_pool, BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
+from .blocks import (droppath_pool, dsn_domain, BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
                      init_weights_)
 from .decode import MLPDecoderFM, UnetDecodingBlockTransformer
 
 
 class _EncoderDecoder(nn.Module):
     _base_semantics = False
+    _dsn = 0            # > 0: domain-specific norms (MDViT_DSN): that many norms per BatchNorm / LayerNorm site
 
     def _build_trunk(self, img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
-                     drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains):
+                     drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains, dsn=0):
         _check_norm(conv_norm)
         if num_stages != 4:
             raise NotImplementedError("num_stages must be 4")
         self.num_stages = num_stages
+        self._dsn = dsn
         E = list(embed_dims)
-        self.stem = nn.Sequential(
-            Conv2d_BN(in_chans, E[0] // 2, kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish, from_image=True),
-            Conv2d_BN(E[0] // 2, E[0], kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish),
-        )
+        s1 = Conv2d_BN(in_chans, E[0] // 2, kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish, from_image=True, dsn=dsn)
+        s2 = Conv2d_BN(E[0] // 2, E[0], kernel_size=3, stride=2, pad=1, act_layer=nn.Hardswish, dsn=dsn)
+        if dsn:
+            self.stem_1, self.stem_2 = s1, s2            # mdvit.py:773-790
+        else:
+            self.stem = nn.Sequential(s1, s2)
         self.patch_embed_stages = nn.ModuleList([
-            DWCPatchEmbed(in_chans=E[i] if i == 0 else E[i - 1], embed_dim=E[i], patch_size=3, stride=1 if i == 0 else 2, conv_norm=conv_norm)
+            DWCPatchEmbed(in_chans=E[i] if i == 0 else E[i - 1], embed_dim=E[i], patch_size=3, stride=1 if i == 0 else 2, conv_norm=conv_norm,
+                          dsn=dsn)
             for i in range(num_stages)])
 
         def stage(i):
             return MHSA_stage_adapt((img_size // 2 ** (i + 2)) ** 2, E[i], num_layers=num_layers[i], num_heads=num_heads[i],
                                     mlp_ratio=mlp_ratios[i], qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate,
                                     attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate, norm_layer=norm_layer,
-                                    adapt_method=adapt_method, num_domains=num_domains, base_semantics=self._base_semantics)
+                                    adapt_method=adapt_method, num_domains=num_domains, base_semantics=self._base_semantics, dsn=dsn)
 
         self.mhsa_stages = nn.ModuleList([stage(i) for i in range(num_stages)])
-        self.bridge = nn.Sequential(ConvParams(E[3], E[3], 3, 3), BatchNormAct(E[3], ACT_RELU), _NoParams(),
-                                    ConvParams(E[3] * 2, E[3], 3, 3), BatchNormAct(E[3] * 2, ACT_RELU), _NoParams())
+        if dsn:                                                          # mdvit.py:815-820
+            self.bridge_conv1 = ConvParams(E[3], E[3], 3, 3)
+            self.bridge_norms1 = nn.ModuleList([BatchNormAct(E[3], ACT_RELU) for _ in range(dsn)])
+            self.bridge_conv2 = ConvParams(E[3] * 2, E[3], 3, 3)
+            self.bridge_norms2 = nn.ModuleList([BatchNormAct(E[3] * 2, ACT_RELU) for _ in range(dsn)])
+        else:
+            self.bridge = nn.Sequential(ConvParams(E[3], E[3], 3, 3), BatchNormAct(E[3], ACT_RELU), _NoParams(),
+                                        ConvParams(E[3] * 2, E[3], 3, 3), BatchNormAct(E[3] * 2, ACT_RELU), _NoParams())
         self.mhsa_list = [stage(i) for i in range(num_stages)]          # plain list, as in the reference (mdvit.py:568)
-        self.decoder1 = UnetDecodingBlockTransformer(E[3] * 2, E[3], self.mhsa_list[3], conv_norm=conv_norm)
-        self.decoder2 = UnetDecodingBlockTransformer(E[3], E[2], self.mhsa_list[2], conv_norm=conv_norm)
-        self.decoder3 = UnetDecodingBlockTransformer(E[2], E[1], self.mhsa_list[1], conv_norm=conv_norm)
-        self.decoder4 = UnetDecodingBlockTransformer(E[1], E[0], self.mhsa_list[0], conv_norm=conv_norm)
+        self.decoder1 = UnetDecodingBlockTransformer(E[3] * 2, E[3], self.mhsa_list[3], conv_norm=conv_norm, dsn=dsn)
+        self.decoder2 = UnetDecodingBlockTransformer(E[3], E[2], self.mhsa_list[2], conv_norm=conv_norm, dsn=dsn)
+        self.decoder3 = UnetDecodingBlockTransformer(E[2], E[1], self.mhsa_list[1], conv_norm=conv_norm, dsn=dsn)
+        self.decoder4 = UnetDecodingBlockTransformer(E[1], E[0], self.mhsa_list[0], conv_norm=conv_norm, dsn=dsn)
         self.finalconv = nn.Sequential(ConvParams(1, E[0], 1, 1))
 
     def _trunk(self, x, domain_label, groups: int = 1):
@@ -69,17 +80,23 @@ class _EncoderDecoder(nn.Module):
         if x.dim() != 4:
             raise ValueError("expected a (B,C,H,W) image batch")
         B, _, Hi, Wi = x.shape
-        x = self.stem[1](self.stem[0](x.float()))
+        x = self.stem_2(self.stem_1(x.float())) if self._dsn else self.stem[1](self.stem[0](x.float()))
         enc = []
         for idx in range(self.num_stages):
             x = self.patch_embed_stages[idx](x)
             _, H, W, Cn = x.shape
             x = self.mhsa_stages[idx](x.view(B, H * W, Cn), H, W, domain_label).view(B, H, W, Cn)
             enc.append(x)
-        out = ops.conv3x3_dense(enc[3], self.bridge[0].weight, self.bridge[0].bias, 1)
-        out = self.bridge[1](out)
-        out = ops.conv3x3_dense(out, self.bridge[3].weight, self.bridge[3].bias, 1)
-        out = self.bridge[4](out)
+        if self._dsn:
+            from .blocks import _dsn_domain_index
+            di = _dsn_domain_index(self._dsn)
+            out = self.bridge_norms1[di](ops.conv3x3_dense(enc[3], self.bridge_conv1.weight, self.bridge_conv1.bias, 1))
+            out = self.bridge_norms2[di](ops.conv3x3_dense(out, self.bridge_conv2.weight, self.bridge_conv2.bias, 1))
+        else:
+            out = ops.conv3x3_dense(enc[3], self.bridge[0].weight, self.bridge[0].bias, 1)
+            out = self.bridge[1](out)
+            out = ops.conv3x3_dense(out, self.bridge[3].weight, self.bridge[3].bias, 1)
+            out = self.bridge[4](out)
         out = self.decoder1(out, enc[3], domain_label)
         out = self.decoder2(out, enc[2], domain_label)
         out = self.decoder3(out, enc[1], domain_label)
@@ -160,6 +177,36 @@ class MDViT(_EncoderDecoder):
         if out_feat:
             return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}
         return [logits, aux_out]
+
+
+class MDViT_DSN(MDViT):
+    """mdvit.py:735-960: MDViT with domain-specific norms -- every trunk BatchNorm / LayerNorm is a ModuleList of
+    num_domains norms (stem_{1,2}.bns, patch_conv.bns, norm1s / norm2s, bridge_norms{1,2}, conv_after.bns) indexed by
+    int(d); everything else, the peer heads included, is MDViT.  `d` is therefore required; a domain-batched forward
+    (list of ids) is not offered because the groups would need different affine parameters."""
+
+    def __init__(self, img_size=512, in_chans=3, num_stages=4, num_layers=[2, 2, 2, 2], embed_dims=[64, 128, 320, 512],
+                 mlp_ratios=[8, 8, 4, 4], num_heads=[8, 8, 8, 8], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=None, conv_norm=nn.BatchNorm2d, adapt_method=None, num_domains=4,
+                 decoder_name="MLP", **kwargs):
+        _EncoderDecoder.__init__(self)
+        if decoder_name != "MLPFM":
+            raise NotImplementedError(f"decoder_name={decoder_name!r}: only the 'MLPFM' peer heads are built")
+        self.decoder_name = decoder_name
+        self.adapt_method = adapt_method
+        self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
+                          drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains, dsn=num_domains)
+        self.debranch1 = MLPDecoderFM(embed_dims, 1, 512)
+        self.debranch2 = MLPDecoderFM(embed_dims, 1, 512)
+        self.debranch3 = MLPDecoderFM(embed_dims, 1, 512)
+        self.debranch4 = MLPDecoderFM(embed_dims, 1, 512)
+        init_weights_(self)
+
+    def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
+        if isinstance(d, (list, tuple)):
+            raise NotImplementedError("MDViT_DSN: one domain per forward (its norms are selected by int(d))")
+        with dsn_domain(int(d)):
+            return MDViT.forward(self, x, domain_label, str(d), out_feat, out_seg)
 
 
 class BASE(_EncoderDecoder):

@@ -66,6 +66,8 @@ def test_module_surface_matches_reference_inventory():
     assert set(sd) == set(param_spec("MDViT", "Sup")) | set(alias_map())
     b = mdvit_amd.BASE(drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method=False)
     assert set(k for k in b.state_dict()) == set(param_spec("BASE", False)) | set(alias_map("BASE"))
+    dsn = mdvit_amd.MDViT_DSN(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4, decoder_name="MLPFM")
+    assert set(dsn.state_dict()) == set(param_spec("MDViT_DSN", "Sup")) | set(alias_map())       # 852 unique + 128 aliases (mdvit.py:735-960)
     with pytest.raises(NotImplementedError):
         mdvit_amd.MDViT(decoder_name="DeepLabV3")
     # reference init scheme (mdvit.py:648-664)
