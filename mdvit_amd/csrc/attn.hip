@@ -3,15 +3,16 @@
 // forward and backward.  There is no N x N score matrix: softmax runs over the
 // TOKEN axis of K per (batch, channel) column, M = softmax(K)^T V is Ch x Ch per head.
 //
-//   fwd  A: per (token tile, head chunk, batch): tile column max / exp-sum / partial K^T V    -> ws
+//   fwd  A: per (token tile, channel group, batch): tile column max / exp-sum / partial K^T V on fp32 MFMA  -> ws
 //        B: combine tiles (rescale by exp(m_t - m)) -> M [B,C,Ch], column stats kmax/ksum [B,C]
-//        C: U = dwconv_{3|5|7}(v) + bias (saved);  out = a * (Ch^-0.5 * q.M + q * U)
-//   bwd  1: dU = a*G*q (stored), e[b,c] = sum_n G*out          (e = a * dL/da, needs no division)
-//        2: dM = Q^T dFA via the same tile-partial / combine scheme as fwd A/B (no softmax)
-//        3: crpe weight/bias gradients: depthwise-window wgrad of (dU, V), one launch per window size
-//        4: t = sum_e dM*M          5: dq, dk, dv per token with the head rows staged in LDS
-// All HBM/L2-bound VALU kernels: lanes run along channels (coalesced), token-axis reductions are
-// two-stage (tile partials in a workspace, then a combine) so every launch has >= hundreds of workgroups.
+//        C: U = dwconv_{3|5|7}(v) + bias (LDS-tiled, conv_tile.h; saved);  out = a * (Ch^-0.5 * q.M + q * U)
+//   bwd  1: dU = a*G*q (stored), e[b,c] = sum_n G*out as per-workgroup partial rows + fixed-order reduce
+//        2: dM = Q^T dFA via the same MFMA tile partials, summed by the batched partial reducer
+//        3: crpe weight/bias gradients (tile kernel + finish kernel per window size; mdvit_factoratt_wgrad lets the
+//           caller run them on a side stream), conv^T(dU) with the flipped windows
+//        4: dq, dk, dv on fp32 MFMA per channel group (t = sum_e dM*M folded into its staging)
+// HBM-bound kernels: lanes run along channels (coalesced float4), the Ch x Ch products sit on the matrix cores, token-axis
+// reductions are two-stage (partials in a workspace, then a fixed-order combine): deterministic, hundreds of workgroups.
 #include "common.h"
 #include "conv_tile.h"
 
@@ -23,23 +24,6 @@ struct FaGeom {
     int B, H, W, N, C, heads, Ch, s3, s5, s7;
     float scale;
 };
-
-struct CrpeW { const float* w3; const float* b3; const float* w5; const float* b5; const float* w7; const float* b7; };
-
-__device__ __forceinline__ int crpe_radius(const FaGeom& g, int c) {
-    const int head = c / g.Ch;
-    return head < g.s3 ? 1 : (head < g.s3 + g.s5 ? 2 : 3);
-}
-__device__ __forceinline__ const float* crpe_wptr(const FaGeom& g, const CrpeW& cw, int c, int r) {
-    if (r == 1) return cw.w3 + (long)c * 9;
-    if (r == 2) return cw.w5 + (long)(c - g.s3 * g.Ch) * 25;
-    return cw.w7 + (long)(c - (g.s3 + g.s5) * g.Ch) * 49;
-}
-__device__ __forceinline__ float crpe_bias(const FaGeom& g, const CrpeW& cw, int c, int r) {
-    if (r == 1) return cw.b3[c];
-    if (r == 2) return cw.b5[c - g.s3 * g.Ch];
-    return cw.b7[c - (g.s3 + g.s5) * g.Ch];
-}
 
 // ---- tile partials: P[c][e] = sum_{n in tile} f(X[n,c]) * Y[n, head(c)*Ch + e] ----------------------
 // SOFTMAX: f = exp(x - tile max), also emits tile max / exp-sum (fwd A, X = k, Y = v).
@@ -477,14 +461,6 @@ bool make_geom(FaGeom& g, int B, int H, int W, int C, int heads, int s3, int s5,
     return true;
 }
 
-int fa_cw(const FaGeom& g) {
-    int hp = 64 / g.Ch;
-    if (hp < 1) hp = 1;
-    if (hp > g.heads) hp = g.heads;
-    while (g.heads % hp) --hp;
-    return hp * g.Ch;
-}
-
 // fwd: ws_m, ws_s [B,NT,C] + ws_P [B,NT,C,Ch].   bwd: dU, dVc [B,N,C] each + tcol [B,C] + dM [B,C,Ch] + ws_P [B,NT,C,Ch].
 size_t fa_ws_floats(int B, int N, int C, int heads) {
     const int Ch = C / heads;
@@ -523,8 +499,7 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     FaGeom g;
     MDVIT_CHECK_ARG(make_geom(g, B, H, W, C, heads, s3, s5, s7), MDVIT_E_SHAPE, "factoratt_fwd: bad geometry B=%d H=%d W=%d C=%d heads=%d splits=%d/%d/%d", B, H, W, C, heads, s3, s5, s7);
     MDVIT_CHECK_ARG(ws_bytes >= fa_ws_floats(B, g.N, C, heads) * sizeof(float), MDVIT_E_WORKSPACE, "factoratt_fwd: workspace too small (%zu bytes)", ws_bytes);
-    const int NT = cdiv(g.N, FA_T), CW = fa_cw(g);
-    MDVIT_CHECK_ARG(CW <= 128, MDVIT_E_SHAPE, "factoratt_fwd: head dim %d too large", g.Ch);
+    const int NT = cdiv(g.N, FA_T);
     float* ws_m = (float*)ws;
     float* ws_s = ws_m + (long)B * NT * C;
     float* ws_P = ws_s + (long)B * NT * C;
@@ -581,8 +556,7 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     MDVIT_CHECK_ARG(ws_bytes >= fa_ws_floats(B, g.N, C, heads) * sizeof(float), MDVIT_E_WORKSPACE, "factoratt_bwd: workspace too small (%zu bytes)", ws_bytes);
     MDVIT_CHECK_ARG(C <= 512, MDVIT_E_SHAPE, "factoratt_bwd: C=%d > 512 not built", C);
     MDVIT_CHECK_ARG((a == nullptr) == (e == nullptr), MDVIT_E_SHAPE, "factoratt_bwd: a and e must both be given or both be NULL");
-    const int Ch = g.Ch, NT = cdiv(g.N, FA_T), CW = fa_cw(g);
-    MDVIT_CHECK_ARG(CW <= 128, MDVIT_E_SHAPE, "factoratt_bwd: head dim %d too large", Ch);
+    const int Ch = g.Ch, NT = cdiv(g.N, FA_T);
     float* dU = (float*)ws;
     float* dVc = dU + (long)B * g.N * C;
     float* tcol = dVc + (long)B * g.N * C;
