@@ -1,11 +1,12 @@
-// fp32 GEMM family on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
-// bit-for-bit an fmaf chain, 157 TF peak).  One kernel template covers the forward linear layers
-// (NT), dgrad (NN) and wgrad (TN, split along the token axis with fp32 atomics), with the
-// elementwise neighbours of each GEMM fused in:
-//   A-prologue : dropout-mask x per-sample DropPath scale applied to A while it is staged
-//                (the backward of  res + droppath(dropout(.)) ).
-//   epilogue   : +bias | exact-erf GELU (dual store u, h=dropout(gelu(u))) | dropout |
-//                DropPath row scale | +residual | x gelu'(u) x dropout-mask (fc2 dgrad).
+// GEMM family on the CDNA4 matrix cores; fp32 in HBM, two arithmetic modes:
+//   bf16x3 (default): every operand split hi + lo into bf16 while it is staged into LDS, hi*hi + hi*lo + lo*hi on
+//                     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~4e-6 relative);
+//   fp32            : v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain (157 TF peak).
+// One kernel template covers the forward linear layers and the data gradients (NT; dgrad reads the cached W^T) and the
+// weight gradients (TN, split along the token axis into dense slabs + a fixed-order reduce; the bias gradient rides on its
+// A stream), with the element-wise neighbours of each GEMM fused into the epilogue:
+//   +bias | exact-erf GELU (dual store u, h=dropout(gelu(u))) | dropout | DropPath row scale | +residual |
+//   x gelu'(u) x dropout-mask (fc2 dgrad).
 // Replaces nn.Linear / 1x1 nn.Conv2d / einsum call sites of the reference:
 //   mdvit.py:288 (qkv), :310-311 (proj+drop), mpvit.py:71-78 (Mlp), Decoders.py:196,319-331 (1x1 convs).
 #include "common.h"
