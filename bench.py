@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base"], default="mdvit", help="mdvit_dsn: MDViT_DSN, domain-specific norms (one forward per domain)")
+    ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base"], default="mdvit", help="mdvit_dsn: MDViT_DSN, domain-specific norms")
     ap.add_argument("--no-side-stream", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel); "
@@ -116,7 +116,7 @@ def main():
     # a small pool of distinct synthetic steps, resident in HBM before timing
     pool = [make_step_batches(args.batch, args.size, rank=rank, step=s, device=dev, domains=domains) for s in range(2)]
 
-    fuse = max(1, min(len(domains), args.fuse_images // max(1, args.batch))) if args.model == "mdvit" else 1      # DSN: norms differ per domain
+    fuse = max(1, min(len(domains), args.fuse_images // max(1, args.batch))) if args.model in ("mdvit", "mdvit_dsn") else 1
 
     def step_batches(b):
         if args.model != "base":

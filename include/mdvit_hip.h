@@ -109,14 +109,17 @@ int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, voi
                      float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale,
                      int32_t accumulate, const uint32_t* drop_seed, void* stream);
 
-/* ---- LayerNorm over C (nn.LayerNorm eps=1e-6, mdvit.py:327,342,498) ------------------------- */
+/* ---- LayerNorm over C (nn.LayerNorm eps=1e-6, mdvit.py:327,342,498) -------------------------
+ * groups: the M rows are `groups` equal consecutive row groups, group g normalised with parameter row g of
+ * gamma/beta [groups, C] (the domain-specific norm banks of MDViT_DSN, mdvit.py:364-412,735-790, on a
+ * domain-batched tensor); groups = 1 is the plain LayerNorm.  dgamma/dbeta are [groups, C]. */
 int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int32_t M, int32_t C, float eps, void* stream);
+                        int32_t M, int32_t C, int32_t groups, float eps, void* stream);
 /* add (optional, [M,C]): gradient arriving at x along the residual branch that forked off before the norm
  * (x + f(LN(x)), mdvit.py:353-360) -- dx = LN-backward(dy) + add in the same pass. */
 int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                         const float* add, float* dx, float* dgamma, float* dbeta, void* ws /* n = 2C */, size_t ws_bytes,
-                        int32_t M, int32_t C, void* stream);
+                        int32_t M, int32_t C, int32_t groups, void* stream);
 
 /* ---- 3x3 convolutions on NHWC ------------------------------------------------------------------
  * dwconv3x3: depthwise, pad 1, stride 1|2, optional bias, optional "+ input" (ConvPosEnc,
@@ -151,17 +154,20 @@ int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, void* ws 
  * runs one forward per domain); statistics, normalisation and the backward sums are per group -- mean/rstd are
  * [groups, C] -- and the running statistics receive the groups' momentum updates in order, i.e. exactly what
  * `groups` consecutive forwards of M/groups rows each produce.  dgamma/dbeta are summed over the groups.
+ * per_group_affine != 0 (MDViT_DSN's per-domain BatchNorm banks, mdvit.py:23-70,127-179): gamma/beta, the running
+ * statistics and dgamma/dbeta are [groups, C], num_batches_tracked is [groups]; group g reads and updates row g only.
  * drop2d: nn.Dropout2d on (sample, channel) planes (Decoders.py:309,333). */
 size_t mdvit_bn_ws_bytes(int32_t M, int32_t C, int32_t groups);
 int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* mean, float* rstd, float* running_mean, float* running_var,
-                   int64_t* num_batches_tracked, int32_t M, int32_t C, int32_t groups, float eps, float momentum, void* stream);
+                   int64_t* num_batches_tracked, int32_t M, int32_t C, int32_t groups, int32_t per_group_affine, float eps,
+                   float momentum, void* stream);
 int mdvit_bn_eval_prep(const float* running_mean, const float* running_var, float* mean, float* rstd, int32_t C, float eps, void* stream);
 int mdvit_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, float* z,
-                   int32_t M, int32_t C, int32_t groups, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1,
-                   const uint32_t* drop_seed, int32_t rows_per_sample, void* stream);
+                   int32_t M, int32_t C, int32_t groups, int32_t per_group_affine, int32_t act, float drop2d_p, uint32_t key0,
+                   uint32_t key1, const uint32_t* drop_seed, int32_t rows_per_sample, void* stream);
 int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                 float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t groups, int32_t act,
-                 int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, int32_t rows_per_sample,
+                 float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t groups,
+                 int32_t per_group_affine, int32_t act, int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, int32_t rows_per_sample,
                  void* stream);
 
 /* ---- bilinear resize, align_corners=False, NHWC (F.interpolate call sites mdvit.py:699,

@@ -54,8 +54,8 @@ _SIGS = {
     "mdvit_rowdot_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mdvit_rowdot_bwd": [vp, i64, vp, vp, vp, i64, vp, vp, vp, C.c_size_t, i32, i32, vp],
     "mdvit_colsum_f32": [vp, i64, vp, vp, vp, C.c_size_t, i32, i32, f32, u32, u32, vp, i32, i32, vp, vp],
-    "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
-    "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, vp],
+    "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, vp],
     "mdvit_dwconv3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_gconv2_3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -64,10 +64,10 @@ _SIGS = {
     "mdvit_col2im3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
-    "mdvit_bn_stats": [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
+    "mdvit_bn_stats": [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp],
     "mdvit_bn_eval_prep": [vp, vp, vp, vp, i32, f32, vp],
-    "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
-    "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
+    "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
+    "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_upsample_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_upsample_bwd": [vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],

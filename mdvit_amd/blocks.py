@@ -89,7 +89,62 @@ class _NoParams(nn.Module):
 # ---- domain-specific norms (the *_M classes of the reference: mdvit.py:23-70,127-179,364-412; Decoders.py:66-118) ------
 # A module built with dsn=D holds D norms in a ModuleList under the reference's name (bns / norm1s / norm2s) and applies
 # the one the model's forward selected with dsn_domain(int(d)); dsn=0 is the ordinary single-norm module.
+# dsn_domain((d0, d1, ...)) -- a tuple, one DISTINCT domain per group of a domain-batched forward (ops.bn_groups) --
+# applies norm d_g to the g-th batch group in ONE launch: the bank's parameters are stacked to [G, C] rows and the
+# BN / LN kernels index the row by group (include/mdvit_hip.h: per_group_affine / groups).
 _dsn_domain = None
+
+
+class _BankBN:
+    """G BatchNormAct modules applied to the G batch groups of y in one pass."""
+
+    def __init__(self, mods):
+        self.mods = mods
+
+    def __call__(self, y, drop2d_p: float = 0.0):
+        mods, m0 = self.mods, self.mods[0]
+        gamma = torch.stack([m.weight for m in mods])
+        beta = torch.stack([m.bias for m in mods])
+        with torch.no_grad():
+            rm = torch.stack([m.running_mean for m in mods])
+            rv = torch.stack([m.running_var for m in mods])
+        z = ops.bn_act(y, gamma, beta, rm, rv, None, m0.training, m0.act, m0.eps, m0.momentum, drop2d_p if m0.training else 0.0)
+        if m0.training:
+            with torch.no_grad():              # hand the updated rows back to the modules' own buffers (state_dict layout)
+                torch._foreach_copy_([m.running_mean for m in mods] + [m.running_var for m in mods], list(rm.unbind(0)) + list(rv.unbind(0)))
+                torch._foreach_add_([m.num_batches_tracked for m in mods], 1)
+        return z
+
+
+class _BankLN:
+    def __init__(self, mods):
+        self.mods = mods
+
+    def _params(self):
+        return torch.stack([m.weight for m in self.mods]), torch.stack([m.bias for m in self.mods])
+
+    def __call__(self, x):
+        g, b = self._params()
+        return ops.layer_norm(x, g, b, self.mods[0].eps)
+
+    def fork(self, x):
+        g, b = self._params()
+        return ops.layer_norm_fork(x, g, b, self.mods[0].eps)
+
+
+def _bank_select(b):
+    """the norm (or group-batched bank view) the active dsn_domain selects from ModuleList b"""
+    d = _dsn_domain
+    if isinstance(d, tuple):
+        if len(set(d)) != len(d) or not all(0 <= v < len(b) for v in d):
+            raise ValueError(f"domain-batched domain-specific norms need distinct domain ids in 0..{len(b) - 1} (got {d!r})")
+        if len(d) != ops._bn_groups:
+            raise ValueError(f"{len(d)} domain ids for bn_groups({ops._bn_groups})")
+        mods = [b[v] for v in d]
+        return _BankBN(mods) if isinstance(mods[0], BatchNormAct) else _BankLN(mods)
+    if d is None or not 0 <= d < len(b):
+        raise ValueError(f"domain-specific norms need the domain id d in 0..{len(b) - 1} (got {d!r})")
+    return b[d]
 
 
 class dsn_domain:
@@ -107,12 +162,6 @@ class dsn_domain:
         return False
 
 
-def _dsn_domain_index(n: int) -> int:
-    if _dsn_domain is None or not 0 <= _dsn_domain < n:
-        raise ValueError(f"domain-specific norms need the domain id d in 0..{n - 1} (got {_dsn_domain!r})")
-    return _dsn_domain
-
-
 def _bank(make, dsn):
     return nn.ModuleList([make() for _ in range(dsn)])
 
@@ -121,9 +170,7 @@ def _pick(mod, single: str, bank: str):
     b = getattr(mod, bank, None)
     if b is None:
         return getattr(mod, single)
-    if _dsn_domain is None or not 0 <= _dsn_domain < len(b):
-        raise ValueError(f"domain-specific norms need the domain id d in 0..{len(b) - 1} (got {_dsn_domain!r})")
-    return b[_dsn_domain]
+    return _bank_select(b)
 
 
 # ---- conv blocks -----------------------------------------------------------------------------------

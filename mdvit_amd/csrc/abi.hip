@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     const int i = blockIdx.x * 8 + cl;
     part += (long)blockIdx.y * nblk * stride;        // batched mode (grid.y > 1): one reduction per batch, out0 [batch][n0]
     out0 += (long)blockIdx.y * n0;
+    if (out1) out1 += (long)blockIdx.y * n1;
     float s = 0.f;
     if (i < n) {
         int b = rl;
@@ -84,6 +85,13 @@ int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, floa
 int mdvit_reduce_partials_batched(const float* part, int batches, int nblk, int n, float* out, hipStream_t stream) {
     if (n <= 0 || nblk <= 0 || batches <= 0) return MDVIT_OK;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 7) / 8, batches), dim3(256), 0, stream, part, nblk, (long)n, n, out, 0, (float*)nullptr, 0);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+int mdvit_reduce_partials_batched2(const float* part, int batches, int nblk, int n0, float* out0, int n1, float* out1, hipStream_t stream) {
+    if (n0 + n1 <= 0 || nblk <= 0 || batches <= 0) return MDVIT_OK;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n0 + n1 + 7) / 8, batches), dim3(256), 0, stream, part, nblk, (long)(n0 + n1), n0, out0, n1, out1, 0);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -45,6 +45,8 @@ int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream);
 int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream);
 // `batches` independent reductions: part [batch][nblk][n] -> out [batch][n]
 int mdvit_reduce_partials_batched(const float* part, int batches, int nblk, int n, float* out, hipStream_t stream);
+// batched with two outputs per batch: out0 [batch][n0], out1 [batch][n1]; partial rows are [n0 | n1] wide
+int mdvit_reduce_partials_batched2(const float* part, int batches, int nblk, int n0, float* out0, int n1, float* out1, hipStream_t stream);
 constexpr int MDVIT_MAX_PARTIAL_ROWS = 2048;        // every partial-row reduction launches at most this many workgroups
 #define MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, n, what)                                                              \
     MDVIT_CHECK_ARG((ws) != nullptr && (ws_bytes) >= sizeof(float) * (size_t)(nblk) * (size_t)(n), MDVIT_E_WORKSPACE,    \

@@ -9,10 +9,21 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per token row, row held in registers (C <= 64*VPT).
 // ------------------------------------------------------------------------------------------------
+// grid.y = parameter group: `M` consecutive rows per group, each with its own gamma/beta row (one launch normalises a
+// domain-batched tensor with per-domain LayerNorm parameters; groups = 1 is the plain LayerNorm)
+#define LN_GROUP_FWD(C_)                                                                                   \
+    { const long g_ = blockIdx.y; x += g_ * M * (C_); y += g_ * M * (C_); mean += g_ * M; rstd += g_ * M;   \
+      gamma += g_ * (C_); beta += g_ * (C_); }
+#define LN_GROUP_BWD(C_)                                                                                   \
+    { const long g_ = blockIdx.y; dy += g_ * M * (C_); x += g_ * M * (C_); dx += g_ * M * (C_);             \
+      if (add) add += g_ * M * (C_);                                                                       \
+      mean += g_ * M; rstd += g_ * M; gamma += g_ * (C_); part += g_ * gridDim.x * 2 * (C_); }
+
 template <int VPT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int C, float eps) {
+    LN_GROUP_FWD(C);
     const int lane = threadIdx.x & 63;
     const int nw = (gridDim.x * blockDim.x) >> 6;
     for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < M; row += nw) {
@@ -49,6 +60,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ add, float* __restrict__ dx,
                                                      float* __restrict__ part, int M, int C) {
+    LN_GROUP_BWD(C);
     __shared__ float s_dg[4][64 * VPT];
     __shared__ float s_db[4][64 * VPT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, float* __restrict__ y,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int M, float eps) {
     constexpr int C = 64 * VPL;
+    LN_GROUP_FWD(C);
     const int sub = threadIdx.x & 15;
     const long r0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, nr = ((long)gridDim.x * blockDim.x) >> 4;
     float4 ga[VPL], be[VPL];
@@ -146,6 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__
                                                        const float* __restrict__ rstd, const float* __restrict__ add, float* __restrict__ dx,
                                                        float* __restrict__ part, int M) {
     constexpr int C = 64 * VPL;
+    LN_GROUP_BWD(C);
     __shared__ float s_dg[4][C], s_db[4][C];
     const int sub = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long r0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, nr = ((long)gridDim.x * blockDim.x) >> 4;
@@ -223,6 +237,8 @@ struct ChanArgs {
     int groups;                               // BN over `groups` consecutive row groups of M rows each (MODE0/1: grid.y = group;
                                               // mean/rstd/ws/part are per group); apply kernels: M = all rows, rows_per_group below
     long rows_per_group;
+    int affine_stride;                        // 0: one gamma/beta/running-stat row shared by all groups; C: one row per group
+                                              // (domain-specific normalisation: group g uses parameter row g)
 };
 
 __device__ __forceinline__ float act_grad(int act, float pre) {
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
     float mu[4], rs[4], ga[4], be[4];
     if (MODE == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; }
+        for (int j = 0; j < 4; ++j) { mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[grp * p.affine_stride + c + j]; be[j] = p.beta[grp * p.affine_stride + c + j]; }
     }
     for (long e = t0; e < total; e += T) {
         const long row = row0 + e / QC;
@@ -345,8 +361,25 @@ __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* __restr
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* mean, float* rstd, float* rmean, float* rvar,
-                                   int64_t* nbt, int M, int C, float eps, float momentum, int groups) {
+                                   int64_t* nbt, int M, int C, float eps, float momentum, int groups, int per_group) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (per_group) {                            // domain-specific banks: group g updates running-stat row g once
+        if (c < C)
+            for (int g = 0; g < groups; ++g) {
+                const double m = ws[(long)g * 2 * C + c] / M;
+                double var = ws[(long)g * 2 * C + C + c] / M - m * m;
+                if (var < 0.0) var = 0.0;
+                mean[g * C + c] = (float)m;
+                rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+                const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+                if (rmean) {
+                    rmean[g * C + c] = (1.f - momentum) * rmean[g * C + c] + momentum * (float)m;
+                    rvar[g * C + c] = (1.f - momentum) * rvar[g * C + c] + momentum * (float)unb;
+                }
+            }
+        if (c < groups && nbt) nbt[c] += 1;
+        return;
+    }
     if (c < C) {
         float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
         for (int g = 0; g < groups; ++g) {      // running statistics: the same update sequence as `groups` consecutive forwards
@@ -380,7 +413,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(ChanArgs p, float* __rest
     const long row0 = (long)grp * p.M, rstep = T / QC;
     float mu[4], rs[4], ga[4], be[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; }
+    for (int j = 0; j < 4; ++j) { mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[grp * p.affine_stride + c + j]; be[j] = p.beta[grp * p.affine_stride + c + j]; }
     for (long r = t0 / QC; r < p.M; r += rstep) {
         const long row = row0 + r;
         const float4 yv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
@@ -409,7 +442,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __
     float mu[4], rs[4], ga[4], be[4], sg[4], sgx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j];
+        mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[grp * p.affine_stride + c + j]; be[j] = p.beta[grp * p.affine_stride + c + j];
         sg[j] = training ? (float)(wsg[c + j] * invM) : 0.f;
         sgx[j] = training ? (float)(wsg[p.C + c + j] * invM) : 0.f;
     }
@@ -432,7 +465,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(ChanArgs p, float* __
         }
         *reinterpret_cast<float4*>(dy + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (blockIdx.x == 0 && p.affine_stride) {            // per-group parameters: each group's sums are its own gradient row
+        for (int cc = threadIdx.x; cc < p.C; cc += blockDim.x) {
+            dbeta[grp * p.C + cc] = (float)wsg[cc]; dgamma[grp * p.C + cc] = (float)wsg[p.C + cc];
+        }
+    } else if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (int cc = threadIdx.x; cc < p.C; cc += blockDim.x) {
             double sb = 0.0, sgm = 0.0;
             for (int g = 0; g < p.groups; ++g) { sb += p.ws[(long)g * 2 * p.C + cc]; sgm += p.ws[(long)g * 2 * p.C + p.C + cc]; }
@@ -527,47 +564,52 @@ void fill_drop(ChanArgs& a, float p, uint32_t k0, uint32_t k1, int rows_per_samp
     } while (0)
 
 extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                   int32_t M, int32_t C, float eps, void* stream) {
+                                   int32_t M, int32_t C, int32_t groups, float eps, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_fwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
+    MDVIT_CHECK_ARG(groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "layernorm_fwd: M=%d is not a multiple of groups=%d", M, groups);
+    const int Mg = M / groups;                 // rows per parameter group (kernels take the per-group row count; grid.y = group)
     if (C == 64 || C == 128 || C == 320 || C == 512) {
-        dim3 grid16(min(cdiv(M, 16), 4096));
-        if (C == 64) hipLaunchKernelGGL((ln_fwd16_kernel<1>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
-        else if (C == 128) hipLaunchKernelGGL((ln_fwd16_kernel<2>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
-        else if (C == 320) hipLaunchKernelGGL((ln_fwd16_kernel<5>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
-        else hipLaunchKernelGGL((ln_fwd16_kernel<8>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, M, eps);
+        dim3 grid16(min(cdiv(Mg, 16), max(1, 4096 / groups)), groups);
+        if (C == 64) hipLaunchKernelGGL((ln_fwd16_kernel<1>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, Mg, eps);
+        else if (C == 128) hipLaunchKernelGGL((ln_fwd16_kernel<2>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, Mg, eps);
+        else if (C == 320) hipLaunchKernelGGL((ln_fwd16_kernel<5>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, Mg, eps);
+        else hipLaunchKernelGGL((ln_fwd16_kernel<8>), grid16, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, Mg, eps);
         MDVIT_LAUNCH_CHECK();
         return MDVIT_OK;
     }
-    dim3 grid(min(cdiv(M, 4), 4096));
-    LN_DISPATCH(ln_fwd_kernel, C, x, gamma, beta, y, mean, rstd, M, C, eps);
+    dim3 grid(min(cdiv(Mg, 4), max(1, 4096 / groups)), groups);
+    LN_DISPATCH(ln_fwd_kernel, C, x, gamma, beta, y, mean, rstd, Mg, C, eps);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
 
+// dgamma / dbeta: [groups, C] each
 extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                    const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                                   int32_t M, int32_t C, void* stream) {
+                                   int32_t M, int32_t C, int32_t groups, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
-    float* part = (float*)ws;
+    MDVIT_CHECK_ARG(groups > 0 && groups <= 64 && M % groups == 0, MDVIT_E_SHAPE, "layernorm_bwd: M=%d is not a multiple of groups=%d", M, groups);
+    const int Mg = M / groups;
+    float* part = (float*)ws;                  // [group][workgroup][dgamma | dbeta]
     int nblk;
     if (C == 64 || C == 128 || C == 320 || C == 512) {
-        nblk = min(cdiv(M, 64), 1024);
-        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 2 * C, "layernorm_bwd");
-        dim3 grid16(nblk);
-        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
-        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
-        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
-        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, M);
+        nblk = min(cdiv(Mg, 64), 1024 / groups);
+        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");
+        dim3 grid16(nblk, groups);
+        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
+        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
+        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
+        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
     } else {
-        nblk = min(cdiv(M, 16), 1024);
-        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 2 * C, "layernorm_bwd");
-        dim3 grid(nblk);
-        LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, add, dx, part, M, C);
+        nblk = min(cdiv(Mg, 16), 1024 / groups);
+        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");
+        dim3 grid(nblk, groups);
+        LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, add, dx, part, Mg, C);
     }
     MDVIT_LAUNCH_CHECK();
-    return mdvit_reduce_partials(part, nblk, 2L * C, C, dgamma, C, dbeta, 0, s);      // fixed-order sums of the per-workgroup rows
+    return mdvit_reduce_partials_batched2(part, groups, nblk, C, dgamma, C, dbeta, s);      // fixed-order sums of the per-workgroup rows
 }
 
 constexpr int CHAN_MAX_BLOCKS = 512;
@@ -583,7 +625,7 @@ extern "C" size_t mdvit_bn_ws_bytes(int32_t M, int32_t C, int32_t groups) {
 }
 
 extern "C" int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* mean, float* rstd, float* running_mean, float* running_var,
-                              int64_t* nbt, int32_t M, int32_t C, int32_t groups, float eps, float momentum, void* stream) {
+                              int64_t* nbt, int32_t M, int32_t C, int32_t groups, int32_t per_group_affine, float eps, float momentum, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_stats: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
     MDVIT_CHECK_ARG(groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "bn_stats: M=%d is not a multiple of groups=%d", M, groups);
@@ -595,7 +637,7 @@ extern "C" int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* 
     const int grid = chan_grid(Mg, C, CHAN_MAX_BLOCKS);
     hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid, groups), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32), groups), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, a.ws, mean, rstd, running_mean, running_var, nbt, Mg, C, eps, momentum, groups);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, a.ws, mean, rstd, running_mean, running_var, nbt, Mg, C, eps, momentum, groups, per_group_affine);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -607,13 +649,13 @@ extern "C" int mdvit_bn_eval_prep(const float* rm, const float* rv, float* mean,
 }
 
 extern "C" int mdvit_bn_apply(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, float* z,
-                              int32_t M, int32_t C, int32_t groups, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* seed,
-                              int32_t rows_per_sample, void* stream) {
+                              int32_t M, int32_t C, int32_t groups, int32_t per_group_affine, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1,
+                              const uint32_t* seed, int32_t rows_per_sample, void* stream) {
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, MDVIT_E_SHAPE, "bn_apply: need C %% 4 == 0 (M=%d C=%d)", M, C);
     MDVIT_CHECK_ARG(groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "bn_apply: M=%d is not a multiple of groups=%d", M, groups);
     ChanArgs a; memset(&a, 0, sizeof(a));
     a.a = y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
-    a.groups = groups; a.rows_per_group = M / groups;
+    a.groups = groups; a.rows_per_group = M / groups; a.affine_stride = per_group_affine ? C : 0;
     a.M = M / groups;                          // rows per statistics group (grid.y = group)
     fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
     a.seed = seed;
@@ -623,8 +665,8 @@ extern "C" int mdvit_bn_apply(const float* y, const float* mean, const float* rs
 }
 
 extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                            float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t groups, int32_t act,
-                            int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* seed, int32_t rows_per_sample,
+                            float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t groups,
+                            int32_t per_group_affine, int32_t act, int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* seed, int32_t rows_per_sample,
                             void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_bwd: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
@@ -633,7 +675,7 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
     MDVIT_CHECK_ARG(ws_bytes >= bn_ws_bytes(Mg, C, groups), MDVIT_E_WORKSPACE, "bn_bwd: workspace too small");
     ChanArgs a; memset(&a, 0, sizeof(a));
     a.a = dz; a.b = y; a.lda = C; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = Mg; a.C = C; a.act = act;
-    a.groups = groups; a.rows_per_group = Mg;
+    a.groups = groups; a.rows_per_group = Mg; a.affine_stride = per_group_affine ? C : 0;
     a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * (size_t)C * groups);
     fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
     a.seed = seed;

@@ -88,10 +88,9 @@ class _EncoderDecoder(nn.Module):
             x = self.mhsa_stages[idx](x.view(B, H * W, Cn), H, W, domain_label).view(B, H, W, Cn)
             enc.append(x)
         if self._dsn:
-            from .blocks import _dsn_domain_index
-            di = _dsn_domain_index(self._dsn)
-            out = self.bridge_norms1[di](ops.conv3x3_dense(enc[3], self.bridge_conv1.weight, self.bridge_conv1.bias, 1))
-            out = self.bridge_norms2[di](ops.conv3x3_dense(out, self.bridge_conv2.weight, self.bridge_conv2.bias, 1))
+            from .blocks import _bank_select
+            out = _bank_select(self.bridge_norms1)(ops.conv3x3_dense(enc[3], self.bridge_conv1.weight, self.bridge_conv1.bias, 1))
+            out = _bank_select(self.bridge_norms2)(ops.conv3x3_dense(out, self.bridge_conv2.weight, self.bridge_conv2.bias, 1))
         else:
             out = ops.conv3x3_dense(enc[3], self.bridge[0].weight, self.bridge[0].bias, 1)
             out = self.bridge[1](out)
@@ -182,8 +181,8 @@ class MDViT(_EncoderDecoder):
 class MDViT_DSN(MDViT):
     """mdvit.py:735-960: MDViT with domain-specific norms -- every trunk BatchNorm / LayerNorm is a ModuleList of
     num_domains norms (stem_{1,2}.bns, patch_conv.bns, norm1s / norm2s, bridge_norms{1,2}, conv_after.bns) indexed by
-    int(d); everything else, the peer heads included, is MDViT.  `d` is therefore required; a domain-batched forward
-    (list of ids) is not offered because the groups would need different affine parameters."""
+    int(d); everything else, the peer heads included, is MDViT.  `d` is therefore required.  A list of DISTINCT ids runs
+    the domain-batched forward: norm d_g on the g-th batch group, through the group-indexed BN / LN kernels."""
 
     def __init__(self, img_size=512, in_chans=3, num_stages=4, num_layers=[2, 2, 2, 2], embed_dims=[64, 128, 320, 512],
                  mlp_ratios=[8, 8, 4, 4], num_heads=[8, 8, 8, 8], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
@@ -204,7 +203,8 @@ class MDViT_DSN(MDViT):
 
     def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
         if isinstance(d, (list, tuple)):
-            raise NotImplementedError("MDViT_DSN: one domain per forward (its norms are selected by int(d))")
+            with dsn_domain(tuple(int(v) for v in d)):
+                return self._forward_domains(x, domain_label, [str(v) for v in d], out_feat, out_seg)
         with dsn_domain(int(d)):
             return MDViT.forward(self, x, domain_label, str(d), out_feat, out_seg)
 

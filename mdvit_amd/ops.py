@@ -588,10 +588,13 @@ class _LayerNorm(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         _chk(x, gamma, beta)
         M, Cn = x.shape
+        groups = gamma.shape[0] if gamma.dim() == 2 else 1       # [G, C]: parameter row g for the g-th of G equal row groups
+        if M % groups:
+            raise ValueError(f"layer_norm: {M} rows are not {groups} equal groups")
         y = _empty_like(x)
         mean = _empty((M,), device=x.device, dtype=torch.float32)
         rstd = _empty_like(mean)
-        call("mdvit_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cn, eps, _stream())
+        call("mdvit_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, Cn, groups, eps, _stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
         if fork:
             return y, x.view_as(x)
@@ -608,21 +611,23 @@ class _LayerNorm(torch.autograd.Function):
         dg, db = _flat_like(gamma, gamma)
         gp = None if g_pass is None else _c(g_pass)
         wsp, wsb, _keep = _partials_ws(2 * Cn, x.device)
-        call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(gp), _p(dx), _p(dg), _p(db), wsp, wsb, M, Cn, _stream())
+        call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(gp), _p(dx), _p(dg), _p(db), wsp, wsb, M, Cn,
+             gamma.shape[0] if gamma.dim() == 2 else 1, _stream())
         if _dgrad_only:
             return dx, None, None, None, None
         return dx, dg, db, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-6):
+    """gamma/beta [C], or [G, C] for G equal consecutive row groups with their own parameters (domain-specific norms)."""
     shp = x.shape
-    return _LayerNorm.apply(_c(x).view(-1, shp[-1]), gamma, beta, float(eps), False).view(shp)
+    return _LayerNorm.apply(_c(x).view(-1, shp[-1]), _c(gamma), _c(beta), float(eps), False).view(shp)
 
 
 def layer_norm_fork(x, gamma, beta, eps=1e-6):
     """-> (LN(x), x_res): use x_res (same values as x) for the residual branch; see _LayerNorm."""
     shp = x.shape
-    y, xr = _LayerNorm.apply(_c(x).view(-1, shp[-1]), gamma, beta, float(eps), True)
+    y, xr = _LayerNorm.apply(_c(x).view(-1, shp[-1]), _c(gamma), _c(beta), float(eps), True)
     return y.view(shp), xr.view(shp)
 
 
@@ -796,7 +801,11 @@ class _BNAct(torch.autograd.Function):
         Cn = y.shape[-1]
         M = y.numel() // Cn
         dev = y.device
-        if not training:
+        pga = int(gamma.dim() == 2)    # [G, C] parameters / running statistics: row g belongs to group g (domain-specific norms)
+        if pga:
+            if gamma.shape[0] != groups:
+                raise ValueError(f"bn_act: {gamma.shape[0]} parameter rows for {groups} groups")
+        elif not training:
             groups = 1                 # eval normalises every sample with the shared running statistics
         mean = _empty((groups, Cn), device=dev, dtype=torch.float32)
         rstd = _empty_like(mean)
@@ -804,15 +813,15 @@ class _BNAct(torch.autograd.Function):
             wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn, groups)
             ws = _empty((wsb // 8 + 1,), device=dev, dtype=torch.float64)
             call("mdvit_bn_stats", _p(y), _p(ws), wsb, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
-                 C.c_void_p(nbt.data_ptr()) if nbt is not None else None, M, Cn, groups, eps, momentum, _stream())
+                 C.c_void_p(nbt.data_ptr()) if nbt is not None else None, M, Cn, groups, pga, eps, momentum, _stream())
         else:
-            call("mdvit_bn_eval_prep", _p(running_mean), _p(running_var), _p(mean), _p(rstd), Cn, eps, _stream())
+            call("mdvit_bn_eval_prep", _p(running_mean), _p(running_var), _p(mean), _p(rstd), Cn * groups, eps, _stream())
         key = _next_key() if drop2d_p > 0 else (0, 0)
         z = _empty_like(y)
-        call("mdvit_bn_apply", _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), M, Cn, groups, act, drop2d_p, key[0], key[1],
+        call("mdvit_bn_apply", _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(z), M, Cn, groups, pga, act, drop2d_p, key[0], key[1],
              _seed_ptr() if drop2d_p > 0 else None, rows_per_sample, _stream())
         ctx.save_for_backward(y, gamma, beta, mean, rstd)
-        ctx.meta = (training, act, drop2d_p, key, rows_per_sample, groups)
+        ctx.meta = (training, act, drop2d_p, key, rows_per_sample, groups, pga)
         return z
 
     @staticmethod
@@ -820,7 +829,7 @@ class _BNAct(torch.autograd.Function):
         if g is None:
             return (None,) * 13
         y, gamma, beta, mean, rstd = ctx.saved_tensors
-        training, act, drop2d_p, key, rps, groups = ctx.meta
+        training, act, drop2d_p, key, rps, groups, pga = ctx.meta
         g = _c(g)
         Cn = y.shape[-1]
         M = y.numel() // Cn
@@ -829,7 +838,7 @@ class _BNAct(torch.autograd.Function):
         wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn, groups)
         ws = _empty((wsb // 8 + 1,), device=y.device, dtype=torch.float64)
         call("mdvit_bn_bwd", _p(g), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dg), _p(db), _p(ws), wsb,
-             M, Cn, groups, act, int(training), drop2d_p, key[0], key[1], _seed_ptr() if drop2d_p > 0 else None, rps, _stream())
+             M, Cn, groups, pga, act, int(training), drop2d_p, key[0], key[1], _seed_ptr() if drop2d_p > 0 else None, rps, _stream())
         if _dgrad_only:
             dg = db = None
         return dy, dg, db, None, None, None, None, None, None, None, None, None, None
@@ -887,11 +896,13 @@ def split_groups(x, groups: int):
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, nbt, training, act, eps=1e-5, momentum=0.1, drop2d_p=0.0):
+    """gamma/beta/running_* [C]; or [G, C] (+ nbt [G] or None) with bn_groups(G) active: group g is normalised with -- and
+    updates -- parameter/statistics row g (the per-domain norm banks of MDViT_DSN on a domain-batched tensor)."""
     rows_per_sample = y.numel() // (y.shape[0] * y.shape[-1])
-    groups = _bn_groups if training else 1
+    groups = _bn_groups if (training or gamma.dim() == 2) else 1
     if groups > 1 and y.shape[0] % groups:
         raise ValueError(f"bn_groups({groups}) needs a batch that is a multiple of it, got {y.shape[0]}")
-    return _BNAct.apply(_c(y), gamma, beta, running_mean, running_var, nbt, bool(training), float(eps), float(momentum),
+    return _BNAct.apply(_c(y), _c(gamma), _c(beta), running_mean, running_var, nbt, bool(training), float(eps), float(momentum),
                         int(act), float(drop2d_p), int(rows_per_sample), int(groups))
 
 

@@ -344,6 +344,62 @@ def test_bn_act_grouped_equals_consecutive_forwards(G, Bg, H, W, C):
     assert torch.equal(sep, out.detach()) and torch.equal(rm2, rmh) and torch.equal(rv2, rvh)
 
 
+@pytest.mark.parametrize("G,Bg,H,W,C,training", [(4, 2, 8, 8, 64, True), (2, 3, 5, 3, 320, True), (3, 1, 16, 16, 32, True), (4, 2, 4, 4, 128, False)])
+def test_bn_act_per_group_parameters(G, Bg, H, W, C, training):
+    """[G, C] parameter / running-statistic rows (the per-domain BatchNorm banks of MDViT_DSN on a domain-batched
+    tensor): group g is normalised with row g and updates row g only == G independent BatchNorms"""
+    from mdvit_amd import ops, _lib
+    y, g = rnd(G * Bg, C, H, W, seed=186, scale=2.0) + 0.3, rnd(G * Bg, C, H, W, seed=189)
+    y = y + torch.arange(G).repeat_interleave(Bg).view(-1, 1, 1, 1).float()
+    ga, be = 1 + 0.5 * rnd(G, C, seed=187), rnd(G, C, seed=188, scale=0.2)
+    rm0, rv0 = rnd(G, C, seed=184, scale=0.1), 1 + 0.5 * rnd(G, C, seed=185).abs()
+    rm, rv = rm0.clone().double(), rv0.clone().double()
+
+    def ref_fn(y, ga, be):
+        return torch.cat([F.relu(F.batch_norm(y[i * Bg:(i + 1) * Bg].double(), rm[i], rv[i], ga[i].double(), be[i].double(), training, 0.1, 1e-5))
+                          for i in range(G)], 0)
+    ref, gr = grads_of(ref_fn, [y, ga, be], g.double())
+    rmh, rvh, nbt = rm0.to(dev()), rv0.to(dev()), torch.zeros(G, dtype=torch.long, device=dev())
+
+    def our_fn(y, ga, be):
+        with ops.bn_groups(G):
+            return ops.bn_act(y, ga, be, rmh, rvh, nbt, training, _lib.ACT_RELU)
+    out, go = grads_of(our_fn, [nhwc(y).to(dev()), ga.to(dev()), be.to(dev())], nhwc(g))
+    check(nchw(out), ref, name="z")
+    check(nchw(go[0]), gr[0], tol=3e-4, name="dy")
+    check(go[1], gr[1], tol=3e-4, name="dgamma rows")
+    check(go[2], gr[2], tol=3e-4, name="dbeta rows")
+    check(rmh, rm, name="running_mean rows")
+    check(rvh, rv, name="running_var rows")
+    assert nbt.tolist() == [1 if training else 0] * G
+    with pytest.raises(ValueError):
+        ops.bn_act(nhwc(y).to(dev()), ga.to(dev()), be.to(dev()), rmh, rvh, None, training, _lib.ACT_RELU)      # no bn_groups(G) active
+
+
+@pytest.mark.parametrize("G,Mg,C", [(4, 128, 64), (2, 100, 128), (4, 37, 320), (3, 50, 512), (2, 33, 96), (1, 77, 64)])
+def test_layer_norm_per_group_parameters(G, Mg, C):
+    """gamma/beta [G, C]: row g normalises the g-th of G equal row groups (norm1s / norm2s of MDViT_DSN on a
+    domain-batched token tensor) == G LayerNorms; the forked form adds the residual gradient"""
+    from mdvit_amd import ops
+    x, g, g2 = rnd(G * Mg, C, seed=190, scale=1.5) + 0.2, rnd(G * Mg, C, seed=191), rnd(G * Mg, C, seed=192)
+    ga, be = 1 + 0.5 * rnd(G, C, seed=193), rnd(G, C, seed=194, scale=0.3)
+
+    def ref_fn(x, ga, be):
+        return torch.cat([F.layer_norm(x[i * Mg:(i + 1) * Mg].double(), (C,), ga[i].double(), be[i].double(), 1e-6) for i in range(G)], 0)
+    ref, gr = grads_of(ref_fn, [x, ga, be], g.double())
+    out, go = grads_of(lambda x, ga, be: ops.layer_norm(x, ga, be, 1e-6), [x.to(dev()), ga.to(dev()), be.to(dev())], g)
+    check(out, ref, name="y")
+    check(go[0], gr[0], tol=3e-4, name="dx")
+    check(go[1], gr[1], tol=3e-4, name="dgamma rows")
+    check(go[2], gr[2], tol=3e-4, name="dbeta rows")
+    # forked: (LN(x), x) with the gradient of the second output added inside the backward kernel
+    xs = [t.to(dev()).requires_grad_(True) for t in (x, ga, be)]
+    yv, xr = ops.layer_norm_fork(xs[0], xs[1], xs[2], 1e-6)
+    torch.autograd.backward([yv, xr], [g.to(dev()), g2.to(dev())])
+    check(xs[0].grad, gr[0] + g2.double(), tol=3e-4, name="dx + residual gradient")
+    check(xs[1].grad, gr[1], tol=3e-4, name="dgamma rows (fork)")
+
+
 def test_split_groups_backward_handles_missing_gradients():
     from mdvit_amd import ops
     x = rnd(6, 5, 4, seed=120).to(dev()).requires_grad_(True)

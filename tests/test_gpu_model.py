@@ -173,7 +173,8 @@ def test_mdvit_two_sweep_step_vs_golden(golden, gemm_precision):
 def test_mdvit_dsn_two_sweep_step_vs_golden(golden):
     """MDViT_DSN (domain-specific norms, mdvit.py:735-960): 4-domain two-sweep step against the real reference's
     fixture -- logits, losses, the per-domain running statistics (only the forward's own norms move), gradients of
-    every norm bank, and the train step harness (per-domain forwards; fusing is refused)"""
+    every norm bank, and the train step harness (per-domain forwards, and the domain-batched forward with the
+    group-indexed norm kernels)"""
     import mdvit_amd
     from mdvit_amd.losses import domain_losses
     from mdvit_amd.train import mdvit_train_step
@@ -229,8 +230,36 @@ def test_mdvit_dsn_two_sweep_step_vs_golden(golden):
     m2 = build()
     res = mdvit_train_step(m2, batches, optimizer=None, merged_sweeps=True)
     check(torch.stack([res["loss"], res["aux_loss"], res["kt_loss"]]), g["total_losses"], name="step losses")
-    with pytest.raises(NotImplementedError):
-        mdvit_train_step(build(), batches, optimizer=None, fuse_domains=4)
+    # the domain-batched step: ONE forward, norm bank row d on batch group d -- same losses, gradients, running statistics
+    m3 = build()
+    res3 = mdvit_train_step(m3, batches, optimizer=None, merged_sweeps=True, fuse_domains=4)
+    check(torch.stack([res3["loss"], res3["aux_loss"], res3["kt_loss"]]), g["total_losses"], name="domain-batched step losses")
+    sd3 = m3.state_dict()
+    check(torch.tensor([float(sd3[str(k)].double().sum()) for k in g["bn_names"]]), g["bn_sums"], name="BN running stats per domain (batched)")
+    assert int(sd3["stem_1.bns.2.num_batches_tracked"]) == 1
+    g2 = dict(m2.named_parameters())
+    for n, p in m3.named_parameters():
+        assert (p.grad is None) == (g2[n].grad is None), n
+        if p.grad is not None:
+            check_grad(p.grad, g2[n].grad, name=f"batched vs per-domain {n}", l2_tol=3e-4, max_tol=3e-3)
+    for key in g.files:
+        if key.startswith("grad::"):
+            check_grad(m3.get_parameter(key[6:]).grad.cpu(), g[key], name="batched " + key, l2_tol=1e-2)
+    # permuted / partial domain lists select the matching bank rows; repeated ids are refused
+    img2 = torch.cat([batches[3][0], batches[1][0]]); lab2 = F.one_hot(torch.tensor([3] * B + [1] * B), 4).float().to(dev())
+    m4 = build()
+    out2, aux2 = m4(img2, lab2, ["3", "1"])
+    check(out2[:B].reshape(-1)[::7], g["out_3"], name="batched ['3','1'] -> out_3")
+    check(aux2[B:].reshape(-1)[::7], g["aux_1"], name="batched ['3','1'] -> aux_1")
+    assert int(m4.state_dict()["stem_1.bns.3.num_batches_tracked"]) == 1 and int(m4.state_dict()["stem_1.bns.0.num_batches_tracked"]) == 0
+    with pytest.raises(ValueError):
+        m4(img2, lab2, ["1", "1"])
+    # eval: the running statistics of each group's own bank
+    m4.eval()
+    with torch.no_grad():
+        e_b = m4(img2, lab2, ["3", "1"])[0]
+        e_s = torch.cat([m4(img2[:B], lab2[:B], "3")[0], m4(img2[B:], lab2[B:], "1")[0]])
+    check(e_b, e_s, tol=1e-5, name="eval batched vs per-domain")
 
 
 def test_mdvit_eval_vs_golden(golden):
