@@ -10,7 +10,7 @@ import re
 from typing import List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmdvit_hip.so")
+LIB_PATH = os.environ.get("MDVIT_HIP_LIB") or os.path.join(_HERE, "lib", "libmdvit_hip.so")      # env: a variant build (tuning experiments)
 HEADER_PATH = os.path.join(_HERE, "..", "include", "mdvit_hip.h")
 
 EPI_NONE, EPI_GELU_DUAL, EPI_DGELU = 0, 1, 2

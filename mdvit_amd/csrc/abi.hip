@@ -46,54 +46,101 @@ int mdvit_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
 }
 
 namespace {
-// 8 columns x 32 row lanes per workgroup: lane r adds rows r, r+32, ... (4 loads in flight), the 32 lane sums are folded by a
-// fixed shuffle tree.  (Few outputs, up to ~1000 rows: the serial row walk, not bandwidth, sets the time.)
+// Column sums of partial rows: part [nblk][stride] -> out [n0 | n1].  A column QUAD (float4) is summed by LPQ row lanes
+// (lane r adds rows r, r+LPQ, ... with all of its loads in flight at once), 256/LPQ quads per workgroup; the lane sums are
+// folded by a fixed shuffle tree (and, for LPQ = 256, a fixed-order pass through LDS), so the result is deterministic.
+// LPQ follows the row count: ~1000 rows x few columns wants every thread on rows (the walk is latency, not bandwidth,
+// bound); a few rows x many columns (the attention's tile partials) wants the threads on columns.
+template <int LPQ>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, long stride, int n0,
-                                                              float* __restrict__ out0, int n1, float* __restrict__ out1, int accumulate) {
+                                                              float* __restrict__ out0, int n1, float* __restrict__ out1, int accumulate, int vec) {
+    __shared__ float4 s_red[4];
     const int n = n0 + n1;
-    const int rl = threadIdx.x & 31, cl = threadIdx.x >> 5;      // a 32-lane half-wavefront per column
-    const int i = blockIdx.x * 8 + cl;
-    part += (long)blockIdx.y * nblk * stride;        // batched mode (grid.y > 1): one reduction per batch, out0 [batch][n0]
+    const int rl = threadIdx.x % LPQ;
+    const int c = (blockIdx.x * (256 / LPQ) + threadIdx.x / LPQ) * 4;
+    part += (long)blockIdx.y * nblk * stride;        // batched mode (grid.y > 1): one reduction per batch, out [batch][n0] (+ [batch][n1])
     out0 += (long)blockIdx.y * n0;
     if (out1) out1 += (long)blockIdx.y * n1;
-    float s = 0.f;
-    if (i < n) {
-        int b = rl;
-        for (; b + 96 < nblk; b += 128) {
-            const float v0 = part[(long)b * stride + i], v1 = part[(long)(b + 32) * stride + i];
-            const float v2 = part[(long)(b + 64) * stride + i], v3 = part[(long)(b + 96) * stride + i];
-            s += v0; s += v1; s += v2; s += v3;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n) {
+        if (vec && c + 3 < n) {
+            int b = rl;
+            for (; b + 3 * LPQ < nblk; b += 4 * LPQ) {
+                const float4 v0 = *reinterpret_cast<const float4*>(part + (long)b * stride + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(b + LPQ) * stride + c);
+                const float4 v2 = *reinterpret_cast<const float4*>(part + (long)(b + 2 * LPQ) * stride + c);
+                const float4 v3 = *reinterpret_cast<const float4*>(part + (long)(b + 3 * LPQ) * stride + c);
+                s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+                s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+                s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+                s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+            }
+            for (; b < nblk; b += LPQ) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (long)b * stride + c);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        } else {
+            for (int b = rl; b < nblk; b += LPQ) {
+                const float* r = part + (long)b * stride + c;
+                s.x += r[0];
+                if (c + 1 < n) s.y += r[1];
+                if (c + 2 < n) s.z += r[2];
+                if (c + 3 < n) s.w += r[3];
+            }
         }
-        for (; b < nblk; b += 32) s += part[(long)b * stride + i];
     }
+    constexpr int W = LPQ < 64 ? LPQ : 64;
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_down(s, o, 32);
-    if (rl == 0 && i < n) {
-        float* dst = i < n0 ? out0 + i : (out1 ? out1 + (i - n0) : nullptr);
-        if (dst) *dst = accumulate ? *dst + s : s;
+    for (int o = W / 2; o > 0; o >>= 1) {
+        s.x += __shfl_down(s.x, o, W); s.y += __shfl_down(s.y, o, W); s.z += __shfl_down(s.z, o, W); s.w += __shfl_down(s.w, o, W);
     }
+    if (LPQ == 256) {
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float4 a = s_red[0], b = s_red[1], d = s_red[2], e = s_red[3];
+            s = make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
+        }
+    }
+    if (rl == 0 && c < n) {
+        const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c + j;
+            if (col >= n) break;
+            float* dst = col < n0 ? out0 + col : (out1 ? out1 + (col - n0) : nullptr);
+            if (dst) *dst = accumulate ? *dst + v[j] : v[j];
+        }
+    }
+}
+
+int launch_reduce(const float* part, int batches, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream) {
+    const int n = n0 + n1, nq = (n + 3) / 4;
+    const int vec = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0) && (((long)nblk * stride) % 4 == 0);
+    if (nblk >= 256)
+        hipLaunchKernelGGL((reduce_partials_kernel<256>), dim3(nq, batches), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate, vec);
+    else if (nblk >= 16)
+        hipLaunchKernelGGL((reduce_partials_kernel<32>), dim3((nq + 7) / 8, batches), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate, vec);
+    else
+        hipLaunchKernelGGL((reduce_partials_kernel<4>), dim3((nq + 63) / 64, batches), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate, vec);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
 }
 }  // namespace
 
 int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream) {
     if (n0 + n1 <= 0 || nblk <= 0) return MDVIT_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n0 + n1 + 7) / 8), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate);
-    MDVIT_LAUNCH_CHECK();
-    return MDVIT_OK;
+    return launch_reduce(part, 1, nblk, stride, n0, out0, n1, out1, accumulate, stream);
 }
 
 int mdvit_reduce_partials_batched(const float* part, int batches, int nblk, int n, float* out, hipStream_t stream) {
     if (n <= 0 || nblk <= 0 || batches <= 0) return MDVIT_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 7) / 8, batches), dim3(256), 0, stream, part, nblk, (long)n, n, out, 0, (float*)nullptr, 0);
-    MDVIT_LAUNCH_CHECK();
-    return MDVIT_OK;
+    return launch_reduce(part, batches, nblk, (long)n, n, out, 0, nullptr, 0, stream);
 }
 
 int mdvit_reduce_partials_batched2(const float* part, int batches, int nblk, int n0, float* out0, int n1, float* out1, hipStream_t stream) {
     if (n0 + n1 <= 0 || nblk <= 0 || batches <= 0) return MDVIT_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n0 + n1 + 7) / 8, batches), dim3(256), 0, stream, part, nblk, (long)(n0 + n1), n0, out0, n1, out1, 0);
-    MDVIT_LAUNCH_CHECK();
-    return MDVIT_OK;
+    return launch_reduce(part, batches, nblk, (long)(n0 + n1), n0, out0, n1, out1, 0, stream);
 }
 
 extern "C" size_t mdvit_partials_ws_bytes(int32_t n_outputs) {

@@ -139,29 +139,31 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
     }
 }
 
-// Combine the token-tile partials of the softmax(K)^T V product: online-softmax rescale by exp(m_t - m).  8 outputs (c,e)
-// per workgroup, 32 lanes walk the NT tiles of one output (a single thread per output paid NT dependent loads), lane
+// Combine the token-tile partials of the softmax(K)^T V product: online-softmax rescale by exp(m_t - m).  LPO lanes walk the
+// NT tiles of one output (c,e) -- 32 for the long token axes of the early stages (a single thread per output paid NT
+// dependent loads), 4 or 1 for the late stages' handful of tiles (where 32 lanes per output left 30 of them idle) -- lane
 // results folded by a fixed shuffle tree.  (The plain sums of the backward use mdvit_reduce_partials_batched.)
+template <int LPO>
 __global__ __launch_bounds__(256) void fa_combine_softmax_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_s,
                                                                  const float* __restrict__ ws_P, float* __restrict__ kmax, float* __restrict__ ksum,
                                                                  float* __restrict__ Mout, FaGeom g, int NT) {
-    const int b = blockIdx.y, rl = threadIdx.x & 31;
-    const int o = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (o >= g.C * g.Ch) return;                       // whole 32-lane groups leave together
+    const int b = blockIdx.y, rl = threadIdx.x % LPO;
+    const int o = blockIdx.x * (256 / LPO) + threadIdx.x / LPO;
+    if (o >= g.C * g.Ch) return;                       // whole LPO-lane groups leave together
     const int c = o / g.Ch, e = o % g.Ch;
     float m = -INFINITY;
-    for (int t = rl; t < NT; t += 32) m = fmaxf(m, ws_m[((long)b * NT + t) * g.C + c]);
+    for (int t = rl; t < NT; t += LPO) m = fmaxf(m, ws_m[((long)b * NT + t) * g.C + c]);
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    for (int off = LPO / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, LPO));
     float ssum = 0.f, acc = 0.f;
-    for (int t = rl; t < NT; t += 32) {
+    for (int t = rl; t < NT; t += LPO) {
         const long i = ((long)b * NT + t) * g.C + c;
         const float f = expf(ws_m[i] - m);
         ssum = fmaf(ws_s[i], f, ssum);
         acc = fmaf(ws_P[i * g.Ch + e], f, acc);
     }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) { ssum += __shfl_down(ssum, off, 32); acc += __shfl_down(acc, off, 32); }
+    for (int off = LPO / 2; off > 0; off >>= 1) { ssum += __shfl_down(ssum, off, LPO); acc += __shfl_down(acc, off, LPO); }
     if (rl == 0) {
         Mout[((long)b * g.C + c) * g.Ch + e] = acc / ssum;
         if (e == 0) { kmax[(long)b * g.C + c] = m; ksum[(long)b * g.C + c] = ssum; }
@@ -365,7 +367,15 @@ __global__ __launch_bounds__(256) void da_fwd_kernel(const float* __restrict__ l
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
-        for (int i = 0; i < hid; ++i) s = fmaf(h1[i], W2[(long)c * hid + i], s);
+        const float* wr = W2 + (long)c * hid;
+        if ((hid & 3) == 0 && (reinterpret_cast<uintptr_t>(wr) & 15) == 0) {
+            for (int i = 0; i < hid; i += 4) {           // same summation order, a quarter of the dependent loads
+                const float4 w4 = *reinterpret_cast<const float4*>(wr + i);
+                s = fmaf(h1[i], w4.x, s); s = fmaf(h1[i + 1], w4.y, s); s = fmaf(h1[i + 2], w4.z, s); s = fmaf(h1[i + 3], w4.w, s);
+            }
+        } else {
+            for (int i = 0; i < hid; ++i) s = fmaf(h1[i], wr[i], s);
+        }
         z[c] = s + b2[c];
     }
     __syncthreads();
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(256) void da_fwd_kernel(const float* __restrict__ l
 
 // backward from e = a * dL/da:  dz[c] = e[c] - a[c] * sum_{heads} e[., ch]   (softmax over heads)
 // stage 1 (grid = B): dz -> dzbuf [B,C], relu(h1) -> hbuf [B,hid], dh -> dhbuf [B,hid]
-__global__ __launch_bounds__(256) void da_bwd_stage1_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
+__global__ __launch_bounds__(1024) void da_bwd_stage1_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
                                                             const float* __restrict__ W2, const float* __restrict__ a, const float* __restrict__ e,
                                                             float* __restrict__ dzbuf, float* __restrict__ hbuf, float* __restrict__ dhbuf,
                                                             int D, int hid, int C, int heads, float scale) {
@@ -397,12 +407,13 @@ __global__ __launch_bounds__(256) void da_bwd_stage1_kernel(const float* __restr
         dzbuf[(long)b * C + c] = v;
     }
     __syncthreads();
-    // t[i] = sum_c dz[c] W2[c][i]: the C-long walk is split over 256/hid thread groups (a single thread per i paid C
+    // t[i] = sum_c dz[c] W2[c][i]: the C-long walk is split over blockDim/hid thread groups (a single thread per i paid C
     // dependent L2 round trips -- 30 us per launch on a B-block grid), partial sums meet in LDS in a fixed order
     float* tpart = sm + C;                 // [nseg][hid]
-    const int nseg = hid <= 256 ? 256 / hid : 1;
-    for (int i0 = 0; i0 < hid; i0 += 256) {
-        const int i = i0 + (int)threadIdx.x % (hid <= 256 ? hid : 256), seg = hid <= 256 ? (int)threadIdx.x / hid : 0;
+    const int BD = blockDim.x;
+    const int nseg = hid <= BD ? BD / hid : 1;
+    for (int i0 = 0; i0 < hid; i0 += BD) {
+        const int i = i0 + (int)threadIdx.x % (hid <= BD ? hid : BD), seg = hid <= BD ? (int)threadIdx.x / hid : 0;
         if (i < hid && seg < nseg) {
             const int c_beg = (int)((long)C * seg / nseg), c_end = (int)((long)C * (seg + 1) / nseg);
             float t = 0.f;
@@ -517,7 +528,12 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
         }
 #undef FA_PART_LAUNCH
     }
-    hipLaunchKernelGGL(fa_combine_softmax_kernel, dim3(cdiv((long)C * g.Ch, 8), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
+    if (NT > 8)
+        hipLaunchKernelGGL((fa_combine_softmax_kernel<32>), dim3(cdiv((long)C * g.Ch, 8), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
+    else if (NT > 2)
+        hipLaunchKernelGGL((fa_combine_softmax_kernel<4>), dim3(cdiv((long)C * g.Ch, 64), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
+    else
+        hipLaunchKernelGGL((fa_combine_softmax_kernel<1>), dim3(cdiv((long)C * g.Ch, 256), B), dim3(256), 0, s, ws_m, ws_s, ws_P, kmax, ksum, Mmat, g, NT);
     MDVIT_CHECK_ARG(C <= 512, MDVIT_E_SHAPE, "factoratt_fwd: C=%d > 512 not built", C);
     // U = dwconv_win(v) + bias, one tiled launch per window class (channels [0,s3*Ch) | [..) | [..))
     const int Ch = g.Ch, c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
@@ -674,7 +690,7 @@ extern "C" int mdvit_da_bwd(const float* label, const float* W1, const float* b1
     float* dzbuf = (float*)ws;
     float* hbuf = dzbuf + (long)B * C;
     float* dhbuf = hbuf + (long)B * hid;
-    hipLaunchKernelGGL(da_bwd_stage1_kernel, dim3(B), dim3(256), sizeof(float) * (C + (size_t)max(hid, 256)), s, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads, scale);
+    hipLaunchKernelGGL(da_bwd_stage1_kernel, dim3(B), dim3(1024), sizeof(float) * (C + (size_t)max(hid, 1024)), s, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads, scale);
     const long total = (long)C * hid + (long)hid * D + C + hid;
     hipLaunchKernelGGL(da_bwd_stage2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, label, dzbuf, hbuf, dhbuf, dW1, db1, dW2, db2, B, D, hid, C);
     MDVIT_LAUNCH_CHECK();

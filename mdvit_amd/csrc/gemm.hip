@@ -10,6 +10,9 @@
 // Replaces nn.Linear / 1x1 nn.Conv2d / einsum call sites of the reference:
 //   mdvit.py:288 (qkv), :310-311 (proj+drop), mpvit.py:71-78 (Mlp), Decoders.py:196,319-331 (1x1 convs).
 #include "common.h"
+#ifndef MDVIT_NO_DB
+#define MDVIT_NO_DB 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     constexpr int KT = BK / 4;                                        // threads per k-contiguous row
     // 64x64 tiles (little MFMA work per K slab) double-buffer the LDS stage: the next slab is written while the current
     // one is being multiplied, ONE barrier per slab instead of two.  (The larger tiles would exceed the 64 KB static limit.)
-    constexpr bool DB = (BM == 64 && BN == 64 && !TA);     // (the pair-staged wgrad measured slower with the doubled LDS footprint)
+    constexpr bool DB = (BM == 64 && BN == 64 && !TA) && !MDVIT_NO_DB;     // (the pair-staged wgrad measured slower with the doubled LDS footprint)
     __shared__ __attribute__((aligned(16))) float smem[DB ? 2 * SMEM_FLOATS : SMEM_FLOATS];
     float* As = smem;
     float* Bs = smem + BK * LDSA;

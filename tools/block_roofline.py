@@ -1,0 +1,183 @@
+"""Roofline of ONE MHSA + Domain-Adapter block (SerialBlock_adapt, mdvit.py:316-361) forward + backward on the GPU.
+
+BASELINE.json's target is quoted on "the fused MHSA+DA block at bs=32, 512x512": this tool times that block alone at
+the four encoder stage shapes (tokens N = (512/4/2^s)^2, C = 64/128/320/512, 8 heads, MLP ratio 8/8/4/4) and prices it
+against the chip roofs.  The bound is the sum over the block's operators of max(bytes / 8 TB/s, flops / MFMA roof),
+bytes = the operator's compulsory fp32 inputs + outputs (the layout in HBM; nothing is counted twice inside an
+operator, nothing is assumed fused across operators beyond what the reference math allows: bias / GELU / dropout /
+DropPath / residual ride in the GEMM that produces the tensor, the Domain Adapter rides in the attention kernel).
+
+    python tools/block_roofline.py [--batch 32] [--iters 10] [--json out.json]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+HBM = 8.0e12
+MFMA = {"bf16x3": 2500e12 / 3.0, "fp32": 157.3e12}       # useful flops/s (bf16x3 spends 3 bf16 MFMAs per product)
+ATT_MFMA = 157.3e12                                      # the attention's small products run on fp32 MFMA
+
+
+def block_ops(T, C, Hd, heads):
+    """(name, floats moved, flops, mfma roof key) per operator of the block; T = B*N tokens."""
+    Ch = C // heads
+    taps = 60.0          # 2 * mean window taps per channel: heads 2x(3x3) + 3x(5x5) + 3x(7x7) -> 30 MACs
+    f = []
+    # ---- forward
+    f += [("cpe dw3x3 + x", 2 * T * C, 18 * T * C, None)]
+    f += [("LN1", 2 * T * C, 8 * T * C, None)]
+    f += [("qkv GEMM", T * C + 3 * C * C + 3 * T * C, 6 * T * C * C, "gemm")]
+    f += [("factor-att + crpe + DA", 4 * T * C, 4 * T * C * Ch + taps * T * C, "att")]
+    f += [("proj GEMM + drop + res", 3 * T * C + C * C, 2 * T * C * C, "gemm")]
+    f += [("LN2", 2 * T * C, 8 * T * C, None)]
+    f += [("fc1 GEMM + GELU", T * C + C * Hd + T * Hd, 2 * T * C * Hd, "gemm")]
+    f += [("fc2 GEMM + drop + res", T * Hd + C * Hd + 2 * T * C, 2 * T * C * Hd, "gemm")]
+    b = []
+    # ---- backward
+    b += [("fc2 dgrad (x gelu')", T * C + C * Hd + 2 * T * Hd, 2 * T * C * Hd, "gemm")]
+    b += [("fc2 wgrad", T * Hd + T * C + C * Hd, 2 * T * C * Hd, "gemm")]
+    b += [("fc1 dgrad", T * Hd + C * Hd + T * C, 2 * T * C * Hd, "gemm")]
+    b += [("fc1 wgrad", T * C + T * Hd + C * Hd, 2 * T * C * Hd, "gemm")]
+    b += [("LN2 bwd (+res grad)", 4 * T * C, 12 * T * C, None)]
+    b += [("proj dgrad", 2 * T * C + C * C, 2 * T * C * C, "gemm")]
+    b += [("proj wgrad", 2 * T * C + C * C, 2 * T * C * C, "gemm")]
+    b += [("factor-att + crpe + DA bwd", 7 * T * C, 8 * T * C * Ch + 2 * taps * T * C, "att")]
+    b += [("qkv dgrad", 3 * T * C + 3 * C * C + T * C, 6 * T * C * C, "gemm")]
+    b += [("qkv wgrad", T * C + 3 * T * C + 3 * C * C, 6 * T * C * C, "gemm")]
+    b += [("LN1 bwd (+res grad)", 4 * T * C, 12 * T * C, None)]
+    b += [("cpe bwd", 2 * T * C, 36 * T * C, None)]
+    return f, b
+
+
+def bound_seconds(ops_list, precision):
+    tot = 0.0
+    rows = []
+    for name, floats, flops, kind in ops_list:
+        tb = 4.0 * floats / HBM
+        tf = flops / (MFMA[precision] if kind == "gemm" else ATT_MFMA) if kind else 0.0
+        tot += max(tb, tf)
+        rows.append({"op": name, "bytes": 4.0 * floats, "flops": float(flops), "bound_us": 1e6 * max(tb, tf), "by": "hbm" if tb >= tf else "mfma"})
+    return tot, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--img", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--drop", type=float, default=0.1, help="drop_rate = drop_path_rate of the block (the train scripts' 0.1)")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--stages", default="0,1,2,3")
+    ap.add_argument("--eager", action="store_true", help="time eager launches (host-bound on the small stages) instead of HIP-graph replays")
+    args = ap.parse_args()
+
+    from mdvit_amd import ops
+    from mdvit_amd.blocks import MHSA_stage_adapt, init_weights_
+    ops.set_gemm_precision(args.precision)
+    dev = torch.device("cuda:0")
+    dims, ratios, heads = [64, 128, 320, 512], [8, 8, 4, 4], 8
+    B = args.batch
+    out = {"batch": B, "img": args.img, "precision": args.precision, "hbm_peak": HBM, "mfma_peak": MFMA[args.precision], "stages": []}
+    tot_fb = [0.0, 0.0, 0.0, 0.0]
+    for s, (C, r) in enumerate(zip(dims, ratios)):
+        if str(s) not in args.stages.split(","):
+            continue
+        side = args.img // 4 // (2 ** s)
+        N, T, Hd = side * side, B * side * side, C * r
+        torch.manual_seed(10 + s)
+        st = MHSA_stage_adapt(N, C, 1, heads, r, qkv_bias=True, drop_rate=args.drop, attn_drop_rate=0.0, drop_path_rate=args.drop,
+                              num_domains=4, adapt_method="Sup")
+        init_weights_(st)
+        st = st.to(dev).train()
+        blk = st.mhca_blks[0]
+        x = torch.randn(B, N, C, device=dev).requires_grad_(True)
+        lab = F.one_hot(torch.full((B,), 1), 4).float().to(dev)
+        g = torch.randn(B, N, C, device=dev)
+
+        def fwd():
+            return blk(x, (side, side), lab)
+
+        wstream = torch.cuda.Stream()         # warm up on a side stream, as torch asks before a capture that runs backward
+        wstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(wstream):
+            for _ in range(args.warmup):
+                y = fwd(); y.backward(g)
+                ops.refresh_transposes()
+        torch.cuda.current_stream().wait_stream(wstream)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf = tb = 0.0
+        if args.eager:
+            for _ in range(args.iters):
+                for p in st.parameters():
+                    p.grad = None
+                x.grad = None
+                ev[0].record(); y = fwd(); ev[1].record(); y.backward(g); ev[2].record()
+                torch.cuda.synchronize()
+                tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2])
+            tf, tb = tf / args.iters * 1e-3, tb / args.iters * 1e-3
+        else:
+            # GPU time without the host's launch cadence: replay the forward, and forward + backward, as HIP graphs
+            # (the training step keeps the queue full, so this -- not the eager time of an isolated block -- is what a
+            # block costs inside it); backward = (forward + backward) - forward
+            ops.enable_device_seed(True)
+            times = []
+            for with_bwd in (False, True):
+                for p in st.parameters():
+                    p.grad = None
+                x.grad = None
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    if with_bwd:
+                        y = fwd()
+                        y.backward(g)
+                    else:
+                        with torch.no_grad():       # the same forward kernels; nothing is kept for a backward
+                            y = fwd()
+                gr.replay(); torch.cuda.synchronize()
+                ev[0].record()
+                for _ in range(args.iters):
+                    gr.replay()
+                ev[1].record()
+                torch.cuda.synchronize()
+                times.append(ev[0].elapsed_time(ev[1]) / args.iters * 1e-3)
+                del gr
+            tf, tb = times[0], times[1] - times[0]
+        fo, bo = block_ops(T, C, Hd, heads)
+        bf, rows_f = bound_seconds(fo, args.precision)
+        bb, rows_b = bound_seconds(bo, args.precision)
+        by = sum(4.0 * o[1] for o in fo + bo)
+        fl = sum(o[2] for o in fo + bo)
+        rec = {"stage": s, "C": C, "tokens_per_image": N, "rows": T, "hidden": Hd,
+               "fwd_ms": tf * 1e3, "bwd_ms": tb * 1e3, "bound_fwd_ms": bf * 1e3, "bound_bwd_ms": bb * 1e3,
+               "frac_fwd": bf / tf, "frac_bwd": bb / tb, "frac": (bf + bb) / (tf + tb),
+               "algorithmic_GB": by / 1e9, "GFLOP": fl / 1e9, "achieved_TBps": by / (tf + tb) / 1e12, "achieved_TFLOPs": fl / (tf + tb) / 1e12,
+               "ops_fwd": rows_f, "ops_bwd": rows_b}
+        out["stages"].append(rec)
+        for i, v in enumerate((tf, tb, bf, bb)):
+            tot_fb[i] += v
+        print(f"stage {s}: C={C:4d} N={N:6d} rows={T:8d}  fwd {tf * 1e3:7.3f} ms (bound {bf * 1e3:6.3f}, {100 * bf / tf:4.1f}%)  "
+              f"bwd {tb * 1e3:7.3f} ms (bound {bb * 1e3:6.3f}, {100 * bb / tb:4.1f}%)  block {100 * (bf + bb) / (tf + tb):4.1f}% of roofline  "
+              f"[{by / (tf + tb) / 1e12:.2f} TB/s, {fl / (tf + tb) / 1e12:.1f} TF/s]", flush=True)
+        del st, blk, x, g, y
+        torch.cuda.empty_cache()
+    out["all_stages"] = {"fwd_ms": tot_fb[0] * 1e3, "bwd_ms": tot_fb[1] * 1e3, "bound_fwd_ms": tot_fb[2] * 1e3, "bound_bwd_ms": tot_fb[3] * 1e3,
+                         "frac": (tot_fb[2] + tot_fb[3]) / (tot_fb[0] + tot_fb[1])}
+    print(f"all four stages: {100 * out['all_stages']['frac']:.1f}% of the roofline bound")
+    if args.json:
+        with open(args.json, "w") as fh:
+            json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
