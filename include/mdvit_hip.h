@@ -79,6 +79,11 @@ typedef struct MdvitGemmDesc {
                                        * accumulation (~1e-5 relative); built for NT (all epilogues) and TN (plain) */
     const uint32_t* drop_seed;        /* optional device {s0,s1}: effective keys (key0 ^ s0, key1 + s1) -- lets a captured
                                          HIP graph draw fresh dropout masks on every replay */
+    /* DGELU with a RECOMPUTED pre-activation (NT only, gelu_u == NULL): u = rc_a[M,rc_k] rc_b[N,rc_k]^T + rc_bias[N] is formed
+     * in the kernel as a second product over the output tile, with the slab / MFMA sequence of the forward GEMM (bit-identical
+     * u).  For the MLP of the C <= 128 stages (Mlp.fc1, mpvit.py:73-76: K = C): the forward then stores gelu(u) only
+     * (GELU_DUAL with C2 == NULL writes gelu(u) x dropout to C) and neither pass moves the [tokens, hidden] u through HBM. */
+    const float* rc_a; int64_t rc_lda; const float* rc_b; int64_t rc_ldb; const float* rc_bias; int32_t rc_k;
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */

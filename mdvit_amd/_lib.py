@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("colsum_a", vp),
         ("precision", i32),
         ("drop_seed", vp),
+        ("rc_a", vp), ("rc_lda", i64), ("rc_b", vp), ("rc_ldb", i64), ("rc_bias", vp), ("rc_k", i32),
     ]
 
 

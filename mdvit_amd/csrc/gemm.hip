@@ -36,6 +36,7 @@ struct GemmArgs {
     const float* e_rowscale; int e_rows_per_scale;
     const float* residual; long ldr;
     const float* gelu_u; long ldu;
+    const float* rc_a; long rc_lda; const float* rc_b; long rc_ldb; const float* rc_bias; int rc_k;    // DGELU_RC: u = rc_a rc_b^T + rc_bias
     int splits; int k_per_split;   // split along K: each split writes a dense [M,N] slab, reduced by a second kernel
     float* slab;
     int accumulate;
@@ -55,7 +56,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // do-everything kernel was ~20k instructions, far beyond the instruction cache):
 //   0 PLAIN  : (+bias) | split slab | accumulate        1 GELU_DUAL    2 DGELU (x dropout mask)
 //   3 FULL   : +bias, dropout, DropPath row scale, +residual
-enum { EPI_PLAIN = 0, EPI_GELU2 = 1, EPI_DGELU = 2, EPI_FULL = 3 };
+//   4 DGELU_RC : DGELU whose pre-activation u is not read from HBM but RECOMPUTED in the kernel as a second product
+//                u = rc_a rc_b^T + rc_bias over the same output tile (the MLP's fc1: K = C <= 128, a few MFMAs) -- the same
+//                slab / MFMA sequence as the forward GEMM, so u is bit-identical to the one the forward computed.  Saves the
+//                forward's store of u and this kernel's read of it ([tokens, hidden] each) on the HBM-bound MLPs.
+enum { EPI_PLAIN = 0, EPI_GELU2 = 1, EPI_DGELU = 2, EPI_FULL = 3, EPI_DGELU_RC = 4 };
 
 // BF3 ("bf16x3", NT layout only): every fp32 operand is split as x = hi + lo (two RNE bf16 values, |x - hi - lo| <= 2^-18 |x|)
 // while it is staged into LDS, and each product runs as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
@@ -121,8 +126,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
+    constexpr bool RC = EPI == EPI_DGELU_RC;
+    int kbeg = blockIdx.y * p.k_per_split;
+    int kend = min(p.K, kbeg + p.k_per_split);
+    const float* gA = p.A; const float* gB = p.B;          // the operands the staging lambdas read (RC swaps them between its two products)
+    long glda = p.lda, gldb = p.ldb;
+    if (RC) { gA = p.rc_a; glda = p.rc_lda; gB = p.rc_b; gldb = p.rc_ldb; kbeg = 0; kend = p.rc_k; }
     const int wm0 = (wave / WAVES_N) * (BM / WAVES_M), wn0 = (wave % WAVES_N) * (BN / WAVES_N);
 
     f32x16 acc[WTM][WTN];
@@ -148,8 +157,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 const int k = k0 + 2 * kp, m = m0 + 4 * mq;
                 float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
                 if (m < p.M) {
-                    if (k < kend) x0 = *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m);
-                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(p.A + (long)(k + 1) * p.lda + m);
+                    if (k < kend) x0 = *reinterpret_cast<const float4*>(gA + (long)k * glda + m);
+                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(gA + (long)(k + 1) * glda + m);
                 }
                 ra[2 * v] = x0; ra[2 * v + 1] = x1;
             }
@@ -160,11 +169,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TA) {   // A[m][k], k contiguous: BK/4 threads per row
                 const int r = tid / KT + v * (NTHREADS / KT), m = m0 + r, k = k0 + (tid % KT) * 4;
-                if (m < p.M && k < kend) x = *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k);
+                if (m < p.M && k < kend) x = *reinterpret_cast<const float4*>(gA + (long)m * glda + k);
             } else {     // A stored [k][m], m contiguous (wgrad: A = dY^T)
                 constexpr int TPR = BM / 4;                 // threads per k-row
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, m = m0 + (tid % TPR) * 4;
-                if (k < kend && m < p.M) x = *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m);
+                if (k < kend && m < p.M) x = *reinterpret_cast<const float4*>(gA + (long)k * glda + m);
             }
             ra[v] = x;
         }
@@ -177,8 +186,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                 const int k = k0 + 2 * kp, n = n0 + 4 * nq;
                 float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
                 if (n < p.N) {
-                    if (k < kend) x0 = *reinterpret_cast<const float4*>(p.B + (long)k * p.ldb + n);
-                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(p.B + (long)(k + 1) * p.ldb + n);
+                    if (k < kend) x0 = *reinterpret_cast<const float4*>(gB + (long)k * gldb + n);
+                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(gB + (long)(k + 1) * gldb + n);
                 }
                 rb[2 * v] = x0; rb[2 * v + 1] = x1;
             }
@@ -189,11 +198,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TB) {    // B[n][k], k contiguous (weights as stored by nn.Linear)
                 const int r = tid / KT + v * (NTHREADS / KT), n = n0 + r, k = k0 + (tid % KT) * 4;
-                if (n < p.N && k < kend) x = *reinterpret_cast<const float4*>(p.B + (long)n * p.ldb + k);
+                if (n < p.N && k < kend) x = *reinterpret_cast<const float4*>(gB + (long)n * gldb + k);
             } else {     // B[k][n], n contiguous
                 constexpr int TPR = BN / 4;
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, n = n0 + (tid % TPR) * 4;
-                if (k < kend && n < p.N) x = *reinterpret_cast<const float4*>(p.B + (long)k * p.ldb + n);
+                if (k < kend && n < p.N) x = *reinterpret_cast<const float4*>(gB + (long)k * gldb + n);
             }
             rb[v] = x;
         }
@@ -305,6 +314,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             if (src && row < p.M && col < p.N) epre[q] = *reinterpret_cast<const float4*>(src + (long)row * lds_ + col);
         }
     }
+    auto run_product = [&]() {
     load_a(kbeg);
     load_b(kbeg);
     store_smem();
@@ -371,6 +381,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
             __syncthreads();
         }
     }
+    if (DB) stage(0);
+    };
+
+    f32x16 uacc[RC ? WTM : 1][RC ? WTN : 1];
+    if (RC) {                      // first product: the pre-activation tile; then the gradient product over the real operands
+        run_product();
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { uacc[i][j][r] = acc[i][j][r]; acc[i][j][r] = 0.f; }
+        gA = p.A; glda = p.lda; gB = p.B; gldb = p.ldb; kbeg = 0; kend = p.K;
+    }
+    run_product();
 
     if (TA && do_cs) {              // (the main loop ended with a barrier: the staging LDS is free)
         float* s_cs = smem;
@@ -439,12 +464,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
                         const float4 ds = mdvit_drop_scale4(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
                         h.x *= ds.x; h.y *= ds.y; h.z *= ds.z; h.w *= ds.w;
                     }
-                    *reinterpret_cast<float4*>(dst) = v;
-                    *reinterpret_cast<float4*>(p.C2 + (long)row * p.ldc + col) = h;
+                    if (p.C2) {                     // dual store: C = pre-activation u, C2 = gelu(u) x dropout
+                        *reinterpret_cast<float4*>(dst) = v;
+                        *reinterpret_cast<float4*>(p.C2 + (long)row * p.ldc + col) = h;
+                    } else {                        // single store (the backward recomputes u: EPI_DGELU_RC)
+                        *reinterpret_cast<float4*>(dst) = h;
+                    }
                     continue;
                 }
                 if (EPI == EPI_DGELU) {
                     const float4 u4 = EPRE ? epre[q] : *reinterpret_cast<const float4*>(p.gelu_u + (long)row * p.ldu + col);
+                    v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
+                }
+                if (RC) {
+                    float4 u4 = make_float4(uacc[RC ? i : 0][RC ? j : 0][4 * q + 0], uacc[RC ? i : 0][RC ? j : 0][4 * q + 1],
+                                            uacc[RC ? i : 0][RC ? j : 0][4 * q + 2], uacc[RC ? i : 0][RC ? j : 0][4 * q + 3]);
+                    if (p.rc_bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.rc_bias + col); u4.x += b4.x; u4.y += b4.y; u4.z += b4.z; u4.w += b4.w; }
                     v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
                 }
                 if (p.e_drop) {
@@ -506,11 +541,13 @@ int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, int bf3, hipStream_t 
         if (bf3) {
             if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2, true);
             else if (epi == EPI_DGELU) MDVIT_GEMM_LAUNCH(false, true, EPI_DGELU, true);
+            else if (epi == EPI_DGELU_RC) { if (BM == 64 && BN == 64) MDVIT_GEMM_LAUNCH(false, true, (BM == 64 && BN == 64 ? EPI_DGELU_RC : EPI_DGELU), true); else return 1; }
             else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL, true);
             else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, true);
             else return 1;
         } else {
             if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2, false);
+            else if (epi == EPI_DGELU_RC) { if (BM == 64 && BN == 64) MDVIT_GEMM_LAUNCH(false, true, (BM == 64 && BN == 64 ? EPI_DGELU_RC : EPI_GELU2), false); else return 1; }
             else if (epi == EPI_FULL) MDVIT_GEMM_LAUNCH(false, true, EPI_FULL, false);
             else if (epi == EPI_PLAIN) MDVIT_GEMM_LAUNCH(false, true, EPI_PLAIN, false);
             else return 1;
@@ -551,7 +588,8 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
     best.kps = cdiv(d->K, BK) * BK;
     double best_cost = 1e300;
     for (int c = 0; c < 3; ++c) {
-        if (g_force_cfg >= 0 && c != g_force_cfg) continue;
+        if (g_force_cfg >= 0 && c != g_force_cfg && !d->rc_a) continue;
+        if (d->rc_a && c != 2) continue;                 // the recomputing epilogue is built on the 64x64 tile (two accumulator sets)
         const long tm = cdiv(d->M, BMs[c]), tn = cdiv(d->N, BNs[c]);
         const long tiles = tm * tn;
         for (int si = 0; si < (int)(sizeof(SPLITS) / sizeof(int)); ++si) {
@@ -567,7 +605,7 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
             // bf16x3: 3 x 32-cycle MFMAs per 32x32x16 on 4 SIMDs, plus the hi/lo split of every staged element (VALU)
             // epilogue: the 64x64 tile prefetches gelu_u / the residual ahead of the K loop; the larger tiles load them in the
             // epilogue, exposed to HBM latency at 2 workgroups per CU
-            const bool loads_epi = d->epi == MDVIT_EPI_DGELU || d->residual != nullptr;
+            const bool loads_epi = (d->epi == MDVIT_EPI_DGELU && !d->rc_a) || d->residual != nullptr;
             const double epi_cycles = (loads_epi && c != 2 ? 30.0 : 6.0) * BMs[c] * BNs[c] / 64.0;
             const double wg_cycles = d->precision == 1
                 ? 0.0015 * BMs[c] * BNs[c] * (double)kps + (d->trans_a ? 0.12 : 0.06) * (BMs[c] + BNs[c]) * (double)kps + 800.0 + epi_cycles
@@ -594,8 +632,13 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
                     "gemm: operands must be 16-byte aligned with leading dimensions %% 4 == 0 (lda=%ld ldb=%ld)", d->lda, d->ldb);
     MDVIT_CHECK_ARG(d->trans_a ? (d->M % 4 == 0) : (d->K % 4 == 0), MDVIT_E_ALIGN, "gemm: contiguous extent of A must be %% 4 (M=%d K=%d ta=%d)", d->M, d->K, d->trans_a);
     MDVIT_CHECK_ARG(d->trans_b ? (d->K % 4 == 0) : (d->N % 4 == 0), MDVIT_E_ALIGN, "gemm: contiguous extent of B must be %% 4 (N=%d K=%d tb=%d)", d->N, d->K, d->trans_b);
-    MDVIT_CHECK_ARG(d->epi != MDVIT_EPI_GELU_DUAL || d->C2, MDVIT_E_SHAPE, "gemm: GELU_DUAL needs C2");
-    MDVIT_CHECK_ARG(d->epi != MDVIT_EPI_DGELU || d->gelu_u, MDVIT_E_SHAPE, "gemm: DGELU needs gelu_u");
+    MDVIT_CHECK_ARG(d->epi != MDVIT_EPI_DGELU || d->gelu_u || d->rc_a, MDVIT_E_SHAPE, "gemm: DGELU needs gelu_u (or rc_a/rc_b to recompute it)");
+    if (d->rc_a) {
+        MDVIT_CHECK_ARG(d->epi == MDVIT_EPI_DGELU && !d->gelu_u && d->rc_b && d->rc_k > 0 && !d->trans_a && d->trans_b, MDVIT_E_SHAPE,
+                        "gemm: rc_a/rc_b (recomputed pre-activation) go with the NT DGELU epilogue and no gelu_u");
+        MDVIT_CHECK_ARG(aligned16(d->rc_a) && aligned16(d->rc_b) && d->rc_lda % 4 == 0 && d->rc_ldb % 4 == 0 && d->rc_k % 4 == 0 &&
+                        (!d->rc_bias || aligned16(d->rc_bias)), MDVIT_E_ALIGN, "gemm: rc operands must be 16-byte aligned, leading dimensions and rc_k %% 4 == 0");
+    }
     MDVIT_CHECK_ARG(!(d->e_drop_p > 0.f) || (long)d->M * d->N < (1L << 32), MDVIT_E_SHAPE, "gemm: dropout index space exceeds 2^32");
 
     GemmArgs a;
@@ -608,6 +651,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.e_thresh = (uint32_t)((double)d->e_drop_p * 4294967296.0); a.e_inv_keep = 1.f / (1.f - d->e_drop_p);
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
+    a.rc_a = d->rc_a; a.rc_lda = d->rc_lda; a.rc_b = d->rc_b; a.rc_ldb = d->rc_ldb; a.rc_bias = d->rc_bias; a.rc_k = d->rc_k;
     a.accumulate = d->accumulate;
     a.colsum = d->colsum_a;
     MDVIT_CHECK_ARG(!d->colsum_a || (d->trans_a && !d->trans_b), MDVIT_E_SHAPE, "gemm: colsum_a rides on the TN (wgrad) layout only");
@@ -625,7 +669,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     // epilogue kind
     int epi = EPI_PLAIN;
     if (d->epi == MDVIT_EPI_GELU_DUAL) epi = EPI_GELU2;
-    else if (d->epi == MDVIT_EPI_DGELU) epi = EPI_DGELU;
+    else if (d->epi == MDVIT_EPI_DGELU) epi = d->rc_a ? EPI_DGELU_RC : EPI_DGELU;
     else if (a.e_drop || d->e_rowscale || d->residual) epi = EPI_FULL;
     a.vec = ((d->N & 3) == 0) && ((d->ldc & 3) == 0) && aligned16(d->C);
     if (epi != EPI_PLAIN) {

@@ -306,10 +306,19 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
     }
     if (MODE == 2) {
         if (!p.out) return;                   // masked copy only
-#pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&s_acc[c + j], s1[j]);
+        // fixed-order fold of the threads that share a channel quad (as MODE 0/1 below), one partial row per workgroup
+        float* s_p4 = s_acc + 2 * p.C;        // [blockDim][4]
+        *reinterpret_cast<float4*>(&s_p4[threadIdx.x * 4]) = make_float4(s1[0], s1[1], s1[2], s1[3]);
         __syncthreads();
-        for (int i = threadIdx.x; i < p.C; i += blockDim.x) p.part[(long)blockIdx.x * p.C + i] = s_acc[i];   // one partial row per workgroup
+        const int bq0 = (int)(((long)blockIdx.x * blockDim.x) % QC);
+        for (int qq = threadIdx.x; qq < QC; qq += blockDim.x) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tt = (qq - bq0 + QC) % QC; tt < (int)blockDim.x; tt += QC) {
+                const float4 v = *reinterpret_cast<const float4*>(&s_p4[tt * 4]);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            *reinterpret_cast<float4*>(p.part + (long)blockIdx.x * p.C + qq * 4) = a;
+        }
         return;
     }
     // MODE 0/1: bitwise-reproducible reduction.  Every thread parks its 8 partials in LDS; the partials of one
@@ -701,7 +710,7 @@ extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* 
     fill_drop(a, drop_p, key0, key1, 1);
     a.seed = seed;
     a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-    hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(nblk), dim3(256), sizeof(float) * 2 * N, s, a);
+    hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(nblk), dim3(256), sizeof(float) * (2 * N + 256 * 4), s, a);
     MDVIT_LAUNCH_CHECK();
     return out ? mdvit_reduce_partials((const float*)ws, nblk, (long)N, N, out, 0, nullptr, accumulate, s) : MDVIT_OK;
 }

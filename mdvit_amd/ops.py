@@ -201,7 +201,8 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
-         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None):
+         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None, rc=None):
+    """rc = (a, lda, b, ldb, bias, k): DGELU with the pre-activation recomputed in the kernel (include/mdvit_hip.h)."""
     if precision is None:
         precision = _gemm_precision if (bool(trans_b) != bool(trans_a)) else 0      # built for NT and TN
     d = GemmDesc()
@@ -220,6 +221,8 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.precision = int(precision)
     d.colsum_a = colsum_a
     d.drop_seed = _seed_ptr() if e_drop > 0 else None
+    if rc is not None:
+        d.rc_a, d.rc_lda, d.rc_b, d.rc_ldb, d.rc_bias, d.rc_k = rc
     ws = None
     if allow_split:
         need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
@@ -231,7 +234,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
         #  so an event pair around them measures the wait as well; rocprofv3 has their true durations)
         call("mdvit_gemm_f32", C.byref(d), _stream())
         return
-    kepi = 1 if epi == _lib.EPI_GELU_DUAL else 2 if epi == _lib.EPI_DGELU else \
+    kepi = 1 if epi == _lib.EPI_GELU_DUAL else (4 if rc is not None else 2) if epi == _lib.EPI_DGELU else \
         3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
     pkey = (M, N, K, bool(trans_a), bool(trans_b), kepi, int(precision), bool(allow_split))
     plan = _plan_cache.get(pkey)
@@ -255,6 +258,8 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     e1.record()
     # algorithmic HBM bytes of the launch: A, B read once, C (and C2 / residual / gelu_u) once
     nbytes = 4.0 * (M * K + N * K + M * N * (1 + (out2 is not None) + (residual is not None) + (gelu_u is not None)))
+    if rc is not None:
+        nbytes += 4.0 * (M + N) * rc[5]
     _events.append((name, 2.0 * M * N * K, nbytes, e0, e1))
 
 
@@ -503,6 +508,9 @@ def matmul(A, B):
 # ------------------------------------------------------------------------------------------------
 # MLP with residual:  out = res + DropPath(Dropout(fc2(Dropout(GELU(fc1(x))))))      mpvit.py:71-78
 # ------------------------------------------------------------------------------------------------
+_mlp_recompute = os.environ.get("MDVIT_MLP_RECOMPUTE", "1") != "0"
+
+
 class _MlpResidual(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, W1, b1, W2, b2, rowscale, drop_p, rows_per_scale):
@@ -510,12 +518,18 @@ class _MlpResidual(torch.autograd.Function):
         _chk(x, res, W1, b1, W2, b2, rowscale)
         M, Cin = x.shape
         Hd = W1.shape[0]
-        u = _empty((M, Hd), device=x.device, dtype=torch.float32)
-        h = _empty_like(u)
+        h = _empty((M, Hd), device=x.device, dtype=torch.float32)
         k1 = _next_key() if drop_p > 0 else (0, 0)
         k2 = _next_key() if drop_p > 0 else (0, 0)
-        gemm(_p(x), _p(W1), _p(u), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), out2=_p(h),
-             epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
+        # HBM-bound MLPs (fc1's K = C <= 128): keep gelu(u) only; the backward recomputes the pre-activation u inside the fc2
+        # data-gradient GEMM (one more K = C product per tile) instead of moving [tokens, hidden] u through HBM twice
+        if _mlp_recompute and _gemm_precision == 1 and Cin <= 128 and Cin % 4 == 0 and Hd % 4 == 0:
+            u = None
+            gemm(_p(x), _p(W1), _p(h), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
+        else:
+            u = _empty_like(h)
+            gemm(_p(x), _p(W1), _p(u), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), out2=_p(h),
+                 epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
         out = _empty((M, Cin), device=x.device, dtype=torch.float32)
         gemm(_p(h), _p(W2), _p(out), M, Cin, Hd, lda=Hd, ldb=Hd, ldc=Cin, bias=_p(b2),
              e_drop=drop_p, e_key=k2, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale, residual=_p(res), ldr=Cin)
@@ -547,8 +561,11 @@ class _MlpResidual(torch.autograd.Function):
             call("mdvit_colsum_f32", _p(g), Cin, None if _dgrad_only else _p(sinks[3] if sunk else db2), _p(gm) if masked else None, wsp, wsb, M, Cin,
                  drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         # du = (gm W2) * gelu'(u) * mask1
-        du = _empty_like(u)
-        _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)
+        du = _empty_like(h)
+        if u is None:
+            _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, rc=(_p(x), Cin, _p(W1), Cin, _p(ctx.b1_ref), Cin), e_drop=drop_p, e_key=k1)
+        else:
+            _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)
         dx = _empty_like(x)
         _dgrad(du, W1, dx, M, Cin, Hd, Cin, allow_split=True)
         if not _dgrad_only:

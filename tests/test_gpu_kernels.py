@@ -63,6 +63,7 @@ def test_linear_and_mlp_bf16x3_vs_fp64(M, N, K):
     g2 = rnd(M, K, seed=8)
     mref, mgr = grads_of(lambda x, W, b, W2, b2: res.double() + F.linear(F.gelu(F.linear(x.double(), W.double(), b.double())), W2.double(), b2.double()),
                          [x, W, b, W2, b2], g2.double())
+    prev = ops.gemm_precision()
     ops.set_gemm_precision("bf16x3")
     try:
         assert ops.gemm_precision() == "bf16x3"
@@ -73,7 +74,7 @@ def test_linear_and_mlp_bf16x3_vs_fp64(M, N, K):
         ops.linear(x.to(dev()), W.to(dev()), b.to(dev()))
         names = list(ops.kernel_events_end())
     finally:
-        ops.set_gemm_precision("fp32")
+        ops.set_gemm_precision(prev)
     assert names and all(n.split(">")[0].endswith("true") for n in names), names        # the bf16x3 instantiation really ran
     check(out, ref, name="y")
     for n, a, r in zip(("dx", "dW", "db"), go, gr):
@@ -194,6 +195,32 @@ def test_mlp_residual(M, C, r, gemm_precision):
     check(out, ref, tol=tol, name="y")
     for n, a, r_ in zip(("dx", "dres", "dW1", "db1", "dW2", "db2"), go, gr):
         check(a, r_, tol=tol, name=n)
+
+
+@pytest.mark.parametrize("M,C,r,drop", [(512, 64, 8, 0.0), (1030, 64, 8, 0.25), (130, 128, 8, 0.1), (70, 32, 4, 0.0)])
+def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatch):
+    """C <= 128 (bf16x3): the forward keeps gelu(u) only and the fc2 data-gradient GEMM recomputes u = x W1^T + b1 per output
+    tile -- same slab / MFMA sequence as the forward, so every output and gradient equals the stored-u path bit for bit"""
+    from mdvit_amd import ops
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("the recomputing epilogue is the bf16x3 path's")
+    Hd = C * r
+    ins = [rnd(M, C, seed=120), rnd(M, C, seed=121), rnd(Hd, C, seed=122, scale=C ** -0.5), rnd(Hd, seed=123, scale=0.1),
+           rnd(C, Hd, seed=124, scale=Hd ** -0.5), rnd(C, seed=125, scale=0.1)]
+    g = rnd(M, C, seed=126)
+    rowscale = (torch.rand(2, generator=torch.Generator().manual_seed(5)) < 0.7).float().div(0.7).to(dev()) if drop > 0 else None
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "_mlp_recompute", flag)
+        monkeypatch.setattr(ops, "_key_counter", __import__("itertools").count(77))       # the same dropout keys in both runs
+        out, go = grads_of(lambda *a: ops.mlp_residual(*a, rowscale=rowscale, drop_p=drop, rows_per_scale=(M + 1) // 2),
+                           [t.to(dev()) for t in ins], g)
+        res.append([out.detach()] + go)
+    for name, a, b in zip(("y", "dx", "dres", "dW1", "db1", "dW2", "db2"), res[0], res[1]):
+        if name == "db1":       # column sums riding on the wgrad: one float atomicAdd per tile and K-split, order not fixed
+            check(a, b, tol=1e-5, name=name)
+            continue
+        assert torch.equal(a, b), f"{name}: recomputed-u path differs from the stored-u path (max {float((a - b).abs().max()):.3e})"
 
 
 @pytest.mark.parametrize("M,C", [(1000, 64), (77, 128), (300, 320), (64, 512), (5, 1024), (33, 96), (4099, 64)])
