@@ -87,7 +87,7 @@ __device__ __forceinline__ void split_pair_bf16x3(float x0, float x1, uint32_t& 
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI, bool BF3>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM == 256 && TA) ? 2 : 3, 8))) void gemm_f32_kernel(GemmArgs p) {
     // bf16x3 staging: a k-contiguous operand (A of NT/NN, B of NT) is split float4-wise into [row][k] bf16 planes; an
     // m/n-contiguous operand (A and B of the TN wgrad) is loaded as PAIRS of consecutive k rows, so that each
     // (row, k..k+1) bf16 pair is one v_cvt_pk_bf16_f32 and one ds_write_b32 -- with lanes running along k the writes

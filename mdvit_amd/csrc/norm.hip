@@ -1,7 +1,7 @@
 // LayerNorm, BatchNorm(+activation, +Dropout2d), 1-output linear ("rowdot") and column sums.
 // All HBM-bound streaming kernels over token-major [M, C] fp32: lanes run along C (coalesced),
 // row statistics by wavefront shuffle reductions, channel statistics / parameter gradients by per-thread partials ->
-// LDS -> one partial row per workgroup -> fixed-order second stage (no global atomics anywhere).
+// LDS -> one partial row per workgroup -> fixed-order second stage (no global atomics in this file).
 #include "common.h"
 
 namespace {
