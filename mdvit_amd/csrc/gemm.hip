@@ -10,6 +10,7 @@
 // Replaces nn.Linear / 1x1 nn.Conv2d / einsum call sites of the reference:
 //   mdvit.py:288 (qkv), :310-311 (proj+drop), mpvit.py:71-78 (Mlp), Decoders.py:196,319-331 (1x1 convs).
 #include "common.h"
+#include <type_traits>
 #ifndef MDVIT_NO_DB
 #define MDVIT_NO_DB 0
 #endif
@@ -127,11 +128,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     constexpr bool RC = EPI == EPI_DGELU_RC;
-    int kbeg = blockIdx.y * p.k_per_split;
-    int kend = min(p.K, kbeg + p.k_per_split);
-    const float* gA = p.A; const float* gB = p.B;          // the operands the staging lambdas read (RC swaps them between its two products)
-    long glda = p.lda, gldb = p.ldb;
-    if (RC) { gA = p.rc_a; glda = p.rc_lda; gB = p.rc_b; gldb = p.rc_ldb; kbeg = 0; kend = p.rc_k; }
+    // RC walks ONE virtual K axis: slabs [0, rc_k) multiply rc_a x rc_b^T into the pre-activation accumulators, slabs
+    // [rc_k, rc_k + K) multiply A x B^T into the gradient accumulators -- a single software pipeline over both products
+    const int kbeg = RC ? 0 : blockIdx.y * p.k_per_split;
+    const int kend = RC ? p.rc_k + p.K : min(p.K, kbeg + p.k_per_split);
+    const float* gA = p.A; const float* gB = p.B;
+    const long glda = p.lda, gldb = p.ldb;
     const int wm0 = (wave / WAVES_N) * (BM / WAVES_M), wn0 = (wave % WAVES_N) * (BN / WAVES_N);
 
     f32x16 acc[WTM][WTN];
@@ -142,14 +144,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_V4], rb[B_V4];
+    // global -> register staging sets: the double-buffered (64x64) path keeps TWO slabs in flight
+    using SET0 = std::integral_constant<int, 0>;
+    using SET1 = std::integral_constant<int, 1>;
+    constexpr bool PF2 = DB && !RC;           // (RC carries a second accumulator set: two staging sets would spill)
+    float4 ra[PF2 ? 2 : 1][A_V4], rb[PF2 ? 2 : 1][B_V4];
     constexpr int NCS = A_PAIR ? A_V4 / 2 : 1;             // column-sum partials (TN + colsum, tile column 0 only)
     float4 cs[NCS];
 #pragma unroll
     for (int v = 0; v < NCS; ++v) cs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_cs = TA && p.colsum != nullptr && tn == 0;
 
-    auto load_a = [&](int k0) {
+    auto load_a = [&](int k0, auto setc) {
+        constexpr int S = decltype(setc)::value;
         if (A_PAIR) {           // rows k = k0 + 2*kp, +1 ; columns m0 + 4*mq .. +3
 #pragma unroll
             for (int v = 0; v < A_V4 / 2; ++v) {
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
                     if (k < kend) x0 = *reinterpret_cast<const float4*>(gA + (long)k * glda + m);
                     if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(gA + (long)(k + 1) * glda + m);
                 }
-                ra[2 * v] = x0; ra[2 * v + 1] = x1;
+                ra[S][2 * v] = x0; ra[S][2 * v + 1] = x1;
             }
             return;
         }
@@ -169,16 +176,22 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TA) {   // A[m][k], k contiguous: BK/4 threads per row
                 const int r = tid / KT + v * (NTHREADS / KT), m = m0 + r, k = k0 + (tid % KT) * 4;
-                if (m < p.M && k < kend) x = *reinterpret_cast<const float4*>(gA + (long)m * glda + k);
+                const bool first = RC && k0 < p.rc_k;              // (uniform: scalar selects)
+                const float* src = first ? p.rc_a : gA;
+                const long ld = first ? p.rc_lda : glda;
+                const int kl = (RC && !first) ? k - p.rc_k : k;
+                const int ke = RC ? (first ? p.rc_k : p.K) : kend;
+                if (m < p.M && kl < ke) x = *reinterpret_cast<const float4*>(src + (long)m * ld + kl);
             } else {     // A stored [k][m], m contiguous (wgrad: A = dY^T)
                 constexpr int TPR = BM / 4;                 // threads per k-row
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, m = m0 + (tid % TPR) * 4;
                 if (k < kend && m < p.M) x = *reinterpret_cast<const float4*>(gA + (long)k * glda + m);
             }
-            ra[v] = x;
+            ra[S][v] = x;
         }
     };
-    auto load_b = [&](int k0) {
+    auto load_b = [&](int k0, auto setc) {
+        constexpr int S = decltype(setc)::value;
         if (B_PAIR) {
 #pragma unroll
             for (int v = 0; v < B_V4 / 2; ++v) {
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
                     if (k < kend) x0 = *reinterpret_cast<const float4*>(gB + (long)k * gldb + n);
                     if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(gB + (long)(k + 1) * gldb + n);
                 }
-                rb[2 * v] = x0; rb[2 * v + 1] = x1;
+                rb[S][2 * v] = x0; rb[S][2 * v + 1] = x1;
             }
             return;
         }
@@ -198,26 +211,32 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TB) {    // B[n][k], k contiguous (weights as stored by nn.Linear)
                 const int r = tid / KT + v * (NTHREADS / KT), n = n0 + r, k = k0 + (tid % KT) * 4;
-                if (n < p.N && k < kend) x = *reinterpret_cast<const float4*>(gB + (long)n * gldb + k);
+                const bool first = RC && k0 < p.rc_k;
+                const float* src = first ? p.rc_b : gB;
+                const long ld = first ? p.rc_ldb : gldb;
+                const int kl = (RC && !first) ? k - p.rc_k : k;
+                const int ke = RC ? (first ? p.rc_k : p.K) : kend;
+                if (n < p.N && kl < ke) x = *reinterpret_cast<const float4*>(src + (long)n * ld + kl);
             } else {     // B[k][n], n contiguous
                 constexpr int TPR = BN / 4;
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, n = n0 + (tid % TPR) * 4;
                 if (k < kend && n < p.N) x = *reinterpret_cast<const float4*>(gB + (long)k * gldb + n);
             }
-            rb[v] = x;
+            rb[S][v] = x;
         }
     };
-    auto store_smem = [&]() {
+    auto store_smem = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
         if (TA && do_cs) {          // raw fp32 values of the staged A slab (zeros outside the matrix)
             if (A_PAIR) {
 #pragma unroll
                 for (int v = 0; v < A_V4 / 2; ++v) {
-                    cs[v].x += ra[2 * v].x + ra[2 * v + 1].x; cs[v].y += ra[2 * v].y + ra[2 * v + 1].y;
-                    cs[v].z += ra[2 * v].z + ra[2 * v + 1].z; cs[v].w += ra[2 * v].w + ra[2 * v + 1].w;
+                    cs[v].x += ra[S][2 * v].x + ra[S][2 * v + 1].x; cs[v].y += ra[S][2 * v].y + ra[S][2 * v + 1].y;
+                    cs[v].z += ra[S][2 * v].z + ra[S][2 * v + 1].z; cs[v].w += ra[S][2 * v].w + ra[S][2 * v + 1].w;
                 }
             } else {
 #pragma unroll
-                for (int v = 0; v < A_V4; ++v) { cs[0].x += ra[v].x; cs[0].y += ra[v].y; cs[0].z += ra[v].z; cs[0].w += ra[v].w; }
+                for (int v = 0; v < A_V4; ++v) { cs[0].x += ra[S][v].x; cs[0].y += ra[S][v].y; cs[0].z += ra[S][v].z; cs[0].w += ra[S][v].w; }
             }
         }
         if (BF3) {
@@ -225,8 +244,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
 #pragma unroll
                 for (int v = 0; v < A_V4 / 2; ++v) {
                     const int kp = tid & 15, mq = (tid >> 4) + 16 * v;
-                    const float x0[4] = {ra[2 * v].x, ra[2 * v].y, ra[2 * v].z, ra[2 * v].w};
-                    const float x1[4] = {ra[2 * v + 1].x, ra[2 * v + 1].y, ra[2 * v + 1].z, ra[2 * v + 1].w};
+                    const float x0[4] = {ra[S][2 * v].x, ra[S][2 * v].y, ra[S][2 * v].z, ra[S][2 * v].w};
+                    const float x1[4] = {ra[S][2 * v + 1].x, ra[S][2 * v + 1].y, ra[S][2 * v + 1].z, ra[S][2 * v + 1].w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         uint32_t hi, lo;
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
                 for (int v = 0; v < A_V4; ++v) {
                     const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
                     uint2 hi, lo;
-                    split_bf16x3(ra[v], hi, lo);
+                    split_bf16x3(ra[S][v], hi, lo);
                     *reinterpret_cast<uint2*>(Ahi + r * LDKB + c * 2) = hi;
                     *reinterpret_cast<uint2*>(Alo + r * LDKB + c * 2) = lo;
                 }
@@ -249,8 +268,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
 #pragma unroll
                 for (int v = 0; v < B_V4 / 2; ++v) {
                     const int kp = tid & 15, nq = (tid >> 4) + 16 * v;
-                    const float x0[4] = {rb[2 * v].x, rb[2 * v].y, rb[2 * v].z, rb[2 * v].w};
-                    const float x1[4] = {rb[2 * v + 1].x, rb[2 * v + 1].y, rb[2 * v + 1].z, rb[2 * v + 1].w};
+                    const float x0[4] = {rb[S][2 * v].x, rb[S][2 * v].y, rb[S][2 * v].z, rb[S][2 * v].w};
+                    const float x1[4] = {rb[S][2 * v + 1].x, rb[S][2 * v + 1].y, rb[S][2 * v + 1].z, rb[S][2 * v + 1].w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         uint32_t hi, lo;
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
                 for (int v = 0; v < B_V4; ++v) {
                     const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
                     uint2 hi, lo;
-                    split_bf16x3(rb[v], hi, lo);
+                    split_bf16x3(rb[S][v], hi, lo);
                     *reinterpret_cast<uint2*>(Bhi + r * LDKB + c * 2) = hi;
                     *reinterpret_cast<uint2*>(Blo + r * LDKB + c * 2) = lo;
                 }
@@ -275,24 +294,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
         for (int v = 0; v < A_V4; ++v) {
             if (!TA) {
                 const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                As[(c + 0) * LDSA + r] = ra[v].x; As[(c + 1) * LDSA + r] = ra[v].y;
-                As[(c + 2) * LDSA + r] = ra[v].z; As[(c + 3) * LDSA + r] = ra[v].w;
+                As[(c + 0) * LDSA + r] = ra[S][v].x; As[(c + 1) * LDSA + r] = ra[S][v].y;
+                As[(c + 2) * LDSA + r] = ra[S][v].z; As[(c + 3) * LDSA + r] = ra[S][v].w;
             } else {
                 constexpr int TPR = BM / 4;
                 const int kk = tid / TPR + v * (NTHREADS / TPR), c = (tid % TPR) * 4;
-                *reinterpret_cast<float4*>(&As[kk * LDSA + c]) = ra[v];
+                *reinterpret_cast<float4*>(&As[kk * LDSA + c]) = ra[S][v];
             }
         }
 #pragma unroll
         for (int v = 0; v < B_V4; ++v) {
             if (TB) {
                 const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                Bs[(c + 0) * LDSB + r] = rb[v].x; Bs[(c + 1) * LDSB + r] = rb[v].y;
-                Bs[(c + 2) * LDSB + r] = rb[v].z; Bs[(c + 3) * LDSB + r] = rb[v].w;
+                Bs[(c + 0) * LDSB + r] = rb[S][v].x; Bs[(c + 1) * LDSB + r] = rb[S][v].y;
+                Bs[(c + 2) * LDSB + r] = rb[S][v].z; Bs[(c + 3) * LDSB + r] = rb[S][v].w;
             } else {
                 constexpr int TPR = BN / 4;
                 const int kk = tid / TPR + v * (NTHREADS / TPR), c = (tid % TPR) * 4;
-                *reinterpret_cast<float4*>(&Bs[kk * LDSB + c]) = rb[v];
+                *reinterpret_cast<float4*>(&Bs[kk * LDSB + c]) = rb[S][v];
             }
         }
     };
@@ -314,23 +333,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
             if (src && row < p.M && col < p.N) epre[q] = *reinterpret_cast<const float4*>(src + (long)row * lds_ + col);
         }
     }
-    auto run_product = [&]() {
-    load_a(kbeg);
-    load_b(kbeg);
-    store_smem();
-    __syncthreads();
-    int buf = 0;
-    if (DB && kbeg + BK < kend) { load_a(kbeg + BK); load_b(kbeg + BK); }      // slab 1 in flight before the loop
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = (k0 + BK) < kend;
-        if (DB) {
-            if (more) {                         // registers hold slab k+1 (loaded one iteration ago): park it in the other buffer
-                stage(buf ^ 1);
-                store_smem();
-                stage(buf);
-                if (k0 + 2 * BK < kend) { load_a(k0 + 2 * BK); load_b(k0 + 2 * BK); }
-            }
-        } else if (more) { load_a(k0 + BK); load_b(k0 + BK); }
+    f32x16 uacc[RC ? WTM : 1][RC ? WTN : 1];
+    if (RC) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) uacc[RC ? i : 0][RC ? j : 0][r] = 0.f;
+    }
+    auto mma_into = [&](auto& Cacc) __attribute__((always_inline)) {          // one K slab of the current LDS stage into the given accumulators
         if (BF3) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
@@ -352,9 +364,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
                 for (int i = 0; i < WTM; ++i)
 #pragma unroll
                     for (int j = 0; j < WTN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                        Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], Cacc[i][j], 0, 0, 0);
+                        Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], Cacc[i][j], 0, 0, 0);
+                        Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], Cacc[i][j], 0, 0, 0);
                     }
             }
         } else
@@ -370,32 +382,79 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
                 for (int j = 0; j < WTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+                    Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], Cacc[i][j], 0, 0, 0);
         }
+    };
+    auto mma = [&](int k0) __attribute__((always_inline)) {
+        if constexpr (RC) {
+            if (k0 < p.rc_k) mma_into(uacc);
+            else mma_into(acc);
+        } else {
+            mma_into(acc);
+        }
+    };
+    if (DB && !PF2) {
+        // one slab in flight behind the one being multiplied
+        int buf = 0;
+        load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
+        store_smem(SET0{});
         __syncthreads();
-        if (DB) {
+        if (kbeg + BK < kend) { load_a(kbeg + BK, SET0{}); load_b(kbeg + BK, SET0{}); }
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            if (k0 + BK < kend) {
+                stage(buf ^ 1);
+                store_smem(SET0{});
+                stage(buf);
+                if (k0 + 2 * BK < kend) { load_a(k0 + 2 * BK, SET0{}); load_b(k0 + 2 * BK, SET0{}); }
+            }
+            mma(k0);
+            __syncthreads();
             buf ^= 1;
             stage(buf);
-        } else if (more) {
-            store_smem();
+        }
+        stage(0);
+    } else if (DB) {
+        // two slabs in flight: the global loads of slab i+2 are issued before slab i is multiplied, so a workgroup exposes ONE
+        // load latency at its start instead of one per slab (K = 64 / 128: the whole tile's operands are requested up front)
+        int buf = 0;
+        load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
+        using SETB = std::integral_constant<int, PF2 ? 1 : 0>;        // (SET1 where this path is compiled for real)
+        if (kbeg + BK < kend) { load_a(kbeg + BK, SETB{}); load_b(kbeg + BK, SETB{}); }
+        store_smem(SET0{});
+        __syncthreads();
+        if (kbeg + 2 * BK < kend) { load_a(kbeg + 2 * BK, SET0{}); load_b(kbeg + 2 * BK, SET0{}); }
+        auto step = [&](int k0, auto setc) __attribute__((always_inline)) {       // setc: the register set that holds slab k0 + BK
+            if (k0 + BK < kend) {
+                stage(buf ^ 1);
+                store_smem(setc);
+                stage(buf);
+                if (k0 + 3 * BK < kend) { load_a(k0 + 3 * BK, setc); load_b(k0 + 3 * BK, setc); }
+            }
+            mma(k0);
             __syncthreads();
+            buf ^= 1;
+            stage(buf);
+        };
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+            step(k0, SETB{});
+            if (k0 + BK < kend) step(k0 + BK, SET0{});
+        }
+        stage(0);
+    } else {
+        load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
+        store_smem(SET0{});
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            const bool more = (k0 + BK) < kend;
+            if (more) { load_a(k0 + BK, SET0{}); load_b(k0 + BK, SET0{}); }
+            mma(k0);
+            __syncthreads();
+            if (more) {
+                store_smem(SET0{});
+                __syncthreads();
+            }
         }
     }
-    if (DB) stage(0);
-    };
-
-    f32x16 uacc[RC ? WTM : 1][RC ? WTN : 1];
-    if (RC) {                      // first product: the pre-activation tile; then the gradient product over the real operands
-        run_product();
-#pragma unroll
-        for (int i = 0; i < WTM; ++i)
-#pragma unroll
-            for (int j = 0; j < WTN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { uacc[i][j][r] = acc[i][j][r]; acc[i][j][r] = 0.f; }
-        gA = p.A; glda = p.lda; gB = p.B; gldb = p.ldb; kbeg = 0; kend = p.K;
-    }
-    run_product();
 
     if (TA && do_cs) {              // (the main loop ended with a barrier: the staging LDS is free)
         float* s_cs = smem;
@@ -636,8 +695,8 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     if (d->rc_a) {
         MDVIT_CHECK_ARG(d->epi == MDVIT_EPI_DGELU && !d->gelu_u && d->rc_b && d->rc_k > 0 && !d->trans_a && d->trans_b, MDVIT_E_SHAPE,
                         "gemm: rc_a/rc_b (recomputed pre-activation) go with the NT DGELU epilogue and no gelu_u");
-        MDVIT_CHECK_ARG(aligned16(d->rc_a) && aligned16(d->rc_b) && d->rc_lda % 4 == 0 && d->rc_ldb % 4 == 0 && d->rc_k % 4 == 0 &&
-                        (!d->rc_bias || aligned16(d->rc_bias)), MDVIT_E_ALIGN, "gemm: rc operands must be 16-byte aligned, leading dimensions and rc_k %% 4 == 0");
+        MDVIT_CHECK_ARG(aligned16(d->rc_a) && aligned16(d->rc_b) && d->rc_lda % 4 == 0 && d->rc_ldb % 4 == 0 && d->rc_k % BK == 0 &&
+                        (!d->rc_bias || aligned16(d->rc_bias)), MDVIT_E_ALIGN, "gemm: rc operands must be 16-byte aligned, leading dimensions %% 4 == 0, rc_k %% 32 == 0");
     }
     MDVIT_CHECK_ARG(!(d->e_drop_p > 0.f) || (long)d->M * d->N < (1L << 32), MDVIT_E_SHAPE, "gemm: dropout index space exceeds 2^32");
 

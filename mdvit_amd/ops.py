@@ -523,7 +523,7 @@ class _MlpResidual(torch.autograd.Function):
         k2 = _next_key() if drop_p > 0 else (0, 0)
         # HBM-bound MLPs (fc1's K = C <= 128): keep gelu(u) only; the backward recomputes the pre-activation u inside the fc2
         # data-gradient GEMM (one more K = C product per tile) instead of moving [tokens, hidden] u through HBM twice
-        if _mlp_recompute and _gemm_precision == 1 and Cin <= 128 and Cin % 4 == 0 and Hd % 4 == 0:
+        if _mlp_recompute and _gemm_precision == 1 and Cin <= 128 and Cin % 32 == 0 and Hd % 4 == 0:
             u = None
             gemm(_p(x), _p(W1), _p(h), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
         else:
