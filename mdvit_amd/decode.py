@@ -54,6 +54,7 @@ class MLPDecoderFM(nn.Module):
         self.dropout = nn.Dropout2d(dropout_ratio)      # holds p only; the mask is applied inside the BN+ReLU kernel
         self.linear_out = ConvParams(out_channel, hidden_channel, 1, 1)
         self.hidden = hidden_channel
+        self.with_fm = outfeature_channel > 0
 
     def forward(self, features, img_size, out_feat=False):
         if out_feat:
@@ -64,14 +65,17 @@ class MLPDecoderFM(nn.Module):
         Wf = self.linear_fuse[0].weight.view(hid, -1)          # [hid, 4*hid + C5]
         bias = self.linear_fuse[0].bias
         lins = (self.linear1, self.linear2, self.linear3, self.linear4)
-        # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)
-        acc = ops.linear(features[4], Wf[:, 4 * hid:], bias)                                  # [B,h,w,hid]
+        # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)      (MLPDecoder: no x5 term, bf rides on q = 0)
+        acc = ops.linear(features[4], Wf[:, 4 * hid:], bias) if self.with_fm else None        # [B,h,w,hid]
         for q, lin in enumerate(lins):
             Wf_q = Wf[:, q * hid:(q + 1) * hid]
             Wc = ops.matmul(Wf_q, lin.weight.view(hid, -1))                                    # [hid, C_q]
             bc = ops.rowdot(Wf_q, lin.bias)                                                    # [hid]
             fq = features[q]
-            if fq.shape[1] == h and fq.shape[2] == w:
+            if acc is None:
+                assert fq.shape[1] == h and fq.shape[2] == w
+                acc = ops.linear(fq, Wc, bc + bias)
+            elif fq.shape[1] == h and fq.shape[2] == w:
                 acc = ops.linear(fq, Wc, bc, residual=acc)
             else:
                 acc = ops.upsample_bilinear(ops.linear(fq, Wc, bc), h, w, base=acc)
@@ -80,3 +84,11 @@ class MLPDecoderFM(nn.Module):
         low = ops.rowdot(y, self.linear_out.weight, self.linear_out.bias)                     # [B,h,w]
         out = ops.upsample_bilinear(low.view(B, h, w, 1), int(img_size[0]), int(img_size[1]))
         return out.view(B, 1, int(img_size[0]), int(img_size[1]))
+
+
+class MLPDecoder(MLPDecoderFM):
+    """Decoders.py:239-286 (decoder_name='MLP'): the SegFormer-style head over the four encoder features only -- MLPDecoderFM
+    without the main decoder's feature in the fuse conv (same parameter names, linear_fuse.0 takes 4*hidden channels)."""
+
+    def __init__(self, in_channels, out_channel, hidden_channel=256, dropout_ratio=0.1, conv_norm=nn.BatchNorm2d):
+        super().__init__(in_channels, out_channel, hidden_channel, outfeature_channel=0, dropout_ratio=dropout_ratio, conv_norm=conv_norm)

@@ -19,7 +19,7 @@ from . import ops
 from ._lib import ACT_RELU
 from .blocks import (droppath_pool, dsn_domain, BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
                      init_weights_)
-from .decode import MLPDecoderFM, UnetDecodingBlockTransformer
+from .decode import MLPDecoder, MLPDecoderFM, UnetDecodingBlockTransformer
 
 
 class _EncoderDecoder(nn.Module):
@@ -124,17 +124,23 @@ class MDViT(_EncoderDecoder):
                  drop_path_rate=0.0, norm_layer=None, conv_norm=nn.BatchNorm2d, adapt_method=None, num_domains=4,
                  decoder_name="MLPFM", **kwargs):
         super().__init__()
-        if decoder_name != "MLPFM":
-            raise NotImplementedError(f"decoder_name={decoder_name!r}: only the default 'MLPFM' peer heads are built")
         self.decoder_name = decoder_name
         self.adapt_method = adapt_method
         self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
                           drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains)
-        self.debranch1 = MLPDecoderFM(embed_dims, 1, 512)
-        self.debranch2 = MLPDecoderFM(embed_dims, 1, 512)
-        self.debranch3 = MLPDecoderFM(embed_dims, 1, 512)
-        self.debranch4 = MLPDecoderFM(embed_dims, 1, 512)
+        self._build_peer_heads(embed_dims, decoder_name)
         init_weights_(self)
+
+    def _build_peer_heads(self, embed_dims, decoder_name):
+        """mdvit.py:593-606 / 852-873: four peer heads, 'MLPFM' (also fed the main decoder's last feature) or 'MLP'"""
+        if decoder_name == "MLPFM":
+            mk = lambda: MLPDecoderFM(embed_dims, 1, 512)
+        elif decoder_name == "MLP":
+            mk = lambda: MLPDecoder(embed_dims, 1, 512)
+        else:
+            raise NotImplementedError(f"decoder_name={decoder_name!r}: the 'MLPFM' and 'MLP' peer heads are built "
+                                      "('DeepLabV3' and 'Transformer' are not)")
+        self.debranch1, self.debranch2, self.debranch3, self.debranch4 = mk(), mk(), mk(), mk()
 
     def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
         """d: the reference's domain id string ('0'..'3').  Extension: a list/tuple of G domain ids runs a DOMAIN-BATCHED
@@ -189,16 +195,11 @@ class MDViT_DSN(MDViT):
                  drop_path_rate=0.0, norm_layer=None, conv_norm=nn.BatchNorm2d, adapt_method=None, num_domains=4,
                  decoder_name="MLP", **kwargs):
         _EncoderDecoder.__init__(self)
-        if decoder_name != "MLPFM":
-            raise NotImplementedError(f"decoder_name={decoder_name!r}: only the 'MLPFM' peer heads are built")
         self.decoder_name = decoder_name
         self.adapt_method = adapt_method
         self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
                           drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains, dsn=num_domains)
-        self.debranch1 = MLPDecoderFM(embed_dims, 1, 512)
-        self.debranch2 = MLPDecoderFM(embed_dims, 1, 512)
-        self.debranch3 = MLPDecoderFM(embed_dims, 1, 512)
-        self.debranch4 = MLPDecoderFM(embed_dims, 1, 512)
+        self._build_peer_heads(embed_dims, decoder_name)
         init_weights_(self)
 
     def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):

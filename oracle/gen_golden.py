@@ -68,19 +68,24 @@ def _sample(t: torch.Tensor, stride: int = 37) -> np.ndarray:
     return t.detach().reshape(-1)[::stride].float().numpy().copy()
 
 
-def _build_mdvit(ns, pn, img_size, adapt="Sup"):
+def _build_mdvit(ns, pn, img_size, adapt="Sup", decoder_name="MLPFM"):
     m = ns.MDViT(img_size=img_size, drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d,
-                 adapt_method=adapt, num_domains=4, decoder_name="MLPFM")
+                 adapt_method=adapt, num_domains=4, decoder_name=decoder_name)
     load_params_into(m, pn)
     for d in range(1, 5):                 # Dropout2d(0.1) is a fixed default of MLPDecoderFM (Decoders.py:294)
         getattr(m, f"debranch{d}").dropout.p = 0.0
     return m
 
 
-def gen_mdvit_step(ns, S=64, B=2, seed=0):
+def gen_mdvit_mlp_step(ns, S=64, B=2, seed=6):
+    """the same step with decoder_name='MLP' peer heads (MLPDecoder, Decoders.py:239-286; mdvit.py:601-606)"""
+    return gen_mdvit_step(ns, S, B, seed, decoder_name="MLP")
+
+
+def gen_mdvit_step(ns, S=64, B=2, seed=0, decoder_name="MLPFM"):
     """4-domain two-sweep step, train mode -- multi_train_MDViT.py:129-207."""
-    pn = make_params(seed, model="MDViT", adapt_method="Sup")
-    m = _build_mdvit(ns, pn, S).train()
+    pn = make_params(seed, model="MDViT", adapt_method="Sup", decoder_name=decoder_name)
+    m = _build_mdvit(ns, pn, S, decoder_name=decoder_name).train()
     out = {}
     tot = tot_aux = tot_kt = 0.0
     bce = torch.nn.BCELoss()
@@ -108,9 +113,9 @@ def gen_mdvit_step(ns, S=64, B=2, seed=0):
     grads = {n: p.grad for n, p in m.named_parameters()}
     names, norms, heads = grad_digest(grads)
     sd = m.state_dict()
-    bn_names = sorted(k for k, (kind, _) in param_spec("MDViT", "Sup").items() if kind in ("bn_rm", "bn_rv"))
+    bn_names = sorted(k for k, (kind, _) in param_spec("MDViT", "Sup", decoder_name=decoder_name).items() if kind in ("bn_rm", "bn_rv"))
     out.update(grad_names=np.array(names), grad_norms=norms, grad_heads=heads,
-               da_grad_none_after_aux_sweep=np.array(da_none),
+               da_grad_none_after_aux_sweep=np.array(da_none), n_state_dict_keys=np.array(len(m.state_dict())),
                bn_names=np.array(bn_names), bn_sums=np.array([float(sd[k].double().sum()) for k in bn_names]),
                total_losses=np.array([float(tot), float(tot_aux), float(tot_kt)]),
                meta=np.array([S, B, seed]))
@@ -273,7 +278,7 @@ def main():
     torch.set_num_threads(8)
     ns = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    jobs = {"mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
+    jobs = {"mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
             "base_step_64": gen_base_step, "factoratt_small": gen_factoratt, "losses_small": gen_losses}
     only = set(sys.argv[1:])
     for name, fn in jobs.items():

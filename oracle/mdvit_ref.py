@@ -209,14 +209,16 @@ def decoder_block(P: Params, j: int, x: Tensor, skip: Tensor, heads: int, layers
 
 
 def aux_head(P: Params, d: int, feats: Sequence[Tensor], img_size, st: RefState) -> Tensor:
-    """MLPDecoderFM.forward, Decoders.py:315-339; d = 1..4 picks debranch{d} (mdvit.py:715-724)."""
+    """MLPDecoderFM.forward, Decoders.py:315-339 -- or MLPDecoder.forward, Decoders.py:262-286, when the fuse conv takes the
+    four encoder features only (decoder_name='MLP'); d = 1..4 picks debranch{d} (mdvit.py:715-724)."""
     p = f"debranch{d}"
     h, w = feats[0].shape[2:]
     ups = []
     for q in range(4):
         y = F.conv2d(feats[q], P[f"{p}.linear{q + 1}.weight"], P[f"{p}.linear{q + 1}.bias"])
         ups.append(F.interpolate(y, size=(h, w), mode="bilinear", align_corners=False))
-    y = torch.cat(ups + [feats[4]], 1)
+    with_fm = P[p + ".linear_fuse.0.weight"].shape[1] > sum(u.shape[1] for u in ups)      # MLPFM: + the main decoder's feature
+    y = torch.cat(ups + ([feats[4]] if with_fm else []), 1)
     y = F.conv2d(y, P[p + ".linear_fuse.0.weight"], P[p + ".linear_fuse.0.bias"])
     y = torch.relu(batch_norm(P, p + ".linear_fuse.1", y, st, kinks=(0.0,)))
     if st.training and st.aux_drop > 0:

@@ -64,10 +64,12 @@ def _stage(spec, prefix, C, r, heads, layers, sup, num_domains):
 
 def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_DOMAINS,
                embed_dims=EMBED_DIMS, mlp_ratios=MLP_RATIOS, num_heads=NUM_HEADS,
-               num_layers=NUM_LAYERS, in_chans: int = 3) -> "OrderedDict[str, tuple]":
-    """name -> (kind, shape) for every unique parameter and buffer."""
+               num_layers=NUM_LAYERS, in_chans: int = 3, decoder_name: str = "MLPFM") -> "OrderedDict[str, tuple]":
+    """name -> (kind, shape) for every unique parameter and buffer.  decoder_name: 'MLPFM' (peer heads that also take the
+    main decoder's last feature, Decoders.py:289-339) or 'MLP' (Decoders.py:239-286: the four encoder features only)."""
+    assert decoder_name in ("MLPFM", "MLP")
     if model == "MDViT_DSN":
-        return _dsn_spec(param_spec("MDViT", adapt_method, num_domains, embed_dims, mlp_ratios, num_heads, num_layers, in_chans), num_domains)
+        return _dsn_spec(param_spec("MDViT", adapt_method, num_domains, embed_dims, mlp_ratios, num_heads, num_layers, in_chans, decoder_name), num_domains)
     assert model in ("MDViT", "BASE")
     sup = adapt_method == "Sup"
     E = tuple(embed_dims)
@@ -106,7 +108,7 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
             for q in range(1, 5):
                 spec[f"debranch{d}.linear{q}.weight"] = ("conv", (AUX_HIDDEN, E[q - 1], 1, 1))
                 spec[f"debranch{d}.linear{q}.bias"] = ("bias", (AUX_HIDDEN,))
-            spec[f"debranch{d}.linear_fuse.0.weight"] = ("conv", (AUX_HIDDEN, 4 * AUX_HIDDEN + 64, 1, 1))
+            spec[f"debranch{d}.linear_fuse.0.weight"] = ("conv", (AUX_HIDDEN, 4 * AUX_HIDDEN + (64 if decoder_name == "MLPFM" else 0), 1, 1))
             spec[f"debranch{d}.linear_fuse.0.bias"] = ("bias", (AUX_HIDDEN,))
             _bn(spec, f"debranch{d}.linear_fuse.1", AUX_HIDDEN)
             spec[f"debranch{d}.linear_out.weight"] = ("conv", (1, AUX_HIDDEN, 1, 1))

@@ -65,12 +65,12 @@ def load_params(model, params_np):
     return model
 
 
-def build_mdvit(seed, img_size=64, drop=0.0):
+def build_mdvit(seed, img_size=64, drop=0.0, decoder_name="MLPFM"):
     import mdvit_amd
     from oracle.params import make_params
     m = mdvit_amd.MDViT(img_size=img_size, drop_rate=drop, drop_path_rate=drop, conv_norm=torch.nn.BatchNorm2d,
-                        adapt_method="Sup", num_domains=4, decoder_name="MLPFM")
-    load_params(m, make_params(seed, model="MDViT", adapt_method="Sup"))
+                        adapt_method="Sup", num_domains=4, decoder_name=decoder_name)
+    load_params(m, make_params(seed, model="MDViT", adapt_method="Sup", decoder_name=decoder_name))
     if drop == 0.0:
         for d in range(1, 5):
             getattr(m, f"debranch{d}").dropout.p = 0.0
@@ -125,14 +125,18 @@ def test_factoratt_module_vs_golden(golden, tag):
             check(named[key.split("::")[1]].grad.reshape(-1)[::29], g[key], name=key)
 
 
-def test_mdvit_two_sweep_step_vs_golden(golden, gemm_precision):
+@pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP")])
+def test_mdvit_two_sweep_step_vs_golden(golden, gemm_precision, fixture, decoder_name):
     """4-domain step, multi_train_MDViT.py:129-207: logits, the three losses, BN running stats and every
-    parameter gradient after the aux sweep (domain_layer frozen) + uni sweep."""
+    parameter gradient after the aux sweep (domain_layer frozen) + uni sweep.  decoder_name='MLP': the peer heads
+    without the main decoder's feature (MLPDecoder, Decoders.py:239-286; mdvit.py:601-606)."""
     from mdvit_amd.losses import domain_losses
     from oracle.gen_golden import synth_image, synth_label, grad_digest
-    g = golden("mdvit_step_64")
+    g = golden(fixture)
     S, B, seed = [int(v) for v in g["meta"]]
-    m = build_mdvit(seed, S).train()
+    m = build_mdvit(seed, S, decoder_name=decoder_name).train()
+    if "n_state_dict_keys" in g.files:
+        assert len(m.state_dict()) == int(g["n_state_dict_keys"])
     tot = tot_aux = tot_kt = 0.0
     for d in range(4):
         img, lab = synth_image(100 + d, B, S, S).to(dev()), synth_label(200 + d, B, S, S).to(dev())

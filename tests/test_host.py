@@ -68,6 +68,11 @@ def test_module_surface_matches_reference_inventory():
     assert set(k for k in b.state_dict()) == set(param_spec("BASE", False)) | set(alias_map("BASE"))
     dsn = mdvit_amd.MDViT_DSN(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4, decoder_name="MLPFM")
     assert set(dsn.state_dict()) == set(param_spec("MDViT_DSN", "Sup")) | set(alias_map())       # 852 unique + 128 aliases (mdvit.py:735-960)
+    mlp = mdvit_amd.MDViT(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4, decoder_name="MLP")
+    spec_mlp = param_spec("MDViT", "Sup", decoder_name="MLP")
+    assert set(mlp.state_dict()) == set(spec_mlp) | set(alias_map())
+    assert tuple(mlp.debranch3.linear_fuse[0].weight.shape) == spec_mlp["debranch3.linear_fuse.0.weight"][1] == (512, 2048, 1, 1)
+    assert mdvit_amd.MDViT_DSN(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", decoder_name="MLP").decoder_name == "MLP"
     with pytest.raises(NotImplementedError):
         mdvit_amd.MDViT(decoder_name="DeepLabV3")
     # reference init scheme (mdvit.py:648-664)

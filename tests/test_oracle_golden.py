@@ -40,10 +40,12 @@ def test_generator_is_stable():
     assert abs(float(p["finalconv.0.weight"].std()) - 0.125) < 0.03
 
 
-def test_mdvit_two_sweep_step(golden):
-    g = golden("mdvit_step_64")
+@pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP")])
+def test_mdvit_two_sweep_step(golden, fixture, decoder_name):
+    """decoder_name='MLP': the peer heads without the main decoder's feature (MLPDecoder, Decoders.py:239-286)"""
+    g = golden(fixture)
     S, B, seed = [int(v) for v in g["meta"]]
-    P = R.to_torch(make_params(seed, model="MDViT", adapt_method="Sup"))
+    P = R.to_torch(make_params(seed, model="MDViT", adapt_method="Sup", decoder_name=decoder_name))
     batches = [(synth_image(100 + d, B, S, S), synth_label(200 + d, B, S, S), d) for d in range(4)]
     # forward logits per domain (fresh params each so BN buffers evolve exactly as in the fixture)
     st = R.RefState(training=True)
