@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base"], default="mdvit", help="mdvit_dsn: MDViT_DSN, domain-specific norms")
+    ap.add_argument("--decoder", choices=["MLPFM", "MLP", "Transformer"], default="MLPFM", help="peer heads (MDViT decoder_name); the headline config is MLPFM")
     ap.add_argument("--no-side-stream", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel); "
@@ -98,7 +99,7 @@ def main():
     if args.model in ("mdvit", "mdvit_dsn"):
         cls = mdvit_amd.MDViT if args.model == "mdvit" else mdvit_amd.MDViT_DSN
         model = cls(img_size=args.size, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d,
-                    adapt_method="Sup", num_domains=4, decoder_name="MLPFM").to(dev).train()
+                    adapt_method="Sup", num_domains=4, decoder_name=args.decoder).to(dev).train()
         domains, flop_per_img = (0, 1, 2, 3), 251.0e9
     else:
         model = mdvit_amd.BASE(drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method=False).to(dev).train()
@@ -223,7 +224,7 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 storage; GEMM operands split hi+lo bf16, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{ {'mdvit': 'MDViT Sup+MLPFM', 'mdvit_dsn': 'MDViT_DSN Sup+MLPFM', 'base': 'BASE'}[args.model] } train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
+            "config": {"workload": f"{ {'mdvit': 'MDViT Sup+' + args.decoder, 'mdvit_dsn': 'MDViT_DSN Sup+' + args.decoder, 'base': 'BASE'}[args.model] } train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
             "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),

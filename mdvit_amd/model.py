@@ -68,7 +68,7 @@ class _EncoderDecoder(nn.Module):
         self.finalconv = nn.Sequential(ConvParams(1, E[0], 1, 1))
 
     def _trunk(self, x, domain_label, groups: int = 1):
-        """x NCHW image -> (logits (B,1,H,W), encoder_outs NHWC list, decoder4 output NHWC).
+        """x NCHW image -> (logits (B,1,H,W), encoder_outs NHWC list, decoder4 output NHWC, image size, bridge output NHWC).
         groups > 1: x is `groups` equal consecutive domain batches; BatchNorm statistics stay per domain batch."""
         blocks = [blk for st in list(self.mhsa_stages) + list(self.mhsa_list) for blk in st.mhca_blks]
         keep = 1.0 - blocks[0].drop_path_p
@@ -96,6 +96,7 @@ class _EncoderDecoder(nn.Module):
             out = self.bridge[1](out)
             out = ops.conv3x3_dense(out, self.bridge[3].weight, self.bridge[3].bias, 1)
             out = self.bridge[4](out)
+        bridge_out = out
         out = self.decoder1(out, enc[3], domain_label)
         out = self.decoder2(out, enc[2], domain_label)
         out = self.decoder3(out, enc[1], domain_label)
@@ -104,7 +105,7 @@ class _EncoderDecoder(nn.Module):
         _, h, w, _ = dec4.shape
         low = ops.rowdot(dec4, self.finalconv[0].weight, self.finalconv[0].bias)          # 1x1 conv (1 channel) at H/4
         logits = ops.upsample_bilinear(low.view(B, h, w, 1), Hi, Wi).view(B, 1, Hi, Wi)
-        return logits, enc, dec4, (Hi, Wi)
+        return logits, enc, dec4, (Hi, Wi), bridge_out
 
     @staticmethod
     def _pooled_feat(enc3):
@@ -129,6 +130,9 @@ class MDViT(_EncoderDecoder):
         self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
                           drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains)
         self._build_peer_heads(embed_dims, decoder_name)
+        if decoder_name == "Transformer":
+            self._build_transformer_peers(img_size, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale, drop_rate,
+                                          attn_drop_rate, drop_path_rate, norm_layer, conv_norm, num_domains)
         init_weights_(self)
 
     def _build_peer_heads(self, embed_dims, decoder_name):
@@ -137,10 +141,45 @@ class MDViT(_EncoderDecoder):
             mk = lambda: MLPDecoderFM(embed_dims, 1, 512)
         elif decoder_name == "MLP":
             mk = lambda: MLPDecoder(embed_dims, 1, 512)
+        elif decoder_name == "Transformer":
+            return                                     # built by _build_transformer_peers (needs the trunk's hyper-parameters)
         else:
-            raise NotImplementedError(f"decoder_name={decoder_name!r}: the 'MLPFM' and 'MLP' peer heads are built "
-                                      "('DeepLabV3' and 'Transformer' are not)")
+            raise NotImplementedError(f"decoder_name={decoder_name!r}: the 'MLPFM', 'MLP' and 'Transformer' peer heads are built "
+                                      "('DeepLabV3' is not)")
         self.debranch1, self.debranch2, self.debranch3, self.debranch4 = mk(), mk(), mk(), mk()
+
+    def _build_transformer_peers(self, img_size, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale, drop_rate,
+                                 attn_drop_rate, drop_path_rate, norm_layer, conv_norm, num_domains):
+        """mdvit.py:614-642: per domain a transformer decoder of its own -- four UnetDecodingBlockTransformer over MHSA stages
+        WITHOUT Domain Adapter (adapt_method=False) and a 1x1 conv to one channel: debranchs.{d}.{0..3}, debranchs.{d}.4.0"""
+        E = embed_dims
+        peers = []
+        for _ in range(num_domains):
+            st = [MHSA_stage_adapt((img_size // 2 ** (i + 2)) ** 2, E[i], num_layers=num_layers[i], num_heads=num_heads[i], mlp_ratio=mlp_ratios[i],
+                                   qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate,
+                                   drop_path_rate=drop_path_rate, norm_layer=norm_layer, adapt_method=False, num_domains=num_domains)
+                  for i in range(num_stages)]
+            peers.append(nn.ModuleList([UnetDecodingBlockTransformer(E[3] * 2, E[3], st[3], conv_norm=conv_norm),
+                                        UnetDecodingBlockTransformer(E[3], E[2], st[2], conv_norm=conv_norm),
+                                        UnetDecodingBlockTransformer(E[2], E[1], st[1], conv_norm=conv_norm),
+                                        UnetDecodingBlockTransformer(E[1], E[0], st[0], conv_norm=conv_norm),
+                                        nn.Sequential(ConvParams(1, E[0], 1, 1))]))
+        self.debranchs = nn.ModuleList(peers)
+
+    def _peer_out(self, dd, feats, bridge_out, img_size):
+        """the peer head of domain id string dd on (a batch group of) the trunk's features"""
+        if self.decoder_name == "Transformer":
+            peer = self.debranchs[int(dd)]
+            a = bridge_out
+            for j in range(4):
+                a = peer[j](a, feats[3 - j])                       # no domain label: these decoders carry no adapter
+            B, h, w, _ = a.shape
+            low = ops.rowdot(a, peer[4][0].weight, peer[4][0].bias)                        # 1x1 conv at H/4, then upsample
+            return ops.upsample_bilinear(low.view(B, h, w, 1), int(img_size[0]), int(img_size[1])).view(B, 1, int(img_size[0]), int(img_size[1]))
+        heads = {"0": "debranch1", "1": "debranch2", "2": "debranch3", "3": "debranch4"}
+        if dd not in heads:
+            return None
+        return getattr(self, heads[dd])(feats, img_size=img_size)
 
     def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
         """d: the reference's domain id string ('0'..'3').  Extension: a list/tuple of G domain ids runs a DOMAIN-BATCHED
@@ -149,20 +188,10 @@ class MDViT(_EncoderDecoder):
         (multi_train_MDViT.py:137-153) concatenated along the batch axis."""
         if isinstance(d, (list, tuple)):
             return self._forward_domains(x, domain_label, [str(v) for v in d], out_feat, out_seg)
-        logits, enc, dec4, img_size = self._trunk(x, domain_label)
+        logits, enc, dec4, img_size, bridge_out = self._trunk(x, domain_label)
         if not out_seg:
             return {"seg": None, "feat": self._pooled_feat(enc[3])}
-        feats = enc + [dec4]
-        if d == "0":
-            aux_out = self.debranch1(feats, img_size=img_size)
-        elif d == "1":
-            aux_out = self.debranch2(feats, img_size=img_size)
-        elif d == "2":
-            aux_out = self.debranch3(feats, img_size=img_size)
-        elif d == "3":
-            aux_out = self.debranch4(feats, img_size=img_size)
-        else:
-            aux_out = None
+        aux_out = self._peer_out(d, enc + [dec4], bridge_out, img_size)
         if out_feat:
             return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}
         return [logits, aux_out]
@@ -172,12 +201,12 @@ class MDViT(_EncoderDecoder):
         G = len(ds)
         if x.shape[0] % G:
             raise ValueError(f"batch {x.shape[0]} is not {G} equal domain batches")
-        logits, enc, dec4, img_size = self._trunk(x, domain_label, groups=G)
+        logits, enc, dec4, img_size, bridge_out = self._trunk(x, domain_label, groups=G)
         if not out_seg:
             return {"seg": None, "feat": self._pooled_feat(enc[3])}
-        heads = {"0": self.debranch1, "1": self.debranch2, "2": self.debranch3, "3": self.debranch4}
         parts = [ops.split_groups(f, G) for f in enc + [dec4]]          # per feature: G batch views
-        aux = [heads[dd]([pf[g] for pf in parts], img_size=img_size) if dd in heads else None for g, dd in enumerate(ds)]
+        bparts = ops.split_groups(bridge_out, G) if self.decoder_name == "Transformer" else [None] * G
+        aux = [self._peer_out(dd, [pf[g] for pf in parts], bparts[g], img_size) for g, dd in enumerate(ds)]
         aux_out = None if any(a is None for a in aux) else torch.cat(aux, 0)
         if out_feat:
             return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}
@@ -195,6 +224,8 @@ class MDViT_DSN(MDViT):
                  drop_path_rate=0.0, norm_layer=None, conv_norm=nn.BatchNorm2d, adapt_method=None, num_domains=4,
                  decoder_name="MLP", **kwargs):
         _EncoderDecoder.__init__(self)
+        if decoder_name == "Transformer":
+            raise NotImplementedError("MDViT_DSN has no 'Transformer' peer decoders (mdvit.py:852-873 builds MLP / DeepLabV3 / MLPFM only)")
         self.decoder_name = decoder_name
         self.adapt_method = adapt_method
         self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
@@ -223,7 +254,7 @@ class BASE(_EncoderDecoder):
         init_weights_(self)
 
     def forward(self, x, domain_label=None, out_feat=False, out_seg=True):
-        logits, enc, dec4, _ = self._trunk(x, domain_label)
+        logits, enc, dec4, _, _ = self._trunk(x, domain_label)
         if not out_seg:
             return {"seg": None, "feat": self._pooled_feat(enc[3])}
         if out_feat:

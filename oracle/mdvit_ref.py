@@ -191,11 +191,12 @@ def bridge(P: Params, x: Tensor, st: RefState) -> Tensor:
     return torch.relu(batch_norm(P, "bridge.4", F.conv2d(y, P["bridge.3.weight"], P["bridge.3.bias"], 1, 1), st, kinks=(0.0,)))
 
 
-def decoder_block(P: Params, j: int, x: Tensor, skip: Tensor, heads: int, layers: int,
+def decoder_block(P: Params, j, x: Tensor, skip: Tensor, heads: int, layers: int,
                   domain_label: Optional[Tensor], st: RefState) -> Tensor:
     """UnetDecodingBlockTransformer.forward (use_res=False), Decoders.py:194-214, with the
-    Decoders.py flavour of DWConv2d_BN (:15-63: Conv2d(2*out, out, 3, groups=out))."""
-    p = f"decoder{j}"
+    Decoders.py flavour of DWConv2d_BN (:15-63: Conv2d(2*out, out, 3, groups=out)).  j: 1..4 -> decoder{j}, or the
+    module prefix itself (the 'Transformer' peer decoders debranchs.{d}.{j})."""
+    p = f"decoder{j}" if isinstance(j, int) else j
     H, W = skip.shape[2:]
     u = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False)
     u = F.conv2d(u, P[p + ".conv_before.weight"], P[p + ".conv_before.bias"])
@@ -242,6 +243,7 @@ def _encoder_decoder(P: Params, x: Tensor, domain_label: Optional[Tensor], st: R
         x = tokens_to_image(t, H, W)
         enc.append(x)
     out = bridge(P, enc[3], st)
+    st.bridge_out = out                       # (the 'Transformer' peer decoders start from it, mdvit.py:706-709)
     for j in range(1, 5):
         s = 4 - j
         out = decoder_block(P, j, out, enc[s], heads[s], layers[s], domain_label, st)
@@ -259,7 +261,15 @@ def mdvit_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, d
         domain_label = None
     logits, enc, dec4, img_size = _encoder_decoder(P, x, domain_label, st)
     aux = None
-    if d in ("0", "1", "2", "3"):
+    if "debranchs.0.4.0.weight" in P:          # decoder_name='Transformer' (mdvit.py:705-713): the domain's own decoder, no adapter
+        k = int(d)
+        a = st.bridge_out
+        for j in range(4):
+            s = 3 - j
+            a = decoder_block(P, f"debranchs.{k}.{j}", a, enc[s], 8, 2, None, st)
+        a = F.interpolate(a, size=tuple(img_size), mode="bilinear", align_corners=False)
+        aux = F.conv2d(a, P[f"debranchs.{k}.4.0.weight"], P[f"debranchs.{k}.4.0.bias"])
+    elif d in ("0", "1", "2", "3"):
         aux = aux_head(P, int(d) + 1, enc + [dec4], img_size, st)
     return [logits, aux]
 

@@ -66,8 +66,9 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
                embed_dims=EMBED_DIMS, mlp_ratios=MLP_RATIOS, num_heads=NUM_HEADS,
                num_layers=NUM_LAYERS, in_chans: int = 3, decoder_name: str = "MLPFM") -> "OrderedDict[str, tuple]":
     """name -> (kind, shape) for every unique parameter and buffer.  decoder_name: 'MLPFM' (peer heads that also take the
-    main decoder's last feature, Decoders.py:289-339) or 'MLP' (Decoders.py:239-286: the four encoder features only)."""
-    assert decoder_name in ("MLPFM", "MLP")
+    main decoder's last feature, Decoders.py:289-339), 'MLP' (Decoders.py:239-286: the four encoder features only) or
+    'Transformer' (mdvit.py:614-642: per domain a full transformer decoder without Domain Adapter, `debranchs.{d}.{0..4}`)."""
+    assert decoder_name in ("MLPFM", "MLP", "Transformer")
     if model == "MDViT_DSN":
         return _dsn_spec(param_spec("MDViT", adapt_method, num_domains, embed_dims, mlp_ratios, num_heads, num_layers, in_chans, decoder_name), num_domains)
     assert model in ("MDViT", "BASE")
@@ -103,7 +104,20 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
         _stage(spec, f"decoder{j}.mhsa_block", E[s], mlp_ratios[s], num_heads[s], num_layers[s], sup, num_domains)
     spec["finalconv.0.weight"] = ("conv", (1, E[0], 1, 1))
     spec["finalconv.0.bias"] = ("bias", (1,))
-    if model == "MDViT":
+    if model == "MDViT" and decoder_name == "Transformer":
+        for d in range(num_domains):
+            for j, (cin, cout) in enumerate(dec_io):
+                pre = f"debranchs.{d}.{j}"
+                spec[f"{pre}.conv_before.weight"] = ("conv", (cout, cin, 1, 1))
+                spec[f"{pre}.conv_before.bias"] = ("bias", (cout,))
+                spec[f"{pre}.conv_after.dwconv.weight"] = ("dwconv", (cout, 2, 3, 3))
+                spec[f"{pre}.conv_after.pwconv.weight"] = ("conv", (cout, cout, 1, 1))
+                _bn(spec, f"{pre}.conv_after.bn", cout)
+                s = 3 - j
+                _stage(spec, f"{pre}.mhsa_block", E[s], mlp_ratios[s], num_heads[s], num_layers[s], False, num_domains)
+            spec[f"debranchs.{d}.4.0.weight"] = ("conv", (1, E[0], 1, 1))
+            spec[f"debranchs.{d}.4.0.bias"] = ("bias", (1,))
+    elif model == "MDViT":
         for d in range(1, 5):
             for q in range(1, 5):
                 spec[f"debranch{d}.linear{q}.weight"] = ("conv", (AUX_HIDDEN, E[q - 1], 1, 1))
@@ -224,13 +238,14 @@ def make_params(seed: int = 0, **spec_kwargs) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
-def alias_map(model: str = "MDViT", num_layers=NUM_LAYERS) -> dict:
+def alias_map(model: str = "MDViT", num_layers=NUM_LAYERS, decoder_name: str = "MLPFM", num_domains: int = NUM_DOMAINS) -> dict:
     """alias state_dict key -> unique key (shared cpe/crpe registered under every block;
     mdvit.py:426-435)."""
     amap = {}
-    stages = [f"mhsa_stages.{s}" for s in range(4)] + [f"decoder{j}.mhsa_block" for j in range(1, 5)]
-    for st in stages:
-        s = int(st.split(".")[1]) if st.startswith("mhsa_stages") else 4 - int(st[7])
+    stages = [(f"mhsa_stages.{s}", s) for s in range(4)] + [(f"decoder{j}.mhsa_block", 4 - j) for j in range(1, 5)]
+    if decoder_name == "Transformer":
+        stages += [(f"debranchs.{d}.{j}.mhsa_block", 3 - j) for d in range(num_domains) for j in range(4)]
+    for st, s in stages:
         for i in range(num_layers[s]):
             for t in ("weight", "bias"):
                 amap[f"{st}.mhca_blks.{i}.cpe.proj.{t}"] = f"{st}.cpe.proj.{t}"

