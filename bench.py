@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base"], default="mdvit", help="mdvit_dsn: MDViT_DSN, domain-specific norms")
-    ap.add_argument("--decoder", choices=["MLPFM", "MLP", "Transformer"], default="MLPFM", help="peer heads (MDViT decoder_name); the headline config is MLPFM")
+    ap.add_argument("--decoder", choices=["MLPFM", "MLP", "Transformer", "DeepLabV3"], default="MLPFM", help="peer heads (MDViT decoder_name); the headline config is MLPFM")
     ap.add_argument("--no-side-stream", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel); "

@@ -142,10 +142,14 @@ int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const float* w, flo
 int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const float* up, const float* w,
                          float* dskip, float* dup, float* dw, void* ws /* n = 18C; unused if dw == NULL */, size_t ws_bytes,
                          int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate /* dw += */, void* stream);
-/* Dense 3x3 (pad 1) as im2col + GEMM: col is [B*Ho*Wo, Cin*9], column order (cin,kh,kw) == weight.view(Cout,-1)
- * (stem.1 mpvit.py:104-111, bridge mdvit.py:557-564). */
-int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream);
-int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream);
+/* Dense 3x3 (padding = dilation) as im2col + GEMM: col is [B*Ho*Wo, Cin*9], column order (cin,kh,kw) == weight.view(Cout,-1)
+ * (stem.1 mpvit.py:104-111, bridge mdvit.py:557-564; dilation 6/12/18 at stride 1: the ASPP branches of the 'DeepLabV3'
+ * peer heads, Utils/_deeplab.py:115-122). */
+int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, int32_t dilation, void* stream);
+int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, int32_t dilation, void* stream);
+/* y = x * dropmask / (1 - p), element-wise (nn.Dropout, Utils/_deeplab.py:155), the mask of the GEMM epilogues' counter hash:
+ * the backward is the same call on the gradient with the same keys. */
+int mdvit_dropout_f32(const float* x, float* y, int64_t n, float p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, void* stream);
 /* stem.0: NCHW image [B,Cin,H,W] -> NHWC [B,H/2,W/2,Cout], 3x3 s2 p1, no bias (mdvit.py:509-517). */
 int mdvit_stemconv_fwd(const float* img, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw, void* ws /* n = 27*Cout */, size_t ws_bytes,

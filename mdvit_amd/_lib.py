@@ -61,8 +61,9 @@ _SIGS = {
     "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_gconv2_3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "mdvit_gconv2_3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp],
-    "mdvit_im2col3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
-    "mdvit_col2im3x3": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_im2col3x3": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_col2im3x3": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_dropout_f32": [vp, vp, i64, f32, u32, u32, vp, vp],
     "mdvit_stemconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_bn_stats": [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp],

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void gconv2_wgrad_kernel(const float* __restri
 
 // ---- im2col / col2im for dense 3x3 pad 1; column order (cin, kh, kw) ---------------------------
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ col,
-                                                        int B, int Hi, int Wi, int Cin, int stride) {
+                                                        int B, int Hi, int Wi, int Cin, int stride, int dil) {
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     const long total = (long)B * Ho * Wo * Cin;
     const int K = Cin * 9;
@@ -287,10 +287,10 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
         float* dst = col + m * K + c * 9;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int hi = ho * stride + kh - 1;
+            const int hi = ho * stride + (kh - 1) * dil;             // padding = dilation (a "same" 3x3 at stride 1)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int wi = wo * stride + kw - 1;
+                const int wi = wo * stride + (kw - 1) * dil;
                 const bool ok = hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
                 dst[kh * 3 + kw] = ok ? x[(((long)b * Hi + hi) * Wi + wi) * Cin + c] : 0.f;
             }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, float* __restrict__ dx,
-                                                        int B, int Hi, int Wi, int Cin, int stride) {
+                                                        int B, int Hi, int Wi, int Cin, int stride, int dil) {
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     const long total = (long)B * Hi * Wi * Cin;
     const int K = Cin * 9;
@@ -312,13 +312,13 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict_
         float acc = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int hn = hi - kh + 1;
+            const int hn = hi - (kh - 1) * dil;
             if (hn < 0 || (hn % stride) != 0) continue;
             const int ho = hn / stride;
             if (ho >= Ho) continue;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int wn = wi - kw + 1;
+                const int wn = wi - (kw - 1) * dil;
                 if (wn < 0 || (wn % stride) != 0) continue;
                 const int wo = wn / stride;
                 if (wo >= Wo) continue;
@@ -507,6 +507,17 @@ __global__ __launch_bounds__(256) void upsample_bwd_pass_kernel(const float* __r
     }
 }
 
+// y = x * dropmask / (1 - p): one hash per aligned float4 (mdvit_drop_scale4), n % 4 == 0
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, uint32_t k0, uint32_t k1,
+                                                      const uint32_t* __restrict__ seed, uint32_t thresh, float inv_keep) {
+    const uint32_t k0e = k0 ^ (seed ? seed[0] : 0u), k1e = k1 + (seed ? seed[1] : 0u);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(x + 4 * i);
+        const float4 d = mdvit_drop_scale4(k0e, k1e, (uint32_t)(4 * i), thresh, inv_keep);
+        *reinterpret_cast<float4*>(y + 4 * i) = make_float4(v.x * d.x, v.y * d.y, v.z * d.z, v.w * d.w);
+    }
+}
+
 inline int ew_grid(long total) { return (int)min((total + 255) / 256, 16384L); }
 
 }  // namespace
@@ -594,17 +605,28 @@ extern "C" int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const fl
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream) {
-    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && (stride == 1 || stride == 2), MDVIT_E_SHAPE, "im2col3x3: bad shape");
+extern "C" int mdvit_im2col3x3(const float* x, float* col, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, int32_t dilation, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && (stride == 1 || stride == 2) && dilation >= 1 && (dilation == 1 || stride == 1), MDVIT_E_SHAPE,
+                    "im2col3x3: bad shape (stride %d, dilation %d)", stride, dilation);
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(ew_grid((long)B * Ho * Wo * Cin)), dim3(256), 0, (hipStream_t)stream, x, col, B, Hi, Wi, Cin, stride);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(ew_grid((long)B * Ho * Wo * Cin)), dim3(256), 0, (hipStream_t)stream, x, col, B, Hi, Wi, Cin, stride, dilation);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
 
-extern "C" int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, void* stream) {
-    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && (stride == 1 || stride == 2), MDVIT_E_SHAPE, "col2im3x3: bad shape");
-    hipLaunchKernelGGL(col2im3x3_kernel, dim3(ew_grid((long)B * Hi * Wi * Cin)), dim3(256), 0, (hipStream_t)stream, dcol, dx, B, Hi, Wi, Cin, stride);
+extern "C" int mdvit_col2im3x3(const float* dcol, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, int32_t stride, int32_t dilation, void* stream) {
+    MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && (stride == 1 || stride == 2) && dilation >= 1 && (dilation == 1 || stride == 1), MDVIT_E_SHAPE,
+                    "col2im3x3: bad shape (stride %d, dilation %d)", stride, dilation);
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(ew_grid((long)B * Hi * Wi * Cin)), dim3(256), 0, (hipStream_t)stream, dcol, dx, B, Hi, Wi, Cin, stride, dilation);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_dropout_f32(const float* x, float* y, int64_t n, float p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(n > 0 && n % 4 == 0 && n < (1L << 32) && p >= 0.f && p < 1.f, MDVIT_E_SHAPE, "dropout: need 0 < n < 2^32, n %% 4 == 0, 0 <= p < 1 (n=%ld p=%g)", (long)n, p);
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(y), MDVIT_E_ALIGN, "dropout: 16-byte aligned buffers");
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, (long)(n / 4), key0, key1, drop_seed,
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p));
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -92,3 +92,53 @@ class MLPDecoder(MLPDecoderFM):
 
     def __init__(self, in_channels, out_channel, hidden_channel=256, dropout_ratio=0.1, conv_norm=nn.BatchNorm2d):
         super().__init__(in_channels, out_channel, hidden_channel, outfeature_channel=0, dropout_ratio=dropout_ratio, conv_norm=conv_norm)
+
+
+class _ASPP(nn.Module):
+    """Utils/_deeplab.py:137-166: 1x1 conv | three dilated 3x3 convs | global-pool branch, each -> BN -> ReLU, concatenated and
+    projected by a 1x1 conv -> BN -> ReLU -> Dropout(0.1).  Same child indices as the reference's Sequentials."""
+
+    def __init__(self, in_channels, atrous_rates, out_channels=256):
+        super().__init__()
+        mods = [nn.Sequential(ConvParams(out_channels, in_channels, 1, 1, bias=False), BatchNormAct(out_channels, ACT_RELU), _NoParams())]
+        for _ in atrous_rates:
+            mods.append(nn.Sequential(ConvParams(out_channels, in_channels, 3, 3, bias=False), BatchNormAct(out_channels, ACT_RELU), _NoParams()))
+        mods.append(nn.Sequential(_NoParams(), ConvParams(out_channels, in_channels, 1, 1, bias=False), BatchNormAct(out_channels, ACT_RELU), _NoParams()))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(ConvParams(out_channels, (len(atrous_rates) + 2) * out_channels, 1, 1, bias=False),
+                                     BatchNormAct(out_channels, ACT_RELU), _NoParams(), nn.Dropout(0.1))
+        self.rates = tuple(atrous_rates)
+        self.out_channels = out_channels
+
+    def forward(self, x):
+        B, h, w, _ = x.shape
+        oc = self.out_channels
+        res = [self.convs[0][1](ops.linear(x, self.convs[0][0].weight.view(oc, -1)))]
+        for i, r in enumerate(self.rates, start=1):
+            res.append(self.convs[i][1](ops.conv3x3_dense(x, self.convs[i][0].weight, None, 1, dilation=r)))
+        pool = self.convs[-1]
+        pooled = ops.linear(ops.global_avg_pool(x), pool[1].weight.view(oc, -1)).view(B, 1, 1, oc)
+        res.append(ops.upsample_bilinear(pool[2](pooled), h, w))                    # a 1x1 source: the constant, broadcast
+        y = self.project[1](ops.linear(torch.cat(res, dim=-1), self.project[0].weight.view(oc, -1)))
+        return ops.dropout(y, self.project[3].p, self.training)
+
+
+class DeepLabV3Decoder(nn.Module):
+    """Decoders.py:218-236 (decoder_name='DeepLabV3'): ASPP over the last encoder feature -> conv3x3 -> BN -> ReLU -> conv1x1
+    to one channel -> bilinear upsample to the image (the 1x1 conv commutes with the upsample and runs at H/32)."""
+
+    def __init__(self, in_channel, out_channel, aspp_dilate=(6, 12, 18), conv_norm=nn.BatchNorm2d):
+        super().__init__()
+        _check_norm(conv_norm)
+        assert out_channel == 1
+        self.classifier = nn.Sequential(_ASPP(in_channel, aspp_dilate), ConvParams(256, 256, 3, 3, bias=False), BatchNormAct(256, ACT_RELU),
+                                        _NoParams(), ConvParams(out_channel, 256, 1, 1))
+
+    def forward(self, features, img_size, out_feat=False):
+        x = features[3] if isinstance(features, (list, tuple)) else features       # encoder_outs[-1] (mdvit.py:715-724 pass the 4 encoder features)
+        c = self.classifier
+        y = c[2](ops.conv3x3_dense(c[0](x), c[1].weight, None, 1))
+        B, h, w, _ = y.shape
+        low = ops.rowdot(y, c[4].weight, c[4].bias)
+        out = ops.upsample_bilinear(low.view(B, h, w, 1), int(img_size[0]), int(img_size[1]))
+        return out.view(B, 1, int(img_size[0]), int(img_size[1]))

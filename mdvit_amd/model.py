@@ -19,7 +19,7 @@ from . import ops
 from ._lib import ACT_RELU
 from .blocks import (droppath_pool, dsn_domain, BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
                      init_weights_)
-from .decode import MLPDecoder, MLPDecoderFM, UnetDecodingBlockTransformer
+from .decode import DeepLabV3Decoder, MLPDecoder, MLPDecoderFM, UnetDecodingBlockTransformer
 
 
 class _EncoderDecoder(nn.Module):
@@ -136,16 +136,17 @@ class MDViT(_EncoderDecoder):
         init_weights_(self)
 
     def _build_peer_heads(self, embed_dims, decoder_name):
-        """mdvit.py:593-606 / 852-873: four peer heads, 'MLPFM' (also fed the main decoder's last feature) or 'MLP'"""
+        """mdvit.py:593-612 / 852-873: four peer heads -- 'MLPFM' (also fed the main decoder's last feature), 'MLP', 'DeepLabV3'"""
         if decoder_name == "MLPFM":
             mk = lambda: MLPDecoderFM(embed_dims, 1, 512)
         elif decoder_name == "MLP":
             mk = lambda: MLPDecoder(embed_dims, 1, 512)
+        elif decoder_name == "DeepLabV3":
+            mk = lambda: DeepLabV3Decoder(embed_dims[3], 1)
         elif decoder_name == "Transformer":
             return                                     # built by _build_transformer_peers (needs the trunk's hyper-parameters)
         else:
-            raise NotImplementedError(f"decoder_name={decoder_name!r}: the 'MLPFM', 'MLP' and 'Transformer' peer heads are built "
-                                      "('DeepLabV3' is not)")
+            raise ValueError(f"decoder_name={decoder_name!r}: the reference knows 'MLPFM', 'MLP', 'DeepLabV3', 'Transformer'")
         self.debranch1, self.debranch2, self.debranch3, self.debranch4 = mk(), mk(), mk(), mk()
 
     def _build_transformer_peers(self, img_size, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale, drop_rate,

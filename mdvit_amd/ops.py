@@ -737,34 +737,94 @@ def gconv2_3x3(skip, up, w):
 # ------------------------------------------------------------------------------------------------
 class _Im2col(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stride):
+    def forward(ctx, x, stride, dilation=1):
         ctx.set_materialize_grads(False)
         _chk(x)
         B, H, W_, Cn = x.shape
         Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
         col = _empty((B * Ho * Wo, Cn * 9), device=x.device, dtype=torch.float32)
-        call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cn, stride, _stream())
-        ctx.meta = (B, H, W_, Cn, stride)
+        call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cn, stride, dilation, _stream())
+        ctx.meta = (B, H, W_, Cn, stride, dilation)
         return col
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 2
-        B, H, W_, Cn, stride = ctx.meta
+            return (None,) * 3
+        B, H, W_, Cn, stride, dilation = ctx.meta
         g = _c(g)
         dx = _empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
-        call("mdvit_col2im3x3", _p(g), _p(dx), B, H, W_, Cn, stride, _stream())
-        return dx, None
+        call("mdvit_col2im3x3", _p(g), _p(dx), B, H, W_, Cn, stride, dilation, _stream())
+        return dx, None, None
 
 
-def conv3x3_dense(x, w, bias=None, stride=1):
-    """x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] -> [B,Ho,Wo,Cout]."""
+def conv3x3_dense(x, w, bias=None, stride=1, dilation=1):
+    """x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] -> [B,Ho,Wo,Cout]; padding = dilation (dilation > 1 at stride 1 only)."""
     B, H, W_, Cn = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
-    col = _Im2col.apply(_c(x), int(stride))
+    col = _Im2col.apply(_c(x), int(stride), int(dilation))
     y = _Linear.apply(col, w if w.is_contiguous() else w.reshape(w.shape[0], -1), bias, None, None, 0.0, 1)
     return y.view(B, Ho, Wo, w.shape[0])
+
+
+class _Dropout(torch.autograd.Function):
+    """element-wise nn.Dropout with the counter-hash mask of the GEMM epilogues (same call, same keys, on the gradient)"""
+
+    @staticmethod
+    def forward(ctx, x, p, key):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        y = _empty_like(x)
+        call("mdvit_dropout_f32", _p(x), _p(y), x.numel(), p, key[0], key[1], _seed_ptr(), _stream())
+        ctx.meta = (p, key)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        p, key = ctx.meta
+        g = _c(g)
+        dx = _empty_like(g)
+        call("mdvit_dropout_f32", _p(g), _p(dx), g.numel(), p, key[0], key[1], _seed_ptr(), _stream())
+        return dx, None, None
+
+
+def dropout(x, p: float, training: bool = True):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(_c(x), float(p), _next_key())
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    """NHWC [B,H,W,C] -> [B,C] token mean (nn.AdaptiveAvgPool2d(1)): column sums per sample; the backward broadcasts g / (H W)
+    back over the pixels with the bilinear kernel (a 1x1 source is a constant)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        B, H, W_, Cn = x.shape
+        out = _empty((B, Cn), device=x.device, dtype=torch.float32)
+        wsp, wsb, _keep = _partials_ws(Cn, x.device)
+        for b in range(B):
+            call("mdvit_colsum_f32", _p(x[b]), Cn, _p(out[b]), None, wsp, wsb, H * W_, Cn, 0.0, 0, 0, None, 1, 0, None, _stream())
+        ctx.meta = (B, H, W_, Cn)
+        return out.mul_(1.0 / (H * W_))
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None
+        B, H, W_, Cn = ctx.meta
+        gs = _c(g).mul(1.0 / (H * W_))
+        dx = _empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
+        call("mdvit_upsample_fwd", _p(gs), _p(dx), B, 1, 1, H, W_, Cn, 0, _stream())
+        return dx
+
+
+def global_avg_pool(x):
+    return _GlobalAvgPool.apply(_c(x))
 
 
 class _StemConv(torch.autograd.Function):

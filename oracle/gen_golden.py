@@ -73,7 +73,9 @@ def _build_mdvit(ns, pn, img_size, adapt="Sup", decoder_name="MLPFM"):
                  adapt_method=adapt, num_domains=4, decoder_name=decoder_name)
     load_params_into(m, pn)
     for d in range(1, 5):                 # Dropout2d(0.1) is a fixed default of MLPDecoderFM (Decoders.py:294)
-        if hasattr(m, f"debranch{d}"):
+        if decoder_name == "DeepLabV3":   # ... and Dropout(0.1) of the ASPP projection (Utils/_deeplab.py:155)
+            getattr(m, f"debranch{d}").classifier[0].project[3].p = 0.0
+        elif hasattr(m, f"debranch{d}"):
             getattr(m, f"debranch{d}").dropout.p = 0.0
     return m
 
@@ -86,6 +88,11 @@ def gen_mdvit_mlp_step(ns, S=64, B=2, seed=6):
 def gen_mdvit_transformer_step(ns, S=64, B=2, seed=7):
     """the same step with decoder_name='Transformer': per-domain transformer peer decoders (mdvit.py:614-642,705-713)"""
     return gen_mdvit_step(ns, S, B, seed, decoder_name="Transformer")
+
+
+def gen_mdvit_deeplab_step(ns, S=64, B=2, seed=8):
+    """the same step with decoder_name='DeepLabV3' peer heads (Decoders.py:218-236, Utils/_deeplab.py:115-166)"""
+    return gen_mdvit_step(ns, S, B, seed, decoder_name="DeepLabV3")
 
 
 def gen_mdvit_step(ns, S=64, B=2, seed=0, decoder_name="MLPFM"):
@@ -129,7 +136,8 @@ def gen_mdvit_step(ns, S=64, B=2, seed=0, decoder_name="MLPFM"):
     for n in ("finalconv.0.weight", "mhsa_stages.0.mhca_blks.0.factoratt_crpe.domain_layer.0.weight",
               "mhsa_stages.0.cpe.proj.weight", "mhsa_stages.0.crpe.conv_list.2.weight",
               "decoder4.conv_after.dwconv.weight", "stem.0.conv.weight", "debranch2.linear_out.weight",
-              "debranchs.2.4.0.weight", "debranchs.1.3.conv_after.dwconv.weight", "debranchs.3.0.mhsa_block.mhca_blks.1.norm1.weight",
+              "debranchs.2.4.0.weight", "debranchs.1.3.conv_after.dwconv.weight", "debranch3.classifier.4.weight",
+              "debranch1.classifier.0.convs.4.2.weight", "debranch4.classifier.0.convs.2.1.weight", "debranch2.classifier.0.project.1.bias", "debranchs.3.0.mhsa_block.mhca_blks.1.norm1.weight",
               "mhsa_stages.3.mhca_blks.1.norm2.weight", "stem.1.bn.weight"):
         if n in grads:
             out["grad::" + n] = grads[n].numpy().copy()
@@ -286,7 +294,7 @@ def main():
     torch.set_num_threads(8)
     ns = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    jobs = {"mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
+    jobs = {"mdvit_deeplab_step_64": gen_mdvit_deeplab_step, "mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
             "base_step_64": gen_base_step, "factoratt_small": gen_factoratt, "losses_small": gen_losses}
     only = set(sys.argv[1:])
     for name, fn in jobs.items():

@@ -228,6 +228,25 @@ def aux_head(P: Params, d: int, feats: Sequence[Tensor], img_size, st: RefState)
     return F.conv2d(y, P[p + ".linear_out.weight"], P[p + ".linear_out.bias"])
 
 
+def deeplab_head(P: Params, d: int, feats: Sequence[Tensor], img_size, st: RefState) -> Tensor:
+    """DeepLabV3Decoder.forward, Decoders.py:229-236, over ASPP (Utils/_deeplab.py:115-166, rates 6/12/18) on encoder_outs[-1]."""
+    p = f"debranch{d}.classifier"
+    x = feats[3]
+    a = p + ".0"
+    res = [torch.relu(batch_norm(P, a + ".convs.0.1", F.conv2d(x, P[a + ".convs.0.0.weight"]), st, kinks=(0.0,)))]
+    for i, r in ((1, 6), (2, 12), (3, 18)):
+        res.append(torch.relu(batch_norm(P, f"{a}.convs.{i}.1", F.conv2d(x, P[f"{a}.convs.{i}.0.weight"], None, 1, r, r), st, kinks=(0.0,))))
+    g = F.adaptive_avg_pool2d(x, 1)
+    g = torch.relu(batch_norm(P, a + ".convs.4.2", F.conv2d(g, P[a + ".convs.4.1.weight"]), st, kinks=(0.0,)))
+    res.append(F.interpolate(g, size=x.shape[-2:], mode="bilinear", align_corners=False))
+    y = torch.relu(batch_norm(P, a + ".project.1", F.conv2d(torch.cat(res, 1), P[a + ".project.0.weight"]), st, kinks=(0.0,)))
+    if st.training and st.aux_drop > 0:
+        y = F.dropout(y, st.aux_drop, True)              # nn.Dropout(0.1), _deeplab.py:155
+    y = torch.relu(batch_norm(P, p + ".2", F.conv2d(y, P[p + ".1.weight"], None, 1, 1), st, kinks=(0.0,)))
+    y = F.conv2d(y, P[p + ".4.weight"], P[p + ".4.bias"])
+    return F.interpolate(y, size=tuple(img_size), mode="bilinear", align_corners=False)
+
+
 # ---- whole models -----------------------------------------------------------------------------
 
 def _encoder_decoder(P: Params, x: Tensor, domain_label: Optional[Tensor], st: RefState,
@@ -270,7 +289,8 @@ def mdvit_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, d
         a = F.interpolate(a, size=tuple(img_size), mode="bilinear", align_corners=False)
         aux = F.conv2d(a, P[f"debranchs.{k}.4.0.weight"], P[f"debranchs.{k}.4.0.bias"])
     elif d in ("0", "1", "2", "3"):
-        aux = aux_head(P, int(d) + 1, enc + [dec4], img_size, st)
+        head = deeplab_head if f"debranch{int(d) + 1}.classifier.4.weight" in P else aux_head
+        aux = head(P, int(d) + 1, enc + [dec4], img_size, st)
     return [logits, aux]
 
 

@@ -67,8 +67,9 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
                num_layers=NUM_LAYERS, in_chans: int = 3, decoder_name: str = "MLPFM") -> "OrderedDict[str, tuple]":
     """name -> (kind, shape) for every unique parameter and buffer.  decoder_name: 'MLPFM' (peer heads that also take the
     main decoder's last feature, Decoders.py:289-339), 'MLP' (Decoders.py:239-286: the four encoder features only) or
-    'Transformer' (mdvit.py:614-642: per domain a full transformer decoder without Domain Adapter, `debranchs.{d}.{0..4}`)."""
-    assert decoder_name in ("MLPFM", "MLP", "Transformer")
+    'Transformer' (mdvit.py:614-642: per domain a full transformer decoder without Domain Adapter, `debranchs.{d}.{0..4}`),
+    'DeepLabV3' (Decoders.py:218-236 + Utils/_deeplab.py:115-166: ASPP heads on the last encoder feature)."""
+    assert decoder_name in ("MLPFM", "MLP", "Transformer", "DeepLabV3")
     if model == "MDViT_DSN":
         return _dsn_spec(param_spec("MDViT", adapt_method, num_domains, embed_dims, mlp_ratios, num_heads, num_layers, in_chans, decoder_name), num_domains)
     assert model in ("MDViT", "BASE")
@@ -117,6 +118,22 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
                 _stage(spec, f"{pre}.mhsa_block", E[s], mlp_ratios[s], num_heads[s], num_layers[s], False, num_domains)
             spec[f"debranchs.{d}.4.0.weight"] = ("conv", (1, E[0], 1, 1))
             spec[f"debranchs.{d}.4.0.bias"] = ("bias", (1,))
+    elif model == "MDViT" and decoder_name == "DeepLabV3":
+        for d in range(1, 5):
+            a = f"debranch{d}.classifier.0"
+            spec[f"{a}.convs.0.0.weight"] = ("conv", (256, E[3], 1, 1))
+            _bn(spec, f"{a}.convs.0.1", 256)
+            for i in (1, 2, 3):
+                spec[f"{a}.convs.{i}.0.weight"] = ("conv", (256, E[3], 3, 3))
+                _bn(spec, f"{a}.convs.{i}.1", 256)
+            spec[f"{a}.convs.4.1.weight"] = ("conv", (256, E[3], 1, 1))
+            _bn(spec, f"{a}.convs.4.2", 256)
+            spec[f"{a}.project.0.weight"] = ("conv", (256, 5 * 256, 1, 1))
+            _bn(spec, f"{a}.project.1", 256)
+            spec[f"debranch{d}.classifier.1.weight"] = ("conv", (256, 256, 3, 3))
+            _bn(spec, f"debranch{d}.classifier.2", 256)
+            spec[f"debranch{d}.classifier.4.weight"] = ("conv", (1, 256, 1, 1))
+            spec[f"debranch{d}.classifier.4.bias"] = ("bias", (1,))
     elif model == "MDViT":
         for d in range(1, 5):
             for q in range(1, 5):

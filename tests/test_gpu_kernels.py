@@ -299,6 +299,41 @@ def test_conv3x3_dense(B, H, W, Cin, Cout, stride, bias):
         check(go[2], gr[2], name="db")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,dil", [(2, 16, 16, 32, 64, 6), (1, 8, 8, 64, 32, 12), (2, 5, 7, 32, 32, 18), (1, 20, 13, 32, 64, 2)])
+def test_conv3x3_dense_dilated(B, H, W, Cin, Cout, dil):
+    """the ASPP branches of the 'DeepLabV3' peer heads (Utils/_deeplab.py:115-122): 3x3, dilation = padding = 6 / 12 / 18, also
+    where the dilation exceeds the feature map (only the centre tap stays inside)"""
+    from mdvit_amd import ops
+    x, w, g = rnd(B, Cin, H, W, seed=160), rnd(Cout, Cin, 3, 3, seed=161, scale=(Cin * 9) ** -0.5), rnd(B, Cout, H, W, seed=163)
+    ref, gr = grads_of(lambda x, w: F.conv2d(x.double(), w.double(), None, 1, dil, dil), [x, w], g.double())
+    out, go = grads_of(lambda x, w: ops.conv3x3_dense(x, w, None, 1, dilation=dil), [nhwc(x).to(dev()), w.to(dev())], nhwc(g))
+    check(nchw(out), ref, name="y")
+    check(nchw(go[0]), gr[0], name="dx")
+    check(go[1], gr[1], name="dw")
+
+
+def test_elementwise_dropout_and_global_avg_pool(monkeypatch):
+    from mdvit_amd import ops
+    x = rnd(3, 11, 13, 64, seed=170).to(dev()).requires_grad_(True)
+    # global average pool (nn.AdaptiveAvgPool2d(1)) and its broadcast backward
+    g = rnd(3, 64, seed=171).to(dev())
+    y = ops.global_avg_pool(x)
+    y.backward(g)
+    check(y, x.detach().double().mean(dim=(1, 2)), name="pooled")
+    check(x.grad, (g.double() / (11 * 13)).view(3, 1, 1, 64).expand(3, 11, 13, 64), name="d pooled")
+    # element-wise dropout: kept fraction, scaling, and the SAME mask on the gradient
+    t = torch.ones(1 << 18, device=dev(), requires_grad=True)
+    d = ops.dropout(t, 0.25, True)
+    kept = d.detach() != 0
+    assert abs(float(kept.float().mean()) - 0.75) < 5e-3
+    assert torch.allclose(d.detach()[kept], torch.full_like(d.detach()[kept], 1.0 / 0.75))
+    d.backward(torch.full_like(d, 3.0))
+    assert torch.equal(t.grad != 0, kept) and torch.allclose(t.grad[kept], torch.full_like(t.grad[kept], 4.0))
+    assert ops.dropout(t, 0.25, False) is t and ops.dropout(t, 0.0, True) is t
+    d2 = ops.dropout(t, 0.25, True)
+    assert not torch.equal(d2.detach() != 0, kept)                     # a new key per call
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 17, 23), (3, 64, 48)])
 def test_stem_conv(B, H, W):
     from mdvit_amd import ops

@@ -71,7 +71,10 @@ def build_mdvit(seed, img_size=64, drop=0.0, decoder_name="MLPFM"):
     m = mdvit_amd.MDViT(img_size=img_size, drop_rate=drop, drop_path_rate=drop, conv_norm=torch.nn.BatchNorm2d,
                         adapt_method="Sup", num_domains=4, decoder_name=decoder_name)
     load_params(m, make_params(seed, model="MDViT", adapt_method="Sup", decoder_name=decoder_name))
-    if drop == 0.0 and decoder_name != "Transformer":
+    if drop == 0.0 and decoder_name == "DeepLabV3":
+        for d in range(1, 5):
+            getattr(m, f"debranch{d}").classifier[0].project[3].p = 0.0
+    elif drop == 0.0 and decoder_name != "Transformer":
         for d in range(1, 5):
             getattr(m, f"debranch{d}").dropout.p = 0.0
     return m.to(dev())
@@ -126,7 +129,7 @@ def test_factoratt_module_vs_golden(golden, tag):
 
 
 @pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP"),
-                                                  ("mdvit_transformer_step_64", "Transformer")])
+                                                  ("mdvit_transformer_step_64", "Transformer"), ("mdvit_deeplab_step_64", "DeepLabV3")])
 def test_mdvit_two_sweep_step_vs_golden(golden, gemm_precision, fixture, decoder_name):
     """4-domain step, multi_train_MDViT.py:129-207: logits, the three losses, BN running stats and every
     parameter gradient after the aux sweep (domain_layer frozen) + uni sweep.  decoder_name='MLP': the peer heads
@@ -168,8 +171,11 @@ def test_mdvit_two_sweep_step_vs_golden(golden, gemm_precision, fixture, decoder
     assert names == [str(n) for n in g["grad_names"]]
     ref = g["grad_norms"]
     rel = np.abs(norms - ref) / np.maximum(ref, 1e-6 * ref.max())
+    # (the ASPP pooling branch of the DeepLabV3 heads normalises B = 2 pooled vectors: a two-sample BatchNorm's backward divides
+    #  by the tiny batch variance and amplifies the bf16x3 rounding of what feeds it -- and its gradient reaches the whole encoder)
+    norm_tol = 1.5e-2 if (decoder_name == "DeepLabV3" and gemm_precision == "bf16x3") else 5e-3
     worst = int(rel.argmax())
-    assert rel.max() < 5e-3, f"grad norm mismatch at {names[worst]}: {rel.max():.2e} (ours {norms[worst]:.4e} ref {ref[worst]:.4e})"
+    assert rel.max() < norm_tol, f"grad norm mismatch at {names[worst]}: {rel.max():.2e} (ours {norms[worst]:.4e} ref {ref[worst]:.4e})"
     for key in g.files:
         if key.startswith("grad::"):      # 4-domain sums; this fixture's kink margin is 1.9e-6 (a flip is likely somewhere)
             check_grad(grads[key[6:]], g[key], name=key, l2_tol=1e-2)
@@ -477,7 +483,7 @@ def test_train_step_metrics_on_device_match_host_restatement():
         m.zero_grad(set_to_none=True)
 
 
-@pytest.mark.parametrize("fuse,decoder_name", [(2, "MLPFM"), (4, "MLPFM"), (2, "MLP"), (4, "Transformer")])
+@pytest.mark.parametrize("fuse,decoder_name", [(2, "MLPFM"), (4, "MLPFM"), (2, "MLP"), (4, "Transformer"), (4, "DeepLabV3")])
 def test_domain_batched_step_equals_per_domain_forwards(fuse, decoder_name):
     """ONE forward over the concatenated domain batches (per-domain BatchNorm statistics, per-domain peer heads and
     losses) == the reference's one forward per domain: logits, the three losses, every gradient, BN running stats"""

@@ -76,8 +76,10 @@ def test_module_surface_matches_reference_inventory():
     tr = mdvit_amd.MDViT(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4, decoder_name="Transformer")
     assert set(tr.state_dict()) == set(param_spec("MDViT", "Sup", decoder_name="Transformer")) | set(alias_map(decoder_name="Transformer"))
     assert not any("domain_layer" in k for k in tr.state_dict() if k.startswith("debranchs."))      # peers carry no adapter (mdvit.py:631)
-    with pytest.raises(NotImplementedError):
-        mdvit_amd.MDViT(decoder_name="DeepLabV3")
+    dl = mdvit_amd.MDViT(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4, decoder_name="DeepLabV3")
+    assert set(dl.state_dict()) == set(param_spec("MDViT", "Sup", decoder_name="DeepLabV3")) | set(alias_map())
+    with pytest.raises(ValueError):
+        mdvit_amd.MDViT(decoder_name="UperNet")
     with pytest.raises(NotImplementedError):
         mdvit_amd.MDViT_DSN(decoder_name="Transformer")
     # reference init scheme (mdvit.py:648-664)
