@@ -261,3 +261,34 @@ class BASE(_EncoderDecoder):
         if out_feat:
             return {"seg": logits, "feat": self._pooled_feat(enc[3])}
         return logits
+
+
+class BASE_DSN(BASE):
+    """base.py:515-700: BASE with domain-specific norms (the trunk of MDViT_DSN: stem_{1,2}.bns, norm1s / norm2s, bridge_norms{1,2},
+    conv_after.bns, indexed by int(d)); forward(x, domain_label, d) -> logits.  A list of distinct ids runs the domain-batched
+    forward through the group-indexed BN / LN kernels."""
+
+    def __init__(self, img_size=512, in_chans=3, num_stages=4, num_layers=[2, 2, 2, 2], embed_dims=[64, 128, 320, 512],
+                 mlp_ratios=[8, 8, 4, 4], num_heads=[8, 8, 8, 8], qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=None, conv_norm=nn.BatchNorm2d, adapt_method=None, num_domains=4, **kwargs):
+        _EncoderDecoder.__init__(self)
+        self.adapt_method = adapt_method
+        self._build_trunk(img_size, in_chans, num_stages, num_layers, embed_dims, mlp_ratios, num_heads, qkv_bias, qk_scale,
+                          drop_rate, attn_drop_rate, drop_path_rate, norm_layer, conv_norm, adapt_method, num_domains, dsn=num_domains)
+        init_weights_(self)
+
+    def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
+        if isinstance(d, (list, tuple)):
+            G = len(d)
+            if x.shape[0] % G:
+                raise ValueError(f"batch {x.shape[0]} is not {G} equal domain batches")
+            with dsn_domain(tuple(int(v) for v in d)):
+                logits, enc, _, _, _ = self._trunk(x, domain_label, groups=G)
+        else:
+            with dsn_domain(int(d)):
+                logits, enc, _, _, _ = self._trunk(x, domain_label)
+        if not out_seg:
+            return {"seg": None, "feat": self._pooled_feat(enc[3])}
+        if out_feat:
+            return {"seg": logits, "feat": self._pooled_feat(enc[3])}
+        return logits

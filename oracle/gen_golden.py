@@ -233,6 +233,31 @@ def gen_base_step(ns, S=64, B=2, seed=3):
             "grad_norms": norms, "grad_heads": heads, "meta": np.array([S, B, seed])}
 
 
+def gen_base_dsn_step(ns, S=64, B=2, seed=9):
+    """BASE_DSN (base.py:515-700) with adapt_method='Sup': two domains, forward(img, domain_label, d), BCE+Dice, one backward"""
+    pn = make_params(seed, model="BASE_DSN", adapt_method="Sup")
+    m = ns.BASE_DSN(drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4)
+    load_params_into(m, pn)
+    m.train()
+    out = {"n_state_dict_keys": np.array(len(m.state_dict())), "meta": np.array([S, B, seed])}
+    loss = 0.0
+    for d in (2, 0):
+        img, lab = synth_image(700 + d, B, S, S), synth_label(800 + d, B, S, S)
+        dl = F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float()
+        o = m(img, dl, str(d))
+        so = torch.sigmoid(o)
+        loss = loss + torch.nn.BCELoss()(so, lab) + ns.dice_loss(so, lab)
+        out[f"out_{d}"] = o.detach().numpy().copy()
+    m.zero_grad()
+    loss.backward()
+    names, norms, heads = grad_digest({n: p.grad for n, p in m.named_parameters()})
+    sd = m.state_dict()
+    bn_names = sorted(k for k, (kind, _) in param_spec("BASE_DSN", "Sup").items() if kind in ("bn_rm", "bn_rv"))
+    out.update(loss=np.array(float(loss)), grad_names=np.array(names), grad_norms=norms, grad_heads=heads,
+               bn_names=np.array(bn_names), bn_sums=np.array([float(sd[k].double().sum()) for k in bn_names]))
+    return out
+
+
 def gen_factoratt(ns, seed=4):
     """FactorAtt_ConvRelPosEnc_Sup fwd + grads at small shapes (mdvit.py:243-313), and the plain
     variant (mpvit.py:321-373)."""
@@ -294,7 +319,7 @@ def main():
     torch.set_num_threads(8)
     ns = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    jobs = {"mdvit_deeplab_step_64": gen_mdvit_deeplab_step, "mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
+    jobs = {"base_dsn_step_64": gen_base_dsn_step, "mdvit_deeplab_step_64": gen_mdvit_deeplab_step, "mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
             "base_step_64": gen_base_step, "factoratt_small": gen_factoratt, "losses_small": gen_losses}
     only = set(sys.argv[1:])
     for name, fn in jobs.items():

@@ -309,6 +309,14 @@ def mdvit_dsn_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = Non
     return mdvit_forward(dsn_view(P, int(d), names), x, domain_label, d, st)
 
 
+def base_dsn_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, d: Optional[str] = None,
+                     st: Optional[RefState] = None) -> Tensor:
+    """BASE_DSN.forward, base.py:651-700: BASE.forward on the norms of domain int(d)."""
+    from .params import param_spec
+    names = param_spec("BASE", st.adapt_method if st is not None else False).keys()
+    return base_forward(dsn_view(P, int(d), names), x, domain_label, st)
+
+
 def base_forward(P: Params, x: Tensor, domain_label: Optional[Tensor] = None, st: Optional[RefState] = None) -> Tensor:
     """BASE.forward, base.py:477-512 -> logits tensor."""
     st = st or RefState()
@@ -386,14 +394,16 @@ def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: f
 
 
 def base_train_step(P: Params, img: Tensor, label: Tensor, domain_label: Optional[Tensor] = None,
-                    st: Optional[RefState] = None):
-    """multi_train_BASE.py:168-200 for one domain: loss = BCE+Dice, single backward."""
+                    st: Optional[RefState] = None, forward=None):
+    """multi_train_BASE.py:168-200 for one domain: loss = BCE+Dice, single backward.  forward: base_forward, or a closure over
+    base_dsn_forward with the domain id."""
     st = st or RefState()
+    base_forward_ = forward or base_forward
     leaves = {k: v for k, v in P.items() if v.is_floating_point() and "running_" not in k}
     for v in leaves.values():
         v.requires_grad_(True)
         v.grad = None
-    o = torch.sigmoid(base_forward(P, img, domain_label, st))
+    o = torch.sigmoid(base_forward_(P, img, domain_label, st))
     loss = bce_loss(o, label) + dice_loss(o, label)
     loss.backward()
     grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in leaves.items()}

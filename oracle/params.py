@@ -72,6 +72,8 @@ def param_spec(model: str = "MDViT", adapt_method="Sup", num_domains: int = NUM_
     assert decoder_name in ("MLPFM", "MLP", "Transformer", "DeepLabV3")
     if model == "MDViT_DSN":
         return _dsn_spec(param_spec("MDViT", adapt_method, num_domains, embed_dims, mlp_ratios, num_heads, num_layers, in_chans, decoder_name), num_domains)
+    if model == "BASE_DSN":        # base.py:515-700: BASE with the same per-domain norm banks
+        return _dsn_spec(param_spec("BASE", adapt_method, num_domains, embed_dims, mlp_ratios, num_heads, num_layers, in_chans), num_domains)
     assert model in ("MDViT", "BASE")
     sup = adapt_method == "Sup"
     E = tuple(embed_dims)

@@ -89,7 +89,7 @@ def import_reference():
     from Models import Decoders as ref_dec
     from Utils import losses as ref_losses
     ns = types.SimpleNamespace(
-        MDViT=ref_mdvit.MDViT, MDViT_DSN=ref_mdvit.MDViT_DSN, BASE=ref_base.BASE,
+        MDViT=ref_mdvit.MDViT, MDViT_DSN=ref_mdvit.MDViT_DSN, BASE=ref_base.BASE, BASE_DSN=ref_base.BASE_DSN,
         FactorAtt_Sup=ref_mdvit.FactorAtt_ConvRelPosEnc_Sup, FactorAtt=ref_mpvit.FactorAtt_ConvRelPosEnc,
         SerialBlock_adapt=ref_mdvit.SerialBlock_adapt, MHSA_stage_adapt=ref_mdvit.MHSA_stage_adapt,
         ConvPosEnc=ref_mpvit.ConvPosEnc, ConvRelPosEnc=ref_mpvit.ConvRelPosEnc, Mlp=ref_mpvit.Mlp,

@@ -320,6 +320,50 @@ def test_base_step_vs_golden(golden):
     assert rel.max() < 5e-3, f"{names[int(rel.argmax())]} {rel.max():.2e}"
 
 
+def test_base_dsn_step_vs_golden(golden):
+    """BASE_DSN (base.py:515-700): per-domain norm banks under BASE's forward; also as ONE domain-batched forward"""
+    import mdvit_amd
+    from mdvit_amd.losses import seg_loss
+    from oracle.gen_golden import synth_image, synth_label, grad_digest
+    from oracle.params import make_params
+    g = golden("base_dsn_step_64")
+    S, B, seed = [int(v) for v in g["meta"]]
+
+    def build():
+        m = mdvit_amd.BASE_DSN(drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4)
+        load_params(m, make_params(seed, model="BASE_DSN", adapt_method="Sup"))
+        return m.to(dev()).train()
+
+    m = build()
+    assert len(m.state_dict()) == int(g["n_state_dict_keys"])
+    data = {d: (synth_image(700 + d, B, S, S).to(dev()), synth_label(800 + d, B, S, S).to(dev()),
+                F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float().to(dev())) for d in (2, 0)}
+    loss = 0.0
+    for d in (2, 0):
+        out = m(data[d][0], data[d][2], str(d))
+        check(out, g[f"out_{d}"], name=f"base_dsn out_{d}")
+        loss = loss + seg_loss(out, data[d][1])
+    check(loss, g["loss"], name="base_dsn loss")
+    loss.backward()
+    names, norms, _ = grad_digest({n: (None if p.grad is None else p.grad.detach().cpu()) for n, p in m.named_parameters()})
+    assert names == [str(n) for n in g["grad_names"]]
+    ref = g["grad_norms"]
+    rel = np.abs(norms - ref) / np.maximum(ref, 1e-6 * ref.max())
+    assert rel.max() < 5e-3, f"{names[int(rel.argmax())]} {rel.max():.2e}"
+    sd = m.state_dict()
+    check(torch.tensor([float(sd[str(k)].double().sum()) for k in g["bn_names"]]), g["bn_sums"], name="BN running stats per domain")
+    # one domain-batched forward over both domains: bank row d on batch group d
+    m2 = build()
+    outb = m2(torch.cat([data[2][0], data[0][0]]), torch.cat([data[2][2], data[0][2]]), ["2", "0"])
+    check(outb[:B], g["out_2"], name="batched out_2")
+    check(outb[B:], g["out_0"], name="batched out_0")
+    (seg_loss(outb[:B], data[2][1]) + seg_loss(outb[B:], data[0][1])).backward()
+    for (n, p), (_, q) in zip(m2.named_parameters(), m.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            check_grad(p.grad, q.grad, name="batched " + n, l2_tol=1e-3, max_tol=1e-2)
+
+
 def test_mdvit_vs_oracle_128(gemm_precision):
     """same seeded inputs, larger image (128x128), HIP path vs the CPU oracle incl. input-side gradients of
     every parameter (full tensors, not digests)."""

@@ -78,6 +78,8 @@ def test_module_surface_matches_reference_inventory():
     assert not any("domain_layer" in k for k in tr.state_dict() if k.startswith("debranchs."))      # peers carry no adapter (mdvit.py:631)
     dl = mdvit_amd.MDViT(img_size=64, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4, decoder_name="DeepLabV3")
     assert set(dl.state_dict()) == set(param_spec("MDViT", "Sup", decoder_name="DeepLabV3")) | set(alias_map())
+    bd = mdvit_amd.BASE_DSN(conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4)
+    assert set(bd.state_dict()) == set(param_spec("BASE_DSN", "Sup")) | set(alias_map("BASE"))
     with pytest.raises(ValueError):
         mdvit_amd.MDViT(decoder_name="UperNet")
     with pytest.raises(NotImplementedError):

@@ -118,6 +118,34 @@ def test_base_step(golden):
     assert rel.max() < 2e-3
 
 
+def test_base_dsn_step(golden):
+    """BASE_DSN (base.py:515-700): per-domain norm banks under BASE's forward, two domains, one backward"""
+    g = golden("base_dsn_step_64")
+    S, B, seed = [int(v) for v in g["meta"]]
+    P = R.to_torch(make_params(seed, model="BASE_DSN", adapt_method="Sup"))
+    assert len(P) + len(alias_map("BASE")) == int(g["n_state_dict_keys"])
+    st = R.RefState(training=True, adapt_method="Sup")
+    leaves = {k: v for k, v in P.items() if v.is_floating_point() and "running_" not in k}
+    for v in leaves.values():
+        v.requires_grad_(True)
+    loss = 0.0
+    for d in (2, 0):
+        img, lab = synth_image(700 + d, B, S, S), synth_label(800 + d, B, S, S)
+        dl = F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float()
+        o = R.base_dsn_forward(P, img, dl, str(d), st)
+        close(o.detach(), g[f"out_{d}"], name=f"base_dsn out_{d}")
+        so = torch.sigmoid(o)
+        loss = loss + R.bce_loss(so, lab) + R.dice_loss(so, lab)
+    close(float(loss), g["loss"], name="base_dsn loss")
+    loss.backward()
+    names, norms, _ = grad_digest({k: v.grad for k, v in leaves.items()})
+    assert names == [str(n) for n in g["grad_names"]]
+    ref = g["grad_norms"]
+    rel = np.abs(norms - ref) / np.maximum(ref, 1e-6 * ref.max())
+    assert rel.max() < 2e-3, f"{names[int(rel.argmax())]} {rel.max():.2e}"
+    close([float(P[str(k)].double().sum()) for k in g["bn_names"]], g["bn_sums"], name="bn running sums per domain")
+
+
 def _factoratt_params(tag_shape, seed=4):
     """Rebuild the module-local weights gen_golden.gen_factoratt used (sorted named_parameters order)."""
     B, H, W, C = tag_shape
