@@ -181,8 +181,8 @@ int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float
 
 /* ---- bilinear resize, align_corners=False, NHWC (F.interpolate call sites mdvit.py:699,
  * Decoders.py:196,320-329,336) ------------------------------------------------------------------ */
-int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C,
-                       int32_t accumulate, void* stream);
+int mdvit_upsample_fwd(const float* x, const float* base /* optional [B,Ho,Wo,C]: y = base + resize(x); may be y itself */, float* y,
+                       int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
 size_t mdvit_upsample_bwd_ws_bytes(int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C);
 /* adjoint, separable: dy [B,Ho,Wo,C] -> (width pass) ws [B,Ho,Wi,C] -> (height pass) dx [B,Hi,Wi,C] */
 int mdvit_upsample_bwd(const float* dy, float* dx, void* ws, size_t ws_bytes, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,

@@ -70,7 +70,7 @@ _SIGS = {
     "mdvit_bn_eval_prep": [vp, vp, vp, vp, i32, f32, vp],
     "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
-    "mdvit_upsample_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_upsample_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_upsample_bwd": [vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_da_bwd": [vp] * 7 + [f32] + [vp] * 4 + [vp, C.c_size_t] + [i32] * 5 + [vp],

@@ -420,8 +420,8 @@ __device__ __forceinline__ void bilin_src(int o, int in_size, float scale, int& 
     l1 = src - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                           int B, int Hi, int Wi, int Ho, int Wo, int C, int accumulate) {
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, const float* base_, float* y,
+                                                           int B, int Hi, int Wi, int Ho, int Wo, int C) {
     const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
     const bool vec = (C & 3) == 0;
     const int QC = vec ? C >> 2 : C;
@@ -448,14 +448,14 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
             o.y = c00 * v00.y + c01 * v01.y + c10 * v10.y + c11 * v11.y;
             o.z = c00 * v00.z + c01 * v01.z + c10 * v10.z + c11 * v11.z;
             o.w = c00 * v00.w + c01 * v01.w + c10 * v10.w + c11 * v11.w;
-            float4* dst = reinterpret_cast<float4*>(y + (((long)b * Ho + ho) * Wo + wo) * C + c);
-            if (accumulate) o = f4_add(o, *dst);
-            *dst = o;
+            const long oi = (((long)b * Ho + ho) * Wo + wo) * C + c;
+            if (base_) o = f4_add(o, *reinterpret_cast<const float4*>(base_ + oi));        // y = base + up (base may be y itself)
+            *reinterpret_cast<float4*>(y + oi) = o;
         } else {
             const float v = c00 * x[(base + (long)h0 * Wi + w0) * C + q] + c01 * x[(base + (long)h0 * Wi + w1) * C + q] +
                             c10 * x[(base + (long)h1 * Wi + w0) * C + q] + c11 * x[(base + (long)h1 * Wi + w1) * C + q];
-            float* dst = y + (((long)b * Ho + ho) * Wo + wo) * C + q;
-            *dst = accumulate ? *dst + v : v;
+            const long oi = (((long)b * Ho + ho) * Wo + wo) * C + q;
+            y[oi] = base_ ? base_[oi] + v : v;
         }
     }
 }
@@ -656,10 +656,10 @@ extern "C" int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw
     return mdvit_reduce_partials((const float*)ws, nblk, 27L * Cout, 27 * Cout, dw, 0, nullptr, accumulate, s);
 }
 
-extern "C" int mdvit_upsample_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, int32_t accumulate, void* stream) {
+extern "C" int mdvit_upsample_fwd(const float* x, const float* base, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream) {
     MDVIT_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, MDVIT_E_SHAPE, "upsample_fwd: bad shape");
     const long total = (long)B * Ho * Wo * ((C & 3) == 0 ? C / 4 : C);
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hi, Wi, Ho, Wo, C, accumulate);
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, base, y, B, Hi, Wi, Ho, Wo, C);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -819,7 +819,7 @@ class _GlobalAvgPool(torch.autograd.Function):
         B, H, W_, Cn = ctx.meta
         gs = _c(g).mul(1.0 / (H * W_))
         dx = _empty((B, H, W_, Cn), device=g.device, dtype=torch.float32)
-        call("mdvit_upsample_fwd", _p(gs), _p(dx), B, 1, 1, H, W_, Cn, 0, _stream())
+        call("mdvit_upsample_fwd", _p(gs), None, _p(dx), B, 1, 1, H, W_, Cn, _stream())
         return dx
 
 
@@ -994,11 +994,8 @@ class _Upsample(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         _chk(x, base)
         B, H, W_, Cn = x.shape
-        if base is None:
-            y = _empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
-        else:
-            y = base.clone()
-        call("mdvit_upsample_fwd", _p(x), _p(y), B, H, W_, Ho, Wo, Cn, int(base is not None), _stream())
+        y = _empty((B, Ho, Wo, Cn), device=x.device, dtype=torch.float32)
+        call("mdvit_upsample_fwd", _p(x), _p(base), _p(y), B, H, W_, Ho, Wo, Cn, _stream())          # y = (base +) resize(x): one pass, no clone
         ctx.meta = (B, H, W_, Ho, Wo, Cn, base is not None)
         return y
 

@@ -505,7 +505,7 @@ def test_upsample(B, Hi, Wi, Ho, Wo, C):
     check(nchw(out), ref, name="y")
     check(nchw(go[0]), gr[0], name="dx")
     base = rnd(B, Ho, Wo, C, seed=102).to(dev())
-    out2 = _Upsample.apply(nhwc(x).to(dev()), Ho, Wo, base)
+    out2 = _Upsample.apply(nhwc(x).to(dev()), Ho, Wo, base)          # base + resize(x) in one pass
     check(out2, out.detach() + base, name="accumulate")
 
 
