@@ -66,9 +66,10 @@ class MLPDecoderFM(nn.Module):
         bias = self.linear_fuse[0].bias
         lins = (self.linear1, self.linear2, self.linear3, self.linear4)
         # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)      (MLPDecoder: no x5 term, bf rides on q = 0)
-        acc = ops.linear(features[4], Wf[:, 4 * hid:], bias) if self.with_fm else None        # [B,h,w,hid]
+        blocks = ops.split_cols(Wf, [hid] * 4 + ([Wf.shape[1] - 4 * hid] if self.with_fm else []))      # column blocks of the fuse weight
+        acc = ops.linear(features[4], blocks[4], bias) if self.with_fm else None              # [B,h,w,hid]
         for q, lin in enumerate(lins):
-            Wf_q = Wf[:, q * hid:(q + 1) * hid]
+            Wf_q = blocks[q]
             Wc = ops.matmul(Wf_q, lin.weight.view(hid, -1))                                    # [hid, C_q]
             bc = ops.rowdot(Wf_q, lin.bias)                                                    # [hid]
             fq = features[q]

@@ -337,7 +337,10 @@ def refresh_transposes():
 def _dgrad(g, W, dx, M, K, N, ldb, **kw):
     """dx[M,K] = g[M,N] @ W[N,K]: NN on the fp32 path; NT against the cached W^T on the bf16x3 path."""
     if _gemm_precision:
-        gemm(_p(g), _p(wt(W)), _p(dx), M, K, N, lda=N, ldb=N, ldc=K, trans_b=True, **kw)
+        Wt = wt(W)          # held until the launch is enqueued: for a non-leaf W the transpose is a temporary, and gemm() allocates
+        #                     its split-K workspace before launching -- a freed W^T block could be handed out as that workspace
+        gemm(_p(g), _p(Wt), _p(dx), M, K, N, lda=N, ldb=N, ldc=K, trans_b=True, **kw)
+        del Wt
     else:
         gemm(_p(g), _p(W), _p(dx), M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False, **kw)
 
@@ -965,6 +968,34 @@ class _SplitGroups(torch.autograd.Function):
             else:
                 out[i].copy_(g)
         return out.view((ctx.shape[0] * ctx.shape[1],) + ctx.shape[2:]), None
+
+
+class _SplitCols(torch.autograd.Function):
+    """W [R, sum(sizes)] -> column-block views (no copy); backward concatenates the block gradients once.  (Plain slicing makes
+    autograd allocate a zero tensor of W's size, copy the block gradient in and add it, per block.)"""
+
+    @staticmethod
+    def forward(ctx, W, sizes):
+        ctx.set_materialize_grads(False)
+        ctx.sizes, ctx.rows = tuple(sizes), W.shape[0]
+        out, off = [], 0
+        for n in sizes:
+            out.append(W[:, off:off + n])
+            off += n
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None, None
+        ref = next(g for g in gs if g is not None)
+        parts = [g if g is not None else torch.zeros((ctx.rows, n), device=ref.device, dtype=ref.dtype) for g, n in zip(gs, ctx.sizes)]
+        return torch.cat(parts, 1), None
+
+
+def split_cols(W, sizes):
+    assert W.dim() == 2 and sum(sizes) == W.shape[1]
+    return _SplitCols.apply(W, tuple(int(n) for n in sizes))
 
 
 def split_groups(x, groups: int):

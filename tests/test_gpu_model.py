@@ -364,6 +364,19 @@ def test_base_dsn_step_vs_golden(golden):
             check_grad(p.grad, q.grad, name="batched " + n, l2_tol=1e-3, max_tol=1e-2)
 
 
+@pytest.mark.parametrize("fuse,decoder_name", [(1, "MLPFM"), (4, "MLPFM"), (4, "DeepLabV3")])
+def test_no_kernel_reads_an_unwritten_buffer(fuse, decoder_name):
+    """MDVIT_POISON=1 NaN-fills every buffer an op allocates; a forward + backward must stay NaN-free.  (Caught a temporary W^T
+    of a composed -- non-leaf -- weight being freed before the split-K data-gradient GEMM allocated its workspace over it:
+    wrong gradients only when the allocator happened to reuse that block.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_poison.py"), str(fuse), decoder_name],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MDVIT_POISON="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "forward NaN: False False" in r.stdout and "\n0 gradients with NaN" in r.stdout, r.stdout[-2000:]
+
+
 def test_mdvit_vs_oracle_128(gemm_precision):
     """same seeded inputs, larger image (128x128), HIP path vs the CPU oracle incl. input-side gradients of
     every parameter (full tensors, not digests)."""
