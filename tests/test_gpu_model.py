@@ -375,6 +375,11 @@ def test_no_kernel_reads_an_unwritten_buffer(fuse, decoder_name):
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, MDVIT_POISON="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "forward NaN: False False" in r.stdout and "\n0 gradients with NaN" in r.stdout, r.stdout[-2000:]
+    if fuse == 4 and decoder_name == "MLPFM":      # and the whole bench-style step: side-stream weight gradients into the buckets, fused AdamW
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "debug_poison_step.py")], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MDVIT_POISON="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "0 non-finite parameters" in r.stdout and "0 non-finite buffers" in r.stdout, r.stdout[-2000:]
 
 
 def test_mdvit_vs_oracle_128(gemm_precision):
