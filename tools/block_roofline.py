@@ -6,6 +6,7 @@ against the chip roofs.  The bound is the sum over the block's operators of max(
 bytes = the operator's compulsory fp32 inputs + outputs (the layout in HBM; nothing is counted twice inside an
 operator, nothing is assumed fused across operators beyond what the reference math allows: bias / GELU / dropout /
 DropPath / residual ride in the GEMM that produces the tensor, the Domain Adapter rides in the attention kernel).
+Next to it: SURVEY.md 8(d)'s much stricter per-block figure -- the whole block as ONE fused bf16 kernel.
 
     python tools/block_roofline.py [--batch 32] [--iters 10] [--json out.json]
 """
@@ -55,6 +56,19 @@ def block_ops(T, C, Hd, heads):
     b += [("LN1 bwd (+res grad)", 4 * T * C, 12 * T * C, None)]
     b += [("cpe bwd", 2 * T * C, 36 * T * C, None)]
     return f, b
+
+
+def survey_bound(B, N, C, r, heads, num_domains=4):
+    """SURVEY.md 8(d) "per-block figures": the WHOLE block fused, bf16 storage, QKV materialised once ("two-phase").
+    fwd: MACs = (4+2r) N C^2 + 2 N C Ch + 9 N C + 240 N Ch + (4 hid + hid C) per image, bytes = (8 N C B + params) * 2;
+    bwd ~ 2x the flops, 3x the activation bytes.  Roofs: 2.5 PFLOP/s dense bf16, 8 TB/s."""
+    Ch, hid = C // heads, max(C // 2, 4)
+    macs = (4 + 2 * r) * N * C * C + 2 * N * C * Ch + 9 * N * C + 240 * N * Ch + (num_domains * hid + hid * C)
+    params = (4 + 2 * r) * C * C + (5 + r) * C + 4 * C + num_domains * hid + hid + hid * C + C
+    act = 8.0 * N * C * B * 2.0
+    fwd = max(2.0 * macs * B / 2500e12, (act + 2.0 * params) / HBM)
+    bwd = max(4.0 * macs * B / 2500e12, (3.0 * act + 2.0 * params) / HBM)
+    return fwd, bwd
 
 
 def bound_seconds(ops_list, precision):
@@ -158,7 +172,10 @@ def main():
         bb, rows_b = bound_seconds(bo, args.precision)
         by = sum(4.0 * o[1] for o in fo + bo)
         fl = sum(o[2] for o in fo + bo)
+        sf, sb = survey_bound(B, N, C, r, heads)
         rec = {"stage": s, "C": C, "tokens_per_image": N, "rows": T, "hidden": Hd,
+               "survey_fused_bf16_bound_fwd_ms": sf * 1e3, "survey_fused_bf16_bound_bwd_ms": sb * 1e3,
+               "frac_of_survey_fused_bf16_bound": (sf + sb) / (tf + tb),
                "fwd_ms": tf * 1e3, "bwd_ms": tb * 1e3, "bound_fwd_ms": bf * 1e3, "bound_bwd_ms": bb * 1e3,
                "frac_fwd": bf / tf, "frac_bwd": bb / tb, "frac": (bf + bb) / (tf + tb),
                "algorithmic_GB": by / 1e9, "GFLOP": fl / 1e9, "achieved_TBps": by / (tf + tb) / 1e12, "achieved_TFLOPs": fl / (tf + tb) / 1e12,
@@ -168,7 +185,8 @@ def main():
             tot_fb[i] += v
         print(f"stage {s}: C={C:4d} N={N:6d} rows={T:8d}  fwd {tf * 1e3:7.3f} ms (bound {bf * 1e3:6.3f}, {100 * bf / tf:4.1f}%)  "
               f"bwd {tb * 1e3:7.3f} ms (bound {bb * 1e3:6.3f}, {100 * bb / tb:4.1f}%)  block {100 * (bf + bb) / (tf + tb):4.1f}% of roofline  "
-              f"[{by / (tf + tb) / 1e12:.2f} TB/s, {fl / (tf + tb) / 1e12:.1f} TF/s]", flush=True)
+              f"[{by / (tf + tb) / 1e12:.2f} TB/s, {fl / (tf + tb) / 1e12:.1f} TF/s]  | SURVEY 8d fused-bf16 bound fwd {sf * 1e6:.0f} + bwd {sb * 1e6:.0f} us: "
+              f"{100 * (sf + sb) / (tf + tb):.1f}%", flush=True)
         del st, blk, x, g, y
         torch.cuda.empty_cache()
     out["all_stages"] = {"fwd_ms": tot_fb[0] * 1e3, "bwd_ms": tot_fb[1] * 1e3, "bound_fwd_ms": tot_fb[2] * 1e3, "bound_bwd_ms": tot_fb[3] * 1e3,
