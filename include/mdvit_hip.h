@@ -99,6 +99,14 @@ int mdvit_transpose_many(const void* items_dev, int32_t n, int32_t blocks_per_it
 int mdvit_gemm_force_plan(int32_t cfg, int32_t splits);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 
+/* Fused MLP forward of the C = 64 stages (Mlp.forward mpvit.py:71-78 + the block's DropPath / residual, mdvit.py:357-360):
+ *   h = drop1(gelu(x W1^T + b1))  [M, hidden]  (written: the backward's operand),   y = res + rowscale * drop2(h W2^T + b2)  [M, C]
+ * in one kernel that never re-reads h; same bf16x3 arithmetic and dropout keys as the two mdvit_gemm_f32 calls it replaces (bit-identical
+ * h and y), so the backward -- fc2 data gradient with the recomputed pre-activation, wgrads -- is unchanged.  hidden % 64 == 0. */
+int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* res,
+                      const float* rowscale /* optional */, int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t hidden,
+                      float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
+
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,
  * linear_out Decoders.py:311).  bwd: dx[m,k] = dy[m] w[k]; dw[k] = sum_m dy[m] x[m,k]; db = sum dy. */
 int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y,

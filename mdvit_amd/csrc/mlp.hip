@@ -1,0 +1,189 @@
+// Fused MLP forward for the C = 64 stages (Mlp.forward mpvit.py:71-78 inside SerialBlock, mdvit.py:357-360):
+//     y = res + rowscale * drop2( gelu_drop1(x W1^T + b1) W2^T + b2 ),      h = gelu_drop1(.) also written (the backward's operand)
+// One workgroup owns 64 tokens and walks the hidden axis in chunks of 64: u-chunk = x W1c^T on the matrix cores, bias + erf-GELU +
+// dropout in registers, the h-chunk goes to HBM once (for the backward) and -- as bf16 hi/lo planes through LDS -- straight into the
+// second product y += h-chunk W2c^T.  Against the two-GEMM form this drops the re-read of h [tokens, hidden] by fc2 (42 % of the
+// forward MLP traffic at hidden = 8 C) and one launch; the pre-activation u never exists in HBM (the backward recomputes it,
+// EPI_DGELU_RC in gemm.hip).  Arithmetic is the bf16x3 GEMM's, element for element: operands split hi + lo, hi*lo + lo*hi + hi*hi
+// on v_mfma_f32_32x32x16_bf16, k ascending in slabs of 32 -- so y and h are bit-identical to the two-GEMM path.
+#include "common.h"
+
+typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 mlp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mlp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mlp_f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int LDKB = 80;           // bytes per [row][32 x bf16] LDS row (64 + 16 pad: conflict-free ds_read_b128 fragments)
+
+__device__ __forceinline__ void mlp_split(const float4 x, uint2& hi, uint2& lo) {
+    mlp_f32x2 a = {x.x, x.y}, b = {x.z, x.w};
+    const mlp_bf16x2 ha = __builtin_convertvector(a, mlp_bf16x2), hb = __builtin_convertvector(b, mlp_bf16x2);
+    const uint32_t hau = __builtin_bit_cast(uint32_t, ha), hbu = __builtin_bit_cast(uint32_t, hb);
+    mlp_f32x2 la = {x.x - __uint_as_float(hau << 16), x.y - __uint_as_float(hau & 0xffff0000u)};
+    mlp_f32x2 lb = {x.z - __uint_as_float(hbu << 16), x.w - __uint_as_float(hbu & 0xffff0000u)};
+    const mlp_bf16x2 lab = __builtin_convertvector(la, mlp_bf16x2), lbb = __builtin_convertvector(lb, mlp_bf16x2);
+    hi = make_uint2(hau, hbu);
+    lo = make_uint2(__builtin_bit_cast(uint32_t, lab), __builtin_bit_cast(uint32_t, lbb));
+}
+
+struct MlpArgs {
+    const float* x; const float* W1; const float* b1; const float* W2; const float* b2; const float* res; const float* rowscale;
+    float* h; float* y;
+    int M, Hd, rows_per_scale;
+    int drop; uint32_t k1a, k1b, k2a, k2b, thresh; float inv_keep;
+    const uint32_t* seed;
+};
+
+// LDS operand: `slabs` K-slabs of 32, each slab = hi plane [rows][LDKB] then lo plane [rows][LDKB]
+__device__ __forceinline__ char* plane(char* base, int rows, int slab, int lo_plane) { return base + ((slab * 2 + lo_plane) * rows) * LDKB; }
+
+template <int C>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs p) {
+    constexpr int BM = 64, HC = 64;                 // tokens per workgroup, hidden chunk
+    constexpr int S1 = C / 32, S2 = HC / 32;        // K slabs of the two products
+    static_assert(C == 64, "tile mapping below is written for C = 64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                                 // [S1][2][BM][LDKB]
+    char* sW1 = sX + S1 * 2 * BM * LDKB;             // [S1][2][HC][LDKB]
+    char* sH = sW1 + S1 * 2 * HC * LDKB;             // [S2][2][BM][LDKB]
+    char* sW2 = sH + S2 * 2 * BM * LDKB;             // [S2][2][C][LDKB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1, k2a = p.k2a ^ s0, k2b = p.k2b + s1;
+
+    // stage a [64 rows][64 k] fp32 tile (row-major, leading dimension ld) as bf16 hi/lo planes: 4 float4 per thread
+    float4 r1[4], r2[4];
+    auto load_tile = [&](float4 (&r)[4], const float* src, long ld, int row0, int nrows) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
+            r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + row < nrows) r[v] = *reinterpret_cast<const float4*>(src + (long)(row0 + row) * ld + c4 * 4);
+        }
+    };
+    auto store_tile = [&](const float4 (&r)[4], char* dst) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int idx = tid + 256 * v, row = idx >> 4, k = (idx & 15) * 4;
+            uint2 hi, lo;
+            mlp_split(r[v], hi, lo);
+            *reinterpret_cast<uint2*>(plane(dst, 64, k >> 5, 0) + row * LDKB + (k & 31) * 2) = hi;
+            *reinterpret_cast<uint2*>(plane(dst, 64, k >> 5, 1) + row * LDKB + (k & 31) * 2) = lo;
+        }
+    };
+    // one 64-deep product of a wave's 32x32 block: A rows = tokens (wm0 + l31), B rows = output columns (wn0 + l31)
+    auto product = [&](const char* A, const char* B, mlp_f32x16& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int koff = (2 * ks + lhi) * 16;
+                const mlp_bf16x8 ah = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(A), 64, s, 0) + (wm0 + l31) * LDKB + koff));
+                const mlp_bf16x8 al = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(A), 64, s, 1) + (wm0 + l31) * LDKB + koff));
+                const mlp_bf16x8 bh = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(B), 64, s, 0) + (wn0 + l31) * LDKB + koff));
+                const mlp_bf16x8 bl = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(B), 64, s, 1) + (wn0 + l31) * LDKB + koff));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc, 0, 0, 0);
+            }
+    };
+
+    // x tile (resident for the whole walk) and the first weight chunks
+    load_tile(r1, p.x, C, m0, p.M);
+    store_tile(r1, sX);
+    load_tile(r1, p.W1, C, 0, p.Hd);                       // W1 rows [0, 64), all C columns
+    load_tile(r2, p.W2, p.Hd, 0, C);                       // W2 rows = all C outputs, columns [0, 64)
+    mlp_f32x16 yacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yacc[r] = 0.f;
+    const int row = m0 + wm0 + l31;                        // the token row this lane's accumulator quads belong to
+
+    for (int hc0 = 0; hc0 < p.Hd; hc0 += HC) {
+        store_tile(r1, sW1);
+        store_tile(r2, sW2);
+        __syncthreads();
+        if (hc0 + HC < p.Hd) {                             // next chunk's weights in flight behind this chunk's arithmetic
+            load_tile(r1, p.W1 + (long)(hc0 + HC) * C, C, 0, p.Hd - (hc0 + HC));
+            load_tile(r2, p.W2 + (hc0 + HC), p.Hd, 0, C);
+        }
+        mlp_f32x16 uacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) uacc[r] = 0.f;
+        product(sX, sW1, uacc);
+        // bias + GELU + dropout; h to HBM (float4 per quad) and to the LDS operand planes of the second product
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wn0 + 8 * q + 4 * lhi, hd = hc0 + col;
+            const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + hd);
+            float4 hv = make_float4(gelu_f(uacc[4 * q + 0] + b4.x), gelu_f(uacc[4 * q + 1] + b4.y),
+                                    gelu_f(uacc[4 * q + 2] + b4.z), gelu_f(uacc[4 * q + 3] + b4.w));
+            if (p.drop) {
+                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
+                hv.x *= ds.x; hv.y *= ds.y; hv.z *= ds.z; hv.w *= ds.w;
+            }
+            if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = hv;
+            uint2 hi, lo;
+            mlp_split(hv, hi, lo);
+            *reinterpret_cast<uint2*>(plane(sH, 64, col >> 5, 0) + (wm0 + l31) * LDKB + (col & 31) * 2) = hi;
+            *reinterpret_cast<uint2*>(plane(sH, 64, col >> 5, 1) + (wm0 + l31) * LDKB + (col & 31) * 2) = lo;
+        }
+        __syncthreads();
+        product(sH, sW2, yacc);
+        __syncthreads();                                   // sW1 / sW2 / sH are rewritten by the next chunk
+    }
+
+    if (row < p.M) {
+        const float rsc = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wn0 + 8 * q + 4 * lhi;
+            const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + col);
+            float4 v = make_float4(yacc[4 * q + 0] + b4.x, yacc[4 * q + 1] + b4.y, yacc[4 * q + 2] + b4.z, yacc[4 * q + 3] + b4.w);
+            if (p.drop) {
+                const float4 ds = mdvit_drop_scale4(k2a, k2b, (uint32_t)((long)row * C + col), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+            const float4 r4 = *reinterpret_cast<const float4*>(p.res + (long)row * C + col);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            *reinterpret_cast<float4*>(p.y + (long)row * C + col) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* res,
+                                 const float* rowscale, int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd,
+                                 float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed,
+                                 void* stream) {
+    MDVIT_CHECK_ARG(C == 64, MDVIT_E_SHAPE, "mlp_fwd: built for C = 64 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd > 0 && Hd % 64 == 0, MDVIT_E_SHAPE, "mlp_fwd: need M > 0, hidden %% 64 == 0 (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(x && W1 && b1 && W2 && b2 && res && h && y, MDVIT_E_SHAPE, "mlp_fwd: null operand");
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(W1) && aligned16(b1) && aligned16(W2) && aligned16(b2) && aligned16(res) && aligned16(h) && aligned16(y),
+                    MDVIT_E_ALIGN, "mlp_fwd: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_fwd: dropout index space exceeds 2^32");
+    MlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.res = res; a.rowscale = rowscale; a.h = h; a.y = y;
+    a.M = M; a.Hd = Hd; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    a.drop = drop_p > 0.f; a.k1a = key1_0; a.k1b = key1_1; a.k2a = key2_0; a.k2b = key2_1;
+    a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
+    a.seed = drop_seed;
+    constexpr size_t smem = (size_t)(2 + 2 + 2 + 2) * 2 * 64 * LDKB;          // X, W1c, Hc, W2c: 80 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_fwd_kernel<64>), dim3(cdiv(M, 64)), dim3(256), smem, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}

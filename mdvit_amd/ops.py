@@ -512,6 +512,7 @@ def matmul(A, B):
 # MLP with residual:  out = res + DropPath(Dropout(fc2(Dropout(GELU(fc1(x))))))      mpvit.py:71-78
 # ------------------------------------------------------------------------------------------------
 _mlp_recompute = os.environ.get("MDVIT_MLP_RECOMPUTE", "1") != "0"
+_mlp_fused = os.environ.get("MDVIT_MLP_FUSED", "1") != "0"
 
 
 class _MlpResidual(torch.autograd.Function):
@@ -526,6 +527,16 @@ class _MlpResidual(torch.autograd.Function):
         k2 = _next_key() if drop_p > 0 else (0, 0)
         # HBM-bound MLPs (fc1's K = C <= 128): keep gelu(u) only; the backward recomputes the pre-activation u inside the fc2
         # data-gradient GEMM (one more K = C product per tile) instead of moving [tokens, hidden] u through HBM twice
+        if _mlp_recompute and _mlp_fused and _gemm_precision == 1 and Cin == 64 and Hd % 64 == 0 and b1 is not None and b2 is not None \
+                and res is not None and W1.is_contiguous() and W2.is_contiguous() and M * Hd < (1 << 32):
+            # C = 64: both GEMMs in ONE kernel -- h goes to HBM once (for the backward) and, through LDS, straight into fc2
+            out = _empty((M, Cin), device=x.device, dtype=torch.float32)
+            call("mdvit_mlp_fwd_f32", _p(x), _p(W1), _p(b1), _p(W2), _p(b2), _p(res), _p(rowscale), rows_per_scale, _p(h), _p(out), M, Cin, Hd,
+                 drop_p, k1[0], k1[1], k2[0], k2[1], _seed_ptr() if drop_p > 0 else None, _stream())
+            ctx.save_for_backward(x, None, h, W1, W2, rowscale)
+            ctx.meta = (drop_p, k1, k2, rows_per_scale)
+            ctx.b1_ref, ctx.b2_ref = b1, b2
+            return out
         if _mlp_recompute and _gemm_precision == 1 and Cin <= 128 and Cin % 32 == 0 and Hd % 4 == 0:
             u = None
             gemm(_p(x), _p(W1), _p(h), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
