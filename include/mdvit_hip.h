@@ -107,6 +107,14 @@ int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b1, const fl
                       const float* rowscale /* optional */, int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t hidden,
                       float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
 
+/* ... and its backward data path:  dx = ((gm W2) * gelu'(x W1^T + b1) * dropmask1) W1  in one kernel (gm = the masked upstream
+ * gradient from mdvit_colsum_f32; W2t / W1t = the cached transposes, [hidden, C] and [C, hidden]).  du (optional, [M, hidden]):
+ * the hidden-layer gradient for the weight-gradient GEMMs; with du == NULL (the data-gradient-only sweep) no [M, hidden] tensor
+ * touches HBM at all.  Same products, slab order and dropout key as mdvit_gemm_f32(DGELU + rc_*) followed by the fc1 data-gradient GEMM. */
+int mdvit_mlp_bwd_dgrad_f32(const float* gm, const float* x, const float* W1, const float* b1, const float* W2t, const float* W1t,
+                            float* du /* optional */, float* dx, int32_t M, int32_t C, int32_t hidden, float drop_p,
+                            uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
+
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,
  * linear_out Decoders.py:311).  bwd: dx[m,k] = dy[m] w[k]; dw[k] = sum_m dy[m] x[m,k]; db = sum dy. */
 int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y,

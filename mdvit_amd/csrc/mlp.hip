@@ -157,6 +157,148 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs p) {
     }
 }
 
+// ---- backward data path of the same MLP:  dx = ((gm W2) * gelu'(u) * dropmask1) W1,  u = x W1^T + b1 recomputed per chunk ----
+// gm = the masked upstream gradient (mdvit_colsum_f32).  A workgroup owns 64 tokens; the MFMA A-fragments of its x and gm tiles live
+// in registers for the whole walk (they are the A operands of two K = C products per hidden chunk); per chunk: u = x W1c^T and
+// d = gm W2c on the matrix cores, d *= gelu'(u + b1) * mask in registers, d to HBM only if the caller wants it (the weight
+// gradients of the full sweep do; the data-gradient-only sweep does not -- then [tokens, hidden] never touches HBM), d through LDS
+// into dx += d W1c.  Same products, slab order and keys as the recomputing GEMM + fc1 data-gradient GEMM it replaces.
+struct MlpBwdArgs {
+    const float* gm; const float* x; const float* W1; const float* b1; const float* W2t; const float* W1t;
+    float* du; float* dx;
+    int M, Hd;
+    int drop; uint32_t k1a, k1b, thresh; float inv_keep;
+    const uint32_t* seed;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void mlp_bwd_dgrad_kernel(MlpBwdArgs p) {
+    constexpr int BM = 64, HC = 64;
+    static_assert(C == 64, "tile mapping below is written for C = 64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 2 * 2 * 64 * LDKB;          // one [64 rows][64 k] operand: 2 slabs x (hi, lo) planes
+    char* sW1 = smem;                                // W1 rows [hc0, hc0+64) x k = c            (B of u = x W1c^T)
+    char* sW2t = sW1 + TILE;                         // W2^T rows [hc0, hc0+64) x k = c          (B of d = gm W2c)
+    char* sW1t = sW2t + TILE;                        // W1^T rows c x k = [hc0, hc0+64)          (B of dx += d W1c)
+    char* sD = sW1t + TILE;                          // d chunk: rows = tokens x k = hidden chunk (A of the third product)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1;
+
+    float4 r1[4], r2[4], r3[4];
+    auto load_tile = [&](float4 (&r)[4], const float* src, long ld, int row0, int nrows) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
+            r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + row < nrows) r[v] = *reinterpret_cast<const float4*>(src + (long)(row0 + row) * ld + c4 * 4);
+        }
+    };
+    auto store_tile = [&](const float4 (&r)[4], char* dst) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int idx = tid + 256 * v, row = idx >> 4, k = (idx & 15) * 4;
+            uint2 hi, lo;
+            mlp_split(r[v], hi, lo);
+            *reinterpret_cast<uint2*>(plane(dst, 64, k >> 5, 0) + row * LDKB + (k & 31) * 2) = hi;
+            *reinterpret_cast<uint2*>(plane(dst, 64, k >> 5, 1) + row * LDKB + (k & 31) * 2) = lo;
+        }
+    };
+    auto frag = [&](char* base, int s, int lo_plane, int rowi, int ks) {
+        return __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(base, 64, s, lo_plane) + rowi * LDKB + (2 * ks + lhi) * 16));
+    };
+
+    // x and gm tiles -> LDS (through the W1 / W2t regions) -> this wave's A-fragments, kept in registers
+    load_tile(r1, p.x, C, m0, p.M);
+    load_tile(r2, p.gm, C, m0, p.M);
+    store_tile(r1, sW1);
+    store_tile(r2, sW2t);
+    __syncthreads();
+    mlp_bf16x8 xh[4], xl[4], gh[4], gl[4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            xh[2 * s + ks] = frag(sW1, s, 0, wm0 + l31, ks); xl[2 * s + ks] = frag(sW1, s, 1, wm0 + l31, ks);
+            gh[2 * s + ks] = frag(sW2t, s, 0, wm0 + l31, ks); gl[2 * s + ks] = frag(sW2t, s, 1, wm0 + l31, ks);
+        }
+    __syncthreads();
+    load_tile(r1, p.W1, C, 0, p.Hd);
+    load_tile(r2, p.W2t, C, 0, p.Hd);
+    load_tile(r3, p.W1t, p.Hd, 0, C);
+    mlp_f32x16 dxacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dxacc[r] = 0.f;
+    const int row = m0 + wm0 + l31;
+
+    for (int hc0 = 0; hc0 < p.Hd; hc0 += HC) {
+        store_tile(r1, sW1);
+        store_tile(r2, sW2t);
+        store_tile(r3, sW1t);
+        __syncthreads();
+        if (hc0 + HC < p.Hd) {
+            load_tile(r1, p.W1 + (long)(hc0 + HC) * C, C, 0, p.Hd - (hc0 + HC));
+            load_tile(r2, p.W2t + (long)(hc0 + HC) * C, C, 0, p.Hd - (hc0 + HC));
+            load_tile(r3, p.W1t + (hc0 + HC), p.Hd, 0, C);
+        }
+        mlp_f32x16 uacc, dacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { uacc[r] = 0.f; dacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const mlp_bf16x8 bh = frag(sW1, s, 0, wn0 + l31, ks), bl = frag(sW1, s, 1, wn0 + l31, ks);
+                uacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, xh[2 * s + ks], uacc, 0, 0, 0);
+                uacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xl[2 * s + ks], uacc, 0, 0, 0);
+                uacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xh[2 * s + ks], uacc, 0, 0, 0);
+                const mlp_bf16x8 ch = frag(sW2t, s, 0, wn0 + l31, ks), cl = frag(sW2t, s, 1, wn0 + l31, ks);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl, gh[2 * s + ks], dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, gl[2 * s + ks], dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, gh[2 * s + ks], dacc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wn0 + 8 * q + 4 * lhi, hd = hc0 + col;
+            const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + hd);
+            float4 dv = make_float4(dacc[4 * q + 0] * gelu_grad_f(uacc[4 * q + 0] + b4.x), dacc[4 * q + 1] * gelu_grad_f(uacc[4 * q + 1] + b4.y),
+                                    dacc[4 * q + 2] * gelu_grad_f(uacc[4 * q + 2] + b4.z), dacc[4 * q + 3] * gelu_grad_f(uacc[4 * q + 3] + b4.w));
+            if (p.drop) {
+                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
+                dv.x *= ds.x; dv.y *= ds.y; dv.z *= ds.z; dv.w *= ds.w;
+            }
+            if (p.du && row < p.M) *reinterpret_cast<float4*>(p.du + (long)row * p.Hd + hd) = dv;
+            uint2 hi, lo;
+            mlp_split(dv, hi, lo);
+            *reinterpret_cast<uint2*>(plane(sD, 64, col >> 5, 0) + (wm0 + l31) * LDKB + (col & 31) * 2) = hi;
+            *reinterpret_cast<uint2*>(plane(sD, 64, col >> 5, 1) + (wm0 + l31) * LDKB + (col & 31) * 2) = lo;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const mlp_bf16x8 ah = frag(sD, s, 0, wm0 + l31, ks), al = frag(sD, s, 1, wm0 + l31, ks);
+                const mlp_bf16x8 bh = frag(sW1t, s, 0, wn0 + l31, ks), bl = frag(sW1t, s, 1, wn0 + l31, ks);
+                dxacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, dxacc, 0, 0, 0);
+                dxacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, dxacc, 0, 0, 0);
+                dxacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, dxacc, 0, 0, 0);
+            }
+        __syncthreads();
+    }
+    if (row < p.M) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wn0 + 8 * q + 4 * lhi;
+            *reinterpret_cast<float4*>(p.dx + (long)row * C + col) = make_float4(dxacc[4 * q + 0], dxacc[4 * q + 1], dxacc[4 * q + 2], dxacc[4 * q + 3]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* res,
@@ -184,6 +326,33 @@ extern "C" int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b
         attr_set = true;
     }
     hipLaunchKernelGGL((mlp_fwd_kernel<64>), dim3(cdiv(M, 64)), dim3(256), smem, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_mlp_bwd_dgrad_f32(const float* gm, const float* x, const float* W1, const float* b1, const float* W2t, const float* W1t,
+                                       float* du, float* dx, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                                       const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(C == 64, MDVIT_E_SHAPE, "mlp_bwd_dgrad: built for C = 64 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd > 0 && Hd % 64 == 0, MDVIT_E_SHAPE, "mlp_bwd_dgrad: need M > 0, hidden %% 64 == 0 (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(gm && x && W1 && b1 && W2t && W1t && dx, MDVIT_E_SHAPE, "mlp_bwd_dgrad: null operand");
+    MDVIT_CHECK_ARG(aligned16(gm) && aligned16(x) && aligned16(W1) && aligned16(b1) && aligned16(W2t) && aligned16(W1t) && aligned16(dx) &&
+                    (!du || aligned16(du)), MDVIT_E_ALIGN, "mlp_bwd_dgrad: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_bwd_dgrad: dropout index space exceeds 2^32");
+    MlpBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gm = gm; a.x = x; a.W1 = W1; a.b1 = b1; a.W2t = W2t; a.W1t = W1t; a.du = du; a.dx = dx; a.M = M; a.Hd = Hd;
+    a.drop = drop_p > 0.f; a.k1a = key1_0; a.k1b = key1_1;
+    a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
+    a.seed = drop_seed;
+    constexpr size_t smem = (size_t)4 * 2 * 2 * 64 * LDKB;                    // W1c, W2tc, W1tc, d chunk: 80 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_dgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_bwd_dgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mlp_bwd_dgrad_kernel<64>), dim3(cdiv(M, 64)), dim3(256), smem, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

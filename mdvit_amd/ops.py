@@ -575,13 +575,21 @@ class _MlpResidual(torch.autograd.Function):
             call("mdvit_colsum_f32", _p(g), Cin, None if _dgrad_only else _p(sinks[3] if sunk else db2), _p(gm) if masked else None, wsp, wsb, M, Cin,
                  drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         # du = (gm W2) * gelu'(u) * mask1
-        du = _empty_like(h)
-        if u is None:
-            _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, rc=(_p(x), Cin, _p(W1), Cin, _p(ctx.b1_ref), Cin), e_drop=drop_p, e_key=k1)
-        else:
-            _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)
         dx = _empty_like(x)
-        _dgrad(du, W1, dx, M, Cin, Hd, Cin, allow_split=True)
+        if u is None and _mlp_fused and _gemm_precision == 1 and Cin == 64 and Hd % 64 == 0 and W1.is_contiguous() and W2.is_contiguous():
+            # C = 64: the whole data path in one kernel; the hidden-layer gradient is materialised only for the weight gradients
+            du = None if _dgrad_only else _empty_like(h)
+            W2t, W1t = wt(W2), wt(W1)
+            call("mdvit_mlp_bwd_dgrad_f32", _p(gm), _p(x), _p(W1), _p(ctx.b1_ref), _p(W2t), _p(W1t), _p(du), _p(dx), M, Cin, Hd,
+                 drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, _stream())
+            del W2t, W1t
+        else:
+            du = _empty_like(h)
+            if u is None:
+                _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, rc=(_p(x), Cin, _p(W1), Cin, _p(ctx.b1_ref), Cin), e_drop=drop_p, e_key=k1)
+            else:
+                _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)
+            _dgrad(du, W1, dx, M, Cin, Hd, Cin, allow_split=True)
         if not _dgrad_only:
             if sunk:
                 dW1_, db1_, dW2_, _ = sinks

@@ -200,7 +200,9 @@ def test_mlp_residual(M, C, r, gemm_precision):
 @pytest.mark.parametrize("M,C,r,drop", [(512, 64, 8, 0.0), (1030, 64, 8, 0.25), (130, 128, 8, 0.1), (70, 32, 4, 0.0)])
 def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatch):
     """C <= 128 (bf16x3): the forward keeps gelu(u) only and the fc2 data-gradient GEMM recomputes u = x W1^T + b1 per output
-    tile -- same slab / MFMA sequence as the forward, so every output and gradient equals the stored-u path bit for bit"""
+    tile -- same slab / MFMA sequence as the forward, so every output and gradient equals the stored-u path bit for bit.
+    C = 64 additionally runs the fused forward (mdvit_mlp_fwd_f32) and the fused backward data path (mdvit_mlp_bwd_dgrad_f32)
+    against the separate GEMMs."""
     from mdvit_amd import ops
     if ops.gemm_precision() != "bf16x3":
         pytest.skip("the recomputing epilogue is the bf16x3 path's")
@@ -218,6 +220,9 @@ def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatc
         res.append([out.detach()] + go)
     for name, a, b in zip(("y", "dx", "dres", "dW1", "db1", "dW2", "db2"), res[0], res[1]):
         if name == "db1":       # column sums riding on the wgrad: one float atomicAdd per tile and K-split, order not fixed
+            check(a, b, tol=1e-5, name=name)
+            continue
+        if name == "dx" and C == 64:      # the fused backward sums the hidden axis in order; the GEMM form may split K at this small M
             check(a, b, tol=1e-5, name=name)
             continue
         assert torch.equal(a, b), f"{name}: recomputed-u path differs from the stored-u path (max {float((a - b).abs().max()):.3e})"
