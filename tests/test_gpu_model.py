@@ -382,6 +382,15 @@ def test_no_kernel_reads_an_unwritten_buffer(fuse, decoder_name):
         assert "0 non-finite parameters" in r.stdout and "0 non-finite buffers" in r.stdout, r.stdout[-2000:]
 
 
+def test_forty_steps_on_one_batch_drive_the_losses_down():
+    """end to end: domain-batched forward, merged sweeps, side-stream weight gradients into the buckets, one-launch AdamW"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "overfit_check.py"), "64", "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and "ok: loss" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
 def test_mdvit_vs_oracle_128(gemm_precision):
     """same seeded inputs, larger image (128x128), HIP path vs the CPU oracle incl. input-side gradients of
     every parameter (full tensors, not digests)."""
