@@ -197,7 +197,8 @@ def test_mlp_residual(M, C, r, gemm_precision):
         check(a, r_, tol=tol, name=n)
 
 
-@pytest.mark.parametrize("M,C,r,drop", [(512, 64, 8, 0.0), (1030, 64, 8, 0.25), (130, 128, 8, 0.1), (70, 32, 4, 0.0)])
+@pytest.mark.parametrize("M,C,r,drop", [(512, 64, 8, 0.0), (1030, 64, 8, 0.25), (130, 128, 8, 0.1), (70, 32, 4, 0.0), (37, 64, 8, 0.1), (200, 64, 16, 0.0),
+                                        (8192, 64, 8, 0.1)])
 def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatch):
     """C <= 128 (bf16x3): the forward keeps gelu(u) only and the fc2 data-gradient GEMM recomputes u = x W1^T + b1 per output
     tile -- same slab / MFMA sequence as the forward, so every output and gradient equals the stored-u path bit for bit.
