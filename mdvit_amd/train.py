@@ -10,6 +10,8 @@ order exactly.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -49,18 +51,31 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
     if fuse_domains > 1:
         batches = _fuse_batches(batches, fuse_domains, num_domains, use_domain_label)
 
-    def sweep(loss, last, retain=False):
+    def sweep(loss, last, retain=False, join=True):
         if accumulator is not None:
             accumulator.begin_sweep(last)
         elif last and reducer is not None:
             reducer.arm()
         loss.backward(retain_graph=retain)
-        ops.join_side_stream()          # weight gradients may have been produced on the side stream
+        if join:
+            ops.join_side_stream()      # weight gradients may have been produced on the side stream
         if accumulator is not None:
             accumulator.end_sweep(last)
 
     def two_sweeps(aux_sum, uni, last):
         if merged_sweeps:
+            if accumulator is not None and os.environ.get("MDVIT_SWEEP_ORDER", "full_first") == "full_first":
+                # the ordinary backward of aux + uni FIRST, and no join after it: its weight-gradient kernels (side stream, straight
+                # into the bucket sinks) then drain underneath the whole data-gradient-only sweep instead of piling up behind the
+                # last kernels of the step.  (The two sweeps commute; what this sweep hands autograd is folded into the buckets
+                # on the main stream and touches other bucket elements than the sinks.)
+                sweep(aux_sum + uni, False, retain=True, join=False)
+                ops.set_dgrad_only(True)
+                try:
+                    sweep(aux_sum, last)
+                finally:
+                    ops.set_dgrad_only(False)
+                return
             ops.set_dgrad_only(True)
             try:
                 sweep(aux_sum, False, retain=True)
