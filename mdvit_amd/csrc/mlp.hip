@@ -40,7 +40,7 @@ struct MlpArgs {
 __device__ __forceinline__ char* plane(char* base, int rows, int slab, int lo_plane) { return base + ((slab * 2 + lo_plane) * rows) * LDKB; }
 
 template <int C>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_fwd_kernel(MlpArgs p) {
     constexpr int BM = 64, HC = 64;                 // tokens per workgroup, hidden chunk
     constexpr int S1 = C / 32, S2 = HC / 32;        // K slabs of the two products
     static_assert(C == 64, "tile mapping below is written for C = 64");
@@ -172,7 +172,7 @@ struct MlpBwdArgs {
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void mlp_bwd_dgrad_kernel(MlpBwdArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_bwd_dgrad_kernel(MlpBwdArgs p) {
     constexpr int BM = 64, HC = 64;
     static_assert(C == 64, "tile mapping below is written for C = 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
