@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restric
 typedef float fa_f32x16 __attribute__((ext_vector_type(16)));
 
 template <int CH>
-__global__ __launch_bounds__(256) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 2 : 1, CH <= 16 ? 2 : 1))) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
                                                            const float* __restrict__ U, const float* __restrict__ dVc,
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
