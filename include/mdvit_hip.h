@@ -99,6 +99,52 @@ int mdvit_transpose_many(const void* items_dev, int32_t n, int32_t blocks_per_it
 int mdvit_gemm_force_plan(int32_t cfg, int32_t splits);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 
+/* ---- "plane" GEMM family: operands pre-split into bf16 planes ------------------------------------------------
+ * A plane tensor is [planes][rows][ld] bf16 (uint16 storage): plane 0 = hi = RNE bf16(x), plane 1 = lo = RNE bf16(x - hi),
+ * `*_plane` = distance between the planes in elements.  planes = 2 runs the bf16x3 arithmetic of mdvit_gemm_f32 (bit-identical
+ * results: same products, same order), planes = 1 is the bf16 speed mode (hi only, one MFMA per product).  No conversion
+ * work is left in the main loop: slabs go HBM/L2 -> LDS by global_load_lds.  Weights are split once per optimizer step
+ * (mdvit_split_planes_many: W for the forward, W^T for the data gradients), activations by their producers.
+ *   NT : C[M,N] = A[M,K] B[N,K]^T  (a_f32 = 1: A is fp32 [M,K], lda in floats, split while staged)
+ * The result of every epilogue can be written as fp32 (C) and / or as planes (Cp) -- the operand format of the next GEMM.
+ *   NONE      : acc + bias, then optional dropout, DropPath row scale, + residual; accumulate / allow_split as mdvit_gemm_f32
+ *   GELU_DUAL : U = acc + bias (optional fp32 pre-activation), result = dropout(gelu(U))
+ *   DGELU     : result = acc * gelu'(u) * dropmask, u = gelu_u (fp32) or recomputed from rc_a / rc_b planes (+ rc_bias)
+ * K % 32 == 0, N % 4 == 0 (other shapes: mdvit_gemm_f32).
+ * Replaces the call sites of mdvit_gemm_f32: mdvit.py:288,310-311; mpvit.py:71-78; Decoders.py:185,196,300-331. */
+typedef struct MdvitPlaneGemmDesc {
+    const void* A; int64_t lda; int64_t a_plane; int32_t a_f32;
+    const void* B; int64_t ldb; int64_t b_plane;
+    int32_t planes;                   /* 2: bf16x3, 1: bf16 */
+    int32_t trans;                    /* 0: NT.  (1: TN, the weight gradient: mdvit_gemm_planes_tn) */
+    int32_t M, N, K;
+    float* C; int64_t ldc;            /* fp32 result, optional */
+    void* Cp; int64_t ldcp; int64_t c_plane;   /* plane result, optional */
+    float* U; int64_t ldu_out;        /* GELU_DUAL: fp32 pre-activation, optional */
+    const float* bias;
+    int32_t epi;                      /* MDVIT_EPI_* */
+    float e_drop_p; uint32_t e_key0, e_key1;
+    const float* e_rowscale; int32_t e_rows_per_scale;
+    const float* residual; int64_t ldr;
+    const float* gelu_u; int64_t ldu;
+    const void* rc_a; int64_t rc_lda; int64_t rc_a_plane; const void* rc_b; int64_t rc_ldb; int64_t rc_b_plane; const float* rc_bias; int32_t rc_k;
+    int32_t allow_split; void* ws; uint64_t ws_bytes;
+    int32_t accumulate;
+    const uint32_t* drop_seed;
+} MdvitPlaneGemmDesc;
+size_t mdvit_gemm_planes_ws_bytes(const MdvitPlaneGemmDesc* desc);
+int mdvit_gemm_planes_plan(const MdvitPlaneGemmDesc* desc, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
+int mdvit_gemm_planes_force_plan(int32_t cfg, int32_t splits);      /* tuning hook: cfg 0: 128x128, 1: 128x64, 2: 64x64; -1 / 0: planner */
+int mdvit_gemm_planes(const MdvitPlaneGemmDesc* desc, void* stream);
+/* fp32 [rows, cols] (ld_in) -> planes [planes][rows][ld_out]; cols % 8 == 0 */
+int mdvit_split_planes(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t plane_stride, int64_t rows, int32_t cols, int32_t planes, void* stream);
+/* one tensor, any shape, optionally transposed (out = planes of in^T, [cols][rows]): non-leaf / sliced weights */
+int mdvit_split_planes_t(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t plane_stride, int32_t rows, int32_t cols, int32_t transpose,
+                         int32_t planes, void* stream);
+/* n weight splits in one launch.  items_dev: device array [n][8] of int64 {src fp32, dst planes, ld_src, rows, cols, transpose (0/1),
+ * ld_dst, plane_stride}; transpose = 1 writes the planes of the transposed matrix ([cols][rows]: the data gradients' W^T). */
+int mdvit_split_planes_many(const void* items_dev, int32_t n, int32_t blocks_per_item, int32_t planes, void* stream);
+
 /* Fused MLP forward of the C = 64 stages (Mlp.forward mpvit.py:71-78 + the block's DropPath / residual, mdvit.py:357-360):
  *   h = drop1(gelu(x W1^T + b1))  [M, hidden]  (written: the backward's operand),   y = res + rowscale * drop2(h W2^T + b2)  [M, C]
  * in one kernel that never re-reads h; same bf16x3 arithmetic and dropout keys as the two mdvit_gemm_f32 calls it replaces (bit-identical

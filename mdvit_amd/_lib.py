@@ -46,7 +46,35 @@ class GemmDesc(C.Structure):
     ]
 
 
+class PlaneGemmDesc(C.Structure):
+    _fields_ = [
+        ("A", vp), ("lda", i64), ("a_plane", i64), ("a_f32", i32),
+        ("B", vp), ("ldb", i64), ("b_plane", i64),
+        ("planes", i32), ("trans", i32),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("C", vp), ("ldc", i64),
+        ("Cp", vp), ("ldcp", i64), ("c_plane", i64),
+        ("U", vp), ("ldu_out", i64),
+        ("bias", vp),
+        ("epi", i32),
+        ("e_drop_p", f32), ("e_key0", u32), ("e_key1", u32),
+        ("e_rowscale", vp), ("e_rows_per_scale", i32),
+        ("residual", vp), ("ldr", i64),
+        ("gelu_u", vp), ("ldu", i64),
+        ("rc_a", vp), ("rc_lda", i64), ("rc_a_plane", i64), ("rc_b", vp), ("rc_ldb", i64), ("rc_b_plane", i64), ("rc_bias", vp), ("rc_k", i32),
+        ("allow_split", i32), ("ws", vp), ("ws_bytes", C.c_uint64),
+        ("accumulate", i32),
+        ("drop_seed", vp),
+    ]
+
+
 _SIGS = {
+    "mdvit_gemm_planes": [C.POINTER(PlaneGemmDesc), vp],
+    "mdvit_gemm_planes_plan": [C.POINTER(PlaneGemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+    "mdvit_gemm_planes_force_plan": [i32, i32],
+    "mdvit_split_planes": [vp, i64, vp, i64, i64, i64, i32, i32, vp],
+    "mdvit_split_planes_many": [vp, i32, i32, i32, vp],
+    "mdvit_split_planes_t": [vp, i64, vp, i64, i64, i32, i32, i32, i32, vp],
     "mdvit_gemm_f32": [C.POINTER(GemmDesc), vp],
     "mdvit_gemm_plan": [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_force_plan": [i32, i32],
@@ -121,6 +149,8 @@ def load():
     lib.mdvit_factoratt_ws_bytes.argtypes = [i32, i32, i32, i32]
     lib.mdvit_gemm_ws_bytes.restype = C.c_size_t
     lib.mdvit_gemm_ws_bytes.argtypes = [C.POINTER(GemmDesc)]
+    lib.mdvit_gemm_planes_ws_bytes.restype = C.c_size_t
+    lib.mdvit_gemm_planes_ws_bytes.argtypes = [C.POINTER(PlaneGemmDesc)]
     lib.mdvit_bn_ws_bytes.restype = C.c_size_t
     lib.mdvit_bn_ws_bytes.argtypes = [i32, i32, i32]
     lib.mdvit_upsample_bwd_ws_bytes.restype = C.c_size_t

@@ -82,6 +82,32 @@ __device__ __forceinline__ float4 mdvit_drop_scale4(uint32_t k0, uint32_t k1, ui
                        __builtin_rotateright32(h, 24) >= thresh ? inv_keep : 0.0f);
 }
 
+// ---- bf16 "planes": x = hi + lo with hi = RNE bf16(x), lo = RNE bf16(x - hi)  (|x - hi - lo| <= 2^-18 |x|) -------------------
+typedef __bf16 mdvit_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mdvit_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mdvit_split_bf16x3(const float4 x, uint2& hi, uint2& lo) {
+    mdvit_f32x2 a = {x.x, x.y}, b = {x.z, x.w};
+    const mdvit_bf16x2 ha = __builtin_convertvector(a, mdvit_bf16x2), hb = __builtin_convertvector(b, mdvit_bf16x2);
+    const uint32_t hau = __builtin_bit_cast(uint32_t, ha), hbu = __builtin_bit_cast(uint32_t, hb);
+    mdvit_f32x2 la = {x.x - __uint_as_float(hau << 16), x.y - __uint_as_float(hau & 0xffff0000u)};
+    mdvit_f32x2 lb = {x.z - __uint_as_float(hbu << 16), x.w - __uint_as_float(hbu & 0xffff0000u)};
+    const mdvit_bf16x2 lab = __builtin_convertvector(la, mdvit_bf16x2), lbb = __builtin_convertvector(lb, mdvit_bf16x2);
+    hi = make_uint2(hau, hbu);
+    lo = make_uint2(__builtin_bit_cast(uint32_t, lab), __builtin_bit_cast(uint32_t, lbb));
+}
+__device__ __forceinline__ void mdvit_split1_bf16x3(float x, uint16_t& hi, uint16_t& lo) {
+    mdvit_f32x2 a = {x, 0.f};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, mdvit_bf16x2));
+    mdvit_f32x2 l = {x - __uint_as_float(h << 16), 0.f};
+    hi = (uint16_t)(h & 0xffffu);
+    lo = (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(l, mdvit_bf16x2)) & 0xffffu);
+}
+// 4 consecutive elements of a plane pair -> fp32 (hi + lo; lo == nullptr: the bf16 speed mode keeps hi only)
+__device__ __forceinline__ float4 mdvit_join_planes4(const uint2 hi, const uint2 lo) {
+    return make_float4(__uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16), __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u),
+                       __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16), __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u));
+}
+
 // ---- wave / block reductions -----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -640,7 +640,7 @@ int g_force_cfg = -1, g_force_splits = 0;      // tuning hook (mdvit_gemm_force_
 GemmPlan plan_gemm(const MdvitGemmDesc* d) {
     static const int BMs[3] = {128, 256, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 2, 4};
     static const double EFF[3] = {0.8, 0.8, 1.0};       // measured (tools/gemm_sweep.py): the 64x64 tile at 4 workgroups / CU wins almost everywhere
-    static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+    static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024};
     const bool plain = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual;
     const bool can_split = d->allow_split && plain && d->K >= 512 && (d->N % 4 == 0);
     GemmPlan best; best.cfg = 0; best.tiles_m = cdiv(d->M, 128); best.tiles_n = cdiv(d->N, 128); best.splits = 1;
@@ -681,6 +681,21 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
 }
 
 }  // namespace
+
+// the slab reduction as a library-internal entry (gemm_bp.hip's split-K launches share it)
+int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, hipStream_t s) {
+    const long total = (long)M * N / 4;
+#define MDVIT_REDUCE_LAUNCH(R_) \
+    hipLaunchKernelGGL((gemm_splitk_reduce_kernel<R_>), dim3((int)min((total * R_ + 255) / 256, 4096L)), dim3(256), 0, s, \
+                       slab, bias, C, ldc, M, N, splits, accumulate)
+    if (total >= 65536 || splits < 4) MDVIT_REDUCE_LAUNCH(1);
+    else if (total >= 16384 || splits < 16) MDVIT_REDUCE_LAUNCH(4);
+    else if (total >= 4096 || splits < 64) MDVIT_REDUCE_LAUNCH(16);
+    else MDVIT_REDUCE_LAUNCH(64);
+#undef MDVIT_REDUCE_LAUNCH
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
 
 extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -204,7 +204,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
          residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None, rc=None):
     """rc = (a, lda, b, ldb, bias, k): DGELU with the pre-activation recomputed in the kernel (include/mdvit_hip.h)."""
     if precision is None:
-        precision = _gemm_precision if (bool(trans_b) != bool(trans_a)) else 0      # built for NT and TN
+        precision = min(_gemm_precision, 1) if (bool(trans_b) != bool(trans_a)) else 0      # built for NT and TN
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = A, B, out, out2
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
@@ -229,9 +229,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
         if need:
             ws = _empty((need // 4,), device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
             d.ws, d.ws_bytes = _p(ws), need
-    if _events is None or (_side_stream is not None and torch.cuda.current_stream() == _side_stream):
-        # (side-stream launches are not event-timed: they queue behind, and share the chip with, the main stream's kernels,
-        #  so an event pair around them measures the wait as well; rocprofv3 has their true durations)
+    if _events is None:
         call("mdvit_gemm_f32", C.byref(d), _stream())
         return
     kepi = 1 if epi == _lib.EPI_GELU_DUAL else (4 if rc is not None else 2) if epi == _lib.EPI_DGELU else \
@@ -267,8 +265,11 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
 # 0 "fp32": fp32-input MFMA, bit-for-bit an fmaf chain.  1 "bf16x3": operands split hi+lo into bf16 while staged,
 # hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate (~1e-5 relative).  The bf16x3 kernel wants both
 # operands k-contiguous, so the data-gradient GEMMs read a transposed copy of the weight (wt()).
-_PRECISIONS = {"fp32": 0, "bf16x3": 1}
+#   "bf16" : the speed mode -- operands rounded to ONE bf16 plane, one MFMA per product, fp32 accumulate (~3e-3 relative per GEMM);
+#            never the parity mode.  (Layouts the plane kernels do not cover fall back to the bf16x3 kernels.)
+_PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 _gemm_precision = _PRECISIONS[os.environ.get("MDVIT_GEMM_PRECISION", "bf16x3")]
+_use_plane_gemm = os.environ.get("MDVIT_PLANE_GEMM", "1") != "0"      # 0: the split-while-staging kernels of gemm.hip everywhere
 
 
 def set_gemm_precision(name: str):
@@ -277,7 +278,11 @@ def set_gemm_precision(name: str):
 
 
 def gemm_precision() -> str:
-    return "bf16x3" if _gemm_precision else "fp32"
+    return {0: "fp32", 1: "bf16x3", 2: "bf16"}[_gemm_precision]
+
+
+def _nplanes() -> int:
+    return 1 if _gemm_precision == 2 else 2
 
 
 _wt_cache = {}       # id(leaf weight) -> (weakref to it, version, data_ptr, rows, cols, ld, W^T); the weakref guards against id reuse
@@ -289,7 +294,7 @@ def wt(W):
     at once by refresh_transposes() at the start of a step."""
     N, K, ld = _ld_view(W)
     leaf = W.grad_fn is None and W.requires_grad
-    tag = (W._version, W.data_ptr(), N, K, ld)
+    tag = (W._version + (_weights_epoch << 32), W.data_ptr(), N, K, ld)      # the epoch moves when an optimizer writes through raw pointers
     out = None
     if leaf:
         hit = _wt_cache.get(id(W))
@@ -319,7 +324,7 @@ def refresh_transposes():
         W = hit[0]()
         if W is not None and hit[2:6] == (W.data_ptr(),) + tuple(hit[3:6]) and W.data_ptr() == hit[2]:
             entries.append((key, W, hit))
-    if len(entries) < 2:
+    if not entries:
         return
     sig = tuple((h[2], h[6].data_ptr(), h[5], h[3], h[4]) for _, _, h in entries)       # (in, out, ld, rows, cols)
     if _wt_table is None or _wt_table[0] != sig:
@@ -331,11 +336,194 @@ def refresh_transposes():
         _wt_table = (sig, torch.tensor(rows, dtype=torch.int64, device=dev), int(min(tiles, 64)))
     call("mdvit_transpose_many", _p(_wt_table[1]), len(entries), _wt_table[2], _stream())
     for key, W, hit in entries:
-        _wt_cache[key] = (hit[0], W._version) + tuple(hit[2:])
+        _wt_cache[key] = (hit[0], W._version + (_weights_epoch << 32)) + tuple(hit[2:])
+    refresh_weight_planes()
+
+
+# ---- weight planes: every GEMM weight pre-split into bf16 planes ONCE per optimizer step -------------------------------------
+# The plane GEMMs (csrc/gemm_bp.hip) take their B operand as bf16 planes: W [N,K] for the forward layers, W^T [K,N] for the data
+# gradients.  Leaf parameters are cached (both orientations, refreshed together by one launch at the start of a step); weights
+# that are computed on the tape (composed / sliced) are split per call.  Staleness: the tag holds the parameter's version counter
+# AND a global epoch that optimizers writing through raw pointers (optim.FusedAdamW) bump after every update.
+_weights_epoch = 0
+_wp_cache = {}       # id(leaf weight) -> {"ref": weakref, "planes": {transposed: tensor}, "tags": {transposed: tag}}
+_wp_table = None
+
+
+def mark_weights_updated():
+    """Call after parameters were modified in a way autograd's version counters do not see (a kernel writing through data_ptr())."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _wplanes(W, transposed: bool):
+    """bf16 planes [P, rows, cols] of W (rows, cols = N, K) or of W^T (K, N)."""
+    N, K, ld = _ld_view(W)
+    P = _nplanes()
+    rows, cols = (K, N) if transposed else (N, K)
+    leaf = W.grad_fn is None and W.requires_grad
+    buf = None
+    if leaf:
+        tag = (W._version, _weights_epoch, W.data_ptr(), N, K, ld, P)
+        ent = _wp_cache.get(id(W))
+        if ent is None or ent["ref"]() is not W:
+            key = id(W)
+            ent = _wp_cache[key] = {"ref": weakref.ref(W, lambda _r, key=key: _wp_cache.pop(key, None)), "planes": {}, "tags": {}}
+        buf = ent["planes"].get(transposed)
+        if buf is not None and ent["tags"].get(transposed) == tag:
+            return buf
+        if buf is not None and tuple(buf.shape) != (P, rows, cols):
+            buf = None
+    if buf is None:
+        buf = torch.empty((P, rows, cols), device=W.device, dtype=torch.bfloat16)
+    call("mdvit_split_planes_t", _p(W), ld, _p(buf), cols, rows * cols, N, K, int(transposed), P, _stream())
+    if leaf:
+        ent["planes"][transposed] = buf
+        ent["tags"][transposed] = tag
+    return buf
+
+
+def refresh_weight_planes():
+    """Re-split EVERY cached weight orientation in one launch (start of a step, after the optimizer update)."""
+    global _wp_table
+    items, live = [], []
+    P = _nplanes()
+    for key, ent in list(_wp_cache.items()):
+        W = ent["ref"]()
+        if W is None:
+            continue
+        N, K, ld = _ld_view(W)
+        for tr, buf in ent["planes"].items():
+            rows, cols = (K, N) if tr else (N, K)
+            if tuple(buf.shape) != (P, rows, cols):
+                continue
+            items.append((W.data_ptr(), buf.data_ptr(), ld, N, K, int(tr), cols, rows * cols))
+            live.append((ent, tr, (W._version, _weights_epoch, W.data_ptr(), N, K, ld, P)))
+    if not items:
+        return
+    sig = tuple(items)
+    if _wp_table is None or _wp_table[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            return                            # host-built table: must exist before capture (warm-up steps build it)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        tiles = max(((it[3] + 31) // 32) * ((it[4] + 31) // 32) for it in items)
+        _wp_table = (sig, torch.tensor([list(it) for it in items], dtype=torch.int64, device=dev), int(min(tiles, 64)))
+    call("mdvit_split_planes_many", _p(_wp_table[1]), len(items), _wp_table[2], P, _stream())
+    for ent, tr, tag in live:
+        ent["tags"][tr] = tag
+
+
+class Planes:
+    """An activation stored as bf16 planes [P, M, K] (hi, lo) -- the A-operand format of the plane GEMMs.  `h` is the autograd
+    handle: an fp32 tensor of the LOGICAL shape whose values are never read (stride-0 phantom), so producers and consumers stay
+    ordinary autograd nodes while the data travels in `p`."""
+    __slots__ = ("p", "h")
+
+    def __init__(self, p, h=None):
+        self.p, self.h = p, h
+
+    @property
+    def shape(self):
+        return self.p.shape[1:] if self.h is None else self.h.shape
+
+
+def to_planes(x2d):
+    """fp32 [M, K] -> bf16 planes [P, M, K] (one pass; for producers that do not write planes themselves yet)"""
+    M, K = x2d.shape
+    P = _nplanes()
+    out = _empty((P, M, K), device=x2d.device, dtype=torch.bfloat16)
+    call("mdvit_split_planes", _p(x2d), K, _p(out), K, M * K, M, K, P, _stream())
+    return out
+
+
+def _plane_ok(M, N, K) -> bool:
+    """the plane kernels cover this product (otherwise: the split-while-staging kernels of gemm.hip)"""
+    return _use_plane_gemm and _gemm_precision >= 1 and K % 32 == 0 and N % 4 == 0
+
+
+def _pp(v):
+    """tensor | ctypes pointer | None -> ctypes pointer | None"""
+    return _p(v) if isinstance(v, torch.Tensor) else v
+
+
+def gemm_nt(x, W, out, M, N, K, *, w_transposed=False, bias=None, epi=_lib.EPI_NONE, e_drop=0.0, e_key=(0, 0), e_rowscale=None,
+            e_rows_per_scale=1, residual=None, gelu_u=None, U=None, out_planes=None, allow_split=False, accumulate=False, rc=None,
+            ldr=None, ldu=None):
+    """out[M,N] = x[M,K] @ B^T with B = W [N,K] (w_transposed=False: a forward layer) or B = W^T where W is [K,N] (the data
+    gradient dx = g W).  x: fp32 tensor [M,K] (split while staged) or bf16 planes [P,M,K]; out: fp32 tensor or None;
+    out_planes: bf16 planes [P,M,N] or None.  rc = (x_planes, W1, b1, rc_k): DGELU with the recomputed pre-activation."""
+    B = _wplanes(W, w_transposed)                     # [P, N, K]
+    P = B.shape[0]
+    d = _lib.PlaneGemmDesc()
+    a_f32 = x.dtype == torch.float32
+    assert (ldr is None or ldr == N or residual is None) and (ldu is None or ldu == N or gelu_u is None)
+    d.A = _p(x); d.lda = K; d.a_plane = 0 if a_f32 else M * K; d.a_f32 = int(a_f32)
+    d.B = _p(B); d.ldb = K; d.b_plane = N * K
+    d.planes = P; d.trans = 0
+    d.M, d.N, d.K = M, N, K
+    if out is not None:
+        d.C = _pp(out); d.ldc = N
+    if out_planes is not None:
+        d.Cp = _p(out_planes); d.ldcp = N; d.c_plane = M * N
+    if U is not None:
+        d.U = _pp(U); d.ldu_out = N
+    d.bias = _pp(bias)
+    d.epi = epi
+    d.e_drop_p, d.e_key0, d.e_key1 = e_drop, e_key[0], e_key[1]
+    d.e_rowscale, d.e_rows_per_scale = _pp(e_rowscale), e_rows_per_scale
+    d.residual, d.ldr = _pp(residual), N
+    d.gelu_u, d.ldu = _pp(gelu_u), N
+    keep = None
+    if rc is not None:
+        ra, W1, b1, rk = rc
+        rb = _wplanes(W1, False)
+        keep = rb
+        d.rc_a = _p(ra); d.rc_lda = rk; d.rc_a_plane = M * rk
+        d.rc_b = _p(rb); d.rc_ldb = rk; d.rc_b_plane = N * rk
+        d.rc_bias = _pp(b1); d.rc_k = rk
+    d.allow_split = int(allow_split)
+    d.accumulate = int(accumulate)
+    d.drop_seed = _seed_ptr() if e_drop > 0 else None
+    ws = None
+    if allow_split:
+        need = _lib.load().mdvit_gemm_planes_ws_bytes(C.byref(d))
+        if need:
+            ws = _empty((need // 4,), device=B.device, dtype=torch.float32)
+            d.ws, d.ws_bytes = _p(ws), need
+    if _events is None:
+        call("mdvit_gemm_planes", C.byref(d), _stream())
+        return
+    kepi = 1 if epi == _lib.EPI_GELU_DUAL else (4 if rc is not None else 2) if epi == _lib.EPI_DGELU else \
+        3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
+    pkey = ("bp", M, N, K, kepi, P, a_f32, bool(allow_split))
+    plan = _plan_cache.get(pkey)
+    if plan is None:
+        tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+        call("mdvit_gemm_planes_plan", C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp))
+        plan = _plan_cache[pkey] = (tm.value, tn.value, sp.value)
+    name = "gemm_bp_nt_kernel<%d, %d, %d, %s, %d>%s" % (plan[0], plan[1], P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
+    if _events_by_shape:
+        name += " M=%d N=%d K=%d sp=%d" % (M, N, K, plan[2])
+    if _events_only is not None and name != _events_only:
+        call("mdvit_gemm_planes", C.byref(d), _stream())
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call("mdvit_gemm_planes", C.byref(d), _stream())
+    e1.record()
+    abytes = 4.0 if a_f32 else 2.0 * P
+    nbytes = abytes * M * K + 2.0 * P * N * K + M * N * (4.0 * (out is not None) + 2.0 * P * (out_planes is not None) + 4.0 * (U is not None)
+                                                        + 4.0 * (residual is not None) + 4.0 * (gelu_u is not None))
+    if rc is not None:
+        nbytes += 2.0 * P * (M + N) * rc[3]
+    _events.append((name, 2.0 * M * N * K, nbytes, e0, e1))
 
 
 def _dgrad(g, W, dx, M, K, N, ldb, **kw):
-    """dx[M,K] = g[M,N] @ W[N,K]: NN on the fp32 path; NT against the cached W^T on the bf16x3 path."""
+    """dx[M,K] = g[M,N] @ W[N,K]: NN on the fp32 path; NT against the cached W^T (planes) on the bf16x3 / bf16 paths."""
+    if _plane_ok(M, K, N) and "rc" not in kw and "precision" not in kw:
+        gemm_nt(g, W, dx, M, K, N, w_transposed=True, **kw)
+        return
     if _gemm_precision:
         Wt = wt(W)          # held until the launch is enqueued: for a non-leaf W the transpose is a temporary, and gemm() allocates
         #                     its split-K workspace before launching -- a freed W^T block could be handed out as that workspace
@@ -403,9 +591,13 @@ class _Linear(torch.autograd.Function):
         assert K == K2
         y = _empty((M, N), device=x.device, dtype=torch.float32)
         key = _next_key() if drop_p > 0 else (0, 0)
-        gemm(_p(x), _p(W), _p(y), M, N, K, lda=K, ldb=ldb, ldc=N, bias=_p(b),
-             e_drop=drop_p, e_key=key, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale,
-             residual=_p(residual), ldr=N, allow_split=True)
+        if _plane_ok(M, N, K):
+            gemm_nt(x, W, y, M, N, K, bias=b, e_drop=drop_p, e_key=key, e_rowscale=rowscale, e_rows_per_scale=rows_per_scale,
+                    residual=residual, allow_split=True)
+        else:
+            gemm(_p(x), _p(W), _p(y), M, N, K, lda=K, ldb=ldb, ldc=N, bias=_p(b),
+                 e_drop=drop_p, e_key=key, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale,
+                 residual=_p(residual), ldr=N, allow_split=True)
         ctx.save_for_backward(x, W, rowscale)
         ctx.meta = (drop_p, key, rows_per_scale, b is not None, residual is not None)
         ctx.bias_ref = b if (b is not None and b.grad_fn is None) else None      # leaf bias: only to look up its gradient sink
@@ -527,7 +719,7 @@ class _MlpResidual(torch.autograd.Function):
         k2 = _next_key() if drop_p > 0 else (0, 0)
         # HBM-bound MLPs (fc1's K = C <= 128): keep gelu(u) only; the backward recomputes the pre-activation u inside the fc2
         # data-gradient GEMM (one more K = C product per tile) instead of moving [tokens, hidden] u through HBM twice
-        if _mlp_recompute and _mlp_fused and _gemm_precision == 1 and Cin == 64 and Hd % 64 == 0 and b1 is not None and b2 is not None \
+        if _mlp_recompute and _mlp_fused and _gemm_precision >= 1 and Cin == 64 and Hd % 64 == 0 and b1 is not None and b2 is not None \
                 and res is not None and W1.is_contiguous() and W2.is_contiguous() and M * Hd < (1 << 32):
             # C = 64: both GEMMs in ONE kernel -- h goes to HBM once (for the backward) and, through LDS, straight into fc2
             out = _empty((M, Cin), device=x.device, dtype=torch.float32)
@@ -537,16 +729,26 @@ class _MlpResidual(torch.autograd.Function):
             ctx.meta = (drop_p, k1, k2, rows_per_scale)
             ctx.b1_ref, ctx.b2_ref = b1, b2
             return out
-        if _mlp_recompute and _gemm_precision == 1 and Cin <= 128 and Cin % 32 == 0 and Hd % 4 == 0:
+        plane = _plane_ok(M, Hd, Cin) and _plane_ok(M, Cin, Hd) and W1.is_contiguous() and W2.is_contiguous()
+        if _mlp_recompute and _gemm_precision >= 1 and Cin <= 128 and Cin % 32 == 0 and Hd % 4 == 0:
             u = None
-            gemm(_p(x), _p(W1), _p(h), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
+            if plane:
+                gemm_nt(x, W1, h, M, Hd, Cin, bias=b1, epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
+            else:
+                gemm(_p(x), _p(W1), _p(h), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
         else:
             u = _empty_like(h)
-            gemm(_p(x), _p(W1), _p(u), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), out2=_p(h),
-                 epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
+            if plane:
+                gemm_nt(x, W1, h, M, Hd, Cin, bias=b1, U=u, epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
+            else:
+                gemm(_p(x), _p(W1), _p(u), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), out2=_p(h),
+                     epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
         out = _empty((M, Cin), device=x.device, dtype=torch.float32)
-        gemm(_p(h), _p(W2), _p(out), M, Cin, Hd, lda=Hd, ldb=Hd, ldc=Cin, bias=_p(b2),
-             e_drop=drop_p, e_key=k2, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale, residual=_p(res), ldr=Cin)
+        if plane:
+            gemm_nt(h, W2, out, M, Cin, Hd, bias=b2, e_drop=drop_p, e_key=k2, e_rowscale=rowscale, e_rows_per_scale=rows_per_scale, residual=res)
+        else:
+            gemm(_p(h), _p(W2), _p(out), M, Cin, Hd, lda=Hd, ldb=Hd, ldc=Cin, bias=_p(b2),
+                 e_drop=drop_p, e_key=k2, e_rowscale=_p(rowscale), e_rows_per_scale=rows_per_scale, residual=_p(res), ldr=Cin)
         ctx.save_for_backward(x, u, h, W1, W2, rowscale)
         ctx.meta = (drop_p, k1, k2, rows_per_scale)
         ctx.b1_ref, ctx.b2_ref = b1, b2           # leaf biases: only to look up their gradient sinks
@@ -576,7 +778,7 @@ class _MlpResidual(torch.autograd.Function):
                  drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         # du = (gm W2) * gelu'(u) * mask1
         dx = _empty_like(x)
-        if u is None and _mlp_fused and _gemm_precision == 1 and Cin == 64 and Hd % 64 == 0 and W1.is_contiguous() and W2.is_contiguous():
+        if u is None and _mlp_fused and _gemm_precision >= 1 and Cin == 64 and Hd % 64 == 0 and W1.is_contiguous() and W2.is_contiguous():
             # C = 64: the whole data path in one kernel; the hidden-layer gradient is materialised only for the weight gradients
             du = None if _dgrad_only else _empty_like(h)
             W2t, W1t = wt(W2), wt(W1)
@@ -585,7 +787,11 @@ class _MlpResidual(torch.autograd.Function):
             del W2t, W1t
         else:
             du = _empty_like(h)
-            if u is None:
+            if u is None and _plane_ok(M, Hd, Cin) and W1.is_contiguous() and W2.is_contiguous():
+                # the plane kernel's recompute epilogue takes every operand as planes: x and gm are split here (two small passes)
+                gemm_nt(to_planes(gm), W2, du, M, Hd, Cin, w_transposed=True, epi=_lib.EPI_DGELU, rc=(to_planes(x), W1, ctx.b1_ref, Cin),
+                        e_drop=drop_p, e_key=k1)
+            elif u is None:
                 _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, rc=(_p(x), Cin, _p(W1), Cin, _p(ctx.b1_ref), Cin), e_drop=drop_p, e_key=k1)
             else:
                 _dgrad(gm, W2, du, M, Hd, Cin, Hd, epi=_lib.EPI_DGELU, gelu_u=_p(u), ldu=Hd, e_drop=drop_p, e_key=k1)

@@ -106,35 +106,82 @@ class GradBucketReducer:
 
 
 class GradAccumulator:
-    """Gradient accumulation over the 4 domains x 2 sweeps of one step with a handful of kernels.
+    """Gradient accumulation over the 4 domains x 2 sweeps of one step with a handful of kernels, and the data-parallel
+    all-reduce of the buckets UNDERNEATH the rest of the backward.
 
     autograd's AccumulateGrad issues one small add per parameter per backward() (432 x 7 per step).  Here every
     sweep runs with p.grad = None and its fresh gradients are folded into flat buckets by ONE multi-tensor add (most
-    weight gradients never reach autograd: the wgrad kernels add them into the buckets directly, see attach_sinks);
-    after the last sweep, with world_size > 1, the buckets are all-reduced (RCCL) and averaged.
-    (GradBucketReducer above is the hook-driven variant that overlaps the all-reduce with a plain autograd backward.)"""
+    weight gradients never reach autograd: the wgrad kernels add them into the buckets directly, see attach_sinks).
 
-    def __init__(self, params, bucket_bytes: int = 32 << 20, process_group=None, average: bool = True):
-        self.reducer = GradBucketReducer(params, bucket_bytes, process_group, average)
+    Overlap (world_size > 1).  `late`: parameters that still receive gradients after the heavy sweep -- in the merged
+    two-sweep step (train.mdvit_train_step, full sweep first) only the domain adapters do (the data-gradient-only aux
+    sweep hands them minus their aux gradient).  They get buckets of their own at the END of the bucket list, so every
+    other bucket is final as soon as the full sweep's kernels are done: end_sweep(last=False, remaining=late) then issues
+    the all-reduce of those buckets on the process group's stream, ordered after the side stream's weight-gradient
+    kernels and the main stream's fold -- it runs over xGMI while the main stream works through the aux sweep.  The late
+    buckets (a few hundred KB) follow after the last sweep; finish() makes the main stream wait and applies 1/world.
+    Sweep orders in which the last sweep still touches everything (the reference's literal two sweeps) reduce all
+    buckets at the end -- same code path, no overlap.
+    (GradBucketReducer above is the hook-driven variant for a plain autograd backward.)"""
+
+    def __init__(self, params, bucket_bytes: int = 32 << 20, process_group=None, average: bool = True, late=None):
+        params = [p for p in params if p.requires_grad]
+        late_ids = {id(p) for p in (late or [])}
+        # GradBucketReducer buckets in REVERSE registration order: put the late parameters first so they end up in the last buckets,
+        # and cut a bucket boundary between the two classes
+        early = [p for p in params if id(p) not in late_ids]
+        latep = [p for p in params if id(p) in late_ids]
+        self.reducer = GradBucketReducer(early, bucket_bytes, process_group, average)
+        self._n_early = len(self.reducer.buckets)
+        if latep:
+            lr = GradBucketReducer(latep, bucket_bytes, process_group, average)
+            for h in lr._hooks:
+                h.remove()
+            off = len(self.reducer.buckets)
+            self.reducer.buckets += lr.buckets
+            self.reducer._bucket_sizes += lr._bucket_sizes
+            for p, bi in lr._bucket_of.items():
+                self.reducer._bucket_of[p] = bi + off
+            self.reducer.params += lr.params
+        for h in self.reducer._hooks:          # this class drives the reduction itself; the per-parameter hooks stay off
+            h.remove()
+        self.reducer._hooks = []
         self.params = self.reducer.params
         self.views = [p.grad for p in self.params]          # views into the flat buckets
         for p in self.params:
             p.grad = None
         self.sinks = {p: v for p, v in zip(self.params, self.views) if p.is_cuda}
+        self._handles = []
+        self._reduced = [False] * len(self.reducer.buckets)
+        self.overlapped_buckets = 0          # how many buckets of the last step were reduced before its last sweep ended (tests / bench)
 
     def attach_sinks(self, flag: bool = True):
         """Let the HIP wgrad kernels add weight gradients straight into the buckets (mdvit_amd.ops.set_grad_sinks)."""
         from . import ops
         ops.set_grad_sinks(self.sinks if flag else None)
 
+    def view_of(self, p):
+        """the bucket view that holds p's gradient"""
+        for q, v in zip(self.params, self.views):
+            if q is p:
+                return v
+        raise KeyError("not a parameter of this accumulator")
+
     @property
     def world(self):
         return self.reducer.world
+
+    def _collective(self) -> bool:
+        from . import ops as _ops
+        return self.world > 1 or (_ops._force_collectives and dist.is_available() and dist.is_initialized())
 
     def zero(self):
         self.reducer.zero_grad()
         for p in self.params:
             p.grad = None
+        self._handles = []
+        self._reduced = [False] * len(self.reducer.buckets)
+        self.overlapped_buckets = 0
 
     def begin_sweep(self, last: bool):
         # Every sweep runs with p.grad = None and is folded into the buckets by one multi-tensor add; weight gradients that
@@ -142,29 +189,63 @@ class GradAccumulator:
         for p in self.params:
             p.grad = None
 
-    def end_sweep(self, last: bool):
+    def _fold(self):
         dst, src = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is not None:
                 dst.append(v); src.append(p.grad)
         if dst:
             torch._foreach_add_(dst, src)
+
+    def _launch(self, indices):
+        """all-reduce of the given buckets, issued from a stream that is ordered after BOTH the main stream (folds) and the side
+        stream (weight-gradient kernels writing the sinks); async: the main stream goes on"""
+        from . import ops as _ops
+        side = _ops._side_stream
+        main = torch.cuda.current_stream() if torch.cuda.is_available() and self.reducer.buckets[0].is_cuda else None
+        ctx = None
+        if side is not None and main is not None:
+            side.wait_stream(main)             # the fold above (and everything before it) precedes the collective
+            ctx = torch.cuda.stream(side)      # ProcessGroupNCCL orders its stream after the CURRENT stream: the side stream's tail
+            ctx.__enter__()
+        try:
+            for bi in indices:
+                if not self._reduced[bi]:
+                    self._handles.append(dist.all_reduce(self.reducer.buckets[bi], op=dist.ReduceOp.SUM, group=self.reducer.group, async_op=True))
+                    self._reduced[bi] = True
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
+    def end_sweep(self, last: bool, remaining=None):
+        """remaining: the parameters that later sweeps of this step can still touch (None: unknown -> every bucket stays open
+        until the last sweep).  Buckets holding none of them are final now and go on the wire."""
+        self._fold()
+        if self._collective():
+            if last:
+                self._launch(range(len(self.reducer.buckets)))
+            elif remaining is not None:
+                open_b = {self.reducer._bucket_of[p] for p in remaining if p in self.reducer._bucket_of}
+                early = [bi for bi in range(len(self.reducer.buckets)) if bi not in open_b]
+                self._launch(early)
+                self.overlapped_buckets = len(early)
         if last:
-            from . import ops as _ops
-            if self.world > 1 or (_ops._force_collectives and dist.is_initialized()):
-                # ONE all-reduce per bucket per step over RCCL/xGMI, all in flight together (35 M parameters = 140 MB:
-                # ~1-2 ms on 8 GPUs against a ~60 ms step, so it is not worth giving up the side-stream weight gradients
-                # -- which bypass autograd's hooks -- to overlap it with the backward)
-                handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.reducer.group, async_op=True) for b in self.reducer.buckets]
-                for h in handles:
-                    h.wait()
-                if self.reducer.average:
-                    torch._foreach_div_(self.reducer.buckets, float(self.world))
+            self.finish()
             for p, v in zip(self.params, self.views):       # hand the accumulated gradients to the optimizer
                 p.grad = v
         else:
             for p in self.params:
                 p.grad = None
+
+    def finish(self):
+        """the main stream waits for the collectives; 1/world average"""
+        if not self._handles:
+            return
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if self.reducer.average and self.world > 1:
+            torch._foreach_div_(self.reducer.buckets, float(self.world))
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):

@@ -51,7 +51,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
     if fuse_domains > 1:
         batches = _fuse_batches(batches, fuse_domains, num_domains, use_domain_label)
 
-    def sweep(loss, last, retain=False, join=True):
+    def sweep(loss, last, retain=False, join=True, remaining=None):
         if accumulator is not None:
             accumulator.begin_sweep(last)
         elif last and reducer is not None:
@@ -60,7 +60,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
         if join:
             ops.join_side_stream()      # weight gradients may have been produced on the side stream
         if accumulator is not None:
-            accumulator.end_sweep(last)
+            accumulator.end_sweep(last, remaining=remaining)
 
     def two_sweeps(aux_sum, uni, last):
         if merged_sweeps:
@@ -69,7 +69,9 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
                 # into the bucket sinks) then drain underneath the whole data-gradient-only sweep instead of piling up behind the
                 # last kernels of the step.  (The two sweeps commute; what this sweep hands autograd is folded into the buckets
                 # on the main stream and touches other bucket elements than the sinks.)
-                sweep(aux_sum + uni, False, retain=True, join=False)
+                # Data parallel: what the aux sweep can still touch is the domain adapters only -- on the last domain forward of the
+                # step every other gradient bucket is final after this sweep and its all-reduce is issued underneath the aux sweep.
+                sweep(aux_sum + uni, False, retain=True, join=False, remaining=(da if last else None))
                 ops.set_dgrad_only(True)
                 try:
                     sweep(aux_sum, last)
@@ -187,6 +189,7 @@ def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Op
                     num_domains: int = 4, use_domain_label: bool = False,
                     accumulator: Optional[GradAccumulator] = None) -> Dict[str, torch.Tensor]:
     """multi_train_BASE.py:150-200: per domain loss = BCE + Dice, one backward of the sum."""
+    ops.refresh_transposes()          # cached W^T / weight planes follow the last optimizer update (one launch each)
     if accumulator is not None:
         accumulator.zero()
     elif reducer is not None:

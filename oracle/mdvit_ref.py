@@ -361,12 +361,14 @@ def domain_losses(out: Tensor, aux: Tensor, label: Tensor):
     return bce_loss(o, label) + dice_loss(o, label), bce_loss(a, label) + dice_loss(a, label), dice_loss(a, o)
 
 
-def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: float = 0.5, forward=None):
+def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: float = 0.5, forward=None, timing=None):
     """One optimisation step's losses and gradients, multi_train_MDViT.py:129-207.
 
     batches: list of (img, label, set_id:int) -- one per domain.  Returns (losses dict, grads dict).
     The aux sweep runs with every ``domain_layer`` parameter frozen, the uni sweep with all
-    parameters live; gradients accumulate."""
+    parameters live; gradients accumulate.  timing: optional dict, receives fwd_ms / bwd_ms (bench.py's CPU baseline)."""
+    import time as _time
+    _t0 = _time.perf_counter()
     st = st or RefState()
     leaves = {k: v for k, v in P.items() if v.is_floating_point() and "running_" not in k}
     for v in leaves.values():
@@ -379,6 +381,7 @@ def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: f
         l, la, lk = domain_losses(out, aux, label)
         tot, tot_aux, tot_kt = tot + l, tot_aux + la, tot_kt + lk
     da = [v for k, v in leaves.items() if "domain_layer" in k]
+    _t1 = _time.perf_counter()
     for v in da:
         v.requires_grad_(False)
     tot_aux.backward(retain_graph=True)
@@ -386,6 +389,9 @@ def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: f
         v.requires_grad_(True)
     uni = alpha * tot_kt + (1 - alpha) * tot
     uni.backward()
+    if timing is not None:
+        timing["fwd_ms"] = (_t1 - _t0) * 1e3
+        timing["bwd_ms"] = (_time.perf_counter() - _t1) * 1e3
     grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in leaves.items()}
     losses = {"loss": float(tot.detach()), "aux_loss": float(tot_aux.detach()), "kt_loss": float(tot_kt.detach())}
     for v in leaves.values():
@@ -394,7 +400,7 @@ def mdvit_train_step(P: Params, batches, st: Optional[RefState] = None, alpha: f
 
 
 def base_train_step(P: Params, img: Tensor, label: Tensor, domain_label: Optional[Tensor] = None,
-                    st: Optional[RefState] = None, forward=None):
+                    st: Optional[RefState] = None, forward=None, timing=None):
     """multi_train_BASE.py:168-200 for one domain: loss = BCE+Dice, single backward.  forward: base_forward, or a closure over
     base_dsn_forward with the domain id."""
     st = st or RefState()
@@ -403,9 +409,15 @@ def base_train_step(P: Params, img: Tensor, label: Tensor, domain_label: Optiona
     for v in leaves.values():
         v.requires_grad_(True)
         v.grad = None
+    import time as _time
+    _t0 = _time.perf_counter()
     o = torch.sigmoid(base_forward_(P, img, domain_label, st))
     loss = bce_loss(o, label) + dice_loss(o, label)
+    _t1 = _time.perf_counter()
     loss.backward()
+    if timing is not None:
+        timing["fwd_ms"] = (_t1 - _t0) * 1e3
+        timing["bwd_ms"] = (_time.perf_counter() - _t1) * 1e3
     grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in leaves.items()}
     for v in leaves.values():
         v.requires_grad_(False)

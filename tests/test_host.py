@@ -156,6 +156,45 @@ for step in range(2):
     acc.begin_sweep(True); model2(xs).abs().mean().backward(); acc.end_sweep(True)
 for p, q in zip(model2.parameters(), ref.parameters()):
     assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
+# ---- the product path of the merged two-sweep step: gradient SINKS (weight gradients written straight into the buckets, never
+# seen by autograd), `late` parameters (the domain adapters) in buckets of their own, every other bucket all-reduced right after
+# the full sweep -- i.e. underneath the second (adapter-only) sweep -- and the late buckets after it
+model3 = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 3))
+model3.load_state_dict(ref.state_dict())
+late = list(model3[2].parameters())                       # plays the domain adapters
+acc3 = GradAccumulator(list(model3.parameters()), bucket_bytes=4096, late=late)
+late_buckets = {{acc3.reducer._bucket_of[p] for p in late}}
+assert all(acc3.reducer._bucket_of[p] not in late_buckets for p in model3.parameters() if all(p is not q for q in late))
+sunk = [model3[0].weight, model3[4].weight]              # their "wgrad kernels" add into the sinks
+for step in range(2):
+    acc3.zero()
+    l_aux = ((model3(xs) - ys) ** 2).mean(); l_uni = model3(xs).abs().mean()
+    acc3.begin_sweep(False)
+    (l_aux + l_uni).backward(retain_graph=True)           # the full sweep first ...
+    for p in sunk:
+        acc3.view_of(p).add_(p.grad); p.grad = None         # ... with these gradients delivered through the sinks
+    acc3.end_sweep(False, remaining=late)
+    assert acc3.overlapped_buckets == len(acc3.reducer.buckets) - len(late_buckets) > 0
+    acc3.begin_sweep(True)                                # ... then the adapter-only sweep: minus their aux gradient
+    for p, g_ in zip(late, torch.autograd.grad(l_aux, late)):
+        p.grad = -g_
+    acc3.end_sweep(True)
+ref3 = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 3))
+ref3.load_state_dict(ref.state_dict())
+tot_aux = tot_uni = 0
+for r in range(world):
+    xr, yr = X[r * 4:(r + 1) * 4], Y[r * 4:(r + 1) * 4]
+    tot_aux = tot_aux + ((ref3(xr) - yr) ** 2).mean() / world
+    tot_uni = tot_uni + ref3(xr).abs().mean() / world
+late3 = list(ref3[2].parameters())
+for q in late3:
+    q.requires_grad_(False)
+tot_aux.backward(retain_graph=True)                       # the reference's order: aux with the adapters frozen, then uni into everything
+for q in late3:
+    q.requires_grad_(True)
+tot_uni.backward()
+for p, q in zip(model3.parameters(), ref3.parameters()):
+    assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
