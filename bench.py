@@ -38,9 +38,10 @@ def parse():
                     help="PCIe-inclusive variant: every step's images (uint8 HWC) and labels (uint8) start in pinned host memory and cross to the "
                          "device inside the timed region (the headline number keeps its inputs resident in HBM)")
     ap.add_argument("--no-side-stream", action="store_true")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel); "
-                         "fp32 = fp32-input MFMA")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32", "bf16"], default="bf16x3",
+                    help="GEMM arithmetic: bf16x3 = fp32 operands split hi+lo into bf16, 3 bf16 MFMAs per product, fp32 accumulate (~1e-5 rel: the "
+                         "parity mode and the headline); fp32 = fp32-input MFMA; bf16 = the speed mode: GEMM operands rounded to ONE bf16 plane, one "
+                         "MFMA per product, fp32 accumulate, fp32 norms / softmax statistics / losses (drifts ~1e-2: never the parity mode)")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of the one-launch HIP AdamW")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in a HIP graph and replay it")
     ap.add_argument("--fuse-images", type=int, default=128,
@@ -208,7 +209,7 @@ def main():
 
     ops.set_gemm_precision(args.precision)
     # useful-flop roof of the GEMM arithmetic in use: fp32 MFMA peak, or a third of the bf16 peak (3 MFMAs per product)
-    peak_mfma = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    peak_mfma = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.precision]
     torch.manual_seed(0)
     if args.model in ("mdvit", "mdvit_dsn"):
         cls = mdvit_amd.MDViT if args.model == "mdvit" else mdvit_amd.MDViT_DSN
@@ -233,6 +234,20 @@ def main():
     pool = [make_step_batches(args.batch, args.size, rank=rank, step=s, device=dev, domains=domains) for s in range(2)]
 
     fuse = max(1, min(len(domains), args.fuse_images // max(1, args.batch))) if args.model in ("mdvit", "mdvit_dsn") else 1
+
+    drift = None
+    if args.precision == "bf16" and args.model == "mdvit":
+        # what the speed mode costs in accuracy: the same weights and images through the parity arithmetic and through bf16
+        import torch.nn.functional as F
+        img0 = pool[0][0][0][:2]
+        dl0 = F.one_hot(torch.zeros(img0.shape[0], dtype=torch.long), 4).float().to(dev)
+        model.eval()
+        with torch.no_grad():
+            ops.set_gemm_precision("bf16x3"); o_ref, a_ref = model(img0, dl0, "0")
+            ops.set_gemm_precision("bf16"); o_b, a_b = model(img0, dl0, "0")
+        model.train()
+        drift = {"what": "eval-mode logits, bf16 vs bf16x3 GEMMs, same weights and 2 images: max |diff| / max |logit|",
+                 "out": round(float((o_b - o_ref).abs().max() / o_ref.abs().max()), 5), "aux": round(float((a_b - a_ref).abs().max() / a_ref.abs().max()), 5)}
 
     def step_batches(b):
         if args.model != "base":
@@ -368,6 +383,11 @@ def main():
             extra["bs32"] = {k: b32.get(k) for k in ("value", "unit", "ms_per_step", "phase_ms", "steps", "warmup", "error") if k in b32}
             if "config" in b32:
                 extra["bs32"]["workload"] = b32["config"]["workload"]
+            if args.precision == "bf16x3":
+                # the bf16 speed mode NEXT TO the parity-mode headline (never instead of it)
+                sp = _child_json([sys.executable, os.path.abspath(__file__), "--precision", "bf16", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                  "--no-cpu-baseline", "--no-extra-legs", "--no-kernel-events"] + (["--no-side-stream"] if args.no_side_stream else []), 600)
+                extra["bf16_speed_mode"] = {k: sp.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "drift_vs_parity_mode", "error") if k in sp}
             blk_json = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mdvit_block_roofline_{os.getpid()}.json")
             _child_json([sys.executable, os.path.join(ROOT, "tools", "block_roofline.py"), "--batch", "32", "--precision", args.precision,
                          "--json", blk_json], 600)
@@ -389,12 +409,13 @@ def main():
                       ("512x512 images/sec MDViT_DSN train step" if args.model == "mdvit_dsn" else "512x512 images/sec BASE train step"),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 storage; GEMM operands split hi+lo bf16, fp32 accumulate)", "data": "synthetic" + (" (inputs cross PCIe inside the timed region)" if args.host_inputs else ""),
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (fp32 storage; GEMM operands split hi+lo bf16, fp32 accumulate)",
+                      "bf16": "bf16 (GEMM operands one bf16 plane, one MFMA per product, fp32 accumulate; fp32 storage, norms and losses)"}[args.precision], "data": "synthetic" + (" (inputs cross PCIe inside the timed region)" if args.host_inputs else ""),
             "config": {"workload": f"{ {'mdvit': 'MDViT Sup+' + args.decoder, 'mdvit_dsn': 'MDViT_DSN Sup+' + args.decoder, 'base': 'BASE'}[args.model] } train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
             "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),
-            "phase_ms": phase_ms, "roofline": roof, "cpu_baseline": cpu,
+            "phase_ms": phase_ms, "roofline": roof, "cpu_baseline": cpu, "drift_vs_parity_mode": drift,
             "world": world, "rccl_ranks": rccl_ranks, "devices": devices,
             "allreduce": {"buckets": n_buckets, "issued_under_the_aux_sweep": overlapped_buckets},
         }

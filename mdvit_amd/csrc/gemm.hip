@@ -640,7 +640,7 @@ int g_force_cfg = -1, g_force_splits = 0;      // tuning hook (mdvit_gemm_force_
 GemmPlan plan_gemm(const MdvitGemmDesc* d) {
     static const int BMs[3] = {128, 256, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 2, 4};
     static const double EFF[3] = {0.8, 0.8, 1.0};       // measured (tools/gemm_sweep.py): the 64x64 tile at 4 workgroups / CU wins almost everywhere
-    static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024};
+    static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
     const bool plain = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual;
     const bool can_split = d->allow_split && plain && d->K >= 512 && (d->N % 4 == 0);
     GemmPlan best; best.cfg = 0; best.tiles_m = cdiv(d->M, 128); best.tiles_n = cdiv(d->N, 128); best.splits = 1;

@@ -270,6 +270,11 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
 _PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 _gemm_precision = _PRECISIONS[os.environ.get("MDVIT_GEMM_PRECISION", "bf16x3")]
 _use_plane_gemm = os.environ.get("MDVIT_PLANE_GEMM", "1") != "0"      # 0: the split-while-staging kernels of gemm.hip everywhere
+# bf16x3: plane kernels for K >= this.  Measured in the step (profiles/r02g_ab.txt): the plane NT kernel is a wash-to-slower against the
+# split-while-staging kernel at equal arithmetic (both sit at the same ~30 % of the MFMA roof: the limit is not the split VALU), so
+# the parity mode keeps the calibrated gemm.hip planner and the plane kernels serve the bf16 speed mode (half the operand bytes).
+_plane_min_k = int(os.environ.get("MDVIT_PLANE_MIN_K", "1000000"))
+_plane_rc = os.environ.get("MDVIT_PLANE_RC", "0") != "0"              # the recomputing fc2 data gradient of the C = 128 MLPs on the plane kernel
 
 
 def set_gemm_precision(name: str):
@@ -438,7 +443,9 @@ def to_planes(x2d):
 
 def _plane_ok(M, N, K) -> bool:
     """the plane kernels cover this product (otherwise: the split-while-staging kernels of gemm.hip)"""
-    return _use_plane_gemm and _gemm_precision >= 1 and K % 32 == 0 and N % 4 == 0
+    if not (_use_plane_gemm and _gemm_precision >= 1 and K % 32 == 0 and N % 4 == 0):
+        return False
+    return _gemm_precision == 2 or K >= _plane_min_k
 
 
 def _pp(v):
@@ -787,7 +794,7 @@ class _MlpResidual(torch.autograd.Function):
             del W2t, W1t
         else:
             du = _empty_like(h)
-            if u is None and _plane_ok(M, Hd, Cin) and W1.is_contiguous() and W2.is_contiguous():
+            if u is None and (_plane_rc or _gemm_precision == 2) and _use_plane_gemm and Cin % 32 == 0 and W1.is_contiguous() and W2.is_contiguous():
                 # the plane kernel's recompute epilogue takes every operand as planes: x and gm are split here (two small passes)
                 gemm_nt(to_planes(gm), W2, du, M, Hd, Cin, w_transposed=True, epi=_lib.EPI_DGELU, rc=(to_planes(x), W1, ctx.b1_ref, Cin),
                         e_drop=drop_p, e_key=k1)

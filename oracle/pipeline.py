@@ -1,6 +1,11 @@
 """CPU restatement (TEST INFRASTRUCTURE ONLY -- never imported by mdvit_amd) of the two host-side pieces around the hot
 path that SURVEY 8f-3 moves onto the device.
 
+PARITY UNPINNED: the arithmetic restated here lives in two third-party packages (medpy, torchvision) that are neither under
+/root/reference nor installed in this image, and the reference holds no test vectors for them -- so this file can only be checked
+against the packages' published definitions (below) and hand-computed known answers (tests/test_oracle_golden.py:
+`test_metric_and_loader_restatements_known_answers`), not against outputs of the packages themselves.  The integer counts behind the metrics are exact.
+
 * Metrics: multi_train_MDViT.py:172-179,275-288 call medpy.metric.binary.dc / jc on `sigmoid(output) > 0.5` and the
   label.  medpy (requirements: medpy, unpinned; algorithm as published in medpy 0.4.0 metric/binary.py) is not under
   /root/reference and not installed here, so its algorithm is restated:

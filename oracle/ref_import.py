@@ -1,7 +1,7 @@
 """Import the real reference (read-only, /root/reference) in the BUILD CONTAINER only.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Used by oracle/gen_golden.py to produce the
-committed fixtures and by the (auto-skipping) live cross-check in tests/test_oracle_vs_reference.py.
+committed fixtures (tests/test_oracle_golden.py then pins the restatement to them).
 /root/reference does not exist on the GPU box; nothing on the GPU path may import this module.
 
 The reference needs `timm` and `turtle` (tkinter), which this image lacks; the stubs below are

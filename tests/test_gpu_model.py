@@ -754,7 +754,7 @@ def test_base_fused_adamw_second_step_gradients_follow_the_updated_weights():
     assert not bad, f"{len(bad)} gradient tensors off after an optimizer step: {bad[:5]}"
 
 
-def test_mdvit_512_one_image_vs_oracle():
+def test_mdvit_512_one_image_vs_oracle(gemm_precision):
     """The benchmark's image size: MDViT Sup, one domain, one 512x512 image, HIP vs the CPU oracle -- logits and the three losses
     at 1e-3, every gradient tensor by relative L2 (the tile-count-, split-K- and planner-dependent kernel paths that 64x64 / 128x128
     inputs never reach: 128 attention tiles per image, the 128x128 / 256x64 GEMM plans, split-K weight gradients over 16384 tokens)."""
@@ -795,8 +795,13 @@ def test_mdvit_512_one_image_vs_oracle():
         ref = grads[n]
         if ref is None:
             continue
-        try:          # B = 1: the bridge BatchNorms see 256 samples here (16 at 128x128), so the kink-flip allowance is the ordinary one
-            check_grad(g_, ref, name=n, l2_tol=1e-2, max_tol=6e-2)
+        # tolerances as in test_mdvit_vs_oracle_128: fp32 GEMMs 3e-3 (mask flips only); bf16x3 perturbs the forward by ~5e-6 (a few more
+        # flips): 1e-2, and the bridge -- one image: its BatchNorms normalise over 256 samples, one flipped ReLU moves a channel's
+        # gradient by ~1/256 of it, several flip -- is bounded separately (test_gradients_away_from_activation_kinks_match_tightly
+        # shows the allowance covers nothing but flips)
+        l2_tol, max_tol = (3e-3, 6e-2) if gemm_precision == "fp32" else ((5e-2, 0.5) if n.startswith("bridge.") else (1e-2, 6e-2))
+        try:
+            check_grad(g_, ref, name=n, l2_tol=l2_tol, max_tol=max_tol)
         except AssertionError as exc:
             bad.append(str(exc))
     assert not bad, f"{len(bad)} gradient tensors off at 512x512: {bad[:6]}"
@@ -916,3 +921,37 @@ def test_gradients_away_from_activation_kinks_match_tightly():
         except AssertionError as exc:
             bad.append(str(exc))
     assert not bad, f"kink margin {margin:.2e}: {len(bad)} gradient tensors off: {bad[:6]}"
+
+
+def test_bf16_speed_mode_drift_is_bounded_and_reported():
+    """The bf16 speed mode (GEMM operands one bf16 plane) is NOT the parity mode: its drift against the oracle is measured here and
+    held to 5e-2 on logits / 2e-2 on the losses (bf16 autocast of the reference itself drifts 2-3 % on logits)."""
+    from mdvit_amd import ops
+    from mdvit_amd.losses import domain_losses
+    from oracle import mdvit_ref as R
+    from oracle.gen_golden import synth_image, synth_label
+    from oracle.params import make_params
+    S, B, d = 64, 2, 2
+    pn = make_params(31, model="MDViT", adapt_method="Sup")
+    img, lab = synth_image(3100, B, S, S), synth_label(3101, B, S, S)
+    P = R.to_torch(pn)
+    with torch.no_grad():
+        ro, ra = R.mdvit_forward({k: v.clone() for k, v in P.items()}, img, F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float(), str(d),
+                                 R.RefState(training=True))
+    losses, _ = R.mdvit_train_step(P, [(img, lab, d)], R.RefState(training=True))
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision("bf16")
+    try:
+        m = build_mdvit(31, S).train()
+        dl = F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float().to(dev())
+        out, aux = m(img.to(dev()), dl, str(d))
+        l, la, lk = domain_losses(out, aux, lab.to(dev()))
+        (l + la + lk).backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    finally:
+        ops.set_gemm_precision(prev)
+    e_out, e_aux = relerr(out, ro), relerr(aux, ra)
+    e_loss = relerr(torch.stack([l, la, lk]), [losses["loss"], losses["aux_loss"], losses["kt_loss"]])
+    print(f"bf16 speed mode drift vs oracle: logits {e_out:.2e}, aux logits {e_aux:.2e}, losses {e_loss:.2e}")
+    assert e_out <= 5e-2 and e_aux <= 5e-2 and e_loss <= 2e-2, (e_out, e_aux, e_loss)
+    assert e_out > 1e-5          # it IS a different arithmetic: if this were parity-class the mode would not be running

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 HBM = 8.0e12
-MFMA = {"bf16x3": 2500e12 / 3.0, "fp32": 157.3e12}       # useful flops/s (bf16x3 spends 3 bf16 MFMAs per product)
+MFMA = {"bf16x3": 2500e12 / 3.0, "fp32": 157.3e12, "bf16": 2500e12}       # useful flops/s (bf16x3 spends 3 bf16 MFMAs per product)
 ATT_MFMA = 157.3e12                                      # the attention's small products run on fp32 MFMA
 
 
@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--drop", type=float, default=0.1, help="drop_rate = drop_path_rate of the block (the train scripts' 0.1)")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32", "bf16"], default="bf16x3")
     ap.add_argument("--json", default=None)
     ap.add_argument("--stages", default="0,1,2,3")
     ap.add_argument("--eager", action="store_true", help="time eager launches (host-bound on the small stages) instead of HIP-graph replays")
