@@ -319,11 +319,15 @@ extern "C" int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b
     a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
     a.seed = drop_seed;
     constexpr size_t smem = (size_t)(2 + 2 + 2 + 2) * 2 * 64 * LDKB;          // X, W1c, Hc, W2c: 80 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
+    {   // the attribute is per DEVICE: one flag per device ordinal (a process may drive several GPUs)
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL((mlp_fwd_kernel<64>), dim3(cdiv(M, 64)), dim3(256), smem, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
@@ -346,11 +350,15 @@ extern "C" int mdvit_mlp_bwd_dgrad_f32(const float* gm, const float* x, const fl
     a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
     a.seed = drop_seed;
     constexpr size_t smem = (size_t)4 * 2 * 2 * 64 * LDKB;                    // W1c, W2tc, W1tc, d chunk: 80 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_dgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_bwd_dgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
+    {
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_dgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_bwd_dgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL((mlp_bwd_dgrad_kernel<64>), dim3(cdiv(M, 64)), dim3(256), smem, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();

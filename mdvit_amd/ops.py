@@ -145,12 +145,26 @@ def _sink_of(t):
 
 _side_keepalive = []     # tensors the side stream still reads; holding a reference also stops autograd from
                          # accumulating into them IN PLACE on the main stream (it only does so when it is the sole owner)
+_side_blocks = []        # (event recorded on the side stream after a block's launches, number of keep-alive entries up to there)
+
+
+def _release_finished_side_blocks():
+    """Drop the keep-alive references of side-stream blocks whose kernels have finished (the event recorded behind them has
+    completed), so an un-joined sweep does not hold a whole backward's worth of gradients until the next join."""
+    done = 0
+    while _side_blocks and _side_blocks[0][0].query():
+        done = _side_blocks.pop(0)[1]
+    if done:
+        del _side_keepalive[:done]
+        for i, (ev, n) in enumerate(_side_blocks):
+            _side_blocks[i] = (ev, n - done)
 
 
 def join_side_stream():
     if _side_stream is not None:
         torch.cuda.current_stream().wait_stream(_side_stream)
         _side_keepalive.clear()
+        _side_blocks.clear()
 
 
 class _on_side:
@@ -174,6 +188,12 @@ class _on_side:
 
     def __exit__(self, *exc):
         if self.ctx is not None:
+            marked = _side_blocks[-1][1] if _side_blocks else 0
+            if len(_side_keepalive) - marked >= 32 and not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()                 # one marker per ~32 protected tensors: host cost stays negligible
+                ev.record(_side_stream)
+                _side_blocks.append((ev, len(_side_keepalive)))
+                _release_finished_side_blocks()
             self.ctx.__exit__(*exc)
         return False
 
