@@ -153,6 +153,10 @@ int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b1, const fl
                       const float* rowscale /* optional */, int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t hidden,
                       float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
 
+/* tuning / diagnosis hook: token count from which the fused MLP forward uses its 128-token tile (<= 0: never); ablate != 0 switches
+ * parts of the forward kernel off for timing experiments (tools/mlp_check.py) -- results are then wrong by design; 0 in production */
+int mdvit_mlp_config(int32_t wide_min_tokens, int32_t ablate);
+
 /* ... and its backward data path:  dx = ((gm W2) * gelu'(x W1^T + b1) * dropmask1) W1  in one kernel (gm = the masked upstream
  * gradient from mdvit_colsum_f32; W2t / W1t = the cached transposes, [hidden, C] and [C, hidden]).  du (optional, [M, hidden]):
  * the hidden-layer gradient for the weight-gradient GEMMs; with du == NULL (the data-gradient-only sweep) no [M, hidden] tensor

@@ -72,6 +72,7 @@ _SIGS = {
     "mdvit_gemm_planes": [C.POINTER(PlaneGemmDesc), vp],
     "mdvit_gemm_planes_plan": [C.POINTER(PlaneGemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_planes_force_plan": [i32, i32],
+    "mdvit_mlp_config": [i32, i32],
     "mdvit_split_planes": [vp, i64, vp, i64, i64, i64, i32, i32, vp],
     "mdvit_split_planes_many": [vp, i32, i32, i32, vp],
     "mdvit_split_planes_t": [vp, i64, vp, i64, i64, i32, i32, i32, i32, vp],

@@ -34,14 +34,17 @@ struct MlpArgs {
     int M, Hd, rows_per_scale;
     int drop; uint32_t k1a, k1b, k2a, k2b, thresh; float inv_keep;
     const uint32_t* seed;
+    int abl;                       // diagnosis only (tools/mlp_check.py): 1 no h store, 2 no weight reloads, 4 no GELU, 8 no second product
 };
 
 // LDS operand: `slabs` K-slabs of 32, each slab = hi plane [rows][LDKB] then lo plane [rows][LDKB]
 __device__ __forceinline__ char* plane(char* base, int rows, int slab, int lo_plane) { return base + ((slab * 2 + lo_plane) * rows) * LDKB; }
 
-template <int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_fwd_kernel(MlpArgs p) {
-    constexpr int BM = 64, HC = 64;                 // tokens per workgroup, hidden chunk
+// BM tokens per workgroup (BM / 16 threads: 64 -> 4 waves, 2 workgroups per CU; 128 -> 8 waves, 1 workgroup per CU).  Every workgroup
+// streams ALL of W1 and W2 (256 KB at hidden = 512) from L2 through its LDS: the wider tile halves that traffic per token.
+template <int C, int BM>
+__global__ __launch_bounds__(BM * 4) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_fwd_kernel(MlpArgs p) {
+    constexpr int HC = 64, NT = BM * 4;             // hidden chunk, threads
     constexpr int S1 = C / 32, S2 = HC / 32;        // K slabs of the two products
     static_assert(C == 64, "tile mapping below is written for C = 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,35 +60,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
     const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1, k2a = p.k2a ^ s0, k2b = p.k2b + s1;
 
-    // stage a [64 rows][64 k] fp32 tile (row-major, leading dimension ld) as bf16 hi/lo planes: 4 float4 per thread
-    float4 r1[4], r2[4];
-    auto load_tile = [&](float4 (&r)[4], const float* src, long ld, int row0, int nrows) {
+    // stage a [ROWS][64 k] fp32 tile (row-major, leading dimension ld) as bf16 hi/lo planes: ROWS * 16 / NT float4 per thread
+    constexpr int XV = BM * 16 / NT, WV = 64 * 16 / NT;
+    float4 rx[XV], r1[WV], r2[WV];
+    auto load_tile = [&](auto& r, const float* src, long ld, int row0, int nrows) {
+        constexpr int NV = sizeof(r) / sizeof(float4);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + NT * v, row = idx >> 4, c4 = idx & 15;
             r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + row < nrows) r[v] = *reinterpret_cast<const float4*>(src + (long)(row0 + row) * ld + c4 * 4);
         }
     };
-    auto store_tile = [&](const float4 (&r)[4], char* dst) {
+    auto store_tile = [&](const auto& r, char* dst, int rows) {
+        constexpr int NV = sizeof(r) / sizeof(float4);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int idx = tid + 256 * v, row = idx >> 4, k = (idx & 15) * 4;
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + NT * v, row = idx >> 4, k = (idx & 15) * 4;
             uint2 hi, lo;
             mlp_split(r[v], hi, lo);
-            *reinterpret_cast<uint2*>(plane(dst, 64, k >> 5, 0) + row * LDKB + (k & 31) * 2) = hi;
-            *reinterpret_cast<uint2*>(plane(dst, 64, k >> 5, 1) + row * LDKB + (k & 31) * 2) = lo;
+            *reinterpret_cast<uint2*>(plane(dst, rows, k >> 5, 0) + row * LDKB + (k & 31) * 2) = hi;
+            *reinterpret_cast<uint2*>(plane(dst, rows, k >> 5, 1) + row * LDKB + (k & 31) * 2) = lo;
         }
     };
     // one 64-deep product of a wave's 32x32 block: A rows = tokens (wm0 + l31), B rows = output columns (wn0 + l31)
-    auto product = [&](const char* A, const char* B, mlp_f32x16& acc) __attribute__((always_inline)) {
+    auto product = [&](const char* A, int arows, const char* B, mlp_f32x16& acc) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int koff = (2 * ks + lhi) * 16;
-                const mlp_bf16x8 ah = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(A), 64, s, 0) + (wm0 + l31) * LDKB + koff));
-                const mlp_bf16x8 al = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(A), 64, s, 1) + (wm0 + l31) * LDKB + koff));
+                const mlp_bf16x8 ah = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(A), arows, s, 0) + (wm0 + l31) * LDKB + koff));
+                const mlp_bf16x8 al = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(A), arows, s, 1) + (wm0 + l31) * LDKB + koff));
                 const mlp_bf16x8 bh = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(B), 64, s, 0) + (wn0 + l31) * LDKB + koff));
                 const mlp_bf16x8 bl = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(plane(const_cast<char*>(B), 64, s, 1) + (wn0 + l31) * LDKB + koff));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc, 0, 0, 0);
@@ -95,8 +101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     // x tile (resident for the whole walk) and the first weight chunks
-    load_tile(r1, p.x, C, m0, p.M);
-    store_tile(r1, sX);
+    load_tile(rx, p.x, C, m0, p.M);
+    store_tile(rx, sX, BM);
     load_tile(r1, p.W1, C, 0, p.Hd);                       // W1 rows [0, 64), all C columns
     load_tile(r2, p.W2, p.Hd, 0, C);                       // W2 rows = all C outputs, columns [0, 64)
     mlp_f32x16 yacc;
@@ -105,36 +111,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int row = m0 + wm0 + l31;                        // the token row this lane's accumulator quads belong to
 
     for (int hc0 = 0; hc0 < p.Hd; hc0 += HC) {
-        store_tile(r1, sW1);
-        store_tile(r2, sW2);
+        store_tile(r1, sW1, 64);
+        store_tile(r2, sW2, 64);
         __syncthreads();
-        if (hc0 + HC < p.Hd) {                             // next chunk's weights in flight behind this chunk's arithmetic
+        if (hc0 + HC < p.Hd && !(p.abl & 2)) {             // next chunk's weights in flight behind this chunk's arithmetic
             load_tile(r1, p.W1 + (long)(hc0 + HC) * C, C, 0, p.Hd - (hc0 + HC));
             load_tile(r2, p.W2 + (hc0 + HC), p.Hd, 0, C);
         }
         mlp_f32x16 uacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) uacc[r] = 0.f;
-        product(sX, sW1, uacc);
+        product(sX, BM, sW1, uacc);
         // bias + GELU + dropout; h to HBM (float4 per quad) and to the LDS operand planes of the second product
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = wn0 + 8 * q + 4 * lhi, hd = hc0 + col;
             const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + hd);
-            float4 hv = make_float4(gelu_f(uacc[4 * q + 0] + b4.x), gelu_f(uacc[4 * q + 1] + b4.y),
-                                    gelu_f(uacc[4 * q + 2] + b4.z), gelu_f(uacc[4 * q + 3] + b4.w));
+            float4 hv = (p.abl & 4) ? make_float4(uacc[4 * q + 0] + b4.x, uacc[4 * q + 1] + b4.y, uacc[4 * q + 2] + b4.z, uacc[4 * q + 3] + b4.w)
+                                    : make_float4(gelu_f(uacc[4 * q + 0] + b4.x), gelu_f(uacc[4 * q + 1] + b4.y),
+                                                  gelu_f(uacc[4 * q + 2] + b4.z), gelu_f(uacc[4 * q + 3] + b4.w));
             if (p.drop) {
                 const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
                 hv.x *= ds.x; hv.y *= ds.y; hv.z *= ds.z; hv.w *= ds.w;
             }
-            if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = hv;
+            if (row < p.M && !(p.abl & 1)) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = hv;
             uint2 hi, lo;
             mlp_split(hv, hi, lo);
-            *reinterpret_cast<uint2*>(plane(sH, 64, col >> 5, 0) + (wm0 + l31) * LDKB + (col & 31) * 2) = hi;
-            *reinterpret_cast<uint2*>(plane(sH, 64, col >> 5, 1) + (wm0 + l31) * LDKB + (col & 31) * 2) = lo;
+            *reinterpret_cast<uint2*>(plane(sH, BM, col >> 5, 0) + (wm0 + l31) * LDKB + (col & 31) * 2) = hi;
+            *reinterpret_cast<uint2*>(plane(sH, BM, col >> 5, 1) + (wm0 + l31) * LDKB + (col & 31) * 2) = lo;
         }
         __syncthreads();
-        product(sH, sW2, yacc);
+        if (!(p.abl & 8)) product(sH, BM, sW2, yacc);
         __syncthreads();                                   // sW1 / sW2 / sH are rewritten by the next chunk
     }
 
@@ -301,6 +308,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
+int g_mlp_wide_min_tokens = 32768;       // tokens from which the 128-token tile is used (tuning hook: mdvit_mlp_config)
+int g_mlp_abl = 0;
+
+extern "C" int mdvit_mlp_config(int32_t wide_min_tokens, int32_t ablate) {
+    g_mlp_wide_min_tokens = wide_min_tokens > 0 ? wide_min_tokens : 0x7fffffff;
+    g_mlp_abl = ablate;
+    return MDVIT_OK;
+}
+
 extern "C" int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* res,
                                  const float* rowscale, int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd,
                                  float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed,
@@ -318,18 +334,22 @@ extern "C" int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b
     a.drop = drop_p > 0.f; a.k1a = key1_0; a.k1b = key1_1; a.k2a = key2_0; a.k2b = key2_1;
     a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
     a.seed = drop_seed;
-    constexpr size_t smem = (size_t)(2 + 2 + 2 + 2) * 2 * 64 * LDKB;          // X, W1c, Hc, W2c: 80 KB
+    a.abl = g_mlp_abl;
+    constexpr size_t smem64 = (size_t)(2 + 2 + 2 + 2) * 2 * 64 * LDKB;         // X, W1c, Hc, W2c at 64 tokens: 80 KB
+    constexpr size_t smem128 = (size_t)(4 + 2 + 4 + 2) * 2 * 64 * LDKB;        // 128 tokens: X and Hc double: 120 KB
     {   // the attribute is per DEVICE: one flag per device ordinal (a process may drive several GPUs)
         static bool attr_set[64] = {false};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!attr_set[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
             if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
             attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL((mlp_fwd_kernel<64>), dim3(cdiv(M, 64)), dim3(256), smem, (hipStream_t)stream, a);
+    if (M >= g_mlp_wide_min_tokens) hipLaunchKernelGGL((mlp_fwd_kernel<64, 128>), dim3(cdiv(M, 128)), dim3(512), smem128, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<64, 64>), dim3(cdiv(M, 64)), dim3(256), smem64, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

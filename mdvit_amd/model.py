@@ -198,6 +198,31 @@ class MDViT(_EncoderDecoder):
         return [logits, aux_out]
 
 
+    def _peer_heads(self, ds, parts, bparts, img_size):
+        """The G peer heads of a domain-batched forward.  They share nothing (each reads its own batch group of the trunk's
+        features through its own weights), so each runs on a stream of its own -- and so does its backward: autograd executes a
+        node's backward on the stream its forward ran on and orders the streams at the graph's edges."""
+        G = len(ds)
+        streams = [ops.peer_stream(g) for g in range(G)] if (G > 1 and parts[0][0].is_cuda) else [None] * G
+        if any(s is None for s in streams):
+            return [self._peer_out(dd, [pf[g] for pf in parts], bparts[g], img_size) for g, dd in enumerate(ds)]
+        main = torch.cuda.current_stream()
+        aux = []
+        for g, dd in enumerate(ds):
+            st = streams[g]
+            st.wait_stream(main)                                   # the trunk's features are complete
+            feats = [pf[g] for pf in parts]
+            for t in feats + ([bparts[g]] if bparts[g] is not None else []):
+                t.record_stream(st)                                # main-stream memory read on st: keep it until st is done with it
+            with torch.cuda.stream(st):
+                a = self._peer_out(dd, feats, bparts[g], img_size)
+            if a is not None:
+                a.record_stream(main)                              # consumed (concatenated, losses) on the main stream
+            aux.append(a)
+        for st in streams:
+            main.wait_stream(st)
+        return aux
+
     def _forward_domains(self, x, domain_label, ds, out_feat, out_seg):
         G = len(ds)
         if x.shape[0] % G:
@@ -207,7 +232,7 @@ class MDViT(_EncoderDecoder):
             return {"seg": None, "feat": self._pooled_feat(enc[3])}
         parts = [ops.split_groups(f, G) for f in enc + [dec4]]          # per feature: G batch views
         bparts = ops.split_groups(bridge_out, G) if self.decoder_name == "Transformer" else [None] * G
-        aux = [self._peer_out(dd, [pf[g] for pf in parts], bparts[g], img_size) for g, dd in enumerate(ds)]
+        aux = self._peer_heads(ds, parts, bparts, img_size)
         aux_out = None if any(a is None for a in aux) else torch.cat(aux, 0)
         if out_feat:
             return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}

@@ -143,6 +143,22 @@ def _sink_of(t):
     return _sinks.get((t.data_ptr(), t.numel()))
 
 
+# ---- peer streams: the G peer heads of a domain-batched forward are independent chains of small kernels --------------------
+# Each head (its forward, and -- because autograd runs a node's backward on the stream its forward ran on -- its backward too) goes
+# to a stream of its own, so the heads overlap each other instead of queueing behind each other on the main stream.
+_peer_streams = []
+_use_peer_streams = os.environ.get("MDVIT_PEER_STREAMS", "1") != "0"
+
+
+def peer_stream(i: int):
+    """the i-th peer stream, or None when disabled / capturing (a captured graph keeps the single-stream order)"""
+    if not _use_peer_streams or torch.cuda.is_current_stream_capturing():
+        return None
+    while len(_peer_streams) <= i:
+        _peer_streams.append(torch.cuda.Stream())
+    return _peer_streams[i]
+
+
 _side_keepalive = []     # tensors the side stream still reads; holding a reference also stops autograd from
                          # accumulating into them IN PLACE on the main stream (it only does so when it is the sole owner)
 _side_blocks = []        # (event recorded on the side stream after a block's launches, number of keep-alive entries up to there)
