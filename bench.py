@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base"], default="mdvit", help="mdvit_dsn: MDViT_DSN, domain-specific norms")
+    ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base", "transfuse"], default="mdvit",
+                    help="mdvit_dsn: MDViT_DSN, domain-specific norms; transfuse: TransFuse_S_adapt (BASELINE configs[4]: use --batch 8 --size 256)")
     ap.add_argument("--decoder", choices=["MLPFM", "MLP", "Transformer", "DeepLabV3"], default="MLPFM", help="peer heads (MDViT decoder_name); the headline config is MLPFM")
     ap.add_argument("--host-inputs", action="store_true",
                     help="PCIe-inclusive variant: every step's images (uint8 HWC) and labels (uint8) start in pinned host memory and cross to the "
@@ -216,6 +217,12 @@ def main():
         model = cls(img_size=args.size, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d,
                     adapt_method="Sup", num_domains=4, decoder_name=args.decoder).to(dev).train()
         domains, flop_per_img = (0, 1, 2, 3), 251.0e9
+    elif args.model == "transfuse":
+        from mdvit_amd.transfuse import TransFuse_S_adapt, transfuse_train_step
+        if args.size != 256:
+            raise SystemExit("TransFuse_S_adapt accepts 256x256 inputs only (DeiT.py:134): use --size 256")
+        model = TransFuse_S_adapt(num_classes=1, drop_rate=0.2, pretrained=False, num_domains=4).to(dev).train()      # multi_train_TransFuse.py's constructor defaults
+        domains, flop_per_img = (0, 1, 2, 3), 71.1e9          # ~11.86 GMAC forward per 256x256 image, x3 for the train step
     else:
         model = mdvit_amd.BASE(drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method=False).to(dev).train()
         domains, flop_per_img = (0,), 137.7e9
@@ -250,6 +257,8 @@ def main():
                  "out": round(float((o_b - o_ref).abs().max() / o_ref.abs().max()), 5), "aux": round(float((a_b - a_ref).abs().max() / a_ref.abs().max()), 5)}
 
     def step_batches(b):
+        if args.model == "transfuse":
+            return transfuse_train_step(model, b, optimizer=opt, accumulator=accum)
         if args.model != "base":
             return mdvit_train_step(model, b, optimizer=opt, accumulator=accum, merged_sweeps=not args.reference_sweeps, fuse_domains=fuse)
         return base_train_step(model, b, optimizer=opt, accumulator=accum)
@@ -324,7 +333,7 @@ def main():
     # fwd / bwd / optimizer split (the metric's "fwd+bwd ms"): two extra, untimed, instrumented steps -- each phase ends with an
     # event on the main stream (the backward's events come after the side stream has been joined)
     phase_ms = None
-    if args.model != "base" and not args.graph:
+    if args.model in ("mdvit", "mdvit_dsn") and not args.graph:
         acc_ms = {"fwd": 0.0, "bwd": 0.0, "opt": 0.0}
         reps = 2
         for i in range(reps):
@@ -405,13 +414,13 @@ def main():
             except Exception as e:
                 extra["block_bs32"] = {"error": repr(e)}
         line = {
-            "metric": "512x512 images/sec MDViT train step (fwd+bwd, two-sweep, AdamW)" if args.model == "mdvit" else
-                      ("512x512 images/sec MDViT_DSN train step" if args.model == "mdvit_dsn" else "512x512 images/sec BASE train step"),
+            "metric": {"mdvit": "512x512 images/sec MDViT train step (fwd+bwd, two-sweep, AdamW)", "mdvit_dsn": "512x512 images/sec MDViT_DSN train step",
+                       "base": "512x512 images/sec BASE train step", "transfuse": "256x256 images/sec TransFuse_S_adapt train step (fwd+bwd, structure_loss, AdamW)"}[args.model],
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (fp32 storage; GEMM operands split hi+lo bf16, fp32 accumulate)",
                       "bf16": "bf16 (GEMM operands one bf16 plane, one MFMA per product, fp32 accumulate; fp32 storage, norms and losses)"}[args.precision], "data": "synthetic" + (" (inputs cross PCIe inside the timed region)" if args.host_inputs else ""),
-            "config": {"workload": f"{ {'mdvit': 'MDViT Sup+' + args.decoder, 'mdvit_dsn': 'MDViT_DSN Sup+' + args.decoder, 'base': 'BASE'}[args.model] } train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
+            "config": {"workload": f"{ {'mdvit': 'MDViT Sup+' + args.decoder, 'mdvit_dsn': 'MDViT_DSN Sup+' + args.decoder, 'base': 'BASE', 'transfuse': 'TransFuse_S_adapt'}[args.model] } train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
             "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),

@@ -322,6 +322,62 @@ int mdvit_image_normalize_u8(const uint8_t* img_nhwc, float* out_nchw, int32_t B
 int mdvit_adamw_step(const void* table_dev, int32_t n_tensors, int32_t blocks_per_tensor, const float* lr_dev, float* step_dev,
                      float beta1, float beta2, float eps, float weight_decay, int32_t zero_grad, void* stream);
 
+/* ---- TransFuse_S_adapt path (BASELINE configs[4]; csrc/transfuse.hip) ------------------------------------------------------------
+ * What Models/Hybrid_models/TransFuseFolder/{TransFuse,vision_transformer,DeiT}.py and multi_train_TransFuse.py need beyond the MDViT
+ * kernels above (dense 3x3 / 1x1 convolutions, BatchNorm, LayerNorm, Linear / MLP GEMMs and the Domain Adapter are shared).  NHWC fp32. */
+/* ResNet conv1: KxK stride 2 pad K/2 on the NCHW image -> NHWC (torchvision resnet conv1; TransFuse.py:243).  ksize = 7, in_chans = 3.
+ * wgrad ws: mdvit_partials_ws_bytes(147 * Cout) */
+int mdvit_imgconv_fwd(const float* img, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t in_chans, int32_t Cout, int32_t ksize, void* stream);
+int mdvit_imgconv_wgrad(const float* img, const float* dy, float* dw, void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t in_chans,
+                        int32_t Cout, int32_t ksize, int32_t accumulate, void* stream);
+/* nn.MaxPool2d(3, 2, 1) (TransFuse.py:246); idx: uint8 winning tap per output element */
+int mdvit_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int mdvit_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* bilinear resize with align_corners=True (nn.Upsample in Up, TransFuse.py:528; F.interpolate of the heads, :267-269) */
+int mdvit_resize_ac_fwd(const float* x, float* y, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+int mdvit_resize_ac_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+/* element-wise, n elements.  mode 0: y = relu(a + b) (b optional)   1: y = a * b   2: y = a * (b > 0)   3: y = a + b
+ * (BasicBlock / DoubleConv / Attention_block add+ReLU: TransFuse.py:598,573; W_g*W_x: :57; their backward) */
+int mdvit_ew(const float* a, const float* b, float* y, int64_t n, int32_t mode, void* stream);
+/* y[b, r] = x[b, r] + pe[r] (DeiT_adapt.forward x + pos_embed, DeiT.py:63-65); out[r] = sum_b g[b, r] (its gradient) */
+int mdvit_add_bcast(const float* x, const float* pe, float* y, int32_t B, int64_t R, void* stream);
+int mdvit_sum_batch(const float* g, float* out, int32_t B, int64_t R, void* stream);
+/* y = sigmoid(s) * x on x [B, P, C]; mode 0: s [B, P] (spatial attention / Attention_block psi: TransFuse.py:63,576), mode 1: s [B, C]
+ * (SE channel attention: :71).  bwd: dx = g sigmoid(s), ds = sigmoid'(s) * sum (g x) over the broadcast axis */
+int mdvit_gate_fwd(const float* x, const float* s, float* y, int32_t B, int64_t P, int32_t C, int32_t mode, void* stream);
+int mdvit_gate_bwd(const float* g, const float* x, const float* s, float* dx, float* ds, int32_t B, int64_t P, int32_t C, int32_t mode, void* stream);
+/* ChannelPool (TransFuse.py:20-22): x [M, C] -> y [M, 2] = (max_c, mean_c); idx [M] int32 argmax */
+int mdvit_chanpool_fwd(const float* x, float* y, int32_t* idx, int64_t M, int32_t C, void* stream);
+int mdvit_chanpool_bwd(const float* dy, const int32_t* idx, float* dx, int64_t M, int32_t C, void* stream);
+/* BiFusion_block.spatial: 7x7 conv, 2 -> 1 channels, pad 3, no bias (TransFuse.py:37): x [B,H,W,2], w [1,2,7,7] -> y [B,H,W] */
+int mdvit_conv7x7_2to1_fwd(const float* x, const float* w, float* y, int32_t B, int32_t H, int32_t W, void* stream);
+int mdvit_conv7x7_2to1_bwd(const float* dy, const float* x, const float* w, float* dx /* optional */, float* dw /* optional, [98] */, int32_t B, int32_t H,
+                           int32_t W, void* stream);
+/* BatchNorm2d(1) (spatial.bn, psi.1): x [M] -> y [M]; stat [2] = (mean, rstd) kept for the backward; dgamma_dbeta [2] */
+int mdvit_bn1_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* num_batches_tracked, float* y,
+                  float* stat, int64_t M, int32_t training, float eps, float momentum, void* stream);
+int mdvit_bn1_bwd(const float* g, const float* x, const float* gamma, const float* stat, float* dx, float* dgamma_dbeta, int64_t M, int32_t training, void* stream);
+/* every second pixel (the 1x1 stride-2 shortcut convs of ResNet layer2.0 / layer3.0); backward = 1: scatter src [B,H/2,W/2,C] into dst [B,H,W,C] */
+int mdvit_subsample2(const float* src, float* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t backward, void* stream);
+/* PatchEmbed's gather (vision_transformer.py:233-240): NCHW image -> [B (H/p) (W/p), Cin p p] rows in (c, ky, kx) order (then a Linear) */
+int mdvit_patchify(const float* img, float* out, int32_t B, int32_t in_chans, int32_t H, int32_t W, int32_t patch, void* stream);
+/* nn.Dropout2d on x [B, P, C]: one keep decision per (sample, channel); the backward is the same call on the gradient */
+int mdvit_dropout2d(const float* x, float* y, int32_t B, int64_t P, int32_t C, float p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, void* stream);
+/* Attention_Sup core (vision_transformer.py:148-169): out[b,n,(h d)] = a[b,(h d)] * (softmax(q k^T / sqrt(d)) v)[b,h,n,d] from qkv [B,N,3C]
+ * (q|k|v, channel = head * 64 + d); a [B, C] = the Domain Adapter's head-softmax (mdvit_da_fwd) or NULL.  P [B,heads,N,N] (softmax
+ * probabilities) is kept for the backward; dS: scratch of the same size.  e [B, C] = a * dL/da = sum_n g out (input of mdvit_da_bwd).
+ * head dimension 64, N <= 256. */
+int mdvit_sdpa_fwd(const float* qkv, const float* a, float* out, float* P, int32_t B, int32_t N, int32_t C, int32_t heads, void* stream);
+int mdvit_sdpa_bwd(const float* g, const float* qkv, const float* P, const float* out, const float* a, float* dqkv, float* e, float* dS, int32_t B, int32_t N,
+                   int32_t C, int32_t heads, void* stream);
+/* structure_loss (multi_train_TransFuse.py:29-38): weit = 1 + 5 |avg_pool2d(mask, 31, 1, 15) - mask| (tmp: scratch [B,H,W]);
+ * loss = mean_b [ sum(weit bce_with_logits) / sum(weit) + 1 - (I + 1) / (U - I + 1) ], I = sum(sigmoid(pred) mask weit), U = sum((sigmoid(pred) + mask) weit);
+ * sums [B][4] double kept for the backward; gscale [1] = upstream gradient of the scalar loss */
+int mdvit_structure_weight(const float* mask, float* tmp, float* weit, int32_t B, int32_t H, int32_t W, void* stream);
+int mdvit_structure_loss_fwd(const float* pred, const float* mask, const float* weit, double* sums, float* loss, int32_t B, int64_t HW, void* stream);
+int mdvit_structure_loss_bwd(const float* pred, const float* mask, const float* weit, const double* sums, const float* gscale, float* dpred, int32_t B, int64_t HW,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

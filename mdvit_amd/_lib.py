@@ -73,6 +73,31 @@ _SIGS = {
     "mdvit_gemm_planes_plan": [C.POINTER(PlaneGemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_planes_force_plan": [i32, i32],
     "mdvit_mlp_config": [i32, i32],
+    "mdvit_imgconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_imgconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_maxpool3x3s2_fwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_maxpool3x3s2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_resize_ac_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_resize_ac_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_ew": [vp, vp, vp, i64, i32, vp],
+    "mdvit_add_bcast": [vp, vp, vp, i32, i64, vp],
+    "mdvit_sum_batch": [vp, vp, i32, i64, vp],
+    "mdvit_gate_fwd": [vp, vp, vp, i32, i64, i32, i32, vp],
+    "mdvit_gate_bwd": [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp],
+    "mdvit_chanpool_fwd": [vp, vp, vp, i64, i32, vp],
+    "mdvit_chanpool_bwd": [vp, vp, vp, i64, i32, vp],
+    "mdvit_conv7x7_2to1_fwd": [vp, vp, vp, i32, i32, i32, vp],
+    "mdvit_conv7x7_2to1_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "mdvit_bn1_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
+    "mdvit_bn1_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "mdvit_subsample2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_patchify": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "mdvit_dropout2d": [vp, vp, i32, i64, i32, f32, u32, u32, vp, vp],
+    "mdvit_sdpa_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_sdpa_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_structure_weight": [vp, vp, vp, i32, i32, i32, vp],
+    "mdvit_structure_loss_fwd": [vp, vp, vp, vp, vp, i32, i64, vp],
+    "mdvit_structure_loss_bwd": [vp, vp, vp, vp, vp, vp, i32, i64, vp],
     "mdvit_split_planes": [vp, i64, vp, i64, i64, i64, i32, i32, vp],
     "mdvit_split_planes_many": [vp, i32, i32, i32, vp],
     "mdvit_split_planes_t": [vp, i64, vp, i64, i64, i32, i32, i32, i32, vp],

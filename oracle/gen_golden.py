@@ -314,12 +314,48 @@ def gen_losses(ns, seed=5):
             "d_out_from_uni": o.grad.numpy().copy(), "d_aux_from_uni": a.grad.numpy().copy()}
 
 
+def gen_transfuse_step(ns_unused=None, S=256, B=2, seed=12):
+    """BASELINE configs[4]: the reference's TransFuse_S_adapt (drop_rate = 0, train mode) on two domains x B images at its only legal size
+    256x256 (TransFuse.py:228-270), step loss 0.5 SL(map_2) + 0.3 SL(map_1) + 0.2 SL(map_x) with structure_loss
+    (multi_train_TransFuse.py:29-38,162-172), ONE backward of the sum (:186-189)."""
+    from .ref_import import import_transfuse
+    from . import transfuse_ref as T
+    tf = import_transfuse()
+    pn = T.make_params(seed)
+    m = tf.TransFuse_S_adapt(num_classes=1, drop_rate=0.0, normal_init=False, pretrained=False, num_domains=4)
+    sd = m.state_dict()
+    assert set(sd) == set(pn), (sorted(set(sd) - set(pn))[:5], sorted(set(pn) - set(sd))[:5])
+    load_params_into(m, pn)
+    m.train()
+    out = {"n_state_dict_keys": np.array(len(sd)), "meta": np.array([S, B, seed])}
+    tot = 0.0
+    for di, d in enumerate((1, 3)):
+        img, lab = synth_image(1200 + d, B, S, S), synth_label(1300 + d, B, S, S)
+        dl = F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float()
+        m4, m3, m2 = m(img, dl)
+        l = 0.5 * T.structure_loss(m2, lab) + 0.3 * T.structure_loss(m3, lab) + 0.2 * T.structure_loss(m4, lab)
+        out[f"loss_{d}"] = np.array(float(l))
+        for nm, t in (("map_x", m4), ("map_1", m3), ("map_2", m2)):
+            out[f"{nm}_{d}"] = _sample(t, 61)
+            out[f"{nm}_{d}_sum"] = np.array([float(t.double().sum()), float(t.double().abs().sum())])
+        tot = tot + l
+    tot.backward()
+    names, norms, heads = grad_digest({n: p.grad for n, p in m.named_parameters()})
+    out["grad_names"] = np.array(names); out["grad_norms"] = norms; out["grad_heads"] = heads
+    for n in ("resnet.conv1.weight", "resnet.layer3.5.conv2.weight", "transformer.blocks.0.attn.domain_layer.2.weight", "transformer.blocks.7.attn.qkv.weight",
+              "transformer.pos_embed", "up_c.spatial.conv.weight", "up_c_1_2.attn_block.psi.0.weight", "final_x.2.conv.weight", "up_c.fc1.weight"):
+        out["grad__" + n] = dict(m.named_parameters())[n].grad.reshape(-1)[::7].numpy().copy()
+    for k in ("resnet.bn1.running_mean", "up_c.residual.bn1.running_var", "up_c_2_2.attn_block.psi.1.running_mean"):
+        out["buf__" + k] = m.state_dict()[k].numpy().copy()
+    return out
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    jobs = {"base_dsn_step_64": gen_base_dsn_step, "mdvit_deeplab_step_64": gen_mdvit_deeplab_step, "mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
+    jobs = {"transfuse_step_256": gen_transfuse_step, "base_dsn_step_64": gen_base_dsn_step, "mdvit_deeplab_step_64": gen_mdvit_deeplab_step, "mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
             "base_step_64": gen_base_step, "factoratt_small": gen_factoratt, "losses_small": gen_losses}
     only = set(sys.argv[1:])
     for name, fn in jobs.items():

@@ -110,3 +110,77 @@ def load_params_into(module, params_np, strict_unique: bool = True):
         for k, v in params_np.items():
             sd[k].copy_(torch.from_numpy(v))
     return module
+
+
+# ---- TransFuse (BASELINE configs[4]) ------------------------------------------------------------------------------------------
+def _install_torchvision_stub():
+    """`from torchvision.models import resnet34, resnet50` (TransFuse.py:3-4).  torchvision is not installed: the stub is the
+    published ResNet architecture (He et al. 2016; torchvision.models.resnet: 7x7/2 stem + BN + ReLU + 3x3/2 max-pool, BasicBlock
+    stages [3, 4, 6, 3] at 64/128/256/512 channels, stride-2 first block with a 1x1 stride-2 conv + BN shortcut) under
+    torchvision's module names (conv1, bn1, layer{1..4}.{i}.conv{1,2} / bn{1,2} / downsample.{0,1}, fc), so that checkpoints of
+    the reference keep their keys.  resnet50 is only imported, never built by TransFuse_S_adapt."""
+    if "torchvision" in sys.modules:
+        return
+    import torch
+    from torch import nn
+
+    class BasicBlock(nn.Module):
+        def __init__(self, inp, out, stride=1):
+            super().__init__()
+            self.conv1 = nn.Conv2d(inp, out, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(out)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(out, out, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(out)
+            self.downsample = None
+            if stride != 1 or inp != out:
+                self.downsample = nn.Sequential(nn.Conv2d(inp, out, 1, stride, bias=False), nn.BatchNorm2d(out))
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            y = self.relu(self.bn1(self.conv1(x)))
+            y = self.bn2(self.conv2(y))
+            return self.relu(y + idt)
+
+    class ResNet34(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            chans, depth, inp = (64, 128, 256, 512), (3, 4, 6, 3), 64
+            for i, (c, n) in enumerate(zip(chans, depth), start=1):
+                blocks = [BasicBlock(inp, c, 1 if i == 1 else 2)] + [BasicBlock(c, c) for _ in range(n - 1)]
+                setattr(self, f"layer{i}", nn.Sequential(*blocks))
+                inp = c
+            self.avgpool = nn.AdaptiveAvgPool2d(1)
+            self.fc = nn.Linear(512, 1000)
+
+    def resnet34(*a, **k):
+        return ResNet34()
+
+    def resnet50(*a, **k):
+        raise NotImplementedError("resnet50 is not needed by TransFuse_S_adapt")
+
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvm.resnet34, tvm.resnet50 = resnet34, resnet50
+    tv.models = tvm
+    tv._mdvit_stub = True
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+
+
+def import_transfuse():
+    """-> the reference's TransFuse_S_adapt class and structure_loss (multi_train_TransFuse.py:29-38 restated: that script runs its
+    training at import time and cannot be imported)."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present (only available in the build container)")
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    _install_torchvision_stub()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from Models.Hybrid_models.TransFuseFolder import TransFuse as ref_tf
+    return types.SimpleNamespace(TransFuse_S_adapt=ref_tf.TransFuse_S_adapt, module=ref_tf)

@@ -249,3 +249,36 @@ def test_mdvit_dsn_two_sweep_step(golden):
     for key in g.files:
         if key.startswith("grad::"):
             close(grads[key[6:]], g[key], rtol=1e-3, name=key)
+
+
+def test_transfuse_oracle_vs_golden(golden):
+    """oracle/transfuse_ref.py (TransFuse_S_adapt + structure_loss restated, ResNet-34 restated) against the fixture the reference's own
+    TransFuse_S_adapt produced: 630 state_dict names, the three logit maps of two domains, the step losses, the norm and head of
+    every one of the gradient tensors, BatchNorm running statistics."""
+    from oracle import transfuse_ref as T
+    from oracle.gen_golden import synth_image, synth_label, grad_digest
+    g = golden("transfuse_step_256")
+    S, B, seed = [int(v) for v in g["meta"]]
+    pn = T.make_params(seed)
+    assert len(pn) == int(g["n_state_dict_keys"]) == 630
+    assert abs(sum(v.size for k, v in pn.items() if v.dtype.kind == "f" and "running_" not in k) - 26.873877e6) < 1
+    P = T.to_torch(pn)
+    batches = [(synth_image(1200 + d, B, S, S), synth_label(1300 + d, B, S, S), d) for d in (1, 3)]
+    with torch.no_grad():
+        for img, lab, d in batches:
+            dl = torch.nn.functional.one_hot(torch.full((B,), d, dtype=torch.long), 4).float()
+            m4, m3, m2 = T.transfuse_forward({k: v.clone() for k, v in P.items()}, img, dl, T.TFState(training=True))
+            for nm, t in (("map_x", m4), ("map_1", m3), ("map_2", m2)):
+                ref = g[f"{nm}_{d}"]
+                got = t.reshape(-1)[::61].numpy()
+                assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), (nm, d)
+    losses, grads = T.transfuse_train_step(P, batches, T.TFState(training=True))
+    for l, d in zip(losses, (1, 3)):
+        assert abs(l - float(g[f"loss_{d}"])) <= 2e-4 * abs(float(g[f"loss_{d}"]))
+    names, norms, heads = grad_digest(grads)
+    assert list(names) == [str(n) for n in g["grad_names"]]
+    ref = g["grad_norms"]
+    rel = np.abs(norms - ref) / np.maximum(ref, 1e-6 * ref.max())
+    assert rel.max() < 5e-3, (names[int(rel.argmax())], float(rel.max()))
+    for k in ("resnet.bn1.running_mean", "up_c.residual.bn1.running_var", "up_c_2_2.attn_block.psi.1.running_mean"):
+        assert np.abs(P[k].numpy() - g["buf__" + k]).max() <= 2e-4 * max(np.abs(g["buf__" + k]).max(), 1e-6), k
