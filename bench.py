@@ -258,7 +258,7 @@ def main():
 
     def step_batches(b):
         if args.model == "transfuse":
-            return transfuse_train_step(model, b, optimizer=opt, accumulator=accum)
+            return transfuse_train_step(model, b, optimizer=opt, accumulator=accum, fuse_domains=args.fuse_images >= len(domains) * args.batch)
         if args.model != "base":
             return mdvit_train_step(model, b, optimizer=opt, accumulator=accum, merged_sweeps=not args.reference_sweeps, fuse_domains=fuse)
         return base_train_step(model, b, optimizer=opt, accumulator=accum)

@@ -330,6 +330,8 @@ int mdvit_adamw_step(const void* table_dev, int32_t n_tensors, int32_t blocks_pe
 int mdvit_imgconv_fwd(const float* img, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t in_chans, int32_t Cout, int32_t ksize, void* stream);
 int mdvit_imgconv_wgrad(const float* img, const float* dy, float* dw, void* ws, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t in_chans,
                         int32_t Cout, int32_t ksize, int32_t accumulate, void* stream);
+/* the same conv's im2col: col [B Ho Wo, ldc] with columns (ci, kh, kw) zero-padded to ldc (>= 147, % 4 == 0): stem conv and weight gradient as GEMMs */
+int mdvit_imgconv_im2col(const float* img, float* col, int32_t B, int32_t H, int32_t W, int32_t in_chans, int32_t ksize, int32_t ldc, void* stream);
 /* nn.MaxPool2d(3, 2, 1) (TransFuse.py:246); idx: uint8 winning tap per output element */
 int mdvit_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int mdvit_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
@@ -345,7 +347,9 @@ int mdvit_sum_batch(const float* g, float* out, int32_t B, int64_t R, void* stre
 /* y = sigmoid(s) * x on x [B, P, C]; mode 0: s [B, P] (spatial attention / Attention_block psi: TransFuse.py:63,576), mode 1: s [B, C]
  * (SE channel attention: :71).  bwd: dx = g sigmoid(s), ds = sigmoid'(s) * sum (g x) over the broadcast axis */
 int mdvit_gate_fwd(const float* x, const float* s, float* y, int32_t B, int64_t P, int32_t C, int32_t mode, void* stream);
-int mdvit_gate_bwd(const float* g, const float* x, const float* s, float* dx, float* ds, int32_t B, int64_t P, int32_t C, int32_t mode, void* stream);
+size_t mdvit_gate_bwd_ws_bytes(int32_t B, int64_t P, int32_t C, int32_t mode);
+int mdvit_gate_bwd(const float* g, const float* x, const float* s, float* dx, float* ds, void* ws, size_t ws_bytes, int32_t B, int64_t P, int32_t C, int32_t mode,
+                   void* stream);
 /* ChannelPool (TransFuse.py:20-22): x [M, C] -> y [M, 2] = (max_c, mean_c); idx [M] int32 argmax */
 int mdvit_chanpool_fwd(const float* x, float* y, int32_t* idx, int64_t M, int32_t C, void* stream);
 int mdvit_chanpool_bwd(const float* dy, const int32_t* idx, float* dx, int64_t M, int32_t C, void* stream);
@@ -353,10 +357,12 @@ int mdvit_chanpool_bwd(const float* dy, const int32_t* idx, float* dx, int64_t M
 int mdvit_conv7x7_2to1_fwd(const float* x, const float* w, float* y, int32_t B, int32_t H, int32_t W, void* stream);
 int mdvit_conv7x7_2to1_bwd(const float* dy, const float* x, const float* w, float* dx /* optional */, float* dw /* optional, [98] */, int32_t B, int32_t H,
                            int32_t W, void* stream);
-/* BatchNorm2d(1) (spatial.bn, psi.1): x [M] -> y [M]; stat [2] = (mean, rstd) kept for the backward; dgamma_dbeta [2] */
+/* BatchNorm2d(1) (spatial.bn, psi.1): x [M] -> y [M]; `groups` equal consecutive slices keep their own statistics (the domain-batched forward);
+ * stat [groups][2] = (mean, rstd) kept for the backward; dgamma_dbeta [2] */
 int mdvit_bn1_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* num_batches_tracked, float* y,
-                  float* stat, int64_t M, int32_t training, float eps, float momentum, void* stream);
-int mdvit_bn1_bwd(const float* g, const float* x, const float* gamma, const float* stat, float* dx, float* dgamma_dbeta, int64_t M, int32_t training, void* stream);
+                  float* stat, int64_t M, int32_t groups, int32_t training, float eps, float momentum, void* stream);
+int mdvit_bn1_bwd(const float* g, const float* x, const float* gamma, const float* stat, float* dx, float* dgamma_dbeta, int64_t M, int32_t groups, int32_t training,
+                  void* stream);
 /* every second pixel (the 1x1 stride-2 shortcut convs of ResNet layer2.0 / layer3.0); backward = 1: scatter src [B,H/2,W/2,C] into dst [B,H,W,C] */
 int mdvit_subsample2(const float* src, float* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t backward, void* stream);
 /* PatchEmbed's gather (vision_transformer.py:233-240): NCHW image -> [B (H/p) (W/p), Cin p p] rows in (c, ky, kx) order (then a Linear) */

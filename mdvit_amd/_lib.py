@@ -83,13 +83,14 @@ _SIGS = {
     "mdvit_add_bcast": [vp, vp, vp, i32, i64, vp],
     "mdvit_sum_batch": [vp, vp, i32, i64, vp],
     "mdvit_gate_fwd": [vp, vp, vp, i32, i64, i32, i32, vp],
-    "mdvit_gate_bwd": [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp],
+    "mdvit_gate_bwd": [vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i64, i32, i32, vp],
+    "mdvit_imgconv_im2col": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_chanpool_fwd": [vp, vp, vp, i64, i32, vp],
     "mdvit_chanpool_bwd": [vp, vp, vp, i64, i32, vp],
     "mdvit_conv7x7_2to1_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "mdvit_conv7x7_2to1_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "mdvit_bn1_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
-    "mdvit_bn1_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "mdvit_bn1_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, vp],
+    "mdvit_bn1_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "mdvit_subsample2": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_patchify": [vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_dropout2d": [vp, vp, i32, i64, i32, f32, u32, u32, vp, vp],
@@ -175,6 +176,8 @@ def load():
     lib.mdvit_factoratt_ws_bytes.argtypes = [i32, i32, i32, i32]
     lib.mdvit_gemm_ws_bytes.restype = C.c_size_t
     lib.mdvit_gemm_ws_bytes.argtypes = [C.POINTER(GemmDesc)]
+    lib.mdvit_gate_bwd_ws_bytes.restype = C.c_size_t
+    lib.mdvit_gate_bwd_ws_bytes.argtypes = [i32, i64, i32, i32]
     lib.mdvit_gemm_planes_ws_bytes.restype = C.c_size_t
     lib.mdvit_gemm_planes_ws_bytes.argtypes = [C.POINTER(PlaneGemmDesc)]
     lib.mdvit_bn_ws_bytes.restype = C.c_size_t

@@ -74,6 +74,29 @@ __global__ __launch_bounds__(256) void imgconv_wgrad_kernel(const float* __restr
     }
 }
 
+// im2col of the same conv (rows = output pixels, columns (ci, kh, kw) padded to ldc with zeros): the stem conv and its weight gradient
+// then run as GEMMs on the matrix cores (the direct kernels above: 0.3 ms forward, 3 ms weight gradient at 8 x 256 x 256)
+template <int CIN, int KS>
+__global__ __launch_bounds__(256) void imgconv_im2col_kernel(const float* __restrict__ img, float* __restrict__ col, int B, int H, int W, int ldc) {
+    constexpr int KK = CIN * KS * KS, PAD = KS / 2;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)B * Ho * Wo * ldc;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e % ldc);
+        long r = e / ldc;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float v = 0.f;
+        if (k < KK) {
+            const int ci = k / (KS * KS), kh = (k / KS) % KS, kw = k % KS;
+            const int hi = 2 * ho + kh - PAD, wi = 2 * wo + kw - PAD;
+            if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = img[(((long)b * CIN + ci) * H + hi) * W + wi];
+        }
+        col[e] = v;
+    }
+}
+
 // ---- max-pool 3x3 stride 2 pad 1 (NHWC); idx = winning tap 0..8 (first maximum in (kh, kw) order, as ATen) -----------------------
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
                                                           int B, int H, int W, int C) {
@@ -147,22 +170,37 @@ __global__ __launch_bounds__(256) void resize_ac_fwd_kernel(const float* __restr
         y[e] = (1.f - fh) * ((1.f - fw) * v00 + fw * v01) + fh * ((1.f - fw) * v10 + fw * v11);
     }
 }
+// backward as a GATHER (deterministic, no atomics): input pixel (hi, wi) collects from every output pixel whose two taps include it
 __global__ __launch_bounds__(256) void resize_ac_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int C) {
-    const long total = (long)B * Ho * Wo * C;
+    const long total = (long)B * Hi * Wi * C;
+    const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         long r = e / C;
-        const int wo = (int)(r % Wo); r /= Wo;
-        const int ho = (int)(r % Ho);
-        const int b = (int)(r / Ho);
-        int h0, h1, w0, w1; float fh, fw;
-        ac_coord(ho, Hi, Ho, h0, h1, fh); ac_coord(wo, Wi, Wo, w0, w1, fw);
-        float* xb = dx + (long)b * Hi * Wi * C + c;
-        const float g = dy[e];
-        atomicAdd(xb + ((long)h0 * Wi + w0) * C, g * (1.f - fh) * (1.f - fw));
-        atomicAdd(xb + ((long)h0 * Wi + w1) * C, g * (1.f - fh) * fw);
-        atomicAdd(xb + ((long)h1 * Wi + w0) * C, g * fh * (1.f - fw));
-        atomicAdd(xb + ((long)h1 * Wi + w1) * C, g * fh * fw);
+        const int wi = (int)(r % Wi); r /= Wi;
+        const int hi = (int)(r % Hi);
+        const int b = (int)(r / Hi);
+        // candidate output rows: src = ho * sh in (hi - 1, hi + 1)
+        const int ho_lo = sh > 0.f ? max(0, (int)floorf((float)(hi - 1) / sh) - 1) : 0, ho_hi = sh > 0.f ? min(Ho - 1, (int)ceilf((float)(hi + 1) / sh) + 1) : Ho - 1;
+        const int wo_lo = sw > 0.f ? max(0, (int)floorf((float)(wi - 1) / sw) - 1) : 0, wo_hi = sw > 0.f ? min(Wo - 1, (int)ceilf((float)(wi + 1) / sw) + 1) : Wo - 1;
+        float acc = 0.f;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            int h0, h1; float fh;
+            ac_coord(ho, Hi, Ho, h0, h1, fh);
+            float wh = 0.f;
+            if (h0 == hi) wh += 1.f - fh;
+            if (h1 == hi) wh += fh;
+            if (wh == 0.f) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                int w0, w1; float fw;
+                ac_coord(wo, Wi, Wo, w0, w1, fw);
+                float ww = 0.f;
+                if (w0 == wi) ww += 1.f - fw;
+                if (w1 == wi) ww += fw;
+                if (ww != 0.f) acc = fmaf(dy[(((long)b * Ho + ho) * Wo + wo) * C + c], wh * ww, acc);
+            }
+        }
+        dx[e] = acc;
     }
 }
 
@@ -215,15 +253,17 @@ __global__ __launch_bounds__(256) void gate_bwd_spatial_kernel(const float* __re
         if (lane == 0) ds[pix] = acc * sg * (1.f - sg);
     }
 }
-// channel: ds[b,c] = sig (1 - sig) * sum_p g x ; block = (b, 64 channels), 4 pixel lanes, fixed-order LDS reduction
+// channel: ds[b,c] = sig (1 - sig) * sum_p g x.  Pass 1: block = (64 channels, pixel chunk, b) writes dx and ONE partial row per chunk;
+// pass 2 adds the chunks in order and applies sigmoid'.
 __global__ __launch_bounds__(256) void gate_bwd_channel_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ s,
-                                                               float* __restrict__ dx, float* __restrict__ ds, long P, int C) {
+                                                               float* __restrict__ dx, float* __restrict__ part, long P, int C, int chunk) {
     __shared__ float red[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    float acc = 0.f, sg = 0.f;
+    const int b = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    const long p0 = (long)blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+    float acc = 0.f;
     if (c < C) {
-        sg = sigmoidf_(s[(long)b * C + c]);
-        for (long p = pl; p < P; p += 4) {
+        const float sg = sigmoidf_(s[(long)b * C + c]);
+        for (long p = p0 + pl; p < p1; p += 4) {
             const long o = ((long)b * P + p) * C + c;
             const float gv = g[o];
             dx[o] = gv * sg;
@@ -232,7 +272,17 @@ __global__ __launch_bounds__(256) void gate_bwd_channel_kernel(const float* __re
     }
     red[pl][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (pl == 0 && c < C) ds[(long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * sg * (1.f - sg);
+    if (pl == 0 && c < C)
+        part[((long)b * gridDim.y + blockIdx.y) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void gate_bwd_channel_final_kernel(const float* __restrict__ part, const float* __restrict__ s, float* __restrict__ ds, int B, int C, int nchunk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float acc = 0.f;
+    for (int k = 0; k < nchunk; ++k) acc += part[((long)b * nchunk + k) * C + c];
+    const float sg = sigmoidf_(s[i]);
+    ds[i] = acc * sg * (1.f - sg);
 }
 // ChannelPool (TransFuse.py:20-22): y[m] = (max_c x, mean_c x); idx = first argmax.  One wave per pixel.
 __global__ __launch_bounds__(256) void chanpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ idx, long M, int C) {
@@ -321,52 +371,69 @@ __global__ __launch_bounds__(256) void conv7_wgrad_kernel(const float* __restric
     if (threadIdx.x == 0) dw[k] = (float)red[0];
 }
 
-// ---- BatchNorm over ONE channel (spatial.bn, psi.1): a single workgroup; statistics in double -----------------------------------
+// ---- BatchNorm over ONE channel (spatial.bn, psi.1): a single workgroup; statistics in double.  `groups` equal consecutive slices of
+// the batch are normalised separately, in order (the domain-batched forward: each domain batch keeps its own statistics and the running
+// statistics are updated once per domain batch, as four separate forwards would)
 __global__ __launch_bounds__(1024) void bn1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ rm, float* __restrict__ rv, long long* __restrict__ nbt, float* __restrict__ y,
-                                                       float* __restrict__ stat /* mean, rstd */, long M, int training, float eps, float momentum) {
+                                                       float* __restrict__ stat /* [groups][mean, rstd] */, long M, int groups, int training, float eps, float momentum) {
     __shared__ double r1[1024], r2[1024];
     __shared__ float s_mean, s_rstd;
-    if (training) {
-        double a = 0.0, b = 0.0;
-        for (long e = threadIdx.x; e < M; e += 1024) { const double v = x[e]; a += v; b += v * v; }
-        r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+    const long Mg = M / groups;
+    const float ga = gamma[0], be = beta[0];
+    for (int gidx = 0; gidx < groups; ++gidx) {
+        const float* xg = x + gidx * Mg;
+        float* yg = y + gidx * Mg;
         __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; } __syncthreads(); }
-        if (threadIdx.x == 0) {
-            const double mean = r1[0] / (double)M;
-            double var = r2[0] / (double)M - mean * mean; var = var > 0.0 ? var : 0.0;
-            s_mean = (float)mean; s_rstd = (float)(1.0 / sqrt(var + (double)eps));
-            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            rm[0] = (1.f - momentum) * rm[0] + momentum * (float)mean;
-            rv[0] = (1.f - momentum) * rv[0] + momentum * (float)unbiased;
-            if (nbt) nbt[0] += 1;
+        if (training) {
+            double a = 0.0, b = 0.0;
+            for (long e = threadIdx.x; e < Mg; e += 1024) { const double v = xg[e]; a += v; b += v * v; }
+            r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+            __syncthreads();
+            for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; } __syncthreads(); }
+            if (threadIdx.x == 0) {
+                const double mean = r1[0] / (double)Mg;
+                double var = r2[0] / (double)Mg - mean * mean; var = var > 0.0 ? var : 0.0;
+                s_mean = (float)mean; s_rstd = (float)(1.0 / sqrt(var + (double)eps));
+                const double unbiased = Mg > 1 ? var * (double)Mg / (double)(Mg - 1) : var;
+                rm[0] = (1.f - momentum) * rm[0] + momentum * (float)mean;
+                rv[0] = (1.f - momentum) * rv[0] + momentum * (float)unbiased;
+                if (nbt) nbt[0] += 1;
+            }
+        } else if (threadIdx.x == 0) {
+            s_mean = rm[0]; s_rstd = 1.f / sqrtf(rv[0] + eps);
         }
-    } else if (threadIdx.x == 0) {
-        s_mean = rm[0]; s_rstd = 1.f / sqrtf(rv[0] + eps);
+        __syncthreads();
+        const float mean = s_mean, rstd = s_rstd;
+        if (threadIdx.x == 0) { stat[2 * gidx] = mean; stat[2 * gidx + 1] = rstd; }
+        for (long e = threadIdx.x; e < Mg; e += 1024) yg[e] = (xg[e] - mean) * rstd * ga + be;
     }
-    __syncthreads();
-    const float mean = s_mean, rstd = s_rstd, ga = gamma[0], be = beta[0];
-    if (threadIdx.x == 0) { stat[0] = mean; stat[1] = rstd; }
-    for (long e = threadIdx.x; e < M; e += 1024) y[e] = (x[e] - mean) * rstd * ga + be;
 }
 __global__ __launch_bounds__(1024) void bn1_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ stat, float* __restrict__ dx, float* __restrict__ dgb /* dgamma, dbeta */,
-                                                       long M, int training) {
+                                                       long M, int groups, int training) {
     __shared__ double r1[1024], r2[1024];
-    const float mean = stat[0], rstd = stat[1], ga = gamma[0];
-    double a = 0.0, b = 0.0;
-    for (long e = threadIdx.x; e < M; e += 1024) { const double gv = g[e]; a += gv; b += gv * (double)((x[e] - mean) * rstd); }
-    r1[threadIdx.x] = a; r2[threadIdx.x] = b;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; } __syncthreads(); }
-    const float sg = (float)r1[0], sgx = (float)r2[0];
-    if (threadIdx.x == 0) { dgb[0] = sgx; dgb[1] = sg; }
-    const float invM = 1.f / (float)M;
-    for (long e = threadIdx.x; e < M; e += 1024) {
-        const float xh = (x[e] - mean) * rstd;
-        dx[e] = training ? ga * rstd * (g[e] - sg * invM - xh * sgx * invM) : ga * rstd * g[e];
+    const long Mg = M / groups;
+    const float ga = gamma[0];
+    double dgam = 0.0, dbet = 0.0;
+    for (int gidx = 0; gidx < groups; ++gidx) {
+        const float mean = stat[2 * gidx], rstd = stat[2 * gidx + 1];
+        const float* gg = g + gidx * Mg; const float* xg = x + gidx * Mg; float* dxg = dx + gidx * Mg;
+        double a = 0.0, b = 0.0;
+        for (long e = threadIdx.x; e < Mg; e += 1024) { const double gv = gg[e]; a += gv; b += gv * (double)((xg[e] - mean) * rstd); }
+        __syncthreads();
+        r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; } __syncthreads(); }
+        const float sg = (float)r1[0], sgx = (float)r2[0];
+        dgam += r2[0]; dbet += r1[0];
+        const float invM = 1.f / (float)Mg;
+        for (long e = threadIdx.x; e < Mg; e += 1024) {
+            const float xh = (xg[e] - mean) * rstd;
+            dxg[e] = training ? ga * rstd * (gg[e] - sg * invM - xh * sgx * invM) : ga * rstd * gg[e];
+        }
     }
+    if (threadIdx.x == 0) { dgb[0] = (float)dgam; dgb[1] = (float)dbet; }
 }
 
 // ---- stride-2 pixel pick (the 1x1 stride-2 shortcut convolutions of ResNet) ------------------------------------------------------
@@ -636,6 +703,13 @@ extern "C" int mdvit_imgconv_wgrad(const float* img, const float* dy, float* dw,
     TF_LAUNCH((imgconv_wgrad_kernel<3, 7>), (nblk), 256, 0, s, img, dy, (float*)ws, B, H, W, Cout, ppb);
     return mdvit_reduce_partials((const float*)ws, nblk, 147L * Cout, 147 * Cout, dw, 0, nullptr, accumulate, s);
 }
+extern "C" int mdvit_imgconv_im2col(const float* img, float* col, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t ksize, int32_t ldc, void* stream) {
+    MDVIT_CHECK_ARG(img && col && Cin == 3 && ksize == 7 && ldc >= 147 && ldc % 4 == 0, MDVIT_E_SHAPE, "imgconv_im2col: built for in_chans == 3, kernel 7, ldc >= 147 and %% 4 == 0");
+    MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0, MDVIT_E_SHAPE, "imgconv_im2col: bad shape");
+    const long n = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * ldc;
+    TF_LAUNCH((imgconv_im2col_kernel<3, 7>), (tf_grid(n)), 256, 0, (hipStream_t)stream, img, col, B, H, W, ldc);
+    return MDVIT_OK;
+}
 extern "C" int mdvit_maxpool3x3s2_fwd(const float* x, float* y, void* idx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
     MDVIT_CHECK_ARG(x && y && idx && B > 0 && H > 0 && W > 0 && C > 0, MDVIT_E_SHAPE, "maxpool_fwd: bad arguments");
     TF_LAUNCH(maxpool_fwd_kernel, (tf_grid((long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C)), 256, 0, (hipStream_t)stream, x, y, (uint8_t*)idx, B, H, W, C);
@@ -654,8 +728,7 @@ extern "C" int mdvit_resize_ac_fwd(const float* x, float* y, int32_t B, int32_t 
 extern "C" int mdvit_resize_ac_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, int32_t C, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, MDVIT_E_SHAPE, "resize_ac_bwd: bad arguments");
-    MDVIT_ZERO(dx, sizeof(float) * (size_t)B * Hi * Wi * C, s);
-    TF_LAUNCH(resize_ac_bwd_kernel, (tf_grid((long)B * Ho * Wo * C)), 256, 0, s, dy, dx, B, Hi, Wi, Ho, Wo, C);
+    TF_LAUNCH(resize_ac_bwd_kernel, (tf_grid((long)B * Hi * Wi * C)), 256, 0, s, dy, dx, B, Hi, Wi, Ho, Wo, C);
     return MDVIT_OK;
 }
 extern "C" int mdvit_ew(const float* a, const float* b, float* y, int64_t n, int32_t mode, void* stream) {
@@ -678,10 +751,18 @@ extern "C" int mdvit_gate_fwd(const float* x, const float* s, float* y, int32_t 
     TF_LAUNCH(gate_fwd_kernel, (tf_grid((long)B * P * C)), 256, 0, (hipStream_t)stream, x, s, y, (long)P, C, (long)B * P * C, mode);
     return MDVIT_OK;
 }
-extern "C" int mdvit_gate_bwd(const float* g, const float* x, const float* s, float* dx, float* ds, int32_t B, int64_t P, int32_t C, int32_t mode, void* stream) {
+extern "C" size_t mdvit_gate_bwd_ws_bytes(int32_t B, int64_t P, int32_t C, int32_t mode) {
+    return mode == 1 ? sizeof(float) * (size_t)B * (size_t)cdiv(P, 64) * C : 0;
+}
+extern "C" int mdvit_gate_bwd(const float* g, const float* x, const float* s, float* dx, float* ds, void* ws, size_t ws_bytes, int32_t B, int64_t P, int32_t C,
+                              int32_t mode, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
     MDVIT_CHECK_ARG(g && x && s && dx && ds && B > 0 && P > 0 && C > 0 && (mode == 0 || mode == 1), MDVIT_E_SHAPE, "gate_bwd: bad arguments");
-    if (mode == 0) TF_LAUNCH(gate_bwd_spatial_kernel, (tf_grid((long)B * P, 4)), 256, 0, (hipStream_t)stream, g, x, s, dx, ds, (long)B * P, C);
-    else TF_LAUNCH(gate_bwd_channel_kernel, (cdiv(C, 64), B), 256, 0, (hipStream_t)stream, g, x, s, dx, ds, (long)P, C);
+    if (mode == 0) { TF_LAUNCH(gate_bwd_spatial_kernel, (tf_grid((long)B * P, 4)), 256, 0, st, g, x, s, dx, ds, (long)B * P, C); return MDVIT_OK; }
+    const int nchunk = cdiv(P, 64);
+    MDVIT_CHECK_ARG(ws && ws_bytes >= mdvit_gate_bwd_ws_bytes(B, P, C, 1), MDVIT_E_WORKSPACE, "gate_bwd: workspace too small (mdvit_gate_bwd_ws_bytes)");
+    TF_LAUNCH(gate_bwd_channel_kernel, (cdiv(C, 64), nchunk, B), 256, 0, st, g, x, s, dx, (float*)ws, (long)P, C, 64);
+    TF_LAUNCH(gate_bwd_channel_final_kernel, (cdiv(B * C, 256)), 256, 0, st, (const float*)ws, s, ds, B, C, nchunk);
     return MDVIT_OK;
 }
 extern "C" int mdvit_chanpool_fwd(const float* x, float* y, int32_t* idx, int64_t M, int32_t C, void* stream) {
@@ -707,15 +788,17 @@ extern "C" int mdvit_conv7x7_2to1_bwd(const float* dy, const float* x, const flo
     return MDVIT_OK;
 }
 extern "C" int mdvit_bn1_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* num_batches_tracked,
-                             float* y, float* stat, int64_t M, int32_t training, float eps, float momentum, void* stream) {
-    MDVIT_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && stat && M > 0, MDVIT_E_SHAPE, "bn1_fwd: bad arguments");
-    TF_LAUNCH(bn1_fwd_kernel, (1), 1024, 0, (hipStream_t)stream, x, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, y, stat, (long)M, training, eps, momentum);
+                             float* y, float* stat, int64_t M, int32_t groups, int32_t training, float eps, float momentum, void* stream) {
+    MDVIT_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && stat && M > 0 && groups > 0 && M % groups == 0, MDVIT_E_SHAPE,
+                    "bn1_fwd: bad arguments (M=%ld groups=%d)", (long)M, groups);
+    TF_LAUNCH(bn1_fwd_kernel, (1), 1024, 0, (hipStream_t)stream, x, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, y, stat, (long)M, groups,
+              training, eps, momentum);
     return MDVIT_OK;
 }
-extern "C" int mdvit_bn1_bwd(const float* g, const float* x, const float* gamma, const float* stat, float* dx, float* dgamma_dbeta, int64_t M, int32_t training,
-                             void* stream) {
-    MDVIT_CHECK_ARG(g && x && gamma && stat && dx && dgamma_dbeta && M > 0, MDVIT_E_SHAPE, "bn1_bwd: bad arguments");
-    TF_LAUNCH(bn1_bwd_kernel, (1), 1024, 0, (hipStream_t)stream, g, x, gamma, stat, dx, dgamma_dbeta, (long)M, training);
+extern "C" int mdvit_bn1_bwd(const float* g, const float* x, const float* gamma, const float* stat, float* dx, float* dgamma_dbeta, int64_t M, int32_t groups,
+                             int32_t training, void* stream) {
+    MDVIT_CHECK_ARG(g && x && gamma && stat && dx && dgamma_dbeta && M > 0 && groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "bn1_bwd: bad arguments");
+    TF_LAUNCH(bn1_bwd_kernel, (1), 1024, 0, (hipStream_t)stream, g, x, gamma, stat, dx, dgamma_dbeta, (long)M, groups, training);
     return MDVIT_OK;
 }
 extern "C" int mdvit_subsample2(const float* src, float* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t backward, void* stream) {

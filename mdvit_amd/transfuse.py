@@ -49,6 +49,19 @@ class _ImgConv(torch.autograd.Function):
         return None, dw
 
 
+def stem_conv7(img, w):
+    """ResNet conv1 on the matrix cores: im2col of the NCHW image ([B Ho Wo, 148]: 147 columns + one of zeros) x the weight padded likewise;
+    the padding / slicing of the weight is on the autograd tape (copies), so the weight gradient is the TN GEMM of ops.linear's backward."""
+    B, Cin, H, W_ = img.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
+    K = Cin * w.shape[-1] * w.shape[-2]
+    ldc = (K + 3) // 4 * 4
+    col = torch.empty((B * Ho * Wo, ldc), device=img.device, dtype=torch.float32)
+    call("mdvit_imgconv_im2col", _p(_c(img)), _p(col), B, H, W_, Cin, w.shape[-1], ldc, _stream())
+    wp = torch.nn.functional.pad(w.reshape(w.shape[0], K), (0, ldc - K))
+    return ops.linear(col, wp).view(B, Ho, Wo, w.shape[0])
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -169,7 +182,9 @@ class _Gate(torch.autograd.Function):
         x, s = ctx.saved_tensors
         B, P, Cn, mode = ctx.meta
         dx, ds = _empty_like(x), _empty_like(s)
-        call("mdvit_gate_bwd", _p(_c(g)), _p(x), _p(s), _p(dx), _p(ds), B, P, Cn, mode, _stream())
+        wsb = _lib.load().mdvit_gate_bwd_ws_bytes(B, P, Cn, mode)
+        ws = _empty((max(wsb // 4, 1),), device=x.device, dtype=torch.float32)
+        call("mdvit_gate_bwd", _p(_c(g)), _p(x), _p(s), _p(dx), _p(ds), _p(ws), wsb, B, P, Cn, mode, _stream())
         return dx, ds, None
 
 
@@ -224,28 +239,28 @@ class _BN1(torch.autograd.Function):
     """BatchNorm2d(1) over a one-channel map"""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, eps, momentum):
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, training, eps, momentum, groups):
         ctx.set_materialize_grads(False)
         _chk(x, gamma, beta, rm, rv)
         y = _empty_like(x)
-        stat = _empty((2,), device=x.device, dtype=torch.float32)
+        stat = _empty((groups, 2), device=x.device, dtype=torch.float32)
         call("mdvit_bn1_fwd", _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), C.c_void_p(nbt.data_ptr()) if nbt is not None else None, _p(y), _p(stat),
-             x.numel(), int(training), eps, momentum, _stream())
+             x.numel(), groups, int(training), eps, momentum, _stream())
         ctx.save_for_backward(x, gamma, stat)
-        ctx.training = training
+        ctx.training, ctx.groups = training, groups
         return y
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 9
+            return (None,) * 10
         x, gamma, stat = ctx.saved_tensors
         dx = _empty_like(x)
         dgb = _empty((2,), device=x.device, dtype=torch.float32)
-        call("mdvit_bn1_bwd", _p(_c(g)), _p(x), _p(gamma), _p(stat), _p(dx), _p(dgb), x.numel(), int(ctx.training), _stream())
+        call("mdvit_bn1_bwd", _p(_c(g)), _p(x), _p(gamma), _p(stat), _p(dx), _p(dgb), x.numel(), ctx.groups, int(ctx.training), _stream())
         if ops._dgrad_only:
-            return dx, None, None, None, None, None, None, None, None
-        return dx, dgb[0:1].clone(), dgb[1:2].clone(), None, None, None, None, None, None
+            return (dx,) + (None,) * 9
+        return (dx, dgb[0:1].clone(), dgb[1:2].clone()) + (None,) * 7
 
 
 class _Subsample2(torch.autograd.Function):
@@ -429,7 +444,10 @@ class BatchNorm1ch(nn.Module):
         self.eps, self.momentum = eps, momentum
 
     def forward(self, x):
-        return _BN1.apply(_c(x), self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.training, self.eps, self.momentum)
+        groups = ops._bn_groups if self.training else 1             # domain-batched forward: statistics per domain batch (ops.bn_groups)
+        if x.shape[0] % groups:
+            raise ValueError(f"bn_groups({groups}) needs a batch that is a multiple of it, got {x.shape[0]}")
+        return _BN1.apply(_c(x), self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.training, self.eps, self.momentum, groups)
 
 
 class Conv(nn.Module):
@@ -692,7 +710,7 @@ class TransFuse_S_adapt(nn.Module):
         x_b_1 = drop(self.up1(x_b))
         x_b_2 = drop(self.up2(x_b_1))
         r = self.resnet
-        x_u = r.bn1(_ImgConv.apply(_c(imgs), r.conv1.weight))
+        x_u = r.bn1(stem_conv7(imgs, r.conv1.weight))
         x_u = _MaxPool.apply(_c(x_u))
         x_u_2 = drop(r.layer1(x_u))
         x_u_1 = drop(r.layer2(x_u_2))
@@ -709,9 +727,14 @@ class TransFuse_S_adapt(nn.Module):
         return head(self.final_x, x_c, 16), head(self.final_1, x_b_2, 4), head(self.final_2, x_c_2, 4)
 
 
-def transfuse_train_step(model, batches: Sequence[tuple], optimizer=None, accumulator=None, num_domains: int = 4) -> Dict[str, torch.Tensor]:
+def transfuse_train_step(model, batches: Sequence[tuple], optimizer=None, accumulator=None, num_domains: int = 4,
+                         fuse_domains: bool = False) -> Dict[str, torch.Tensor]:
     """multi_train_TransFuse.py:141-189: per domain loss = 0.5 SL(map_2) + 0.3 SL(map_1) + 0.2 SL(map_x); ONE backward of the sum.
-    batches: [(img (B,3,256,256), label (B,1,256,256), set_id (B,) int64 on the host)]."""
+    batches: [(img (B,3,256,256), label (B,1,256,256), set_id (B,) int64 on the host)].
+    fuse_domains: ONE forward over the concatenated, equally sized domain batches.  The reference runs one forward per domain; the only
+    ops that couple the samples of a forward are the BatchNorms, and with ops.bn_groups(G) they keep statistics per domain batch (and
+    update the running statistics G times in order), so the result is the same function with 1/G of the kernel launches (the step is
+    launch-bound: ~5500 launches at 4 x 8 images)."""
     import torch.nn.functional as F
     ops.refresh_transposes()
     if accumulator is not None:
@@ -721,6 +744,20 @@ def transfuse_train_step(model, batches: Sequence[tuple], optimizer=None, accumu
     else:
         model.zero_grad(set_to_none=True)
     tot, per = None, []
+    G = len(batches)
+    if fuse_domains and G > 1 and all(b[0].shape == batches[0][0].shape for b in batches):
+        img = torch.cat([b[0] for b in batches], 0)
+        sid = torch.cat([b[2].cpu() for b in batches], 0)
+        dl = F.one_hot(sid, num_domains).float().to(img.device, non_blocking=True)
+        with ops.bn_groups(G):
+            m4, m3, m2 = model(img, dl)
+        parts = [ops.split_groups(t, G) for t in (m4, m3, m2)]
+        for g_, (_, label, _) in enumerate(batches):
+            weit = structure_weight(label)
+            loss = 0.5 * structure_loss(parts[2][g_], label, weit) + 0.3 * structure_loss(parts[1][g_], label, weit) + 0.2 * structure_loss(parts[0][g_], label, weit)
+            per.append(loss.detach())
+            tot = loss if tot is None else tot + loss
+        batches = []
     for img, label, set_id in batches:
         dl = F.one_hot(set_id.cpu(), num_domains).float().to(img.device, non_blocking=True)
         m4, m3, m2 = model(img, dl)
