@@ -697,6 +697,12 @@ int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, lon
     return MDVIT_OK;
 }
 
+// gemm_tn.hip: the transposing-LDS-read weight-gradient kernel (TN layout, bf16x3 / bf16 arithmetic, plain epilogue)
+bool mdvit_gemm_tn_applies(const MdvitGemmDesc* d);
+size_t mdvit_gemm_tn_ws_bytes(const MdvitGemmDesc* d);
+void mdvit_gemm_tn_plan(const MdvitGemmDesc* d, int* tile_m, int* tile_n, int* splits);
+int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s);
+
 extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(d != nullptr, MDVIT_E_SHAPE, "gemm: null descriptor");
@@ -730,6 +736,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.colsum = d->colsum_a;
     MDVIT_CHECK_ARG(!d->colsum_a || (d->trans_a && !d->trans_b), MDVIT_E_SHAPE, "gemm: colsum_a rides on the TN (wgrad) layout only");
     a.seed = d->drop_seed;
+    if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_launch(d, s);
 
     const GemmPlan pl = plan_gemm(d);
     a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;
@@ -841,6 +848,7 @@ extern "C" int mdvit_gemm_force_plan(int32_t cfg, int32_t splits) {
 
 extern "C" int mdvit_gemm_plan(const MdvitGemmDesc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits) {
     MDVIT_CHECK_ARG(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0, MDVIT_E_SHAPE, "gemm_plan: bad descriptor");
+    if (mdvit_gemm_tn_applies(d)) { mdvit_gemm_tn_plan(d, tile_m, tile_n, splits); return MDVIT_OK; }
     const GemmPlan pl = plan_gemm(d);
     if (tile_m) *tile_m = pl.cfg == 0 ? 128 : (pl.cfg == 1 ? 256 : 64);
     if (tile_n) *tile_n = pl.cfg == 0 ? 128 : 64;
@@ -850,6 +858,7 @@ extern "C" int mdvit_gemm_plan(const MdvitGemmDesc* d, int32_t* tile_m, int32_t*
 
 extern "C" size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* d) {
     if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_ws_bytes(d);
     const GemmPlan pl = plan_gemm(d);
     return pl.splits > 1 ? sizeof(float) * (size_t)pl.splits * d->M * d->N : 0;
 }

@@ -1,0 +1,330 @@
+// Weight-gradient GEMM (TN): C[M,N] (+)= A^T B with A [K,M] and B [K,N] both TOKEN-major (k = token index, the long axis), fp32 in HBM,
+// bf16x3 arithmetic (x = hi + lo bf16 planes; hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) or one bf16 plane.
+// Replaces autograd's `grad_out.t() @ input` of every nn.Linear / 1x1 nn.Conv2d of the reference (mdvit.py:288,310, mpvit.py:73,76,
+// Decoders.py:185,300-311) in the backward of multi_train_MDViT.py:195-213.
+//
+// Both MFMA operands want 8 consecutive k per lane, but memory is contiguous along m / n.  The kernel keeps the k-major order all
+// the way into LDS -- a float4 (four consecutive m at one k) is split and written as ONE ds_write_b64 per plane -- and transposes on the
+// READ with gfx950's ds_read_b64_tr_b16: the LDS image is [k/4][m/16][4 k][16 m] bf16 blocks of 128 B; a 16-lane group hands the
+// hardware the 16 eight-byte pieces of one block and every lane receives the 4 k values of "its" column m.  Two such reads give a
+// lane its 8 k of one MFMA operand; the two 16-lane groups of a 32-lane half read ADJACENT blocks (256 contiguous bytes: no bank
+// conflict), the 16 lanes of a write group fill one whole block (conflict-free too).
+// K is split into slabs over blockIdx.y (dense [M,N] partial per slab + the fixed-order reduce of gemm.hip: deterministic);
+// the loads of slab i+2 are in flight while slab i is multiplied (two register sets, two LDS stages, one barrier per slab).
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef short v8i16 __attribute__((ext_vector_type(8)));
+
+int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, hipStream_t s);
+
+namespace {
+
+constexpr int BK = 32, NTH = 256;
+
+struct TnArgs {
+    const float* A; const float* B; float* C; float* slab; float* colsum; float* cs_part; const float* bias;
+    long lda, ldb, ldc;
+    int M, N, K, kps, splits, tiles_m, tiles_n, accumulate;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void split4(const float4 x, uint2& hi, uint2& lo) {
+    f32x2_t a = {x.x, x.y}, b = {x.z, x.w};
+    const uint32_t hau = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2_t));
+    const uint32_t hbu = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bf16x2_t));
+    f32x2_t la = {x.x - __uint_as_float(hau << 16), x.y - __uint_as_float(hau & 0xffff0000u)};
+    f32x2_t lb = {x.z - __uint_as_float(hbu << 16), x.w - __uint_as_float(hbu & 0xffff0000u)};
+    hi = make_uint2(hau, hbu);
+    lo = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(la, bf16x2_t)), __builtin_bit_cast(uint32_t, __builtin_convertvector(lb, bf16x2_t)));
+}
+
+typedef __attribute__((address_space(3))) v4i16* lds_v4i16_ptr;
+
+template <int BM, int BN, int P, bool CS>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 16384 ? 2 : (BM * BN == 8192 ? 3 : 4), 8))) void gemm_tn_kernel(TnArgs p) {
+    constexpr int MB = BM / 16, NB = BN / 16;                     // 16-column blocks per k-quad
+    constexpr int A_PLANE = BK * BM * 2, B_PLANE = BK * BN * 2;   // bytes of one bf16 plane of one slab
+    constexpr int STAGE = P * (A_PLANE + B_PLANE);
+    constexpr int AV = BM * BK / 4 / NTH, BV = BN * BK / 4 / NTH; // float4 per thread per slab
+    constexpr int WTM = BM / 64, WTN = BN / 64;                   // 32x32 blocks per wave (2 x 2 waves)
+    __shared__ __attribute__((aligned(256))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * p.kps, kend = min(p.K, kbeg + p.kps);
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int l15 = lane & 15, l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging map: a wavefront covers one k-quad (4 rows) x 64 columns; lane -> (column quad mq = l&3, row kr = (l>>2)&3, block l>>4)
+    const int kr = (lane >> 2) & 3;
+    const int colq = 16 * (lane >> 4) + 4 * (lane & 3);           // column offset inside the 64-column unit
+    float4 ra[2][AV], rb[2][BV];
+    float4 cs[BM / 64];                        // CS: the bias gradient (column sums of A) rides on the staging pass; one per 64-column unit
+#pragma unroll
+    for (int v = 0; v < BM / 64; ++v) cs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_cs = CS && tn == 0;
+    const int full_slabs = (kend - kbeg) / BK;                  // slabs at or past this index need their rows past kend zeroed
+
+    // Loads are UNCONDITIONAL (addresses clamped into the matrix, rows past the end of the K range zeroed by a select): a load under
+    // a branch makes the compiler drain the whole vector-memory queue (s_waitcnt vmcnt(0)) at every join, which serialises the
+    // slabs.  Columns past M / N read real elements of the last column quad: they only reach output rows / columns that are never stored.
+    auto load = [&](int slab, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+        const int k0 = kbeg + slab * BK;
+#pragma unroll
+        for (int v = 0; v < AV; ++v) {
+            const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
+            ra[S][v] = *reinterpret_cast<const float4*>(p.A + (long)min(k, kend - 1) * p.lda + m);
+        }
+#pragma unroll
+        for (int v = 0; v < BV; ++v) {
+            const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
+            rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE: the scheduler otherwise sinks them next to their LDS stores
+    };
+    auto store = [&](int slab, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+        char* base = smem + (slab & 1) * STAGE;
+        const int k0 = kbeg + slab * BK;
+        const bool tail = slab >= full_slabs;               // (uniform)
+#pragma unroll
+        for (int v = 0; v < AV; ++v) {
+            const int u = wave + 4 * v;
+            const int off = (((u & 7) * MB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
+            if (tail && k0 + 4 * (u & 7) + kr >= kend) ra[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CS) { float4& c = cs[(4 * v) >> 3]; c.x += ra[S][v].x; c.y += ra[S][v].y; c.z += ra[S][v].z; c.w += ra[S][v].w; }
+            uint2 hi, lo;
+            split4(ra[S][v], hi, lo);
+            *reinterpret_cast<uint2*>(base + off) = hi;
+            if (P == 2) *reinterpret_cast<uint2*>(base + A_PLANE + off) = lo;
+        }
+        char* bb = base + P * A_PLANE;
+#pragma unroll
+        for (int v = 0; v < BV; ++v) {
+            const int u = wave + 4 * v;
+            const int off = (((u & 7) * NB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
+            if (tail && k0 + 4 * (u & 7) + kr >= kend) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4(rb[S][v], hi, lo);
+            *reinterpret_cast<uint2*>(bb + off) = hi;
+            if (P == 2) *reinterpret_cast<uint2*>(bb + B_PLANE + off) = lo;
+        }
+    };
+    // fragment addresses (bytes inside a plane) of this lane for k-step 0, read 0, tile 0
+    const int a_off = ((2 * lhi) * MB + wm0 / 16 + ((lane >> 4) & 1)) * 128 + l15 * 8;
+    const int b_off = ((2 * lhi) * NB + wn0 / 16 + ((lane >> 4) & 1)) * 128 + l15 * 8;
+    auto read8 = [&](const char* plane, int off, int blocks) __attribute__((always_inline)) -> bf16x8_t {
+        // k-quads q and q+1 of this lane's half: two transposing reads, 4 k each
+        const v4i16 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(plane + off));
+        const v4i16 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(plane + off + blocks * 128));
+        const v8i16 r = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        return __builtin_bit_cast(bf16x8_t, r);
+    };
+    auto mma = [&](int stage) __attribute__((always_inline)) {
+        const char* base = smem + stage * STAGE;
+        const char* Ahi = base; const char* Alo = base + A_PLANE;
+        const char* Bhi = base + P * A_PLANE; const char* Blo = Bhi + B_PLANE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8_t ah[WTM], al[WTM], bh[WTN], bl[WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) {
+                const int off = a_off + (4 * ks * MB + 2 * i) * 128;
+                ah[i] = read8(Ahi, off, MB);
+                if (P == 2) al[i] = read8(Alo, off, MB);
+            }
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                const int off = b_off + (4 * ks * NB + 2 * j) * 128;
+                bh[j] = read8(Bhi, off, NB);
+                if (P == 2) bl[j] = read8(Blo, off, NB);
+            }
+            if (P == 2) {
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // branch-free pipeline over an EVEN number of slabs (an odd count gets one phantom slab of zeros): slab i in LDS stage i & 1,
+    // the loads of slab i+2 in flight while slab i is multiplied and slab i+1 is split into the other stage; one barrier per slab
+    load(0, S0{});
+    load(1, S1{});
+    store(0, S0{});
+    __syncthreads();
+    for (int i = 0; i < nslab; i += 2) {
+        load(i + 2, S0{});
+        mma(0);
+        store(i + 1, S1{});
+        __syncthreads();
+        load(i + 3, S1{});
+        mma(1);
+        store(i + 2, S0{});
+        __syncthreads();
+    }
+
+    if (CS && do_cs) {              // bias gradient: column sums of the A stream, added in a FIXED order (the loop ended with a barrier)
+        float* s_cs = reinterpret_cast<float*>(smem);               // [4 waves][BM]
+#pragma unroll
+        for (int h = 0; h < BM / 64; ++h) {
+            float4 c = cs[h];                                        // this thread: rows kr of the wave's k-quads; fold the 4 row lanes
+            c.x += __shfl_xor(c.x, 4); c.y += __shfl_xor(c.y, 4); c.z += __shfl_xor(c.z, 4); c.w += __shfl_xor(c.w, 4);
+            c.x += __shfl_xor(c.x, 8); c.y += __shfl_xor(c.y, 8); c.z += __shfl_xor(c.z, 8); c.w += __shfl_xor(c.w, 8);
+            if (kr == 0) *reinterpret_cast<float4*>(&s_cs[wave * BM + 64 * h + colq]) = c;
+        }
+        __syncthreads();
+        for (int i = tid; i < BM; i += NTH) {
+            if (m0 + i >= p.M) continue;
+            const float t = (s_cs[i] + s_cs[BM + i]) + (s_cs[2 * BM + i] + s_cs[3 * BM + i]);
+            if (p.splits > 1) p.cs_part[(long)blockIdx.y * p.M + m0 + i] = t;     // one row per K-split, summed by the slab reduction
+            else p.colsum[m0 + i] += t;                                          // (this workgroup is the only writer of these columns)
+        }
+    }
+
+    // epilogue: the MFMA ran as D = B-tile^T x A-tile -> D[row = n][col = m]; a lane holds four consecutive n per register quad
+    float* slab = p.splits > 1 ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+        const int row = m0 + wm0 + i * 32 + l31;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + wn0 + j * 32 + 8 * q + 4 * lhi;
+                if (col >= p.N) continue;
+                float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (slab) { *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = v; continue; }
+                float* dst = p.C + (long)row * p.ldc + col;
+                if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *reinterpret_cast<float4*>(dst) = v;
+            }
+    }
+}
+
+int g_tn_enable = 1, g_tn_force_cfg = -1, g_tn_force_splits = 0;
+
+struct TnPlan { int cfg, tiles_m, tiles_n, splits, kps; };
+const int TN_BM[4] = {128, 128, 64, 64}, TN_BN[4] = {128, 64, 128, 64};
+
+TnPlan plan_tn(int M, int N, int K, int allow_split) {
+    static const double EFF[4] = {1.0, 0.9, 0.9, 0.75};
+    TnPlan best; best.cfg = 0; double best_cost = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        if (g_tn_force_cfg >= 0 && c != g_tn_force_cfg) continue;
+        const long tm = cdiv(M, TN_BM[c]), tn = cdiv(N, TN_BN[c]);
+        const double cost = (double)(tm * TN_BM[c]) * (double)(tn * TN_BN[c]) / EFF[c];
+        if (cost < best_cost) { best_cost = cost; best.cfg = c; best.tiles_m = (int)tm; best.tiles_n = (int)tn; }
+    }
+    const long tiles = (long)best.tiles_m * best.tiles_n;
+    // 1.5 workgroups per CU in total (tools/tn_check.py --sweep: 256 .. 512 workgroups is the optimum on every shape of the model),
+    // at least 8 slabs of 32 tokens each per workgroup
+    long want = g_tn_force_splits > 0 ? g_tn_force_splits : (384 + tiles - 1) / tiles;
+    const long max_sp = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
+    if (want > max_sp) want = max_sp;
+    if (want > 1024) want = 1024;
+    if (want < 1 || !allow_split) want = 1;
+    best.kps = cdiv(cdiv(K, want), BK) * BK;
+    best.splits = cdiv(K, best.kps);
+    return best;
+}
+
+}  // namespace
+
+// library-internal: does the transposing-read wgrad kernel take this descriptor?
+bool mdvit_gemm_tn_applies(const MdvitGemmDesc* d) {
+    return g_tn_enable && d->trans_a && !d->trans_b && d->precision >= 1 && d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale &&
+           !d->residual && (d->M % 4 == 0) && (d->N % 4 == 0) && (d->ldc % 4 == 0) && aligned16(d->C) && (!d->bias || aligned16(d->bias));
+}
+
+size_t mdvit_gemm_tn_ws_bytes(const MdvitGemmDesc* d) {
+    const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
+    return pl.splits > 1 ? sizeof(float) * (size_t)pl.splits * d->M * (d->N + (d->colsum_a ? 1 : 0)) : 0;
+}
+
+void mdvit_gemm_tn_plan(const MdvitGemmDesc* d, int* tile_m, int* tile_n, int* splits) {
+    const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
+    if (tile_m) *tile_m = TN_BM[pl.cfg];
+    if (tile_n) *tile_n = TN_BN[pl.cfg];
+    if (splits) *splits = pl.splits;
+}
+
+int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
+    const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
+    TnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum_a; a.bias = d->bias;
+    a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K;
+    a.kps = pl.kps; a.splits = pl.splits; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.accumulate = d->accumulate;
+    if (pl.splits > 1) {
+        const size_t need = sizeof(float) * (size_t)pl.splits * d->M * (d->N + (d->colsum_a ? 1 : 0));
+        MDVIT_CHECK_ARG(d->ws != nullptr && d->ws_bytes >= need, MDVIT_E_WORKSPACE,
+                        "gemm (wgrad): split reduction needs %zu bytes of workspace (mdvit_gemm_ws_bytes), got %zu", need, (size_t)d->ws_bytes);
+        a.slab = (float*)d->ws;
+        a.cs_part = a.slab + (size_t)pl.splits * d->M * d->N;
+    }
+    const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NTH);
+    const bool one = d->precision == 2;
+#define MDVIT_TN_LAUNCH(BM_, BN_)                                                                                   \
+    do {                                                                                                            \
+        if (one) { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, true>), grid, block, 0, s, a);     \
+                   else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, false>), grid, block, 0, s, a); }           \
+        else { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, true>), grid, block, 0, s, a);         \
+               else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, false>), grid, block, 0, s, a); }               \
+    } while (0)
+    if (pl.cfg == 0) MDVIT_TN_LAUNCH(128, 128);
+    else if (pl.cfg == 1) MDVIT_TN_LAUNCH(128, 64);
+    else if (pl.cfg == 2) MDVIT_TN_LAUNCH(64, 128);
+    else MDVIT_TN_LAUNCH(64, 64);
+#undef MDVIT_TN_LAUNCH
+    MDVIT_LAUNCH_CHECK();
+    if (pl.splits > 1) {
+        int rc = mdvit_gemm_splitk_reduce(a.slab, d->bias, d->C, d->ldc, d->M, d->N, pl.splits, d->accumulate, s);
+        if (rc == MDVIT_OK && d->colsum_a)        // the K-splits' column-sum rows, added in slab order
+            rc = mdvit_reduce_partials(a.cs_part, pl.splits, d->M, d->M, d->colsum_a, 0, nullptr, 1, s);
+        return rc;
+    }
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_gemm_tn_config(int32_t enable, int32_t cfg, int32_t splits) {
+    g_tn_enable = enable != 0;
+    g_tn_force_cfg = (cfg >= 0 && cfg <= 3) ? cfg : -1;
+    g_tn_force_splits = splits > 0 ? splits : 0;
+    return MDVIT_OK;
+}

@@ -310,6 +310,8 @@ _use_plane_gemm = os.environ.get("MDVIT_PLANE_GEMM", "1") != "0"      # 0: the s
 # split-while-staging kernel at equal arithmetic (both sit at the same ~30 % of the MFMA roof: the limit is not the split VALU), so
 # the parity mode keeps the calibrated gemm.hip planner and the plane kernels serve the bf16 speed mode (half the operand bytes).
 _plane_min_k = int(os.environ.get("MDVIT_PLANE_MIN_K", "1000000"))
+if os.environ.get("MDVIT_TN_KERNEL", "1") == "0":                       # A/B: weight-gradient GEMMs on the general template instead of gemm_tn.hip
+    _lib.load().mdvit_gemm_tn_config(0, -1, 0)
 _plane_rc = os.environ.get("MDVIT_PLANE_RC", "0") != "0"              # the recomputing fc2 data gradient of the C = 128 MLPs on the plane kernel
 
 

@@ -816,3 +816,58 @@ def test_linear_and_mlp_bf16_speed_mode(M, N, K):
     check(out, ref, tol=2e-2, name="y")
     for n, a, r in zip(("dx", "dW", "db"), go, gr):
         check(a, r, tol=2e-2, name=n)
+
+
+# ---- round 2: the transposing-LDS-read weight-gradient kernel (csrc/gemm_tn.hip) ------------------------------------------------
+@pytest.mark.parametrize("shape", [(64, 64, 1000), (320, 192, 4100), (128, 128, 777), (1280, 320, 2048), (192, 64, 33), (64, 512, 5000),
+                                   (512, 64, 8192), (100, 36, 515), (512, 2048, 8), (4, 64, 300)])
+def test_wgrad_tn_kernel_every_tile_and_split_vs_fp64_and_bitwise_repeatable(shape):
+    """grad_out.t() @ input (TN layout, tokens on the long axis) on gemm_tn.hip: every tile config x forced K-split, ragged M / N / K,
+    accumulate into a non-zero C, the bias gradient (column sums of A) riding on the same pass; results are bitwise repeatable
+    (slab split-K and the column sums are reduced in a fixed order) and equal the general template's to rounding."""
+    from mdvit_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M), generator=g).to(dev()); B = torch.randn((K, N), generator=g).to(dev())
+    out0 = torch.randn((M, N), generator=g).to(dev()); cs0 = torch.randn((M,), generator=g).to(dev())
+    ref = out0.double() + A.double().t() @ B.double()
+    cref = cs0.double() + A.double().sum(0)
+
+    def run():
+        out, cs = out0.clone(), cs0.clone()
+        ops.gemm(ops._p(A), ops._p(B), ops._p(out), M, N, K, lda=M, ldb=N, ldc=N, trans_a=True, trans_b=False, allow_split=True,
+                 accumulate=True, precision=1, colsum_a=ops._p(cs))
+        return out, cs
+    try:
+        for cfg in (-1, 0, 1, 2, 3):
+            for sp in (0, 1, 3):
+                lib.mdvit_gemm_tn_config(1, cfg, sp)
+                out, cs = run()
+                check(out, ref.float(), tol=2e-5, name=f"cfg {cfg} splits {sp}")
+                check(cs, cref.float(), tol=1e-5, name=f"colsum cfg {cfg} splits {sp}")
+                out2, cs2 = run()
+                assert torch.equal(out, out2) and torch.equal(cs, cs2), f"cfg {cfg} splits {sp}: not bitwise repeatable"
+        lib.mdvit_gemm_tn_config(0, -1, 0)                  # the general template
+        old, cso = run()
+        lib.mdvit_gemm_tn_config(1, -1, 0)
+        new, csn = run()
+        check(new, old, tol=2e-5, name="vs the general template"); check(csn, cso, tol=1e-5, name="colsum vs the general template")
+    finally:
+        lib.mdvit_gemm_tn_config(1, -1, 0)
+
+
+def test_wgrad_tn_kernel_strided_operands_and_single_plane():
+    """operands that are column blocks of wider tensors (lda > M, ldb > N), overwrite (no accumulate), and the one-bf16-plane mode"""
+    from mdvit_amd import ops
+    K, M, N = 3000, 128, 64
+    Aw = torch.randn((K, 384), device=dev()); Bw = torch.randn((K, 256), device=dev())
+    ref = Aw[:, 128:256].double().t() @ Bw[:, 64:128].double()
+    for precision, tol in ((1, 2e-5), (2, 2e-2)):
+        out = torch.full((M, N), float("nan"), device=dev())
+        ops.gemm(ops._p(Aw[:, 128:256]), ops._p(Bw[:, 64:128]), ops._p(out), M, N, K, lda=384, ldb=256, ldc=N, trans_a=True, trans_b=False,
+                 allow_split=True, precision=precision)
+        check(out, ref.float(), tol=tol, name=f"precision {precision}")
+    out = torch.full((M, N), float("nan"), device=dev())                # no workspace allowed: one slab, written directly
+    ops.gemm(ops._p(Aw[:, 128:256]), ops._p(Bw[:, 64:128]), ops._p(out), M, N, K, lda=384, ldb=256, ldc=N, trans_a=True, trans_b=False, allow_split=False)
+    check(out, ref.float(), tol=2e-5, name="allow_split=False")
