@@ -175,13 +175,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
         for (int v = 0; v < A_V4; ++v) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TA) {   // A[m][k], k contiguous: BK/4 threads per row
+                // UNCONDITIONAL load from a clamped address (rows past M read row M-1: they only feed output rows that are never
+                // stored; k past the end is zeroed when the slab is written to LDS): a load under a branch makes the compiler drain
+                // the whole vector-memory queue at the join (s_waitcnt vmcnt(0)), which collapsed the two-slab prefetch to one
                 const int r = tid / KT + v * (NTHREADS / KT), m = m0 + r, k = k0 + (tid % KT) * 4;
                 const bool first = RC && k0 < p.rc_k;              // (uniform: scalar selects)
                 const float* src = first ? p.rc_a : gA;
                 const long ld = first ? p.rc_lda : glda;
                 const int kl = (RC && !first) ? k - p.rc_k : k;
                 const int ke = RC ? (first ? p.rc_k : p.K) : kend;
-                if (m < p.M && kl < ke) x = *reinterpret_cast<const float4*>(src + (long)m * ld + kl);
+                x = *reinterpret_cast<const float4*>(src + (long)min(m, p.M - 1) * ld + min(kl, ke - 4));
             } else {     // A stored [k][m], m contiguous (wgrad: A = dY^T)
                 constexpr int TPR = BM / 4;                 // threads per k-row
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, m = m0 + (tid % TPR) * 4;
@@ -209,14 +212,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
 #pragma unroll
         for (int v = 0; v < B_V4; ++v) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TB) {    // B[n][k], k contiguous (weights as stored by nn.Linear)
+            if (TB) {    // B[n][k], k contiguous (weights as stored by nn.Linear); unconditional, as for A
                 const int r = tid / KT + v * (NTHREADS / KT), n = n0 + r, k = k0 + (tid % KT) * 4;
                 const bool first = RC && k0 < p.rc_k;
                 const float* src = first ? p.rc_b : gB;
                 const long ld = first ? p.rc_ldb : gldb;
                 const int kl = (RC && !first) ? k - p.rc_k : k;
                 const int ke = RC ? (first ? p.rc_k : p.K) : kend;
-                if (n < p.N && kl < ke) x = *reinterpret_cast<const float4*>(src + (long)n * ld + kl);
+                x = *reinterpret_cast<const float4*>(src + (long)min(n, p.N - 1) * ld + min(kl, ke - 4));
             } else {     // B[k][n], n contiguous
                 constexpr int TPR = BN / 4;
                 const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, n = n0 + (tid % TPR) * 4;
@@ -225,8 +228,23 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
             rb[S][v] = x;
         }
     };
-    auto store_smem = [&](auto setc) {
+    auto store_smem = [&](auto setc, int k0) {
         constexpr int S = decltype(setc)::value;
+        {   // k-contiguous operands were loaded unconditionally: zero what lies past the end of the K range (last slab only)
+            const bool first = RC && k0 < p.rc_k;
+            const int ke = RC ? (first ? p.rc_k : p.K) : kend;
+            const int kl = ((RC && !first) ? k0 - p.rc_k : k0) + (tid % KT) * 4;
+            if (kl >= ke) {
+                if (!TA) {
+#pragma unroll
+                    for (int v = 0; v < A_V4; ++v) ra[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (TB) {
+#pragma unroll
+                    for (int v = 0; v < B_V4; ++v) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
         if (TA && do_cs) {          // raw fp32 values of the staged A slab (zeros outside the matrix)
             if (A_PAIR) {
 #pragma unroll
@@ -397,13 +415,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
         // one slab in flight behind the one being multiplied
         int buf = 0;
         load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
-        store_smem(SET0{});
+        store_smem(SET0{}, kbeg);
         __syncthreads();
         if (kbeg + BK < kend) { load_a(kbeg + BK, SET0{}); load_b(kbeg + BK, SET0{}); }
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             if (k0 + BK < kend) {
                 stage(buf ^ 1);
-                store_smem(SET0{});
+                store_smem(SET0{}, k0 + BK);
                 stage(buf);
                 if (k0 + 2 * BK < kend) { load_a(k0 + 2 * BK, SET0{}); load_b(k0 + 2 * BK, SET0{}); }
             }
@@ -419,17 +437,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
         int buf = 0;
         load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
         using SETB = std::integral_constant<int, PF2 ? 1 : 0>;        // (SET1 where this path is compiled for real)
-        if (kbeg + BK < kend) { load_a(kbeg + BK, SETB{}); load_b(kbeg + BK, SETB{}); }
-        store_smem(SET0{});
+        // BRANCH-FREE from here on: every load is issued unconditionally (past the end of the K range the clamped addresses re-read
+        // the row's last quad -- an L1 hit -- and store_smem writes zeros), and an odd slab count gets one phantom slab of zeros, so
+        // that no load sits under a branch and the compiler can wait for exactly the older register set (s_waitcnt vmcnt(4))
+        load_a(kbeg + BK, SETB{}); load_b(kbeg + BK, SETB{});
+        store_smem(SET0{}, kbeg);
         __syncthreads();
-        if (kbeg + 2 * BK < kend) { load_a(kbeg + 2 * BK, SET0{}); load_b(kbeg + 2 * BK, SET0{}); }
+        load_a(kbeg + 2 * BK, SET0{}); load_b(kbeg + 2 * BK, SET0{});
         auto step = [&](int k0, auto setc) __attribute__((always_inline)) {       // setc: the register set that holds slab k0 + BK
-            if (k0 + BK < kend) {
-                stage(buf ^ 1);
-                store_smem(setc);
-                stage(buf);
-                if (k0 + 3 * BK < kend) { load_a(k0 + 3 * BK, setc); load_b(k0 + 3 * BK, setc); }
-            }
+            stage(buf ^ 1);
+            store_smem(setc, k0 + BK);
+            stage(buf);
+            load_a(k0 + 3 * BK, setc); load_b(k0 + 3 * BK, setc);
+            __builtin_amdgcn_sched_barrier(0);        // (the scheduler otherwise sinks the loads below the MFMAs)
             mma(k0);
             __syncthreads();
             buf ^= 1;
@@ -437,12 +457,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
         };
         for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
             step(k0, SETB{});
-            if (k0 + BK < kend) step(k0 + BK, SET0{});
+            step(k0 + BK, SET0{});
         }
         stage(0);
     } else {
         load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
-        store_smem(SET0{});
+        store_smem(SET0{}, kbeg);
         __syncthreads();
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             const bool more = (k0 + BK) < kend;
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM ==
             mma(k0);
             __syncthreads();
             if (more) {
-                store_smem(SET0{});
+                store_smem(SET0{}, k0 + BK);
                 __syncthreads();
             }
         }
