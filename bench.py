@@ -310,6 +310,7 @@ def main():
     last = None
     for i in range(args.steps):
         last = step(args.warmup + i)
+    t_enq = time.perf_counter() - t0          # the host has ENQUEUED every step (the GPU is still running them unless the host is the limit)
     fence()
     dt = time.perf_counter() - t0
     table = ops.kernel_events_end() if use_events else {}
@@ -424,6 +425,7 @@ def main():
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
             "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),
+            "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 3),
             "phase_ms": phase_ms, "roofline": roof, "cpu_baseline": cpu, "drift_vs_parity_mode": drift,
             "world": world, "rccl_ranks": rccl_ranks, "devices": devices,
             "allreduce": {"buckets": n_buckets, "issued_under_the_aux_sweep": overlapped_buckets},

@@ -83,8 +83,66 @@ def _partials_ws(n: int, device):
     return C.c_void_p(t.data_ptr()), nbytes, t
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream          # (the Python-level torch.cuda.current_stream() costs ~5 us per call:
+_cur_device = torch._C._cuda_getDevice                    #  with ~2000 launches per step that alone was a fifth of the host's enqueue time)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device"""
+    return C.c_void_p(_raw_stream(_cur_device()))
+
+
+# ---- cheap stream plumbing.  torch.cuda.stream() / Stream.wait_stream() are Python-level wrappers that look the current stream
+# up through several layers and create a fresh Event per call (~20-30 us per fork); the weight-gradient side stream forks a few
+# hundred times per step, so these do the same thing on the C-level entry points with a ring of reusable events.
+_set_stream_raw = torch._C._cuda_setStream                # (stream_id, device_index, device_type)
+_get_stream_raw = torch._C._cuda_getCurrentStream         # device_index -> (stream_id, device_index, device_type)
+_stream_objs = {}
+_ev_ring, _ev_next = [], 0
+
+
+def current_stream_obj():
+    """torch.cuda.current_stream() without the Python-level device bookkeeping (Stream objects cached by id)"""
+    sid, di, dt = _get_stream_raw(_cur_device())
+    st = _stream_objs.get((sid, di))
+    if st is None:
+        st = _stream_objs[(sid, di)] = torch.cuda.Stream(stream_id=sid, device_index=di, device_type=dt)
+    return st
+
+
+def stream_wait(dst, src):
+    """dst.wait_stream(src): everything enqueued on dst from now on runs after what src holds now.  Reuses events: a wait
+    refers to the record that precedes it at ENQUEUE time, so re-recording the event later does not disturb it."""
+    global _ev_next
+    if torch.cuda.is_current_stream_capturing():
+        dst.wait_stream(src)                               # captures want a fresh event node per dependency
+        return
+    if not _ev_ring:
+        _ev_ring.extend(torch.cuda.Event() for _ in range(16))
+    ev = _ev_ring[_ev_next]
+    _ev_next = (_ev_next + 1) & 15
+    ev.record(src)
+    dst.wait_event(ev)
+
+
+class use_stream:
+    """with use_stream(s): torch's current stream is s (what torch.cuda.stream(s) does, minus ~15 us of Python per use)"""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s):
+        self.s, self.prev = s, None
+
+    def __enter__(self):
+        if self.s is not None:
+            self.prev = _get_stream_raw(self.s.device_index)
+            _set_stream_raw(stream_id=self.s.stream_id, device_index=self.s.device_index, device_type=self.s.device_type)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            sid, di, dt = self.prev
+            _set_stream_raw(stream_id=sid, device_index=di, device_type=dt)
+        return False
 
 
 def _chk(*ts):
@@ -178,7 +236,7 @@ def _release_finished_side_blocks():
 
 def join_side_stream():
     if _side_stream is not None:
-        torch.cuda.current_stream().wait_stream(_side_stream)
+        stream_wait(current_stream_obj(), _side_stream)
         _side_keepalive.clear()
         _side_blocks.clear()
 
@@ -194,11 +252,11 @@ class _on_side:
     def __enter__(self):
         if _side_stream is None:
             return self
-        _side_stream.wait_stream(torch.cuda.current_stream())
+        stream_wait(_side_stream, current_stream_obj())
         for t in self.tensors:
             t.record_stream(_side_stream)
         _side_keepalive.extend(self.tensors)
-        self.ctx = torch.cuda.stream(_side_stream)
+        self.ctx = use_stream(_side_stream)
         self.ctx.__enter__()
         return self
 

@@ -55,7 +55,7 @@ class FusedAdamW:
             self.set_lr(self.param_groups[0]["lr"])          # a torch scheduler wrote the new rate into param_groups
         call("mdvit_adamw_step", C.c_void_p(self.table.data_ptr()), len(self.params), self.blocks, C.c_void_p(self.lr_dev.data_ptr()),
              C.c_void_p(self.step_dev.data_ptr()), self.betas[0], self.betas[1], self.eps, self.weight_decay, int(self.zero_grad_after),
-             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+             ops._stream())
         # the kernel wrote the parameters through raw pointers: Tensor._version did not move, so the cached W^T copies and weight
         # planes of the GEMMs are invalidated HERE (they are rebuilt by ops.refresh_transposes() at the start of the next step,
         # or lazily by the first GEMM that touches a weight)

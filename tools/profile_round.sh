@@ -29,6 +29,7 @@ rm -rf "$OUT/${TAG}_tf_trace"
 # the last three (timed) steps of the profiled run: 3 x its own ms_per_step back from the end of the trace
 LAST=$(python3 -c "import json,sys; print(3.0 * json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['ms_per_step'])" "$OUT/${TAG}_bench_bs4_under_rocprof.json")
 python3 tools/trace_summary.py "$OUT/${TAG}_trace" --steps 3 --last-ms "$LAST" > "$OUT/${TAG}_bench_bs4_trace_summary.txt"
+python3 tools/trace_summary.py "$OUT/${TAG}_trace" --steps 3 --last-ms "$LAST" --main-stream > "$OUT/${TAG}_bench_bs4_main_stream.txt"
 python3 tools/trace_gaps.py "$OUT/${TAG}_trace" --last-ms "$LAST" > "$OUT/${TAG}_bench_bs4_idle_gaps.txt"
 KS=$(ls "$OUT/${TAG}_trace"/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$KS" ] && cp "$KS" "$OUT/${TAG}_bench_bs4_kernel_stats.csv"

@@ -1,5 +1,7 @@
 """Summarise a rocprofv3 --kernel-trace csv: per-kernel totals per step, per-stream busy time, idle gaps.
-usage: python tools/trace_summary.py <dir or *_kernel_trace.csv> [--steps K] [--skip-frac F]"""
+usage: python tools/trace_summary.py <dir or *_kernel_trace.csv> [--steps K] [--skip-frac F] [--main-stream]
+--main-stream: the breakdown of the BUSIEST stream only (the critical path of the step: the other streams overlap it), with the
+gaps between its consecutive kernels."""
 import csv, glob, os, sys, collections
 
 def main():
@@ -17,6 +19,18 @@ def main():
     rows = [r for r in rows if int(r["Start_Timestamp"]) >= cut]
     t0 = int(rows[0]["Start_Timestamp"])
     span = (t1 - t0) / 1e6
+    if "--main-stream" in sys.argv:
+        key = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
+        tot_s = collections.defaultdict(float)
+        for r in rows:
+            tot_s[r[key]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        main_id = max(tot_s, key=tot_s.get)
+        rows = [r for r in rows if r[key] == main_id]
+        g = [int(b["Start_Timestamp"]) - int(a["End_Timestamp"]) for a, b in zip(rows[:-1], rows[1:])]
+        g = [x for x in g if x > 0]
+        small = [x for x in g if x < 20000]
+        print(f"main stream {main_id}: {len(rows)} kernels, {len(rows) / steps:.0f}/step; gaps between consecutive kernels: {sum(g) / 1e6 / steps:.2f} ms/step "
+              f"(of which < 20 us: n={len(small) / steps:.0f}/step, {sum(small) / 1e6 / steps:.2f} ms/step, median {sorted(small)[len(small) // 2] / 1e3:.1f} us)")
     per = collections.defaultdict(lambda: [0.0, 0])
     streams = collections.defaultdict(float)
     for r in rows:
