@@ -538,9 +538,12 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     // U = dwconv_win(v) + bias, one tiled launch per window class (channels [0,s3*Ch) | [..) | [..))
     const int Ch = g.Ch, c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
     const CtGeom cg{B, g.H, g.W};
-    launch_conv_tile<3, false>(qkv, 3L * C, 2 * C, w3, b3, U, (long)C, 0, cg, s3 * Ch, s);
-    launch_conv_tile<5, false>(qkv, 3L * C, 2 * C + c5, w5, b5, U, (long)C, c5, cg, s5 * Ch, s);
-    launch_conv_tile<7, false>(qkv, 3L * C, 2 * C + c7, w7, b7, U, (long)C, c7, cg, s7 * Ch, s);
+    {   // the three window classes in one launch
+        const int xoff[3] = {2 * C, 2 * C + c5, 2 * C + c7}, yoff[3] = {0, c5, c7}, ncls[3] = {s3 * Ch, s5 * Ch, s7 * Ch};
+        const float* const ws3[3] = {w3, w5, w7};
+        const float* const bs3[3] = {b3, b5, b7};
+        launch_conv3<false>(qkv, 3L * C, xoff, ws3, bs3, U, (long)C, yoff, cg, ncls, s);
+    }
     {
         const int TLN = max(1, 256 / C), block = TLN * C;
         int tpb = TLN * 8;
@@ -621,9 +624,11 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, wg_part, cg, s7 * Ch, s);
     }
     // conv^T(dU) = correlation with the flipped window
-    launch_conv_tile<3, true>(dU, (long)C, 0, w3, nullptr, dVc, (long)C, 0, cg, s3 * Ch, s);
-    launch_conv_tile<5, true>(dU, (long)C, c5, w5, nullptr, dVc, (long)C, c5, cg, s5 * Ch, s);
-    launch_conv_tile<7, true>(dU, (long)C, c7, w7, nullptr, dVc, (long)C, c7, cg, s7 * Ch, s);
+    {   // transposed (flipped-tap) windows of the three classes in one launch
+        const int off[3] = {0, c5, c7}, ncls[3] = {s3 * Ch, s5 * Ch, s7 * Ch};
+        const float* const ws3[3] = {w3, w5, w7};
+        launch_conv3<true>(dU, (long)C, off, ws3, nullptr, dVc, (long)C, off, cg, ncls, s);
+    }
     // 4, 5
     const int GW = Ch < 32 ? 32 : Ch;
     MDVIT_CHECK_ARG(C % GW == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GW);

@@ -40,15 +40,15 @@ __device__ __forceinline__ void ct_stage_window(float* __restrict__ sx, const fl
     }
 }
 
+// body of one (tile, 32-channel block, image) workgroup; sx / sw: LDS of at least (8+2R)(16+2R)*32 and 32*WIN*WIN floats
 template <int WIN, bool FLIP>
-__global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restrict__ x, long ldx, int xoff,
-                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ y, long ldy, int yoff,
-                                                           int H, int W, int ncls, int tiles_w, int add_center) {
+__device__ __forceinline__ void conv_tile_body(float* __restrict__ sx, float* __restrict__ sw, int cblock,
+                                               const float* __restrict__ x, long ldx, int xoff,
+                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                               float* __restrict__ y, long ldy, int yoff,
+                                               int H, int W, int ncls, int tiles_w, int add_center) {
     constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
-    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
-    __shared__ float sw[CT_CL * WIN * WIN];
-    const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
+    const int b = blockIdx.z, c0 = cblock * CT_CL;
     const int th0 = (blockIdx.x / tiles_w) * CT_TH, tw0 = (blockIdx.x % tiles_w) * CT_TW;
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const long img = (long)b * H * W;
@@ -83,6 +83,52 @@ __global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < CT_TW; ++t)
         if (tw0 + t < W) y[(img + (long)h * W + tw0 + t) * ldy + yoff + c0 + cl] = acc[t];
+}
+
+template <int WIN, bool FLIP>
+__global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restrict__ x, long ldx, int xoff,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, long ldy, int yoff,
+                                                           int H, int W, int ncls, int tiles_w, int add_center) {
+    constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
+    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
+    __shared__ float sw[CT_CL * WIN * WIN];
+    conv_tile_body<WIN, FLIP>(sx, sw, blockIdx.y, x, ldx, xoff, w, bias, y, ldy, yoff, H, W, ncls, tiles_w, add_center);
+}
+
+// The three window classes of ConvRelPosEnc (3x3 / 5x5 / 7x7 head groups, mpvit.py:296-318) in ONE launch: blockIdx.y walks the
+// 32-channel blocks of class 3, then 5, then 7 (a third of the launches of the attention's forward and data-gradient passes).
+struct Conv3Args {
+    const float* x; long ldx; int xoff[3];
+    const float* w[3]; const float* bias[3];
+    float* y; long ldy; int yoff[3];
+    int H, W, ncls[3], yb[3], tiles_w;
+};
+template <bool FLIP>
+__global__ __launch_bounds__(256) void fa_conv3_kernel(Conv3Args p) {
+    __shared__ __attribute__((aligned(16))) float sx[(CT_TH + 6) * (CT_TW + 6) * CT_CL];
+    __shared__ float sw[CT_CL * 49];
+    int yb = blockIdx.y;
+    if (yb < p.yb[0]) { conv_tile_body<3, FLIP>(sx, sw, yb, p.x, p.ldx, p.xoff[0], p.w[0], p.bias[0], p.y, p.ldy, p.yoff[0], p.H, p.W, p.ncls[0], p.tiles_w, 0); return; }
+    yb -= p.yb[0];
+    if (yb < p.yb[1]) { conv_tile_body<5, FLIP>(sx, sw, yb, p.x, p.ldx, p.xoff[1], p.w[1], p.bias[1], p.y, p.ldy, p.yoff[1], p.H, p.W, p.ncls[1], p.tiles_w, 0); return; }
+    yb -= p.yb[1];
+    conv_tile_body<7, FLIP>(sx, sw, yb, p.x, p.ldx, p.xoff[2], p.w[2], p.bias[2], p.y, p.ldy, p.yoff[2], p.H, p.W, p.ncls[2], p.tiles_w, 0);
+}
+
+template <bool FLIP>
+void launch_conv3(const float* x, long ldx, const int xoff[3], const float* const w[3], const float* const bias[3], float* y, long ldy,
+                  const int yoff[3], const CtGeom& g, const int ncls[3], hipStream_t s) {
+    Conv3Args a;
+    a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.H = g.H; a.W = g.W; a.tiles_w = cdiv(g.W, CT_TW);
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+        a.xoff[i] = xoff[i]; a.yoff[i] = yoff[i]; a.w[i] = w[i]; a.bias[i] = bias ? bias[i] : nullptr; a.ncls[i] = ncls[i];
+        a.yb[i] = ncls[i] > 0 ? cdiv(ncls[i], CT_CL) : 0;
+        total += a.yb[i];
+    }
+    if (total == 0) return;
+    hipLaunchKernelGGL((fa_conv3_kernel<FLIP>), dim3(a.tiles_w * cdiv(g.H, CT_TH), total, g.B), dim3(256), 0, s, a);
 }
 
 // dw[ci][i][j] = sum_tokens g[n,cg] * x[n + (i-R, j-R), cx];  db[ci] = sum g.   Thread (channel, window row i)

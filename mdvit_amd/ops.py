@@ -729,13 +729,15 @@ class _Linear(torch.autograd.Function):
         # gradient (column sums of gm); the dgrad / wgrad GEMMs below read gm with no prologue of their own
         masked = drop_p > 0 or rowscale is not None
         gm = _empty_like(g) if masked else g
-        # unmasked: the bias gradient rides on the wgrad GEMM's own pass over g (colsum_a); masked: it is fused into the mask pass
-        ride = want_b and not masked and (sunk or ctx.needs_input_grad[1])
+        # the bias gradient (column sums of gm) rides on the wgrad GEMM's own pass over gm (colsum_a) whenever that GEMM runs: the
+        # mask pass then only masks -- no partial sums, no second-stage reduction launch on the main stream
+        ride = want_b and (sunk or ctx.needs_input_grad[1])
         if want_b and not sunk and ride:
             db.zero_()
         if masked or (want_b and not ride):
-            wsp, wsb, _keep = _partials_ws(N, g.device) if want_b else (None, 0, None)
-            call("mdvit_colsum_f32", _p(g), N, _p(sb if sunk else db) if want_b else None, _p(gm) if masked else None, wsp, wsb, M, N,
+            sums = want_b and not ride
+            wsp, wsb, _keep = _partials_ws(N, g.device) if sums else (None, 0, None)
+            call("mdvit_colsum_f32", _p(g), N, _p(sb if sunk else db) if sums else None, _p(gm) if masked else None, wsp, wsb, M, N,
                  drop_p, key[0], key[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
         if ctx.needs_input_grad[0]:
             dx = _empty_like(x)
@@ -871,14 +873,13 @@ class _MlpResidual(torch.autograd.Function):
         sinks = [_sink_of(t) for t in (W1, ctx.b1_ref, W2, ctx.b2_ref)] if not _dgrad_only else [None] * 4
         sunk = not _dgrad_only and all(t is not None for t in sinks)
         if not _dgrad_only and not sunk:
-            db2 = _empty((Cin,), device=dev, dtype=torch.float32)
-        # gm = g * dropmask2 * droppath scale, and db2 = column sums of gm, in one pass
+            db2 = torch.zeros((Cin,), device=dev, dtype=torch.float32)
+        # gm = g * dropmask2 * droppath scale in one pass; db2 = column sums of gm rides on the fc2 wgrad GEMM's pass over gm (colsum_a)
         masked = drop_p > 0 or rowscale is not None
         gm = _empty_like(g) if masked else g
-        if masked or not _dgrad_only:
-            wsp, wsb, _keep = (None, 0, None) if _dgrad_only else _partials_ws(Cin, dev)
-            call("mdvit_colsum_f32", _p(g), Cin, None if _dgrad_only else _p(sinks[3] if sunk else db2), _p(gm) if masked else None, wsp, wsb, M, Cin,
-                 drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
+        if masked:
+            call("mdvit_colsum_f32", _p(g), Cin, None, _p(gm), None, 0, M, Cin,
+                 drop_p, k2[0], k2[1], _p(rowscale), rps, 0, _seed_ptr() if drop_p > 0 else None, _stream())
         # du = (gm W2) * gelu'(u) * mask1
         dx = _empty_like(x)
         if u is None and _mlp_fused and _gemm_precision >= 1 and Cin == 64 and Hd % 64 == 0 and W1.is_contiguous() and W2.is_contiguous():
@@ -903,13 +904,14 @@ class _MlpResidual(torch.autograd.Function):
             if sunk:
                 dW1_, db1_, dW2_, _ = sinks
                 with _on_side(gm, h, du, x):
-                    gemm(_p(gm), _p(h), _p(dW2_), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, accumulate=True)
+                    gemm(_p(gm), _p(h), _p(dW2_), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, accumulate=True,
+                         colsum_a=_p(sinks[3]))      # db2 = column sums of gm
                     gemm(_p(du), _p(x), _p(dW1_), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, accumulate=True,
                          colsum_a=_p(db1_))          # db1 = column sums of du, taken from the wgrad's A stream
                 db2 = None
             else:
                 dW2 = _empty_like(W2)
-                gemm(_p(gm), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True)
+                gemm(_p(gm), _p(h), _p(dW2), Cin, Hd, M, lda=Cin, ldb=Hd, ldc=Hd, trans_a=True, trans_b=False, allow_split=True, colsum_a=_p(db2))
                 dW1 = _empty_like(W1)
                 db1 = torch.zeros((Hd,), device=dev, dtype=torch.float32)
                 gemm(_p(du), _p(x), _p(dW1), Hd, Cin, M, lda=Hd, ldb=Cin, ldc=Cin, trans_a=True, trans_b=False, allow_split=True, colsum_a=_p(db1))
