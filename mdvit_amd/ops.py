@@ -206,11 +206,12 @@ def _sink_of(t):
 # to a stream of its own, so the heads overlap each other instead of queueing behind each other on the main stream.
 _peer_streams = []
 _use_peer_streams = os.environ.get("MDVIT_PEER_STREAMS", "1") != "0"
+_graph_peers = os.environ.get("MDVIT_GRAPH_PEERS", "0") != "0"      # fork the peer streams inside a HIP-graph capture too
 
 
 def peer_stream(i: int):
     """the i-th peer stream, or None when disabled / capturing (a captured graph keeps the single-stream order)"""
-    if not _use_peer_streams or torch.cuda.is_current_stream_capturing():
+    if not _use_peer_streams or (torch.cuda.is_current_stream_capturing() and not _graph_peers):
         return None
     while len(_peer_streams) <= i:
         _peer_streams.append(torch.cuda.Stream())
