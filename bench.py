@@ -208,6 +208,8 @@ def main():
     from mdvit_amd.synthetic import make_step_batches
     from mdvit_amd.train import base_train_step, mdvit_train_step
 
+    if os.environ.get("MDVIT_AUTOGRAD_MT", "1") == "0":
+        torch.autograd.set_multithreading_enabled(False)
     ops.set_gemm_precision(args.precision)
     # useful-flop roof of the GEMM arithmetic in use: fp32 MFMA peak, or a third of the bf16 peak (3 MFMAs per product)
     peak_mfma = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.precision]
@@ -293,7 +295,7 @@ def main():
         torch.cuda.synchronize()
 
     use_events = not args.no_kernel_events and not args.graph
-    dominant = None
+    dominant, dom_stride = None, 1
     for i in range(args.warmup):
         scout = use_events and not (args.by_shape or args.detail) and i == args.warmup - 1
         if scout:                       # the last warm-up step times EVERY GEMM launch to find the dominant kernel ...
@@ -302,10 +304,11 @@ def main():
         if scout:
             t = ops.kernel_events_end()
             if t:
-                dominant = max(t.items(), key=lambda kv: kv[1]["ms"])[0]
+                dominant, drec = max(t.items(), key=lambda kv: kv[1]["ms"])
+                dom_stride = max(1, drec["n"] // 32)       # ~32 timed launches per step: the events must not become the host's load
     fence()
-    if use_events:                      # ... the timed steps put HIP events around that kernel's launches only (events on all ~700
-        ops.kernel_events_begin(by_shape=args.by_shape, only=dominant)     # GEMM launches cost ~4 % of a step)
+    if use_events:                      # ... the timed steps put HIP events around a sample of that kernel's launches only (events on
+        ops.kernel_events_begin(by_shape=args.by_shape, only=dominant, stride=dom_stride)   # all ~700 GEMM launches cost ~4 % of a step)
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
@@ -366,9 +369,10 @@ def main():
                 roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
             else:
                 roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak_mfma, 1), "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
-            roof.update({"traffic": traffic, "launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
+            launches = rec.get("launches", rec["n"])
+            roof.update({"traffic": traffic, "launches": launches, "timed_launches": rec["n"], "avg_launch_us": round(rec["ms"] * 1e3 / rec["n"], 2),
                          "flop_per_launch": round(rec["flop"] / rec["n"]), "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]),
-                         "mfma_tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "share_of_step": round(rec["ms"] / (dt * 1e3), 4)})
+                         "mfma_tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "share_of_step": round(rec["ms"] * launches / rec["n"] / (dt * 1e3), 4)})
             if args.detail:
                 with open(args.detail, "w") as f:
                     json.dump({"step_ms": dt * 1e3 / args.steps, "kernels": table}, f, indent=1)

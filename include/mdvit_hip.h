@@ -97,6 +97,9 @@ int mdvit_transpose_many(const void* items_dev, int32_t n, int32_t blocks_per_it
 /* Tuning hook for tools/gemm_sweep.py: pin the tile configuration (0: 128x128, 1: 256x64, 2: 64x64; -1: planner) and the
  * requested K-split (one of the planner's candidates; 0: planner) of every following mdvit_gemm_f32 call. */
 int mdvit_gemm_force_plan(int32_t cfg, int32_t splits);
+/* The kernel symbol mdvit_gemm_f32 launches for this descriptor, as rocprofv3 prints it ("+splitk_reduce" appended when the K-split
+ * reduction follows): measurement hook, bench.py matches its HIP-event timings against the committed profile by this name. */
+int mdvit_gemm_kernel_name(const MdvitGemmDesc* d, char* out, int32_t cap);
 /* The TN (weight-gradient: autograd's grad_out.t() @ input of nn.Linear / 1x1 conv) launches of mdvit_gemm_f32 run on a dedicated
  * kernel (gemm_tn.hip: k-major LDS image read through ds_read_b64_tr_b16).  enable = 0 routes them through the general template
  * again; cfg 0..3 = tile 128x128 / 128x64 / 64x128 / 64x64 (-1: planner), splits > 0 forces the K-split (A/B and sweep hook). */

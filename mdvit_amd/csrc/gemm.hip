@@ -876,6 +876,23 @@ extern "C" int mdvit_gemm_plan(const MdvitGemmDesc* d, int32_t* tile_m, int32_t*
     return MDVIT_OK;
 }
 
+// the kernel symbol this descriptor launches, as rocprofv3 prints it (bench.py matches its event timings against the profile by name)
+void mdvit_gemm_tn_name(const MdvitGemmDesc* d, char* out, int cap);
+extern "C" int mdvit_gemm_kernel_name(const MdvitGemmDesc* d, char* out, int32_t cap) {
+    MDVIT_CHECK_ARG(d != nullptr && out != nullptr && cap > 0 && d->M > 0 && d->N > 0 && d->K > 0, MDVIT_E_SHAPE, "gemm_kernel_name: bad arguments");
+    if (mdvit_gemm_tn_applies(d)) { mdvit_gemm_tn_name(d, out, cap); return MDVIT_OK; }
+    const GemmPlan pl = plan_gemm(d);
+    const bool drop = d->e_drop_p > 0.f;
+    int epi = EPI_PLAIN;
+    if (d->epi == MDVIT_EPI_GELU_DUAL) epi = EPI_GELU2;
+    else if (d->epi == MDVIT_EPI_DGELU) epi = d->rc_a ? EPI_DGELU_RC : EPI_DGELU;
+    else if (drop || d->e_rowscale || d->residual) epi = EPI_FULL;
+    const int bm = pl.cfg == 0 ? 128 : (pl.cfg == 1 ? 256 : 64), bn = pl.cfg == 0 ? 128 : 64;
+    snprintf(out, cap, "gemm_f32_kernel<%d, %d, %s, %s, %s, %d, %s>%s", bm, bn, pl.cfg == 1 ? "4, 1" : "2, 2", d->trans_a ? "true" : "false",
+             d->trans_b ? "true" : "false", epi, d->precision ? "true" : "false", pl.splits > 1 ? "+splitk_reduce" : "");
+    return MDVIT_OK;
+}
+
 extern "C" size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* d) {
     if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_ws_bytes(d);

@@ -284,6 +284,12 @@ void mdvit_gemm_tn_plan(const MdvitGemmDesc* d, int* tile_m, int* tile_n, int* s
     if (splits) *splits = pl.splits;
 }
 
+void mdvit_gemm_tn_name(const MdvitGemmDesc* d, char* out, int cap) {
+    const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
+    snprintf(out, cap, "gemm_tn_kernel<%d, %d, %d, %s>%s", TN_BM[pl.cfg], TN_BN[pl.cfg], d->precision == 2 ? 1 : 2, d->colsum_a ? "true" : "false",
+             pl.splits > 1 ? "+splitk_reduce" : "");
+}
+
 int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
     const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
     TnArgs a;

@@ -329,26 +329,25 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
         return
     kepi = 1 if epi == _lib.EPI_GELU_DUAL else (4 if rc is not None else 2) if epi == _lib.EPI_DGELU else \
         3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
-    pkey = (M, N, K, bool(trans_a), bool(trans_b), kepi, int(precision), bool(allow_split))
-    plan = _plan_cache.get(pkey)
-    if plan is None:
+    pkey = (M, N, K, bool(trans_a), bool(trans_b), kepi, int(precision), bool(allow_split), colsum_a is not None)
+    name = _plan_cache.get(pkey)
+    if name is None:
+        buf = C.create_string_buffer(160)
+        call("mdvit_gemm_kernel_name", C.byref(d), buf, 160)       # the symbol as rocprofv3 prints it
         tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
         call("mdvit_gemm_plan", C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp))
-        plan = _plan_cache[pkey] = (tm.value, tn.value, sp.value)
-    tmv, tnv, spv = plan
-    waves = {128: "2, 2", 256: "4, 1", 64: "2, 2"}[tmv]       # kernel symbol as rocprofv3 prints it
-    name = "gemm_f32_kernel<%d, %d, %s, %s, %s, %d, %s>%s" % (
-        tmv, tnv, waves, "true" if trans_a else "false", "true" if trans_b else "false", kepi,
-        "true" if precision else "false", "+splitk_reduce" if spv > 1 else "")
+        name = _plan_cache[pkey] = (buf.value.decode(), sp.value)
+    name, spv = name
     if _events_by_shape:
         name += " M=%d N=%d K=%d sp=%d" % (M, N, K, spv)
-    if _events_only is not None and name != _events_only:
+    if not _event_wanted(name):
         call("mdvit_gemm_f32", C.byref(d), _stream())
         return
+    st = current_stream_obj()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record(st)
     call("mdvit_gemm_f32", C.byref(d), _stream())
-    e1.record()
+    e1.record(st)
     # algorithmic HBM bytes of the launch: A, B read once, C (and C2 / residual / gelu_u) once
     nbytes = 4.0 * (M * K + N * K + M * N * (1 + (out2 is not None) + (residual is not None) + (gelu_u is not None)))
     if rc is not None:
@@ -608,13 +607,14 @@ def gemm_nt(x, W, out, M, N, K, *, w_transposed=False, bias=None, epi=_lib.EPI_N
     name = "gemm_bp_nt_kernel<%d, %d, %d, %s, %d>%s" % (plan[0], plan[1], P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
     if _events_by_shape:
         name += " M=%d N=%d K=%d sp=%d" % (M, N, K, plan[2])
-    if _events_only is not None and name != _events_only:
+    if not _event_wanted(name):
         call("mdvit_gemm_planes", C.byref(d), _stream())
         return
+    st = current_stream_obj()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record(st)
     call("mdvit_gemm_planes", C.byref(d), _stream())
-    e1.record()
+    e1.record(st)
     abytes = 4.0 if a_f32 else 2.0 * P
     nbytes = abytes * M * K + 2.0 * P * N * K + M * N * (4.0 * (out is not None) + 2.0 * P * (out_planes is not None) + 4.0 * (U is not None)
                                                         + 4.0 * (residual is not None) + 4.0 * (gelu_u is not None))
@@ -644,13 +644,27 @@ _events_only = None
 _plan_cache = {}
 
 
-def kernel_events_begin(by_shape: bool = False, only: Optional[str] = None):
-    """only: time the launches of ONE kernel name (as a previous full pass reported it) -- two events per GEMM on every
-    launch cost ~4 % of a step, two events on the dominant kernel's ~30 launches cost nothing."""
-    global _events, _events_by_shape, _events_only
+_events_stride, _events_seen = 1, {}
+
+
+def _event_wanted(name: str) -> bool:
+    if _events_only is not None and name != _events_only:
+        return False
+    n = _events_seen.get(name, 0)
+    _events_seen[name] = n + 1
+    return n % _events_stride == 0
+
+
+def kernel_events_begin(by_shape: bool = False, only: Optional[str] = None, stride: int = 1):
+    """only: time the launches of ONE kernel name (as a previous full pass reported it); stride: time every stride-th of them.
+    Two events per GEMM on every launch cost ~4 % of a step (and on a few hundred side-stream launches per step they made the HOST
+    the limit of the step); two events on ~30 sampled launches of the dominant kernel cost nothing."""
+    global _events, _events_by_shape, _events_only, _events_stride
     _events = []
     _events_by_shape = bool(by_shape)
     _events_only = only
+    _events_stride = max(1, int(stride))
+    _events_seen.clear()
 
 
 def kernel_events_end():
@@ -668,6 +682,8 @@ def kernel_events_end():
         r["ms"] += e0.elapsed_time(e1)
         r["flop"] += flop
         r["bytes"] += nbytes
+    for name, r in table.items():
+        r["launches"] = _events_seen.get(name, r["n"])          # all launches of that kernel since begin (n of them were timed)
     return table
 
 
