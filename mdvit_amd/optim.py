@@ -3,7 +3,12 @@ lr_scheduler.StepLR(step_size=50, gamma=0.5)) as ONE HIP launch per step over ev
 
 FusedAdamW works on a parallel.GradAccumulator: the gradients are the accumulator's flat bucket views, the two moments
 are flat buffers with the same layout, and a device table of pointers drives the kernel; the step counter and the
-learning rate live in device memory (HIP-graph replay safe)."""
+learning rate live in device memory (HIP-graph replay safe).
+
+Deviation from torch.optim.AdamW, by construction: the kernel updates EVERY parameter of the accumulator on every step (gradient =
+the bucket view, zero if nothing was accumulated), so a parameter that received no gradient at all in a step is still weight-decayed
+and its moments still decay -- torch skips parameters whose .grad is None.  In the train steps of this package every parameter is
+reached by the summed loss on every step (checked by the golden gradient-norm tests: no zero-norm entries), so the two agree there."""
 from __future__ import annotations
 
 import ctypes as C
