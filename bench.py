@@ -194,6 +194,16 @@ def main():
         # `python bench.py --gpus N` typed as is: start one fresh process per GPU (torch.distributed.run, rendezvous on
         # 127.0.0.1) BEFORE anything in this process touches the GPU, relay rank 0's JSON line, exit with the job's code.
         sys.exit(_spawn_ranks(args.gpus))
+    if os.environ.get("MDVIT_BENCH_DRYRUN"):
+        # launch-path check without a GPU (tests/test_host.py): the ranks this command line produces rendezvous over gloo on
+        # 127.0.0.1, count themselves, and rank 0 prints the line the driver would parse
+        dist.init_process_group("gloo")
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": args.gpus, "world": world, "ranks_seen": int(ones.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+        dist.barrier(); dist.destroy_process_group()
+        return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
     torch.cuda.set_device(local_rank)

@@ -92,6 +92,35 @@ def test_module_surface_matches_reference_inventory():
     assert abs(float(dw.std()) - (2.0 / 9) ** 0.5) < 0.05
 
 
+def test_transfuse_module_surface_matches_reference_inventory():
+    """TransFuse_S_adapt built on the CPU (parameters only): the reference's 630 state_dict keys and shapes (TransFuse.py:182-226,
+    torchvision's ResNet-34 names, DeiT's transformer.* names), 26.87 M parameters"""
+    from mdvit_amd.transfuse import TransFuse_S_adapt
+    from oracle.transfuse_ref import param_spec
+    m = TransFuse_S_adapt(num_classes=1, drop_rate=0.2, pretrained=False, num_domains=4)
+    sd, spec = m.state_dict(), param_spec()
+    assert set(sd) == set(spec) and len(sd) == 630
+    for k, (kind, shape) in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sum(p.numel() for p in m.parameters()) == 26873877
+
+
+def test_bench_gpus_n_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` typed as is (no torchrun around it): the parent starts the ranks through torch.distributed.run with a
+    127.0.0.1 rendezvous and relays rank 0's JSON line; checked here without a GPU through the dry-run hook (gloo)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDVIT_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=240, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d == {"dryrun": True, "n_gpus": 2, "world": 2, "ranks_seen": 2, "steps": 3, "warmup": 1}
+
+
 def test_synthetic_batches_follow_the_loader_contract():
     from mdvit_amd.synthetic import make_step_batches
     bs = make_step_batches(2, 64, rank=0)
