@@ -383,6 +383,12 @@ int mdvit_dropout2d(const float* x, float* y, int32_t B, int64_t P, int32_t C, f
 int mdvit_sdpa_fwd(const float* qkv, const float* a, float* out, float* P, int32_t B, int32_t N, int32_t C, int32_t heads, void* stream);
 int mdvit_sdpa_bwd(const float* g, const float* qkv, const float* P, const float* out, const float* a, float* dqkv, float* e, float* dS, int32_t B, int32_t N,
                    int32_t C, int32_t heads, void* stream);
+/* The same operator on the fp32 matrix cores for N == 256 tokens (the DeiT trunk's 16 x 16 grid), head dimension 64, <= 6 heads: no [N, N]
+ * tensor in HBM -- the forward keeps lse [B, heads, N] (row log-sum-exp), the backward recomputes the probabilities.
+ * delta: scratch [B, heads, N]. */
+int mdvit_sdpa_mfma_fwd(const float* qkv, const float* a, float* out, float* lse, int32_t B, int32_t N, int32_t C, int32_t heads, void* stream);
+int mdvit_sdpa_mfma_bwd(const float* g, const float* qkv, const float* lse, const float* out, const float* a, float* dqkv, float* e, float* delta,
+                        int32_t B, int32_t N, int32_t C, int32_t heads, void* stream);
 /* structure_loss (multi_train_TransFuse.py:29-38): weit = 1 + 5 |avg_pool2d(mask, 31, 1, 15) - mask| (tmp: scratch [B,H,W]);
  * loss = mean_b [ sum(weit bce_with_logits) / sum(weit) + 1 - (I + 1) / (U - I + 1) ], I = sum(sigmoid(pred) mask weit), U = sum((sigmoid(pred) + mask) weit);
  * sums [B][4] double kept for the backward; gscale [1] = upstream gradient of the scalar loss */

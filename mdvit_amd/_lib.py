@@ -96,6 +96,8 @@ _SIGS = {
     "mdvit_dropout2d": [vp, vp, i32, i64, i32, f32, u32, u32, vp, vp],
     "mdvit_sdpa_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "mdvit_sdpa_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_sdpa_mfma_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_sdpa_mfma_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "mdvit_structure_weight": [vp, vp, vp, i32, i32, i32, vp],
     "mdvit_structure_loss_fwd": [vp, vp, vp, vp, vp, i32, i64, vp],
     "mdvit_structure_loss_bwd": [vp, vp, vp, vp, vp, vp, i32, i64, vp],

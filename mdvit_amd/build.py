@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmdvit_hip.so")
-SOURCES = ["abi.hip", "gemm.hip", "gemm_tn.hip", "gemm_bp.hip", "mlp.hip", "norm.hip", "conv.hip", "attn.hip", "loss.hip", "optim.hip", "transfuse.hip"]
+SOURCES = ["abi.hip", "gemm.hip", "gemm_tn.hip", "gemm_bp.hip", "mlp.hip", "norm.hip", "conv.hip", "attn.hip", "loss.hip", "optim.hip", "transfuse.hip", "sdpa.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

@@ -9,6 +9,7 @@ csrc/transfuse.hip through the autograd Functions below.  Only 256x256 inputs ar
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Dict, Optional, Sequence
 
@@ -334,6 +335,9 @@ def dropout2d(x, p: float, training: bool):
     return _Dropout2d.apply(_c(x), float(p), _next_key())
 
 
+_use_mfma_sdpa = os.environ.get("MDVIT_SDPA_MFMA", "1") != "0"         # A/B switch: 0 = the LDS-tiled fp32 VALU kernels at every N
+
+
 class _SDPA(torch.autograd.Function):
     """Attention_Sup core + Domain Adapter (vision_transformer.py:148-169): qkv [B,N,3C] -> a * softmax(q k^T / sqrt(d)) v  [B,N,C]"""
 
@@ -347,8 +351,13 @@ class _SDPA(torch.autograd.Function):
         a = _empty((B, Cn), device=dev, dtype=torch.float32)
         call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, label.shape[1], W1.shape[0], Cn, heads, _stream())
         out = _empty((B, N, Cn), device=dev, dtype=torch.float32)
-        P = _empty((B, heads, N, N), device=dev, dtype=torch.float32)
-        call("mdvit_sdpa_fwd", _p(qkv), _p(a), _p(out), _p(P), B, N, Cn, heads, _stream())
+        ctx.mfma = N == 256 and heads <= 6 and _use_mfma_sdpa          # the DeiT trunk's shape: fp32 matrix cores, no [N, N] tensor in HBM
+        if ctx.mfma:
+            P = _empty((B, heads, N), device=dev, dtype=torch.float32)      # row log-sum-exp
+            call("mdvit_sdpa_mfma_fwd", _p(qkv), _p(a), _p(out), _p(P), B, N, Cn, heads, _stream())
+        else:
+            P = _empty((B, heads, N, N), device=dev, dtype=torch.float32)
+            call("mdvit_sdpa_fwd", _p(qkv), _p(a), _p(out), _p(P), B, N, Cn, heads, _stream())
         ctx.save_for_backward(qkv, label, W1, b1, W2, b2, a, out, P)
         ctx.heads = heads
         return out
@@ -364,8 +373,9 @@ class _SDPA(torch.autograd.Function):
         dev = qkv.device
         dqkv = _empty_like(qkv)
         e = _empty((B, Cn), device=dev, dtype=torch.float32)
-        dS = _empty_like(P)
-        call("mdvit_sdpa_bwd", _p(_c(g)), _p(qkv), _p(P), _p(out), _p(a), _p(dqkv), _p(e), _p(dS), B, N, Cn, heads, _stream())
+        dS = _empty_like(P)                         # mfma: delta [B, heads, N]; else the [B, heads, N, N] score-gradient scratch
+        call("mdvit_sdpa_mfma_bwd" if ctx.mfma else "mdvit_sdpa_bwd", _p(_c(g)), _p(qkv), _p(P), _p(out), _p(a), _p(dqkv), _p(e), _p(dS),
+             B, N, Cn, heads, _stream())
         if ops._dgrad_only:
             return dqkv, None, None, None, None, None, None
         hid = W1.shape[0]

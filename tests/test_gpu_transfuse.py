@@ -132,10 +132,12 @@ def test_spatial_conv7_and_single_channel_batchnorm():
         assert int(m.num_batches_tracked) == int(bn.num_batches_tracked)
 
 
-def test_softmax_attention_with_domain_adapter():
-    """Attention_Sup core (vision_transformer.py:148-169): softmax(q k^T / 8) v scaled by the head-softmax adapter, fwd + all grads"""
+@pytest.mark.parametrize("N", [256, 128])
+def test_softmax_attention_with_domain_adapter(N):
+    """Attention_Sup core (vision_transformer.py:148-169): softmax(q k^T / 8) v scaled by the head-softmax adapter, fwd + all grads.
+    N = 256 (the DeiT trunk's shape) runs on the fp32-MFMA kernels of csrc/sdpa.hip, other lengths on the LDS-tiled VALU kernels."""
     from mdvit_amd import transfuse as T
-    B, N, heads, D = 2, 256, 6, 64
+    B, heads, D = 2, 6, 64
     Cn, hid = heads * D, 192
     qkv = rnd(B, N, 3 * Cn, seed=22)
     label = F.one_hot(torch.tensor([1, 3]), 4).float()
