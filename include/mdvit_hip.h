@@ -84,6 +84,14 @@ typedef struct MdvitGemmDesc {
      * u).  For the MLP of the C <= 128 stages (Mlp.fc1, mpvit.py:73-76: K = C): the forward then stores gelu(u) only
      * (GELU_DUAL with C2 == NULL writes gelu(u) x dropout to C) and neither pass moves the [tokens, hidden] u through HBM. */
     const float* rc_a; int64_t rc_lda; const float* rc_b; int64_t rc_ldb; const float* rc_bias; int32_t rc_k;
+    /* Implicit 3x3 convolution (conv_c > 0; NT, precision >= 1, plain epilogue): A is NOT a matrix but the NHWC image
+     * [M / (conv_ho conv_wo), conv_h, conv_w, conv_c]; row m = output pixel (b, ho, wo), K = 9 conv_c ordered (tap, channel):
+     * A[m][tap * conv_c + c] = image[b, ho * stride + (tap / 3 - 1) * dilation, wo * stride + (tap % 3 - 1) * dilation, c] (0 outside),
+     * gathered by the kernel while it stages the operand -- the [M, 9 C] im2col matrix is never written (nn.Conv2d(k = 3, padding =
+     * dilation) of mdvit.py:557-564, Utils/_deeplab.py:115-122, torchvision's ResNet BasicBlock; its data gradient at stride 1 is the
+     * same call on the output gradient with the flipped, transposed weight).  B = the weight as [N][tap][channel]
+     * (mdvit_conv_weight_relayout).  conv_c % 32 == 0; lda is ignored. */
+    int32_t conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dilation;
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
@@ -105,6 +113,10 @@ int mdvit_gemm_kernel_name(const MdvitGemmDesc* d, char* out, int32_t cap);
  * again; cfg 0..3 = tile 128x128 / 128x64 / 64x128 / 64x64 (-1: planner), splits > 0 forces the K-split (A/B and sweep hook). */
 int mdvit_gemm_tn_config(int32_t enable, int32_t cfg, int32_t splits);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
+/* Weight layouts of the implicit 3x3 convolution: w [Cout, Cin, 3, 3] (PyTorch) ->
+ *   mode 0: out [Cout][tap][Cin]                    (forward:        y = conv(x, w))
+ *   mode 1: out [Cin][8 - tap][Cout]                (data gradient: dx = conv(dy, flipped / transposed w), stride 1) */
+int mdvit_conv_weight_relayout(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t mode, void* stream);
 
 /* ---- "plane" GEMM family: operands pre-split into bf16 planes ------------------------------------------------
  * A plane tensor is [planes][rows][ld] bf16 (uint16 storage): plane 0 = hi = RNE bf16(x), plane 1 = lo = RNE bf16(x - hi),

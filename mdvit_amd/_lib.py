@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("precision", i32),
         ("drop_seed", vp),
         ("rc_a", vp), ("rc_lda", i64), ("rc_b", vp), ("rc_ldb", i64), ("rc_bias", vp), ("rc_k", i32),
+        ("conv_c", i32), ("conv_h", i32), ("conv_w", i32), ("conv_ho", i32), ("conv_wo", i32), ("conv_stride", i32), ("conv_dilation", i32),
     ]
 
 
@@ -107,6 +108,7 @@ _SIGS = {
     "mdvit_gemm_f32": [C.POINTER(GemmDesc), vp],
     "mdvit_gemm_plan": [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_force_plan": [i32, i32],
+    "mdvit_conv_weight_relayout": [vp, vp, i32, i32, i32, vp],
     "mdvit_gemm_kernel_name": [vp, C.c_char_p, i32],
     "mdvit_gemm_tn_config": [i32, i32, i32],
     "mdvit_transpose_f32": [vp, i64, vp, i32, i32, vp],

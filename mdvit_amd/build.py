@@ -38,7 +38,7 @@ def _digest(paths) -> str:
 def _compile(src: str) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     stamp = obj + ".sha"
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_tile.h"),
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_tile.h"), os.path.join(CSRC, "gemm_body.inc"),
             os.path.join(HERE, "..", "include", "mdvit_hip.h")]
     dig = _digest(deps)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:

@@ -45,6 +45,7 @@ struct GemmArgs {
     int vec;                       // output rows can take 16-byte vector accesses
     const uint32_t* seed;          // optional device-side dropout seed {s0, s1}: key0 ^= s0, key1 += s1 (graph replays draw fresh masks)
     int tiles_m, tiles_n;
+    int conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dil;     // CONV kernels: A is an NHWC image gathered on the fly
 };
 
 // Bijective XCD-aware remap (guide T1): consecutive logical tiles share an XCD's L2.
@@ -87,495 +88,21 @@ __device__ __forceinline__ void split_pair_bf16x3(float x0, float x1, uint32_t& 
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(l, bf16x2_t));
 }
 
+// The kernel body lives in gemm_body.inc and is textually included into both __global__ functions below (a shared __device__
+// function inlined into thin wrappers changed the code generation of the fp32 TN variants -- and their results; the body wants the
+// kernel's own parameter).  It expects: BM BN WAVES_M WAVES_N TA TB EPI BF3 CONV as compile-time constants and GemmArgs p.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI, bool BF3>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BM == 256 && TA) ? 2 : 3, 8))) void gemm_f32_kernel(GemmArgs p) {
-    // bf16x3 staging: a k-contiguous operand (A of NT/NN, B of NT) is split float4-wise into [row][k] bf16 planes; an
-    // m/n-contiguous operand (A and B of the TN wgrad) is loaded as PAIRS of consecutive k rows, so that each
-    // (row, k..k+1) bf16 pair is one v_cvt_pk_bf16_f32 and one ds_write_b32 -- with lanes running along k the writes
-    // are conflict-free (row stride 20 words, 16 k-pairs + 16-word offset between the two row quads of a 32-lane group).
-    constexpr bool A_PAIR = BF3 && TA, B_PAIR = BF3 && !TB;
-    static_assert(!BF3 || !(TA && TB), "bf16x3: TT is not a layout of this model");
-    // k-contiguous operands are transposed on the LDS write: odd leading dimension -> conflict-free ds_write_b32;
-    // m/n-contiguous operands are written as float4: leading dimension % 4 == 0.
-    constexpr int LDSA = TA ? BM + 4 : BM + 1, LDSB = TB ? BN + 1 : BN + 4;
-    constexpr int LDKB = 80;                                            // BF3: bytes per [row][32 x bf16] LDS row (64 + 16 pad)
-    constexpr int SMEM_FLOATS = BF3 ? (BM + BN) * 2 * LDKB / 4 : BK * LDSA + BK * LDSB;
-    constexpr int WTM = BM / WAVES_M / 32, WTN = BN / WAVES_N / 32;   // 32x32 blocks per wave
-    constexpr int A_V4 = BM * BK / 4 / NTHREADS, B_V4 = BN * BK / 4 / NTHREADS;
-    constexpr int KT = BK / 4;                                        // threads per k-contiguous row
-    // 64x64 tiles (little MFMA work per K slab) double-buffer the LDS stage: the next slab is written while the current
-    // one is being multiplied, ONE barrier per slab instead of two.  (The larger tiles would exceed the 64 KB static limit.)
-    constexpr bool DB = (BM == 64 && BN == 64 && !TA) && !MDVIT_NO_DB;     // (the pair-staged wgrad measured slower with the doubled LDS footprint)
-    __shared__ __attribute__((aligned(16))) float smem[DB ? 2 * SMEM_FLOATS : SMEM_FLOATS];
-    float* As = smem;
-    float* Bs = smem + BK * LDSA;
-    // BF3 planes (bytes): A hi | A lo | B hi | B lo
-    char* sb = reinterpret_cast<char*>(smem);
-    char* Ahi = sb; char* Alo = sb + BM * LDKB; char* Bhi = sb + 2 * BM * LDKB; char* Blo = Bhi + BN * LDKB;
-    auto stage = [&](int b) {              // point the staging / fragment pointers at LDS buffer b
-        float* base = smem + b * SMEM_FLOATS;
-        As = base; Bs = base + BK * LDSA;
-        sb = reinterpret_cast<char*>(base);
-        Ahi = sb; Alo = sb + BM * LDKB; Bhi = sb + 2 * BM * LDKB; Blo = Bhi + BN * LDKB;
-    };
+    constexpr bool CONV = false;
+#include "gemm_body.inc"
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t s0 = 0, s1 = 0;
-    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
-    const uint32_t ek0 = p.e_k0 ^ s0, ek1 = p.e_k1 + s1;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    constexpr bool RC = EPI == EPI_DGELU_RC;
-    // RC walks ONE virtual K axis: slabs [0, rc_k) multiply rc_a x rc_b^T into the pre-activation accumulators, slabs
-    // [rc_k, rc_k + K) multiply A x B^T into the gradient accumulators -- a single software pipeline over both products
-    const int kbeg = RC ? 0 : blockIdx.y * p.k_per_split;
-    const int kend = RC ? p.rc_k + p.K : min(p.K, kbeg + p.k_per_split);
-    const float* gA = p.A; const float* gB = p.B;
-    const long glda = p.lda, gldb = p.ldb;
-    const int wm0 = (wave / WAVES_N) * (BM / WAVES_M), wn0 = (wave % WAVES_N) * (BN / WAVES_N);
-
-    f32x16 acc[WTM][WTN];
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-        for (int j = 0; j < WTN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // global -> register staging sets: the double-buffered (64x64) path keeps TWO slabs in flight
-    using SET0 = std::integral_constant<int, 0>;
-    using SET1 = std::integral_constant<int, 1>;
-    constexpr bool PF2 = DB && !RC;           // (RC carries a second accumulator set: two staging sets would spill)
-    float4 ra[PF2 ? 2 : 1][A_V4], rb[PF2 ? 2 : 1][B_V4];
-    constexpr int NCS = A_PAIR ? A_V4 / 2 : 1;             // column-sum partials (TN + colsum, tile column 0 only)
-    float4 cs[NCS];
-#pragma unroll
-    for (int v = 0; v < NCS; ++v) cs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool do_cs = TA && p.colsum != nullptr && tn == 0;
-
-    auto load_a = [&](int k0, auto setc) {
-        constexpr int S = decltype(setc)::value;
-        if (A_PAIR) {           // rows k = k0 + 2*kp, +1 ; columns m0 + 4*mq .. +3
-#pragma unroll
-            for (int v = 0; v < A_V4 / 2; ++v) {
-                const int kp = tid & 15, mq = (tid >> 4) + 16 * v;
-                const int k = k0 + 2 * kp, m = m0 + 4 * mq;
-                float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-                if (m < p.M) {
-                    if (k < kend) x0 = *reinterpret_cast<const float4*>(gA + (long)k * glda + m);
-                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(gA + (long)(k + 1) * glda + m);
-                }
-                ra[S][2 * v] = x0; ra[S][2 * v + 1] = x1;
-            }
-            return;
-        }
-#pragma unroll
-        for (int v = 0; v < A_V4; ++v) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!TA) {   // A[m][k], k contiguous: BK/4 threads per row
-                // UNCONDITIONAL load from a clamped address (rows past M read row M-1: they only feed output rows that are never
-                // stored; k past the end is zeroed when the slab is written to LDS): a load under a branch makes the compiler drain
-                // the whole vector-memory queue at the join (s_waitcnt vmcnt(0)), which collapsed the two-slab prefetch to one
-                const int r = tid / KT + v * (NTHREADS / KT), m = m0 + r, k = k0 + (tid % KT) * 4;
-                const bool first = RC && k0 < p.rc_k;              // (uniform: scalar selects)
-                const float* src = first ? p.rc_a : gA;
-                const long ld = first ? p.rc_lda : glda;
-                const int kl = (RC && !first) ? k - p.rc_k : k;
-                const int ke = RC ? (first ? p.rc_k : p.K) : kend;
-                x = *reinterpret_cast<const float4*>(src + (long)min(m, p.M - 1) * ld + min(kl, ke - 4));
-            } else {     // A stored [k][m], m contiguous (wgrad: A = dY^T)
-                constexpr int TPR = BM / 4;                 // threads per k-row
-                const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, m = m0 + (tid % TPR) * 4;
-                if (k < kend && m < p.M) x = *reinterpret_cast<const float4*>(gA + (long)k * glda + m);
-            }
-            ra[S][v] = x;
-        }
-    };
-    auto load_b = [&](int k0, auto setc) {
-        constexpr int S = decltype(setc)::value;
-        if (B_PAIR) {
-#pragma unroll
-            for (int v = 0; v < B_V4 / 2; ++v) {
-                const int kp = tid & 15, nq = (tid >> 4) + 16 * v;
-                const int k = k0 + 2 * kp, n = n0 + 4 * nq;
-                float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-                if (n < p.N) {
-                    if (k < kend) x0 = *reinterpret_cast<const float4*>(gB + (long)k * gldb + n);
-                    if (k + 1 < kend) x1 = *reinterpret_cast<const float4*>(gB + (long)(k + 1) * gldb + n);
-                }
-                rb[S][2 * v] = x0; rb[S][2 * v + 1] = x1;
-            }
-            return;
-        }
-#pragma unroll
-        for (int v = 0; v < B_V4; ++v) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TB) {    // B[n][k], k contiguous (weights as stored by nn.Linear); unconditional, as for A
-                const int r = tid / KT + v * (NTHREADS / KT), n = n0 + r, k = k0 + (tid % KT) * 4;
-                const bool first = RC && k0 < p.rc_k;
-                const float* src = first ? p.rc_b : gB;
-                const long ld = first ? p.rc_ldb : gldb;
-                const int kl = (RC && !first) ? k - p.rc_k : k;
-                const int ke = RC ? (first ? p.rc_k : p.K) : kend;
-                x = *reinterpret_cast<const float4*>(src + (long)min(n, p.N - 1) * ld + min(kl, ke - 4));
-            } else {     // B[k][n], n contiguous
-                constexpr int TPR = BN / 4;
-                const int kk = tid / TPR + v * (NTHREADS / TPR), k = k0 + kk, n = n0 + (tid % TPR) * 4;
-                if (k < kend && n < p.N) x = *reinterpret_cast<const float4*>(gB + (long)k * gldb + n);
-            }
-            rb[S][v] = x;
-        }
-    };
-    auto store_smem = [&](auto setc, int k0) {
-        constexpr int S = decltype(setc)::value;
-        {   // k-contiguous operands were loaded unconditionally: zero what lies past the end of the K range (last slab only)
-            const bool first = RC && k0 < p.rc_k;
-            const int ke = RC ? (first ? p.rc_k : p.K) : kend;
-            const int kl = ((RC && !first) ? k0 - p.rc_k : k0) + (tid % KT) * 4;
-            if (kl >= ke) {
-                if (!TA) {
-#pragma unroll
-                    for (int v = 0; v < A_V4; ++v) ra[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                if (TB) {
-#pragma unroll
-                    for (int v = 0; v < B_V4; ++v) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-        if (TA && do_cs) {          // raw fp32 values of the staged A slab (zeros outside the matrix)
-            if (A_PAIR) {
-#pragma unroll
-                for (int v = 0; v < A_V4 / 2; ++v) {
-                    cs[v].x += ra[S][2 * v].x + ra[S][2 * v + 1].x; cs[v].y += ra[S][2 * v].y + ra[S][2 * v + 1].y;
-                    cs[v].z += ra[S][2 * v].z + ra[S][2 * v + 1].z; cs[v].w += ra[S][2 * v].w + ra[S][2 * v + 1].w;
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < A_V4; ++v) { cs[0].x += ra[S][v].x; cs[0].y += ra[S][v].y; cs[0].z += ra[S][v].z; cs[0].w += ra[S][v].w; }
-            }
-        }
-        if (BF3) {
-            if (A_PAIR) {
-#pragma unroll
-                for (int v = 0; v < A_V4 / 2; ++v) {
-                    const int kp = tid & 15, mq = (tid >> 4) + 16 * v;
-                    const float x0[4] = {ra[S][2 * v].x, ra[S][2 * v].y, ra[S][2 * v].z, ra[S][2 * v].w};
-                    const float x1[4] = {ra[S][2 * v + 1].x, ra[S][2 * v + 1].y, ra[S][2 * v + 1].z, ra[S][2 * v + 1].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint32_t hi, lo;
-                        split_pair_bf16x3(x0[i], x1[i], hi, lo);
-                        *reinterpret_cast<uint32_t*>(Ahi + (4 * mq + i) * LDKB + kp * 4) = hi;
-                        *reinterpret_cast<uint32_t*>(Alo + (4 * mq + i) * LDKB + kp * 4) = lo;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < A_V4; ++v) {
-                    const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                    uint2 hi, lo;
-                    split_bf16x3(ra[S][v], hi, lo);
-                    *reinterpret_cast<uint2*>(Ahi + r * LDKB + c * 2) = hi;
-                    *reinterpret_cast<uint2*>(Alo + r * LDKB + c * 2) = lo;
-                }
-            }
-            if (B_PAIR) {
-#pragma unroll
-                for (int v = 0; v < B_V4 / 2; ++v) {
-                    const int kp = tid & 15, nq = (tid >> 4) + 16 * v;
-                    const float x0[4] = {rb[S][2 * v].x, rb[S][2 * v].y, rb[S][2 * v].z, rb[S][2 * v].w};
-                    const float x1[4] = {rb[S][2 * v + 1].x, rb[S][2 * v + 1].y, rb[S][2 * v + 1].z, rb[S][2 * v + 1].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint32_t hi, lo;
-                        split_pair_bf16x3(x0[i], x1[i], hi, lo);
-                        *reinterpret_cast<uint32_t*>(Bhi + (4 * nq + i) * LDKB + kp * 4) = hi;
-                        *reinterpret_cast<uint32_t*>(Blo + (4 * nq + i) * LDKB + kp * 4) = lo;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < B_V4; ++v) {
-                    const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                    uint2 hi, lo;
-                    split_bf16x3(rb[S][v], hi, lo);
-                    *reinterpret_cast<uint2*>(Bhi + r * LDKB + c * 2) = hi;
-                    *reinterpret_cast<uint2*>(Blo + r * LDKB + c * 2) = lo;
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int v = 0; v < A_V4; ++v) {
-            if (!TA) {
-                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                As[(c + 0) * LDSA + r] = ra[S][v].x; As[(c + 1) * LDSA + r] = ra[S][v].y;
-                As[(c + 2) * LDSA + r] = ra[S][v].z; As[(c + 3) * LDSA + r] = ra[S][v].w;
-            } else {
-                constexpr int TPR = BM / 4;
-                const int kk = tid / TPR + v * (NTHREADS / TPR), c = (tid % TPR) * 4;
-                *reinterpret_cast<float4*>(&As[kk * LDSA + c]) = ra[S][v];
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < B_V4; ++v) {
-            if (TB) {
-                const int r = tid / KT + v * (NTHREADS / KT), c = (tid % KT) * 4;
-                Bs[(c + 0) * LDSB + r] = rb[S][v].x; Bs[(c + 1) * LDSB + r] = rb[S][v].y;
-                Bs[(c + 2) * LDSB + r] = rb[S][v].z; Bs[(c + 3) * LDSB + r] = rb[S][v].w;
-            } else {
-                constexpr int TPR = BN / 4;
-                const int kk = tid / TPR + v * (NTHREADS / TPR), c = (tid % TPR) * 4;
-                *reinterpret_cast<float4*>(&Bs[kk * LDSB + c]) = rb[S][v];
-            }
-        }
-    };
-
-    const int l31 = lane & 31, lhi = lane >> 5;
-    // Epilogue operands that do not depend on the product (gelu_u of the DGELU epilogue, the residual of the FULL one) are
-    // fetched NOW, ahead of the K loop, when the wavefront owns a single 32x32 block (16 registers): loading them in the
-    // epilogue left every wavefront waiting on HBM latency with nothing else to run.
-    constexpr bool EPRE = (WTM * WTN == 1) && (EPI == EPI_DGELU || EPI == EPI_FULL);
-    float4 epre[EPRE ? 4 : 1];
-    if (EPRE) {
-        const float* src = EPI == EPI_DGELU ? p.gelu_u : p.residual;
-        const long lds_ = EPI == EPI_DGELU ? p.ldu : p.ldr;
-        const int row = m0 + wm0 + l31;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = n0 + wn0 + 8 * q + 4 * lhi;
-            epre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src && row < p.M && col < p.N) epre[q] = *reinterpret_cast<const float4*>(src + (long)row * lds_ + col);
-        }
-    }
-    f32x16 uacc[RC ? WTM : 1][RC ? WTN : 1];
-    if (RC) {
-#pragma unroll
-        for (int i = 0; i < WTM; ++i)
-#pragma unroll
-            for (int j = 0; j < WTN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) uacc[RC ? i : 0][RC ? j : 0][r] = 0.f;
-    }
-    auto mma_into = [&](auto& Cacc) __attribute__((always_inline)) {          // one K slab of the current LDS stage into the given accumulators
-        if (BF3) {
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                const int koff = (2 * ks + lhi) * 16;                   // byte offset of this lane's 8 bf16 in the row
-                bf16x8_t ah[WTM], al[WTM], bh[WTN], bl[WTN];
-#pragma unroll
-                for (int i = 0; i < WTM; ++i) {
-                    const int r = wm0 + i * 32 + l31;
-                    ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ahi + r * LDKB + koff));
-                    al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Alo + r * LDKB + koff));
-                }
-#pragma unroll
-                for (int j = 0; j < WTN; ++j) {
-                    const int r = wn0 + j * 32 + l31;
-                    bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Bhi + r * LDKB + koff));
-                    bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Blo + r * LDKB + koff));
-                }
-#pragma unroll
-                for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WTN; ++j) {
-                        Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], Cacc[i][j], 0, 0, 0);
-                        Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], Cacc[i][j], 0, 0, 0);
-                        Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], Cacc[i][j], 0, 0, 0);
-                    }
-            }
-        } else
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int krow = 2 * kk + lhi;
-            float a[WTM], b[WTN];
-#pragma unroll
-            for (int i = 0; i < WTM; ++i) a[i] = As[krow * LDSA + wm0 + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < WTN; ++j) b[j] = Bs[krow * LDSB + wn0 + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                for (int j = 0; j < WTN; ++j)
-                    Cacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], Cacc[i][j], 0, 0, 0);
-        }
-    };
-    auto mma = [&](int k0) __attribute__((always_inline)) {
-        if constexpr (RC) {
-            if (k0 < p.rc_k) mma_into(uacc);
-            else mma_into(acc);
-        } else {
-            mma_into(acc);
-        }
-    };
-    if (DB && !PF2) {
-        // one slab in flight behind the one being multiplied
-        int buf = 0;
-        load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
-        store_smem(SET0{}, kbeg);
-        __syncthreads();
-        if (kbeg + BK < kend) { load_a(kbeg + BK, SET0{}); load_b(kbeg + BK, SET0{}); }
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            if (k0 + BK < kend) {
-                stage(buf ^ 1);
-                store_smem(SET0{}, k0 + BK);
-                stage(buf);
-                if (k0 + 2 * BK < kend) { load_a(k0 + 2 * BK, SET0{}); load_b(k0 + 2 * BK, SET0{}); }
-            }
-            mma(k0);
-            __syncthreads();
-            buf ^= 1;
-            stage(buf);
-        }
-        stage(0);
-    } else if (DB) {
-        // two slabs in flight: the global loads of slab i+2 are issued before slab i is multiplied, so a workgroup exposes ONE
-        // load latency at its start instead of one per slab (K = 64 / 128: the whole tile's operands are requested up front)
-        int buf = 0;
-        load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
-        using SETB = std::integral_constant<int, PF2 ? 1 : 0>;        // (SET1 where this path is compiled for real)
-        // BRANCH-FREE from here on: every load is issued unconditionally (past the end of the K range the clamped addresses re-read
-        // the row's last quad -- an L1 hit -- and store_smem writes zeros), and an odd slab count gets one phantom slab of zeros, so
-        // that no load sits under a branch and the compiler can wait for exactly the older register set (s_waitcnt vmcnt(4))
-        load_a(kbeg + BK, SETB{}); load_b(kbeg + BK, SETB{});
-        store_smem(SET0{}, kbeg);
-        __syncthreads();
-        load_a(kbeg + 2 * BK, SET0{}); load_b(kbeg + 2 * BK, SET0{});
-        auto step = [&](int k0, auto setc) __attribute__((always_inline)) {       // setc: the register set that holds slab k0 + BK
-            stage(buf ^ 1);
-            store_smem(setc, k0 + BK);
-            stage(buf);
-            load_a(k0 + 3 * BK, setc); load_b(k0 + 3 * BK, setc);
-            __builtin_amdgcn_sched_barrier(0);        // (the scheduler otherwise sinks the loads below the MFMAs)
-            mma(k0);
-            __syncthreads();
-            buf ^= 1;
-            stage(buf);
-        };
-        for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
-            step(k0, SETB{});
-            step(k0 + BK, SET0{});
-        }
-        stage(0);
-    } else {
-        load_a(kbeg, SET0{}); load_b(kbeg, SET0{});
-        store_smem(SET0{}, kbeg);
-        __syncthreads();
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            const bool more = (k0 + BK) < kend;
-            if (more) { load_a(k0 + BK, SET0{}); load_b(k0 + BK, SET0{}); }
-            mma(k0);
-            __syncthreads();
-            if (more) {
-                store_smem(SET0{}, k0 + BK);
-                __syncthreads();
-            }
-        }
-    }
-
-    if (TA && do_cs) {              // (the main loop ended with a barrier: the staging LDS is free)
-        float* s_cs = smem;
-        for (int i = tid; i < BM; i += NTHREADS) s_cs[i] = 0.f;
-        __syncthreads();
-        if (A_PAIR) {
-#pragma unroll
-            for (int v = 0; v < A_V4 / 2; ++v) {
-                const int mq = (tid >> 4) + 16 * v;
-                atomicAdd(&s_cs[4 * mq + 0], cs[v].x); atomicAdd(&s_cs[4 * mq + 1], cs[v].y);
-                atomicAdd(&s_cs[4 * mq + 2], cs[v].z); atomicAdd(&s_cs[4 * mq + 3], cs[v].w);
-            }
-        } else {
-            const int c = (tid % (BM / 4)) * 4;
-            atomicAdd(&s_cs[c + 0], cs[0].x); atomicAdd(&s_cs[c + 1], cs[0].y);
-            atomicAdd(&s_cs[c + 2], cs[0].z); atomicAdd(&s_cs[c + 3], cs[0].w);
-        }
-        __syncthreads();
-        for (int i = tid; i < BM; i += NTHREADS)
-            if (m0 + i < p.M) atomicAdd(&p.colsum[m0 + i], s_cs[i]);
-    }
-
-    // ---- epilogue.  The MFMA ran as D = B^T-tile x A-tile, so D[row = n][col = m]: lane holds, for each
-    // register quad q = r>>2, FOUR CONSECUTIVE output columns n = 8q + 4*(lane>>5) + (r&3) of output row
-    // m = lane&31  ->  one 16-byte store per quad instead of four scalar stores.
-    const bool split = (EPI == EPI_PLAIN) && p.splits > 1;
-    float* slab = split ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) {
-        const int row = m0 + wm0 + i * 32 + l31;
-        if (row >= p.M) continue;
-        float rsc = 1.f;
-        if (EPI == EPI_FULL) rsc = p.e_rowscale ? p.e_rowscale[row / p.e_rows_per_scale] : 1.f;
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = n0 + wn0 + j * 32 + 8 * q + 4 * lhi;
-                if (col >= p.N) continue;
-                float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                float* dst = p.C + (long)row * p.ldc + col;
-                if (EPI == EPI_PLAIN) {
-                    if (split) { *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = v; continue; }
-                    if (p.vec) {
-                        if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-                        if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                        *reinterpret_cast<float4*>(dst) = v;
-                    } else {                 // generic (unaligned / N % 4 != 0) path, deliberately not unrolled
-                        const float vv[4] = {v.x, v.y, v.z, v.w};
-                        const int nv = min(4, p.N - col);
-#pragma unroll 1
-                        for (int t = 0; t < nv; ++t) {
-                            float o = vv[t] + (p.bias ? p.bias[col + t] : 0.f);
-                            if (p.accumulate) o += dst[t];
-                            dst[t] = o;
-                        }
-                    }
-                    continue;
-                }
-                // EPI 1..3 require the vector layout (host-checked)
-                if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-                const uint32_t didx = (uint32_t)((long)row * p.N + col);
-                if (EPI == EPI_GELU2) {
-                    float4 h = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
-                    if (p.e_drop) {
-                        const float4 ds = mdvit_drop_scale4(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
-                        h.x *= ds.x; h.y *= ds.y; h.z *= ds.z; h.w *= ds.w;
-                    }
-                    if (p.C2) {                     // dual store: C = pre-activation u, C2 = gelu(u) x dropout
-                        *reinterpret_cast<float4*>(dst) = v;
-                        *reinterpret_cast<float4*>(p.C2 + (long)row * p.ldc + col) = h;
-                    } else {                        // single store (the backward recomputes u: EPI_DGELU_RC)
-                        *reinterpret_cast<float4*>(dst) = h;
-                    }
-                    continue;
-                }
-                if (EPI == EPI_DGELU) {
-                    const float4 u4 = EPRE ? epre[q] : *reinterpret_cast<const float4*>(p.gelu_u + (long)row * p.ldu + col);
-                    v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
-                }
-                if (RC) {
-                    float4 u4 = make_float4(uacc[RC ? i : 0][RC ? j : 0][4 * q + 0], uacc[RC ? i : 0][RC ? j : 0][4 * q + 1],
-                                            uacc[RC ? i : 0][RC ? j : 0][4 * q + 2], uacc[RC ? i : 0][RC ? j : 0][4 * q + 3]);
-                    if (p.rc_bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.rc_bias + col); u4.x += b4.x; u4.y += b4.y; u4.z += b4.z; u4.w += b4.w; }
-                    v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
-                }
-                if (p.e_drop) {
-                    const float4 ds = mdvit_drop_scale4(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
-                    v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
-                }
-                if (EPI == EPI_FULL) {
-                    v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
-                    if (p.residual) {
-                        const float4 r4 = EPRE ? epre[q] : *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col);
-                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                    }
-                }
-                *reinterpret_cast<float4*>(dst) = v;
-            }
-        }
-    }
+// the same NT bf16x3 main loop with the A operand gathered from an NHWC image (3x3 taps): y = conv3x3(x, w) without im2col
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3, 8))) void gemm_conv3x3_kernel(GemmArgs p) {
+    constexpr bool CONV = true, TA = false, TB = true, BF3 = true;
+    constexpr int EPI = EPI_PLAIN;
+#include "gemm_body.inc"
 }
 
 // C[m][n] = sum_s slab[s][m][n] (+ bias[n]).  R lanes share one output quad: lane r adds slabs r, r+R, ... and the R
@@ -616,6 +143,11 @@ int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, int bf3, hipStream_t 
     dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(NTHREADS);
 #define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_, BF3_) \
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_, BF3_>), grid, block, 0, s, a)
+    if (a.conv_c > 0) {
+        if (ta || !tb || !bf3 || epi != EPI_PLAIN) return 1;
+        hipLaunchKernelGGL((gemm_conv3x3_kernel<BM, BN, WM, WN>), grid, block, 0, s, a);
+        return 0;
+    }
     if (!ta && tb) {                                   // forward (weights [N,K]); with transposed weights also dgrad
         if (bf3) {
             if (epi == EPI_GELU2) MDVIT_GEMM_LAUNCH(false, true, EPI_GELU2, true);
@@ -756,6 +288,15 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.colsum = d->colsum_a;
     MDVIT_CHECK_ARG(!d->colsum_a || (d->trans_a && !d->trans_b), MDVIT_E_SHAPE, "gemm: colsum_a rides on the TN (wgrad) layout only");
     a.seed = d->drop_seed;
+    if (d->conv_c > 0) {
+        MDVIT_CHECK_ARG(!d->trans_a && d->trans_b && d->precision >= 1 && d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual &&
+                        !d->rc_a, MDVIT_E_SHAPE, "gemm: the implicit 3x3 convolution is built for the NT layout, precision >= 1, plain epilogue");
+        MDVIT_CHECK_ARG(d->conv_c % BK == 0 && d->K == 9 * d->conv_c && d->conv_h > 0 && d->conv_w > 0 && d->conv_ho > 0 && d->conv_wo > 0 &&
+                        d->conv_stride >= 1 && d->conv_dilation >= 1 && d->M % (d->conv_ho * d->conv_wo) == 0, MDVIT_E_SHAPE,
+                        "gemm: implicit convolution needs conv_c %% 32 == 0, K == 9 conv_c, M == B conv_ho conv_wo (M=%d K=%d conv_c=%d)", d->M, d->K, d->conv_c);
+        a.conv_c = d->conv_c; a.conv_h = d->conv_h; a.conv_w = d->conv_w; a.conv_ho = d->conv_ho; a.conv_wo = d->conv_wo;
+        a.conv_stride = d->conv_stride; a.conv_dil = d->conv_dilation;
+    }
     if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_launch(d, s);
 
     const GemmPlan pl = plan_gemm(d);
@@ -797,6 +338,28 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
         else MDVIT_REDUCE_LAUNCH(64);
 #undef MDVIT_REDUCE_LAUNCH
     }
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+// weight layouts of the implicit 3x3 convolution (see mdvit_hip.h)
+__global__ __launch_bounds__(256) void conv_weight_relayout_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int mode) {
+    const long total = (long)Cout * Cin * 9;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        if (mode == 0) {          // out[co][t][ci]
+            const int ci = (int)(e % Cin); const int t = (int)((e / Cin) % 9); const int co = (int)(e / (9L * Cin));
+            out[e] = w[((long)co * Cin + ci) * 9 + t];
+        } else {                  // out[ci][t][co] = w[co][ci][8 - t]
+            const int co = (int)(e % Cout); const int t = (int)((e / Cout) % 9); const int ci = (int)(e / (9L * Cout));
+            out[e] = w[((long)co * Cin + ci) * 9 + (8 - t)];
+        }
+    }
+}
+
+extern "C" int mdvit_conv_weight_relayout(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t mode, void* stream) {
+    MDVIT_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), MDVIT_E_SHAPE, "conv_weight_relayout: bad arguments");
+    const long total = (long)Cout * Cin * 9;
+    hipLaunchKernelGGL(conv_weight_relayout_kernel, dim3((int)min((total + 255) / 256, 2048L)), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, mode);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -888,6 +451,10 @@ extern "C" int mdvit_gemm_kernel_name(const MdvitGemmDesc* d, char* out, int32_t
     else if (d->epi == MDVIT_EPI_DGELU) epi = d->rc_a ? EPI_DGELU_RC : EPI_DGELU;
     else if (drop || d->e_rowscale || d->residual) epi = EPI_FULL;
     const int bm = pl.cfg == 0 ? 128 : (pl.cfg == 1 ? 256 : 64), bn = pl.cfg == 0 ? 128 : 64;
+    if (d->conv_c > 0) {
+        snprintf(out, cap, "gemm_conv3x3_kernel<%d, %d, %s>%s", bm, bn, pl.cfg == 1 ? "4, 1" : "2, 2", pl.splits > 1 ? "+splitk_reduce" : "");
+        return MDVIT_OK;
+    }
     snprintf(out, cap, "gemm_f32_kernel<%d, %d, %s, %s, %s, %d, %s>%s", bm, bn, pl.cfg == 1 ? "4, 1" : "2, 2", d->trans_a ? "true" : "false",
              d->trans_b ? "true" : "false", epi, d->precision ? "true" : "false", pl.splits > 1 ? "+splitk_reduce" : "");
     return MDVIT_OK;

@@ -296,8 +296,9 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
-         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None, rc=None):
-    """rc = (a, lda, b, ldb, bias, k): DGELU with the pre-activation recomputed in the kernel (include/mdvit_hip.h)."""
+         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None, rc=None, conv=None):
+    """rc = (a, lda, b, ldb, bias, k): DGELU with the pre-activation recomputed in the kernel (include/mdvit_hip.h).
+    conv = (C, H, W, Ho, Wo, stride, dilation): A is the NHWC image, gathered as the implicit im2col operand of a 3x3 convolution."""
     if precision is None:
         precision = min(_gemm_precision, 1) if (bool(trans_b) != bool(trans_a)) else 0      # built for NT and TN
     d = GemmDesc()
@@ -318,6 +319,8 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     d.drop_seed = _seed_ptr() if e_drop > 0 else None
     if rc is not None:
         d.rc_a, d.rc_lda, d.rc_b, d.rc_ldb, d.rc_bias, d.rc_k = rc
+    if conv is not None:
+        d.conv_c, d.conv_h, d.conv_w, d.conv_ho, d.conv_wo, d.conv_stride, d.conv_dilation = conv
     ws = None
     if allow_split:
         need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
@@ -329,7 +332,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
         return
     kepi = 1 if epi == _lib.EPI_GELU_DUAL else (4 if rc is not None else 2) if epi == _lib.EPI_DGELU else \
         3 if (e_drop > 0 or e_rowscale is not None or residual is not None) else 0
-    pkey = (M, N, K, bool(trans_a), bool(trans_b), kepi, int(precision), bool(allow_split), colsum_a is not None)
+    pkey = (M, N, K, bool(trans_a), bool(trans_b), kepi, int(precision), bool(allow_split), colsum_a is not None, conv is not None)
     name = _plan_cache.get(pkey)
     if name is None:
         buf = C.create_string_buffer(160)
@@ -1108,10 +1111,97 @@ class _Im2col(torch.autograd.Function):
         return dx, None, None
 
 
+_conv_w_cache = {}      # (id(weight), mode) -> (weakref, version tag, relaid-out copy)
+_use_implicit_conv = os.environ.get("MDVIT_IMPLICIT_CONV", "1") != "0"      # A/B switch: 0 = im2col + GEMM everywhere
+
+
+def _conv_weight(w, mode: int):
+    """w [Cout, Cin, 3, 3] in the layout the implicit convolution reads (mdvit_conv_weight_relayout), cached per leaf weight and
+    rebuilt when the weight changed (version counter / optimizer epoch)."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    tag = (w._version, _weights_epoch, w.data_ptr())
+    key = (id(w), mode)
+    hit = _conv_w_cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2]
+    out = hit[2] if (hit is not None and hit[0]() is w) else torch.empty(((Cout, 9 * Cin) if mode == 0 else (Cin, 9 * Cout)), device=w.device, dtype=torch.float32)
+    call("mdvit_conv_weight_relayout", _p(w), _p(out), Cout, Cin, mode, _stream())
+    if w.grad_fn is None:
+        _conv_w_cache[key] = (weakref.ref(w, lambda _r, key=key: _conv_w_cache.pop(key, None)), tag, out)
+    return out
+
+
+class _Conv3x3(torch.autograd.Function):
+    """Dense 3x3 convolution (padding = dilation) as an IMPLICIT GEMM: the kernel gathers the tap-shifted pixel rows while it stages
+    its A operand, so the [B Ho Wo, 9 Cin] im2col matrix is never written or read (forward, and the data gradient at stride 1 = the
+    same call on dy with the flipped / transposed weight).  The weight gradient still multiplies dy^T with an im2col matrix, built
+    on the side stream where it overlaps the data-gradient chain."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, dilation):
+        ctx.set_materialize_grads(False)
+        _chk(x, w, bias)
+        B, H, W_, Cin = x.shape
+        Cout = w.shape[0]
+        Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+        y = _empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        gemm(_p(x), _p(_conv_weight(w, 0)), _p(y), B * Ho * Wo, Cout, 9 * Cin, lda=9 * Cin, ldb=9 * Cin, ldc=Cout, bias=_p(bias), allow_split=True,
+             conv=(Cin, H, W_, Ho, Wo, stride, dilation))
+        ctx.save_for_backward(x, w)
+        ctx.meta = (stride, dilation, bias is not None)
+        ctx.bias_ref = bias if (bias is not None and bias.grad_fn is None) else None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 5
+        x, w = ctx.saved_tensors
+        stride, dilation, has_b = ctx.meta
+        g = _c(g)
+        B, H, W_, Cin = x.shape
+        Cout = w.shape[0]
+        Ho, Wo = g.shape[1], g.shape[2]
+        M = B * Ho * Wo
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty_like(x)
+            if stride == 1 and Cout % 32 == 0:
+                gemm(_p(g), _p(_conv_weight(w, 1)), _p(dx), B * H * W_, Cin, 9 * Cout, lda=9 * Cout, ldb=9 * Cout, ldc=Cin, allow_split=True,
+                     conv=(Cout, Ho, Wo, H, W_, 1, dilation))
+            else:                                   # strided: dcol = g W, folded back by col2im
+                dcol = _empty((M, 9 * Cin), device=g.device, dtype=torch.float32)
+                _dgrad(g.view(M, Cout), w, dcol, M, 9 * Cin, Cout, 9 * Cin, allow_split=True)
+                call("mdvit_col2im3x3", _p(dcol), _p(dx), B, H, W_, Cin, stride, dilation, _stream())
+        want_w = not _dgrad_only and (ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]))
+        if want_w:
+            sW = _sink_of(w)
+            sb = _sink_of(ctx.bias_ref) if has_b else None
+            sunk = sW is not None and (not has_b or sb is not None)
+            g2 = g.view(M, Cout)
+            if sunk:
+                with _on_side(g, x):
+                    col = _empty((M, 9 * Cin), device=g.device, dtype=torch.float32)
+                    call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cin, stride, dilation, _stream())
+                    gemm(_p(g2), _p(col), _p(sW), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
+                         accumulate=True, colsum_a=_p(sb) if has_b else None)
+            else:
+                col = _empty((M, 9 * Cin), device=g.device, dtype=torch.float32)
+                call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cin, stride, dilation, _stream())
+                dW = _empty_like(w)
+                if has_b and ctx.needs_input_grad[2]:
+                    db = torch.zeros((Cout,), device=g.device, dtype=torch.float32)
+                gemm(_p(g2), _p(col), _p(dW), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
+                     colsum_a=_p(db) if db is not None else None)
+        return dx, dW, db, None, None
+
+
 def conv3x3_dense(x, w, bias=None, stride=1, dilation=1):
     """x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] -> [B,Ho,Wo,Cout]; padding = dilation (dilation > 1 at stride 1 only)."""
     B, H, W_, Cn = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+    if _use_implicit_conv and _gemm_precision >= 1 and Cn % 32 == 0 and w.dim() == 4 and w.is_contiguous() and w.shape[0] % 4 == 0:
+        return _Conv3x3.apply(_c(x), w, bias, int(stride), int(dilation))
     col = _Im2col.apply(_c(x), int(stride), int(dilation))
     y = _Linear.apply(col, w if w.is_contiguous() else w.reshape(w.shape[0], -1), bias, None, None, 0.0, 1)
     return y.view(B, Ho, Wo, w.shape[0])
