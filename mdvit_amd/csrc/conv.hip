@@ -462,7 +462,16 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
 
 // adjoint in gather form: for every input pixel, visit the output pixels whose 2-tap stencil can touch it.
 __device__ __forceinline__ void out_range(int i, int in_size, int out_size, int& lo, int& hi) {
-    // outputs o with floor(src(o)) in {i-1, i}; conservative bounds, exact weights are re-derived per o
+    // outputs o with floor(src(o)) in {i-1, i}; exact weights are re-derived per o
+    if (out_size % in_size == 0 && ((out_size / in_size) & 1) == 0) {
+        // even integer scale s (every resize of this model: x2 / x4 / x8): src(o) = (o + 0.5) / s - 0.5, so input i is touched exactly by
+        // o in [s i - s/2, s i + 3 s / 2) -- 2 s taps instead of the conservative 3 s + 2 (the clamped border outputs fall inside too)
+        const int s = out_size / in_size;
+        lo = s * i - s / 2; hi = s * i + 3 * s / 2;
+        if (lo < 0) lo = 0;
+        if (hi > out_size) hi = out_size;
+        return;
+    }
     const float inv = (float)out_size / (float)in_size;
     lo = (int)floorf(((float)i - 1.0f) * inv) - 1;
     hi = (int)ceilf(((float)i + 2.0f) * inv) + 1;
