@@ -402,7 +402,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             common = ["--precision", args.precision] + (["--no-side-stream"] if args.no_side_stream else [])
-            b32 = _child_json([sys.executable, os.path.abspath(__file__), "--batch", "32", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+            b32 = _child_json([sys.executable, os.path.abspath(__file__), "--batch", "32", "--steps", "4", "--warmup", "4", "--no-cpu-baseline",
                                "--no-extra-legs", "--no-kernel-events"] + common, 600)
             extra["bs32"] = {k: b32.get(k) for k in ("value", "unit", "ms_per_step", "phase_ms", "steps", "warmup", "error") if k in b32}
             if "config" in b32:

@@ -115,7 +115,9 @@ int mdvit_gemm_tn_config(int32_t enable, int32_t cfg, int32_t splits);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 /* Weight layouts of the implicit 3x3 convolution: w [Cout, Cin, 3, 3] (PyTorch) ->
  *   mode 0: out [Cout][tap][Cin]                    (forward:        y = conv(x, w))
- *   mode 1: out [Cin][8 - tap][Cout]                (data gradient: dx = conv(dy, flipped / transposed w), stride 1) */
+ *   mode 1: out [Cin][8 - tap][Cout]                (data gradient: dx = conv(dy, flipped / transposed w), stride 1)
+ *   mode 2 / 3: w = a gradient in the [Cout][tap][Cin] order of the implicit weight-gradient GEMM (TN with conv_c > 0: A = dy [tokens, Cout],
+ *               B = the image, N = 9 Cin) -> out [Cout, Cin, 3, 3], overwritten (2) or accumulated into (3) */
 int mdvit_conv_weight_relayout(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t mode, void* stream);
 
 /* ---- "plane" GEMM family: operands pre-split into bf16 planes ------------------------------------------------

@@ -289,13 +289,19 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     MDVIT_CHECK_ARG(!d->colsum_a || (d->trans_a && !d->trans_b), MDVIT_E_SHAPE, "gemm: colsum_a rides on the TN (wgrad) layout only");
     a.seed = d->drop_seed;
     if (d->conv_c > 0) {
-        MDVIT_CHECK_ARG(!d->trans_a && d->trans_b && d->precision >= 1 && d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual &&
-                        !d->rc_a, MDVIT_E_SHAPE, "gemm: the implicit 3x3 convolution is built for the NT layout, precision >= 1, plain epilogue");
-        MDVIT_CHECK_ARG(d->conv_c % BK == 0 && d->K == 9 * d->conv_c && d->conv_h > 0 && d->conv_w > 0 && d->conv_ho > 0 && d->conv_wo > 0 &&
-                        d->conv_stride >= 1 && d->conv_dilation >= 1 && d->M % (d->conv_ho * d->conv_wo) == 0, MDVIT_E_SHAPE,
-                        "gemm: implicit convolution needs conv_c %% 32 == 0, K == 9 conv_c, M == B conv_ho conv_wo (M=%d K=%d conv_c=%d)", d->M, d->K, d->conv_c);
-        a.conv_c = d->conv_c; a.conv_h = d->conv_h; a.conv_w = d->conv_w; a.conv_ho = d->conv_ho; a.conv_wo = d->conv_wo;
-        a.conv_stride = d->conv_stride; a.conv_dil = d->conv_dilation;
+        MDVIT_CHECK_ARG(d->precision >= 1 && d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual && !d->rc_a, MDVIT_E_SHAPE,
+                        "gemm: the implicit 3x3 convolution is built for precision >= 1 and the plain epilogue");
+        MDVIT_CHECK_ARG(d->conv_c % BK == 0 && d->conv_h > 0 && d->conv_w > 0 && d->conv_ho > 0 && d->conv_wo > 0 && d->conv_stride >= 1 && d->conv_dilation >= 1,
+                        MDVIT_E_SHAPE, "gemm: implicit convolution needs conv_c %% 32 == 0 and positive extents (conv_c=%d)", d->conv_c);
+        if (d->trans_a && !d->trans_b) {       // weight gradient: B = the image, K = tokens, N = 9 conv_c (tap-major)
+            MDVIT_CHECK_ARG(d->N == 9 * d->conv_c && d->K % (d->conv_ho * d->conv_wo) == 0 && mdvit_gemm_tn_applies(d), MDVIT_E_SHAPE,
+                            "gemm: implicit-convolution weight gradient needs N == 9 conv_c, K == B conv_ho conv_wo (N=%d K=%d conv_c=%d)", d->N, d->K, d->conv_c);
+        } else {
+            MDVIT_CHECK_ARG(!d->trans_a && d->trans_b && d->K == 9 * d->conv_c && d->M % (d->conv_ho * d->conv_wo) == 0, MDVIT_E_SHAPE,
+                            "gemm: implicit convolution (NT) needs K == 9 conv_c, M == B conv_ho conv_wo (M=%d K=%d conv_c=%d)", d->M, d->K, d->conv_c);
+            a.conv_c = d->conv_c; a.conv_h = d->conv_h; a.conv_w = d->conv_w; a.conv_ho = d->conv_ho; a.conv_wo = d->conv_wo;
+            a.conv_stride = d->conv_stride; a.conv_dil = d->conv_dilation;
+        }
     }
     if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_launch(d, s);
 
@@ -349,15 +355,19 @@ __global__ __launch_bounds__(256) void conv_weight_relayout_kernel(const float* 
         if (mode == 0) {          // out[co][t][ci]
             const int ci = (int)(e % Cin); const int t = (int)((e / Cin) % 9); const int co = (int)(e / (9L * Cin));
             out[e] = w[((long)co * Cin + ci) * 9 + t];
-        } else {                  // out[ci][t][co] = w[co][ci][8 - t]
+        } else if (mode == 1) {   // out[ci][t][co] = w[co][ci][8 - t]
             const int co = (int)(e % Cout); const int t = (int)((e / Cout) % 9); const int ci = (int)(e / (9L * Cout));
             out[e] = w[((long)co * Cin + ci) * 9 + (8 - t)];
+        } else {                  // back: out[co][ci][t] (+)= w[co][t][ci]   (mode 3 accumulates)
+            const int t = (int)(e % 9); const int ci = (int)((e / 9) % Cin); const int co = (int)(e / (9L * Cin));
+            const float v = w[((long)co * 9 + t) * Cin + ci];
+            out[e] = mode == 3 ? out[e] + v : v;
         }
     }
 }
 
 extern "C" int mdvit_conv_weight_relayout(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t mode, void* stream) {
-    MDVIT_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), MDVIT_E_SHAPE, "conv_weight_relayout: bad arguments");
+    MDVIT_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && mode >= 0 && mode <= 3, MDVIT_E_SHAPE, "conv_weight_relayout: bad arguments");
     const long total = (long)Cout * Cin * 9;
     hipLaunchKernelGGL(conv_weight_relayout_kernel, dim3((int)min((total + 255) / 256, 2048L)), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, mode);
     MDVIT_LAUNCH_CHECK();

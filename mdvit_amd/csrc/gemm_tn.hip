@@ -31,6 +31,7 @@ struct TnArgs {
     const float* A; const float* B; float* C; float* slab; float* colsum; float* cs_part; const float* bias;
     long lda, ldb, ldc;
     int M, N, K, kps, splits, tiles_m, tiles_n, accumulate;
+    int cv_c, cv_h, cv_w, cv_ho, cv_wo, cv_s, cv_d;      // CONVB: B is the NHWC image x, gathered as the im2col matrix [token][tap * C + c]
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -50,7 +51,7 @@ __device__ __forceinline__ void split4(const float4 x, uint2& hi, uint2& lo) {
 
 typedef __attribute__((address_space(3))) v4i16* lds_v4i16_ptr;
 
-template <int BM, int BN, int P, bool CS>
+template <int BM, int BN, int P, bool CS, bool CONVB>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 16384 ? 2 : (BM * BN == 8192 ? 3 : 4), 8))) void gemm_tn_kernel(TnArgs p) {
     constexpr int MB = BM / 16, NB = BN / 16;                     // 16-column blocks per k-quad
     constexpr int A_PLANE = BK * BM * 2, B_PLANE = BK * BN * 2;   // bytes of one bf16 plane of one slab
@@ -80,6 +81,18 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
     const int kr = (lane >> 2) & 3;
     const int colq = 16 * (lane >> 4) + 4 * (lane & 3);           // column offset inside the 64-column unit
     float4 ra[2][AV], rb[2][BV];
+    // CONVB (weight gradient of a 3x3 convolution, dW'[co][tap][ci] = sum_m dy[m][co] x[pixel(m) + tap][ci]): this thread's B columns
+    // -- tap and channel -- are fixed for the whole K loop; per slab only the token (= output pixel) moves
+    int bt_dy[CONVB ? BV : 1], bt_dx[CONVB ? BV : 1], bt_c[CONVB ? BV : 1];
+    uint32_t bmask[2] = {0u, 0u};
+    if (CONVB) {
+#pragma unroll
+        for (int v = 0; v < BV; ++v) {
+            const int n = min(n0 + 64 * ((wave + 4 * v) >> 3) + colq, p.N - 4);
+            const int tap = n / p.cv_c;
+            bt_c[v] = n - tap * p.cv_c; bt_dy[v] = (tap / 3 - 1) * p.cv_d; bt_dx[v] = (tap % 3 - 1) * p.cv_d;
+        }
+    }
     float4 cs[BM / 64];                        // CS: the bias gradient (column sums of A) rides on the staging pass; one per 64-column unit
 #pragma unroll
     for (int v = 0; v < BM / 64; ++v) cs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -97,10 +110,26 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
             const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
             ra[S][v] = *reinterpret_cast<const float4*>(p.A + (long)min(k, kend - 1) * p.lda + m);
         }
+        if (CONVB) {
+            uint32_t ok = 0;
+            const int hw = p.cv_ho * p.cv_wo;
 #pragma unroll
-        for (int v = 0; v < BV; ++v) {
-            const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
-            rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+            for (int v = 0; v < BV; ++v) {
+                const int u = wave + 4 * v, m = min(k0 + 4 * (u & 7) + kr, kend - 1);
+                const int bb = m / hw, rem = m - bb * hw, ho = rem / p.cv_wo, wo = rem - ho * p.cv_wo;
+                const int y = ho * p.cv_s + bt_dy[v], x = wo * p.cv_s + bt_dx[v];
+                const bool in = y >= 0 && y < p.cv_h && x >= 0 && x < p.cv_w;
+                const int yc = min(max(y, 0), p.cv_h - 1), xc = min(max(x, 0), p.cv_w - 1);
+                rb[S][v] = *reinterpret_cast<const float4*>(p.B + ((long)(bb * p.cv_h + yc) * p.cv_w + xc) * p.cv_c + bt_c[v]);
+                ok |= (in ? 1u : 0u) << v;
+            }
+            bmask[S] = ok;
+        } else {
+#pragma unroll
+            for (int v = 0; v < BV; ++v) {
+                const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
+                rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE: the scheduler otherwise sinks them next to their LDS stores
     };
@@ -126,6 +155,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
             const int u = wave + 4 * v;
             const int off = (((u & 7) * NB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
             if (tail && k0 + 4 * (u & 7) + kr >= kend) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CONVB && !((bmask[S] >> v) & 1u)) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4(rb[S][v], hi, lo);
             *reinterpret_cast<uint2*>(bb + off) = hi;
@@ -286,8 +316,8 @@ void mdvit_gemm_tn_plan(const MdvitGemmDesc* d, int* tile_m, int* tile_n, int* s
 
 void mdvit_gemm_tn_name(const MdvitGemmDesc* d, char* out, int cap) {
     const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
-    snprintf(out, cap, "gemm_tn_kernel<%d, %d, %d, %s>%s", TN_BM[pl.cfg], TN_BN[pl.cfg], d->precision == 2 ? 1 : 2, d->colsum_a ? "true" : "false",
-             pl.splits > 1 ? "+splitk_reduce" : "");
+    snprintf(out, cap, "gemm_tn_kernel<%d, %d, %d, %s, %s>%s", TN_BM[pl.cfg], TN_BN[pl.cfg], (d->precision == 2 && d->conv_c <= 0) ? 1 : 2,
+             d->colsum_a ? "true" : "false", d->conv_c > 0 ? "true" : "false", pl.splits > 1 ? "+splitk_reduce" : "");
 }
 
 int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
@@ -297,6 +327,9 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
     a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum_a; a.bias = d->bias;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K;
     a.kps = pl.kps; a.splits = pl.splits; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.accumulate = d->accumulate;
+    if (d->conv_c > 0) {
+        a.cv_c = d->conv_c; a.cv_h = d->conv_h; a.cv_w = d->conv_w; a.cv_ho = d->conv_ho; a.cv_wo = d->conv_wo; a.cv_s = d->conv_stride; a.cv_d = d->conv_dilation;
+    }
     if (pl.splits > 1) {
         const size_t need = sizeof(float) * (size_t)pl.splits * d->M * (d->N + (d->colsum_a ? 1 : 0));
         MDVIT_CHECK_ARG(d->ws != nullptr && d->ws_bytes >= need, MDVIT_E_WORKSPACE,
@@ -308,10 +341,13 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
     const bool one = d->precision == 2;
 #define MDVIT_TN_LAUNCH(BM_, BN_)                                                                                   \
     do {                                                                                                            \
-        if (one) { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, true>), grid, block, 0, s, a);     \
-                   else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, false>), grid, block, 0, s, a); }           \
-        else { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, true>), grid, block, 0, s, a);         \
-               else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, false>), grid, block, 0, s, a); }               \
+        if (a.cv_c > 0) {                                                                                           \
+            if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, true, true>), grid, block, 0, s, a);      \
+            else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, false, true>), grid, block, 0, s, a);              \
+        } else if (one) { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, true, false>), grid, block, 0, s, a);     \
+                   else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, false, false>), grid, block, 0, s, a); }           \
+        else { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, true, false>), grid, block, 0, s, a);         \
+               else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, false, false>), grid, block, 0, s, a); }               \
     } while (0)
     if (pl.cfg == 0) MDVIT_TN_LAUNCH(128, 128);
     else if (pl.cfg == 1) MDVIT_TN_LAUNCH(128, 64);

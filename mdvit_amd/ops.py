@@ -1134,8 +1134,8 @@ def _conv_weight(w, mode: int):
 class _Conv3x3(torch.autograd.Function):
     """Dense 3x3 convolution (padding = dilation) as an IMPLICIT GEMM: the kernel gathers the tap-shifted pixel rows while it stages
     its A operand, so the [B Ho Wo, 9 Cin] im2col matrix is never written or read (forward, and the data gradient at stride 1 = the
-    same call on dy with the flipped / transposed weight).  The weight gradient still multiplies dy^T with an im2col matrix, built
-    on the side stream where it overlaps the data-gradient chain."""
+    same call on dy with the flipped / transposed weight; the weight gradient = the TN kernel with the image as its gathered B
+    operand, on the side stream).  Only the strided data gradient still goes through dcol + col2im."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, dilation):
@@ -1175,24 +1175,27 @@ class _Conv3x3(torch.autograd.Function):
                 call("mdvit_col2im3x3", _p(dcol), _p(dx), B, H, W_, Cin, stride, dilation, _stream())
         want_w = not _dgrad_only and (ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]))
         if want_w:
+            # dW'[co][tap][ci] = sum_m dy[m][co] x[pixel(m) + tap][ci]: the TN kernel gathers the image rows as its B operand (no im2col);
+            # a small pass folds the tap-major result into the PyTorch [Cout, Cin, 3, 3] gradient (or its bucket view)
             sW = _sink_of(w)
             sb = _sink_of(ctx.bias_ref) if has_b else None
             sunk = sW is not None and (not has_b or sb is not None)
             g2 = g.view(M, Cout)
+            cv = (Cin, H, W_, Ho, Wo, stride, dilation)
             if sunk:
                 with _on_side(g, x):
-                    col = _empty((M, 9 * Cin), device=g.device, dtype=torch.float32)
-                    call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cin, stride, dilation, _stream())
-                    gemm(_p(g2), _p(col), _p(sW), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
-                         accumulate=True, colsum_a=_p(sb) if has_b else None)
+                    dWt = _empty((Cout, 9 * Cin), device=g.device, dtype=torch.float32)
+                    gemm(_p(g2), _p(x), _p(dWt), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
+                         colsum_a=_p(sb) if has_b else None, conv=cv)
+                    call("mdvit_conv_weight_relayout", _p(dWt), _p(sW), Cout, Cin, 3, _stream())
             else:
-                col = _empty((M, 9 * Cin), device=g.device, dtype=torch.float32)
-                call("mdvit_im2col3x3", _p(x), _p(col), B, H, W_, Cin, stride, dilation, _stream())
-                dW = _empty_like(w)
+                dWt = _empty((Cout, 9 * Cin), device=g.device, dtype=torch.float32)
                 if has_b and ctx.needs_input_grad[2]:
                     db = torch.zeros((Cout,), device=g.device, dtype=torch.float32)
-                gemm(_p(g2), _p(col), _p(dW), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
-                     colsum_a=_p(db) if db is not None else None)
+                gemm(_p(g2), _p(x), _p(dWt), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
+                     colsum_a=_p(db) if db is not None else None, conv=cv)
+                dW = _empty_like(w)
+                call("mdvit_conv_weight_relayout", _p(dWt), _p(dW), Cout, Cin, 2, _stream())
         return dx, dW, db, None, None
 
 
