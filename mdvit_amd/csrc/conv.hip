@@ -602,13 +602,24 @@ extern "C" int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const fl
     MDVIT_CHECK_ARG((dskip == nullptr) == (dup == nullptr), MDVIT_E_SHAPE, "gconv2_bwd: dskip and dup go together");
     if (dskip) hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
     if (dw) {
-        const long ntok = (long)B * H * W;
-        int tpb = (int)max(64L, (ntok + 1023) / 1024);
-        const int nblk = cdiv(ntok, tpb);
-        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 18 * C, "gconv2_bwd");
-        hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(nblk), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, (float*)ws, B, H, W, C, tpb);
-        const int rc = mdvit_reduce_partials((const float*)ws, nblk, 18L * C, 18 * C, dw, 0, nullptr, accumulate, s);
-        if (rc != MDVIT_OK) return rc;
+        // dw[g][j][tap] = sum dy[.., g] cat[.. + tap, 2g + j]: per concat half a depthwise-style weight gradient on the LDS tiles of
+        // conv_tile.h (input read once instead of nine times), the gradient channel of input channel c being c / 2
+        const CtGeom cg{B, H, W};
+        int tpb; long nblk;
+        conv_wgrad_plan(cg, C, tpb, nblk);
+        if (C % 8 == 0 && ws != nullptr && ws_bytes >= sizeof(float) * (size_t)nblk * CT_CL * 10) {
+            int rc = launch_conv_tile_wgrad<3, 2>(dy, (long)C, 0, skip, (long)C, 0, dw, nullptr, (float*)ws, cg, C, s, accumulate);
+            if (rc == MDVIT_OK) rc = launch_conv_tile_wgrad<3, 2>(dy, (long)C, C / 2, up, (long)C, 0, dw + 9L * C, nullptr, (float*)ws, cg, C, s, accumulate);
+            if (rc != MDVIT_OK) return rc;
+        } else {
+            const long ntok = (long)B * H * W;
+            int tpb2 = (int)max(64L, (ntok + 1023) / 1024);
+            const int nb = cdiv(ntok, tpb2);
+            MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nb, 18 * C, "gconv2_bwd");
+            hipLaunchKernelGGL(gconv2_wgrad_kernel, dim3(nb), dim3(256), sizeof(float) * 18 * C, s, dy, skip, up, (float*)ws, B, H, W, C, tpb2);
+            const int rc = mdvit_reduce_partials((const float*)ws, nb, 18L * C, 18 * C, dw, 0, nullptr, accumulate, s);
+            if (rc != MDVIT_OK) return rc;
+        }
     }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;

@@ -135,7 +135,8 @@ void launch_conv3(const float* x, long ldx, const int xoff[3], const float* cons
 // slides along w with the x row in registers; every (channel, tap) of the block's 32 channels is owned by one thread,
 // which writes its partial into the block's row of `part` ([y][z*x][32*(WIN*WIN+1)]); mdvit_reduce_partials adds the
 // rows in a fixed order (deterministic; ~1000 same-address float atomics per tap cost more than the whole kernel).
-template <int WIN>
+// GDIV = 2: channel c of x pairs with gradient channel c / 2 (the grouped decoder conv on (skip, up): output group g reads inputs 2g, 2g+1)
+template <int WIN, int GDIV = 1>
 __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __restrict__ g, long ldg, int goff,
                                                                  const float* __restrict__ x, long ldx, int xoff,
                                                                  float* __restrict__ part,
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int th0 = (tile / tiles_w) * CT_TH, tw0 = (tile % tiles_w) * CT_TW;
         ct_stage_window<LH, LW>(sx, x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
-        ct_stage_window<CT_TH, CT_TW>(sg, g + goff + c0, ldg, img, th0, tw0, H, W, ncls - c0);
+        ct_stage_window<CT_TH, CT_TW>(sg, g + goff + c0 / GDIV, ldg, img, th0, tw0, H, W, (ncls - c0) / GDIV);
         __syncthreads();
         if (rl < WIN && chan_ok) {
 #pragma unroll 2
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
 #pragma unroll
                 for (int t = 0; t < LW; ++t) row[t] = sx[((h + rl) * LW + t) * CT_CL + cl];
 #pragma unroll
-                for (int t = 0; t < CT_TW; ++t) gr[t] = sg[(h * CT_TW + t) * CT_CL + cl];
+                for (int t = 0; t < CT_TW; ++t) gr[t] = sg[(h * CT_TW + t) * CT_CL + cl / GDIV];
 #pragma unroll
                 for (int t = 0; t < CT_TW; ++t) {
                     if (rl == 0) accb += gr[t];
@@ -227,7 +228,7 @@ void conv_wgrad_plan(const CtGeom& g, int ncls, int& tpb, long& nblk) {
     nblk = (long)cdiv(tiles, tpb) * cdiv(ncls, CT_CL) * g.B;
 }
 
-template <int WIN>
+template <int WIN, int GDIV = 1>
 int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x, long ldx, int xoff, float* dw, float* db, float* part,
                            const CtGeom& g, int ncls, hipStream_t s, int accumulate = 0) {
     if (ncls <= 0) return MDVIT_OK;
@@ -235,7 +236,7 @@ int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x
     int tpb; long nblk;
     conv_wgrad_plan(g, ncls, tpb, nblk);
     const int gx = cdiv(tiles, tpb), gy = cdiv(ncls, CT_CL);
-    hipLaunchKernelGGL((fa_conv_tile_wgrad_kernel<WIN>), dim3(gx, gy, g.B), dim3(256), 0, s,
+    hipLaunchKernelGGL((fa_conv_tile_wgrad_kernel<WIN, GDIV>), dim3(gx, gy, g.B), dim3(256), 0, s,
                        gsrc, ldg, goff, x, ldx, xoff, part, g.H, g.W, ncls, tiles_w, tiles, tpb);
     // second stage, per 32-channel block y: rows [y][gx*B] of 32*(WIN^2+1) floats -> dw [c][WIN^2], db [c]
     constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
