@@ -92,6 +92,10 @@ typedef struct MdvitGemmDesc {
      * same call on the output gradient with the flipped, transposed weight).  B = the weight as [N][tap][channel]
      * (mdvit_conv_weight_relayout).  conv_c % 32 == 0; lda is ignored. */
     int32_t conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dilation;
+    /* conv_up > 1 (NT only): the image is read as if zero-upsampled by conv_up -- tap position p maps to source pixel p / conv_up when
+     * divisible, else contributes 0: the data gradient of a stride-conv_up convolution (a transposed convolution) as the same
+     * implicit GEMM over the INPUT pixels (conv_ho x conv_wo), image = dy (conv_h x conv_w), conv_stride = 1.  0 / 1 = off. */
+    int32_t conv_up;
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */

@@ -45,7 +45,7 @@ struct GemmArgs {
     int vec;                       // output rows can take 16-byte vector accesses
     const uint32_t* seed;          // optional device-side dropout seed {s0, s1}: key0 ^= s0, key1 += s1 (graph replays draw fresh masks)
     int tiles_m, tiles_n;
-    int conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dil;     // CONV kernels: A is an NHWC image gathered on the fly
+    int conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dil, conv_up;     // CONV kernels: A is an NHWC image gathered on the fly
 };
 
 // Bijective XCD-aware remap (guide T1): consecutive logical tiles share an XCD's L2.
@@ -300,7 +300,8 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
             MDVIT_CHECK_ARG(!d->trans_a && d->trans_b && d->K == 9 * d->conv_c && d->M % (d->conv_ho * d->conv_wo) == 0, MDVIT_E_SHAPE,
                             "gemm: implicit convolution (NT) needs K == 9 conv_c, M == B conv_ho conv_wo (M=%d K=%d conv_c=%d)", d->M, d->K, d->conv_c);
             a.conv_c = d->conv_c; a.conv_h = d->conv_h; a.conv_w = d->conv_w; a.conv_ho = d->conv_ho; a.conv_wo = d->conv_wo;
-            a.conv_stride = d->conv_stride; a.conv_dil = d->conv_dilation;
+            a.conv_stride = d->conv_stride; a.conv_dil = d->conv_dilation; a.conv_up = d->conv_up > 1 ? d->conv_up : 1;
+            MDVIT_CHECK_ARG(a.conv_up == 1 || d->conv_stride == 1, MDVIT_E_SHAPE, "gemm: conv_up (transposed convolution) goes with conv_stride == 1");
         }
     }
     if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_launch(d, s);

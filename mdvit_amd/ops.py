@@ -320,7 +320,8 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     if rc is not None:
         d.rc_a, d.rc_lda, d.rc_b, d.rc_ldb, d.rc_bias, d.rc_k = rc
     if conv is not None:
-        d.conv_c, d.conv_h, d.conv_w, d.conv_ho, d.conv_wo, d.conv_stride, d.conv_dilation = conv
+        d.conv_c, d.conv_h, d.conv_w, d.conv_ho, d.conv_wo, d.conv_stride, d.conv_dilation = conv[:7]
+        d.conv_up = conv[7] if len(conv) > 7 else 0
     ws = None
     if allow_split:
         need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
@@ -1166,9 +1167,11 @@ class _Conv3x3(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = _empty_like(x)
-            if stride == 1 and Cout % 32 == 0:
+            if Cout % 32 == 0 and (stride == 1 or dilation == 1):
+                # the same implicit GEMM on dy against the flipped / transposed weight; stride 2 = a transposed convolution: dy read as
+                # if zero-upsampled (conv_up), rows = the INPUT pixels
                 gemm(_p(g), _p(_conv_weight(w, 1)), _p(dx), B * H * W_, Cin, 9 * Cout, lda=9 * Cout, ldb=9 * Cout, ldc=Cin, allow_split=True,
-                     conv=(Cout, Ho, Wo, H, W_, 1, dilation))
+                     conv=(Cout, Ho, Wo, H, W_, 1, dilation, stride))
             else:                                   # strided: dcol = g W, folded back by col2im
                 dcol = _empty((M, 9 * Cin), device=g.device, dtype=torch.float32)
                 _dgrad(g.view(M, Cout), w, dcol, M, 9 * Cin, Cout, 9 * Cin, allow_split=True)
