@@ -412,6 +412,14 @@ def main():
                 sp = _child_json([sys.executable, os.path.abspath(__file__), "--precision", "bf16", "--steps", str(args.steps), "--warmup", str(args.warmup),
                                   "--no-cpu-baseline", "--no-extra-legs", "--no-kernel-events"] + (["--no-side-stream"] if args.no_side_stream else []), 600)
                 extra["bf16_speed_mode"] = {k: sp.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "drift_vs_parity_mode", "error") if k in sp}
+            # BASELINE configs[0] (BASE, 1 domain x bs=4, 512x512: the case cpu_baseline.base_bs4 times on the host) on the GPU
+            # (4 images per step: the eager step is host-bound at ~17 ms, so this leg replays the captured HIP graph of the step)
+            bb = _child_json([sys.executable, os.path.abspath(__file__), "--model", "base", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                              "--no-extra-legs", "--graph"] + common, 300)
+            extra["base_bs4_gpu"] = {k: bb.get(k) for k in ("value", "unit", "ms_per_step", "error") if k in bb}
+            extra["base_bs4_gpu"]["how"] = "whole-step HIP graph replay (eager: 238 images/s, host-bound)"
+            if "config" in bb:
+                extra["base_bs4_gpu"]["workload"] = bb["config"]["workload"]
             blk_json = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mdvit_block_roofline_{os.getpid()}.json")
             _child_json([sys.executable, os.path.join(ROOT, "tools", "block_roofline.py"), "--batch", "32", "--precision", args.precision,
                          "--json", blk_json], 600)

@@ -199,9 +199,9 @@ def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Op
     else:
         model.zero_grad(set_to_none=True)
     tot = None
-    for i, (img, label, set_id) in enumerate(batches):
+    for i, (img, label, set_id, *pre) in enumerate(batches):          # pre[0]: the one-hot domain label already on the device (graph capture)
         if use_domain_label:
-            out = model(img, F.one_hot(set_id.cpu(), num_domains).float().to(img.device, non_blocking=True))
+            out = model(img, pre[0] if pre and pre[0] is not None else F.one_hot(set_id.cpu(), num_domains).float().to(img.device, non_blocking=True))
         else:
             out = model(img)
         l = seg_loss(out, label)

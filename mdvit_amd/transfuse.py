@@ -757,19 +757,22 @@ def transfuse_train_step(model, batches: Sequence[tuple], optimizer=None, accumu
     G = len(batches)
     if fuse_domains and G > 1 and all(b[0].shape == batches[0][0].shape for b in batches):
         img = torch.cat([b[0] for b in batches], 0)
-        sid = torch.cat([b[2].cpu() for b in batches], 0)
-        dl = F.one_hot(sid, num_domains).float().to(img.device, non_blocking=True)
+        if all(len(b) > 3 and b[3] is not None for b in batches):       # one-hot labels already on the device (graph capture: no H2D copy)
+            dl = torch.cat([b[3] for b in batches], 0)
+        else:
+            sid = torch.cat([b[2].cpu() for b in batches], 0)
+            dl = F.one_hot(sid, num_domains).float().to(img.device, non_blocking=True)
         with ops.bn_groups(G):
             m4, m3, m2 = model(img, dl)
         parts = [ops.split_groups(t, G) for t in (m4, m3, m2)]
-        for g_, (_, label, _) in enumerate(batches):
+        for g_, (_, label, *_rest) in enumerate(batches):
             weit = structure_weight(label)
             loss = 0.5 * structure_loss(parts[2][g_], label, weit) + 0.3 * structure_loss(parts[1][g_], label, weit) + 0.2 * structure_loss(parts[0][g_], label, weit)
             per.append(loss.detach())
             tot = loss if tot is None else tot + loss
         batches = []
-    for img, label, set_id in batches:
-        dl = F.one_hot(set_id.cpu(), num_domains).float().to(img.device, non_blocking=True)
+    for img, label, set_id, *pre in batches:
+        dl = pre[0] if pre and pre[0] is not None else F.one_hot(set_id.cpu(), num_domains).float().to(img.device, non_blocking=True)
         m4, m3, m2 = model(img, dl)
         weit = structure_weight(label)
         loss = 0.5 * structure_loss(m2, label, weit) + 0.3 * structure_loss(m3, label, weit) + 0.2 * structure_loss(m4, label, weit)
