@@ -403,7 +403,7 @@ int mdvit_sdpa_bwd(const float* g, const float* qkv, const float* P, const float
                    int32_t C, int32_t heads, void* stream);
 /* The same operator on the fp32 matrix cores for N == 256 tokens (the DeiT trunk's 16 x 16 grid), head dimension 64, <= 6 heads: no [N, N]
  * tensor in HBM -- the forward keeps lse [B, heads, N] (row log-sum-exp), the backward recomputes the probabilities.
- * delta: scratch [B, heads, N]. */
+ * delta: scratch [2][B, heads, N] floats. */
 int mdvit_sdpa_mfma_fwd(const float* qkv, const float* a, float* out, float* lse, int32_t B, int32_t N, int32_t C, int32_t heads, void* stream);
 int mdvit_sdpa_mfma_bwd(const float* g, const float* qkv, const float* lse, const float* out, const float* a, float* dqkv, float* e, float* delta,
                         int32_t B, int32_t N, int32_t C, int32_t heads, void* stream);

@@ -117,13 +117,14 @@ __global__ __launch_bounds__(256) void sdpa_mfma_fwd_kernel(const float* __restr
     }
 }
 
-// delta[b,h,n] = sum_d g out over the head's channels; e[b,c] = sum_n g out.  One workgroup (16 wavefronts) per sample; lane = d.
-__global__ __launch_bounds__(1024) void sdpa_prep_kernel(const float* __restrict__ g, const float* __restrict__ out, float* __restrict__ delta,
-                                                         float* __restrict__ e, int C, int heads) {
-    __shared__ float s_e[16][6 * 64];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// delta[b,h,n] = sum_d g out over the head's channels; e_part[b][j][c] = sum over the j-th quarter of the tokens of g out (the rows kernel
+// adds the four quarters in order: e[b,c] = sum_n g out, the adapter's gradient carrier).  Workgroup = (sample, token quarter), 4 wavefronts, lane = d.
+__global__ __launch_bounds__(256) void sdpa_prep_kernel(const float* __restrict__ g, const float* __restrict__ out, float* __restrict__ delta,
+                                                        float* __restrict__ e_part, int C, int heads) {
+    __shared__ float s_e[4][6 * 64];
+    const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ecol[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int n = wave; n < SN; n += 16) {
+    for (int n = j * (SN / 4) + wave; n < (j + 1) * (SN / 4); n += 4) {
         const float* gr = g + ((long)b * SN + n) * C;
         const float* orow = out + ((long)b * SN + n) * C;
 #pragma unroll
@@ -139,18 +140,13 @@ __global__ __launch_bounds__(1024) void sdpa_prep_kernel(const float* __restrict
 #pragma unroll
     for (int h = 0; h < 6; ++h) s_e[wave][h * 64 + lane] = ecol[h];
     __syncthreads();
-    if (e)
-        for (int c = threadIdx.x; c < heads * SD; c += 1024) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) t += s_e[w][c];
-            e[(long)b * C + c] = t;
-        }
+    for (int c = threadIdx.x; c < heads * SD; c += 256)
+        e_part[((long)b * 4 + j) * C + c] = (s_e[0][c] + s_e[1][c]) + (s_e[2][c] + s_e[3][c]);
 }
 
 __global__ __launch_bounds__(256) void sdpa_mfma_bwd_rows_kernel(const float* __restrict__ g, const float* __restrict__ qkv, const float* __restrict__ lse,
-                                                                 const float* __restrict__ delta, const float* __restrict__ a, float* __restrict__ dqkv,
-                                                                 int C, int heads, float scale) {
+                                                                 const float* __restrict__ delta, const float* __restrict__ e_part, const float* __restrict__ a,
+                                                                 float* __restrict__ dqkv, float* __restrict__ e, int C, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Kt = smem; float* Vt = smem + SD * SLD;
     const int h = blockIdx.x, b = blockIdx.y;
@@ -159,6 +155,11 @@ __global__ __launch_bounds__(256) void sdpa_mfma_bwd_rows_kernel(const float* __
     const float* base = qkv + (long)b * SN * ld + h * SD;
     stage_t(Kt, base + C, ld, nullptr);
     stage_t(Vt, base + 2 * C, ld, nullptr);
+    if (e && threadIdx.x < SD) {            // this head's 64 channels of e: the four token quarters of the prep pass, in order
+        const int c = h * SD + threadIdx.x;
+        const float* ep = e_part + (long)b * 4 * C + c;
+        e[(long)b * C + c] = (ep[0] + ep[C]) + (ep[2 * C] + ep[3 * C]);
+    }
     __syncthreads();
     for (int qt = wave; qt < SN / 32; qt += 4) {
         const int q = qt * 32 + l31;
@@ -286,7 +287,7 @@ extern "C" int mdvit_sdpa_mfma_fwd(const float* qkv, const float* a, float* out,
     return MDVIT_OK;
 }
 
-/* delta: scratch [B, heads, N] floats */
+/* delta: scratch [2][B, heads, N] floats (row sums, then the partial column sums of the prep pass) */
 extern "C" int mdvit_sdpa_mfma_bwd(const float* g, const float* qkv, const float* lse, const float* out, const float* a, float* dqkv, float* e, float* delta,
                                    int32_t B, int32_t N, int32_t C, int32_t heads, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -298,8 +299,9 @@ extern "C" int mdvit_sdpa_mfma_bwd(const float* g, const float* qkv, const float
     int rc = set_lds(reinterpret_cast<const void*>(&sdpa_mfma_bwd_rows_kernel), m1);
     if (rc == MDVIT_OK) rc = set_lds(reinterpret_cast<const void*>(&sdpa_mfma_bwd_keys_kernel), m2);
     if (rc != MDVIT_OK) return rc;
-    hipLaunchKernelGGL(sdpa_prep_kernel, dim3(B), dim3(1024), 0, s, g, out, delta, e, C, heads);
-    hipLaunchKernelGGL(sdpa_mfma_bwd_rows_kernel, dim3(heads, B), dim3(256), SMEM_BYTES, s, g, qkv, lse, delta, a, dqkv, C, heads, 0.125f);
+    float* e_part = delta + (long)B * heads * N;
+    hipLaunchKernelGGL(sdpa_prep_kernel, dim3(B, 4), dim3(256), 0, s, g, out, delta, e_part, C, heads);
+    hipLaunchKernelGGL(sdpa_mfma_bwd_rows_kernel, dim3(heads, B), dim3(256), SMEM_BYTES, s, g, qkv, lse, delta, e_part, a, dqkv, e, C, heads, 0.125f);
     hipLaunchKernelGGL(sdpa_mfma_bwd_keys_kernel, dim3(heads, B), dim3(256), SMEM_BYTES, s, g, qkv, lse, delta, a, dqkv, C, heads, 0.125f);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;

@@ -632,13 +632,16 @@ __global__ __launch_bounds__(256) void box31_cols_kernel(const float* __restrict
         weit[e] = 1.f + 5.f * fabsf(s * (1.f / 961.f) - m[e]);
     }
 }
-// per sample: S0 = sum weit*bce, S1 = sum weit, S2 = sum p*m*weit, S3 = sum (p+m)*weit   (double, one workgroup per sample)
-__global__ __launch_bounds__(1024) void sl_sums_kernel(const float* __restrict__ pred, const float* __restrict__ mask, const float* __restrict__ weit,
-                                                       double* __restrict__ sums, long HW) {
-    __shared__ double red[4][1024];
+// per sample: S0 = sum weit*bce, S1 = sum weit, S2 = sum p*m*weit, S3 = sum (p+m)*weit   (double).  gridDim.y workgroups share a sample
+// (a domain batch has 8 samples: one workgroup per sample left 248 CUs idle for 80 us) and add their partial sums with double atomics
+// into the zeroed sums (the addition order moves the result by ~1e-16 relative, far below the float it is rounded to)
+__global__ __launch_bounds__(256) void sl_sums_kernel(const float* __restrict__ pred, const float* __restrict__ mask, const float* __restrict__ weit,
+                                                      double* __restrict__ sums, long HW) {
+    __shared__ double red[4][256];
     const long b = blockIdx.x;
+    const long chunk = (HW + gridDim.y - 1) / gridDim.y, e0 = blockIdx.y * chunk, e1 = min(HW, e0 + chunk);
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (long e = threadIdx.x; e < HW; e += 1024) {
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
         const float x = pred[b * HW + e], m = mask[b * HW + e], w = weit[b * HW + e];
         // binary_cross_entropy_with_logits: max(x,0) - x*m + log(1 + exp(-|x|))
         const float bce = fmaxf(x, 0.f) - x * m + log1pf(__expf(-fabsf(x)));
@@ -647,11 +650,11 @@ __global__ __launch_bounds__(1024) void sl_sums_kernel(const float* __restrict__
     }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = s3;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) { for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x < 4) sums[b * 4 + threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x < 4) atomicAdd(&sums[b * 4 + threadIdx.x], red[threadIdx.x][0]);
 }
 // loss = mean_b [ S0/S1 + 1 - (S2 + 1) / (S3 - S2 + 1) ]
 __global__ void sl_final_kernel(const double* __restrict__ sums, float* __restrict__ loss, int B) {
@@ -864,7 +867,8 @@ extern "C" int mdvit_structure_weight(const float* mask, float* tmp, float* weit
 extern "C" int mdvit_structure_loss_fwd(const float* pred, const float* mask, const float* weit, double* sums, float* loss, int32_t B, int64_t HW, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(pred && mask && weit && sums && loss && B > 0 && HW > 0, MDVIT_E_SHAPE, "structure_loss_fwd: bad arguments");
-    TF_LAUNCH(sl_sums_kernel, (B), 1024, 0, s, pred, mask, weit, sums, (long)HW);
+    MDVIT_ZERO(sums, sizeof(double) * 4 * (size_t)B, s);
+    TF_LAUNCH(sl_sums_kernel, (B, (int)min((HW + 4095) / 4096, 64L)), 256, 0, s, pred, mask, weit, sums, (long)HW);
     TF_LAUNCH(sl_final_kernel, (1), 64, 0, s, sums, loss, B);
     return MDVIT_OK;
 }

@@ -373,7 +373,8 @@ class _SDPA(torch.autograd.Function):
         dev = qkv.device
         dqkv = _empty_like(qkv)
         e = _empty((B, Cn), device=dev, dtype=torch.float32)
-        dS = _empty_like(P)                         # mfma: delta [B, heads, N]; else the [B, heads, N, N] score-gradient scratch
+        # mfma: scratch [2][B, heads, N] (row sums delta + partial column sums); else the [B, heads, N, N] score-gradient scratch
+        dS = _empty((2,) + tuple(P.shape), device=dev, dtype=torch.float32) if ctx.mfma else _empty_like(P)
         call("mdvit_sdpa_mfma_bwd" if ctx.mfma else "mdvit_sdpa_bwd", _p(_c(g)), _p(qkv), _p(P), _p(out), _p(a), _p(dqkv), _p(e), _p(dS),
              B, N, Cn, heads, _stream())
         if ops._dgrad_only:
