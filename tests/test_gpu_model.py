@@ -666,6 +666,47 @@ def test_graphed_step_matches_eager_step():
         check(res[1][1][n], res[0][1][n], tol=2e-3, name=n)
 
 
+def test_graphed_base_step_matches_eager_step():
+    """the BASE step (BASELINE configs[0]: what bench.py's base_bs4_gpu leg replays as a HIP graph) captured == eager"""
+    import mdvit_amd
+    from mdvit_amd import ops
+    from mdvit_amd.graph import GraphedStep
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.train import base_train_step
+    from oracle.gen_golden import synth_image, synth_label
+    from oracle.params import make_params
+    S, B = 64, 2
+    batch = [(synth_image(1700, B, S, S).to(dev()), synth_label(1701, B, S, S).to(dev()), torch.zeros(B, dtype=torch.long))]
+    res = []
+    try:
+        for graphed in (False, True):
+            m = mdvit_amd.BASE(drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method=False)
+            load_params(m, make_params(5, model="BASE", adapt_method=False))
+            m = m.to(dev()).train()
+            opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, foreach=True)
+            acc = GradAccumulator(m.parameters())
+            acc.attach_sinks()
+            fn = lambda b: base_train_step(m, b, optimizer=opt, accumulator=acc)
+            losses = []
+            if graphed:
+                g = GraphedStep(fn, batch, warmup=1, fuse_domains=1)
+                losses.append(None)
+                for _ in range(2):
+                    losses.append(float(g(batch)["loss"]))
+            else:
+                for _ in range(3):
+                    losses.append(float(fn(batch)["loss"]))
+            torch.cuda.synchronize()
+            res.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
+    finally:
+        ops.set_grad_sinks(None)
+        ops.enable_device_seed(False)
+    for a, b in zip(res[0][0][1:], res[1][0][1:]):
+        assert abs(a - b) <= 2e-4 * abs(a), (res[0][0], res[1][0])
+    for n in res[0][1]:
+        check(res[1][1][n], res[0][1][n], tol=2e-3, name=n)
+
+
 _DP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
