@@ -81,29 +81,33 @@ class _EncoderDecoder(nn.Module):
             raise ValueError("expected a (B,C,H,W) image batch")
         B, _, Hi, Wi = x.shape
         x = self.stem_2(self.stem_1(x.float())) if self._dsn else self.stem[1](self.stem[0](x.float()))
-        enc = []
-        for idx in range(self.num_stages):
+        enc, skip = [], []          # every stage output has three consumers: the next stage / bridge, the decoder's skip path, the peer
+        for idx in range(self.num_stages):          # heads -- forked explicitly so that the gradients are summed by ops._Fork, not by autograd
             x = self.patch_embed_stages[idx](x)
             _, H, W, Cn = x.shape
             x = self.mhsa_stages[idx](x.view(B, H * W, Cn), H, W, domain_label).view(B, H, W, Cn)
-            enc.append(x)
+            x, s_, e_ = ops.fork(x, 3)
+            skip.append(s_); enc.append(e_)
         if self._dsn:
             from .blocks import _bank_select
-            out = _bank_select(self.bridge_norms1)(ops.conv3x3_dense(enc[3], self.bridge_conv1.weight, self.bridge_conv1.bias, 1))
+            out = _bank_select(self.bridge_norms1)(ops.conv3x3_dense(x, self.bridge_conv1.weight, self.bridge_conv1.bias, 1))
             out = _bank_select(self.bridge_norms2)(ops.conv3x3_dense(out, self.bridge_conv2.weight, self.bridge_conv2.bias, 1))
         else:
-            out = ops.conv3x3_dense(enc[3], self.bridge[0].weight, self.bridge[0].bias, 1)
+            out = ops.conv3x3_dense(x, self.bridge[0].weight, self.bridge[0].bias, 1)
             out = self.bridge[1](out)
             out = ops.conv3x3_dense(out, self.bridge[3].weight, self.bridge[3].bias, 1)
             out = self.bridge[4](out)
-        bridge_out = out
-        out = self.decoder1(out, enc[3], domain_label)
-        out = self.decoder2(out, enc[2], domain_label)
-        out = self.decoder3(out, enc[1], domain_label)
-        out = self.decoder4(out, enc[0], domain_label)
-        dec4 = out
+        if getattr(self, "decoder_name", None) == "Transformer":
+            out, bridge_out = ops.fork(out, 2)          # the per-domain transformer peers start from the bridge output too
+        else:
+            bridge_out = out
+        out = self.decoder1(out, skip[3], domain_label)
+        out = self.decoder2(out, skip[2], domain_label)
+        out = self.decoder3(out, skip[1], domain_label)
+        out = self.decoder4(out, skip[0], domain_label)
+        out, dec4 = ops.fork(out, 2)                     # the final 1x1 conv and the peer heads' fifth feature
         _, h, w, _ = dec4.shape
-        low = ops.rowdot(dec4, self.finalconv[0].weight, self.finalconv[0].bias)          # 1x1 conv (1 channel) at H/4
+        low = ops.rowdot(out, self.finalconv[0].weight, self.finalconv[0].bias)          # 1x1 conv (1 channel) at H/4
         logits = ops.upsample_bilinear(low.view(B, h, w, 1), Hi, Wi).view(B, 1, Hi, Wi)
         return logits, enc, dec4, (Hi, Wi), bridge_out
 

@@ -1388,6 +1388,36 @@ class bn_groups:
         _bn_groups = self.prev
 
 
+class _Fork(torch.autograd.Function):
+    """x -> n aliases of x for n consumers; the backward adds the n gradients HERE (one launch per extra gradient, on the stream
+    this backward runs on).  Without it autograd sums the gradients of a tensor with several consumers itself -- at::add launches
+    on the stream it attributes to the node, which is not where a sweep that was moved to another stream (set_sweep_stream)
+    produced them."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = _c(gs[0])
+        for g in gs[1:]:
+            g = _c(g)
+            out = _empty_like(acc)
+            call("mdvit_ew", _p(acc), _p(g), _p(out), acc.numel(), 3, _stream())          # mode 3: y = a + b
+            acc = out
+        return acc, None
+
+
+def fork(x, n: int):
+    """n aliases of x, one per consumer (see _Fork)"""
+    return _Fork.apply(x, int(n)) if (n > 1 and x.requires_grad) else (x,) * n
+
+
 class _SplitGroups(torch.autograd.Function):
     """x [G*B, ...] -> G views [B, ...] (no copy); backward concatenates the G gradients once."""
 
@@ -1720,3 +1750,59 @@ def image_normalize_u8(img_u8_nhwc):
     y = torch.empty((B, 3, H, W_), device=x.device, dtype=torch.float32)
     call("mdvit_image_normalize_u8", _p(x), _p(y), B, H, W_, _stream())
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# a whole backward sweep on a stream of its own
+# ------------------------------------------------------------------------------------------------
+# Autograd runs a node's backward on the stream its forward ran on, so two sweeps over the same graph queue behind each other.  With
+# set_sweep_stream(s) every backward of THIS module's Functions switches torch's current stream to s for its duration: a sweep
+# whose nodes are all ours (ops.fork at every tensor with several consumers, an explicit `gradient=` at the root) then runs on s
+# from end to end, next to the sweep that stays on the main stream (train.mdvit_train_step: the data-gradient-only aux sweep).
+_sweep_stream = None
+
+
+def set_sweep_stream(stream):
+    global _sweep_stream
+    _sweep_stream = stream
+
+
+_sweep_stream_obj = None
+_ones = {}
+
+
+def sweep_stream():
+    """the stream the second backward sweep runs on (created once); None while a HIP graph is being captured"""
+    global _sweep_stream_obj
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    if _sweep_stream_obj is None:
+        _sweep_stream_obj = torch.cuda.Stream()
+    return _sweep_stream_obj
+
+
+def one_like(t):
+    """a cached tensor of ones shaped like t: the explicit root gradient of a sweep (autograd would fill a fresh one on the main stream)"""
+    key = (t.device, tuple(t.shape), t.dtype)
+    o = _ones.get(key)
+    if o is None:
+        o = _ones[key] = torch.ones_like(t)
+    return o
+
+
+def _install_sweep_stream_override():
+    def wrap(orig):
+        def backward(ctx, *gs):
+            st = _sweep_stream
+            if st is None:
+                return orig(ctx, *gs)
+            with use_stream(st):
+                return orig(ctx, *gs)
+        backward.__wrapped__ = orig
+        return backward
+    for _name, cls in list(globals().items()):
+        if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function:
+            cls.backward = staticmethod(wrap(cls.backward))
+
+
+_install_sweep_stream_override()

@@ -22,6 +22,9 @@ from .losses import domain_losses, seg_loss
 from .parallel import GradAccumulator, GradBucketReducer
 
 
+_two_stream_sweeps = os.environ.get("MDVIT_SWEEP_STREAMS", "1") != "0"      # A/B switch: 0 = both sweeps on the main stream
+
+
 def _da_params(model):
     return [p for n, p in model.named_parameters() if "domain_layer" in n]
 
@@ -39,6 +42,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
       grad(aux)].  Sweep 1 therefore runs data-gradients-only (no wgrad GEMMs / reductions) and hands every domain adapter
       MINUS its aux gradient; sweep 2 is one ordinary backward of aux + uni."""
     da = _da_params(model)
+    fused_forward = fuse_domains > 1 and len(batches) > 0 and fuse_domains >= len(batches)       # one forward per step: every module is used once
     ops.refresh_transposes()          # the W^T copies of the bf16x3 data-gradient GEMMs follow the last optimizer update (one launch)
     if accumulator is not None:
         accumulator.zero()
@@ -51,12 +55,23 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
     if fuse_domains > 1:
         batches = _fuse_batches(batches, fuse_domains, num_domains, use_domain_label)
 
-    def sweep(loss, last, retain=False, join=True, remaining=None):
+    def sweep(loss, last, retain=False, join=True, remaining=None, on_stream=None):
         if accumulator is not None:
             accumulator.begin_sweep(last)
         elif last and reducer is not None:
             reducer.arm()
-        loss.backward(retain_graph=retain)
+        if on_stream is None:
+            loss.backward(retain_graph=retain)
+        else:
+            # the whole sweep on a stream of its own (ops.set_sweep_stream): every node of it is one of our Functions (ops.fork at the
+            # trunk's multi-consumer tensors) and the root gradient is handed in, so nothing of it is launched on the main stream
+            main = ops.current_stream_obj()
+            ops.set_sweep_stream(on_stream)
+            try:
+                loss.backward(retain_graph=retain, gradient=ops.one_like(loss))
+            finally:
+                ops.set_sweep_stream(None)
+            ops.stream_wait(main, on_stream)
         if join:
             ops.join_side_stream()      # weight gradients may have been produced on the side stream
         if accumulator is not None:
@@ -71,10 +86,15 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
                 # on the main stream and touches other bucket elements than the sinks.)
                 # Data parallel: what the aux sweep can still touch is the domain adapters only -- on the last domain forward of the
                 # step every other gradient bucket is final after this sweep and its all-reduce is issued underneath the aux sweep.
+                # Two streams: the data-gradient-only aux sweep does not depend on the full sweep, only on the forward -- it runs on a
+                # stream of its own, ordered after the forward (the event below) and joined before the gradients are folded.
+                s2 = ops.sweep_stream() if (_two_stream_sweeps and fused_forward and aux_sum.is_cuda) else None
+                if s2 is not None:
+                    ops.stream_wait(s2, ops.current_stream_obj())          # recorded BEFORE the full sweep is enqueued
                 sweep(aux_sum + uni, False, retain=True, join=False, remaining=(da if last else None))
                 ops.set_dgrad_only(True)
                 try:
-                    sweep(aux_sum, last)
+                    sweep(aux_sum, last, on_stream=s2)
                 finally:
                     ops.set_dgrad_only(False)
                 return
