@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__
             *reinterpret_cast<float4*>(dx + row * C + 4 * (sub + 16 * j)) = o;
         }
     }
+    if (part == nullptr) return;          // data-gradient-only sweep: no parameter gradients wanted (uniform)
     // fold the 4 row slots of the wavefront (lanes sub, sub+16, sub+32, sub+48), then the 4 wavefronts through LDS
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     float adb = 0.f;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) { adw[j] = 0.f; const int k = lane + 64 * j; wv[j] = k < K ? w[k] : 0.f; }
+    const bool want_w = part != nullptr;          // data-gradient-only call: x is not even read
     for (int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < M; row += nw) {
         const float g = dy[row];
         adb += g;
@@ -524,11 +526,12 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
         for (int j = 0; j < VPT; ++j) {
             const int k = lane + 64 * j;
             if (k < K) {
-                adw[j] += g * x[(long)row * ldx + k];
+                if (want_w) adw[j] += g * x[(long)row * ldx + k];
                 if (dx) dx[(long)row * lddx + k] = g * wv[j];
             }
         }
     }
+    if (!want_w) return;
 #pragma unroll
     for (int j = 0; j < VPT; ++j) s_dw[wave][lane + 64 * j] = adw[j];
     if (lane == 0) s_db[wave] = adb;     // every lane of a wave holds the same adb
@@ -601,11 +604,12 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
     MDVIT_CHECK_ARG(groups > 0 && groups <= 64 && M % groups == 0, MDVIT_E_SHAPE, "layernorm_bwd: M=%d is not a multiple of groups=%d", M, groups);
     const int Mg = M / groups;
-    float* part = (float*)ws;                  // [group][workgroup][dgamma | dbeta]
+    const bool want_params = dgamma != nullptr || dbeta != nullptr;        // both NULL: data gradient only (no partial sums, no reduction launch)
+    float* part = want_params ? (float*)ws : nullptr;                      // [group][workgroup][dgamma | dbeta]
     int nblk;
     if (C == 64 || C == 128 || C == 320 || C == 512) {
         nblk = min(cdiv(Mg, 64), 1024 / groups);
-        MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");
+        if (want_params) MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");
         dim3 grid16(nblk, groups);
         if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
         else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
@@ -614,10 +618,12 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
     } else {
         nblk = min(cdiv(Mg, 16), 1024 / groups);
         MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");
+        part = (float*)ws;                                                 // (the generic-C kernel always writes its partial rows)
         dim3 grid(nblk, groups);
         LN_DISPATCH(ln_bwd_kernel, C, dy, x, gamma, mean, rstd, add, dx, part, Mg, C);
     }
     MDVIT_LAUNCH_CHECK();
+    if (!want_params) return MDVIT_OK;
     return mdvit_reduce_partials_batched2(part, groups, nblk, C, dgamma, C, dbeta, s);      // fixed-order sums of the per-workgroup rows
 }
 
@@ -728,11 +734,14 @@ extern "C" int mdvit_rowdot_bwd(const float* x, int64_t ldx, const float* w, con
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && K > 0 && K <= 1024, MDVIT_E_SHAPE, "rowdot_bwd: need K <= 1024 (M=%d K=%d)", M, K);
     const int nblk = min(cdiv(M, 4), 1024);      // one row per wavefront per pass: small M (weight composition) still fills the chip
-    MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, K + 1, "rowdot_bwd");
+    const bool want_w = dw != nullptr || db != nullptr;          // both NULL: dx only (no read of x, no partial rows, no reduction launch)
+    MDVIT_CHECK_ARG(want_w || dx != nullptr, MDVIT_E_SHAPE, "rowdot_bwd: nothing to produce");
+    if (want_w) MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, K + 1, "rowdot_bwd");
     dim3 grid(nblk);
     const int C = K;
-    float* part = (float*)ws;
+    float* part = want_w ? (float*)ws : nullptr;
     LN_DISPATCH(rowdot_bwd_kernel, C, x, (long)ldx, w, dy, dx, (long)lddx, part, db != nullptr, M, K);
     MDVIT_LAUNCH_CHECK();
+    if (!want_w) return MDVIT_OK;
     return mdvit_reduce_partials(part, nblk, (long)K + 1, K, dw, 1, db, 0, s);
 }

@@ -979,8 +979,13 @@ class _LayerNorm(torch.autograd.Function):
         g = _c(g)
         M, Cn = x.shape
         dx = _empty_like(x)
-        dg, db = _flat_like(gamma, gamma)
         gp = None if g_pass is None else _c(g_pass)
+        fast = Cn in (64, 128, 320, 512)
+        if _dgrad_only and fast:          # the aux sweep: no parameter gradients -> no partial sums, no reduction launch
+            call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(gp), _p(dx), None, None, None, 0, M, Cn,
+                 gamma.shape[0] if gamma.dim() == 2 else 1, _stream())
+            return dx, None, None, None, None
+        dg, db = _flat_like(gamma, gamma)
         wsp, wsb, _keep = _partials_ws(2 * Cn, x.device)
         call("mdvit_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(gp), _p(dx), _p(dg), _p(db), wsp, wsb, M, Cn,
              gamma.shape[0] if gamma.dim() == 2 else 1, _stream())
@@ -1546,11 +1551,13 @@ class _RowDot(torch.autograd.Function):
         g = _c(g)
         M, K, ldx = _ld_view(x)
         dx = _empty((M, K), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        if _dgrad_only:                  # the aux sweep: dx = g w only
+            if dx is not None:
+                call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, None, None, None, 0, M, K, _stream())
+            return dx, None, None
         dw, db = _flat_like(w.reshape(-1), (1,) if ctx.has_b else None)
         wsp, wsb, _keep = _partials_ws(K + 1, g.device)
         call("mdvit_rowdot_bwd", _p(x), ldx, _p(w), _p(g), _p(dx), K, _p(dw), _p(db), wsp, wsb, M, K, _stream())
-        if _dgrad_only:
-            return dx, None, None
         return dx, dw.view_as(w), db
 
 
