@@ -296,7 +296,8 @@ int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const flo
  * out[b,n,c] = a[b,c] * ( Ch^-0.5 * sum_j q[n,head,j] M[b,head,j,ch] + q[n,c] * U[b,n,c] )
  * with M = softmax_over_tokens(k)^T v.  crpe weights: [s3*Ch,1,3,3], [s5*Ch,1,5,5], [s7*Ch,1,7,7] (+bias).
  * a == NULL: no domain adapter (mpvit.py:347-373).  kmax/ksum [B,C] and Mmat [B,C,Ch] are saved for backward.
- * Backward returns dqkv, the crpe gradients (all six may be NULL: dgrad only) and e = a * dL/da (NULL when a is NULL). */
+ * Backward returns dqkv, the crpe gradients (all six may be NULL: dgrad only) and e = a * dL/da (NULL when a is NULL).  dqkv == NULL: e alone (one pass over dout and out) --
+ * what the data-gradient-only sweep needs at the first adapter of the network. */
 size_t mdvit_factoratt_ws_bytes(int32_t B, int32_t N, int32_t C, int32_t heads);
 int mdvit_factoratt_fwd(const float* qkv, const float* w3, const float* b3, const float* w5, const float* b5,
                         const float* w7, const float* b7, const float* a, float* out, float* U, float* kmax, float* ksum, float* Mmat,

@@ -290,7 +290,8 @@ class _FactorAttBase(nn.Module):
         B, N, Cn = x.shape
         H, W = size
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
-        y = ops.factor_att(qkv, self.crpe.params(), H, W, self.num_heads, self.crpe.head_splits, domain_label, da_params)
+        y = ops.factor_att(qkv, self.crpe.params(), H, W, self.num_heads, self.crpe.head_splits, domain_label, da_params,
+                           aux_first=getattr(self, "aux_first", False))
         # proj + proj_drop (+ DropPath + residual when the caller hands them in)
         return ops.linear(y, self.proj.weight, self.proj.bias, residual=res, rowscale=rowscale,
                           drop_p=self.proj_drop_p if self.training else 0.0, rows_per_scale=N)

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restric
         const long tok = (long)b * g.N + i / QC;
         const float4 G = *reinterpret_cast<const float4*>(dout + tok * C + c);
         const float4 q = *reinterpret_cast<const float4*>(qkv + tok * 3 * C + c);
-        *reinterpret_cast<float4*>(dU + tok * C + c) = make_float4(av.x * G.x * q.x, av.y * G.y * q.y, av.z * G.z * q.z, av.w * G.w * q.w);
+        if (dU) *reinterpret_cast<float4*>(dU + tok * C + c) = make_float4(av.x * G.x * q.x, av.y * G.y * q.y, av.z * G.z * q.z, av.w * G.w * q.w);
         if (e) {
             const float4 o = *reinterpret_cast<const float4*>(out + tok * C + c);
             acc.x = fmaf(G.x, o.x, acc.x); acc.y = fmaf(G.y, o.y, acc.y); acc.z = fmaf(G.z, o.z, acc.z); acc.w = fmaf(G.w, o.w, acc.w);
@@ -584,6 +584,17 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     const bool want_wgrad = dw3 != nullptr;
     MDVIT_CHECK_ARG(want_wgrad ? (db3 && dw5 && db5 && dw7 && db7) : !(db3 || dw5 || db5 || dw7 || db7), MDVIT_E_SHAPE,
                     "factoratt_bwd: the six crpe gradient outputs must be all given or all NULL");
+    if (dqkv == nullptr) {
+        // the adapter's gradient carrier only: e = sum_n dout * out (the data-gradient-only aux sweep at the FIRST adapter of the network --
+        // nothing below it carries an adapter, so nothing below it is needed)
+        MDVIT_CHECK_ARG(e != nullptr && !want_wgrad, MDVIT_E_SHAPE, "factoratt_bwd: dqkv == NULL asks for e alone");
+        const int QC0 = C / 4;
+        const int gx = quad_grid((long)g.N * QC0, QC0, 512);
+        float* e_part = ws_P + (long)B * NT * C * Ch;
+        hipLaunchKernelGGL(fa_bwd_prep_kernel, dim3(gx, B), dim3(256), sizeof(float) * C, s, dout, qkv, out, a, (float*)nullptr, e_part, g);
+        MDVIT_LAUNCH_CHECK();
+        return mdvit_reduce_partials_batched(e_part, B, gx, C, e, s);
+    }
     // 1: dU, e
     const int QC = C / 4;
     {

@@ -52,6 +52,11 @@ class _EncoderDecoder(nn.Module):
                                     adapt_method=adapt_method, num_domains=num_domains, base_semantics=self._base_semantics, dsn=dsn)
 
         self.mhsa_stages = nn.ModuleList([stage(i) for i in range(num_stages)])
+        # the first adapter of the network in forward order (None without adapters): see ops.aux_stop / factor_att(aux_first=)
+        att0 = self.mhsa_stages[0].mhca_blks[0].factoratt_crpe
+        self._has_aux_first = hasattr(att0, "domain_layer")              # (a plain flag: a module reference would enter the state_dict)
+        if self._has_aux_first:
+            att0.aux_first = True
         if dsn:                                                          # mdvit.py:815-820
             self.bridge_conv1 = ConvParams(E[3], E[3], 3, 3)
             self.bridge_norms1 = nn.ModuleList([BatchNormAct(E[3], ACT_RELU) for _ in range(dsn)])
@@ -85,6 +90,8 @@ class _EncoderDecoder(nn.Module):
         for idx in range(self.num_stages):          # heads -- forked explicitly so that the gradients are summed by ops._Fork, not by autograd
             x = self.patch_embed_stages[idx](x)
             _, H, W, Cn = x.shape
+            if idx == 0 and self._has_aux_first:
+                x = ops.aux_stop(x)          # the aux (data-gradient-only) sweep ends at the first adapter: the stem / patch embed carry none
             x = self.mhsa_stages[idx](x.view(B, H * W, Cn), H, W, domain_label).view(B, H, W, Cn)
             x, s_, e_ = ops.fork(x, 3)
             skip.append(s_); enc.append(e_)

@@ -1577,9 +1577,10 @@ class _FactorAtt(torch.autograd.Function):
     from the attention backward (no division by a).  label is None -> no adapter (BASE / mpvit flavour)."""
 
     @staticmethod
-    def forward(ctx, qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, H, W_, heads, splits):
+    def forward(ctx, qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, H, W_, heads, splits, aux_first=False):
         _chk(qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2)
         ctx.set_materialize_grads(False)
+        ctx.aux_first = bool(aux_first)
         B, N, C3 = qkv.shape
         Cn = C3 // 3
         Ch = Cn // heads
@@ -1604,13 +1605,27 @@ class _FactorAtt(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 16
+            return (None,) * 17
         qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, a, out, U, kmax, ksum, Mmat = ctx.saved_tensors
         H, W_, heads, splits = ctx.meta
         g = _c(g)
         B, N, C3 = qkv.shape
         Cn = C3 // 3
         dev = qkv.device
+        if _dgrad_only and ctx.aux_first and a is not None:
+            # the first adapter of the network in the aux sweep: its (negated) gradient from e = sum_n g out, and nothing is handed on
+            e = _empty((B, Cn), device=dev, dtype=torch.float32)
+            wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, Cn, heads)
+            ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
+            call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(out), _p(U), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
+                 _p(Mmat), None, _p(e), None, None, None, None, None, None, _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2], _stream())
+            hid = W1.shape[0]
+            dW1, db1, dW2, db2 = _empty_like(W1), _empty_like(b1), _empty_like(W2), _empty_like(b2)
+            dab = _lib.load().mdvit_da_ws_bytes(B, hid, Cn)
+            daws = _empty((dab // 4,), device=dev, dtype=torch.float32)
+            call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), -1.0, _p(dW1), _p(db1), _p(dW2), _p(db2), _p(daws), dab,
+                 B, label.shape[1], hid, Cn, heads, _stream())
+            return (None,) * 8 + (dW1, db1, dW2, db2) + (None,) * 5
         dqkv = _empty_like(qkv)
         crpe = (w3, b3, w5, b5, w7, b7)
         sinks = [_sink_of(t) for t in crpe] if (not _dgrad_only and _side_stream is not None) else [None] * 6
@@ -1638,16 +1653,37 @@ class _FactorAtt(torch.autograd.Function):
             # dgrad-only (aux) sweep: MINUS the adapter gradient, cancelled against the merged sweep's (see set_dgrad_only)
             call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), -1.0 if _dgrad_only else 1.0,
                  _p(dW1), _p(db1), _p(dW2), _p(db2), _p(daws), dab, B, label.shape[1], hid, Cn, heads, _stream())
-        return (dqkv, *dws, None, dW1, db1, dW2, db2, None, None, None, None)
+        return (dqkv, *dws, None, dW1, db1, dW2, db2, None, None, None, None, None)
 
 
-def factor_att(qkv, crpe_params, H, W_, heads, splits=(2, 3, 3), domain_label=None, da_params=None):
-    """qkv [B,N,3C]; crpe_params = (w3,b3,w5,b5,w7,b7); domain_label [B,D] + da_params (W1,b1,W2,b2) or None -> [B,N,C]."""
+class _AuxStop(torch.autograd.Function):
+    """identity; in the data-gradient-only (aux) sweep the gradient stops here -- placed at the input of the first block that carries
+    a domain adapter: nothing upstream of it has adapter parameters, which are all that sweep is run for"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None if _dgrad_only else g
+
+
+def aux_stop(x):
+    return _AuxStop.apply(x) if x.requires_grad else x
+
+
+def factor_att(qkv, crpe_params, H, W_, heads, splits=(2, 3, 3), domain_label=None, da_params=None, aux_first=False):
+    """qkv [B,N,3C]; crpe_params = (w3,b3,w5,b5,w7,b7); domain_label [B,D] + da_params (W1,b1,W2,b2) or None -> [B,N,C].
+    aux_first: this is the FIRST adapter of the network in forward order -- in the data-gradient-only sweep its backward produces the
+    adapter gradient only and hands no gradient on (nothing below carries an adapter)."""
     w3, b3, w5, b5, w7, b7 = crpe_params
     if domain_label is None:
-        return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, None, None, None, None, None, int(H), int(W_), int(heads), tuple(splits))
+        return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, None, None, None, None, None, int(H), int(W_), int(heads), tuple(splits), False)
     W1, b1, W2, b2 = da_params
-    return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, _c(domain_label.float()), W1, b1, W2, b2, int(H), int(W_), int(heads), tuple(splits))
+    return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, _c(domain_label.float()), W1, b1, W2, b2, int(H), int(W_), int(heads), tuple(splits),
+                            bool(aux_first))
 
 
 def domain_adapter(label, W1, b1, W2, b2, heads):
