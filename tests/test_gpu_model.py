@@ -895,6 +895,34 @@ def test_bench_step_fused_forward_equals_per_domain_at_512():
     assert not bad, f"{len(bad)} gradient tensors differ between the fused and the per-domain step: {bad[:6]}"
 
 
+def test_aux_sweep_on_its_own_stream_equals_single_stream_step():
+    """The bench step with the data-gradient-only aux sweep on a stream of its own (ops.set_sweep_stream, ops.fork, the gradient stop at
+    the first adapter) == the same step with both sweeps on the main stream: same kernels in the same per-stream order, so the losses are
+    identical and every gradient agrees to the last bits (window-weight gradients use LDS float atomics).  Repeated: a missing
+    dependency between the streams would show up as run-to-run differences."""
+    from mdvit_amd import train
+    from mdvit_amd.synthetic import make_step_batches
+    batches = make_step_batches(2, 256, rank=0, step=0, device=dev())
+    prev = train._two_stream_sweeps
+    res = []
+    try:
+        for two in (False, True, True, True):
+            train._two_stream_sweeps = two
+            m = build_mdvit(31, 256).train()
+            res.append(_bench_step(m, batches, 4, True))
+            del m
+    finally:
+        train._two_stream_sweeps = prev
+    (l0, g0) = res[0]
+    for (l1, g1) in res[1:]:
+        for k in ("loss", "aux_loss", "kt_loss"):
+            assert l1[k] == l0[k], (k, l0[k], l1[k])
+        for n in g0:
+            assert torch.isfinite(g1[n]).all(), n
+            d = float((g1[n].double() - g0[n].double()).norm()) / max(float(g0[n].double().norm()), 1e-30)
+            assert d <= 1e-5, f"{n}: two-stream vs single-stream gradients differ by {d:.2e}"
+
+
 def test_bs32_shape_fused_128_image_forward_matches_per_domain_forwards():
     """BASELINE configs[2]'s per-GPU shape: one 128-image (4 domains x 32) domain-batched train-mode forward at 512x512 -- tensors
     beyond 4 GiB -- against four 32-image per-domain forwards with the same weights, on a strided sample of the logits."""
