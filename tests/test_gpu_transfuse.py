@@ -336,3 +336,32 @@ def test_transfuse_domain_batched_step_equals_per_domain_step():
         if not e <= (0.3 if ref.numel() == 1 else 5e-2):          # same arithmetic, different GEMM tilings at 3x the rows: kink flips only
             bad.append(f"{n}: {e:.2e}")
     assert not bad, bad[:8]
+
+
+def test_transfuse_thirty_steps_on_one_batch_drive_the_loss_down():
+    """end to end with everything the bench uses: domain-batched forward, implicit-GEMM convolutions, MFMA attention, weight gradients on
+    the side stream straight into the buckets, the one-launch AdamW -- the summed structure loss of a fixed batch must fall and stay finite"""
+    from mdvit_amd import ops
+    from mdvit_amd.optim import FusedAdamW
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.transfuse import transfuse_train_step
+    from oracle.gen_golden import synth_image, synth_label
+    B, S = 2, 256
+    batches = [(synth_image(4200 + d, B, S, S).to(dev()), synth_label(4300 + d, B, S, S).to(dev()), torch.full((B,), d, dtype=torch.long)) for d in range(4)]
+    m, _ = _build(11, drop=0.1)
+    m.train()
+    ops.enable_side_stream(True)
+    acc = GradAccumulator(m.parameters(), late=[p for n, p in m.named_parameters() if "domain_layer" in n])
+    acc.attach_sinks()
+    try:
+        opt = FusedAdamW(acc, lr=2e-4, weight_decay=0.01)
+        losses = []
+        for _ in range(30):
+            losses.append(transfuse_train_step(m, batches, optimizer=opt, accumulator=acc, fuse_domains=True)["loss"])
+        torch.cuda.synchronize()
+        losses = [float(l) for l in losses]
+    finally:
+        ops.enable_side_stream(False)
+        ops.set_grad_sinks(None)
+    assert all(np.isfinite(l) for l in losses), losses
+    assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:3]), (losses[:3], losses[-5:])
