@@ -67,9 +67,10 @@ __global__ __launch_bounds__(BM * 4) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int NV = sizeof(r) / sizeof(float4);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
+            // UNCONDITIONAL (rows past the end re-read the last row: they only feed outputs that are never stored): a load under a
+            // branch makes hipcc drain the whole vector-memory queue at the join, which defeats the weight prefetch below
             const int idx = tid + NT * v, row = idx >> 4, c4 = idx & 15;
-            r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + row < nrows) r[v] = *reinterpret_cast<const float4*>(src + (long)(row0 + row) * ld + c4 * 4);
+            r[v] = *reinterpret_cast<const float4*>(src + (long)min(row0 + row, nrows - 1) * ld + c4 * 4);
         }
     };
     auto store_tile = [&](const auto& r, char* dst, int rows) {
@@ -114,10 +115,19 @@ __global__ __launch_bounds__(BM * 4) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         store_tile(r1, sW1, 64);
         store_tile(r2, sW2, 64);
         __syncthreads();
-        if (hc0 + HC < p.Hd && !(p.abl & 2)) {             // next chunk's weights in flight behind this chunk's arithmetic
-            load_tile(r1, p.W1 + (long)(hc0 + HC) * C, C, 0, p.Hd - (hc0 + HC));
-            load_tile(r2, p.W2 + (hc0 + HC), p.Hd, 0, C);
+        // this chunk's bias quads FIRST, then the next chunk's weights (the last iteration re-reads its own chunk): the epilogue
+        // below then waits for the OLDER loads only (counted vmcnt) and the weight prefetch stays in flight behind the arithmetic.
+        // (It used to read b1 in the epilogue: in-order vmcnt made every chunk wait for the prefetch it had just issued.)
+        float4 b1q[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1q[q] = *reinterpret_cast<const float4*>(p.b1 + hc0 + wn0 + 8 * q + 4 * lhi);
+        __builtin_amdgcn_sched_barrier(0);          // (keeps the bias loads OLDER than the prefetch in the in-order vmcnt queue)
+        {
+            const int hn = min(hc0 + HC, p.Hd - HC);
+            load_tile(r1, p.W1 + (long)hn * C, C, 0, HC);
+            load_tile(r2, p.W2 + hn, p.Hd, 0, C);
         }
+        __builtin_amdgcn_sched_barrier(0);
         mlp_f32x16 uacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) uacc[r] = 0.f;
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(BM * 4) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = wn0 + 8 * q + 4 * lhi, hd = hc0 + col;
-            const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + hd);
+            const float4 b4 = b1q[q];
             float4 hv = (p.abl & 4) ? make_float4(uacc[4 * q + 0] + b4.x, uacc[4 * q + 1] + b4.y, uacc[4 * q + 2] + b4.z, uacc[4 * q + 3] + b4.w)
                                     : make_float4(gelu_f(uacc[4 * q + 0] + b4.x), gelu_f(uacc[4 * q + 1] + b4.y),
                                                   gelu_f(uacc[4 * q + 2] + b4.z), gelu_f(uacc[4 * q + 3] + b4.w));
@@ -145,21 +155,30 @@ __global__ __launch_bounds__(BM * 4) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __syncthreads();                                   // sW1 / sW2 / sH are rewritten by the next chunk
     }
 
-    if (row < p.M) {
-        const float rsc = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
+    {
+        // all epilogue operands requested at once (one exposed latency instead of eight): bias and residual quads, the row's DropPath scale
+        const int rowc = min(row, p.M - 1);
+        float4 b2q[4], rq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = wn0 + 8 * q + 4 * lhi;
-            const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + col);
+            b2q[q] = *reinterpret_cast<const float4*>(p.b2 + col);
+            rq[q] = *reinterpret_cast<const float4*>(p.res + (long)rowc * C + col);
+        }
+        const float rsc = p.rowscale ? p.rowscale[rowc / p.rows_per_scale] : 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wn0 + 8 * q + 4 * lhi;
+            const float4 b4 = b2q[q];
             float4 v = make_float4(yacc[4 * q + 0] + b4.x, yacc[4 * q + 1] + b4.y, yacc[4 * q + 2] + b4.z, yacc[4 * q + 3] + b4.w);
             if (p.drop) {
                 const float4 ds = mdvit_drop_scale4(k2a, k2b, (uint32_t)((long)row * C + col), p.thresh, p.inv_keep);
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
             }
             v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
-            const float4 r4 = *reinterpret_cast<const float4*>(p.res + (long)row * C + col);
+            const float4 r4 = rq[q];
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-            *reinterpret_cast<float4*>(p.y + (long)row * C + col) = v;
+            if (row < p.M) *reinterpret_cast<float4*>(p.y + (long)row * C + col) = v;
         }
     }
 }
@@ -200,9 +219,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto load_tile = [&](float4 (&r)[4], const float* src, long ld, int row0, int nrows) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;
-            r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + row < nrows) r[v] = *reinterpret_cast<const float4*>(src + (long)(row0 + row) * ld + c4 * 4);
+            const int idx = tid + 256 * v, row = idx >> 4, c4 = idx & 15;          // unconditional, see mlp_fwd_kernel
+            r[v] = *reinterpret_cast<const float4*>(src + (long)min(row0 + row, nrows - 1) * ld + c4 * 4);
         }
     };
     auto store_tile = [&](const float4 (&r)[4], char* dst) {
@@ -247,11 +265,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         store_tile(r2, sW2t);
         store_tile(r3, sW1t);
         __syncthreads();
-        if (hc0 + HC < p.Hd) {
-            load_tile(r1, p.W1 + (long)(hc0 + HC) * C, C, 0, p.Hd - (hc0 + HC));
-            load_tile(r2, p.W2t + (long)(hc0 + HC) * C, C, 0, p.Hd - (hc0 + HC));
-            load_tile(r3, p.W1t + (hc0 + HC), p.Hd, 0, C);
+        float4 b1q[4];                      // bias quads before the prefetch: see mlp_fwd_kernel
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1q[q] = *reinterpret_cast<const float4*>(p.b1 + hc0 + wn0 + 8 * q + 4 * lhi);
+        __builtin_amdgcn_sched_barrier(0);          // (keeps the bias loads OLDER than the prefetch in the in-order vmcnt queue)
+        {
+            const int hn = min(hc0 + HC, p.Hd - HC);
+            load_tile(r1, p.W1 + (long)hn * C, C, 0, HC);
+            load_tile(r2, p.W2t + (long)hn * C, C, 0, HC);
+            load_tile(r3, p.W1t + hn, p.Hd, 0, C);
         }
+        __builtin_amdgcn_sched_barrier(0);
         mlp_f32x16 uacc, dacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { uacc[r] = 0.f; dacc[r] = 0.f; }
@@ -271,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = wn0 + 8 * q + 4 * lhi, hd = hc0 + col;
-            const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + hd);
+            const float4 b4 = b1q[q];
             float4 dv = make_float4(dacc[4 * q + 0] * gelu_grad_f(uacc[4 * q + 0] + b4.x), dacc[4 * q + 1] * gelu_grad_f(uacc[4 * q + 1] + b4.y),
                                     dacc[4 * q + 2] * gelu_grad_f(uacc[4 * q + 2] + b4.z), dacc[4 * q + 3] * gelu_grad_f(uacc[4 * q + 3] + b4.w));
             if (p.drop) {
