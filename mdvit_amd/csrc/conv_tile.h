@@ -20,24 +20,37 @@ constexpr int CT_TH = 8, CT_TW = 16, CT_CL = 32;
 // first LDS store (a load -> store loop would pay the HBM latency once per iteration).  x already points at the first
 // channel of the block; nch % 4 == 0.
 template <int LH, int LW>
+struct CtWindow {
+    static constexpr int NP = LH * LW, PASSES = (NP + 31) / 32;
+    float4 v[PASSES];
+    // request the whole window (global -> registers); nothing waits here
+    __device__ __forceinline__ void load(const float* __restrict__ x, long ldx, long img, int h0, int w0, int H, int W, int nch) {
+        const int q4 = (threadIdx.x & 7) * 4, pl = threadIdx.x >> 3;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int p = pl + 32 * i;
+            const int hh = h0 + p / LW, ww = w0 + p % LW;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < NP && hh >= 0 && hh < H && ww >= 0 && ww < W && q4 < nch)
+                v[i] = *reinterpret_cast<const float4*>(x + (img + (long)hh * W + ww) * ldx + q4);
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ sx) const {
+        const int q4 = (threadIdx.x & 7) * 4, pl = threadIdx.x >> 3;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int p = pl + 32 * i;
+            if (p < NP) *reinterpret_cast<float4*>(sx + p * CT_CL + q4) = v[i];
+        }
+    }
+};
+
+template <int LH, int LW>
 __device__ __forceinline__ void ct_stage_window(float* __restrict__ sx, const float* __restrict__ x, long ldx, long img,
                                                 int h0, int w0, int H, int W, int nch) {
-    constexpr int NP = LH * LW, PASSES = (NP + 31) / 32;
-    const int q4 = (threadIdx.x & 7) * 4, pl = threadIdx.x >> 3;
-    float4 v[PASSES];
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-        const int p = pl + 32 * i;
-        const int hh = h0 + p / LW, ww = w0 + p % LW;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < NP && hh >= 0 && hh < H && ww >= 0 && ww < W && q4 < nch)
-            v[i] = *reinterpret_cast<const float4*>(x + (img + (long)hh * W + ww) * ldx + q4);
-    }
-#pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-        const int p = pl + 32 * i;
-        if (p < NP) *reinterpret_cast<float4*>(sx + p * CT_CL + q4) = v[i];
-    }
+    CtWindow<LH, LW> win;
+    win.load(x, ldx, img, h0, w0, H, W, nch);
+    win.store(sx);
 }
 
 // body of one (tile, 32-channel block, image) workgroup; sx / sw: LDS of at least (8+2R)(16+2R)*32 and 32*WIN*WIN floats
@@ -52,11 +65,25 @@ __device__ __forceinline__ void conv_tile_body(float* __restrict__ sx, float* __
     const int th0 = (blockIdx.x / tiles_w) * CT_TH, tw0 = (blockIdx.x % tiles_w) * CT_TW;
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const long img = (long)b * H * W;
-    for (int i = threadIdx.x; i < CT_CL * WIN * WIN; i += 256) {
-        const int c = i / (WIN * WIN), t = i % (WIN * WIN);
-        sw[i] = (c0 + c < ncls) ? w[(long)(c0 + c) * WIN * WIN + (FLIP ? WIN * WIN - 1 - t : t)] : 0.f;
+    // the window AND the 32 x WIN^2 weights are requested before anything is stored to LDS: one exposed load latency per workgroup
+    // (a load -> LDS-store loop over the weights paid it up to seven more times)
+    CtWindow<LH, LW> win;
+    win.load(x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
+    constexpr int NWQ = (CT_CL * WIN * WIN + 255) / 256;
+    float wq[NWQ];
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+        const int i = threadIdx.x + 256 * j, c = i / (WIN * WIN), t = i % (WIN * WIN);
+        const bool ok = i < CT_CL * WIN * WIN && c0 + c < ncls;
+        const float wv = w[ok ? (long)(c0 + c) * WIN * WIN + (FLIP ? WIN * WIN - 1 - t : t) : 0];
+        wq[j] = ok ? wv : 0.f;
     }
-    ct_stage_window<LH, LW>(sx, x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < CT_CL * WIN * WIN) sw[i] = wq[j];
+    }
+    win.store(sx);
     __syncthreads();
     const int h = th0 + rl;
     if (c0 + cl >= ncls || h >= H) return;
@@ -155,8 +182,14 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
     const int t_beg = blockIdx.x * tiles_per_block, t_end = min(tiles_total, t_beg + tiles_per_block);
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int th0 = (tile / tiles_w) * CT_TH, tw0 = (tile % tiles_w) * CT_TW;
-        ct_stage_window<LH, LW>(sx, x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
-        ct_stage_window<CT_TH, CT_TW>(sg, g + goff + c0 / GDIV, ldg, img, th0, tw0, H, W, (ncls - c0) / GDIV);
+        {   // both windows requested before either is stored
+            CtWindow<LH, LW> wx;
+            CtWindow<CT_TH, CT_TW> wg;
+            wx.load(x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
+            wg.load(g + goff + c0 / GDIV, ldg, img, th0, tw0, H, W, (ncls - c0) / GDIV);
+            wx.store(sx);
+            wg.store(sg);
+        }
         __syncthreads();
         if (rl < WIN && chan_ok) {
 #pragma unroll 2
