@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--by-shape", action="store_true", help="key the GEMM event table by (variant, M, N, K) -- for tools/gemm_shapes.py")
     ap.add_argument("--detail", default="", help="write the per-kernel table to this JSON file")
+    ap.add_argument("--max-inflight", type=int, default=2,
+                    help="steps the host may have enqueued ahead of the GPU (a training loop that reads its loss every step has 1-2): bounds the "
+                         "memory that cross-stream tensors hold until their events complete -- at bs=32 an unbounded run-ahead grows the pool "
+                         "past 288 GB and the allocator's free-and-retry path takes over")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the bs=32 leg and the MHSA+DA block roofline at bs=32 that the default N=1 run appends to its JSON line")
     return ap.parse_args()
@@ -304,9 +308,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    inflight = []
+
+    def throttle():                     # called before a step is enqueued; done() after it
+        while len(inflight) >= max(1, args.max_inflight):
+            inflight.pop(0).synchronize()
+
+    def done():
+        e = torch.cuda.Event()
+        e.record()
+        inflight.append(e)
+
     use_events = not args.no_kernel_events and not args.graph
     dominant, dom_stride = None, 1
     for i in range(args.warmup):
+        throttle()
         scout = use_events and not (args.by_shape or args.detail) and i == args.warmup - 1
         if scout:                       # the last warm-up step times EVERY GEMM launch to find the dominant kernel ...
             ops.kernel_events_begin()
@@ -316,13 +332,17 @@ def main():
             if t:
                 dominant, drec = max(t.items(), key=lambda kv: kv[1]["ms"])
                 dom_stride = max(1, drec["n"] // 32)       # ~32 timed launches per step: the events must not become the host's load
+        done()
     fence()
+    inflight.clear()
     if use_events:                      # ... the timed steps put HIP events around a sample of that kernel's launches only (events on
         ops.kernel_events_begin(by_shape=args.by_shape, only=dominant, stride=dom_stride)   # all ~700 GEMM launches cost ~4 % of a step)
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
+        throttle()
         last = step(args.warmup + i)
+        done()
     t_enq = time.perf_counter() - t0          # the host has ENQUEUED every step (the GPU is still running them unless the host is the limit)
     fence()
     dt = time.perf_counter() - t0

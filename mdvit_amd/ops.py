@@ -204,15 +204,20 @@ def _sink_of(t):
 # ---- peer streams: the G peer heads of a domain-batched forward are independent chains of small kernels --------------------
 # Each head (its forward, and -- because autograd runs a node's backward on the stream its forward ran on -- its backward too) goes
 # to a stream of its own, so the heads overlap each other instead of queueing behind each other on the main stream.
+# OFF by default since the aux sweep has a stream of its own: main + weight-gradient + aux-sweep streams already fill the GPU, and
+# with the heads' streams on top there are more streams than hardware queues (4) -- the bs=4 step is 6-8 % SLOWER with four peer
+# streams, level with one (profiles/r02k_stream_config_ab.txt); MDVIT_PEER_STREAMS=1 switches them on (single-sweep use).
 _peer_streams = []
-_use_peer_streams = os.environ.get("MDVIT_PEER_STREAMS", "1") != "0"
+_use_peer_streams = os.environ.get("MDVIT_PEER_STREAMS", "0") != "0"
 _graph_peers = os.environ.get("MDVIT_GRAPH_PEERS", "0") != "0"      # fork the peer streams inside a HIP-graph capture too
+_peer_stream_count = max(1, int(os.environ.get("MDVIT_PEER_STREAM_COUNT", "4")))   # heads i, i + count, ... share a stream
 
 
 def peer_stream(i: int):
     """the i-th peer stream, or None when disabled / capturing (a captured graph keeps the single-stream order)"""
     if not _use_peer_streams or (torch.cuda.is_current_stream_capturing() and not _graph_peers):
         return None
+    i %= _peer_stream_count
     while len(_peer_streams) <= i:
         _peer_streams.append(torch.cuda.Stream())
     return _peer_streams[i]
@@ -831,6 +836,7 @@ def matmul(A, B):
 # ------------------------------------------------------------------------------------------------
 _mlp_recompute = os.environ.get("MDVIT_MLP_RECOMPUTE", "1") != "0"
 _mlp_fused = os.environ.get("MDVIT_MLP_FUSED", "1") != "0"
+_mlp_recompute_maxc = int(os.environ.get("MDVIT_MLP_RECOMPUTE_MAXC", "128"))
 
 
 class _MlpResidual(torch.autograd.Function):
@@ -856,7 +862,7 @@ class _MlpResidual(torch.autograd.Function):
             ctx.b1_ref, ctx.b2_ref = b1, b2
             return out
         plane = _plane_ok(M, Hd, Cin) and _plane_ok(M, Cin, Hd) and W1.is_contiguous() and W2.is_contiguous()
-        if _mlp_recompute and _gemm_precision >= 1 and Cin <= 128 and Cin % 32 == 0 and Hd % 4 == 0:
+        if _mlp_recompute and _gemm_precision >= 1 and Cin <= _mlp_recompute_maxc and Cin % 32 == 0 and Hd % 4 == 0:
             u = None
             if plane:
                 gemm_nt(x, W1, h, M, Hd, Cin, bias=b1, epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)

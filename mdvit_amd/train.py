@@ -23,6 +23,17 @@ from .parallel import GradAccumulator, GradBucketReducer
 
 
 _two_stream_sweeps = os.environ.get("MDVIT_SWEEP_STREAMS", "1") != "0"      # A/B switch: 0 = both sweeps on the main stream
+# One device per process: the autograd engine's hand-off of every sweep to its per-device worker thread buys nothing and costs a
+# thread switch per sweep plus cross-thread stream bookkeeping; the sweeps run on the calling thread (+1-2 % on the bs=4 step).
+_autograd_mt = os.environ.get("MDVIT_AUTOGRAD_MT", "0") != "0"
+
+
+def _backward(loss, **kw):
+    if _autograd_mt:
+        loss.backward(**kw)
+    else:
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward(**kw)
 
 
 def _da_params(model):
@@ -61,14 +72,14 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
         elif last and reducer is not None:
             reducer.arm()
         if on_stream is None:
-            loss.backward(retain_graph=retain)
+            _backward(loss, retain_graph=retain)
         else:
             # the whole sweep on a stream of its own (ops.set_sweep_stream): every node of it is one of our Functions (ops.fork at the
             # trunk's multi-consumer tensors) and the root gradient is handed in, so nothing of it is launched on the main stream
             main = ops.current_stream_obj()
             ops.set_sweep_stream(on_stream)
             try:
-                loss.backward(retain_graph=retain, gradient=ops.one_like(loss))
+                _backward(loss, retain_graph=retain, gradient=ops.one_like(loss))
             finally:
                 ops.set_sweep_stream(None)
             ops.stream_wait(main, on_stream)

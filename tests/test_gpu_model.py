@@ -923,6 +923,33 @@ def test_aux_sweep_on_its_own_stream_equals_single_stream_step():
             assert d <= 1e-5, f"{n}: two-stream vs single-stream gradients differ by {d:.2e}"
 
 
+def test_peer_heads_on_their_own_streams_equal_heads_on_the_main_stream():
+    """MDVIT_PEER_STREAMS=1 (opt-in since the aux sweep has its own stream): the four peer heads of a domain-batched forward, and
+    their backward chains, on a stream each == the default (heads on the main stream) -- identical losses, gradients to the last bits;
+    repeated so that a missing cross-stream dependency shows up as a run-to-run difference."""
+    from mdvit_amd import ops
+    from mdvit_amd.synthetic import make_step_batches
+    batches = make_step_batches(2, 256, rank=0, step=0, device=dev())
+    prev = ops._use_peer_streams
+    res = []
+    try:
+        for peers in (False, True, True):
+            ops._use_peer_streams = peers
+            m = build_mdvit(31, 256).train()
+            res.append(_bench_step(m, batches, 4, True))
+            del m
+    finally:
+        ops._use_peer_streams = prev
+    (l0, g0) = res[0]
+    for (l1, g1) in res[1:]:
+        for k in ("loss", "aux_loss", "kt_loss"):
+            assert l1[k] == l0[k], (k, l0[k], l1[k])
+        for n in g0:
+            assert torch.isfinite(g1[n]).all(), n
+            d = float((g1[n].double() - g0[n].double()).norm()) / max(float(g0[n].double().norm()), 1e-30)
+            assert d <= 1e-5, f"{n}: peer-stream vs main-stream gradients differ by {d:.2e}"
+
+
 def test_bs32_shape_fused_128_image_forward_matches_per_domain_forwards():
     """BASELINE configs[2]'s per-GPU shape: one 128-image (4 domains x 32) domain-batched train-mode forward at 512x512 -- tensors
     beyond 4 GiB -- against four 32-image per-domain forwards with the same weights, on a strided sample of the logits."""

@@ -8,6 +8,8 @@ from mdvit_amd.optim import FusedAdamW
 from mdvit_amd.parallel import GradAccumulator
 from mdvit_amd.synthetic import make_step_batches
 from mdvit_amd.train import mdvit_train_step
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+NSTEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = mdvit_amd.MDViT(img_size=512, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup",
@@ -16,9 +18,9 @@ ops.enable_side_stream(True)
 accum = GradAccumulator(model.parameters(), late=[p for n, p in model.named_parameters() if "domain_layer" in n])
 accum.attach_sinks()
 opt = FusedAdamW(accum, lr=1e-4, weight_decay=0.05)
-pool = [make_step_batches(4, 512, rank=0, step=s, device=dev) for s in range(2)]
+pool = [make_step_batches(BATCH, 512, rank=0, step=s, device=dev) for s in range(2)]
 torch.cuda.synchronize()
-for i in range(16):
+for i in range(NSTEPS):
     st = torch.cuda.memory_stats()
     a0 = st.get("num_device_alloc", 0)
     t0 = time.perf_counter()
@@ -27,4 +29,4 @@ for i in range(16):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     st = torch.cuda.memory_stats()
-    print(f"step {i:2d}: enqueue {1e3 * (t1 - t0):7.1f} ms  to idle {1e3 * (t2 - t0):7.1f} ms  device allocs +{st.get('num_device_alloc', 0) - a0}  reserved {st['reserved_bytes.all.current'] / 2**30:.1f} GiB", flush=True)
+    print(f"step {i:2d}: enqueue {1e3 * (t1 - t0):7.1f} ms  to idle {1e3 * (t2 - t0):7.1f} ms  device allocs +{st.get('num_device_alloc', 0) - a0}  reserved {st['reserved_bytes.all.current'] / 2**30:.1f} GiB  allocated peak {st['allocated_bytes.all.peak'] / 2**30:.1f} GiB  retries {st.get('num_alloc_retries', 0)}  device frees {st.get('num_device_free', 0)}", flush=True)
