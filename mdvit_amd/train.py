@@ -28,6 +28,17 @@ _two_stream_sweeps = os.environ.get("MDVIT_SWEEP_STREAMS", "1") != "0"      # A/
 _autograd_mt = os.environ.get("MDVIT_AUTOGRAD_MT", "0") != "0"
 
 
+_timeline = None      # tools/sweep_timeline.py: a list here collects (tag, event, host seconds) at the sweeps' stream ends
+
+
+def _tl(tag, stream=None):
+    if _timeline is not None:
+        import time
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream) if stream is not None else e.record()
+        _timeline.append((tag, e, time.perf_counter()))
+
+
 def _backward(loss, **kw):
     if _autograd_mt:
         loss.backward(**kw)
@@ -82,8 +93,13 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
                 _backward(loss, retain_graph=retain, gradient=ops.one_like(loss))
             finally:
                 ops.set_sweep_stream(None)
+            _tl("aux sweep: last kernel (its stream)", on_stream)
             ops.stream_wait(main, on_stream)
+        if on_stream is None:
+            _tl("sweep on main: last kernel")
         if join:
+            if ops._side_stream is not None:
+                _tl("side stream: last weight-gradient kernel", ops._side_stream)
             ops.join_side_stream()      # weight gradients may have been produced on the side stream
         if accumulator is not None:
             accumulator.end_sweep(last, remaining=remaining)
