@@ -37,6 +37,14 @@ enum { MDVIT_ACT_NONE = 0, MDVIT_ACT_HSWISH = 1, MDVIT_ACT_RELU = 2 };
 const char* mdvit_last_error(void);
 int mdvit_version(void);
 
+/* Measurement only (bench.py's `roofline`; no reference counterpart): HIP events owned by the library, and "arm": the NEXT GEMM
+ * main-kernel launch (mdvit_gemm_f32 incl. the implicit convolution and the weight-gradient kernel) records its own begin / end
+ * timestamps into (start, stop) -- the dispatch's execution time as rocprofv3 --kernel-trace reports it.  arm(NULL, NULL) disarms. */
+int mdvit_event_create(void** out_event);
+int mdvit_event_destroy(void* event);
+int mdvit_event_elapsed_ms(void* start_event, void* stop_event, float* ms);
+int mdvit_timing_arm(void* start_event, void* stop_event);
+
 /* Reductions over the token axis (weight / bias gradients, column sums) write ONE row of partial sums per workgroup into
  * the caller's workspace and add the rows in a fixed order in a second tiny launch -- deterministic, and much faster than
  * ~1000 same-address float atomics.  `ws` of those entry points: mdvit_partials_ws_bytes(n) bytes, n = number of floats

@@ -106,6 +106,10 @@ _SIGS = {
     "mdvit_split_planes": [vp, i64, vp, i64, i64, i64, i32, i32, vp],
     "mdvit_split_planes_many": [vp, i32, i32, i32, vp],
     "mdvit_split_planes_t": [vp, i64, vp, i64, i64, i32, i32, i32, i32, vp],
+    "mdvit_event_create": [C.POINTER(vp)],
+    "mdvit_event_destroy": [vp],
+    "mdvit_event_elapsed_ms": [vp, vp, C.POINTER(f32)],
+    "mdvit_timing_arm": [vp, vp],
     "mdvit_gemm_f32": [C.POINTER(GemmDesc), vp],
     "mdvit_gemm_plan": [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_force_plan": [i32, i32],

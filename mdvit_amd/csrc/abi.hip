@@ -14,6 +14,32 @@ int mdvit_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* mdvit_last_error(void) { return g_mdvit_err; }
+
+hipEvent_t g_mdvit_t0 = nullptr, g_mdvit_t1 = nullptr;
+
+extern "C" int mdvit_timing_arm(void* start_event, void* stop_event) {
+    g_mdvit_t0 = (hipEvent_t)start_event;
+    g_mdvit_t1 = start_event ? (hipEvent_t)stop_event : nullptr;
+    return MDVIT_OK;
+}
+extern "C" int mdvit_event_create(void** out) {
+    MDVIT_CHECK_ARG(out != nullptr, MDVIT_E_SHAPE, "event_create: null output");
+    hipEvent_t e = nullptr;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(rc));
+    *out = (void*)e;
+    return MDVIT_OK;
+}
+extern "C" int mdvit_event_destroy(void* ev) {
+    if (ev) hipEventDestroy((hipEvent_t)ev);
+    return MDVIT_OK;
+}
+extern "C" int mdvit_event_elapsed_ms(void* start_event, void* stop_event, float* ms) {
+    MDVIT_CHECK_ARG(start_event && stop_event && ms, MDVIT_E_SHAPE, "event_elapsed_ms: null argument");
+    hipError_t rc = hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+    if (rc != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "hipEventElapsedTime failed: %s", hipGetErrorString(rc));
+    return MDVIT_OK;
+}
 extern "C" int mdvit_version(void) { return MDVIT_ABI_VERSION; }
 
 namespace {

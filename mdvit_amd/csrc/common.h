@@ -1,6 +1,7 @@
 // Shared device/host helpers for libmdvit_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -16,6 +17,20 @@ int mdvit_set_error(int code, const char* fmt, ...);
 #define MDVIT_CHECK_ARG(cond, code, ...)                      \
     do {                                                      \
         if (!(cond)) return mdvit_set_error(code, __VA_ARGS__); \
+    } while (0)
+
+// Kernel-execution timing for bench.py's roofline: mdvit_timing_arm(start, stop) makes the NEXT GEMM main-kernel launch record its
+// own begin / end timestamps into the two events (hipExtLaunchKernelGGL) -- the dispatch's duration as rocprofv3 reports it, without
+// the time the launch waits for CUs held by the other streams' kernels, which a record-before / record-after event pair includes.
+extern hipEvent_t g_mdvit_t0, g_mdvit_t1;       // abi.hip
+#define MDVIT_TIMED_LAUNCH(kernel, grid, block, shmem, s, ...)                                                       \
+    do {                                                                                                              \
+        if (g_mdvit_t0) {                                                                                             \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, s, g_mdvit_t0, g_mdvit_t1, 0, __VA_ARGS__);             \
+            g_mdvit_t0 = g_mdvit_t1 = nullptr;                                                                        \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, s, __VA_ARGS__);                                           \
+        }                                                                                                             \
     } while (0)
 
 #define MDVIT_LAUNCH_CHECK()                                                         \

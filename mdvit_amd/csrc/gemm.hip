@@ -142,10 +142,10 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, int bf3, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(NTHREADS);
 #define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_, BF3_) \
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_, BF3_>), grid, block, 0, s, a)
+    MDVIT_TIMED_LAUNCH((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_, BF3_>), grid, block, 0, s, a)
     if (a.conv_c > 0) {
         if (ta || !tb || !bf3 || epi != EPI_PLAIN) return 1;
-        hipLaunchKernelGGL((gemm_conv3x3_kernel<BM, BN, WM, WN>), grid, block, 0, s, a);
+        MDVIT_TIMED_LAUNCH((gemm_conv3x3_kernel<BM, BN, WM, WN>), grid, block, 0, s, a);
         return 0;
     }
     if (!ta && tb) {                                   // forward (weights [N,K]); with transposed weights also dgrad

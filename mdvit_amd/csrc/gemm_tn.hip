@@ -342,12 +342,12 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
 #define MDVIT_TN_LAUNCH(BM_, BN_)                                                                                   \
     do {                                                                                                            \
         if (a.cv_c > 0) {                                                                                           \
-            if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, true, true>), grid, block, 0, s, a);      \
-            else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, false, true>), grid, block, 0, s, a);              \
-        } else if (one) { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, true, false>), grid, block, 0, s, a);     \
-                   else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 1, false, false>), grid, block, 0, s, a); }           \
-        else { if (a.colsum) hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, true, false>), grid, block, 0, s, a);         \
-               else hipLaunchKernelGGL((gemm_tn_kernel<BM_, BN_, 2, false, false>), grid, block, 0, s, a); }               \
+            if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, true, true>), grid, block, 0, s, a);      \
+            else MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, false, true>), grid, block, 0, s, a);              \
+        } else if (one) { if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 1, true, false>), grid, block, 0, s, a);     \
+                   else MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 1, false, false>), grid, block, 0, s, a); }           \
+        else { if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, true, false>), grid, block, 0, s, a);         \
+               else MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, false, false>), grid, block, 0, s, a); }               \
     } while (0)
     if (pl.cfg == 0) MDVIT_TN_LAUNCH(128, 128);
     else if (pl.cfg == 1) MDVIT_TN_LAUNCH(128, 64);
