@@ -871,3 +871,39 @@ def test_wgrad_tn_kernel_strided_operands_and_single_plane():
     out = torch.full((M, N), float("nan"), device=dev())                # no workspace allowed: one slab, written directly
     ops.gemm(ops._p(Aw[:, 128:256]), ops._p(Bw[:, 64:128]), ops._p(out), M, N, K, lda=384, ldb=256, ldc=N, trans_a=True, trans_b=False, allow_split=False)
     check(out, ref.float(), tol=2e-5, name="allow_split=False")
+
+
+def test_armed_gemm_launch_records_its_own_begin_and_end():
+    """mdvit_timing_arm (bench.py's roofline timer): the NEXT GEMM launch -- and only that one -- writes its own begin / end timestamps
+    into the two library events; the result of an armed launch is the result of a plain one; the event-sampled table of ops names the
+    kernel and counts every launch."""
+    import ctypes as C
+    from mdvit_amd import _lib, ops
+    M, N, K = 4096, 320, 512
+    x, W = rnd(M, K, seed=5).to(dev()), rnd(N, K, seed=6).to(dev())
+    y0, y1 = torch.empty((M, N), device=dev()), torch.empty((M, N), device=dev())
+    ops.gemm(ops._p(x), ops._p(W), ops._p(y0), M, N, K, lda=K, ldb=K, ldc=N)
+    h0, h1 = C.c_void_p(), C.c_void_p()
+    _lib.call("mdvit_event_create", C.byref(h0)); _lib.call("mdvit_event_create", C.byref(h1))
+    try:
+        _lib.call("mdvit_timing_arm", h0.value, h1.value)
+        ops.gemm(ops._p(x), ops._p(W), ops._p(y1), M, N, K, lda=K, ldb=K, ldc=N)
+        ops.gemm(ops._p(x), ops._p(W), ops._p(y0), M, N, K, lda=K, ldb=K, ldc=N)       # not armed any more
+        torch.cuda.synchronize()
+        ms = C.c_float(-1.0)
+        _lib.call("mdvit_event_elapsed_ms", h0.value, h1.value, C.byref(ms))
+        assert 1e-3 < ms.value < 5.0, ms.value                   # one 1.3 GFLOP launch: microseconds, not the three of them, not zero
+        assert torch.equal(y0, y1)
+        with pytest.raises(_lib.MdvitHipError):
+            _lib.call("mdvit_event_elapsed_ms", None, h1.value, C.byref(ms))
+    finally:
+        _lib.call("mdvit_timing_arm", None, None)
+        _lib.call("mdvit_event_destroy", h0.value); _lib.call("mdvit_event_destroy", h1.value)
+    ops.kernel_events_begin(stride=2)
+    for _ in range(8):
+        ops.gemm(ops._p(x), ops._p(W), ops._p(y1), M, N, K, lda=K, ldb=K, ldc=N)
+    t = ops.kernel_events_end()
+    assert len(t) == 1
+    (name, rec), = t.items()
+    assert name.startswith("gemm_f32_kernel<") and rec["launches"] == 8 and 1 <= rec["n"] <= 8 and rec["ms"] > 0
+    assert rec["timer"].startswith("kernel begin/end") and rec["flop"] == rec["n"] * 2.0 * M * N * K
