@@ -327,10 +327,13 @@ def main():
         torch.cuda.synchronize()
 
     inflight = []
+    waited = [0.0]                      # seconds the host spent in throttle() during the timed steps (not enqueue work)
 
     def throttle():                     # called before a step is enqueued; done() after it
         while len(inflight) >= max(1, args.max_inflight):
+            tw = time.perf_counter()
             inflight.pop(0).synchronize()
+            waited[0] += time.perf_counter() - tw
 
     def done():
         e = torch.cuda.Event()
@@ -353,6 +356,7 @@ def main():
         done()
     fence()
     inflight.clear()
+    waited[0] = 0.0
     if use_events:                      # ... the timed steps put HIP events around a sample of that kernel's launches only (events on
         ops.kernel_events_begin(by_shape=args.by_shape, only=dominant, stride=dom_stride)   # all ~700 GEMM launches cost ~4 % of a step)
     t0 = time.perf_counter()
@@ -489,7 +493,8 @@ def main():
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
             "model_flops_util": round(value / world * flop_per_img / 1e12 / peak_mfma, 4),
-            "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 3),
+            "host_enqueue_ms_per_step": round((t_enq - waited[0]) * 1e3 / args.steps, 3),
+            "host_throttle_wait_ms_per_step": round(waited[0] * 1e3 / args.steps, 3),
             "phase_ms": phase_ms, "roofline": roof, "cpu_baseline": cpu, "drift_vs_parity_mode": drift,
             "world": world, "rccl_ranks": rccl_ranks, "devices": devices,
             "allreduce": {"buckets": n_buckets, "issued_under_the_aux_sweep": overlapped_buckets},
