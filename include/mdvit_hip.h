@@ -131,6 +131,8 @@ int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
  *   mode 2 / 3: w = a gradient in the [Cout][tap][Cin] order of the implicit weight-gradient GEMM (TN with conv_c > 0: A = dy [tokens, Cout],
  *               B = the image, N = 9 Cin) -> out [Cout, Cin, 3, 3], overwritten (2) or accumulated into (3) */
 int mdvit_conv_weight_relayout(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t mode, void* stream);
+/* modes 0 / 1 for many weights in one launch: items [n][5] int64 in device memory = {w, out, Cout, Cin, mode} (the per-step refresh of every cached layout) */
+int mdvit_conv_weight_relayout_many(const void* items_dev, int32_t n, int32_t blocks_per_item, void* stream);
 
 /* ---- "plane" GEMM family: operands pre-split into bf16 planes ------------------------------------------------
  * A plane tensor is [planes][rows][ld] bf16 (uint16 storage): plane 0 = hi = RNE bf16(x), plane 1 = lo = RNE bf16(x - hi),

@@ -114,6 +114,7 @@ _SIGS = {
     "mdvit_gemm_plan": [C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_force_plan": [i32, i32],
     "mdvit_conv_weight_relayout": [vp, vp, i32, i32, i32, vp],
+    "mdvit_conv_weight_relayout_many": [vp, i32, i32, vp],
     "mdvit_gemm_kernel_name": [vp, C.c_char_p, i32],
     "mdvit_gemm_tn_config": [i32, i32, i32],
     "mdvit_transpose_f32": [vp, i64, vp, i32, i32, vp],

@@ -367,6 +367,31 @@ __global__ __launch_bounds__(256) void conv_weight_relayout_kernel(const float* 
     }
 }
 
+// the same for many weights in ONE launch (modes 0 / 1 only): items [n][5] int64 in device memory = {w, out, Cout, Cin, mode}; grid.y = item
+__global__ __launch_bounds__(256) void conv_weight_relayout_many_kernel(const long long* __restrict__ items) {
+    const long long* it = items + 5 * (long)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(it[0]);
+    float* out = reinterpret_cast<float*>(it[1]);
+    const int Cout = (int)it[2], Cin = (int)it[3], mode = (int)it[4];
+    const long total = (long)Cout * Cin * 9;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        if (mode == 0) {          // out[co][t][ci]
+            const int ci = (int)(e % Cin); const int t = (int)((e / Cin) % 9); const int co = (int)(e / (9L * Cin));
+            out[e] = w[((long)co * Cin + ci) * 9 + t];
+        } else {                  // out[ci][t][co] = w[co][ci][8 - t]
+            const int co = (int)(e % Cout); const int t = (int)((e / Cout) % 9); const int ci = (int)(e / (9L * Cout));
+            out[e] = w[((long)co * Cin + ci) * 9 + (8 - t)];
+        }
+    }
+}
+
+extern "C" int mdvit_conv_weight_relayout_many(const void* items_dev, int32_t n, int32_t blocks_per_item, void* stream) {
+    MDVIT_CHECK_ARG(items_dev && n > 0 && blocks_per_item > 0, MDVIT_E_SHAPE, "conv_weight_relayout_many: bad arguments");
+    hipLaunchKernelGGL(conv_weight_relayout_many_kernel, dim3(blocks_per_item, n), dim3(256), 0, (hipStream_t)stream, (const long long*)items_dev);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
 extern "C" int mdvit_conv_weight_relayout(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t mode, void* stream) {
     MDVIT_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && mode >= 0 && mode <= 3, MDVIT_E_SHAPE, "conv_weight_relayout: bad arguments");
     const long total = (long)Cout * Cin * 9;

@@ -432,6 +432,7 @@ def refresh_transposes():
     """Re-transpose EVERY cached weight in one launch (call once per step, after the optimizer update): ~100 weights would
     otherwise each pay their own launch the first time a data-gradient GEMM touches them."""
     global _wt_table
+    refresh_conv_weights()
     entries = []
     for key, hit in list(_wt_cache.items()):
         W = hit[0]()
@@ -1170,6 +1171,33 @@ _conv_w_cache = {}      # (id(weight), mode) -> (weakref, version tag, relaid-ou
 _use_implicit_conv = os.environ.get("MDVIT_IMPLICIT_CONV", "1") != "0"      # A/B switch: 0 = im2col + GEMM everywhere
 
 
+_conv_w_table = None     # (signature, device int64 table [n,5], blocks per item)
+
+
+def refresh_conv_weights():
+    """Rebuild EVERY cached implicit-convolution weight layout in one launch (called with refresh_transposes at the start of a step):
+    TransFuse holds ~65 dense 3x3 convolutions x two layouts, each of which would otherwise pay its own launch on first use."""
+    global _conv_w_table
+    entries = []
+    for key, hit in list(_conv_w_cache.items()):
+        w = hit[0]()
+        if w is not None and hit[1][2] == w.data_ptr() and key[1] in (0, 1):
+            entries.append((key, w, hit))
+    stale = [e for e in entries if e[2][1] != (e[1]._version, _weights_epoch, e[1].data_ptr())]
+    if not stale:
+        return
+    sig = tuple((w.data_ptr(), h[2].data_ptr(), w.shape[0], w.shape[1], key[1]) for key, w, h in entries)
+    if _conv_w_table is None or _conv_w_table[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            return                            # host-built table: the warm-up steps before a capture build it
+        dev = entries[0][1].device
+        blocks = max((w.shape[0] * w.shape[1] * 9 + 255) // 256 for _, w, _ in entries)
+        _conv_w_table = (sig, torch.tensor([list(r) for r in sig], dtype=torch.int64, device=dev), int(min(blocks, 64)))
+    call("mdvit_conv_weight_relayout_many", _p(_conv_w_table[1]), len(entries), _conv_w_table[2], _stream())
+    for key, w, hit in entries:
+        _conv_w_cache[key] = (hit[0], (w._version, _weights_epoch, w.data_ptr()), hit[2])
+
+
 def _conv_weight(w, mode: int):
     """w [Cout, Cin, 3, 3] in the layout the implicit convolution reads (mdvit_conv_weight_relayout), cached per leaf weight and
     rebuilt when the weight changed (version counter / optimizer epoch)."""
@@ -1871,6 +1899,20 @@ def sweep_stream():
     if _sweep_stream_obj is None:
         _sweep_stream_obj = torch.cuda.Stream()
     return _sweep_stream_obj
+
+
+# One device per process: the autograd engine's hand-off of a sweep to its per-device worker thread buys nothing and costs a thread
+# switch per sweep plus cross-thread stream bookkeeping; the sweeps run on the calling thread (+1-2 % on the bs=4 step).
+_autograd_mt = os.environ.get("MDVIT_AUTOGRAD_MT", "0") != "0"
+
+
+def backward(loss, **kw):
+    """loss.backward(**kw) on the CALLING thread (MDVIT_AUTOGRAD_MT=1: on autograd's worker thread, torch's default)"""
+    if _autograd_mt:
+        loss.backward(**kw)
+    else:
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward(**kw)
 
 
 def one_like(t):

@@ -23,11 +23,6 @@ from .parallel import GradAccumulator, GradBucketReducer
 
 
 _two_stream_sweeps = os.environ.get("MDVIT_SWEEP_STREAMS", "1") != "0"      # A/B switch: 0 = both sweeps on the main stream
-# One device per process: the autograd engine's hand-off of every sweep to its per-device worker thread buys nothing and costs a
-# thread switch per sweep plus cross-thread stream bookkeeping; the sweeps run on the calling thread (+1-2 % on the bs=4 step).
-_autograd_mt = os.environ.get("MDVIT_AUTOGRAD_MT", "0") != "0"
-
-
 _timeline = None      # tools/sweep_timeline.py: a list here collects (tag, event, host seconds) at the sweeps' stream ends
 
 
@@ -40,11 +35,7 @@ def _tl(tag, stream=None):
 
 
 def _backward(loss, **kw):
-    if _autograd_mt:
-        loss.backward(**kw)
-    else:
-        with torch.autograd.set_multithreading_enabled(False):
-            loss.backward(**kw)
+    ops.backward(loss, **kw)
 
 
 def _da_params(model):
@@ -257,7 +248,7 @@ def base_train_step(model, batches: Sequence[tuple], optimizer=None, reducer: Op
             accumulator.begin_sweep(last)
         elif reducer is not None and last:
             reducer.arm()
-        l.backward()
+        _backward(l)
         ops.join_side_stream()
         if accumulator is not None:
             accumulator.end_sweep(last)

@@ -781,7 +781,7 @@ def transfuse_train_step(model, batches: Sequence[tuple], optimizer=None, accumu
         tot = loss if tot is None else tot + loss
     if accumulator is not None:
         accumulator.begin_sweep(True)
-    tot.backward()
+    ops.backward(tot)
     ops.join_side_stream()
     if accumulator is not None:
         accumulator.end_sweep(True)
