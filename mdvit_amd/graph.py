@@ -67,4 +67,7 @@ class GraphedStep:
             s_lab.copy_(b[1], non_blocking=True)
         assert [int(b[2][0]) for b in batches] == self.sids, "the captured step is specialised to its domain order"
         self.graph.replay()
+        # the replay moved the weights (captured optimizer) without touching any host-side tag: the derived-weight caches (W^T,
+        # planes, conv layouts) a later EAGER step or eval would hit are one update behind -- invalidate them
+        ops.mark_weights_updated()
         return self.out

@@ -380,8 +380,9 @@ _use_plane_gemm = os.environ.get("MDVIT_PLANE_GEMM", "1") != "0"      # 0: the s
 # split-while-staging kernel at equal arithmetic (both sit at the same ~30 % of the MFMA roof: the limit is not the split VALU), so
 # the parity mode keeps the calibrated gemm.hip planner and the plane kernels serve the bf16 speed mode (half the operand bytes).
 _plane_min_k = int(os.environ.get("MDVIT_PLANE_MIN_K", "1000000"))
-if os.environ.get("MDVIT_TN_KERNEL", "1") == "0":                       # A/B: weight-gradient GEMMs on the general template instead of gemm_tn.hip
-    _lib.load().mdvit_gemm_tn_config(0, -1, 0)
+_tn_kernel = os.environ.get("MDVIT_TN_KERNEL", "1") != "0"
+if not _tn_kernel:                                                      # A/B: weight-gradient GEMMs on the general template instead of gemm_tn.hip
+    _lib.load().mdvit_gemm_tn_config(0, -1, 0)                          # (the implicit-convolution weight gradient lives in gemm_tn.hip: conv3x3_dense then takes im2col + GEMM)
 _plane_rc = os.environ.get("MDVIT_PLANE_RC", "0") != "0"              # the recomputing fc2 data gradient of the C = 128 MLPs on the plane kernel
 
 
@@ -399,6 +400,20 @@ def _nplanes() -> int:
 
 
 _wt_cache = {}       # id(leaf weight) -> (weakref to it, version, data_ptr, rows, cols, ld, W^T); the weakref guards against id reuse
+
+# The derived-weight caches (W^T, weight planes, implicit-convolution layouts) are filled lazily ON THE STREAM THAT FIRST NEEDS THEM and a
+# later hit -- possibly from another stream -- returns the buffer with no stream ordering.  Every lazy fill therefore raises this flag;
+# whoever runs two sweeps on two streams (train.mdvit_train_step) reads it with take_cache_fill_flag() after enqueueing the first sweep
+# and, when set, orders the second stream after it (a cold step only: the per-step refresh_*() launches on the main stream precede
+# both sweeps and do not raise the flag).
+_cache_filled = False
+
+
+def take_cache_fill_flag() -> bool:
+    """True if a derived-weight cache entry was (re)built lazily since the last call; clears the flag."""
+    global _cache_filled
+    f, _cache_filled = _cache_filled, False
+    return f
 
 
 def wt(W):
@@ -419,6 +434,8 @@ def wt(W):
     if out is None:
         out = torch.empty((K, N), device=W.device, dtype=torch.float32)
     call("mdvit_transpose_f32", _p(W), ld, _p(out), N, K, _stream())
+    global _cache_filled
+    _cache_filled = True
     if leaf:
         key = id(W)
         _wt_cache[key] = (weakref.ref(W, lambda _r, key=key: _wt_cache.pop(key, None)),) + tag + (out,)
@@ -439,6 +456,7 @@ def refresh_transposes():
         if W is not None and hit[2:6] == (W.data_ptr(),) + tuple(hit[3:6]) and W.data_ptr() == hit[2]:
             entries.append((key, W, hit))
     if not entries:
+        refresh_weight_planes()           # plane-only configurations still get their one batched split per step
         return
     sig = tuple((h[2], h[6].data_ptr(), h[5], h[3], h[4]) for _, _, h in entries)       # (in, out, ld, rows, cols)
     if _wt_table is None or _wt_table[0] != sig:
@@ -491,6 +509,8 @@ def _wplanes(W, transposed: bool):
     if buf is None:
         buf = torch.empty((P, rows, cols), device=W.device, dtype=torch.bfloat16)
     call("mdvit_split_planes_t", _p(W), ld, _p(buf), cols, rows * cols, N, K, int(transposed), P, _stream())
+    global _cache_filled
+    _cache_filled = True
     if leaf:
         ent["planes"][transposed] = buf
         ent["tags"][transposed] = tag
@@ -1183,9 +1203,9 @@ def refresh_conv_weights():
         w = hit[0]()
         if w is not None and hit[1][2] == w.data_ptr() and key[1] in (0, 1):
             entries.append((key, w, hit))
-    stale = [e for e in entries if e[2][1] != (e[1]._version, _weights_epoch, e[1].data_ptr())]
-    if not stale:
+    if not entries:
         return
+    # unconditional, like refresh_transposes(): a replayed HIP graph updates the weights without moving any host-side tag
     sig = tuple((w.data_ptr(), h[2].data_ptr(), w.shape[0], w.shape[1], key[1]) for key, w, h in entries)
     if _conv_w_table is None or _conv_w_table[0] != sig:
         if torch.cuda.is_current_stream_capturing():
@@ -1209,6 +1229,8 @@ def _conv_weight(w, mode: int):
         return hit[2]
     out = hit[2] if (hit is not None and hit[0]() is w) else torch.empty(((Cout, 9 * Cin) if mode == 0 else (Cin, 9 * Cout)), device=w.device, dtype=torch.float32)
     call("mdvit_conv_weight_relayout", _p(w), _p(out), Cout, Cin, mode, _stream())
+    global _cache_filled
+    _cache_filled = True
     if w.grad_fn is None:
         _conv_w_cache[key] = (weakref.ref(w, lambda _r, key=key: _conv_w_cache.pop(key, None)), tag, out)
     return out
@@ -1228,8 +1250,10 @@ class _Conv3x3(torch.autograd.Function):
         Cout = w.shape[0]
         Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
         y = _empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-        gemm(_p(x), _p(_conv_weight(w, 0)), _p(y), B * Ho * Wo, Cout, 9 * Cin, lda=9 * Cin, ldb=9 * Cin, ldc=Cout, bias=_p(bias), allow_split=True,
+        wl = _conv_weight(w, 0)         # held until the launch is enqueued (an uncached temporary must not be handed out as the split-K workspace)
+        gemm(_p(x), _p(wl), _p(y), B * Ho * Wo, Cout, 9 * Cin, lda=9 * Cin, ldb=9 * Cin, ldc=Cout, bias=_p(bias), allow_split=True,
              conv=(Cin, H, W_, Ho, Wo, stride, dilation))
+        del wl
         ctx.save_for_backward(x, w)
         ctx.meta = (stride, dilation, bias is not None)
         ctx.bias_ref = bias if (bias is not None and bias.grad_fn is None) else None
@@ -1252,8 +1276,10 @@ class _Conv3x3(torch.autograd.Function):
             if Cout % 32 == 0 and (stride == 1 or dilation == 1):
                 # the same implicit GEMM on dy against the flipped / transposed weight; stride 2 = a transposed convolution: dy read as
                 # if zero-upsampled (conv_up), rows = the INPUT pixels
-                gemm(_p(g), _p(_conv_weight(w, 1)), _p(dx), B * H * W_, Cin, 9 * Cout, lda=9 * Cout, ldb=9 * Cout, ldc=Cin, allow_split=True,
+                wl = _conv_weight(w, 1)
+                gemm(_p(g), _p(wl), _p(dx), B * H * W_, Cin, 9 * Cout, lda=9 * Cout, ldb=9 * Cout, ldc=Cin, allow_split=True,
                      conv=(Cout, Ho, Wo, H, W_, 1, dilation, stride))
+                del wl
             else:                                   # strided: dcol = g W, folded back by col2im
                 dcol = _empty((M, 9 * Cin), device=g.device, dtype=torch.float32)
                 _dgrad(g.view(M, Cout), w, dcol, M, 9 * Cin, Cout, 9 * Cin, allow_split=True)
@@ -1288,7 +1314,7 @@ def conv3x3_dense(x, w, bias=None, stride=1, dilation=1):
     """x NHWC [B,H,W,Cin], w [Cout,Cin,3,3] -> [B,Ho,Wo,Cout]; padding = dilation (dilation > 1 at stride 1 only)."""
     B, H, W_, Cn = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W_ - 1) // stride + 1
-    if _use_implicit_conv and _gemm_precision >= 1 and Cn % 32 == 0 and w.dim() == 4 and w.is_contiguous() and w.shape[0] % 4 == 0:
+    if _use_implicit_conv and _tn_kernel and _gemm_precision >= 1 and Cn % 32 == 0 and w.dim() == 4 and w.is_contiguous() and w.shape[0] % 4 == 0:
         return _Conv3x3.apply(_c(x), w, bias, int(stride), int(dilation))
     col = _Im2col.apply(_c(x), int(stride), int(dilation))
     y = _Linear.apply(col, w if w.is_contiguous() else w.reshape(w.shape[0], -1), bias, None, None, 0.0, 1)

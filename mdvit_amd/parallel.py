@@ -131,6 +131,8 @@ class GradAccumulator:
         # and cut a bucket boundary between the two classes
         early = [p for p in params if id(p) not in late_ids]
         latep = [p for p in params if id(p) in late_ids]
+        if not early:                          # every parameter is "late": nothing can go on the wire early -- one class, no split
+            early, latep = latep, []
         self.reducer = GradBucketReducer(early, bucket_bytes, process_group, average)
         self._n_early = len(self.reducer.buckets)
         if latep:
@@ -202,6 +204,8 @@ class GradAccumulator:
         stream (weight-gradient kernels writing the sinks); async: the main stream goes on"""
         from . import ops as _ops
         side = _ops._side_stream
+        if not self.reducer.buckets:
+            return
         main = torch.cuda.current_stream() if torch.cuda.is_available() and self.reducer.buckets[0].is_cuda else None
         ctx = None
         if side is not None and main is not None:

@@ -109,7 +109,12 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
                 s2 = ops.sweep_stream() if (_two_stream_sweeps and fused_forward and aux_sum.is_cuda) else None
                 if s2 is not None:
                     ops.stream_wait(s2, ops.current_stream_obj())          # recorded BEFORE the full sweep is enqueued
+                ops.take_cache_fill_flag()
                 sweep(aux_sum + uni, False, retain=True, join=False, remaining=(da if last else None))
+                if s2 is not None and ops.take_cache_fill_flag():
+                    # a cold step: the full sweep just (re)built derived-weight cache entries (W^T / planes / conv layouts) on the main
+                    # stream; the aux sweep would hit them by host-side tag with no stream ordering -- order it after the fills
+                    ops.stream_wait(s2, ops.current_stream_obj())
                 ops.set_dgrad_only(True)
                 try:
                     sweep(aux_sum, last, on_stream=s2)

@@ -351,7 +351,7 @@ class _SDPA(torch.autograd.Function):
         a = _empty((B, Cn), device=dev, dtype=torch.float32)
         call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, label.shape[1], W1.shape[0], Cn, heads, _stream())
         out = _empty((B, N, Cn), device=dev, dtype=torch.float32)
-        ctx.mfma = N == 256 and heads <= 6 and _use_mfma_sdpa          # the DeiT trunk's shape: fp32 matrix cores, no [N, N] tensor in HBM
+        ctx.mfma = N == 256 and heads <= 6 and Cn == heads * 64 and _use_mfma_sdpa          # the DeiT trunk's shape: fp32 matrix cores, no [N, N] tensor in HBM
         if ctx.mfma:
             P = _empty((B, heads, N), device=dev, dtype=torch.float32)      # row log-sum-exp
             call("mdvit_sdpa_mfma_fwd", _p(qkv), _p(a), _p(out), _p(P), B, N, Cn, heads, _stream())
