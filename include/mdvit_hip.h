@@ -200,6 +200,29 @@ int mdvit_mlp_bwd_dgrad_f32(const float* gm, const float* x, const float* W1, co
                             float* du /* optional */, float* dx, int32_t M, int32_t C, int32_t hidden, float drop_p,
                             uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
 
+/* ---- MLP whose hidden activation never touches HBM (csrc/mlp_rc.hip; C = 64; replaces Mlp.forward mpvit.py:71-78 inside
+ * SerialBlock_adapt mdvit.py:357-360 and autograd's backward of it) ------------------------------------------------------------------
+ * Weights arrive as the per-step bf16 planes ([2][rows][cols], mdvit_split_planes_many): W1p = planes of W1 [hidden, C], W2p = planes of
+ * W2 [C, hidden], W2tp = planes of W2^T [hidden, C], W1tp = planes of W1^T [C, hidden].  Same bf16x3 arithmetic, k order and dropout keys
+ * as mdvit_mlp_fwd_f32 / mdvit_mlp_bwd_dgrad_f32 (y and dx bit-identical to them); nothing of size [M, hidden] is read or written:
+ *   fwd   : y = res + rowscale * drop2(drop1(gelu(x W1^T + b1)) W2^T + b2)
+ *   dgrad : dx = ((gm W2) * gelu'(x W1^T + b1) * dropmask1) W1                    (gm: the masked upstream gradient, mdvit_colsum_f32)
+ *   wgrad : dW1 (+)= du^T x, db1 (+)= colsum(du), dW2 (+)= gm^T h with u, h, du RECOMPUTED per 32-token tile from x and gm (the operands
+ *           of autograd's two weight-gradient products are never materialised); fixed-order partial sums in ws
+ *           (mdvit_mlp_rc_wgrad_ws_bytes), accumulate != 0 adds into dW1 / db1 / dW2 (gradient buckets).  hidden % 256 == 0.
+ *           (db2 = colsum(gm) comes from mdvit_colsum_f32's `out`.) */
+int mdvit_mlp_rc_fwd(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res,
+                     const float* rowscale /* optional */, int32_t rows_per_scale, float* y, int32_t M, int32_t C, int32_t hidden,
+                     float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
+int mdvit_mlp_rc_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx,
+                       int32_t M, int32_t C, int32_t hidden, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
+size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
+/* tuning hook (tools/mlp_rc_check.py): forward kernel variant -- 2: software-pipelined waves at 2 per SIMD, 3: plain waves at 3 per SIMD */
+int mdvit_mlp_rc_config(int32_t fwd_variant);
+int mdvit_mlp_rc_wgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, float* dW1, float* db1, float* dW2,
+                       void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t hidden, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                       const uint32_t* drop_seed, int32_t accumulate, void* stream);
+
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,
  * linear_out Decoders.py:311).  bwd: dx[m,k] = dy[m] w[k]; dw[k] = sum_m dy[m] x[m,k]; db = sum dy. */
 int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y,

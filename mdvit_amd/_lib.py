@@ -75,6 +75,10 @@ _SIGS = {
     "mdvit_gemm_planes_plan": [C.POINTER(PlaneGemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_planes_force_plan": [i32, i32],
     "mdvit_mlp_config": [i32, i32],
+    "mdvit_mlp_rc_config": [i32],
+    "mdvit_mlp_rc_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
+    "mdvit_mlp_rc_dgrad": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
+    "mdvit_mlp_rc_wgrad": [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_imgconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_imgconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_maxpool3x3s2_fwd": [vp, vp, vp, i32, i32, i32, i32, vp],
@@ -198,6 +202,8 @@ def load():
     lib.mdvit_upsample_bwd_ws_bytes.argtypes = [i32] * 6
     lib.mdvit_partials_ws_bytes.restype = C.c_size_t
     lib.mdvit_partials_ws_bytes.argtypes = [i32]
+    lib.mdvit_mlp_rc_wgrad_ws_bytes.restype = C.c_size_t
+    lib.mdvit_mlp_rc_wgrad_ws_bytes.argtypes = [i32, i32, i32]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t
     lib.mdvit_da_ws_bytes.argtypes = [i32, i32, i32]
     for name, sig in _SIGS.items():

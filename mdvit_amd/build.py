@@ -15,8 +15,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmdvit_hip.so")
-SOURCES = ["abi.hip", "gemm.hip", "gemm_tn.hip", "gemm_bp.hip", "mlp.hip", "norm.hip", "conv.hip", "attn.hip", "loss.hip", "optim.hip", "transfuse.hip", "sdpa.hip"]
+SOURCES = ["abi.hip", "gemm.hip", "gemm_tn.hip", "gemm_bp.hip", "mlp.hip", "mlp_rc.hip", "norm.hip", "conv.hip", "attn.hip", "loss.hip", "optim.hip", "transfuse.hip", "sdpa.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# per-file extras.  -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 adds / muls of an activation into v_pk_* instructions,
+# which next to MFMAs cost ~20 cycles more than the two plain VALU they replace (MI355X_MICROARCH.md, per-instruction constants)
+EXTRA_FLAGS = {"mlp_rc.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -40,10 +43,11 @@ def _compile(src: str) -> str:
     stamp = obj + ".sha"
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_tile.h"), os.path.join(CSRC, "gemm_body.inc"),
             os.path.join(HERE, "..", "include", "mdvit_hip.h")]
-    dig = _digest(deps)
+    extra = EXTRA_FLAGS.get(src, [])
+    dig = _digest(deps) + " ".join(extra)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -1,0 +1,916 @@
+// Fused MLP of the HBM-bound stages whose hidden activation NEVER touches HBM (Mlp.forward mpvit.py:71-78 inside SerialBlock_adapt,
+// mdvit.py:357-360, and its autograd backward):
+//     forward   y  = res + rowscale * drop2( drop1(gelu(x W1^T + b1)) W2^T + b2 )                          x, res in -> y out
+//     dgrad     dx = ((gm W2) * gelu'(x W1^T + b1) * mask1) W1                                             x, gm in  -> dx out
+//     wgrad     dW1 = du^T x, db1 = colsum(du), dW2 = gm^T h   with h, du RECOMPUTED from x, gm            x, gm in  -> dW1, db1, dW2 out
+// Round 2's kernels (mlp.hip) wrote h [tokens, hidden] in the forward and du [tokens, hidden] in the backward for the two weight-gradient
+// GEMMs: 4.3 of the 5.3 GB the MLP of one stage-0 block moves at bs=32.  Here nothing of that size exists: the weight-gradient kernel
+// recomputes u, h and du tile by tile from the [tokens, C] operands.
+//
+// Structure (forward / dgrad): a WAVE owns 32 tokens end to end; the waves of a workgroup share only the weight sub-tiles, which arrive
+// PRE-SPLIT (the per-step bf16 planes of mdvit_split_planes_many) by global_load_lds through three-slot rings with counted vmcnt and a raw
+// s_barrier per 32-wide hidden step -- no conversion work on weights, two steps of prefetch in flight, no ordinary global load inside the
+// loop (biases sit in LDS).  Product 1 runs as D[hidden][token], so a lane holds 16 hidden values of ITS token: after bias / GELU /
+// dropout / hi-lo split, two v_permlane32_swap per operand register pair put them into the natural k order of product 2's operand --
+// the hidden chunk never leaves the register file and the arithmetic is the bf16x3 GEMM's, element for element and k step for k step
+// (y is bit-identical to mdvit_mlp_fwd_f32 / the two-GEMM path).  The loop is software-pipelined across hidden steps: the MFMAs of
+// product 1 (step i+1) and product 2 (step i-1) are issued around the GELU VALU work of step i.
+#include "common.h"
+
+typedef float rc_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 rc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned rc_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned rc_u2 __attribute__((ext_vector_type(2)));
+typedef float rc_f4 __attribute__((ext_vector_type(4)));
+typedef short rc_v4i16 __attribute__((ext_vector_type(4)));
+typedef short rc_v8i16 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) rc_v4i16* rc_lds_v4i16_ptr;
+
+namespace {
+
+// 16-byte-chunk XOR swizzle of a [rows][ROWB bytes] bf16 tile: conflict-free row-per-lane ds_read_b128 (lane groups of MI355X_MICROARCH
+// "LDS") and, for 128-byte rows, at most 2-way ds_read_b64_tr_b16 of 4-row blocks
+template <int ROWB>
+__device__ __forceinline__ int rc_swz(int row) {
+    if (ROWB == 64) return (row >> 2) & 3;
+    if (ROWB == 128) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    return row & 15;
+}
+
+// one 1 KiB piece of a [rows][ROWB] plane: HBM/L2 -> LDS by global_load_lds (the LDS side is wave-uniform base + lane * 16: the swizzle goes
+// on the SOURCE address).  src: bf16 plane, element (row, k) at src[row * ld + k].
+template <int ROWB>
+__device__ __forceinline__ void rc_glds_piece(const uint16_t* __restrict__ src, long ld, int piece, int lane, char* tile) {
+    constexpr int LPR = ROWB / 16, RPP = 1024 / ROWB;          // lanes per row, rows per piece
+    const int row = piece * RPP + lane / LPR;
+    const int lc = (lane % LPR) ^ rc_swz<ROWB>(row);
+    __builtin_amdgcn_global_load_lds(src + (long)row * ld + (lc << 3), (__attribute__((address_space(3))) void*)(tile + piece * 1024), 16, 0, 0);
+}
+
+// MFMA operand fragment of a lane: 8 consecutive k (one 16-byte chunk) of `row`
+template <int ROWB>
+__device__ __forceinline__ rc_bf16x8 rc_frag(const char* tile, int row, int chunk) {
+    return __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(tile + row * ROWB + ((chunk ^ rc_swz<ROWB>(row)) << 4)));
+}
+
+#define RC_MFMA3(acc, ah, al, bh, bl)                                           \
+    do {                                                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);    \
+    } while (0)
+// D[i][j] += sum_k A[i][k] B[k][j]: A-fragment lane (i = l & 31, k = 8 (l >> 5) ..+7), B-fragment lane (j = l & 31, same k); D: lane j,
+// registers i = (r & 3) + 8 (r >> 2) + 4 (l >> 5).  Order lo*hi, hi*lo, hi*hi with the WEIGHT as the lo factor first: gemm_body.inc's.
+
+// fp32 x8 -> hi / lo bf16 x8 (registers 0..3 <-> first quad, 4..7 <-> second quad)
+__device__ __forceinline__ void rc_split8(const float* v, rc_u4& hi, rc_u4& lo) {
+    uint2 h0, l0, h1, l1;
+    mdvit_split_bf16x3(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+    mdvit_split_bf16x3(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+    hi = rc_u4{h0.x, h0.y, h1.x, h1.y};
+    lo = rc_u4{l0.x, l0.y, l1.x, l1.y};
+}
+
+// A lane of product 1's accumulator holds, for the 16-wide hidden block b, the values k = 4 lhi + j (quad 2b) and k = 8 + 4 lhi + j (quad 2b + 1).
+// The natural operand order wants k = 8 lhi .. 8 lhi + 7 in one lane: lanes l < 32 hand their second quad to l + 32 and take its first.
+__device__ __forceinline__ rc_bf16x8 rc_natural_order(rc_u4 v) {
+    const rc_u2 a = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+    const rc_u2 b = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+    return __builtin_bit_cast(rc_bf16x8, (rc_u4{a[0], b[0], a[1], b[1]}));
+}
+
+// the x / gm operand fragments of a wave's 32 tokens (rows past M re-read the last row: they only feed outputs that are never stored)
+template <int C>
+__device__ __forceinline__ void rc_load_rows(const float* __restrict__ src, int row, int M, int lhi, rc_bf16x8 (&hi)[C / 16], rc_bf16x8 (&lo)[C / 16]) {
+    const float* p = src + (long)min(row, M - 1) * C + 8 * lhi;
+    float4 a[C / 16], b[C / 16];
+#pragma unroll
+    for (int kb = 0; kb < C / 16; ++kb) {
+        a[kb] = *reinterpret_cast<const float4*>(p + 16 * kb);
+        b[kb] = *reinterpret_cast<const float4*>(p + 16 * kb + 4);
+    }
+#pragma unroll
+    for (int kb = 0; kb < C / 16; ++kb) {
+        const float v[8] = {a[kb].x, a[kb].y, a[kb].z, a[kb].w, b[kb].x, b[kb].y, b[kb].z, b[kb].w};
+        rc_u4 h, l;
+        rc_split8(v, h, l);
+        hi[kb] = __builtin_bit_cast(rc_bf16x8, h);
+        lo[kb] = __builtin_bit_cast(rc_bf16x8, l);
+    }
+}
+
+struct RcArgs {
+    const float* x; const float* gm; const float* res; const float* rowscale; const float* b1; const float* b2;
+    const uint16_t* W1p;    // planes of W1   [2][Hd][C]   rows = hidden, k = c         u = x W1^T
+    const uint16_t* W2p;    // planes of W2   [2][C][Hd]   rows = c_out,  k = hidden    y = h W2^T
+    const uint16_t* W2tp;   // planes of W2^T [2][Hd][C]   rows = hidden, k = c         d = gm W2
+    const uint16_t* W1tp;   // planes of W1^T [2][C][Hd]   rows = c,      k = hidden    dx = du W1
+    float* y; float* dx;
+    float* part;            // wgrad: per-workgroup partial sums
+    int M, Hd, rows_per_scale;
+    int drop; uint32_t k1a, k1b, k2a, k2b, thresh; float inv_keep;
+    const uint32_t* seed;
+    int groups, tiles_per_group;       // wgrad: token groups, 32-token tiles per group
+};
+
+// Scheduling request for a straight-line loop body of NM MFMAs, ND LDS reads and the VALU work of an activation: LEAD reads first, then
+// 1 MFMA : V VALU : 1 read -- the operand reads run LEAD MFMAs ahead of their consumers (hipcc otherwise puts each ds_read + s_waitcnt right in
+// front of its MFMA: ~100 exposed cycles per read on an in-order wave) and the activation's VALU issues underneath the matrix pipe.
+template <int NM, int V, int ND, int LEAD>
+__device__ __forceinline__ void rc_interleave() {
+    __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+        if (i < ND - LEAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+}
+
+#define RC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int C, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rc_fwd_kernel(RcArgs p) {
+    constexpr int KB = C / 16, CB = C / 32;
+    constexpr int RB1 = C * 2;                       // row bytes of a W1 sub-tile [32 hidden][C]
+    constexpr int T1 = 32 * RB1, T2 = C * 64;        // bytes of one plane of W1 sub [32][C] and W2 sub [C][32 hidden]
+    constexpr int PIECES = (2 * T1 + 2 * T2) / 1024; // per hidden step: W1 hi, lo, W2 hi, lo
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* sW1 = smem;                                // [3 slots][2 planes][T1]
+    char* sW2 = sW1 + 3 * 2 * T1;                    // [3 slots][2 planes][T2]
+    float* sB1 = reinterpret_cast<float*>(sW2 + 3 * 2 * T2);      // [Hd]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
+    const int row = blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const int n = p.Hd >> 5;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1, k2a = p.k2a ^ s0, k2b = p.k2b + s1;
+    const long wplane = (long)p.Hd * C;
+
+    // piece pc of W1 sub-tile `src_s` -> ring slot `slot_s` % 3 (src_s != slot_s only for the clamped dummy fetches past the last step)
+    auto issue_w1 = [&](int slot_s, int src_s, int pc) __attribute__((always_inline)) {
+        constexpr int PP = T1 / 1024;
+        const int pl = pc / PP, q = pc % PP;
+        rc_glds_piece<RB1>(p.W1p + pl * wplane + (long)(src_s * 32) * C, C, q, lane, sW1 + ((slot_s % 3) * 2 + pl) * T1);
+    };
+    auto issue_w2 = [&](int s, int pc) __attribute__((always_inline)) {
+        constexpr int PP = T2 / 1024;
+        const int pl = pc / PP, q = pc % PP;
+        rc_glds_piece<64>(p.W2p + pl * wplane + s * 32, p.Hd, q, lane, sW2 + ((s % 3) * 2 + pl) * T2);
+    };
+    // group g = {W1 sub (g + 2), W2 sub g}: PPW glds per wave, always (past the end the W1 part re-fetches the last sub-tile into the free slot,
+    // so that the counted waits below see the same number of loads per group)
+    auto issue_group = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + i * NW;            // uniform per wave
+            if (pc < 2 * T1 / 1024) issue_w1(g + 2, min(g + 2, n - 1), pc);
+            else issue_w2(g, pc - 2 * T1 / 1024);
+        }
+    };
+
+    // prologue: W1 sub 0, 1 (same piece split as a group), group 0, biases to LDS, x fragments
+#pragma unroll
+    for (int i = 0; i < 2 * T1 / 1024 / NW + (2 * T1 / 1024 % NW != 0); ++i) {
+        const int pc = wave + i * NW;
+        if (pc < 2 * T1 / 1024) { issue_w1(0, 0, pc); issue_w1(1, 1, pc); }
+    }
+    issue_group(0);
+    for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    rc_bf16x8 xh[KB], xl[KB];
+    rc_load_rows<C>(p.x, row, p.M, lhi, xh, xl);
+    rc_f32x16 yacc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[cb][r] = 0.f;
+    RC_WAIT_VM(0);
+    __syncthreads();
+
+    auto prod1 = [&](int s, rc_f32x16& u) __attribute__((always_inline)) {
+        const char* hi = sW1 + ((s % 3) * 2) * T1; const char* lo = hi + T1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const rc_bf16x8 ah = rc_frag<RB1>(hi, l31, 2 * kb + lhi), al = rc_frag<RB1>(lo, l31, 2 * kb + lhi);
+            RC_MFMA3(u, ah, al, xh[kb], xl[kb]);
+        }
+    };
+    auto prod2 = [&](int s, const rc_bf16x8 (&hh)[2], const rc_bf16x8 (&hl)[2]) __attribute__((always_inline)) {
+        const char* hi = sW2 + ((s % 3) * 2) * T2; const char* lo = hi + T2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const rc_bf16x8 ah = rc_frag<64>(hi, cb * 32 + l31, 2 * half + lhi), al = rc_frag<64>(lo, cb * 32 + l31, 2 * half + lhi);
+                RC_MFMA3(yacc[cb], ah, al, hh[half], hl[half]);
+            }
+    };
+    auto act = [&](int s, const rc_f32x16& u, rc_bf16x8 (&hh)[2], rc_bf16x8 (&hl)[2]) __attribute__((always_inline)) {
+        float hv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int hd = s * 32 + 8 * q + 4 * lhi;
+            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + hd);          // (ext_vector load: a HIP float4 LDS read makes hipcc drain the glds ring)
+            float4 v = make_float4(gelu_f(u[4 * q + 0] + b4.x), gelu_f(u[4 * q + 1] + b4.y), gelu_f(u[4 * q + 2] + b4.z), gelu_f(u[4 * q + 3] + b4.w));
+            if (DROP) {
+                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            hv[4 * q + 0] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            rc_u4 h, l;
+            rc_split8(hv + 8 * half, h, l);
+            hh[half] = rc_natural_order(h);
+            hl[half] = rc_natural_order(l);
+        }
+    };
+
+    // Ring discipline.  Phase t runs product 1 of step t + 1 (reads W1 sub t + 1), product 2 of step t - 1 (reads W2 sub t - 1) and the
+    // activation of step t.  Group g = {W1 sub g + 2, W2 sub g} goes into the slots phase g - 2 read last, so it is issued at the top of
+    // phase g - 1, behind that phase's barrier; phase t needs group t - 1, the older of the two groups then in flight: vmcnt(PPW).
+    rc_f32x16 ucur, unext;
+    rc_bf16x8 hh[2], hl[2], gh[2], gl[2];
+    prod1(0, ucur);
+    {   // phase 0
+        __builtin_amdgcn_s_barrier();
+        issue_group(1);
+        prod1(1, unext);
+        act(0, ucur, hh, hl);
+        ucur = unext;
+    }
+    for (int t = 1; t + 1 < n; ++t) {
+        RC_WAIT_VM(PPW);
+        __builtin_amdgcn_s_barrier();
+        issue_group(t + 1);
+        prod1(t + 1, unext);
+        prod2(t - 1, hh, hl);
+        act(t, ucur, gh, gl);
+        rc_interleave<3 * KB + 6 * CB, DROP ? 17 : 14, 2 * KB + 4 * CB + 4, 8>();
+        ucur = unext;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) { hh[h2] = gh[h2]; hl[h2] = gl[h2]; }
+    }
+    {   // phase n - 1
+        RC_WAIT_VM(PPW);
+        __builtin_amdgcn_s_barrier();
+        prod2(n - 2, hh, hl);
+        act(n - 1, ucur, hh, hl);
+    }
+    RC_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    prod2(n - 1, hh, hl);
+
+    // epilogue: + b2, dropout, DropPath scale, + residual (operands requested together)
+    {
+        const int rowc = min(row, p.M - 1);
+        float4 b2q[CB][4], rq[CB][4];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = cb * 32 + 8 * q + 4 * lhi;
+                b2q[cb][q] = *reinterpret_cast<const float4*>(p.b2 + col);
+                rq[cb][q] = *reinterpret_cast<const float4*>(p.res + (long)rowc * C + col);
+            }
+        const float rsc = p.rowscale ? p.rowscale[rowc / p.rows_per_scale] : 1.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = cb * 32 + 8 * q + 4 * lhi;
+                const float4 b4 = b2q[cb][q];
+                float4 v = make_float4(yacc[cb][4 * q + 0] + b4.x, yacc[cb][4 * q + 1] + b4.y, yacc[cb][4 * q + 2] + b4.z, yacc[cb][4 * q + 3] + b4.w);
+                if (DROP) {
+                    const float4 ds = mdvit_drop_scale4(k2a, k2b, (uint32_t)((long)row * C + col), p.thresh, p.inv_keep);
+                    v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+                }
+                v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+                const float4 r4 = rq[cb][q];
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                if (row < p.M) *reinterpret_cast<float4*>(p.y + (long)row * C + col) = v;
+            }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// forward, high-occupancy variant: no software pipelining inside the wave (one u accumulator, ~150 VGPRs -> 3 waves per SIMD, 3 workgroups
+// per CU); the overlap of one wave's MFMAs with another's activation VALU comes from the third wave instead.  Group g = {W1 sub g, W2 sub g},
+// issued two steps ahead into a three-slot ring.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int C, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_rc_fwd3_kernel(RcArgs p) {
+    constexpr int KB = C / 16, CB = C / 32;
+    constexpr int RB1 = C * 2;
+    constexpr int T1 = 32 * RB1, T2 = C * 64;
+    constexpr int PIECES = (2 * T1 + 2 * T2) / 1024;
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* sW1 = smem;
+    char* sW2 = sW1 + 3 * 2 * T1;
+    float* sB1 = reinterpret_cast<float*>(sW2 + 3 * 2 * T2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
+    const int row = blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const int n = p.Hd >> 5;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1, k2a = p.k2a ^ s0, k2b = p.k2b + s1;
+    const long wplane = (long)p.Hd * C;
+    auto issue_group = [&](int g) __attribute__((always_inline)) {
+        const int gs = min(g, n - 1), slot = g % 3;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + i * NW;
+            if (pc < 2 * T1 / 1024) {
+                constexpr int PP = T1 / 1024;
+                const int pl = pc / PP, q = pc % PP;
+                rc_glds_piece<RB1>(p.W1p + pl * wplane + (long)(gs * 32) * C, C, q, lane, sW1 + (slot * 2 + pl) * T1);
+            } else {
+                constexpr int PP = T2 / 1024;
+                const int pc2 = pc - 2 * T1 / 1024, pl = pc2 / PP, q = pc2 % PP;
+                rc_glds_piece<64>(p.W2p + pl * wplane + gs * 32, p.Hd, q, lane, sW2 + (slot * 2 + pl) * T2);
+            }
+        }
+    };
+    issue_group(0);
+    issue_group(1);
+    for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    rc_bf16x8 xh[KB], xl[KB];
+    rc_load_rows<C>(p.x, row, p.M, lhi, xh, xl);
+    rc_f32x16 yacc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[cb][r] = 0.f;
+    __syncthreads();                                   // sB1 visible (the group waits below cover the weight tiles)
+
+    for (int t = 0; t < n; ++t) {
+        RC_WAIT_VM(PPW);                               // group t landed (group t + 1 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        issue_group(t + 2);                            // into the slot step t - 1 read
+        const int slot = t % 3;
+        const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
+        const char* w2h = sW2 + (slot * 2) * T2; const char* w2l = w2h + T2;
+        // u = bias + x W1s^T as D[hidden][token]: the accumulator starts from the bias quads
+        rc_f32x16 u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + t * 32 + 8 * q + 4 * lhi);
+            u[4 * q + 0] = b4.x; u[4 * q + 1] = b4.y; u[4 * q + 2] = b4.z; u[4 * q + 3] = b4.w;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const rc_bf16x8 ah = rc_frag<RB1>(w1h, l31, 2 * kb + lhi), al = rc_frag<RB1>(w1l, l31, 2 * kb + lhi);
+            RC_MFMA3(u, ah, al, xh[kb], xl[kb]);
+        }
+        float hv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(gelu_f(u[4 * q + 0]), gelu_f(u[4 * q + 1]), gelu_f(u[4 * q + 2]), gelu_f(u[4 * q + 3]));
+            if (DROP) {
+                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + t * 32 + 8 * q + 4 * lhi), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            hv[4 * q + 0] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            rc_u4 h, l;
+            rc_split8(hv + 8 * half, h, l);
+            const rc_bf16x8 hh = rc_natural_order(h), hl = rc_natural_order(l);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const rc_bf16x8 ah = rc_frag<64>(w2h, cb * 32 + l31, 2 * half + lhi), al = rc_frag<64>(w2l, cb * 32 + l31, 2 * half + lhi);
+                RC_MFMA3(yacc[cb], ah, al, hh, hl);
+            }
+        }
+    }
+    RC_WAIT_VM(0);                                     // the clamped dummy fetches of the last two steps
+
+    {
+        const int rowc = min(row, p.M - 1);
+        float4 b2q[CB][4], rq[CB][4];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = cb * 32 + 8 * q + 4 * lhi;
+                b2q[cb][q] = *reinterpret_cast<const float4*>(p.b2 + col);
+                rq[cb][q] = *reinterpret_cast<const float4*>(p.res + (long)rowc * C + col);
+            }
+        const float rsc = p.rowscale ? p.rowscale[rowc / p.rows_per_scale] : 1.f;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = cb * 32 + 8 * q + 4 * lhi;
+                const float4 b4 = b2q[cb][q];
+                float4 v = make_float4(yacc[cb][4 * q + 0] + b4.x, yacc[cb][4 * q + 1] + b4.y, yacc[cb][4 * q + 2] + b4.z, yacc[cb][4 * q + 3] + b4.w);
+                if (DROP) {
+                    const float4 ds = mdvit_drop_scale4(k2a, k2b, (uint32_t)((long)row * C + col), p.thresh, p.inv_keep);
+                    v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+                }
+                v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+                const float4 r4 = rq[cb][q];
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                if (row < p.M) *reinterpret_cast<float4*>(p.y + (long)row * C + col) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// backward, data path:  dx = ((gm W2) * gelu'(x W1^T + b1) * mask1) W1      (gm = the masked upstream gradient, mdvit_colsum_f32)
+// Same structure; per hidden step u = x W1s^T and d = gm W2s as D[hidden][token], du = d * gelu'(u + b1) * mask in registers,
+// dx^T += W1s^T-tile * du (the chained operand).  Rings: W1 sub, W2^T sub (needed one step ahead), W1^T sub (one step behind).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int C, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rc_dgrad_kernel(RcArgs p) {
+    constexpr int KB = C / 16, CB = C / 32;
+    constexpr int RB1 = C * 2;
+    constexpr int T1 = 32 * RB1, T3 = C * 64;        // one plane of W1 sub / W2^T sub [32][C], of W1^T sub [C][32 hidden]
+    constexpr int PIECES = (4 * T1 + 2 * T3) / 1024;
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* sW1 = smem;                                // [3][2][T1]
+    char* sW2t = sW1 + 3 * 2 * T1;                   // [3][2][T1]
+    char* sW1t = sW2t + 3 * 2 * T1;                  // [3][2][T3]
+    float* sB1 = reinterpret_cast<float*>(sW1t + 3 * 2 * T3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
+    const int row = blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const int n = p.Hd >> 5;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1;
+    const long wplane = (long)p.Hd * C;
+
+    auto issue_a = [&](int slot_s, int src_s, int pc) __attribute__((always_inline)) {       // pc in [0, 4 T1 / 1024): W1 hi, lo, W2^T hi, lo
+        constexpr int PP = T1 / 1024;
+        const int t = pc / PP, q = pc % PP, pl = t & 1;
+        const uint16_t* src = (t < 2 ? p.W1p : p.W2tp) + pl * wplane + (long)(src_s * 32) * C;
+        rc_glds_piece<RB1>(src, C, q, lane, (t < 2 ? sW1 : sW2t) + ((slot_s % 3) * 2 + pl) * T1);
+    };
+    auto issue_b = [&](int s, int pc) __attribute__((always_inline)) {
+        constexpr int PP = T3 / 1024;
+        const int pl = pc / PP, q = pc % PP;
+        rc_glds_piece<64>(p.W1tp + pl * wplane + s * 32, p.Hd, q, lane, sW1t + ((s % 3) * 2 + pl) * T3);
+    };
+    auto issue_group = [&](int g) __attribute__((always_inline)) {          // {W1 / W2^T sub (g + 2), W1^T sub g}
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + i * NW;
+            if (pc < 4 * T1 / 1024) issue_a(g + 2, min(g + 2, n - 1), pc);
+            else issue_b(g, pc - 4 * T1 / 1024);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < (4 * T1 / 1024 + NW - 1) / NW; ++i) {
+        const int pc = wave + i * NW;
+        if (pc < 4 * T1 / 1024) { issue_a(0, 0, pc); issue_a(1, 1, pc); }
+    }
+    issue_group(0);
+    for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    rc_bf16x8 xh[KB], xl[KB], gh[KB], gl[KB];
+    rc_load_rows<C>(p.x, row, p.M, lhi, xh, xl);
+    rc_load_rows<C>(p.gm, row, p.M, lhi, gh, gl);
+    rc_f32x16 dxacc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxacc[cb][r] = 0.f;
+    RC_WAIT_VM(0);
+    __syncthreads();
+
+    auto prod1 = [&](int s, rc_f32x16& u, rc_f32x16& d) __attribute__((always_inline)) {
+        const char* w1h = sW1 + ((s % 3) * 2) * T1; const char* w1l = w1h + T1;
+        const char* w2h = sW2t + ((s % 3) * 2) * T1; const char* w2l = w2h + T1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { u[r] = 0.f; d[r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const rc_bf16x8 ah = rc_frag<RB1>(w1h, l31, 2 * kb + lhi), al = rc_frag<RB1>(w1l, l31, 2 * kb + lhi);
+            RC_MFMA3(u, ah, al, xh[kb], xl[kb]);
+            const rc_bf16x8 ch = rc_frag<RB1>(w2h, l31, 2 * kb + lhi), cl = rc_frag<RB1>(w2l, l31, 2 * kb + lhi);
+            RC_MFMA3(d, ch, cl, gh[kb], gl[kb]);
+        }
+    };
+    auto prod3 = [&](int s, const rc_bf16x8 (&dh)[2], const rc_bf16x8 (&dl)[2]) __attribute__((always_inline)) {
+        const char* hi = sW1t + ((s % 3) * 2) * T3; const char* lo = hi + T3;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const rc_bf16x8 ah = rc_frag<64>(hi, cb * 32 + l31, 2 * half + lhi), al = rc_frag<64>(lo, cb * 32 + l31, 2 * half + lhi);
+                RC_MFMA3(dxacc[cb], ah, al, dh[half], dl[half]);
+            }
+    };
+    auto act = [&](int s, const rc_f32x16& u, const rc_f32x16& d, rc_bf16x8 (&dh)[2], rc_bf16x8 (&dl)[2]) __attribute__((always_inline)) {
+        float dv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int hd = s * 32 + 8 * q + 4 * lhi;
+            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + hd);
+            float4 v = make_float4(d[4 * q + 0] * gelu_grad_f(u[4 * q + 0] + b4.x), d[4 * q + 1] * gelu_grad_f(u[4 * q + 1] + b4.y),
+                                   d[4 * q + 2] * gelu_grad_f(u[4 * q + 2] + b4.z), d[4 * q + 3] * gelu_grad_f(u[4 * q + 3] + b4.w));
+            if (DROP) {
+                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            dv[4 * q + 0] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            rc_u4 h, l;
+            rc_split8(dv + 8 * half, h, l);
+            dh[half] = rc_natural_order(h);
+            dl[half] = rc_natural_order(l);
+        }
+    };
+
+    rc_f32x16 ucur, dcur, unext, dnext;
+    rc_bf16x8 dh[2], dl[2], eh[2], el[2];
+    prod1(0, ucur, dcur);
+    {
+        __builtin_amdgcn_s_barrier();
+        issue_group(1);
+        prod1(1, unext, dnext);
+        act(0, ucur, dcur, dh, dl);
+        ucur = unext; dcur = dnext;
+    }
+    for (int t = 1; t + 1 < n; ++t) {
+        RC_WAIT_VM(PPW);
+        __builtin_amdgcn_s_barrier();
+        issue_group(t + 1);
+        prod1(t + 1, unext, dnext);
+        prod3(t - 1, dh, dl);
+        act(t, ucur, dcur, eh, el);
+        rc_interleave<6 * KB + 6 * CB, DROP ? 12 : 10, 4 * KB + 4 * CB + 4, 8>();
+        ucur = unext; dcur = dnext;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) { dh[h2] = eh[h2]; dl[h2] = el[h2]; }
+    }
+    {
+        RC_WAIT_VM(PPW);
+        __builtin_amdgcn_s_barrier();
+        prod3(n - 2, dh, dl);
+        act(n - 1, ucur, dcur, dh, dl);
+    }
+    RC_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    prod3(n - 1, dh, dl);
+
+    if (row < p.M) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = cb * 32 + 8 * q + 4 * lhi;
+                *reinterpret_cast<float4*>(p.dx + (long)row * C + col) = make_float4(dxacc[cb][4 * q + 0], dxacc[cb][4 * q + 1], dxacc[cb][4 * q + 2], dxacc[cb][4 * q + 3]);
+            }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// backward, parameter path:  dW1 = du^T x,  db1 = colsum(du),  dW2 = gm^T h   with  u = x W1^T + b1,  h = gelu(u) mask1,
+// du = (gm W2) gelu'(u) mask1  recomputed per 32-token tile -- the [tokens, hidden] operands of the two weight-gradient GEMMs never exist.
+// A workgroup (8 waves) owns a 256-wide hidden range ("role") and a range of token tiles; wave w owns the 32 hidden units 32 w .. +31 of
+// the role: its W1 / W2^T rows stay in REGISTERS as MFMA B-fragments for the whole kernel, its 32x64 blocks of dW1 and dW2 stay in the
+// accumulators.  Per token tile the workgroup stages x and gm once (fp32 -> hi / lo planes in LDS, double buffered); a wave computes
+// u, d as D[token][hidden] (lane <-> hidden), so h^T / du^T are already the k = token operand of the weight-gradient products, and reads
+// the other operand -- x, gm with k = token -- transposed out of the SAME LDS image with ds_read_b64_tr_b16.  Partial sums per workgroup
+// go to `part`, added in a fixed order by rc_reduce_kernel (deterministic).  Workgroups of one token range (all roles) sit on one XCD
+// at adjacent dispatch slots: the second role reads x / gm out of that XCD's L2.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define RC_MFMA3_ACT_A(acc, ah, al, bh, bl)                                     \
+    do {                                                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);    \
+    } while (0)
+
+// every lane of a quad reads lane `src` of its quad (DPP quad_perm broadcast; src is a constant after unrolling)
+__device__ __forceinline__ uint32_t rc_quad_bcast(uint32_t v, int src) {
+    switch (src) {
+        case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, false);
+        case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, false);
+        case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, false);
+        default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, false);
+    }
+}
+
+// 8 k (= tokens t0 .. t0+3 and t0+8 .. t0+11) of column `col` out of a [32 tokens][128-byte rows] plane: two transposing reads
+__device__ __forceinline__ rc_bf16x8 rc_tr8(const char* plane, int t0, int col0, int l15) {
+    // lane i of a 16-lane group hands in piece i = (token t0 + (i >> 2), columns col0 + 4 (i & 3) ..+3) and receives column col0 + i
+    const int r0 = t0 + (l15 >> 2), r1 = r0 + 8, c = col0 + 4 * (l15 & 3);
+    const int o0 = r0 * 128 + (((c >> 3) ^ rc_swz<128>(r0)) << 4) + (c & 4) * 2;
+    const int o1 = r1 * 128 + (((c >> 3) ^ rc_swz<128>(r1)) << 4) + (c & 4) * 2;
+    const rc_v4i16 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(plane + o0));
+    const rc_v4i16 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(plane + o1));
+    const rc_v8i16 r = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    return __builtin_bit_cast(rc_bf16x8, r);
+}
+
+template <int C, bool DROP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rc_wgrad_kernel(RcArgs p) {
+    constexpr int KB = C / 16, CB = C / 32;
+    constexpr int TP = 32 * 128;                     // one plane of a [32 tokens][64 c] tile (C = 64: 128-byte rows)
+    static_assert(C == 64, "token-tile staging below is written for C = 64");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * TP];      // [2 buffers][x hi, x lo, gm hi, gm lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15;
+    const int roles = p.Hd >> 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int role = idx % roles, group = (idx / roles) * 8 + xcd;
+    const int hs = role * 256 + wave * 32;           // this wave's hidden units hs .. hs + 31; lane <-> hs + l31
+    const int ntiles = (p.M + 31) >> 5;
+    const int t_beg = min(group * p.tiles_per_group, ntiles), t_end = min(t_beg + p.tiles_per_group, ntiles);
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1;
+    const long wplane = (long)p.Hd * C;
+
+    // resident B-fragments: W1[hid][c] and W2^T[hid][c] rows of this lane's hidden unit
+    rc_bf16x8 w1h[KB], w1l[KB], w2h[KB], w2l[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const long o = (long)(hs + l31) * C + 16 * kb + 8 * lhi;
+        w1h[kb] = __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(p.W1p + o));
+        w1l[kb] = __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(p.W1p + wplane + o));
+        w2h[kb] = __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(p.W2tp + o));
+        w2l[kb] = __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(p.W2tp + wplane + o));
+    }
+    const float bias = p.b1[hs + l31];
+    rc_f32x16 aw1[CB], aw2[CB];                       // dW1[hid rows][c lanes], dW2[c rows][hid lanes]
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aw1[cb][r] = 0.f; aw2[cb][r] = 0.f; }
+    float db1 = 0.f;
+
+    // staging map: thread -> (token row tid >> 4, float4 column tid & 15)
+    const int srow = tid >> 4, sc4 = tid & 15;
+    const int soff = srow * 128 + (((sc4 >> 1) ^ rc_swz<128>(srow)) << 4) + (sc4 & 1) * 8;
+    float4 rx, rg;
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        const int row = t * 32 + srow, rc = min(row, p.M - 1);
+        rx = *reinterpret_cast<const float4*>(p.x + (long)rc * C + sc4 * 4);
+        rg = *reinterpret_cast<const float4*>(p.gm + (long)rc * C + sc4 * 4);
+        if (row >= p.M) rg = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end contribute nothing
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        char* b = smem + buf * 4 * TP;
+        uint2 hi, lo;
+        mdvit_split_bf16x3(rx, hi, lo);
+        *reinterpret_cast<rc_u2*>(b + soff) = rc_u2{hi.x, hi.y};
+        *reinterpret_cast<rc_u2*>(b + TP + soff) = rc_u2{lo.x, lo.y};
+        mdvit_split_bf16x3(rg, hi, lo);
+        *reinterpret_cast<rc_u2*>(b + 2 * TP + soff) = rc_u2{hi.x, hi.y};
+        *reinterpret_cast<rc_u2*>(b + 3 * TP + soff) = rc_u2{lo.x, lo.y};
+    };
+
+    if (t_beg < t_end) {
+        load_tile(t_beg);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        const char* xb = smem + buf * 4 * TP;
+        const char* xhi = xb; const char* xlo = xb + TP; const char* ghi = xb + 2 * TP; const char* glo = xb + 3 * TP;
+        if (t + 1 < t_end) load_tile(t + 1);
+        // u, d as D[token][hidden]
+        rc_f32x16 u, d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { u[r] = 0.f; d[r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const rc_bf16x8 ah = rc_frag<128>(xhi, l31, 2 * kb + lhi), al = rc_frag<128>(xlo, l31, 2 * kb + lhi);
+            RC_MFMA3_ACT_A(u, ah, al, w1h[kb], w1l[kb]);
+            const rc_bf16x8 ch = rc_frag<128>(ghi, l31, 2 * kb + lhi), cl = rc_frag<128>(glo, l31, 2 * kb + lhi);
+            RC_MFMA3_ACT_A(d, ch, cl, w2h[kb], w2l[kb]);
+        }
+        // per 16-token half: h, du in registers (lane <-> hidden unit, register r <-> token (r & 3) + 8 (r >> 2) + 4 lhi), then the
+        // weight-gradient products over k = those 16 tokens in the order the registers hold them
+        // dropout bits: the mask index of (token, hidden) is token * Hd + hidden and ONE hash serves the four hidden units of an aligned
+        // group -- here four adjacent lanes.  Lane c = l & 3 of a quad hashes the tokens of registers 4c .. 4c+3; every register then takes
+        // its word from lane r >> 2 of the quad (DPP quad broadcast) and rotates out the byte lane of its own hidden unit.
+        uint32_t hb[4];
+        if (DROP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tok = t * 32 + j + 8 * (lane & 3) + 4 * lhi;
+                hb[j] = mdvit_drop_bits(k1a, k1b, (uint32_t)((long)tok * p.Hd + hs + l31));
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float hv[8], dv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 8 * ks + i;
+                const float uu = u[r] + bias;
+                float cdf, pdf;
+                gelu_parts(uu, cdf, pdf);
+                float hval = uu * cdf, g = d[r] * fmaf(uu, pdf, cdf);
+                if (DROP) {
+                    const uint32_t w = rc_quad_bcast(hb[r & 3], r >> 2);
+                    const float ds = __builtin_rotateright32(w, 8u * (lane & 3)) >= p.thresh ? p.inv_keep : 0.0f;
+                    hval *= ds; g *= ds;
+                }
+                hv[i] = hval; dv[i] = g;
+                db1 += g;
+            }
+            rc_u4 hh, hl, dh, dl;
+            rc_split8(hv, hh, hl);
+            rc_split8(dv, dh, dl);
+            const rc_bf16x8 hhf = __builtin_bit_cast(rc_bf16x8, hh), hlf = __builtin_bit_cast(rc_bf16x8, hl);
+            const rc_bf16x8 dhf = __builtin_bit_cast(rc_bf16x8, dh), dlf = __builtin_bit_cast(rc_bf16x8, dl);
+            const int t0 = 16 * ks + 4 * lhi;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int col0 = cb * 32 + 16 * ((lane >> 4) & 1);
+                // dW1[hid][c] += du^T x : A = du^T (registers), B = x[k = token][c] (transposing read)
+                const rc_bf16x8 bxh = rc_tr8(xhi, t0, col0, l15), bxl = rc_tr8(xlo, t0, col0, l15);
+                RC_MFMA3_ACT_A(aw1[cb], dhf, dlf, bxh, bxl);
+                // dW2[c][hid] += gm^T h : A = gm^T[c][k = token] (transposing read), B = h (registers)
+                const rc_bf16x8 agh = rc_tr8(ghi, t0, col0, l15), agl = rc_tr8(glo, t0, col0, l15);
+                RC_MFMA3_ACT_A(aw2[cb], agh, agl, hhf, hlf);
+            }
+        }
+        if (t + 1 < t_end) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial sums of this workgroup: part[group][ dW1 (Hd x C) | dW2 (C x Hd) | db1 (Hd) ]
+    float* pg = p.part + (long)group * (2L * p.Hd * C + p.Hd);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            pg[(long)(hs + i) * C + cb * 32 + l31] = aw1[cb][r];
+            pg[(long)p.Hd * C + (long)(cb * 32 + i) * p.Hd + hs + l31] = aw2[cb][r];
+        }
+    db1 += __shfl_xor(db1, 32, 64);
+    if (lhi == 0) pg[2L * p.Hd * C + hs + l31] = db1;
+}
+
+// out_j[i] (+)= sum_g part[g][off_j + i] for the three segments, groups added in order: one float4 column per thread
+__global__ __launch_bounds__(256) void rc_reduce_kernel(const float* __restrict__ part, int groups, long stride, int n0, float* o0, int n1, float* o1, int n2, float* o2,
+                                                        int accumulate) {
+    const int q = blockIdx.x * 256 + threadIdx.x, n = n0 + n1 + n2;
+    if (q * 4 >= n) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = part + (long)q * 4;
+    int g = 0;
+    for (; g + 4 <= groups; g += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (long)g * stride), b = *reinterpret_cast<const float4*>(src + (long)(g + 1) * stride);
+        const float4 c = *reinterpret_cast<const float4*>(src + (long)(g + 2) * stride), d = *reinterpret_cast<const float4*>(src + (long)(g + 3) * stride);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; g < groups; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (long)g * stride);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    const int i = q * 4;                             // n0, n1, n2 % 4 == 0: a quad never straddles two segments
+    float* dst = i < n0 ? o0 + i : (i < n0 + n1 ? o1 + (i - n0) : o2 + (i - n0 - n1));
+    float4 v = s;
+    if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    *reinterpret_cast<float4*>(dst) = v;
+}
+
+int rc_set_lds(const void* k, int bytes, bool (&flags)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (flags[dev]) return MDVIT_OK;
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "mlp_rc: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    flags[dev] = true;
+    return MDVIT_OK;
+}
+
+void rc_fill(RcArgs& a, int M, int Hd, float drop_p, uint32_t k10, uint32_t k11, uint32_t k20, uint32_t k21, const uint32_t* seed) {
+    a.M = M; a.Hd = Hd;
+    a.drop = drop_p > 0.f; a.k1a = k10; a.k1b = k11; a.k2a = k20; a.k2b = k21;
+    a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
+    a.seed = seed;
+}
+
+}  // namespace
+
+int g_rc_fwd_variant = 3;       // 2: software-pipelined wave, 2 waves per SIMD; 3: plain wave, 3 waves per SIMD (tuning hook: mdvit_mlp_rc_config)
+extern "C" int mdvit_mlp_rc_config(int32_t fwd_variant) {
+    g_rc_fwd_variant = fwd_variant;
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_mlp_rc_fwd(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
+                                int32_t rows_per_scale, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                                uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(C == 64, MDVIT_E_SHAPE, "mlp_rc_fwd: built for C = 64 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd >= 64 && Hd % 64 == 0 && Hd <= 4096, MDVIT_E_SHAPE, "mlp_rc_fwd: need M > 0, hidden %% 64 == 0, hidden <= 4096 (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(x && W1p && b1 && W2p && b2 && res && y, MDVIT_E_SHAPE, "mlp_rc_fwd: null operand");
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(W1p) && aligned16(b1) && aligned16(W2p) && aligned16(b2) && aligned16(res) && aligned16(y), MDVIT_E_ALIGN,
+                    "mlp_rc_fwd: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_rc_fwd: dropout index space exceeds 2^32");
+    RcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2p = (const uint16_t*)W2p; a.b2 = b2; a.res = res; a.rowscale = rowscale; a.y = y;
+    a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    rc_fill(a, M, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed);
+    constexpr int NW = 4;
+    const int smem = 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + Hd * 4;
+    static bool flags[64] = {false};
+    static bool flags2[64] = {false};
+    int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd_kernel<64, NW, false>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, flags);
+    if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd_kernel<64, NW, true>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, flags2);
+    if (rc != MDVIT_OK) return rc;
+    if (g_rc_fwd_variant == 3) {
+        static bool f3[64] = {false}, f4[64] = {false};
+        rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, false>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f3);
+        if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, true>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f4);
+        if (rc != MDVIT_OK) return rc;
+        if (a.drop) hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, false>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+    } else if (a.drop) hipLaunchKernelGGL((mlp_rc_fwd_kernel<64, NW, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_rc_fwd_kernel<64, NW, false>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_mlp_rc_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx,
+                                  int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(C == 64, MDVIT_E_SHAPE, "mlp_rc_dgrad: built for C = 64 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd >= 64 && Hd % 64 == 0 && Hd <= 4096, MDVIT_E_SHAPE, "mlp_rc_dgrad: need M > 0, hidden %% 64 == 0, hidden <= 4096 (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(gm && x && W1p && b1 && W2tp && W1tp && dx, MDVIT_E_SHAPE, "mlp_rc_dgrad: null operand");
+    MDVIT_CHECK_ARG(aligned16(gm) && aligned16(x) && aligned16(W1p) && aligned16(b1) && aligned16(W2tp) && aligned16(W1tp) && aligned16(dx), MDVIT_E_ALIGN,
+                    "mlp_rc_dgrad: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_rc_dgrad: dropout index space exceeds 2^32");
+    RcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gm = gm; a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2tp = (const uint16_t*)W2tp; a.W1tp = (const uint16_t*)W1tp; a.dx = dx;
+    rc_fill(a, M, Hd, drop_p, key1_0, key1_1, 0, 0, drop_seed);
+    constexpr int NW = 4;
+    const int smem = 3 * 4 * (32 * 128) + 3 * 2 * (64 * 64) + Hd * 4;
+    static bool flags[64] = {false};
+    static bool flags2[64] = {false};
+    int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_dgrad_kernel<64, NW, false>), 3 * 4 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, flags);
+    if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_dgrad_kernel<64, NW, true>), 3 * 4 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, flags2);
+    if (rc != MDVIT_OK) return rc;
+    if (a.drop) hipLaunchKernelGGL((mlp_rc_dgrad_kernel<64, NW, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_rc_dgrad_kernel<64, NW, false>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+static int rc_wgrad_groups(int M) {
+    const int ntiles = (M + 31) / 32;
+    int g = (ntiles + 3) / 4;                      // >= 4 tiles per group where the problem allows it
+    g = ((g + 7) / 8) * 8;
+    return g < 8 ? 8 : (g > 128 ? 128 : g);
+}
+
+extern "C" size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t Hd) {
+    return sizeof(float) * (size_t)rc_wgrad_groups(M) * (2u * (size_t)Hd * C + Hd);
+}
+
+extern "C" int mdvit_mlp_rc_wgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, float* dW1, float* db1, float* dW2,
+                                  void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                                  const uint32_t* drop_seed, int32_t accumulate, void* stream) {
+    MDVIT_CHECK_ARG(C == 64, MDVIT_E_SHAPE, "mlp_rc_wgrad: built for C = 64 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd >= 256 && Hd % 256 == 0, MDVIT_E_SHAPE, "mlp_rc_wgrad: need M > 0, hidden %% 256 == 0 (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(gm && x && W1p && b1 && W2tp && dW1 && db1 && dW2, MDVIT_E_SHAPE, "mlp_rc_wgrad: null operand");
+    MDVIT_CHECK_ARG(aligned16(gm) && aligned16(x) && aligned16(W1p) && aligned16(W2tp) && aligned16(dW1) && aligned16(db1) && aligned16(dW2) && aligned16(ws),
+                    MDVIT_E_ALIGN, "mlp_rc_wgrad: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_rc_wgrad: dropout index space exceeds 2^32");
+    const size_t need = mdvit_mlp_rc_wgrad_ws_bytes(M, C, Hd);
+    MDVIT_CHECK_ARG(ws && ws_bytes >= need, MDVIT_E_WORKSPACE, "mlp_rc_wgrad: workspace too small: need %zu bytes (mdvit_mlp_rc_wgrad_ws_bytes), got %zu", need, ws_bytes);
+    RcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gm = gm; a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2tp = (const uint16_t*)W2tp; a.part = (float*)ws;
+    rc_fill(a, M, Hd, drop_p, key1_0, key1_1, 0, 0, drop_seed);
+    a.groups = rc_wgrad_groups(M);
+    a.tiles_per_group = cdiv((M + 31) / 32, a.groups);
+    const int roles = Hd / 256;
+    if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, false>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    const int n0 = Hd * C, n2 = Hd;
+    hipLaunchKernelGGL(rc_reduce_kernel, dim3(cdiv((2L * n0 + n2) / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, a.groups, (long)(2L * n0 + n2), n0, dW1,
+                       n0, dW2, n2, db1, accumulate);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}

@@ -901,6 +901,12 @@ def matmul(A, B):
 _mlp_recompute = os.environ.get("MDVIT_MLP_RECOMPUTE", "1") != "0"
 _mlp_fused = os.environ.get("MDVIT_MLP_FUSED", "1") != "0"
 _mlp_recompute_maxc = int(os.environ.get("MDVIT_MLP_RECOMPUTE_MAXC", "128"))
+_mlp_rc = os.environ.get("MDVIT_MLP_RC", "1") != "0"      # csrc/mlp_rc.hip: no [tokens, hidden] tensor in HBM in either pass (0: round 2's kernels, A/B)
+
+
+def _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M) -> bool:
+    return (_mlp_rc and _mlp_recompute and _gemm_precision == 1 and Cin == 64 and Hd % 256 == 0 and Hd <= 4096 and b1 is not None and b2 is not None and res is not None
+            and W1.is_contiguous() and W2.is_contiguous() and M * Hd < (1 << 32))
 
 
 class _MlpResidual(torch.autograd.Function):
@@ -910,9 +916,22 @@ class _MlpResidual(torch.autograd.Function):
         _chk(x, res, W1, b1, W2, b2, rowscale)
         M, Cin = x.shape
         Hd = W1.shape[0]
-        h = _empty((M, Hd), device=x.device, dtype=torch.float32)
         k1 = _next_key() if drop_p > 0 else (0, 0)
         k2 = _next_key() if drop_p > 0 else (0, 0)
+        if _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M):
+            # C = 64: the hidden activation stays in registers; NOTHING of size [tokens, hidden] is kept for the backward (it recomputes)
+            out = _empty((M, Cin), device=x.device, dtype=torch.float32)
+            W1p, W2p = _wplanes(W1, False), _wplanes(W2, False)
+            call("mdvit_mlp_rc_fwd", _p(x), _p(W1p), _p(b1), _p(W2p), _p(b2), _p(res), _p(rowscale), rows_per_scale, _p(out), M, Cin, Hd,
+                 drop_p, k1[0], k1[1], k2[0], k2[1], _seed_ptr() if drop_p > 0 else None, _stream())
+            del W1p, W2p
+            ctx.save_for_backward(x, None, None, W1, W2, rowscale)
+            ctx.meta = (drop_p, k1, k2, rows_per_scale)
+            ctx.b1_ref, ctx.b2_ref = b1, b2
+            ctx.rc = True
+            return out
+        ctx.rc = False
+        h = _empty((M, Hd), device=x.device, dtype=torch.float32)
         # HBM-bound MLPs (fc1's K = C <= 128): keep gelu(u) only; the backward recomputes the pre-activation u inside the fc2
         # data-gradient GEMM (one more K = C product per tile) instead of moving [tokens, hidden] u through HBM twice
         if _mlp_recompute and _mlp_fused and _gemm_precision >= 1 and Cin == 64 and Hd % 64 == 0 and b1 is not None and b2 is not None \
@@ -963,6 +982,37 @@ class _MlpResidual(torch.autograd.Function):
         dW1 = db1 = dW2 = db2 = None
         sinks = [_sink_of(t) for t in (W1, ctx.b1_ref, W2, ctx.b2_ref)] if not _dgrad_only else [None] * 4
         sunk = not _dgrad_only and all(t is not None for t in sinks)
+        if ctx.rc:
+            # gm = g * dropmask2 * droppath scale (+ db2 = its column sums, when parameter gradients are wanted) in one pass
+            masked = drop_p > 0 or rowscale is not None
+            want_w = not _dgrad_only
+            gm = _empty_like(g) if masked else g
+            if want_w and not sunk:
+                db2 = _empty((Cin,), device=dev, dtype=torch.float32)
+            if masked or want_w:
+                wsp, wsb, _keep = _partials_ws(Cin, dev) if want_w else (None, 0, None)
+                call("mdvit_colsum_f32", _p(g), Cin, _p(sinks[3] if sunk else db2) if want_w else None, _p(gm) if masked else None, wsp, wsb, M, Cin,
+                     drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
+            W1p, W2tp, W1tp = _wplanes(W1, False), _wplanes(W2, True), _wplanes(W1, True)
+            dx = _empty_like(x)
+            call("mdvit_mlp_rc_dgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(W1tp), _p(dx), M, Cin, Hd,
+                 drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, _stream())
+            if want_w:
+                wsb = _lib.load().mdvit_mlp_rc_wgrad_ws_bytes(M, Cin, Hd)
+                if sunk:
+                    with _on_side(gm, x, W1p, W2tp):
+                        ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
+                        _side_keepalive.append(ws)
+                        call("mdvit_mlp_rc_wgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(sinks[0]), _p(sinks[1]), _p(sinks[2]), _p(ws), wsb,
+                             M, Cin, Hd, drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, 1, _stream())
+                    db2 = None
+                else:
+                    dW1, db1, dW2 = _empty_like(W1), _empty((Hd,), device=dev, dtype=torch.float32), _empty_like(W2)
+                    ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
+                    call("mdvit_mlp_rc_wgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(dW1), _p(db1), _p(dW2), _p(ws), wsb,
+                         M, Cin, Hd, drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, 0, _stream())
+            del W1p, W2tp, W1tp
+            return dx, g, dW1, db1, dW2, db2, None, None, None
         if not _dgrad_only and not sunk:
             db2 = torch.zeros((Cin,), device=dev, dtype=torch.float32)
         # gm = g * dropmask2 * droppath scale in one pass; db2 = column sums of gm rides on the fc2 wgrad GEMM's pass over gm (colsum_a)

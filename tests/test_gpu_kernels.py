@@ -228,10 +228,94 @@ def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatc
         if name == "dx" and C == 64:      # the fused backward sums the hidden axis in order; the GEMM form may split K at this small M
             check(a, b, tol=1e-5, name=name)
             continue
-        if C == 64:       # fused MLP kernels (mlp.hip) against the plane GEMMs (gemm_bp.hip): the same products in the same order, but two
-            check(a, b, tol=2e-6, name=name)      # compilations of the GELU epilogue (fma contraction): equal to an ulp or two, not bit for bit
-            continue
+        if C == 64:       # fused MLP kernels (mlp_rc.hip; hidden % 256 != 0: mlp.hip) against the GEMM path: the same products in the same k order, but
+            check(a, b, tol=5e-6, name=name)      # other compilations of the GELU epilogue (fma contraction) and, for the recomputing weight-gradient kernel,
+            continue                              # another summation order over the tokens: equal to a few ulp, not bit for bit
         assert torch.equal(a, b), f"{name}: recomputed-u path differs from the stored-u path (max {float((a - b).abs().max()):.3e})"
+
+
+@pytest.mark.parametrize("M,r,drop", [(37, 8, 0.1), (4173, 8, 0.25), (1030, 4, 0.0), (20000, 8, 0.1), (300, 16, 0.1)])
+def test_mlp_rc_kernels_vs_round2_kernels_and_fp64(M, r, drop, monkeypatch):
+    """csrc/mlp_rc.hip (C = 64, bf16x3): forward, data-gradient and the RECOMPUTING weight-gradient kernel against (a) the fused kernels of
+    mlp.hip + the two weight-gradient GEMMs on the same dropout keys -- same products in the same k order, the activation compiled twice:
+    equal to a few ulp -- and (b) without dropout, an fp64 restatement of mpvit.py:71-78.  Also the data-gradient-only sweep and the
+    accumulate-into-buckets form of the weight-gradient kernel."""
+    from mdvit_amd import ops
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("mlp_rc.hip is the bf16x3 path's")
+    C, Hd = 64, 64 * r
+    ins = [rnd(M, C, seed=220), rnd(M, C, seed=221), rnd(Hd, C, seed=222, scale=C ** -0.5), rnd(Hd, seed=223, scale=0.1),
+           rnd(C, Hd, seed=224, scale=Hd ** -0.5), rnd(C, seed=225, scale=0.1)]
+    g = rnd(M, C, seed=226)
+    rowscale = (torch.rand(3, generator=torch.Generator().manual_seed(6)) < 0.7).float().div(0.7).to(dev()) if drop > 0 else None
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "_mlp_rc", flag)
+        monkeypatch.setattr(ops, "_key_counter", __import__("itertools").count(91))
+        out, go = grads_of(lambda *a: ops.mlp_residual(*a, rowscale=rowscale, drop_p=drop, rows_per_scale=(M + 2) // 3), [t.to(dev()) for t in ins], g)
+        res.append([out.detach()] + go)
+    for name, a, b in zip(("y", "dx", "dres", "dW1", "db1", "dW2", "db2"), res[0], res[1]):
+        check(a, b, tol=5e-6, name=name)
+    monkeypatch.setattr(ops, "_mlp_rc", True)
+    if drop == 0.0:
+        def ref_fn(x, res_, W1, b1, W2, b2):
+            return res_.double() + F.linear(F.gelu(F.linear(x.double(), W1.double(), b1.double())), W2.double(), b2.double())
+        ref, gr = grads_of(ref_fn, ins, g.double())
+        for name, a, b in zip(("y", "dx", "dres", "dW1", "db1", "dW2", "db2"), res[0], [ref] + gr):
+            check(a, b, tol=3e-4, name=name + " vs fp64")
+    # data-gradient-only sweep: dx as before, no parameter gradients
+    monkeypatch.setattr(ops, "_key_counter", __import__("itertools").count(91))
+    ops.set_dgrad_only(True)
+    try:
+        _, go = grads_of(lambda *a: ops.mlp_residual(*a, rowscale=rowscale, drop_p=drop, rows_per_scale=(M + 2) // 3), [t.to(dev()) for t in ins], g)
+    finally:
+        ops.set_dgrad_only(False)
+    assert torch.equal(go[0], res[0][1]) and all(t is None for t in go[2:])
+    # gradient sinks: the weight-gradient kernel ADDS into persistent buffers (bucket views), autograd receives None
+    params = [t.to(dev()).requires_grad_(True) for t in ins[2:]]
+    sinks = {p_: torch.full_like(p_, 0.5) for p_ in params}
+    ops.set_grad_sinks(sinks)
+    try:
+        monkeypatch.setattr(ops, "_key_counter", __import__("itertools").count(91))
+        x_ = ins[0].to(dev()).requires_grad_(True)
+        y = ops.mlp_residual(x_, ins[1].to(dev()), *params, rowscale=rowscale, drop_p=drop, rows_per_scale=(M + 2) // 3)
+        y.backward(g.to(dev()))
+        ops.join_side_stream()
+    finally:
+        ops.set_grad_sinks(None)
+    for name, p_, want in zip(("dW1", "db1", "dW2", "db2"), params, res[0][3:]):
+        assert p_.grad is None
+        check(sinks[p_] - 0.5, want, tol=2e-6, name=name + " (sink)")
+
+
+def test_mlp_rc_keeps_no_hidden_sized_tensor(monkeypatch):
+    """the point of mlp_rc.hip: neither pass allocates anything of size [tokens, hidden] -- round 2's kernels kept h for the backward and
+    wrote du for the weight-gradient GEMMs: the peak allocation of one forward + backward drops by (at least 1.8 of) those two tensors"""
+    from mdvit_amd import ops
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("mlp_rc.hip is the bf16x3 path's")
+    M, C, Hd = 65536, 64, 512
+    x = rnd(M, C, seed=230).to(dev()).requires_grad_(True); res = rnd(M, C, seed=231).to(dev())
+    W1, b1 = rnd(Hd, C, seed=232, scale=C ** -0.5).to(dev()).requires_grad_(True), rnd(Hd, seed=233, scale=0.1).to(dev()).requires_grad_(True)
+    W2, b2 = rnd(C, Hd, seed=234, scale=Hd ** -0.5).to(dev()).requires_grad_(True), rnd(C, seed=235, scale=0.1).to(dev()).requires_grad_(True)
+    g = rnd(M, C, seed=236).to(dev())
+    peaks = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "_mlp_rc", flag)
+        ops.mlp_residual(x, res, W1, b1, W2, b2, drop_p=0.1).backward(g)          # warm the weight caches of this path
+        for t in (x, W1, b1, W2, b2):
+            t.grad = None
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        ops.mlp_residual(x, res, W1, b1, W2, b2, drop_p=0.1).backward(g)
+        torch.cuda.synchronize()
+        peaks[flag] = torch.cuda.max_memory_allocated() - base
+        for t in (x, W1, b1, W2, b2):
+            t.grad = None
+    hidden = M * Hd * 4
+    assert peaks[True] < hidden, f"rc path: peak extra allocation {peaks[True] / 2**20:.0f} MiB, one [tokens, hidden] tensor is {hidden / 2**20:.0f} MiB"
+    assert peaks[False] - peaks[True] > 1.8 * hidden, (peaks, hidden)
 
 
 @pytest.mark.parametrize("M,C", [(1000, 64), (77, 128), (300, 320), (64, 512), (5, 1024), (33, 96), (4099, 64)])
