@@ -223,6 +223,54 @@ int mdvit_mlp_rc_wgrad(const float* gm, const float* x, const void* W1p, const f
                        void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t hidden, float drop_p, uint32_t key1_0, uint32_t key1_1,
                        const uint32_t* drop_seed, int32_t accumulate, void* stream);
 
+/* ---- one entry per SerialBlock_adapt pass (csrc/block.hip) ----------------------------------------------------------------------------
+ * SerialBlock_adapt.forward, mdvit.py:346-361 (and mpvit's SerialBlock, BASE: label == NULL):
+ *     x1 = x + dwconv3x3(x) + b                                  ConvPosEnc                       mpvit.py:239-248
+ *     x2 = x1 + DropPath(Dropout(proj(a * FactorAtt_ConvRelPosEnc(qkv(LN1(x1))))))                mdvit.py:281-313,353
+ *     y  = x2 + DropPath(Dropout(fc2(Dropout(GELU(fc1(LN2(x2)))))))                               mpvit.py:71-78, mdvit.py:357-360
+ * and its autograd backward, ENQUEUED from C: the same kernels in the same order as the operator-level entry points above (bit-identical
+ * results), one host call per pass instead of ~25.  The caller owns three buffers: `save` (mdvit_block_save_bytes: everything the backward
+ * needs, laid out by the library; kept between the passes), a forward workspace and a backward workspace (temporaries, split-K and
+ * partial-sum scratch; the backward workspace must stay alive until the side stream has finished).
+ * Weights: PyTorch layouts; `*_wt` = the transposed copies the bf16x3 data-gradient GEMMs read (mdvit_transpose_many), `fc*_p` = the bf16
+ * planes of mlp_rc (mdvit_split_planes_many; NULL: the MLP runs as GEMMs).  precision: 0 fp32 MFMA, 1 bf16x3.  ln_groups: rows of the
+ * [groups, C] LayerNorm parameters (MDViT_DSN banks on a domain-batched tensor; 1 otherwise).  label: [B, D] one-hot or NULL (no adapter).
+ * Dropout: drop_p with one key pair per site (proj, fc1, fc2) as in the GEMM epilogues; rowscale1/2: DropPath scales [B] or NULL. */
+typedef struct MdvitBlockDesc {
+    int32_t B, H, W, C, heads, hidden, s3, s5, s7, ln_groups, D, da_hidden, precision;
+    float eps, drop_p;
+    uint32_t key_proj[2], key_fc1[2], key_fc2[2];
+    const uint32_t* drop_seed;
+    const float* rowscale1; const float* rowscale2;
+    const float* label;
+    const float *cpe_w, *cpe_b, *n1_g, *n1_b, *qkv_w, *qkv_b, *w3, *b3, *w5, *b5, *w7, *b7, *da_w1, *da_b1, *da_w2, *da_b2, *proj_w, *proj_b, *n2_g, *n2_b, *fc1_w, *fc1_b,
+        *fc2_w, *fc2_b;
+    const float *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;
+    const void *fc1_p, *fc2_p, *fc2t_p, *fc1t_p;
+} MdvitBlockDesc;
+/* Gradient outputs of the backward.  The sixteen "weight-class" outputs (cpe, qkv, crpe windows, proj, fc1, fc2) are overwritten
+ * (accumulate == 0: fresh buffers) or added into (accumulate != 0: gradient buckets; the weight-gradient kernels then run on the side
+ * stream).  The LayerNorm and adapter gradients are always overwritten.  dgrad_only: the data-gradient-only sweep of the merged two-sweep
+ * step (multi_train_MDViT.py:198-207): no parameter gradient except the adapter's, NEGATED; aux_first: this block holds the first adapter of
+ * the network -- that sweep ends here (dx is not produced). */
+typedef struct MdvitBlockGrads {
+    float *cpe_w, *cpe_b, *n1_g, *n1_b, *qkv_w, *qkv_b, *w3, *b3, *w5, *b5, *w7, *b7, *da_w1, *da_b1, *da_w2, *da_b2, *proj_w, *proj_b, *n2_g, *n2_b, *fc1_w, *fc1_b, *fc2_w,
+        *fc2_b;
+    int32_t accumulate, dgrad_only, aux_first;
+} MdvitBlockGrads;
+/* main: the stream of the data-gradient chain; side: the stream of the weight-gradient kernels (NULL or == main: everything on main).
+ * events: n_events HIP events owned by the caller (mdvit_event_create) for the main -> side ordering, used round robin from *next_event. */
+typedef struct MdvitBlockStreams {
+    void* main; void* side;
+    void** events; int32_t n_events; int32_t* next_event;
+} MdvitBlockStreams;
+size_t mdvit_block_save_bytes(const MdvitBlockDesc* d);
+size_t mdvit_block_fwd_ws_bytes(const MdvitBlockDesc* d);
+int mdvit_block_fwd(const MdvitBlockDesc* d, const float* x, float* y, void* save, size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
+size_t mdvit_block_bwd_ws_bytes(const MdvitBlockDesc* d, const MdvitBlockGrads* g, int32_t with_side_stream);
+int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g, const MdvitBlockStreams* st, const float* x, const void* save, size_t save_bytes,
+                    const float* dy, float* dx /* NULL: not wanted */, void* ws, size_t ws_bytes);
+
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,
  * linear_out Decoders.py:311).  bwd: dx[m,k] = dy[m] w[k]; dw[k] = sum_m dy[m] x[m,k]; db = sum dy. */
 int mdvit_rowdot_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y,

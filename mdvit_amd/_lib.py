@@ -70,7 +70,30 @@ class PlaneGemmDesc(C.Structure):
     ]
 
 
+class BlockDesc(C.Structure):
+    _fields_ = ([(n, i32) for n in ("B", "H", "W", "C", "heads", "hidden", "s3", "s5", "s7", "ln_groups", "D", "da_hidden", "precision")]
+                + [("eps", f32), ("drop_p", f32), ("key_proj", u32 * 2), ("key_fc1", u32 * 2), ("key_fc2", u32 * 2), ("drop_seed", vp),
+                   ("rowscale1", vp), ("rowscale2", vp), ("label", vp)]
+                + [(n, vp) for n in ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",
+                                     "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                + [(n, vp) for n in ("qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "fc1_p", "fc2_p", "fc2t_p", "fc1t_p")])
+
+
+BLOCK_PARAMS = ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",
+                "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+class BlockGrads(C.Structure):
+    _fields_ = [(n, vp) for n in BLOCK_PARAMS] + [("accumulate", i32), ("dgrad_only", i32), ("aux_first", i32)]
+
+
+class BlockStreams(C.Structure):
+    _fields_ = [("main", vp), ("side", vp), ("events", C.POINTER(vp)), ("n_events", i32), ("next_event", C.POINTER(i32))]
+
+
 _SIGS = {
+    "mdvit_block_fwd": [C.POINTER(BlockDesc), vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp],
+    "mdvit_block_bwd": [C.POINTER(BlockDesc), C.POINTER(BlockGrads), C.POINTER(BlockStreams), vp, vp, C.c_size_t, vp, vp, vp, C.c_size_t],
     "mdvit_gemm_planes": [C.POINTER(PlaneGemmDesc), vp],
     "mdvit_gemm_planes_plan": [C.POINTER(PlaneGemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_planes_force_plan": [i32, i32],
@@ -204,6 +227,12 @@ def load():
     lib.mdvit_partials_ws_bytes.argtypes = [i32]
     lib.mdvit_mlp_rc_wgrad_ws_bytes.restype = C.c_size_t
     lib.mdvit_mlp_rc_wgrad_ws_bytes.argtypes = [i32, i32, i32]
+    lib.mdvit_block_save_bytes.restype = C.c_size_t
+    lib.mdvit_block_save_bytes.argtypes = [C.POINTER(BlockDesc)]
+    lib.mdvit_block_fwd_ws_bytes.restype = C.c_size_t
+    lib.mdvit_block_fwd_ws_bytes.argtypes = [C.POINTER(BlockDesc)]
+    lib.mdvit_block_bwd_ws_bytes.restype = C.c_size_t
+    lib.mdvit_block_bwd_ws_bytes.argtypes = [C.POINTER(BlockDesc), C.POINTER(BlockGrads), i32]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t
     lib.mdvit_da_ws_bytes.argtypes = [i32, i32, i32]
     for name, sig in _SIGS.items():

@@ -418,19 +418,46 @@ class SerialBlock_adapt(nn.Module):
         m = (torch.rand((2, B), device=device) < keep).float() / keep      # per-sample masks for both branches
         return m[0].contiguous(), m[1].contiguous()
 
+    def _block_entry(self, x, size, domain_label, use_da):
+        """the whole block as one C call (ops.serial_block), or None when the configuration needs the operator-level path"""
+        att, mlp = self.factoratt_crpe, self.mlp
+        if not x.is_cuda or att.proj_drop_p != mlp.drop_p or att.qkv.bias is None:
+            return None
+        n1, n2 = _pick(self, "norm1", "norm1s"), _pick(self, "norm2", "norm2s")
+        if isinstance(n1, _BankLN):
+            (g1, b1), (g2, b2) = n1._params(), n2._params()
+            groups, eps = g1.shape[0], n1.mods[0].eps
+        else:
+            g1, b1, g2, b2, groups, eps = n1.weight, n1.bias, n2.weight, n2.bias, 1, n1.eps
+        da = [None] * 4
+        if use_da:
+            d0, d2 = att.domain_layer[0], att.domain_layer[2]
+            da = [d0.weight, d0.bias, d2.weight, d2.bias]
+        params = [self.cpe.proj.weight, self.cpe.proj.bias, g1, b1, att.qkv.weight, att.qkv.bias, *att.crpe.params(), *da, att.proj.weight, att.proj.bias,
+                  g2, b2, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias]
+        if not ops.block_entry_ok(x.shape[-1], mlp.fc1.weight.shape[0], params):
+            return None
+        s1, s2 = self._droppath_scales(x.shape[0], x.device)
+        meta = (int(size[0]), int(size[1]), att.num_heads, tuple(att.crpe.head_splits), float(eps), float(mlp.drop_p if self.training else 0.0), int(groups),
+                bool(getattr(att, "aux_first", False)))
+        return ops.serial_block(x, domain_label if use_da else None, s1, s2, meta, params)
+
     def forward(self, x, size: Tuple[int, int], domain_label=None):
+        use_da = (domain_label is not None) if self.base_semantics else (self.adapt_method is not None and domain_label is not None)
+        if use_da and not isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
+            raise TypeError("forward() got a domain_label but this block was built without adapt_method='Sup' "
+                            "(the reference raises here too: mdvit.py:350-351)")
+        if not use_da and isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
+            raise TypeError("adapt_method='Sup' blocks need a domain_label (mdvit.py:281)")
+        y = self._block_entry(x, size, domain_label, use_da)
+        if y is not None:
+            return y
         x = self.cpe(x, size)
         s1, s2 = self._droppath_scales(x.shape[0], x.device)
         cur, x = _pick(self, "norm1", "norm1s").fork(x)
-        use_da = (domain_label is not None) if self.base_semantics else (self.adapt_method is not None and domain_label is not None)
         if use_da:
-            if not isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
-                raise TypeError("forward() got a domain_label but this block was built without adapt_method='Sup' "
-                                "(the reference raises here too: mdvit.py:350-351)")
             x = self.factoratt_crpe(cur, size, domain_label, _res=x, _rowscale=s1)
         else:
-            if isinstance(self.factoratt_crpe, FactorAtt_ConvRelPosEnc_Sup):
-                raise TypeError("adapt_method='Sup' blocks need a domain_label (mdvit.py:281)")
             x = self.factoratt_crpe(cur, size, _res=x, _rowscale=s1)
         cur, x = _pick(self, "norm2", "norm2s").fork(x)
         return self.mlp(cur, _res=x, _rowscale=s2)

@@ -1,0 +1,399 @@
+// One C-ABI entry per SerialBlock_adapt pass (mdvit.py:316-361): the forward / backward of a whole block is ENQUEUED from C -- its ~15 / ~35
+// kernels, the fork of the weight-gradient work onto the side stream, the carving of one caller-owned buffer into the block's saved and
+// temporary tensors -- instead of ~25 Python-level operator calls with an autograd node, a handful of torch.empty and a ctypes
+// round trip each.  Round 2 measured the host at 30-38 ms per step against 31 ms of main-stream kernel time (profiles/r02k_*): the step
+// was bound by the enqueue rate, and the 16 blocks are half of its launches.
+// The kernels and their order are exactly those of the operator-level path (mdvit_amd/ops.py: dwconv3x3 + layer_norm + linear + factor_att +
+// linear + layer_norm + mlp_residual and their backward), so both paths give bit-identical results (tests/test_gpu_block.py).
+#include "common.h"
+
+namespace {
+
+struct Arena {
+    char* base; size_t off, cap; bool dry;
+    float* take(size_t floats) {
+        const size_t bytes = (floats * sizeof(float) + 255) & ~(size_t)255;
+        float* p = dry ? nullptr : reinterpret_cast<float*>(base + off);
+        off += bytes;
+        return p;
+    }
+    void* take_bytes(size_t bytes) { return take((bytes + 3) / 4); }
+};
+
+enum { MLP_RC = 0, MLP_RECOMP = 1, MLP_STORED = 2 };
+
+inline int mlp_mode(const MdvitBlockDesc& d) {
+    if (d.precision == 1 && d.C == 64 && d.hidden % 256 == 0 && d.hidden <= 4096 && d.fc1_p && d.fc2_p && (long)d.B * d.H * d.W * d.hidden < (1L << 32)) return MLP_RC;
+    if (d.precision >= 1 && d.C <= 128 && d.C % 32 == 0 && d.hidden % 4 == 0) return MLP_RECOMP;
+    return MLP_STORED;
+}
+
+struct Saved {        // the block's saved-for-backward tensors inside the caller's `save` buffer
+    float *x1, *mean1, *rstd1, *cur1, *qkv, *a, *att, *U, *kmax, *ksum, *Mmat, *x2, *mean2, *rstd2, *cur2, *h, *u;
+};
+
+void layout_saved(const MdvitBlockDesc& d, Arena& A, Saved& s) {
+    const long T = (long)d.B * d.H * d.W, C = d.C, Ch = d.C / d.heads;
+    const int mode = mlp_mode(d);
+    s.x1 = A.take(T * C); s.mean1 = A.take(T); s.rstd1 = A.take(T); s.cur1 = A.take(T * C);
+    s.qkv = A.take(T * 3 * C);
+    s.a = d.label ? A.take((long)d.B * C) : nullptr;
+    s.att = A.take(T * C); s.U = A.take(T * C);
+    s.kmax = A.take((long)d.B * C); s.ksum = A.take((long)d.B * C); s.Mmat = A.take((long)d.B * C * Ch);
+    s.x2 = A.take(T * C); s.mean2 = A.take(T); s.rstd2 = A.take(T); s.cur2 = A.take(T * C);
+    s.h = mode != MLP_RC ? A.take(T * d.hidden) : nullptr;
+    s.u = mode == MLP_STORED ? A.take(T * d.hidden) : nullptr;
+}
+
+void gemm_init(MdvitGemmDesc& g, const MdvitBlockDesc& d) {
+    memset(&g, 0, sizeof(g));
+    g.precision = d.precision >= 1 ? 1 : 0;
+    g.drop_seed = nullptr;
+}
+
+#define BLK_RUN(call)                         \
+    do {                                      \
+        if (!A.dry) {                         \
+            const int rc__ = (call);          \
+            if (rc__ != MDVIT_OK) return rc__; \
+        }                                     \
+    } while (0)
+
+// C = A W^T (+ epilogue): the forward layers
+int gemm_fwd(Arena& A, MdvitGemmDesc& g, hipStream_t s) {
+    g.trans_a = 0; g.trans_b = 1; g.allow_split = 1;
+    const size_t need = mdvit_gemm_ws_bytes(&g);
+    g.ws = need ? A.take_bytes(need) : nullptr; g.ws_bytes = need;
+    BLK_RUN(mdvit_gemm_f32(&g, s));
+    return MDVIT_OK;
+}
+
+// dx[M,K] = g[M,N] W[N,K]: NT against the cached W^T (bf16x3) or NN (fp32)  -- ops._dgrad
+int gemm_dgrad(Arena& A, const MdvitBlockDesc& d, MdvitGemmDesc& g, const float* gy, const float* W, const float* Wt, float* dx, int M, int K, int N, hipStream_t s) {
+    g.A = gy; g.C = dx; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldc = K;
+    if (d.precision >= 1) { g.B = Wt; g.ldb = N; g.trans_a = 0; g.trans_b = 1; g.precision = 1; }
+    else { g.B = W; g.ldb = K; g.trans_a = 0; g.trans_b = 0; g.precision = 0; }
+    const size_t need = g.allow_split ? mdvit_gemm_ws_bytes(&g) : 0;
+    g.ws = need ? A.take_bytes(need) : nullptr; g.ws_bytes = need;
+    BLK_RUN(mdvit_gemm_f32(&g, s));
+    return MDVIT_OK;
+}
+
+// dW[N,K] (+)= gy[M,N]^T x[M,K], db[N] += colsum(gy)  -- the TN launch of ops._Linear.backward
+int gemm_wgrad(Arena& A, const MdvitBlockDesc& d, const float* gy, const float* x, float* dW, float* db, int M, int N, int K, int accumulate, hipStream_t s) {
+    MdvitGemmDesc g;
+    gemm_init(g, d);
+    g.A = gy; g.B = x; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = N; g.ldb = K; g.ldc = K;
+    g.trans_a = 1; g.trans_b = 0; g.allow_split = 1; g.accumulate = accumulate; g.colsum_a = db;
+    const size_t need = mdvit_gemm_ws_bytes(&g);
+    g.ws = need ? A.take_bytes(need) : nullptr; g.ws_bytes = need;
+    BLK_RUN(mdvit_gemm_f32(&g, s));
+    return MDVIT_OK;
+}
+
+// everything the side stream enqueues from here on runs after what the main stream holds now
+int fork_side(const MdvitBlockDesc& d, const MdvitBlockStreams& st, hipStream_t& side) {
+    side = (hipStream_t)st.side;
+    if (side == nullptr || side == (hipStream_t)st.main) { side = (hipStream_t)st.main; return MDVIT_OK; }
+    if (st.n_events <= 0 || st.events == nullptr) return mdvit_set_error(MDVIT_E_SHAPE, "block: a side stream needs events");
+    hipEvent_t ev = (hipEvent_t)st.events[(*st.next_event)++ % st.n_events];
+    hipError_t e = hipEventRecord(ev, (hipStream_t)st.main);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev, 0);
+    if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "block: side-stream fork failed: %s", hipGetErrorString(e));
+    return MDVIT_OK;
+}
+
+int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Arena& A, hipStream_t s) {
+    const int B = d.B, H = d.H, W = d.W, C = d.C, Hd = d.hidden;
+    const long T = (long)B * H * W;
+    const int M = (int)T, N_tok = H * W;
+    const int mode = mlp_mode(d);
+    Saved sv;
+    layout_saved(d, SV, sv);
+    // x1 = x + dwconv3x3(x) + bias            (ConvPosEnc, mpvit.py:239-248)
+    BLK_RUN(mdvit_dwconv3x3_fwd(x, d.cpe_w, d.cpe_b, sv.x1, B, H, W, C, 1, 1, s));
+    // cur1 = LN1(x1)
+    BLK_RUN(mdvit_layernorm_fwd(sv.x1, d.n1_g, d.n1_b, sv.cur1, sv.mean1, sv.rstd1, M, C, d.ln_groups, d.eps, s));
+    // qkv = cur1 Wqkv^T + b                    (mdvit.py:288)
+    {
+        MdvitGemmDesc g;
+        gemm_init(g, d);
+        g.A = sv.cur1; g.B = d.qkv_w; g.C = sv.qkv; g.M = M; g.N = 3 * C; g.K = C; g.lda = C; g.ldb = C; g.ldc = 3 * C; g.bias = d.qkv_b;
+        const int rc = gemm_fwd(A, g, s);
+        if (rc != MDVIT_OK) return rc;
+    }
+    // a = softmax_heads(MLP(one_hot));  att = a * (scale * q (softmax_tokens(k)^T v) + q * crpe(v))      (mdvit.py:293-304)
+    if (d.label) BLK_RUN(mdvit_da_fwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, B, d.D, d.da_hidden, C, d.heads, s));
+    {
+        const size_t fab = mdvit_factoratt_ws_bytes(B, N_tok, C, d.heads);
+        void* faws = A.take_bytes(fab);
+        BLK_RUN(mdvit_factoratt_fwd(sv.qkv, d.w3, d.b3, d.w5, d.b5, d.w7, d.b7, sv.a, sv.att, sv.U, sv.kmax, sv.ksum, sv.Mmat, faws, fab, B, H, W, C, d.heads,
+                                    d.s3, d.s5, d.s7, s));
+    }
+    // x2 = x1 + droppath(drop(att Wproj^T + b))      (mdvit.py:310-311,353)
+    {
+        MdvitGemmDesc g;
+        gemm_init(g, d);
+        g.A = sv.att; g.B = d.proj_w; g.C = sv.x2; g.M = M; g.N = C; g.K = C; g.lda = C; g.ldb = C; g.ldc = C; g.bias = d.proj_b;
+        g.e_drop_p = d.drop_p; g.e_key0 = d.key_proj[0]; g.e_key1 = d.key_proj[1]; g.e_rowscale = d.rowscale1; g.e_rows_per_scale = N_tok;
+        g.residual = sv.x1; g.ldr = C; g.drop_seed = d.drop_p > 0.f ? d.drop_seed : nullptr;
+        const int rc = gemm_fwd(A, g, s);
+        if (rc != MDVIT_OK) return rc;
+    }
+    BLK_RUN(mdvit_layernorm_fwd(sv.x2, d.n2_g, d.n2_b, sv.cur2, sv.mean2, sv.rstd2, M, C, d.ln_groups, d.eps, s));
+    // y = x2 + droppath(drop(fc2(drop(gelu(fc1(cur2))))))                                             (mpvit.py:71-78, mdvit.py:357-360)
+    const uint32_t* seed = d.drop_p > 0.f ? d.drop_seed : nullptr;
+    if (mode == MLP_RC) {
+        BLK_RUN(mdvit_mlp_rc_fwd(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1],
+                                 d.key_fc2[0], d.key_fc2[1], seed, s));
+    } else {
+        MdvitGemmDesc g;
+        gemm_init(g, d);
+        g.A = sv.cur2; g.B = d.fc1_w; g.M = M; g.N = Hd; g.K = C; g.lda = C; g.ldb = C; g.ldc = Hd; g.bias = d.fc1_b; g.epi = MDVIT_EPI_GELU_DUAL;
+        g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc1[0]; g.e_key1 = d.key_fc1[1]; g.drop_seed = seed;
+        if (mode == MLP_RECOMP) { g.C = sv.h; g.C2 = nullptr; }            // gelu(u) only: the backward recomputes u
+        else { g.C = sv.u; g.C2 = sv.h; }
+        g.trans_a = 0; g.trans_b = 1; g.allow_split = 0;
+        BLK_RUN(mdvit_gemm_f32(&g, s));
+        gemm_init(g, d);
+        g.A = sv.h; g.B = d.fc2_w; g.C = y; g.M = M; g.N = C; g.K = Hd; g.lda = Hd; g.ldb = Hd; g.ldc = C; g.bias = d.fc2_b;
+        g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc2[0]; g.e_key1 = d.key_fc2[1]; g.e_rowscale = d.rowscale2; g.e_rows_per_scale = N_tok;
+        g.residual = sv.x2; g.ldr = C; g.drop_seed = seed;
+        g.trans_a = 0; g.trans_b = 1; g.allow_split = 0;
+        BLK_RUN(mdvit_gemm_f32(&g, s));
+    }
+    return MDVIT_OK;
+}
+
+int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBlockStreams& st, const float* x, const float* dy, float* dx, Arena& SV, Arena& A) {
+    const int B = d.B, H = d.H, W = d.W, C = d.C, Hd = d.hidden;
+    const long T = (long)B * H * W;
+    const int M = (int)T, N_tok = H * W;
+    const int mode = mlp_mode(d);
+    const bool dgrad_only = G.dgrad_only != 0, want_w = !dgrad_only;
+    const int acc = G.accumulate;
+    hipStream_t s = (hipStream_t)st.main, side = s;
+    Saved sv;
+    layout_saved(d, SV, sv);
+    const uint32_t* seed = d.drop_p > 0.f ? d.drop_seed : nullptr;
+    const bool fast_ln = C == 64 || C == 128 || C == 320 || C == 512;
+
+    const bool have_side = st.side != nullptr && st.side != st.main;
+    if (want_w && acc == 0) {       // bias gradients ride on column sums that ACCUMULATE: clear the fresh buffers first
+        const MdvitZeroItem z[4] = {{G.qkv_b, sizeof(float) * 3 * C}, {G.proj_b, sizeof(float) * C}, {mode == MLP_RC ? nullptr : G.fc1_b, sizeof(float) * Hd},
+                                    {mode == MLP_RC ? nullptr : G.fc2_b, sizeof(float) * C}};
+        BLK_RUN(mdvit_zero_many(z, 4, s));
+    }
+
+    // ---- MLP --------------------------------------------------------------------------------------------------------------------
+    const bool masked = d.drop_p > 0.f || d.rowscale2 != nullptr;
+    float* gm2 = masked ? A.take(T * C) : const_cast<float*>(dy);
+    float* dcur2 = A.take(T * C);
+    float* du = nullptr;
+    if (mode == MLP_RC) {
+        if (masked || want_w) {
+            const size_t pb = want_w ? mdvit_partials_ws_bytes(C) : 0;
+            void* pw = want_w ? A.take_bytes(pb) : nullptr;
+            BLK_RUN(mdvit_colsum_f32(dy, C, want_w ? G.fc2_b : nullptr, masked ? gm2 : nullptr, pw, pb, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok,
+                                     acc, seed, s));
+        }
+        BLK_RUN(mdvit_mlp_rc_dgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
+        if (want_w) {
+            const size_t wb = mdvit_mlp_rc_wgrad_ws_bytes(M, C, Hd);
+            void* ww = A.take_bytes(wb);
+            if (!A.dry) { const int rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
+            BLK_RUN(mdvit_mlp_rc_wgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, G.fc1_w, G.fc1_b, G.fc2_w, ww, wb, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed,
+                                       acc, side));
+        }
+    } else {
+        if (masked) BLK_RUN(mdvit_colsum_f32(dy, C, nullptr, gm2, nullptr, 0, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok, 0, seed, s));
+        du = A.take(T * Hd);
+        MdvitGemmDesc g;
+        gemm_init(g, d);
+        g.epi = MDVIT_EPI_DGELU; g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc1[0]; g.e_key1 = d.key_fc1[1]; g.drop_seed = seed;
+        if (mode == MLP_RECOMP) { g.rc_a = sv.cur2; g.rc_lda = C; g.rc_b = d.fc1_w; g.rc_ldb = C; g.rc_bias = d.fc1_b; g.rc_k = C; }
+        else { g.gelu_u = sv.u; g.ldu = Hd; }
+        g.allow_split = 0;
+        int rc = gemm_dgrad(A, d, g, gm2, d.fc2_w, d.fc2_wt, du, M, Hd, C, s);            // du = (gm W2) * gelu'(u) * mask
+        if (rc != MDVIT_OK) return rc;
+        gemm_init(g, d);
+        g.allow_split = 1;
+        rc = gemm_dgrad(A, d, g, du, d.fc1_w, d.fc1_wt, dcur2, M, C, Hd, s);               // dx = du W1
+        if (rc != MDVIT_OK) return rc;
+        if (want_w) {
+            if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
+            rc = gemm_wgrad(A, d, gm2, sv.h, G.fc2_w, G.fc2_b, M, C, Hd, acc, side);
+            if (rc == MDVIT_OK) rc = gemm_wgrad(A, d, du, sv.cur2, G.fc1_w, G.fc1_b, M, Hd, C, acc, side);
+            if (rc != MDVIT_OK) return rc;
+        }
+    }
+    // ---- LN2 (+ the residual branch's gradient, which is dy itself) ---------------------------------------------------------------
+    float* dx2 = A.take(T * C);
+    {
+        const bool lnw = want_w || !fast_ln;
+        const size_t pb = lnw ? mdvit_partials_ws_bytes(2 * C) : 0;
+        void* pw = lnw ? A.take_bytes(pb) : nullptr;
+        float* dg = want_w ? G.n2_g : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
+        float* db = want_w ? G.n2_b : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
+        BLK_RUN(mdvit_layernorm_bwd(dcur2, sv.x2, d.n2_g, sv.mean2, sv.rstd2, dy, dx2, dg, db, pw, pb, M, C, d.ln_groups, s));
+    }
+    // ---- proj Linear: masked upstream gradient once, data gradient, weight gradient (side) ------------------------------------------
+    const bool masked1 = d.drop_p > 0.f || d.rowscale1 != nullptr;
+    float* gm1 = masked1 ? A.take(T * C) : dx2;
+    if (masked1) BLK_RUN(mdvit_colsum_f32(dx2, C, nullptr, gm1, nullptr, 0, M, C, d.drop_p, d.key_proj[0], d.key_proj[1], d.rowscale1, N_tok, 0, seed, s));
+    float* datt = A.take(T * C);
+    {
+        MdvitGemmDesc g;
+        gemm_init(g, d);
+        g.allow_split = 1;
+        int rc = gemm_dgrad(A, d, g, gm1, d.proj_w, d.proj_wt, datt, M, C, C, s);
+        if (rc != MDVIT_OK) return rc;
+        if (want_w) {
+            if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
+            rc = gemm_wgrad(A, d, gm1, sv.att, G.proj_w, G.proj_b, M, C, C, acc, side);
+            if (rc != MDVIT_OK) return rc;
+        }
+    }
+    // ---- attention core + adapter ---------------------------------------------------------------------------------------------------
+    const size_t fab = mdvit_factoratt_ws_bytes(B, N_tok, C, d.heads);
+    void* faws = A.take_bytes(fab);
+    float* e = d.label ? A.take((long)B * C) : nullptr;
+    if (dgrad_only && G.aux_first && d.label) {
+        // the first adapter of the network in the data-gradient-only sweep: e = sum_n g * att alone, the adapter's (negated) gradient, and
+        // nothing is handed on -- nothing below carries an adapter (ops._FactorAtt, aux_first)
+        BLK_RUN(mdvit_factoratt_bwd(datt, sv.qkv, sv.att, sv.U, d.w3, d.b3, d.w5, d.b5, d.w7, d.b7, sv.a, sv.kmax, sv.ksum, sv.Mmat, nullptr, e, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, faws, fab, B, H, W, C, d.heads, d.s3, d.s5, d.s7, s));
+        const size_t dab = mdvit_da_ws_bytes(B, d.da_hidden, C);
+        void* daws = A.take_bytes(dab);
+        BLK_RUN(mdvit_da_bwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, e, -1.0f, G.da_w1, G.da_b1, G.da_w2, G.da_b2, daws, dab, B, d.D, d.da_hidden, C, d.heads, s));
+        return MDVIT_OK;
+    }
+    float* dqkv = A.take(T * 3 * C);
+    {
+        // window-weight gradients: deferred to the side stream when they accumulate into buckets (they read dU in the SAME workspace and v);
+        // otherwise produced by the backward call itself, into the fresh buffers
+        const bool deferred = want_w && acc && have_side;
+        const bool inl = want_w && !deferred;
+        BLK_RUN(mdvit_factoratt_bwd(datt, sv.qkv, sv.att, sv.U, d.w3, d.b3, d.w5, d.b5, d.w7, d.b7, sv.a, sv.kmax, sv.ksum, sv.Mmat, dqkv, e, inl ? G.w3 : nullptr,
+                                    inl ? G.b3 : nullptr, inl ? G.w5 : nullptr, inl ? G.b5 : nullptr, inl ? G.w7 : nullptr, inl ? G.b7 : nullptr, faws, fab, B, H, W, C,
+                                    d.heads, d.s3, d.s5, d.s7, s));
+        if (deferred) {
+            if (!A.dry) { const int rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
+            BLK_RUN(mdvit_factoratt_wgrad(sv.qkv, faws, fab, G.w3, G.b3, G.w5, G.b5, G.w7, G.b7, B, H, W, C, d.heads, d.s3, d.s5, d.s7, 1, side));
+        }
+        if (inl && acc) return mdvit_set_error(MDVIT_E_SHAPE, "block_bwd: accumulating window-weight gradients need the side stream");
+    }
+    if (d.label) {
+        const size_t dab = mdvit_da_ws_bytes(B, d.da_hidden, C);
+        void* daws = A.take_bytes(dab);
+        BLK_RUN(mdvit_da_bwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, e, dgrad_only ? -1.0f : 1.0f, G.da_w1, G.da_b1, G.da_w2, G.da_b2, daws, dab, B, d.D,
+                             d.da_hidden, C, d.heads, s));
+    }
+    // ---- qkv Linear -----------------------------------------------------------------------------------------------------------------
+    float* dcur1 = A.take(T * C);
+    {
+        MdvitGemmDesc g;
+        gemm_init(g, d);
+        g.allow_split = 1;
+        int rc = gemm_dgrad(A, d, g, dqkv, d.qkv_w, d.qkv_wt, dcur1, M, C, 3 * C, s);
+        if (rc != MDVIT_OK) return rc;
+        if (want_w) {
+            if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
+            rc = gemm_wgrad(A, d, dqkv, sv.cur1, G.qkv_w, G.qkv_b, M, 3 * C, C, acc, side);
+            if (rc != MDVIT_OK) return rc;
+        }
+    }
+    // ---- LN1 (+ dx2 along the residual branch) ------------------------------------------------------------------------------------
+    float* dx1 = A.take(T * C);
+    {
+        const bool lnw = want_w || !fast_ln;
+        const size_t pb = lnw ? mdvit_partials_ws_bytes(2 * C) : 0;
+        void* pw = lnw ? A.take_bytes(pb) : nullptr;
+        float* dg = want_w ? G.n1_g : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
+        float* db = want_w ? G.n1_b : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
+        BLK_RUN(mdvit_layernorm_bwd(dcur1, sv.x1, d.n1_g, sv.mean1, sv.rstd1, dx2, dx1, dg, db, pw, pb, M, C, d.ln_groups, s));
+    }
+    // ---- ConvPosEnc -----------------------------------------------------------------------------------------------------------------
+    if (dx) BLK_RUN(mdvit_dwconv3x3_bwd(dx1, x, d.cpe_w, dx, nullptr, nullptr, nullptr, 0, B, H, W, C, 1, 1, 0, s));
+    if (want_w) {
+        const size_t pb = mdvit_partials_ws_bytes(10 * C);
+        void* pw = A.take_bytes(pb);
+        if (acc && !A.dry) { const int rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
+        BLK_RUN(mdvit_dwconv3x3_bwd(dx1, x, d.cpe_w, nullptr, G.cpe_w, G.cpe_b, pw, pb, B, H, W, C, 1, 1, acc, acc ? side : s));
+    }
+    return MDVIT_OK;
+}
+
+int check_desc(const MdvitBlockDesc& d, const char* what) {
+    MDVIT_CHECK_ARG(d.B > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.heads > 0 && d.C % d.heads == 0 && d.hidden > 0 && d.C % 4 == 0, MDVIT_E_SHAPE,
+                    "%s: bad geometry B=%d H=%d W=%d C=%d heads=%d hidden=%d", what, d.B, d.H, d.W, d.C, d.heads, d.hidden);
+    MDVIT_CHECK_ARG(d.precision == 0 || d.precision == 1, MDVIT_E_SHAPE, "%s: precision %d (0: fp32, 1: bf16x3)", what, d.precision);
+    MDVIT_CHECK_ARG(d.ln_groups >= 1 && ((long)d.B * d.H * d.W) % d.ln_groups == 0, MDVIT_E_SHAPE, "%s: %d LayerNorm groups do not divide the rows", what, d.ln_groups);
+    MDVIT_CHECK_ARG(d.cpe_w && d.cpe_b && d.n1_g && d.n1_b && d.qkv_w && d.w3 && d.b3 && d.w5 && d.b5 && d.w7 && d.b7 && d.proj_w && d.proj_b && d.n2_g && d.n2_b && d.fc1_w &&
+                        d.fc1_b && d.fc2_w && d.fc2_b, MDVIT_E_SHAPE, "%s: null parameter", what);
+    MDVIT_CHECK_ARG(!d.label || (d.da_w1 && d.da_b1 && d.da_w2 && d.da_b2 && d.D > 0 && d.da_hidden > 0), MDVIT_E_SHAPE, "%s: a domain label needs the adapter's parameters", what);
+    return MDVIT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mdvit_block_save_bytes(const MdvitBlockDesc* d) {
+    if (!d || check_desc(*d, "block_save_bytes") != MDVIT_OK) return 0;
+    Arena SV{nullptr, 0, 0, true};
+    Saved sv;
+    layout_saved(*d, SV, sv);
+    return SV.off;
+}
+
+extern "C" size_t mdvit_block_fwd_ws_bytes(const MdvitBlockDesc* d) {
+    if (!d || check_desc(*d, "block_fwd_ws_bytes") != MDVIT_OK) return 0;
+    Arena SV{nullptr, 0, 0, true}, A{nullptr, 0, 0, true};
+    if (block_fwd(*d, nullptr, nullptr, SV, A, nullptr) != MDVIT_OK) return 0;
+    return A.off + 256;
+}
+
+extern "C" int mdvit_block_fwd(const MdvitBlockDesc* d, const float* x, float* y, void* save, size_t save_bytes, void* ws, size_t ws_bytes, void* stream) {
+    MDVIT_CHECK_ARG(d && x && y && save, MDVIT_E_SHAPE, "block_fwd: null argument");
+    const int rc = check_desc(*d, "block_fwd");
+    if (rc != MDVIT_OK) return rc;
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(y) && (reinterpret_cast<uintptr_t>(save) & 255) == 0 && (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) == 0), MDVIT_E_ALIGN,
+                    "block_fwd: x / y must be 16-byte, save / ws 256-byte aligned");
+    MDVIT_CHECK_ARG(save_bytes >= mdvit_block_save_bytes(d), MDVIT_E_WORKSPACE, "block_fwd: save buffer too small: need %zu bytes (mdvit_block_save_bytes), got %zu",
+                    mdvit_block_save_bytes(d), save_bytes);
+    const size_t need = mdvit_block_fwd_ws_bytes(d);
+    MDVIT_CHECK_ARG(ws_bytes >= need && ws, MDVIT_E_WORKSPACE, "block_fwd: workspace too small: need %zu bytes (mdvit_block_fwd_ws_bytes), got %zu", need, ws_bytes);
+    Arena SV{(char*)save, 0, save_bytes, false}, A{(char*)ws, 0, ws_bytes, false};
+    return block_fwd(*d, x, y, SV, A, (hipStream_t)stream);
+}
+
+extern "C" size_t mdvit_block_bwd_ws_bytes(const MdvitBlockDesc* d, const MdvitBlockGrads* g, int32_t with_side_stream) {
+    if (!d || !g || check_desc(*d, "block_bwd_ws_bytes") != MDVIT_OK) return 0;
+    Arena SV{nullptr, 0, 0, true}, A{nullptr, 0, 0, true};
+    MdvitBlockStreams st;
+    memset(&st, 0, sizeof(st));
+    st.main = (void*)1; st.side = with_side_stream ? (void*)2 : (void*)1;          // only compared, never used: the run is dry
+    float dummy = 0.f;
+    if (block_bwd(*d, *g, st, nullptr, &dummy, &dummy, SV, A) != MDVIT_OK) return 0;
+    return A.off + 256;
+}
+
+extern "C" int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g, const MdvitBlockStreams* st, const float* x, const void* save, size_t save_bytes,
+                               const float* dy, float* dx, void* ws, size_t ws_bytes) {
+    MDVIT_CHECK_ARG(d && g && st && x && save && dy && ws, MDVIT_E_SHAPE, "block_bwd: null argument");
+    const int rc = check_desc(*d, "block_bwd");
+    if (rc != MDVIT_OK) return rc;
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(dy) && (!dx || aligned16(dx)) && (reinterpret_cast<uintptr_t>(save) & 255) == 0 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0,
+                    MDVIT_E_ALIGN, "block_bwd: x / dy / dx must be 16-byte, save / ws 256-byte aligned");
+    MDVIT_CHECK_ARG(save_bytes >= mdvit_block_save_bytes(d), MDVIT_E_WORKSPACE, "block_bwd: save buffer too small");
+    const size_t need = mdvit_block_bwd_ws_bytes(d, g, st->side != nullptr && st->side != st->main);
+    MDVIT_CHECK_ARG(ws_bytes >= need, MDVIT_E_WORKSPACE, "block_bwd: workspace too small: need %zu bytes (mdvit_block_bwd_ws_bytes), got %zu", need, ws_bytes);
+    if (!g->dgrad_only) {
+        MDVIT_CHECK_ARG(g->cpe_w && g->cpe_b && g->n1_g && g->n1_b && g->qkv_w && g->w3 && g->b3 && g->w5 && g->b5 && g->w7 && g->b7 && g->proj_w && g->proj_b && g->n2_g &&
+                            g->n2_b && g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b && (!d->qkv_b || g->qkv_b), MDVIT_E_SHAPE, "block_bwd: null gradient output");
+    }
+    MDVIT_CHECK_ARG(!d->label || (g->da_w1 && g->da_b1 && g->da_w2 && g->da_b2), MDVIT_E_SHAPE, "block_bwd: the adapter's gradient outputs are missing");
+    MDVIT_CHECK_ARG(d->precision == 0 || (d->qkv_wt && d->proj_wt && (mlp_mode(*d) == MLP_RC || (d->fc1_wt && d->fc2_wt))), MDVIT_E_SHAPE,
+                    "block_bwd: the bf16x3 data-gradient GEMMs need the transposed weights");
+    Arena SV{(char*)const_cast<void*>(save), 0, save_bytes, false}, A{(char*)ws, 0, ws_bytes, false};
+    return block_bwd(*d, *g, *st, x, dy, dx, SV, A);
+}

@@ -1849,6 +1849,175 @@ def domain_adapter(label, W1, b1, W2, b2, heads):
 
 
 # ------------------------------------------------------------------------------------------------
+# a whole SerialBlock_adapt pass as ONE C call (csrc/block.hip)
+# ------------------------------------------------------------------------------------------------
+# The same kernels in the same order as cpe -> layer_norm_fork -> linear -> factor_att -> linear -> layer_norm_fork -> mlp_residual above
+# (bit-identical results), but enqueued from C: one autograd node, three torch.empty and one ctypes call per pass instead of ~25
+# operator calls.  The host was the limit of the bs=4 step (30-38 ms of enqueue work against 31 ms of main-stream kernel time).
+_block_entry = os.environ.get("MDVIT_BLOCK_ENTRY", "1") != "0"
+_BLOCK_SINKABLE = (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 20, 21, 22, 23)        # indices into _lib.BLOCK_PARAMS: cpe, qkv, crpe windows, proj, fc1, fc2
+_BLOCK_FRESH = (2, 3, 12, 13, 14, 15, 18, 19)                                      # LayerNorm and adapter gradients: always handed to autograd
+_blk_events = None
+
+
+def _block_streams(side):
+    global _blk_events
+    if _blk_events is None:
+        n = 32
+        arr = (C.c_void_p * n)()
+        for i in range(n):
+            h = C.c_void_p()
+            call("mdvit_event_create", C.byref(h))
+            arr[i] = h.value
+        _blk_events = (arr, C.c_int32(0), n)
+    st = _lib.BlockStreams()
+    st.main = _stream()
+    st.side = C.c_void_p(side.cuda_stream) if side is not None else None
+    st.events = C.cast(_blk_events[0], C.POINTER(C.c_void_p))
+    st.n_events = _blk_events[2]
+    st.next_event = C.pointer(_blk_events[1])
+    return st
+
+
+def _side_protect(*tensors):
+    """main-stream tensors the side stream reads: keep them from being reused until the side work is done (what _on_side does)"""
+    ts = [t for t in tensors if t is not None]
+    for t in ts:
+        t.record_stream(_side_stream)
+    _side_keepalive.extend(ts)
+    marked = _side_blocks[-1][1] if _side_blocks else 0
+    if len(_side_keepalive) - marked >= 32 and not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record(_side_stream)
+        _side_blocks.append((ev, len(_side_keepalive)))
+        _release_finished_side_blocks()
+
+
+def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
+    H, W_, heads, splits, eps, drop_p, ln_groups = meta[:7]
+    B, N, Cn = x.shape
+    d = _lib.BlockDesc()
+    d.B, d.H, d.W, d.C, d.heads, d.hidden = B, H, W_, Cn, heads, params[20].shape[0]
+    d.s3, d.s5, d.s7 = splits
+    d.ln_groups = ln_groups
+    d.precision = min(_gemm_precision, 1)
+    d.eps, d.drop_p = eps, drop_p
+    d.key_proj[0], d.key_proj[1] = keys[0]
+    d.key_fc1[0], d.key_fc1[1] = keys[1]
+    d.key_fc2[0], d.key_fc2[1] = keys[2]
+    d.drop_seed = _seed_ptr() if drop_p > 0 else None
+    d.rowscale1, d.rowscale2 = _p(rs1), _p(rs2)
+    if label is not None:
+        d.label, d.D, d.da_hidden = _p(label), label.shape[1], params[12].shape[0]
+    for name, t in zip(_lib.BLOCK_PARAMS, params):
+        setattr(d, name, _p(t))
+    keep = []
+    W1, W2 = params[20], params[22]
+    if d.precision == 1 and _mlp_rc_ok(Cn, d.hidden, params[21], params[23], x, W1, W2, B * N):
+        p1, p2 = _wplanes(W1, False), _wplanes(W2, False)
+        d.fc1_p, d.fc2_p = _p(p1), _p(p2)
+        keep += [p1, p2]
+        if backward:
+            p3, p4 = _wplanes(W2, True), _wplanes(W1, True)
+            d.fc2t_p, d.fc1t_p = _p(p3), _p(p4)
+            keep += [p3, p4]
+        rc = True
+    else:
+        rc = False
+    if backward and d.precision == 1:
+        ts = [wt(params[4]), wt(params[16])] + ([] if rc else [wt(W1), wt(W2)])
+        d.qkv_wt, d.proj_wt = _p(ts[0]), _p(ts[1])
+        if not rc:
+            d.fc1_wt, d.fc2_wt = _p(ts[2]), _p(ts[3])
+        keep += ts
+    return d, keep
+
+
+class _SerialBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, label, rs1, rs2, meta, *params):
+        ctx.set_materialize_grads(False)
+        _chk(x, label, rs1, rs2, *params)
+        drop_p = meta[5]
+        keys = tuple(_next_key() if drop_p > 0 else (0, 0) for _ in range(3))          # proj, fc1, fc2: the order of the operator-level path
+        d, keep = _block_desc(x, label, rs1, rs2, meta, keys, params, False)
+        lib = _lib.load()
+        sb, wb = lib.mdvit_block_save_bytes(C.byref(d)), lib.mdvit_block_fwd_ws_bytes(C.byref(d))
+        if not sb:
+            raise _lib.MdvitHipError("mdvit_block_save_bytes: " + lib.mdvit_last_error().decode(errors="replace"))
+        save = _empty((sb // 4,), device=x.device, dtype=torch.float32)
+        ws = _empty((wb // 4,), device=x.device, dtype=torch.float32)
+        y = _empty_like(x)
+        call("mdvit_block_fwd", C.byref(d), _p(x), _p(y), _p(save), sb, _p(ws), wb, _stream())
+        del keep
+        ctx.save_for_backward(x, save, label, rs1, rs2, *params)
+        ctx.meta, ctx.keys = meta, keys
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n_in = 5 + len(_lib.BLOCK_PARAMS)
+        if g is None:
+            return (None,) * n_in
+        x, save, label, rs1, rs2, *params = ctx.saved_tensors
+        meta = ctx.meta
+        aux_first = meta[7]
+        g = _c(g)
+        dev = x.device
+        d, keep = _block_desc(x, label, rs1, rs2, meta, ctx.keys, params, True)
+        G = _lib.BlockGrads()
+        G.dgrad_only, G.aux_first = int(_dgrad_only), int(aux_first)
+        want_w = not _dgrad_only
+        out = [None] * len(params)
+        acc = False
+        if want_w:
+            sinks = [_sink_of(params[i]) if params[i] is not None else None for i in _BLOCK_SINKABLE]
+            acc = _side_stream is not None and all((s is not None) or (params[i] is None) for s, i in zip(sinks, _BLOCK_SINKABLE))
+        fresh_idx = [i for i in _BLOCK_FRESH if params[i] is not None and (want_w or 12 <= i <= 15)]
+        if want_w and not acc:
+            fresh_idx = sorted(fresh_idx + [i for i in _BLOCK_SINKABLE if params[i] is not None])
+        bufs = _flat_like(*[params[i] for i in fresh_idx]) if fresh_idx else []
+        for i, b in zip(fresh_idx, bufs):
+            out[i] = b
+            setattr(G, _lib.BLOCK_PARAMS[i], _p(b))
+        if acc:
+            for s_, i in zip(sinks, _BLOCK_SINKABLE):
+                if s_ is not None:
+                    setattr(G, _lib.BLOCK_PARAMS[i], _p(s_))
+        G.accumulate = int(acc)
+        stop_here = _dgrad_only and aux_first and label is not None
+        dx = _empty_like(x) if (ctx.needs_input_grad[0] and not stop_here) else None
+        side = _side_stream if (acc and want_w) else None
+        st = _block_streams(side)
+        wb = _lib.load().mdvit_block_bwd_ws_bytes(C.byref(d), C.byref(G), int(side is not None))
+        ws = _empty((wb // 4,), device=dev, dtype=torch.float32)
+        call("mdvit_block_bwd", C.byref(d), C.byref(G), C.byref(st), _p(x), _p(save), save.numel() * 4, _p(g), _p(dx), _p(ws), wb)
+        if side is not None:
+            _side_protect(ws, save, g, x, *keep)
+        del keep
+        return (dx, None, None, None, None, *out)
+
+
+def serial_block(x, label, rs1, rs2, meta, params):
+    """x [B, N, C] -> [B, N, C]: one SerialBlock_adapt (mdvit.py:346-361).  meta = (H, W, heads, head_splits, eps, drop_p, ln_groups, aux_first);
+    params in _lib.BLOCK_PARAMS order (the adapter's four are None without a domain label)."""
+    return _SerialBlock.apply(_c(x), None if label is None else _c(label.float()), rs1, rs2, meta, *params)
+
+
+def block_entry_ok(Cn, hidden, params) -> bool:
+    """the C-level block covers this configuration (otherwise: the operator-level path)"""
+    if not _block_entry or _gemm_precision > 1 or Cn % 4:
+        return False
+    if not all(p is None or (p.is_contiguous() and p.dtype == torch.float32) for p in params):
+        return False
+    if Cn == 64 and _gemm_precision == 1 and not (_mlp_rc and _mlp_recompute and hidden % 256 == 0 and hidden <= 4096):
+        return False                                   # round 2's fused C = 64 MLP kernels are reachable through the operator path only
+    if _gemm_precision == 1 and Cn <= 128 and not _mlp_recompute:
+        return False
+    return True
+
+
+# ------------------------------------------------------------------------------------------------
 # fused step losses on logits
 # ------------------------------------------------------------------------------------------------
 # Data parallelism: losses over the global batch (see mdvit_seg_losses_sums in the header).  On by default whenever a
