@@ -498,6 +498,8 @@ def main():
             "phase_ms": phase_ms, "roofline": roof, "cpu_baseline": cpu, "drift_vs_parity_mode": drift,
             "world": world, "rccl_ranks": rccl_ranks, "devices": devices,
             "allreduce": {"buckets": n_buckets, "issued_under_the_aux_sweep": overlapped_buckets},
+            "memory": {"peak_allocated_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2), "peak_reserved_gib": round(torch.cuda.max_memory_reserved() / 2**30, 2),
+                       "device_mallocs": int(torch.cuda.memory_stats().get("num_device_alloc", 0)), "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))},
         }
         line.update(extra)
         print(json.dumps(line), flush=True)

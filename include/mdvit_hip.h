@@ -267,9 +267,11 @@ typedef struct MdvitBlockStreams {
 size_t mdvit_block_save_bytes(const MdvitBlockDesc* d);
 size_t mdvit_block_fwd_ws_bytes(const MdvitBlockDesc* d);
 int mdvit_block_fwd(const MdvitBlockDesc* d, const float* x, float* y, void* save, size_t save_bytes, void* ws, size_t ws_bytes, void* stream);
-size_t mdvit_block_bwd_ws_bytes(const MdvitBlockDesc* d, const MdvitBlockGrads* g, int32_t with_side_stream);
+/* two backward workspaces: `ws` holds what only the main stream touches (free to reuse once the call has returned: stream order), `ws_side`
+ * (*side_bytes) what the side stream's weight-gradient kernels read -- the caller keeps that one alive until the side stream is done */
+size_t mdvit_block_bwd_ws_bytes(const MdvitBlockDesc* d, const MdvitBlockGrads* g, int32_t with_side_stream, size_t* side_bytes);
 int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g, const MdvitBlockStreams* st, const float* x, const void* save, size_t save_bytes,
-                    const float* dy, float* dx /* NULL: not wanted */, void* ws, size_t ws_bytes);
+                    const float* dy, float* dx /* NULL: not wanted */, void* ws, size_t ws_bytes, void* ws_side, size_t ws_side_bytes);
 
 /* y[m] (+)= dot(x[m,:K], w[:K]) + b   -- a 1-output-channel 1x1 conv (finalconv mdvit.py:589-591,
  * linear_out Decoders.py:311).  bwd: dx[m,k] = dy[m] w[k]; dw[k] = sum_m dy[m] x[m,k]; db = sum dy. */

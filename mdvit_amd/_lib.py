@@ -93,7 +93,7 @@ class BlockStreams(C.Structure):
 
 _SIGS = {
     "mdvit_block_fwd": [C.POINTER(BlockDesc), vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp],
-    "mdvit_block_bwd": [C.POINTER(BlockDesc), C.POINTER(BlockGrads), C.POINTER(BlockStreams), vp, vp, C.c_size_t, vp, vp, vp, C.c_size_t],
+    "mdvit_block_bwd": [C.POINTER(BlockDesc), C.POINTER(BlockGrads), C.POINTER(BlockStreams), vp, vp, C.c_size_t, vp, vp, vp, C.c_size_t, vp, C.c_size_t],
     "mdvit_gemm_planes": [C.POINTER(PlaneGemmDesc), vp],
     "mdvit_gemm_planes_plan": [C.POINTER(PlaneGemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_planes_force_plan": [i32, i32],
@@ -232,7 +232,7 @@ def load():
     lib.mdvit_block_fwd_ws_bytes.restype = C.c_size_t
     lib.mdvit_block_fwd_ws_bytes.argtypes = [C.POINTER(BlockDesc)]
     lib.mdvit_block_bwd_ws_bytes.restype = C.c_size_t
-    lib.mdvit_block_bwd_ws_bytes.argtypes = [C.POINTER(BlockDesc), C.POINTER(BlockGrads), i32]
+    lib.mdvit_block_bwd_ws_bytes.argtypes = [C.POINTER(BlockDesc), C.POINTER(BlockGrads), i32, C.POINTER(C.c_size_t)]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t
     lib.mdvit_da_ws_bytes.argtypes = [i32, i32, i32]
     for name, sig in _SIGS.items():

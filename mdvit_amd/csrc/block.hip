@@ -165,7 +165,9 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
     return MDVIT_OK;
 }
 
-int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBlockStreams& st, const float* x, const float* dy, float* dx, Arena& SV, Arena& A) {
+// A: temporaries only the main stream touches (the caller may free them when the call returns: stream-ordered reuse); S: everything a
+// side-stream kernel reads or writes (must stay alive until the side stream has finished)
+int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBlockStreams& st, const float* x, const float* dy, float* dx, Arena& SV, Arena& A, Arena& S) {
     const int B = d.B, H = d.H, W = d.W, C = d.C, Hd = d.hidden;
     const long T = (long)B * H * W;
     const int M = (int)T, N_tok = H * W;
@@ -187,8 +189,9 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
 
     // ---- MLP --------------------------------------------------------------------------------------------------------------------
     const bool masked = d.drop_p > 0.f || d.rowscale2 != nullptr;
-    float* gm2 = masked ? A.take(T * C) : const_cast<float*>(dy);
-    float* dcur2 = A.take(T * C);
+    float* gm2 = masked ? S.take(T * C) : const_cast<float*>(dy);
+    float* tmp = A.take(T * C);              // dcur2, then datt, then dcur1: consecutive lifetimes on the main stream
+    float* dcur2 = tmp;
     float* du = nullptr;
     if (mode == MLP_RC) {
         if (masked || want_w) {
@@ -200,14 +203,14 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         BLK_RUN(mdvit_mlp_rc_dgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
         if (want_w) {
             const size_t wb = mdvit_mlp_rc_wgrad_ws_bytes(M, C, Hd);
-            void* ww = A.take_bytes(wb);
+            void* ww = S.take_bytes(wb);
             if (!A.dry) { const int rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
             BLK_RUN(mdvit_mlp_rc_wgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, G.fc1_w, G.fc1_b, G.fc2_w, ww, wb, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed,
                                        acc, side));
         }
     } else {
         if (masked) BLK_RUN(mdvit_colsum_f32(dy, C, nullptr, gm2, nullptr, 0, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok, 0, seed, s));
-        du = A.take(T * Hd);
+        du = S.take(T * Hd);
         MdvitGemmDesc g;
         gemm_init(g, d);
         g.epi = MDVIT_EPI_DGELU; g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc1[0]; g.e_key1 = d.key_fc1[1]; g.drop_seed = seed;
@@ -222,13 +225,13 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         if (rc != MDVIT_OK) return rc;
         if (want_w) {
             if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
-            rc = gemm_wgrad(A, d, gm2, sv.h, G.fc2_w, G.fc2_b, M, C, Hd, acc, side);
-            if (rc == MDVIT_OK) rc = gemm_wgrad(A, d, du, sv.cur2, G.fc1_w, G.fc1_b, M, Hd, C, acc, side);
+            rc = gemm_wgrad(S, d, gm2, sv.h, G.fc2_w, G.fc2_b, M, C, Hd, acc, side);
+            if (rc == MDVIT_OK) rc = gemm_wgrad(S, d, du, sv.cur2, G.fc1_w, G.fc1_b, M, Hd, C, acc, side);
             if (rc != MDVIT_OK) return rc;
         }
     }
     // ---- LN2 (+ the residual branch's gradient, which is dy itself) ---------------------------------------------------------------
-    float* dx2 = A.take(T * C);
+    float* dx2 = (d.drop_p > 0.f || d.rowscale1 != nullptr) ? A.take(T * C) : S.take(T * C);      // (unmasked: it IS the proj weight gradient's operand)
     {
         const bool lnw = want_w || !fast_ln;
         const size_t pb = lnw ? mdvit_partials_ws_bytes(2 * C) : 0;
@@ -239,9 +242,9 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
     }
     // ---- proj Linear: masked upstream gradient once, data gradient, weight gradient (side) ------------------------------------------
     const bool masked1 = d.drop_p > 0.f || d.rowscale1 != nullptr;
-    float* gm1 = masked1 ? A.take(T * C) : dx2;
+    float* gm1 = masked1 ? S.take(T * C) : dx2;
     if (masked1) BLK_RUN(mdvit_colsum_f32(dx2, C, nullptr, gm1, nullptr, 0, M, C, d.drop_p, d.key_proj[0], d.key_proj[1], d.rowscale1, N_tok, 0, seed, s));
-    float* datt = A.take(T * C);
+    float* datt = tmp;
     {
         MdvitGemmDesc g;
         gemm_init(g, d);
@@ -250,13 +253,13 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         if (rc != MDVIT_OK) return rc;
         if (want_w) {
             if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
-            rc = gemm_wgrad(A, d, gm1, sv.att, G.proj_w, G.proj_b, M, C, C, acc, side);
+            rc = gemm_wgrad(S, d, gm1, sv.att, G.proj_w, G.proj_b, M, C, C, acc, side);
             if (rc != MDVIT_OK) return rc;
         }
     }
     // ---- attention core + adapter ---------------------------------------------------------------------------------------------------
     const size_t fab = mdvit_factoratt_ws_bytes(B, N_tok, C, d.heads);
-    void* faws = A.take_bytes(fab);
+    void* faws = S.take_bytes(fab);            // holds dU, which the deferred window-weight gradients read
     float* e = d.label ? A.take((long)B * C) : nullptr;
     if (dgrad_only && G.aux_first && d.label) {
         // the first adapter of the network in the data-gradient-only sweep: e = sum_n g * att alone, the adapter's (negated) gradient, and
@@ -268,7 +271,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         BLK_RUN(mdvit_da_bwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, e, -1.0f, G.da_w1, G.da_b1, G.da_w2, G.da_b2, daws, dab, B, d.D, d.da_hidden, C, d.heads, s));
         return MDVIT_OK;
     }
-    float* dqkv = A.take(T * 3 * C);
+    float* dqkv = S.take(T * 3 * C);
     {
         // window-weight gradients: deferred to the side stream when they accumulate into buckets (they read dU in the SAME workspace and v);
         // otherwise produced by the backward call itself, into the fresh buffers
@@ -290,7 +293,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
                              d.da_hidden, C, d.heads, s));
     }
     // ---- qkv Linear -----------------------------------------------------------------------------------------------------------------
-    float* dcur1 = A.take(T * C);
+    float* dcur1 = tmp;
     {
         MdvitGemmDesc g;
         gemm_init(g, d);
@@ -299,12 +302,12 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         if (rc != MDVIT_OK) return rc;
         if (want_w) {
             if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
-            rc = gemm_wgrad(A, d, dqkv, sv.cur1, G.qkv_w, G.qkv_b, M, 3 * C, C, acc, side);
+            rc = gemm_wgrad(S, d, dqkv, sv.cur1, G.qkv_w, G.qkv_b, M, 3 * C, C, acc, side);
             if (rc != MDVIT_OK) return rc;
         }
     }
     // ---- LN1 (+ dx2 along the residual branch) ------------------------------------------------------------------------------------
-    float* dx1 = A.take(T * C);
+    float* dx1 = S.take(T * C);
     {
         const bool lnw = want_w || !fast_ln;
         const size_t pb = lnw ? mdvit_partials_ws_bytes(2 * C) : 0;
@@ -317,7 +320,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
     if (dx) BLK_RUN(mdvit_dwconv3x3_bwd(dx1, x, d.cpe_w, dx, nullptr, nullptr, nullptr, 0, B, H, W, C, 1, 1, 0, s));
     if (want_w) {
         const size_t pb = mdvit_partials_ws_bytes(10 * C);
-        void* pw = A.take_bytes(pb);
+        void* pw = S.take_bytes(pb);
         if (acc && !A.dry) { const int rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
         BLK_RUN(mdvit_dwconv3x3_bwd(dx1, x, d.cpe_w, nullptr, G.cpe_w, G.cpe_b, pw, pb, B, H, W, C, 1, 1, acc, acc ? side : s));
     }
@@ -366,27 +369,31 @@ extern "C" int mdvit_block_fwd(const MdvitBlockDesc* d, const float* x, float* y
     return block_fwd(*d, x, y, SV, A, (hipStream_t)stream);
 }
 
-extern "C" size_t mdvit_block_bwd_ws_bytes(const MdvitBlockDesc* d, const MdvitBlockGrads* g, int32_t with_side_stream) {
+extern "C" size_t mdvit_block_bwd_ws_bytes(const MdvitBlockDesc* d, const MdvitBlockGrads* g, int32_t with_side_stream, size_t* side_bytes) {
+    if (side_bytes) *side_bytes = 0;
     if (!d || !g || check_desc(*d, "block_bwd_ws_bytes") != MDVIT_OK) return 0;
-    Arena SV{nullptr, 0, 0, true}, A{nullptr, 0, 0, true};
+    Arena SV{nullptr, 0, 0, true}, A{nullptr, 0, 0, true}, S{nullptr, 0, 0, true};
     MdvitBlockStreams st;
     memset(&st, 0, sizeof(st));
     st.main = (void*)1; st.side = with_side_stream ? (void*)2 : (void*)1;          // only compared, never used: the run is dry
     float dummy = 0.f;
-    if (block_bwd(*d, *g, st, nullptr, &dummy, &dummy, SV, A) != MDVIT_OK) return 0;
+    if (block_bwd(*d, *g, st, nullptr, &dummy, &dummy, SV, A, S) != MDVIT_OK) return 0;
+    if (side_bytes) *side_bytes = S.off + 256;
     return A.off + 256;
 }
 
 extern "C" int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g, const MdvitBlockStreams* st, const float* x, const void* save, size_t save_bytes,
-                               const float* dy, float* dx, void* ws, size_t ws_bytes) {
-    MDVIT_CHECK_ARG(d && g && st && x && save && dy && ws, MDVIT_E_SHAPE, "block_bwd: null argument");
+                               const float* dy, float* dx, void* ws, size_t ws_bytes, void* ws_side, size_t ws_side_bytes) {
+    MDVIT_CHECK_ARG(d && g && st && x && save && dy && ws && ws_side, MDVIT_E_SHAPE, "block_bwd: null argument");
     const int rc = check_desc(*d, "block_bwd");
     if (rc != MDVIT_OK) return rc;
-    MDVIT_CHECK_ARG(aligned16(x) && aligned16(dy) && (!dx || aligned16(dx)) && (reinterpret_cast<uintptr_t>(save) & 255) == 0 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0,
-                    MDVIT_E_ALIGN, "block_bwd: x / dy / dx must be 16-byte, save / ws 256-byte aligned");
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(dy) && (!dx || aligned16(dx)) && (reinterpret_cast<uintptr_t>(save) & 255) == 0 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 &&
+                        (reinterpret_cast<uintptr_t>(ws_side) & 255) == 0, MDVIT_E_ALIGN, "block_bwd: x / dy / dx must be 16-byte, save / ws 256-byte aligned");
     MDVIT_CHECK_ARG(save_bytes >= mdvit_block_save_bytes(d), MDVIT_E_WORKSPACE, "block_bwd: save buffer too small");
-    const size_t need = mdvit_block_bwd_ws_bytes(d, g, st->side != nullptr && st->side != st->main);
-    MDVIT_CHECK_ARG(ws_bytes >= need, MDVIT_E_WORKSPACE, "block_bwd: workspace too small: need %zu bytes (mdvit_block_bwd_ws_bytes), got %zu", need, ws_bytes);
+    size_t need_side = 0;
+    const size_t need = mdvit_block_bwd_ws_bytes(d, g, st->side != nullptr && st->side != st->main, &need_side);
+    MDVIT_CHECK_ARG(ws_bytes >= need && ws_side_bytes >= need_side, MDVIT_E_WORKSPACE,
+                    "block_bwd: workspace too small: need %zu + %zu bytes (mdvit_block_bwd_ws_bytes), got %zu + %zu", need, need_side, ws_bytes, ws_side_bytes);
     if (!g->dgrad_only) {
         MDVIT_CHECK_ARG(g->cpe_w && g->cpe_b && g->n1_g && g->n1_b && g->qkv_w && g->w3 && g->b3 && g->w5 && g->b5 && g->w7 && g->b7 && g->proj_w && g->proj_b && g->n2_g &&
                             g->n2_b && g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b && (!d->qkv_b || g->qkv_b), MDVIT_E_SHAPE, "block_bwd: null gradient output");
@@ -394,6 +401,6 @@ extern "C" int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g
     MDVIT_CHECK_ARG(!d->label || (g->da_w1 && g->da_b1 && g->da_w2 && g->da_b2), MDVIT_E_SHAPE, "block_bwd: the adapter's gradient outputs are missing");
     MDVIT_CHECK_ARG(d->precision == 0 || (d->qkv_wt && d->proj_wt && (mlp_mode(*d) == MLP_RC || (d->fc1_wt && d->fc2_wt))), MDVIT_E_SHAPE,
                     "block_bwd: the bf16x3 data-gradient GEMMs need the transposed weights");
-    Arena SV{(char*)const_cast<void*>(save), 0, save_bytes, false}, A{(char*)ws, 0, ws_bytes, false};
-    return block_bwd(*d, *g, *st, x, dy, dx, SV, A);
+    Arena SV{(char*)const_cast<void*>(save), 0, save_bytes, false}, A{(char*)ws, 0, ws_bytes, false}, S{(char*)ws_side, 0, ws_side_bytes, false};
+    return block_bwd(*d, *g, *st, x, dy, dx, SV, A, S);
 }

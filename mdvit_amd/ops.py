@@ -1989,11 +1989,13 @@ class _SerialBlock(torch.autograd.Function):
         dx = _empty_like(x) if (ctx.needs_input_grad[0] and not stop_here) else None
         side = _side_stream if (acc and want_w) else None
         st = _block_streams(side)
-        wb = _lib.load().mdvit_block_bwd_ws_bytes(C.byref(d), C.byref(G), int(side is not None))
-        ws = _empty((wb // 4,), device=dev, dtype=torch.float32)
-        call("mdvit_block_bwd", C.byref(d), C.byref(G), C.byref(st), _p(x), _p(save), save.numel() * 4, _p(g), _p(dx), _p(ws), wb)
+        sbytes = C.c_size_t(0)
+        wb = _lib.load().mdvit_block_bwd_ws_bytes(C.byref(d), C.byref(G), int(side is not None), C.byref(sbytes))
+        ws = _empty((wb // 4,), device=dev, dtype=torch.float32)                  # main-stream temporaries: released when this function returns
+        ws_side = _empty((sbytes.value // 4,), device=dev, dtype=torch.float32)   # what the weight-gradient kernels read: kept until the side stream is done
+        call("mdvit_block_bwd", C.byref(d), C.byref(G), C.byref(st), _p(x), _p(save), save.numel() * 4, _p(g), _p(dx), _p(ws), wb, _p(ws_side), sbytes.value)
         if side is not None:
-            _side_protect(ws, save, g, x, *keep)
+            _side_protect(ws_side, save, g, x, *keep)
         del keep
         return (dx, None, None, None, None, *out)
 
