@@ -370,7 +370,8 @@ class droppath_pool:
         n, B, keep, device, enabled = self.args
         self.prev = _droppath_pool
         if enabled and keep < 1.0:
-            _droppath_pool = {"m": (torch.rand((n, 2, B), device=device) < keep).float() / keep, "keep": keep, "B": B, "next": 0}
+            m = ops.droppath_scales((n, 2, B), keep, device) if torch.device(device).type == "cuda" else (torch.rand((n, 2, B), device=device) < keep).float() / keep
+            _droppath_pool = {"m": m, "keep": keep, "B": B, "next": 0}
         return self
 
     def __exit__(self, *exc):
@@ -415,8 +416,8 @@ class SerialBlock_adapt(nn.Module):
             m = pool["m"][pool["next"]]            # pre-drawn for the whole forward (one torch.rand instead of one per block)
             pool["next"] += 1
             return m[0], m[1]
-        m = (torch.rand((2, B), device=device) < keep).float() / keep      # per-sample masks for both branches
-        return m[0].contiguous(), m[1].contiguous()
+        m = ops.droppath_scales((2, B), keep, device)                      # per-sample masks for both branches
+        return m[0], m[1]
 
     def _block_entry(self, x, size, domain_label, use_da):
         """the whole block as one C call (ops.serial_block), or None when the configuration needs the operator-level path"""

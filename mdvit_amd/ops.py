@@ -1394,6 +1394,32 @@ class _Dropout(torch.autograd.Function):
         return dx, None, None
 
 
+def droppath_scales(shape, keep: float, device):
+    """Per-sample DropPath scales (Bernoulli(keep) / keep, timm's drop_path as used by mdvit.py:353-360) for a whole forward in ONE launch of the
+    counter-hash dropout kernel on a cached tensor of ones -- no torch.rand / compare / divide on the path; under HIP-graph replay the device
+    seed re-keys them like every other mask."""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    n4 = (n + 3) // 4 * 4                              # the kernel works on quads
+    ones = _ones_flat(n4, device)
+    y = torch.empty((n4,), device=device, dtype=torch.float32)
+    key = _next_key()
+    call("mdvit_dropout_f32", _p(ones), _p(y), n4, 1.0 - float(keep), key[0], key[1], _seed_ptr(), _stream())
+    return y[:n].view(*shape)
+
+
+_ones_cache = {}
+
+
+def _ones_flat(n, device):
+    k = (str(device), n)
+    t = _ones_cache.get(k)
+    if t is None:
+        t = _ones_cache[k] = torch.ones((n,), device=device, dtype=torch.float32)
+    return t
+
+
 def dropout(x, p: float, training: bool = True):
     if not training or p <= 0.0:
         return x

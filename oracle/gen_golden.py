@@ -318,9 +318,10 @@ def gen_transfuse_step(ns_unused=None, S=256, B=2, seed=12):
     """BASELINE configs[4]: the reference's TransFuse_S_adapt (drop_rate = 0, train mode) on two domains x B images at its only legal size
     256x256 (TransFuse.py:228-270), step loss 0.5 SL(map_2) + 0.3 SL(map_1) + 0.2 SL(map_x) with structure_loss
     (multi_train_TransFuse.py:29-38,162-172), ONE backward of the sum (:186-189)."""
-    from .ref_import import import_transfuse
+    from .ref_import import import_transfuse, lift_function
     from . import transfuse_ref as T
     tf = import_transfuse()
+    structure_loss = lift_function("multi_train_TransFuse.py", "structure_loss", {"torch": torch, "F": F})      # the reference's own function (:29-38)
     pn = T.make_params(seed)
     m = tf.TransFuse_S_adapt(num_classes=1, drop_rate=0.0, normal_init=False, pretrained=False, num_domains=4)
     sd = m.state_dict()
@@ -333,7 +334,7 @@ def gen_transfuse_step(ns_unused=None, S=256, B=2, seed=12):
         img, lab = synth_image(1200 + d, B, S, S), synth_label(1300 + d, B, S, S)
         dl = F.one_hot(torch.full((B,), d, dtype=torch.long), 4).float()
         m4, m3, m2 = m(img, dl)
-        l = 0.5 * T.structure_loss(m2, lab) + 0.3 * T.structure_loss(m3, lab) + 0.2 * T.structure_loss(m4, lab)
+        l = 0.5 * structure_loss(m2, lab) + 0.3 * structure_loss(m3, lab) + 0.2 * structure_loss(m4, lab)
         out[f"loss_{d}"] = np.array(float(l))
         for nm, t in (("map_x", m4), ("map_1", m3), ("map_2", m2)):
             out[f"{nm}_{d}"] = _sample(t, 61)

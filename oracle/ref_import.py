@@ -184,3 +184,21 @@ def import_transfuse():
         sys.path.insert(0, REFERENCE_ROOT)
     from Models.Hybrid_models.TransFuseFolder import TransFuse as ref_tf
     return types.SimpleNamespace(TransFuse_S_adapt=ref_tf.TransFuse_S_adapt, module=ref_tf)
+
+
+def lift_function(rel_path: str, name: str, namespace: dict):
+    """The function `name` of a reference SCRIPT that cannot be imported (multi_train_TransFuse.py builds its datasets and trains at import
+    time): the FunctionDef node is cut out of the script's syntax tree and compiled on its own in `namespace` -- the fixture's loss is then
+    the reference's own text, not a restatement.  Nothing of the script is executed or copied into this repository."""
+    import ast
+    import os
+    path = os.path.join(REFERENCE_ROOT, rel_path)
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = dict(namespace)
+            exec(compile(mod, path, "exec"), ns)
+            return ns[name]
+    raise KeyError(f"{name} not found in {path}")

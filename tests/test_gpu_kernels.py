@@ -179,6 +179,24 @@ def test_linear_dropout_droppath_statistics_and_backward_mask():
     assert (y2 != y.detach()).any()
 
 
+def test_droppath_scales_from_the_counter_hash(monkeypatch):
+    """ops.droppath_scales: per-sample Bernoulli(keep) / keep scales (timm drop_path in mdvit.py:353-360) drawn by the dropout kernel's
+    counter hash -- values in {0, 1 / keep}, keep rate within 4 sigma, repeatable for equal keys, different for the next key"""
+    from mdvit_amd import ops
+    import itertools
+    keep, n = 0.9, 40002
+    monkeypatch.setattr(ops, "_key_counter", itertools.count(300))
+    a = ops.droppath_scales((n // 2, 2), keep, dev())
+    monkeypatch.setattr(ops, "_key_counter", itertools.count(300))
+    b = ops.droppath_scales((n // 2, 2), keep, dev())
+    c = ops.droppath_scales((n // 2, 2), keep, dev())
+    assert a.shape == (n // 2, 2) and torch.equal(a, b) and not torch.equal(a, c)
+    vals = torch.unique(a).cpu().tolist()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / keep) < 1e-6
+    rate = float((a > 0).float().mean())
+    assert abs(rate - keep) < 4 * (keep * (1 - keep) / n) ** 0.5, rate
+
+
 @pytest.mark.parametrize("M,C,r", [(512, 64, 8), (130, 128, 8), (64, 320, 4), (16, 512, 4)])
 def test_mlp_residual(M, C, r, gemm_precision):
     from mdvit_amd import ops

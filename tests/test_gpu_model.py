@@ -719,33 +719,48 @@ from mdvit_amd.parallel import GradAccumulator, broadcast_parameters
 from mdvit_amd.synthetic import make_step_batches
 from mdvit_amd.train import mdvit_train_step
 res = []
-for force in (False, True):
+# (collectives forced?, adapters in late buckets?, repeats).  The last configuration is bench.py's: every bucket but the adapters' goes on
+# the wire (RCCL, issued from the side stream's context) when the FULL sweep ends and is reduced underneath the aux sweep, which runs on a
+# stream of its own; repeated, because a missing cross-stream dependency shows as run-to-run drift.
+for force, late, reps in ((False, False, 1), (True, False, 1), (True, True, 3)):
     ops._force_collectives = force            # RCCL all-reduce of the loss sums and of the gradient buckets, world = 1
-    torch.manual_seed(0)
-    m = mdvit_amd.MDViT(img_size=64, drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup",
-                        num_domains=4, decoder_name="MLPFM").cuda().train()
-    for d in range(1, 5):
-        getattr(m, f"debranch{d}").dropout.p = 0.0
-    broadcast_parameters(m)
-    ops.enable_side_stream(True)
-    acc = GradAccumulator(m.parameters()); acc.attach_sinks()
-    b = make_step_batches(2, 64, rank=0, step=0, device=torch.device("cuda", 0))
-    out = mdvit_train_step(m, b, optimizer=None, accumulator=acc, merged_sweeps=True, fuse_domains=4)
-    torch.cuda.synchronize()
-    res.append(([float(out[k]) for k in ("loss", "aux_loss", "kt_loss")], [p.grad.clone() for p in m.parameters()]))
-    ops.set_grad_sinks(None); ops.enable_side_stream(False)
-for a, b in zip(res[0][0], res[1][0]):
-    assert abs(a - b) <= 1e-5 * abs(a), (res[0][0], res[1][0])
-worst = max(float((x - y).norm() / (y.norm() + 1e-20)) for x, y in zip(res[1][1], res[0][1]))
-assert worst < 2e-3, worst
+    for rep in range(reps):
+        torch.manual_seed(0)
+        m = mdvit_amd.MDViT(img_size=64, drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup",
+                            num_domains=4, decoder_name="MLPFM").cuda().train()
+        for d in range(1, 5):
+            getattr(m, f"debranch{d}").dropout.p = 0.0
+        broadcast_parameters(m)
+        ops.enable_side_stream(True)
+        da = [p for n, p in m.named_parameters() if "domain_layer" in n]
+        acc = GradAccumulator(m.parameters(), bucket_bytes=4 << 20, late=da if late else None); acc.attach_sinks()
+        b = make_step_batches(2, 64, rank=0, step=0, device=torch.device("cuda", 0))
+        out = mdvit_train_step(m, b, optimizer=None, accumulator=acc, merged_sweeps=True, fuse_domains=4)
+        torch.cuda.synchronize()
+        if late:
+            n_early = acc._n_early
+            assert n_early > 1 and len(acc.reducer.buckets) > n_early, (n_early, len(acc.reducer.buckets))
+            assert acc.overlapped_buckets == n_early, (acc.overlapped_buckets, n_early)        # all of them went on the wire under the aux sweep
+        res.append(([float(out[k]) for k in ("loss", "aux_loss", "kt_loss")], [p.grad.clone() for p in m.parameters()]))
+        ops.set_grad_sinks(None); ops.enable_side_stream(False)
+for r in res[1:]:
+    for a, b in zip(res[0][0], r[0]):
+        assert abs(a - b) <= 1e-5 * abs(a), (res[0][0], r[0])
+    worst = max(float((x - y).norm() / (y.norm() + 1e-20)) for x, y in zip(r[1], res[0][1]))
+    assert worst < 2e-3, worst
+# the three overlapped runs against each other: bitwise but for the float atomics of the window / depthwise weight gradients and the adapter's e
+drift = max(float((x - y).abs().max() / (y.abs().max() + 1e-20)) for r in res[3:] for x, y in zip(r[1], res[2][1]))
+assert drift < 1e-5, drift
 dist.barrier(); dist.destroy_process_group()
-print("dp-path ok", worst)
+print("dp-path ok", worst, drift)
 """
 
 
 def test_data_parallel_code_path_on_one_gpu(tmp_path):
     """the collective code paths of the DP step (RCCL all-reduce of the 16 loss sums per domain and of the gradient buckets,
-    side-stream weight gradients into the buckets) run in a 1-rank NCCL group and reproduce the plain step"""
+    side-stream weight gradients into the buckets) run in a 1-rank NCCL group and reproduce the plain step -- including the OVERLAPPED
+    form bench.py runs: the adapters in `late=` buckets, every other bucket launched from the side stream's context when the full sweep
+    ends (multi_train_MDViT.py:72-74's DataParallel replaced), three times over to catch a missing cross-stream dependency"""
     import subprocess, sys
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
