@@ -989,6 +989,71 @@ def test_bs32_shape_fused_128_image_forward_matches_per_domain_forwards():
             check(a[d * B:(d + 1) * B, :, ::37, ::41], per[d][1], tol=1e-4, name=f"fused aux, domain {d}")
 
 
+def test_bs32_full_step_fused_128_images_equals_four_per_domain_steps():
+    """BASELINE configs[2]'s per-GPU step, exactly as bench.py --batch 32 runs it: ONE 128-image domain-batched forward at 512x512, merged
+    sweeps (full sweep + data-gradient-only aux sweep on its own stream), weight gradients on the side stream into the bucket sinks, the
+    adapters in late buckets -- split-K weight gradients over 2 M tokens, tensors beyond 4 GiB in every backward kernel -- against four
+    32-image per-domain forwards + sweeps with the same weights: the three summed losses and EVERY gradient tensor."""
+    from mdvit_amd.synthetic import make_step_batches
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~200 GB of free HBM")
+    batches = make_step_batches(32, 512, rank=0, step=0, device=dev())
+    res = []
+    for fuse, side in ((4, True), (1, False)):
+        m = build_mdvit(37, 512).train()
+        res.append(_bench_step(m, batches, fuse, side))
+        del m
+        torch.cuda.empty_cache()
+    (la, ga), (lb, gb) = res
+    for k in ("loss", "aux_loss", "kt_loss"):
+        assert np.isfinite(la[k]) and abs(la[k] - lb[k]) <= 1e-4 * abs(lb[k]), (k, la[k], lb[k])
+    bad = []
+    for n in ga:
+        assert torch.isfinite(ga[n]).all(), n
+        try:
+            check_grad(ga[n], gb[n], name=n, l2_tol=3e-3, max_tol=6e-2)
+        except AssertionError as exc:
+            bad.append(str(exc))
+    assert not bad, f"{len(bad)} gradient tensors differ between the fused 128-image step and the per-domain steps: {bad[:6]}"
+
+
+def test_bs16_step_in_the_bf16_mode_at_512_is_finite_and_within_its_drift_bound():
+    """BASELINE configs[3] ("bs=16, mixed bf16 / fp32 loss"): the 64-image fused step at 512x512 with the GEMMs in the bf16 speed mode (one
+    bf16 plane per operand; norms, softmax, losses and storage fp32) against the same step in the parity arithmetic (bf16x3): everything
+    finite, the three losses within 2e-2, the logits of the first images within 5e-2 -- the bound test_bf16_speed_mode_drift... holds at 64x64."""
+    from mdvit_amd import ops
+    from mdvit_amd.synthetic import make_step_batches
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * (1 << 30):
+        pytest.skip("needs ~120 GB of free HBM")
+    batches = make_step_batches(16, 512, rank=0, step=0, device=dev())
+    prev = ops.gemm_precision()
+    res = {}
+    try:
+        for mode in ("bf16x3", "bf16"):
+            ops.set_gemm_precision(mode)
+            m = build_mdvit(41, 512).train()
+            losses, grads = _bench_step(m, batches, 4, True)
+            with torch.no_grad():
+                m.eval()
+                o, a = m(batches[1][0][:2], F.one_hot(torch.full((2,), 1, dtype=torch.long), 4).float().to(dev()), "1")
+            res[mode] = (losses, grads, o.clone(), a.clone())
+            del m
+            torch.cuda.empty_cache()
+    finally:
+        ops.set_gemm_precision(prev)
+    lx, gx, ox, ax = res["bf16x3"]
+    lb, gb, ob, ab = res["bf16"]
+    assert all(np.isfinite(v) for v in lb.values()) and all(torch.isfinite(g).all() for g in gb.values())
+    e_loss = max(abs(lb[k] - lx[k]) / abs(lx[k]) for k in ("loss", "aux_loss", "kt_loss"))
+    e_out, e_aux = relerr(ob, ox), relerr(ab, ax)
+    worst = max(float((gb[n].double() - gx[n].double()).norm() / max(float(gx[n].double().norm()), 1e-30)) for n in gx if float(gx[n].abs().max()) > 1e-7)
+    print(f"bf16 speed mode at bs=16, 512x512 vs bf16x3: losses {e_loss:.2e}, logits {e_out:.2e} / {e_aux:.2e}, worst gradient tensor rel L2 {worst:.2e}")
+    assert e_loss <= 2e-2 and e_out <= 5e-2 and e_aux <= 5e-2, (e_loss, e_out, e_aux)
+    assert e_out > 1e-5
+
+
 def test_gradients_away_from_activation_kinks_match_tightly():
     """Why the whole-model gradient tolerances are 1e-2 / 6 %: the residual error IS mask flips at the ReLU / Hardswish kinks.
     The oracle reports, per BatchNorm output, the distance to the activation's kink; with inputs whose smallest distance is far above

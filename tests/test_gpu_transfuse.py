@@ -209,7 +209,7 @@ def compare_grads(got, ref, precision):
     and the gradients with them -- median 1.6e-2, worst multi-element tensor 3.9e-2, one-element tensors up to 0.25.  Tensors that are
     analytically zero (conv biases in front of a train-mode BatchNorm) hold round-off only and are skipped."""
     big = max(float(v.double().norm()) for v in ref.values() if v is not None)
-    med_tol, tol, tol1 = (6e-3, 2e-2, 8e-2) if precision == "fp32" else (3e-2, 8e-2, 0.4)
+    med_tol, tol, tol1 = (6e-3, 2e-2, 8e-2) if precision == "fp32" else (3e-2, 6e-2, 0.4)      # calibrated: test_transfuse_gradient_error_is_the_round_off_class_...
     errs, bad = [], []
     for n, g_ in got.items():
         r = ref.get(n)
@@ -310,6 +310,55 @@ def test_transfuse_train_step_harness_vs_oracle(gemm_precision):
     compare_grads(got, grads, gemm_precision)
 
 
+def test_transfuse_gradient_error_is_the_round_off_class_of_the_reference_arithmetic(gemm_precision):
+    """Why compare_grads allows 2e-2 (fp32 GEMMs) / 8e-2 (bf16x3) per tensor.  MDViT has a kink-margin test: an input on which no BatchNorm
+    output sits within round-off of its activation's kink, where all gradients agree at 2e-4.  TransFuse offers no such input -- two 256x256
+    images push ~2e7 values through ReLU / max-pool / channel-max, the closest one always lies within fp32 round-off of its kink -- so the
+    allowance is CALIBRATED instead: the oracle is run in fp64 (the derivative masks of exact arithmetic) and in fp32 (the reference's own
+    arithmetic).  The distance of the fp32 oracle from the fp64 one is what two correct implementations differ by; the HIP step must sit in
+    the same class: median and 90th percentile of its per-tensor error against fp64 within a small factor of the fp32 oracle's."""
+    from mdvit_amd import ops
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.transfuse import transfuse_train_step
+    from oracle import transfuse_ref as R
+    from oracle.gen_golden import synth_image, synth_label
+    B, S = 2, 256
+    m, pn = _build(9)
+    m.train()
+    batches_cpu = [(synth_image(4200 + d, B, S, S), synth_label(4300 + d, B, S, S), d) for d in (1, 2)]
+    acc = GradAccumulator(m.parameters()); acc.attach_sinks(); ops.enable_side_stream(True)
+    try:
+        transfuse_train_step(m, [(i.to(dev()), l.to(dev()), torch.full((B,), d, dtype=torch.long)) for i, l, d in batches_cpu], accumulator=acc)
+        torch.cuda.synchronize()
+        got = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
+    finally:
+        ops.enable_side_stream(False); ops.set_grad_sinks(None)
+    _, g32 = R.transfuse_train_step(R.to_torch(pn), batches_cpu, R.TFState(training=True))
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in R.to_torch(pn).items()}
+    _, g64 = R.transfuse_train_step(P64, [(i.double(), l.double(), d) for i, l, d in batches_cpu], R.TFState(training=True))
+    big = max(float(v.norm()) for v in g64.values() if v is not None)
+    e_hip, e_ref = [], []
+    for n, r in g64.items():
+        if r is None or float(r.norm()) <= 1e-5 * big or r.numel() == 1:
+            continue
+        e_hip.append(float((got[n] - r).norm() / r.norm()))
+        e_ref.append(float((g32[n].double() - r).norm() / r.norm()))
+    e_hip, e_ref = np.array(e_hip), np.array(e_ref)
+    med = (float(np.median(e_hip)), float(np.median(e_ref)))
+    p90 = (float(np.quantile(e_hip, 0.9)), float(np.quantile(e_ref, 0.9)))
+    print(f"[transfuse gradient error vs fp64 oracle, {gemm_precision} GEMMs] HIP median {med[0]:.2e} p90 {p90[0]:.2e} max {e_hip.max():.2e} | "
+          f"fp32 oracle median {med[1]:.2e} p90 {p90[1]:.2e} max {e_ref.max():.2e}  ({len(e_hip)} tensors)")
+    # Measured (MI355X, seed 9): fp32 oracle vs fp64 oracle -- median 1.5e-3, p90 5.9e-3, max 7.8e-3: two CORRECT implementations of the same
+    # arithmetic already differ by up to 0.8 % per tensor.  HIP with fp32 GEMMs: median 5.6e-3, p90 1.1e-2, max 2.1e-2 (3.7x / 1.9x the oracle's
+    # own figures: another summation order in every convolution and BatchNorm statistic); bf16x3 GEMMs (forward moved by 2.7e-4 instead of
+    # 1e-6): median 1.8e-2, p90 2.9e-2, max 4.0e-2.  The bounds below are those factors with ~1.6x head room.
+    km, kp = (6.0, 3.0) if gemm_precision == "fp32" else (20.0, 8.0)
+    assert len(e_hip) > 300
+    assert med[0] <= km * med[1] + 1e-4, (med, p90)
+    assert p90[0] <= kp * p90[1] + 1e-4, (med, p90)
+    assert e_hip.max() <= (3e-2 if gemm_precision == "fp32" else 6e-2), float(e_hip.max())
+
+
 def test_transfuse_domain_batched_step_equals_per_domain_step():
     """fuse_domains=True (one forward over the concatenated domain batches, BatchNorm statistics per domain batch incl. the
     single-channel BatchNorms, running statistics updated once per domain in order) == one forward per domain"""
@@ -334,6 +383,43 @@ def test_transfuse_domain_batched_step_equals_per_domain_step():
             continue
         e = float((res[0][1][n].double() - ref.double()).norm() / ref.double().norm())
         if not e <= (0.3 if ref.numel() == 1 else 5e-2):          # same arithmetic, different GEMM tilings at 3x the rows: kink flips only
+            bad.append(f"{n}: {e:.2e}")
+    assert not bad, bad[:8]
+
+
+def test_transfuse_bench_step_32_images_fused_equals_per_domain_at_bs8():
+    """BASELINE configs[4] as bench.py --model transfuse --batch 8 runs it: the 32-image domain-batched step (4 domains x 8 at 256x256,
+    gradient buckets, side stream) against one forward + backward per domain with the same weights: per-domain losses, BatchNorm running
+    statistics and every gradient tensor (same arithmetic, other GEMM tilings at 4x the rows: kink flips only -- see the calibration test)"""
+    from mdvit_amd import ops
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.transfuse import transfuse_train_step
+    from oracle.gen_golden import synth_image, synth_label
+    B, S = 8, 256
+    batches = [(synth_image(5200 + d, B, S, S).to(dev()), synth_label(5300 + d, B, S, S).to(dev()), torch.full((B,), d, dtype=torch.long)) for d in range(4)]
+    res = []
+    for fuse in (True, False):
+        m, _ = _build(11)
+        m.train()
+        acc = GradAccumulator(m.parameters()); acc.attach_sinks(); ops.enable_side_stream(True)
+        try:
+            r = transfuse_train_step(m, batches, accumulator=acc, fuse_domains=fuse)
+            torch.cuda.synchronize()
+            res.append((r, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                        {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+        finally:
+            ops.enable_side_stream(False); ops.set_grad_sinks(None)
+    check(res[0][0]["per_domain"], res[1][0]["per_domain"], tol=1e-5, name="per-domain losses")
+    for k in res[1][2]:
+        check(res[0][2][k], res[1][2][k], tol=1e-5, name=k)
+    big = max(float(v.double().norm()) for v in res[1][1].values())
+    bad = []
+    for n, ref in res[1][1].items():
+        assert torch.isfinite(res[0][1][n]).all(), n
+        if float(ref.double().norm()) <= 1e-5 * big:
+            continue
+        e = float((res[0][1][n].double() - ref.double()).norm() / ref.double().norm())
+        if not e <= (0.3 if ref.numel() == 1 else 5e-2):
             bad.append(f"{n}: {e:.2e}")
     assert not bad, bad[:8]
 
