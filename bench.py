@@ -94,12 +94,12 @@ def _physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(size: int, budget_s: float = 30.0):
+def cpu_baseline(size: int, budget_s: float = 80.0):
     """SURVEY 8(d) protocol on the host cores: the CPU oracle (oracle/mdvit_ref.py, pure torch fp32 -- the same math as
     the reference) for (1) BASELINE configs[0]: BASE bs=4, one domain, and (2) the MDViT sample of the headline workload
-    (one domain x one image): warm-up steps, then timed steps, MEDIAN, forward / backward ms split.  Both legs are
-    bounded (about `budget_s` seconds each: the step count adapts to the first warm-up's duration, never below
-    1 warm-up + 3 timed)."""
+    (one domain x one image): SURVEY 8(d)'s 3 warm-up + 5 timed steps, MEDIAN, forward / backward ms split (~55 s per leg on the pool's
+    EPYC 9575F).  Both legs are bounded by `budget_s` seconds each: on a host where 8 steps would not fit, the step count falls back
+    to 1 warm-up + 3 timed and the JSON says so."""
     import statistics
     import torch
     from oracle import mdvit_ref as R
@@ -423,10 +423,17 @@ def main():
             else:
                 roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak_mfma, 1), "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
             launches = rec.get("launches", rec["n"])
+            rp_us = _rocprof_avg_us(name)
+            if rp_us:
+                rp_gbs, rp_tf = rec["bytes"] / rec["n"] / (rp_us * 1e-6) / 1e9, rec["flop"] / rec["n"] / (rp_us * 1e-6) / 1e12
+                roof["frac_rocprof"] = round(rp_gbs / PEAK_HBM_GBS if roof["bound"] == "hbm" else rp_tf / peak_mfma, 4)
+                roof["frac_live"] = roof["frac"]
+            roof["traffic_source"] = ("profiles/pmc_traffic.json: HBM bytes per launch of this kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command (FETCH x2, gfx950) -- read from the file, NOT measured in this run")
             roof.update({"traffic": traffic, "launches": launches, "timed_launches": rec["n"], "avg_launch_us": round(secs * 1e6 / rec["n"], 2),
                          "avg_launch_us_raw_events": round(rec["ms"] * 1e3 / rec["n"], 2), "event_pair_overhead_us": round(ovh_ms * 1e3, 2),
                          "timer": rec.get("timer"),
-                         "rocprof_avg_launch_us": _rocprof_avg_us(name),
+                         "rocprof_avg_launch_us": rp_us,
                          "flop_per_launch": round(rec["flop"] / rec["n"]), "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]),
                          "mfma_tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "share_of_step": round(secs * 1e3 * launches / rec["n"] / (dt * 1e3), 4)})
             if args.detail:
@@ -466,6 +473,18 @@ def main():
             extra["base_bs4_gpu"]["how"] = "whole-step HIP graph replay (eager: 238 images/s, host-bound)"
             if "config" in bb:
                 extra["base_bs4_gpu"]["workload"] = bb["config"]["workload"]
+            # BASELINE configs[3]: bs=16 per domain, bf16 GEMMs / fp32 losses (one 64-image fused forward)
+            b16 = _child_json([sys.executable, os.path.abspath(__file__), "--batch", "16", "--precision", "bf16", "--steps", "5", "--warmup", "3", "--no-cpu-baseline",
+                               "--no-extra-legs", "--no-kernel-events"] + (["--no-side-stream"] if args.no_side_stream else []), 600)
+            extra["bs16_bf16"] = {k: b16.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "phase_ms", "drift_vs_parity_mode", "memory", "error") if k in b16}
+            if "config" in b16:
+                extra["bs16_bf16"]["workload"] = b16["config"]["workload"]
+            # BASELINE configs[4]: TransFuse_S_adapt, bs=8 per domain at its only legal size 256x256 (one 32-image fused step)
+            tfl = _child_json([sys.executable, os.path.abspath(__file__), "--model", "transfuse", "--batch", "8", "--size", "256", "--steps", "10", "--warmup", "4",
+                               "--no-cpu-baseline", "--no-extra-legs"] + common, 600)
+            extra["transfuse_bs8"] = {k: tfl.get(k) for k in ("value", "unit", "ms_per_step", "host_enqueue_ms_per_step", "roofline", "error") if k in tfl}
+            if "config" in tfl:
+                extra["transfuse_bs8"]["workload"] = tfl["config"]["workload"]
             blk_json = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"mdvit_block_roofline_{os.getpid()}.json")
             _child_json([sys.executable, os.path.join(ROOT, "tools", "block_roofline.py"), "--batch", "32", "--precision", args.precision,
                          "--json", blk_json], 600)
@@ -478,7 +497,19 @@ def main():
                     "stages": [{"stage": r["stage"], "C": r["C"], "rows": r["rows"], "fwd_ms": round(r["fwd_ms"], 3), "bwd_ms": round(r["bwd_ms"], 3),
                                 "frac": round(r["frac"], 4), "frac_survey": round(r["frac_of_survey_fused_bf16_bound"], 4),
                                 "achieved_TBps": round(r["achieved_TBps"], 3), "achieved_TFLOPs": round(r["achieved_TFLOPs"], 1)} for r in blk["stages"]],
-                    "all_stages_frac": round(blk["all_stages"]["frac"], 4)}
+                    "all_stages_frac": round(blk["all_stages"]["frac"], 4), "all_stages_frac_strict": round(blk["all_stages"].get("frac_strict", 0.0), 4),
+                    "strict": "frac_strict = the same bound with the MLP fused (no T x hidden bytes: x, res -> y; gm, x -> dx; gm, x -> dW) / measured"}
+                for r_, o_ in zip(blk["stages"], extra["block_bs32"]["stages"]):
+                    o_["frac_strict"] = round(r_.get("frac_strict", 0.0), 4)
+                if "stage0_mlp_kernels" in blk and "largest" in blk["stage0_mlp_kernels"]:
+                    big = blk["stage0_mlp_kernels"]["largest"]
+                    extra["roofline_block_bs32"] = {
+                        "what": "the largest kernel of the stage-0 block at bs=32 (524288 tokens), timed alone with events on its launch stream",
+                        "kernel": big["kernel"], "us": round(big["us"], 1), "algorithmic_bytes": round(big["algorithmic_bytes"]), "algorithmic_flop": round(big["algorithmic_flop"]),
+                        "bound": big["bound"], "achieved_GBps": round(big["hbm_GBps"], 1), "frac_hbm": round(big["frac_hbm"], 4),
+                        "achieved_useful_TFLOPs": round(big["useful_TFLOPs"], 1), "frac_mfma_bf16x3": round(big["frac_mfma_bf16x3"], 4),
+                        "all_mlp_kernels": [{"kernel": r_["kernel"], "us": round(r_["us"], 1), "frac_hbm": round(r_["frac_hbm"], 4), "frac_mfma_bf16x3": round(r_["frac_mfma_bf16x3"], 4)}
+                                            for r_ in blk["stage0_mlp_kernels"]["kernels"]]}
                 os.remove(blk_json)
             except Exception as e:
                 extra["block_bs32"] = {"error": repr(e)}
