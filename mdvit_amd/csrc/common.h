@@ -81,8 +81,12 @@ __device__ __forceinline__ uint32_t mdvit_hash32(uint32_t x) {
 // rotated by a byte per element: each element still sees a uniform 32-bit value (exact drop probability), the four
 // decisions hang on disjoint top bytes, and the two quarter-rate v_mul_lo_u32 rounds are paid once per float4 instead
 // of once per element (they dominated the VALU time of the K=64/128 MLP GEMM epilogues).
+// (One round of the lowbias32 mixer over (quad index ^ k0) + k1.  Round 2 ran it twice; against the two-round form the keep rates, the
+//  correlations inside a quad, between neighbouring quads and between related keys are indistinguishable over 4 M indices x 6 key pairs x
+//  p in {0.1, 0.25, 0.5} (max |corr| 0.003 either way), and the second round was two more quarter-rate v_mul_lo_u32 per four elements in
+//  every dropout epilogue -- 10 % of the VALU time of the fused MLP kernels, which are VALU-bound.)
 __device__ __forceinline__ uint32_t mdvit_drop_bits(uint32_t k0, uint32_t k1, uint32_t idx) {
-    return mdvit_hash32(mdvit_hash32((idx >> 2) ^ k0) + k1);
+    return mdvit_hash32(((idx >> 2) ^ k0) + k1);
 }
 __device__ __forceinline__ float mdvit_drop_scale(uint32_t k0, uint32_t k1, uint32_t idx, uint32_t thresh, float inv_keep) {
     const uint32_t h = __builtin_rotateright32(mdvit_drop_bits(k0, k1, idx), 8u * (idx & 3u));

@@ -99,6 +99,30 @@ __device__ __forceinline__ void rc_load_rows(const float* __restrict__ src, int 
     }
 }
 
+// erf-GELU parts as common.h's gelu_parts (Abramowitz-Stegun 7.1.26), one multiply shorter: exp(-x^2 / 2) = exp2(x * x * (-0.5 log2 e)) on v_exp_f32
+// directly.  cdf and pdf agree with gelu_parts to an ulp of the exponential's argument.
+__device__ __forceinline__ void rc_gelu_parts(float x, float& cdf, float& pdf) {
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = 1.0f - poly * t * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    pdf = 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float rc_gelu(float x) {
+    float cdf, pdf;
+    rc_gelu_parts(x, cdf, pdf);
+    return x * cdf;
+}
+__device__ __forceinline__ float rc_gelu_grad(float x) {
+    float cdf, pdf;
+    rc_gelu_parts(x, cdf, pdf);
+    return fmaf(x, pdf, cdf);
+}
+
 struct RcArgs {
     const float* x; const float* gm; const float* res; const float* rowscale; const float* b1; const float* b2;
     const uint16_t* W1p;    // planes of W1   [2][Hd][C]   rows = hidden, k = c         u = x W1^T
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int q = 0; q < 4; ++q) {
             const int hd = s * 32 + 8 * q + 4 * lhi;
             const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + hd);          // (ext_vector load: a HIP float4 LDS read makes hipcc drain the glds ring)
-            float4 v = make_float4(gelu_f(u[4 * q + 0] + b4.x), gelu_f(u[4 * q + 1] + b4.y), gelu_f(u[4 * q + 2] + b4.z), gelu_f(u[4 * q + 3] + b4.w));
+            float4 v = make_float4(rc_gelu(u[4 * q + 0] + b4.x), rc_gelu(u[4 * q + 1] + b4.y), rc_gelu(u[4 * q + 2] + b4.z), rc_gelu(u[4 * q + 3] + b4.w));
             if (DROP) {
                 const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
@@ -376,7 +400,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         float hv[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 v = make_float4(gelu_f(u[4 * q + 0]), gelu_f(u[4 * q + 1]), gelu_f(u[4 * q + 2]), gelu_f(u[4 * q + 3]));
+            float4 v = make_float4(rc_gelu(u[4 * q + 0]), rc_gelu(u[4 * q + 1]), rc_gelu(u[4 * q + 2]), rc_gelu(u[4 * q + 3]));
             if (DROP) {
                 const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + t * 32 + 8 * q + 4 * lhi), p.thresh, p.inv_keep);
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
@@ -495,7 +519,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const char* w1h = sW1 + ((s % 3) * 2) * T1; const char* w1l = w1h + T1;
         const char* w2h = sW2t + ((s % 3) * 2) * T1; const char* w2l = w2h + T1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { u[r] = 0.f; d[r] = 0.f; }
+        for (int q = 0; q < 4; ++q) {               // u starts from the bias quads of this step (one add per element less in the activation)
+            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + s * 32 + 8 * q + 4 * lhi);
+            u[4 * q + 0] = b4.x; u[4 * q + 1] = b4.y; u[4 * q + 2] = b4.z; u[4 * q + 3] = b4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const rc_bf16x8 ah = rc_frag<RB1>(w1h, l31, 2 * kb + lhi), al = rc_frag<RB1>(w1l, l31, 2 * kb + lhi);
@@ -519,9 +548,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int hd = s * 32 + 8 * q + 4 * lhi;
-            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + hd);
-            float4 v = make_float4(d[4 * q + 0] * gelu_grad_f(u[4 * q + 0] + b4.x), d[4 * q + 1] * gelu_grad_f(u[4 * q + 1] + b4.y),
-                                   d[4 * q + 2] * gelu_grad_f(u[4 * q + 2] + b4.z), d[4 * q + 3] * gelu_grad_f(u[4 * q + 3] + b4.w));
+            float4 v = make_float4(d[4 * q + 0] * rc_gelu_grad(u[4 * q + 0]), d[4 * q + 1] * rc_gelu_grad(u[4 * q + 1]),
+                                   d[4 * q + 2] * rc_gelu_grad(u[4 * q + 2]), d[4 * q + 3] * rc_gelu_grad(u[4 * q + 3]));
             if (DROP) {
                 const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
@@ -537,37 +565,38 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
 
-    rc_f32x16 ucur, dcur, unext, dnext;
+    // two accumulator sets and two fragment sets alternate roles phase by phase (the loop body holds TWO phases: no register rotation)
+    rc_f32x16 uA, dA, uB, dB;
     rc_bf16x8 dh[2], dl[2], eh[2], el[2];
-    prod1(0, ucur, dcur);
-    {
-        __builtin_amdgcn_s_barrier();
-        issue_group(1);
-        prod1(1, unext, dnext);
-        act(0, ucur, dcur, dh, dl);
-        ucur = unext; dcur = dnext;
-    }
-    for (int t = 1; t + 1 < n; ++t) {
+    auto phase = [&](int t, rc_f32x16& ucur, rc_f32x16& dcur, rc_f32x16& unext, rc_f32x16& dnext, const rc_bf16x8 (&ph)[2], const rc_bf16x8 (&pl)[2],
+                     rc_bf16x8 (&oh)[2], rc_bf16x8 (&ol)[2]) __attribute__((always_inline)) {
         RC_WAIT_VM(PPW);
         __builtin_amdgcn_s_barrier();
         issue_group(t + 1);
         prod1(t + 1, unext, dnext);
-        prod3(t - 1, dh, dl);
-        act(t, ucur, dcur, eh, el);
-        rc_interleave<6 * KB + 6 * CB, DROP ? 12 : 10, 4 * KB + 4 * CB + 4, 8>();
-        ucur = unext; dcur = dnext;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) { dh[h2] = eh[h2]; dl[h2] = el[h2]; }
+        prod3(t - 1, ph, pl);
+        act(t, ucur, dcur, oh, ol);
+    };
+    prod1(0, uA, dA);
+    {
+        __builtin_amdgcn_s_barrier();
+        issue_group(1);
+        prod1(1, uB, dB);
+        act(0, uA, dA, dh, dl);
+    }
+    for (int t = 1; t + 1 < n; t += 2) {              // n is even: phases 1 .. n-2 come in pairs
+        phase(t, uB, dB, uA, dA, dh, dl, eh, el);
+        phase(t + 1, uA, dA, uB, dB, eh, el, dh, dl);
     }
     {
         RC_WAIT_VM(PPW);
         __builtin_amdgcn_s_barrier();
         prod3(n - 2, dh, dl);
-        act(n - 1, ucur, dcur, dh, dl);
+        act(n - 1, uB, dB, eh, el);
     }
     RC_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
-    prod3(n - 1, dh, dl);
+    prod3(n - 1, eh, el);
 
     if (row < p.M) {
 #pragma unroll
@@ -691,7 +720,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // u, d as D[token][hidden]
         rc_f32x16 u, d;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { u[r] = 0.f; d[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { u[r] = bias; d[r] = 0.f; }          // (lane <-> hidden unit: one bias value for all 16 token rows)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const rc_bf16x8 ah = rc_frag<128>(xhi, l31, 2 * kb + lhi), al = rc_frag<128>(xlo, l31, 2 * kb + lhi);
@@ -718,9 +747,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int r = 8 * ks + i;
-                const float uu = u[r] + bias;
+                const float uu = u[r];
                 float cdf, pdf;
-                gelu_parts(uu, cdf, pdf);
+                rc_gelu_parts(uu, cdf, pdf);
                 float hval = uu * cdf, g = d[r] * fmaf(uu, pdf, cdf);
                 if (DROP) {
                     const uint32_t w = rc_quad_bcast(hb[r & 3], r >> 2);

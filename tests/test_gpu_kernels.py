@@ -165,7 +165,7 @@ def test_linear_dropout_droppath_statistics_and_backward_mask():
     assert abs(frac - 0.9) < 0.01, f"keep rate {frac}"
     assert (y[~live] == 0).all(), "DropPath-ed samples must be exactly zero"
     exp_scale = (1 / 0.9) * (1 / 0.9)
-    assert torch.allclose(y.detach()[live][kept], plain[live][kept] * exp_scale, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(y.detach()[live][kept], plain[live][kept] * exp_scale, rtol=1e-4, atol=5e-5)      # (bf16x3 GEMM against torch's fp32 matmul: ~1e-5 of the largest element)
     # backward must use the SAME mask
     g = rnd(M, N, seed=18).to(dev())
     y.backward(g)
