@@ -943,3 +943,4 @@ extern "C" int mdvit_mlp_rc_wgrad(const float* gm, const float* x, const void* W
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
+
