@@ -214,7 +214,7 @@ class MDViT(_EncoderDecoder):
         features through its own weights), so each runs on a stream of its own -- and so does its backward: autograd executes a
         node's backward on the stream its forward ran on and orders the streams at the graph's edges."""
         G = len(ds)
-        streams = [ops.peer_stream(g) for g in range(G)] if (G > 1 and parts[0][0].is_cuda) else [None] * G
+        streams = [ops.peer_stream(g, G * parts[0][0].shape[0]) for g in range(G)] if (G > 1 and parts[0][0].is_cuda) else [None] * G
         if any(s is None for s in streams):
             return [self._peer_out(dd, [pf[g] for pf in parts], bparts[g], img_size) for g, dd in enumerate(ds)]
         main = torch.cuda.current_stream()

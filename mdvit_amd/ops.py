@@ -204,18 +204,23 @@ def _sink_of(t):
 # ---- peer streams: the G peer heads of a domain-batched forward are independent chains of small kernels --------------------
 # Each head (its forward, and -- because autograd runs a node's backward on the stream its forward ran on -- its backward too) goes
 # to a stream of its own, so the heads overlap each other instead of queueing behind each other on the main stream.
-# OFF by default since the aux sweep has a stream of its own: main + weight-gradient + aux-sweep streams already fill the GPU, and
-# with the heads' streams on top there are more streams than hardware queues (4) -- the bs=4 step is 6-8 % SLOWER with four peer
-# streams, level with one (profiles/r02k_stream_config_ab.txt); MDVIT_PEER_STREAMS=1 switches them on (single-sweep use).
+# Round 2 switched them off: with the host as the limit of the step their event traffic cost more than they overlapped (-7 %).  Since round 3 the
+# step is GPU-bound (one C call per transformer-block pass) and two peer streams are worth +2.5 % at bs=4 (362-364 -> 370-375 images/s,
+# interleaved A/B); four are no better, and at bs=32 they buy nothing while every extra stream grows the caching allocator's reserved pool
+# (180 -> 276 GiB).  Default "auto": two peer streams when the domain-batched forward holds at most 32 images; MDVIT_PEER_STREAMS=0 / 1 force.
 _peer_streams = []
-_use_peer_streams = os.environ.get("MDVIT_PEER_STREAMS", "0") != "0"
+_peer_mode = os.environ.get("MDVIT_PEER_STREAMS", "auto")
+_use_peer_streams = _peer_mode != "0"
+_peer_auto_max_images = 32
 _graph_peers = os.environ.get("MDVIT_GRAPH_PEERS", "0") != "0"      # fork the peer streams inside a HIP-graph capture too
-_peer_stream_count = max(1, int(os.environ.get("MDVIT_PEER_STREAM_COUNT", "4")))   # heads i, i + count, ... share a stream
+_peer_stream_count = max(1, int(os.environ.get("MDVIT_PEER_STREAM_COUNT", "2")))   # heads i, i + count, ... share a stream
 
 
-def peer_stream(i: int):
-    """the i-th peer stream, or None when disabled / capturing (a captured graph keeps the single-stream order)"""
+def peer_stream(i: int, n_images: int = 0):
+    """the i-th peer stream, or None when disabled / capturing (a captured graph keeps the single-stream order) / in auto mode for large batches"""
     if not _use_peer_streams or (torch.cuda.is_current_stream_capturing() and not _graph_peers):
+        return None
+    if _peer_mode == "auto" and n_images > _peer_auto_max_images:
         return None
     i %= _peer_stream_count
     while len(_peer_streams) <= i:
