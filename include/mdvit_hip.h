@@ -353,6 +353,19 @@ int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, const float
                  int32_t per_group_affine, int32_t act, int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, int32_t rows_per_sample,
                  void* stream);
 
+/* BatchNorm2d -> activation -> Dropout2d -> 1-output 1x1 conv as ONE op: the tail of the peer heads (linear_fuse.1 -> ReLU -> Dropout2d(0.1) ->
+ * linear_out, Decoders.py:304-311,333-336; the DeepLabV3 head's BN -> ReLU -> 1x1 conv, Utils/_deeplab.py).  The normalised [M, C] tensor between
+ * the norm and the conv is never written: fwd reads y once; bwd (two passes over y and the row gradient g [M]) returns dy and, unless
+ * dgamma / dbeta / dw are NULL (data gradient only), the four parameter gradients.  mean / rstd [C] come from mdvit_bn_stats (training) or
+ * mdvit_bn_eval_prep (eval); one statistics group.  C in {256, 512, 1024}. */
+size_t mdvit_bn_rowdot_ws_bytes(int32_t M, int32_t C);
+int mdvit_bn_rowdot_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w, const float* b /* [1], optional */,
+                        float* low, int32_t M, int32_t C, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed,
+                        int32_t rows_per_sample, void* stream);
+int mdvit_bn_rowdot_bwd(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
+                        float* dy, float* dgamma, float* dbeta, float* dw, float* db /* optional */, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t act,
+                        int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, int32_t rows_per_sample, void* stream);
+
 /* ---- bilinear resize, align_corners=False, NHWC (F.interpolate call sites mdvit.py:699,
  * Decoders.py:196,320-329,336) ------------------------------------------------------------------ */
 int mdvit_upsample_fwd(const float* x, const float* base /* optional [B,Ho,Wo,C]: y = base + resize(x); may be y itself */, float* y,
@@ -361,6 +374,16 @@ size_t mdvit_upsample_bwd_ws_bytes(int32_t B, int32_t Hi, int32_t Wi, int32_t Ho
 /* adjoint, separable: dy [B,Ho,Wo,C] -> (width pass) ws [B,Ho,Wi,C] -> (height pass) dx [B,Hi,Wi,C] */
 int mdvit_upsample_bwd(const float* dy, float* dx, void* ws, size_t ws_bytes, int32_t B, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
                        int32_t C, void* stream);
+
+/* y = base + sum_i resize(x_i) over n <= 3 NHWC sources of different sizes in ONE pass (the sum over the four encoder features in the peer heads'
+ * fuse conv, Decoders.py:320-331: chained single-source calls move the [B,Ho,Wo,512] sum twice per source); base optional, may be y.  The
+ * backward folds dy along W for all sources in one launch (workspace: sum_i B Ho Wi_i C floats) and along H per source.  C % 4 == 0.
+ * xs / dxs / Hi / Wi are HOST arrays of n entries. */
+int mdvit_upsample_multi_fwd(const float* const* xs, const int32_t* Hi, const int32_t* Wi, int32_t n, const float* base, float* y, int32_t B, int32_t Ho,
+                             int32_t Wo, int32_t C, void* stream);
+size_t mdvit_upsample_multi_bwd_ws_bytes(const int32_t* Wi, int32_t n, int32_t B, int32_t Ho, int32_t C);
+int mdvit_upsample_multi_bwd(const float* dy, float* const* dxs, const int32_t* Hi, const int32_t* Wi, int32_t n, void* ws, size_t ws_bytes, int32_t B,
+                             int32_t Ho, int32_t Wo, int32_t C, void* stream);
 
 /* ---- Domain Adapter: a = softmax_heads(W2 relu(W1 label + b1) + b2), [B,C] (mdvit.py:272-276,301-303).
  * Backward takes e[b,c] = a[b,c] * dL/da[b,c] (what mdvit_factoratt_bwd emits -- it needs no division by a):

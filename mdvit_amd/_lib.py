@@ -162,10 +162,14 @@ _SIGS = {
     "mdvit_dropout_f32": [vp, vp, i64, f32, u32, u32, vp, vp],
     "mdvit_stemconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mdvit_stemconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
+    "mdvit_bn_rowdot_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, i32, vp],
+    "mdvit_bn_rowdot_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_bn_stats": [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp],
     "mdvit_bn_eval_prep": [vp, vp, vp, vp, i32, f32, vp],
     "mdvit_bn_apply": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_bn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, f32, u32, u32, vp, i32, vp],
+    "mdvit_upsample_multi_fwd": [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "mdvit_upsample_multi_bwd": [vp, vp, vp, vp, i32, vp, C.c_size_t, i32, i32, i32, i32, vp],
     "mdvit_upsample_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_upsample_bwd": [vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_da_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -219,8 +223,12 @@ def load():
     lib.mdvit_gate_bwd_ws_bytes.argtypes = [i32, i64, i32, i32]
     lib.mdvit_gemm_planes_ws_bytes.restype = C.c_size_t
     lib.mdvit_gemm_planes_ws_bytes.argtypes = [C.POINTER(PlaneGemmDesc)]
+    lib.mdvit_bn_rowdot_ws_bytes.restype = C.c_size_t
+    lib.mdvit_bn_rowdot_ws_bytes.argtypes = [i32, i32]
     lib.mdvit_bn_ws_bytes.restype = C.c_size_t
     lib.mdvit_bn_ws_bytes.argtypes = [i32, i32, i32]
+    lib.mdvit_upsample_multi_bwd_ws_bytes.restype = C.c_size_t
+    lib.mdvit_upsample_multi_bwd_ws_bytes.argtypes = [vp, i32, i32, i32, i32]
     lib.mdvit_upsample_bwd_ws_bytes.restype = C.c_size_t
     lib.mdvit_upsample_bwd_ws_bytes.argtypes = [i32] * 6
     lib.mdvit_partials_ws_bytes.restype = C.c_size_t

@@ -516,6 +516,81 @@ __global__ __launch_bounds__(256) void upsample_bwd_pass_kernel(const float* __r
     }
 }
 
+// ---- several bilinear sources summed onto one base in ONE pass (the peer heads' fuse: sum_q upsample(P_q), Decoders.py:320-331 after the
+// weight composition of decode.py).  Forward: y = base + sum_i resize(x_i); chained single-source calls read and write the [B,Ho,Wo,C] sum once
+// per source.  Backward, width pass: every source's [B*Ho][Wi_i][C] fold of dy in one launch, ordered so that the three folds of a dy row run
+// together (the row comes from HBM once, from L2 afterwards); the height passes stay per source (their inputs are 2-8x smaller).
+struct UpMulti {
+    const float* x[3]; float* d[3];
+    int Hi[3], Wi[3];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void upsample_multi_fwd_kernel(UpMulti p, const float* base_, float* __restrict__ y, int B, int Ho, int Wo, int C) {
+    const int QC = C >> 2;
+    const long total = (long)B * Ho * Wo * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % QC) * 4;
+        long r = e / QC;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const long oi = (((long)b * Ho + ho) * Wo + wo) * C + c;
+        float4 o = base_ ? *reinterpret_cast<const float4*>(base_ + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i >= p.n) break;
+            const int Hi = p.Hi[i], Wi = p.Wi[i];
+            int h0, h1, w0, w1; float lh, lw;
+            bilin_src(ho, Hi, (float)Hi / (float)Ho, h0, h1, lh);
+            bilin_src(wo, Wi, (float)Wi / (float)Wo, w0, w1, lw);
+            const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
+            const float* x = p.x[i] + (long)b * Hi * Wi * C + c;
+            const float4 v00 = *reinterpret_cast<const float4*>(x + ((long)h0 * Wi + w0) * C), v01 = *reinterpret_cast<const float4*>(x + ((long)h0 * Wi + w1) * C);
+            const float4 v10 = *reinterpret_cast<const float4*>(x + ((long)h1 * Wi + w0) * C), v11 = *reinterpret_cast<const float4*>(x + ((long)h1 * Wi + w1) * C);
+            // the same four-tap expression as upsample_fwd_kernel, then added to the running sum: equal to the chained calls bit for bit
+            float4 u;
+            u.x = c00 * v00.x + c01 * v01.x + c10 * v10.x + c11 * v11.x;
+            u.y = c00 * v00.y + c01 * v01.y + c10 * v10.y + c11 * v11.y;
+            u.z = c00 * v00.z + c01 * v01.z + c10 * v10.z + c11 * v11.z;
+            u.w = c00 * v00.w + c01 * v01.w + c10 * v10.w + c11 * v11.w;
+            o = (i == 0 && !base_) ? u : f4_add(u, o);
+        }
+        *reinterpret_cast<float4*>(y + oi) = o;
+    }
+}
+
+// width folds of all sources: work item = (dy row o, source column j in [0, Wi_0 + Wi_1 + Wi_2), channel quad)
+__global__ __launch_bounds__(256) void upsample_multi_bwd_w_kernel(UpMulti p, const float* __restrict__ dy, long outer, int Wo, int C) {
+    const int QC = C >> 2;
+    const int Wsum = p.Wi[0] + (p.n > 1 ? p.Wi[1] : 0) + (p.n > 2 ? p.Wi[2] : 0);
+    const long total = outer * Wsum * QC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % QC) * 4;
+        long r = e / QC;
+        int j = (int)(r % Wsum);
+        const long o = r / Wsum;
+        int src = 0;
+        if (j >= p.Wi[0]) { j -= p.Wi[0]; src = 1; if (j >= p.Wi[1]) { j -= p.Wi[1]; src = 2; } }
+        const int Wi = p.Wi[src];
+        const float sc = (float)Wi / (float)Wo;
+        int lo, hi;
+        out_range(j, Wi, Wo, lo, hi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* base = dy + o * Wo * C + c;
+#pragma unroll 4
+        for (int t = lo; t < hi; ++t) {
+            int i0, i1; float l;
+            bilin_src(t, Wi, sc, i0, i1, l);
+            const float wgt = (i0 == j ? 1.f - l : 0.f) + (i1 == j ? l : 0.f);
+            const float4 g = *reinterpret_cast<const float4*>(base + (long)t * C);
+            acc.x = fmaf(wgt, g.x, acc.x); acc.y = fmaf(wgt, g.y, acc.y); acc.z = fmaf(wgt, g.z, acc.z); acc.w = fmaf(wgt, g.w, acc.w);
+        }
+        float* dsts[3] = {p.d[0], p.d[1], p.d[2]};
+        *reinterpret_cast<float4*>(dsts[src] + (o * Wi + j) * C + c) = acc;
+    }
+}
+
 // y = x * dropmask / (1 - p): one hash per aligned float4 (mdvit_drop_scale4), n % 4 == 0
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, uint32_t k0, uint32_t k1,
                                                       const uint32_t* __restrict__ seed, uint32_t thresh, float inv_keep) {
@@ -708,6 +783,54 @@ extern "C" int mdvit_upsample_bwd(const float* dy, float* dx, void* ws, size_t w
         const long total = (long)B * Hi * Wi * cq;
         hipLaunchKernelGGL((upsample_bwd_pass_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, s, tmp, dx, (long)B, Hi, Ho, (long)Wi * cq, vec);
     }
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+/* see include/mdvit_hip.h */
+extern "C" int mdvit_upsample_multi_fwd(const float* const* xs, const int32_t* Hi, const int32_t* Wi, int32_t n, const float* base, float* y, int32_t B, int32_t Ho,
+                                        int32_t Wo, int32_t C, void* stream) {
+    MDVIT_CHECK_ARG(n >= 1 && n <= 3 && B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, MDVIT_E_SHAPE, "upsample_multi_fwd: 1..3 sources, C %% 4 == 0 (n=%d C=%d)", n, C);
+    UpMulti p; memset(&p, 0, sizeof(p));
+    p.n = n;
+    for (int i = 0; i < n; ++i) {
+        MDVIT_CHECK_ARG(xs[i] && Hi[i] > 0 && Wi[i] > 0 && aligned16(xs[i]), MDVIT_E_SHAPE, "upsample_multi_fwd: bad source %d", i);
+        p.x[i] = xs[i]; p.Hi[i] = Hi[i]; p.Wi[i] = Wi[i];
+    }
+    MDVIT_CHECK_ARG(aligned16(y) && (!base || aligned16(base)), MDVIT_E_ALIGN, "upsample_multi_fwd: y / base must be 16-byte aligned");
+    const long total = (long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(upsample_multi_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p, base, y, B, Ho, Wo, C);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" size_t mdvit_upsample_multi_bwd_ws_bytes(const int32_t* Wi, int32_t n, int32_t B, int32_t Ho, int32_t C) {
+    size_t t = 0;
+    for (int i = 0; i < n && i < 3; ++i) t += (size_t)B * Ho * Wi[i] * C;
+    return sizeof(float) * t;
+}
+
+extern "C" int mdvit_upsample_multi_bwd(const float* dy, float* const* dxs, const int32_t* Hi, const int32_t* Wi, int32_t n, void* ws, size_t ws_bytes, int32_t B,
+                                        int32_t Ho, int32_t Wo, int32_t C, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(n >= 1 && n <= 3 && B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, MDVIT_E_SHAPE, "upsample_multi_bwd: 1..3 sources, C %% 4 == 0 (n=%d C=%d)", n, C);
+    MDVIT_CHECK_ARG(ws && ws_bytes >= mdvit_upsample_multi_bwd_ws_bytes(Wi, n, B, Ho, C) && aligned16(ws) && aligned16(dy), MDVIT_E_WORKSPACE,
+                    "upsample_multi_bwd: workspace too small (mdvit_upsample_multi_bwd_ws_bytes)");
+    UpMulti p; memset(&p, 0, sizeof(p));
+    p.n = n;
+    float* t = (float*)ws;
+    int wsum = 0;
+    for (int i = 0; i < n; ++i) {
+        MDVIT_CHECK_ARG(dxs[i] && Hi[i] > 0 && Wi[i] > 0 && aligned16(dxs[i]), MDVIT_E_SHAPE, "upsample_multi_bwd: bad source %d", i);
+        p.Hi[i] = Hi[i]; p.Wi[i] = Wi[i]; p.d[i] = t;
+        t += (size_t)B * Ho * Wi[i] * C;
+        wsum += Wi[i];
+    }
+    const long cq = C / 4;
+    hipLaunchKernelGGL(upsample_multi_bwd_w_kernel, dim3(ew_grid((long)B * Ho * wsum * cq)), dim3(256), 0, s, p, dy, (long)B * Ho, Wo, C);
+    for (int i = 0; i < n; ++i)          // pass H per source: tmp_i [B][Ho][Wi*C] -> dx_i [B][Hi][Wi*C]
+        hipLaunchKernelGGL((upsample_bwd_pass_kernel<false>), dim3(ew_grid((long)B * Hi[i] * Wi[i] * cq)), dim3(256), 0, s, p.d[i], dxs[i], (long)B, Hi[i], Ho,
+                           (long)Wi[i] * cq, 1);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -541,6 +541,139 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     if (threadIdx.x == 0) row[K] = has_db ? s_db[0] + s_db[1] + s_db[2] + s_db[3] : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm -> activation -> Dropout2d -> 1-output 1x1 conv as ONE op (the tail of the peer heads, Decoders.py:304-311,333-336 and
+// Utils/_deeplab.py head: the [B h w, 512] tensor between the norm and the 512 -> 1 conv never exists).
+//   fwd :  low[m] = b + sum_c w[c] * act((y[m,c] - mean_c) rstd_c gamma_c + beta_c) * drop2d(sample(m), c)        (a wave per row)
+//   bwd :  with G[m,c] = g[m] w[c] act'(pre) drop:  S1_c = sum_m G,  S2_c = sum_m G xhat,  S3_c = sum_m g[m] z[m,c] (= dw),  S4 = sum_m g (= db)
+//          dy[m,c] = gamma_c rstd_c (G - S1_c / M - xhat S2_c / M)   (training; eval: gamma rstd G),  dgamma = S2, dbeta = S1
+// Against bn_apply + rowdot / rowdot_bwd + bn_bwd the forward reads y once instead of moving 4 tensors of its size, the backward moves 3 instead of 7.
+// ------------------------------------------------------------------------------------------------
+template <int VPL>          // VPL float4 per lane: C = 256 * VPL
+__global__ __launch_bounds__(256) void bn_rowdot_fwd_kernel(ChanArgs p, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ low) {
+    const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
+    const int lane = threadIdx.x & 63;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    float sc[VPL][4], sh[VPL][4], wv[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (lane + 64 * v) * 4 + j;
+            const float rs = p.rstd[c] * p.gamma[c];
+            sc[v][j] = rs; sh[v][j] = p.beta[c] - p.mean[c] * rs; wv[v][j] = w[c];
+        }
+    const float b0 = bias ? bias[0] : 0.f;
+    for (long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < p.M; row += nw) {
+        float4 yv[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) yv[v] = *reinterpret_cast<const float4*>(p.a + row * p.C + (lane + 64 * v) * 4);
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const float y4[4] = {yv[v].x, yv[v].y, yv[v].z, yv[v].w};
+            float ds[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop_p > 0.f) {
+                const float4 d4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + (lane + 64 * v) * 4), p.thresh, p.inv_keep);
+                ds[0] = d4.x; ds[1] = d4.y; ds[2] = d4.z; ds[3] = d4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += wv[v][j] * (act_fwd(p.act, fmaf(y4[j], sc[v][j], sh[v][j])) * ds[j]);
+        }
+        s = wave_sum(s);
+        if (lane == 0) low[row] = s + b0;
+    }
+}
+
+// per-channel sums of the backward (thread = one channel quad, fixed-order fold as chan_reduce_kernel): partial row [S1 (C) | S2 (C) | S3 (C) | S4, 0, 0, 0]
+__global__ __launch_bounds__(256) void bn_rowdot_reduce_kernel(ChanArgs p, const float* __restrict__ g, const float* __restrict__ w, int want_w) {
+    extern __shared__ float s_part[];         // [blockDim][13]
+    const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
+    const int QC = p.C >> 2;
+    const long T = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(t0 % QC), c = q * 4;
+    const long total = (long)p.M * QC;
+    float mu[4], rs[4], ga[4], be[4], wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = p.mean[c + j]; rs[j] = p.rstd[c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; wv[j] = w[c + j]; }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, s3[4] = {0.f, 0.f, 0.f, 0.f}, s4 = 0.f;
+    for (long e = t0; e < total; e += T) {
+        const long row = e / QC;
+        const float gr = g[row];
+        const float4 yv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
+        const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop_p > 0.f) {
+            const float4 d4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c), p.thresh, p.inv_keep);
+            ds[0] = d4.x; ds[1] = d4.y; ds[2] = d4.z; ds[3] = d4.w;
+        }
+        if (q == 0) s4 += gr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (y4[j] - mu[j]) * rs[j], pre = xh * ga[j] + be[j];
+            const float G = gr * wv[j] * act_grad(p.act, pre) * ds[j];
+            s1[j] += G; s2[j] += G * xh;
+            if (want_w) s3[j] += gr * (act_fwd(p.act, pre) * ds[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_part[threadIdx.x * 13 + j] = s1[j]; s_part[threadIdx.x * 13 + 4 + j] = s2[j]; s_part[threadIdx.x * 13 + 8 + j] = s3[j]; }
+    s_part[threadIdx.x * 13 + 12] = s4;
+    __syncthreads();
+    const int blk_q0 = (int)(((long)blockIdx.x * blockDim.x) % QC);
+    float* dst = p.part + (long)blockIdx.x * (3 * p.C + 4);
+    for (int qq = threadIdx.x; qq < QC; qq += blockDim.x) {
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, a3[4] = {0.f, 0.f, 0.f, 0.f}, a4 = 0.f;
+        for (int tt = (qq - blk_q0 + QC) % QC; tt < (int)blockDim.x; tt += QC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a1[j] += s_part[tt * 13 + j]; a2[j] += s_part[tt * 13 + 4 + j]; a3[j] += s_part[tt * 13 + 8 + j]; }
+            a4 += s_part[tt * 13 + 12];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[qq * 4 + j] = a1[j]; dst[p.C + qq * 4 + j] = a2[j]; dst[2 * p.C + qq * 4 + j] = a3[j]; }
+        if (qq == 0) { dst[3 * p.C] = a4; dst[3 * p.C + 1] = 0.f; dst[3 * p.C + 2] = 0.f; dst[3 * p.C + 3] = 0.f; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_rowdot_bwd_apply_kernel(ChanArgs p, const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dy,
+                                                                 float* dgamma, float* dbeta, float* dw, float* db, int training) {
+    const uint32_t k0e = p.k0 ^ (p.seed ? p.seed[0] : 0u), k1e = p.k1 + (p.seed ? p.seed[1] : 0u);
+    const int QC = p.C >> 2;
+    const long T = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(t0 % QC) * 4;
+    const long rstep = T / QC;
+    const double invM = 1.0 / (double)p.M;
+    float mu[4], rs[4], ga[4], be[4], wv[4], sg[4], sgx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mu[j] = p.mean[c + j]; rs[j] = p.rstd[c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; wv[j] = w[c + j];
+        sg[j] = training ? (float)(p.ws[c + j] * invM) : 0.f;
+        sgx[j] = training ? (float)(p.ws[p.C + c + j] * invM) : 0.f;
+    }
+    for (long row = t0 / QC; row < p.M; row += rstep) {
+        const float gr = g[row];
+        const float4 yv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
+        const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop_p > 0.f) {
+            const float4 q4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)((row / p.rows_per_sample) * p.C + c), p.thresh, p.inv_keep);
+            ds[0] = q4.x; ds[1] = q4.y; ds[2] = q4.z; ds[3] = q4.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (y4[j] - mu[j]) * rs[j];
+            const float G = gr * wv[j] * act_grad(p.act, xh * ga[j] + be[j]) * ds[j];
+            o[j] = ga[j] * rs[j] * (G - sg[j] - xh * sgx[j]);
+        }
+        *reinterpret_cast<float4*>(dy + row * p.C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (blockIdx.x == 0 && dgamma) {
+        for (int cc = threadIdx.x; cc < p.C; cc += blockDim.x) { dbeta[cc] = (float)p.ws[cc]; dgamma[cc] = (float)p.ws[p.C + cc]; dw[cc] = (float)p.ws[2 * p.C + cc]; }
+        if (threadIdx.x == 0 && db) db[0] = (float)p.ws[3 * p.C];
+    }
+}
+
 int chan_grid(long M, int C, int max_blocks) {
     // grid*256 must be a multiple of C/4
     const int QC = C / 4;
@@ -698,6 +831,53 @@ extern "C" int mdvit_bn_bwd(const float* dz, const float* y, const float* mean, 
     hipLaunchKernelGGL((chan_reduce_kernel<1>), dim3(grid, groups), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32), groups), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chan_grid(Mg, C, max(1, 4096 / groups)), groups), dim3(256), 0, s, a, dy, dgamma, dbeta, training);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" size_t mdvit_bn_rowdot_ws_bytes(int32_t M, int32_t C) {
+    if (M <= 0 || C <= 0 || C % 4) return 0;
+    return sizeof(double) * (3 * (size_t)C + 4) + sizeof(float) * (3 * (size_t)C + 4) * (size_t)chan_grid(M, C, CHAN_MAX_BLOCKS);
+}
+
+extern "C" int mdvit_bn_rowdot_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w, const float* b,
+                                   float* low, int32_t M, int32_t C, int32_t act, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* seed,
+                                   int32_t rows_per_sample, void* stream) {
+    MDVIT_CHECK_ARG(M > 0 && (C == 256 || C == 512 || C == 1024), MDVIT_E_SHAPE, "bn_rowdot_fwd: built for C = 256 / 512 / 1024 (M=%d C=%d)", M, C);
+    MDVIT_CHECK_ARG(y && mean && rstd && gamma && beta && w && low && aligned16(y), MDVIT_E_SHAPE, "bn_rowdot_fwd: null or misaligned operand");
+    ChanArgs a; memset(&a, 0, sizeof(a));
+    a.a = y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
+    fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
+    a.seed = seed;
+    const dim3 grid(min(cdiv(M, 4), 8192));
+    if (C == 256) hipLaunchKernelGGL((bn_rowdot_fwd_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a, w, b, low);
+    else if (C == 512) hipLaunchKernelGGL((bn_rowdot_fwd_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a, w, b, low);
+    else hipLaunchKernelGGL((bn_rowdot_fwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a, w, b, low);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_bn_rowdot_bwd(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w,
+                                   float* dy, float* dgamma, float* dbeta, float* dw, float* db, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t act,
+                                   int32_t training, float drop2d_p, uint32_t key0, uint32_t key1, const uint32_t* seed, int32_t rows_per_sample, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, MDVIT_E_SHAPE, "bn_rowdot_bwd: need C %% 4 == 0, C <= 4096 (M=%d C=%d)", M, C);
+    MDVIT_CHECK_ARG(g && y && mean && rstd && gamma && beta && w && dy && aligned16(y) && aligned16(dy), MDVIT_E_SHAPE, "bn_rowdot_bwd: null or misaligned operand");
+    MDVIT_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (dgamma == nullptr) == (dw == nullptr), MDVIT_E_SHAPE,
+                    "bn_rowdot_bwd: dgamma, dbeta and dw must be all given or all NULL (data gradient only)");
+    MDVIT_CHECK_ARG(ws && ws_bytes >= mdvit_bn_rowdot_ws_bytes(M, C), MDVIT_E_WORKSPACE, "bn_rowdot_bwd: workspace too small (mdvit_bn_rowdot_ws_bytes)");
+    ChanArgs a; memset(&a, 0, sizeof(a));
+    a.a = y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.act = act;
+    a.ws = (double*)ws; a.part = (float*)((double*)ws + 3 * (size_t)C + 4);
+    fill_drop(a, drop2d_p, key0, key1, rows_per_sample);
+    a.seed = seed;
+    const int C2 = 3 * C + 4;
+    if (training || dgamma) {
+        const int grid = chan_grid(M, C, CHAN_MAX_BLOCKS);
+        hipLaunchKernelGGL(bn_rowdot_reduce_kernel, dim3(grid), dim3(256), sizeof(float) * 256 * 13, s, a, g, w, dgamma != nullptr);
+        hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(C2, 32), 1), dim3(256), 0, s, a.part, a.ws, grid, C2);
+    }
+    hipLaunchKernelGGL(bn_rowdot_bwd_apply_kernel, dim3(chan_grid(M, C, 4096)), dim3(256), 0, s, a, g, w, dy, dgamma, dbeta, dw, db, training);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -68,6 +68,7 @@ class MLPDecoderFM(nn.Module):
         # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)      (MLPDecoder: no x5 term, bf rides on q = 0)
         blocks = ops.split_cols(Wf, [hid] * 4 + ([Wf.shape[1] - 4 * hid] if self.with_fm else []))      # column blocks of the fuse weight
         acc = ops.linear(features[4], blocks[4], bias) if self.with_fm else None              # [B,h,w,hid]
+        lows = []                                                                              # the projected lower-resolution features
         for q, lin in enumerate(lins):
             Wf_q = blocks[q]
             Wc = ops.matmul(Wf_q, lin.weight.view(hid, -1))                                    # [hid, C_q]
@@ -79,10 +80,14 @@ class MLPDecoderFM(nn.Module):
             elif fq.shape[1] == h and fq.shape[2] == w:
                 acc = ops.linear(fq, Wc, bc, residual=acc)
             else:
-                acc = ops.upsample_bilinear(ops.linear(fq, Wc, bc), h, w, base=acc)
+                lows.append(ops.linear(fq, Wc, bc))
+        if lows:
+            acc = ops.upsample_sum(acc, lows, h, w)            # acc + sum_q resize(P_q): ONE pass over the [B,h,w,512] sum instead of one per source
         p = self.dropout.p if self.training else 0.0
-        y = self.linear_fuse[1](acc, drop2d_p=p)                                              # BN + ReLU + Dropout2d
-        low = ops.rowdot(y, self.linear_out.weight, self.linear_out.bias)                     # [B,h,w]
+        bn = self.linear_fuse[1]
+        # BN + ReLU + Dropout2d + linear_out (512 -> 1) as ONE op: the normalised [B,h,w,512] tensor is never written
+        low = ops.bn_act_rowdot(acc, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training, bn.act,
+                                self.linear_out.weight, self.linear_out.bias, bn.eps, bn.momentum, p)          # [B,h,w]
         out = ops.upsample_bilinear(low.view(B, h, w, 1), int(img_size[0]), int(img_size[1]))
         return out.view(B, 1, int(img_size[0]), int(img_size[1]))
 
@@ -138,8 +143,10 @@ class DeepLabV3Decoder(nn.Module):
     def forward(self, features, img_size, out_feat=False):
         x = features[3] if isinstance(features, (list, tuple)) else features       # encoder_outs[-1] (mdvit.py:715-724 pass the 4 encoder features)
         c = self.classifier
-        y = c[2](ops.conv3x3_dense(c[0](x), c[1].weight, None, 1))
+        y = ops.conv3x3_dense(c[0](x), c[1].weight, None, 1)
         B, h, w, _ = y.shape
-        low = ops.rowdot(y, c[4].weight, c[4].bias)
+        bn = c[2]
+        low = ops.bn_act_rowdot(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training, bn.act, c[4].weight, c[4].bias,
+                                bn.eps, bn.momentum, 0.0)
         out = ops.upsample_bilinear(low.view(B, h, w, 1), int(img_size[0]), int(img_size[1]))
         return out.view(B, 1, int(img_size[0]), int(img_size[1]))

@@ -1556,6 +1556,68 @@ class _BNAct(torch.autograd.Function):
         return dy, dg, db, None, None, None, None, None, None, None, None, None, None
 
 
+class _BNActRowDot(torch.autograd.Function):
+    """BatchNorm2d -> activation -> Dropout2d -> 1-output 1x1 conv as ONE op (csrc/norm.hip: bn_rowdot_*): the tail of the peer heads
+    (Decoders.py:304-311,333-336).  The normalised tensor between the norm and the conv is never written; the backward needs y and the
+    row gradient only."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, w, b, training, eps, momentum, act, drop2d_p, rows_per_sample):
+        ctx.set_materialize_grads(False)
+        _chk(y, gamma, beta, running_mean, running_var, w, b)
+        Cn = y.shape[-1]
+        M = y.numel() // Cn
+        dev = y.device
+        mean = _empty((Cn,), device=dev, dtype=torch.float32)
+        rstd = _empty_like(mean)
+        if training:
+            wsb = _lib.load().mdvit_bn_ws_bytes(M, Cn, 1)
+            ws = _empty((wsb // 8 + 1,), device=dev, dtype=torch.float64)
+            call("mdvit_bn_stats", _p(y), _p(ws), wsb, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                 C.c_void_p(nbt.data_ptr()) if nbt is not None else None, M, Cn, 1, 0, eps, momentum, _stream())
+        else:
+            call("mdvit_bn_eval_prep", _p(running_mean), _p(running_var), _p(mean), _p(rstd), Cn, eps, _stream())
+        key = _next_key() if drop2d_p > 0 else (0, 0)
+        low = _empty((M,), device=dev, dtype=torch.float32)
+        call("mdvit_bn_rowdot_fwd", _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(w), _p(b), _p(low), M, Cn, act, drop2d_p, key[0], key[1],
+             _seed_ptr() if drop2d_p > 0 else None, rows_per_sample, _stream())
+        ctx.save_for_backward(y, gamma, beta, mean, rstd, w)
+        ctx.meta = (training, act, drop2d_p, key, rows_per_sample, b is not None)
+        return low
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 14
+        y, gamma, beta, mean, rstd, w = ctx.saved_tensors
+        training, act, drop2d_p, key, rps, has_b = ctx.meta
+        g = _c(g)
+        Cn = y.shape[-1]
+        M = y.numel() // Cn
+        dy = _empty_like(y)
+        dg = db_ = dw = dbias = None
+        if not _dgrad_only:
+            dg, db_, dw, dbias = _flat_like(gamma, gamma, w.reshape(-1), (1,) if has_b else None)
+        wsb = _lib.load().mdvit_bn_rowdot_ws_bytes(M, Cn)
+        ws = _empty((wsb // 8 + 1,), device=y.device, dtype=torch.float64)
+        call("mdvit_bn_rowdot_bwd", _p(g), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(w), _p(dy), _p(dg), _p(db_), _p(dw), _p(dbias), _p(ws), wsb,
+             M, Cn, act, int(training), drop2d_p, key[0], key[1], _seed_ptr() if drop2d_p > 0 else None, rps, _stream())
+        return (dy, dg, db_, None, None, None, None if dw is None else dw.view_as(w), dbias, None, None, None, None, None, None)
+
+
+def bn_act_rowdot(y, gamma, beta, running_mean, running_var, nbt, training, act, w, b, eps=1e-5, momentum=0.1, drop2d_p=0.0):
+    """y NHWC [B,h,w,C] -> [B,h,w]: the 1-channel 1x1 conv (w: C elements, b: [1] or None) of Dropout2d(act(BatchNorm(y))).  One statistics
+    group with shared parameters and C in {256, 512, 1024}: one fused op; anything else: bn_act + rowdot."""
+    Cn = y.shape[-1]
+    groups = _bn_groups if (training or gamma.dim() == 2) else 1
+    if groups == 1 and gamma.dim() == 1 and Cn in (256, 512, 1024) and y.is_cuda:
+        rows_per_sample = y.numel() // (y.shape[0] * Cn)
+        low = _BNActRowDot.apply(_c(y), _c(gamma), _c(beta), running_mean, running_var, nbt, w, b, bool(training), float(eps), float(momentum), int(act),
+                                 float(drop2d_p), int(rows_per_sample))
+        return low.view(y.shape[:-1])
+    return rowdot(bn_act(y, gamma, beta, running_mean, running_var, nbt, training, act, eps, momentum, drop2d_p), w, b)
+
+
 # ---- domain-batched forward: the batch is `groups` equal consecutive domain batches -----------------------------
 # The reference runs one forward per domain (multi_train_MDViT.py:137-153); the only op on the trunk that couples the
 # samples of a forward is BatchNorm (batch statistics).  With bn_groups(G) active every train-mode BatchNorm keeps
@@ -1710,6 +1772,55 @@ def upsample_bilinear(x, Ho, Wo, base=None):
     if base is None and x.shape[1] == Ho and x.shape[2] == Wo:
         return x
     return _Upsample.apply(_c(x), int(Ho), int(Wo), None if base is None else _c(base))
+
+
+class _UpsampleSum(torch.autograd.Function):
+    """y = base + sum_i resize(x_i) for up to three NHWC sources of different sizes in ONE pass; the backward folds dy along W for all sources
+    in one launch (the dy row is read from HBM once), along H per source; base's gradient is dy itself."""
+
+    @staticmethod
+    def forward(ctx, base, Ho, Wo, *xs):
+        ctx.set_materialize_grads(False)
+        _chk(base, *xs)
+        B, _, _, Cn = xs[0].shape
+        n = len(xs)
+        y = _empty((B, Ho, Wo, Cn), device=xs[0].device, dtype=torch.float32)
+        ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        Hi = (C.c_int32 * n)(*[x.shape[1] for x in xs])
+        Wi = (C.c_int32 * n)(*[x.shape[2] for x in xs])
+        call("mdvit_upsample_multi_fwd", ptrs, Hi, Wi, n, _p(base), _p(y), B, Ho, Wo, Cn, _stream())
+        ctx.meta = (B, Ho, Wo, Cn, [(x.shape[1], x.shape[2]) for x in xs], base is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Ho, Wo, Cn, dims, has_base = ctx.meta
+        if g is None:
+            return (None,) * (3 + len(dims))
+        g = _c(g)
+        n = len(dims)
+        dxs = [_empty((B, h, w, Cn), device=g.device, dtype=torch.float32) for h, w in dims]
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in dxs])
+        Hi = (C.c_int32 * n)(*[h for h, _ in dims])
+        Wi = (C.c_int32 * n)(*[w for _, w in dims])
+        wsb = _lib.load().mdvit_upsample_multi_bwd_ws_bytes(Wi, n, B, Ho, Cn)
+        ws = _empty((wsb // 4,), device=g.device, dtype=torch.float32)
+        call("mdvit_upsample_multi_bwd", _p(g), ptrs, Hi, Wi, n, _p(ws), wsb, B, Ho, Wo, Cn, _stream())
+        return (g if has_base else None, None, None, *dxs)
+
+
+def upsample_sum(base, xs, Ho, Wo):
+    """base [B,Ho,Wo,C] (or None) + the bilinear resizes (align_corners=False) of the NHWC tensors xs to Ho x Wo, in one pass per three sources."""
+    xs = [_c(x) for x in xs]
+    out = base
+    while xs:
+        chunk, xs = xs[:3], xs[3:]
+        if chunk[0].shape[-1] % 4 or not chunk[0].is_cuda:
+            for x in chunk:
+                out = upsample_bilinear(x, Ho, Wo, base=out)
+            continue
+        out = _UpsampleSum.apply(None if out is None else _c(out), int(Ho), int(Wo), *chunk)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -609,6 +609,63 @@ def test_bn_act_eval_and_dropout2d():
     assert z_plain.abs().min() > 0
 
 
+@pytest.mark.parametrize("B,H,W,C,act,drop,training", [(3, 16, 16, 512, "relu", 0.25, True), (2, 9, 7, 256, "hswish", 0.0, True), (2, 8, 8, 512, "relu", 0.0, False),
+                                                        (1, 32, 32, 1024, "relu", 0.1, True)])
+def test_bn_act_rowdot_fused_equals_bn_act_then_rowdot(B, H, W, C, act, drop, training, monkeypatch):
+    """ops.bn_act_rowdot (BatchNorm -> activation -> Dropout2d -> 1-channel 1x1 conv in one op, the tail of the peer heads, Decoders.py:304-311)
+    against the two operators it replaces on the same dropout key: output, data gradient, the four parameter gradients, running statistics;
+    the data-gradient-only sweep; and without dropout against an fp64 restatement."""
+    import itertools
+    from mdvit_amd import ops
+    from mdvit_amd._lib import ACT_HSWISH, ACT_RELU
+    a = ACT_RELU if act == "relu" else ACT_HSWISH
+    y0, gam, bet = rnd(B, H, W, C, seed=300, scale=2.0), rnd(C, seed=301) + 1.5, rnd(C, seed=302)
+    w, b = rnd(1, C, 1, 1, seed=303, scale=0.2), rnd(1, seed=304)
+    g = rnd(B, H, W, seed=305)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "_key_counter", itertools.count(500))
+        ins = [t.to(dev()).requires_grad_(True) for t in (y0, gam, bet, w, b)]
+        rm, rv, nbt = torch.zeros(C, device=dev()), torch.ones(C, device=dev()), torch.zeros((), dtype=torch.long, device=dev())
+        if not training:
+            rm, rv = rnd(C, seed=306).to(dev()), (rnd(C, seed=307).abs() + 0.5).to(dev())
+        if fused:
+            low = ops.bn_act_rowdot(ins[0], ins[1], ins[2], rm, rv, nbt, training, a, ins[3], ins[4], drop2d_p=drop)
+        else:
+            low = ops.rowdot(ops.bn_act(ins[0], ins[1], ins[2], rm, rv, nbt, training, a, drop2d_p=drop), ins[3], ins[4])
+        low.backward(g.to(dev()))
+        res.append([low.detach()] + [t.grad for t in ins] + [rm.clone(), rv.clone()])
+    for name, x_, r_ in zip(("low", "dy", "dgamma", "dbeta", "dw", "db", "running_mean", "running_var"), res[0], res[1]):
+        check(x_, r_, tol=5e-6, name=name)
+    # data-gradient-only sweep: dy alone
+    monkeypatch.setattr(ops, "_key_counter", itertools.count(500))
+    ins = [t.to(dev()).requires_grad_(True) for t in (y0, gam, bet, w, b)]
+    rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    if not training:
+        rm, rv = rnd(C, seed=306).to(dev()), (rnd(C, seed=307).abs() + 0.5).to(dev())
+    low = ops.bn_act_rowdot(ins[0], ins[1], ins[2], rm, rv, None, training, a, ins[3], ins[4], drop2d_p=drop)
+    ops.set_dgrad_only(True)
+    try:
+        low.backward(g.to(dev()))
+    finally:
+        ops.set_dgrad_only(False)
+    check(ins[0].grad, res[0][1], tol=1e-6, name="dy (data-gradient-only sweep)")
+    assert all(t.grad is None for t in ins[1:])
+    if drop == 0.0:
+        def ref_fn(y, gm_, bt_, w_, b_):
+            y2 = y.double().reshape(-1, C)
+            if training:
+                mu, var = y2.mean(0), y2.var(0, unbiased=False)
+            else:
+                mu, var = rm.double().cpu(), rv.double().cpu()
+            pre = (y2 - mu) / torch.sqrt(var + 1e-5) * gm_.double() + bt_.double()
+            z = torch.relu(pre) if act == "relu" else F.hardswish(pre)
+            return (z @ w_.double().reshape(-1) + b_.double()).reshape(B, H, W)
+        ref, gr = grads_of(ref_fn, [y0, gam, bet, w, b], g.double())
+        for name, x_, r_ in zip(("low", "dy", "dgamma", "dbeta", "dw", "db"), res[0], [ref] + gr):
+            check(x_, r_, tol=2e-4, name=name + " vs fp64")
+
+
 @pytest.mark.parametrize("B,Hi,Wi,Ho,Wo,C", [(2, 8, 8, 16, 16, 64), (1, 4, 4, 32, 32, 128), (2, 16, 16, 64, 64, 1), (1, 3, 4, 24, 32, 512), (2, 5, 7, 11, 13, 8), (1, 6, 8, 6, 8, 64)])
 def test_upsample(B, Hi, Wi, Ho, Wo, C):
     from mdvit_amd.ops import _Upsample
@@ -620,6 +677,36 @@ def test_upsample(B, Hi, Wi, Ho, Wo, C):
     base = rnd(B, Ho, Wo, C, seed=102).to(dev())
     out2 = _Upsample.apply(nhwc(x).to(dev()), Ho, Wo, base)          # base + resize(x) in one pass
     check(out2, out.detach() + base, name="accumulate")
+
+
+def test_upsample_sum_equals_chained_resizes():
+    """ops.upsample_sum (base + three bilinear sources in one pass; the backward's width folds in one launch) == the chained single-source calls:
+    forward and every gradient to fp32 round-off, and the forward against F.interpolate in fp64"""
+    from mdvit_amd import ops
+    B, Ho, Wo, C = 2, 24, 40, 64
+    base = rnd(B, Ho, Wo, C, seed=400)
+    xs = [rnd(B, 12, 20, C, seed=401), rnd(B, 6, 10, C, seed=402), rnd(B, 3, 5, C, seed=403)]
+    g = rnd(B, Ho, Wo, C, seed=404).to(dev())
+    res = []
+    for fused in (True, False):
+        ins = [t.to(dev()).requires_grad_(True) for t in [base] + xs]
+        if fused:
+            y = ops.upsample_sum(ins[0], ins[1:], Ho, Wo)
+        else:
+            y = ins[0]
+            for x in ins[1:]:
+                y = ops.upsample_bilinear(x, Ho, Wo, base=y)
+        y.backward(g)
+        res.append([y.detach()] + [t.grad for t in ins])
+    check(res[0][0], res[1][0], tol=1e-6, name="y fused vs chained")       # the compiler contracts the tap sums differently: round-off, not bits
+    for name, a, b in zip(("dbase", "dx1", "dx2", "dx3"), res[0][1:], res[1][1:]):
+        check(a, b, tol=1e-6, name=name)
+    ref = base.double() + sum(F.interpolate(x.double().permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=False).permute(0, 2, 3, 1) for x in xs)
+    check(res[0][0], ref, tol=1e-5, name="y vs F.interpolate")
+    # without a base
+    y2 = ops.upsample_sum(None, [x.to(dev()) for x in xs[:2]], Ho, Wo)
+    ref2 = sum(F.interpolate(x.double().permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=False).permute(0, 2, 3, 1) for x in xs[:2])
+    check(y2, ref2, tol=1e-5, name="y without base")
 
 
 def test_rowdot():
