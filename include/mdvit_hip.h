@@ -299,6 +299,12 @@ int mdvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                         const float* add, float* dx, float* dgamma, float* dbeta, void* ws /* n = 2C */, size_t ws_bytes,
                         int32_t M, int32_t C, int32_t groups, void* stream);
+/* The same backward with a SECOND output: dx_masked = dx * dropout mask(key0, key1) * rowscale[row / rows_per_scale] -- the masked upstream
+ * gradient of the Linear whose output (after Dropout / DropPath, mdvit.py:310-311,353) is the LayerNorm's input, produced in the pass that
+ * writes dx instead of a second pass over it (mdvit_colsum_f32's `masked` output, same arithmetic).  C in {64, 128, 320, 512}. */
+int mdvit_layernorm_bwd_masked(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* add, float* dx,
+                               float* dx_masked, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t groups,
+                               float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, const uint32_t* seed, void* stream);
 
 /* ---- 3x3 convolutions on NHWC ------------------------------------------------------------------
  * dwconv3x3: depthwise, pad 1, stride 1|2, optional bias, optional "+ input" (ConvPosEnc,

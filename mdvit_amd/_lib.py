@@ -153,6 +153,7 @@ _SIGS = {
     "mdvit_colsum_f32": [vp, i64, vp, vp, vp, C.c_size_t, i32, i32, f32, u32, u32, vp, i32, i32, vp, vp],
     "mdvit_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "mdvit_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, vp],
+    "mdvit_layernorm_bwd_masked": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, f32, u32, u32, vp, i32, vp, vp],
     "mdvit_dwconv3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_dwconv3x3_bwd": [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_gconv2_3x3_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -231,19 +231,25 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
     }
     // ---- LN2 (+ the residual branch's gradient, which is dy itself) ---------------------------------------------------------------
-    float* dx2 = (d.drop_p > 0.f || d.rowscale1 != nullptr) ? A.take(T * C) : S.take(T * C);      // (unmasked: it IS the proj weight gradient's operand)
+    // The proj Linear's masked upstream gradient gm1 = dx2 * mask * row scale leaves the same kernel (one pass over dx2 instead of two)
+    const bool masked1 = d.drop_p > 0.f || d.rowscale1 != nullptr;
+    float* dx2 = masked1 ? A.take(T * C) : S.take(T * C);      // (unmasked: it IS the proj weight gradient's operand)
+    float* gm1 = masked1 ? S.take(T * C) : dx2;
     {
         const bool lnw = want_w || !fast_ln;
         const size_t pb = lnw ? mdvit_partials_ws_bytes(2 * C) : 0;
         void* pw = lnw ? A.take_bytes(pb) : nullptr;
         float* dg = want_w ? G.n2_g : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
         float* db = want_w ? G.n2_b : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
-        BLK_RUN(mdvit_layernorm_bwd(dcur2, sv.x2, d.n2_g, sv.mean2, sv.rstd2, dy, dx2, dg, db, pw, pb, M, C, d.ln_groups, s));
+        if (masked1 && fast_ln) {
+            BLK_RUN(mdvit_layernorm_bwd_masked(dcur2, sv.x2, d.n2_g, sv.mean2, sv.rstd2, dy, dx2, gm1, dg, db, pw, pb, M, C, d.ln_groups, d.drop_p, d.key_proj[0],
+                                               d.key_proj[1], d.rowscale1, N_tok, seed, s));
+        } else {
+            BLK_RUN(mdvit_layernorm_bwd(dcur2, sv.x2, d.n2_g, sv.mean2, sv.rstd2, dy, dx2, dg, db, pw, pb, M, C, d.ln_groups, s));
+            if (masked1) BLK_RUN(mdvit_colsum_f32(dx2, C, nullptr, gm1, nullptr, 0, M, C, d.drop_p, d.key_proj[0], d.key_proj[1], d.rowscale1, N_tok, 0, seed, s));
+        }
     }
-    // ---- proj Linear: masked upstream gradient once, data gradient, weight gradient (side) ------------------------------------------
-    const bool masked1 = d.drop_p > 0.f || d.rowscale1 != nullptr;
-    float* gm1 = masked1 ? S.take(T * C) : dx2;
-    if (masked1) BLK_RUN(mdvit_colsum_f32(dx2, C, nullptr, gm1, nullptr, 0, M, C, d.drop_p, d.key_proj[0], d.key_proj[1], d.rowscale1, N_tok, 0, seed, s));
+    // ---- proj Linear: data gradient, weight gradient (side) ---------------------------------------------------------------------------
     float* datt = tmp;
     {
         MdvitGemmDesc g;

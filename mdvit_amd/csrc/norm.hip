@@ -153,13 +153,20 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const float* __restrict__
     }
 }
 
+// optional second output of the LayerNorm backward: dx * dropout mask * DropPath row scale of the Linear that produced the LayerNorm's input
+struct LnMasked {
+    float* out; float drop_p; uint32_t k0, k1, thresh; float inv_keep; const float* rowscale; int rows_per_scale; const uint32_t* seed;
+};
+
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ add, float* __restrict__ dx,
-                                                       float* __restrict__ part, int M) {
+                                                       float* __restrict__ part, int M, const LnMasked mk) {
     constexpr int C = 64 * VPL;
+    const long grow0 = (long)blockIdx.y * M;         // first row of this parameter group in the whole [rows, C] tensor (mask indices, row scales)
     LN_GROUP_BWD(C);
+    const uint32_t k0e = mk.k0 ^ (mk.seed ? mk.seed[0] : 0u), k1e = mk.k1 + (mk.seed ? mk.seed[1] : 0u);
     __shared__ float s_dg[4][C], s_db[4][C];
     const int sub = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long r0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4, nr = ((long)gridDim.x * blockDim.x) >> 4;
@@ -195,6 +202,16 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__
                 o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
             }
             *reinterpret_cast<float4*>(dx + row * C + 4 * (sub + 16 * j)) = o;
+            if (mk.out) {        // the consumer Linear's masked upstream gradient (chan_reduce_kernel<2>'s arithmetic, no second pass over dx)
+                const long gr = grow0 + row;
+                const float r = mk.rowscale ? mk.rowscale[gr / mk.rows_per_scale] : 1.f;
+                float4 ds = make_float4(r, r, r, r);
+                if (mk.drop_p > 0.f) {
+                    const float4 d4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)(gr * C + 4 * (sub + 16 * j)), mk.thresh, mk.inv_keep);
+                    ds.x *= d4.x; ds.y *= d4.y; ds.z *= d4.z; ds.w *= d4.w;
+                }
+                *reinterpret_cast<float4*>(mk.out + gr * C + 4 * (sub + 16 * j)) = make_float4(o.x * ds.x, o.y * ds.y, o.z * ds.z, o.w * ds.w);
+            }
         }
     }
     if (part == nullptr) return;          // data-gradient-only sweep: no parameter gradients wanted (uniform)
@@ -729,10 +746,35 @@ extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const flo
     return MDVIT_OK;
 }
 
+static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream);
+
 // dgamma / dbeta: [groups, C] each
 extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                    const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                    int32_t M, int32_t C, int32_t groups, void* stream) {
+    LnMasked mk; memset(&mk, 0, sizeof(mk));
+    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
+}
+
+extern "C" int mdvit_layernorm_bwd_masked(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                          const float* add, float* dx, float* dx_masked, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                          int32_t M, int32_t C, int32_t groups, float drop_p, uint32_t key0, uint32_t key1, const float* rowscale,
+                                          int32_t rows_per_scale, const uint32_t* seed, void* stream) {
+    MDVIT_CHECK_ARG(C == 64 || C == 128 || C == 320 || C == 512, MDVIT_E_SHAPE, "layernorm_bwd_masked: C=%d not built (64/128/320/512)", C);
+    MDVIT_CHECK_ARG(dx_masked != nullptr && drop_p >= 0.f && drop_p < 1.f && (rowscale == nullptr || rows_per_scale > 0), MDVIT_E_SHAPE,
+                    "layernorm_bwd_masked: bad mask arguments");
+    MDVIT_CHECK_ARG((long)M * C < (1L << 32), MDVIT_E_SHAPE, "layernorm_bwd_masked: dropout index space exceeds 2^32");
+    LnMasked mk; memset(&mk, 0, sizeof(mk));
+    mk.out = dx_masked; mk.drop_p = drop_p; mk.k0 = key0; mk.k1 = key1; mk.thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    mk.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; mk.rowscale = rowscale; mk.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; mk.seed = seed;
+    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
+}
+
+static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
     MDVIT_CHECK_ARG(groups > 0 && groups <= 64 && M % groups == 0, MDVIT_E_SHAPE, "layernorm_bwd: M=%d is not a multiple of groups=%d", M, groups);
@@ -744,10 +786,10 @@ extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float*
         nblk = min(cdiv(Mg, 64), 1024 / groups);
         if (want_params) MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");
         dim3 grid16(nblk, groups);
-        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
-        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
-        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
-        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg);
+        if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg, mk);
+        else if (C == 128) hipLaunchKernelGGL((ln_bwd16_kernel<2>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg, mk);
+        else if (C == 320) hipLaunchKernelGGL((ln_bwd16_kernel<5>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg, mk);
+        else hipLaunchKernelGGL((ln_bwd16_kernel<8>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg, mk);
     } else {
         nblk = min(cdiv(Mg, 16), 1024 / groups);
         MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");

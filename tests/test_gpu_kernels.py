@@ -347,6 +347,40 @@ def test_layernorm(M, C):
         check(a, r, name=n)
 
 
+@pytest.mark.parametrize("M,C,groups,p,scaled", [(4096, 64, 1, 0.1, True), (1536, 128, 4, 0.1, False), (640, 320, 1, 0.0, True), (512, 512, 2, 0.25, True)])
+def test_layernorm_bwd_masked_second_output_is_the_two_pass_result_bit_for_bit(M, C, groups, p, scaled):
+    """mdvit_layernorm_bwd_masked: dx, dgamma, dbeta == mdvit_layernorm_bwd, and its second output == mdvit_colsum_f32's masked copy of dx
+    (dropout mask of the producing Linear x DropPath row scale) -- one pass over dx instead of two"""
+    from mdvit_amd import ops
+    from mdvit_amd.ops import call, _p, _stream, _partials_ws
+    d = dev()
+    x, g, add = (rnd(M, C, seed=50, scale=2.0) + 0.3).to(d), rnd(M, C, seed=51).to(d), rnd(M, C, seed=52).to(d)
+    ga = (1 + 0.5 * rnd(groups, C, seed=53)).to(d).contiguous()
+    be = rnd(groups, C, seed=54, scale=0.1).to(d).contiguous()
+    y, mean, rstd = torch.empty_like(x), torch.empty(M, device=d), torch.empty(M, device=d)
+    call("mdvit_layernorm_fwd", _p(x), _p(ga), _p(be), _p(y), _p(mean), _p(rstd), M, C, groups, 1e-6, _stream())
+    rows_per_scale = 64
+    rs = (torch.rand(M // rows_per_scale, device=d) > 0.3).float() / 0.7 if scaled else None
+    k0, k1 = 0x1234abcd, 0x9e3779b9
+    res = []
+    for fused in (False, True):
+        dx, dxm = torch.empty_like(x), torch.empty_like(x)
+        dg, db = torch.empty(groups, C, device=d), torch.empty(groups, C, device=d)
+        wsp, wsb, _keep = _partials_ws(2 * C, d)
+        if fused:
+            call("mdvit_layernorm_bwd_masked", _p(g), _p(x), _p(ga), _p(mean), _p(rstd), _p(add), _p(dx), _p(dxm), _p(dg), _p(db), wsp, wsb, M, C, groups,
+                 p, k0, k1, _p(rs), rows_per_scale, None, _stream())
+        else:
+            call("mdvit_layernorm_bwd", _p(g), _p(x), _p(ga), _p(mean), _p(rstd), _p(add), _p(dx), _p(dg), _p(db), wsp, wsb, M, C, groups, _stream())
+            call("mdvit_colsum_f32", _p(dx), C, None, _p(dxm), None, 0, M, C, p, k0, k1, _p(rs), rows_per_scale, 0, None, _stream())
+        res.append((dx, dxm, dg, db))
+    for name, a, b in zip(("dx", "dx_masked", "dgamma", "dbeta"), res[0], res[1]):
+        assert torch.equal(a, b), name
+    if p > 0:
+        keep = float((res[1][1] != 0).float().mean())
+        assert abs(keep - (1 - p) * (float((rs != 0).float().mean()) if scaled else 1.0)) < 0.02
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
