@@ -216,6 +216,18 @@ int mdvit_mlp_rc_fwd(const float* x, const void* W1p, const float* b1, const voi
                      float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
 int mdvit_mlp_rc_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx,
                        int32_t M, int32_t C, int32_t hidden, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
+/* The MLP forward on 16-token waves (16x16x32 MFMA tiles), built for C = 64 and C = 128: fc1 + GELU + Dropout + fc2 + Dropout + DropPath + residual
+ * (mpvit.py:71-78 inside mdvit.py:357-360) in ONE kernel with the hidden chunk chained in registers; h != NULL also writes
+ * h = drop1(gelu(x W1^T + b1)) [M, hidden] once for the fc2 weight-gradient GEMM (C = 128, where recomputing it there costs more than it saves). */
+int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
+                       int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                       uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
+/* The same data gradient on 16-token waves (16x16x32 MFMA tiles), built for C = 64 and C = 128: the C = 128 stages' MLP backward data path
+ * (mpvit.py:71-78 with hidden = 8 C, mdvit.py:357-360) in ONE kernel instead of the recomputing fc2 data-gradient GEMM + the fc1 data-gradient
+ * GEMM.  du != NULL additionally writes the hidden-layer gradient [M, hidden] (operand of the two weight-gradient GEMMs of the full sweep);
+ * du == NULL (data-gradient-only sweep) moves no [tokens, hidden] tensor.  hidden % 32 == 0. */
+int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
+                         int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
 size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
 /* tuning hook (tools/mlp_rc_check.py): forward kernel variant -- 2: software-pipelined waves at 2 per SIMD, 3: plain waves at 3 per SIMD */
 int mdvit_mlp_rc_config(int32_t fwd_variant);

@@ -100,7 +100,9 @@ _SIGS = {
     "mdvit_mlp_config": [i32, i32],
     "mdvit_mlp_rc_config": [i32],
     "mdvit_mlp_rc_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
+    "mdvit_mlp_rc16_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
     "mdvit_mlp_rc_dgrad": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
+    "mdvit_mlp_rc16_dgrad": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
     "mdvit_mlp_rc_wgrad": [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_imgconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_imgconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],

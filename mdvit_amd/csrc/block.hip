@@ -27,6 +27,12 @@ inline int mlp_mode(const MdvitBlockDesc& d) {
     if (d.precision >= 1 && d.C <= 128 && d.C % 32 == 0 && d.hidden % 4 == 0) return MLP_RECOMP;
     return MLP_STORED;
 }
+// MLP_RECOMP at C = 128 with the weight planes given: forward and backward data path as ONE kernel each (mlp_rc.hip, 16-token waves); h and du still
+// reach HBM once each, for the two weight-gradient GEMMs
+inline bool mlp_rc16(const MdvitBlockDesc& d) {
+    return mlp_mode(d) == MLP_RECOMP && d.precision == 1 && d.C == 128 && d.hidden % 32 == 0 && d.hidden <= 4096 && d.fc1_p && d.fc2_p && d.fc1_b && d.fc2_b &&
+           (long)d.B * d.H * d.W * d.hidden < (1L << 32);
+}
 
 struct Saved {        // the block's saved-for-backward tensors inside the caller's `save` buffer
     float *x1, *mean1, *rstd1, *cur1, *qkv, *a, *att, *U, *kmax, *ksum, *Mmat, *x2, *mean2, *rstd2, *cur2, *h, *u;
@@ -146,6 +152,9 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
     if (mode == MLP_RC) {
         BLK_RUN(mdvit_mlp_rc_fwd(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1],
                                  d.key_fc2[0], d.key_fc2[1], seed, s));
+    } else if (mlp_rc16(d)) {
+        BLK_RUN(mdvit_mlp_rc16_fwd(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1],
+                                   d.key_fc2[0], d.key_fc2[1], seed, s));
     } else {
         MdvitGemmDesc g;
         gemm_init(g, d);
@@ -210,19 +219,26 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
     } else {
         if (masked) BLK_RUN(mdvit_colsum_f32(dy, C, nullptr, gm2, nullptr, 0, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok, 0, seed, s));
-        du = S.take(T * Hd);
         MdvitGemmDesc g;
-        gemm_init(g, d);
-        g.epi = MDVIT_EPI_DGELU; g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc1[0]; g.e_key1 = d.key_fc1[1]; g.drop_seed = seed;
-        if (mode == MLP_RECOMP) { g.rc_a = sv.cur2; g.rc_lda = C; g.rc_b = d.fc1_w; g.rc_ldb = C; g.rc_bias = d.fc1_b; g.rc_k = C; }
-        else { g.gelu_u = sv.u; g.ldu = Hd; }
-        g.allow_split = 0;
-        int rc = gemm_dgrad(A, d, g, gm2, d.fc2_w, d.fc2_wt, du, M, Hd, C, s);            // du = (gm W2) * gelu'(u) * mask
-        if (rc != MDVIT_OK) return rc;
-        gemm_init(g, d);
-        g.allow_split = 1;
-        rc = gemm_dgrad(A, d, g, du, d.fc1_w, d.fc1_wt, dcur2, M, C, Hd, s);               // dx = du W1
-        if (rc != MDVIT_OK) return rc;
+        int rc = MDVIT_OK;
+        if (mlp_rc16(d) && d.fc2t_p && d.fc1t_p) {
+            // u recomputed, du = (gm W2) * gelu'(u) * mask and dcur2 = du W1 in one kernel; du reaches HBM only for the weight gradients
+            du = want_w ? S.take(T * Hd) : nullptr;
+            BLK_RUN(mdvit_mlp_rc16_dgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, du, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
+        } else {
+            du = S.take(T * Hd);
+            gemm_init(g, d);
+            g.epi = MDVIT_EPI_DGELU; g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc1[0]; g.e_key1 = d.key_fc1[1]; g.drop_seed = seed;
+            if (mode == MLP_RECOMP) { g.rc_a = sv.cur2; g.rc_lda = C; g.rc_b = d.fc1_w; g.rc_ldb = C; g.rc_bias = d.fc1_b; g.rc_k = C; }
+            else { g.gelu_u = sv.u; g.ldu = Hd; }
+            g.allow_split = 0;
+            rc = gemm_dgrad(A, d, g, gm2, d.fc2_w, d.fc2_wt, du, M, Hd, C, s);            // du = (gm W2) * gelu'(u) * mask
+            if (rc != MDVIT_OK) return rc;
+            gemm_init(g, d);
+            g.allow_split = 1;
+            rc = gemm_dgrad(A, d, g, du, d.fc1_w, d.fc1_wt, dcur2, M, C, Hd, s);               // dx = du W1
+            if (rc != MDVIT_OK) return rc;
+        }
         if (want_w) {
             if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
             rc = gemm_wgrad(S, d, gm2, sv.h, G.fc2_w, G.fc2_b, M, C, Hd, acc, side);
@@ -405,7 +421,7 @@ extern "C" int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g
                             g->n2_b && g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b && (!d->qkv_b || g->qkv_b), MDVIT_E_SHAPE, "block_bwd: null gradient output");
     }
     MDVIT_CHECK_ARG(!d->label || (g->da_w1 && g->da_b1 && g->da_w2 && g->da_b2), MDVIT_E_SHAPE, "block_bwd: the adapter's gradient outputs are missing");
-    MDVIT_CHECK_ARG(d->precision == 0 || (d->qkv_wt && d->proj_wt && (mlp_mode(*d) == MLP_RC || (d->fc1_wt && d->fc2_wt))), MDVIT_E_SHAPE,
+    MDVIT_CHECK_ARG(d->precision == 0 || (d->qkv_wt && d->proj_wt && (mlp_mode(*d) == MLP_RC || (mlp_rc16(*d) && d->fc2t_p && d->fc1t_p) || (d->fc1_wt && d->fc2_wt))), MDVIT_E_SHAPE,
                     "block_bwd: the bf16x3 data-gradient GEMMs need the transposed weights");
     Arena SV{(char*)const_cast<void*>(save), 0, save_bytes, false}, A{(char*)ws, 0, ws_bytes, false}, S{(char*)ws_side, 0, ws_side_bytes, false};
     return block_bwd(*d, *g, *st, x, dy, dx, SV, A, S);

@@ -130,6 +130,8 @@ struct RcArgs {
     const uint16_t* W2tp;   // planes of W2^T [2][Hd][C]   rows = hidden, k = c         d = gm W2
     const uint16_t* W1tp;   // planes of W1^T [2][C][Hd]   rows = c,      k = hidden    dx = du W1
     float* y; float* dx;
+    float* du;              // rc16 dgrad: optional [tokens, hidden] copy of the hidden-layer gradient (the two weight-gradient GEMMs' operand)
+    float* h;               // rc16 forward: optional [tokens, hidden] copy of drop1(gelu(u)) (the fc2 weight-gradient GEMM's operand)
     float* part;            // wgrad: per-workgroup partial sums
     int M, Hd, rows_per_scale;
     int drop; uint32_t k1a, k1b, k2a, k2b, thresh; float inv_keep;
@@ -794,6 +796,283 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (lhi == 0) pg[2L * p.Hd * C + hs + l31] = db1;
 }
 
+// ==============================================================================================================================
+// The data gradient on 16x16x32 MFMA tiles ("rc16"): a wave owns 16 tokens, so the x / gm operand fragments of C = 128 fit the register file
+// (64 VGPRs) next to the 128 x 16 dx accumulator (32) -- the C = 128 stages' MLP backward data path (mpvit.py:71-78, hidden 1024) in ONE kernel:
+//     u = x W1^T + b1 (recomputed), d = gm W2, du = d * gelu'(u) * mask1, dx += du W1          x, gm in -> dx (and optionally du) out
+// instead of the recomputing fc2 data-gradient GEMM (du to HBM) + the fc1 data-gradient GEMM (du back from HBM).  du is written only when the
+// weight-gradient GEMMs of the full sweep need it; the data-gradient-only sweep moves no [tokens, hidden] tensor at all.
+//   v_mfma_f32_16x16x32_bf16: A lane (i = l & 15, k = 8 (l >> 4) ..+7), B lane (j = l & 15, same k), D lane j, registers i = 4 (l >> 4) + r.
+// Products 1 / 2 run as D[hidden][token]: a lane holds the hidden units 4g .. 4g+3 (g = l >> 4) of each 16-row tile of ITS token; product 3
+// contracts over the 32-wide hidden step with k slot (g, i) <-> hidden (i < 4 ? 4g + i : 16 + 4g + i - 4): the W1^T operand is READ in that
+// order (two ds_read_b64 per fragment), so the chained operand needs no lane exchange.
+// ==============================================================================================================================
+typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int ROWB>
+__device__ __forceinline__ int rc16_swz(int row) {       // lanes (row = l & 15 [+16], chunk = base + (l >> 4)): conflict-free ds_read_b128
+    if (ROWB == 64) return (row >> 2) & 3;
+    if (ROWB == 128) return (row >> 1) & 7;
+    return row & 15;
+}
+template <int ROWB>
+__device__ __forceinline__ void rc16_glds_piece(const uint16_t* __restrict__ src, long ld, int piece, int lane, char* tile) {
+    constexpr int LPR = ROWB / 16, RPP = 1024 / ROWB;
+    const int row = piece * RPP + lane / LPR;
+    const int lc = (lane % LPR) ^ rc16_swz<ROWB>(row);
+    __builtin_amdgcn_global_load_lds(src + (long)row * ld + (lc << 3), (__attribute__((address_space(3))) void*)(tile + piece * 1024), 16, 0, 0);
+}
+template <int ROWB>
+__device__ __forceinline__ rc_bf16x8 rc16_frag(const char* tile, int row, int chunk) {
+    return __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(tile + row * ROWB + ((chunk ^ rc16_swz<ROWB>(row)) << 4)));
+}
+// the permuted-k fragment of a [rows][32 k] tile (64-byte rows): k slots 0..3 <- k = 4g .. 4g+3, slots 4..7 <- k = 16 + 4g .. 16 + 4g + 3
+__device__ __forceinline__ rc_bf16x8 rc16_frag_perm(const char* tile, int row, int g) {
+    const int f = rc16_swz<64>(row);
+    const rc_u2 a = *reinterpret_cast<const rc_u2*>(tile + row * 64 + (((g >> 1) ^ f) << 4) + (g & 1) * 8);
+    const rc_u2 b = *reinterpret_cast<const rc_u2*>(tile + row * 64 + (((2 + (g >> 1)) ^ f) << 4) + (g & 1) * 8);
+    return __builtin_bit_cast(rc_bf16x8, (rc_u4{a[0], a[1], b[0], b[1]}));
+}
+
+#define RC16_MFMA3(acc, ah, al, bh, bl)                                         \
+    do {                                                                        \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);    \
+    } while (0)
+
+// x / gm operand fragments of a wave's 16 tokens: lane (token l & 15, g = l >> 4) holds c = 32 ks + 8 g ..+7 for every k step
+template <int C>
+__device__ __forceinline__ void rc16_load_rows(const float* __restrict__ src, int row, int M, int g, rc_bf16x8 (&hi)[C / 32], rc_bf16x8 (&lo)[C / 32]) {
+    const float* p = src + (long)min(row, M - 1) * C + 8 * g;
+    float4 a[C / 32], b[C / 32];
+#pragma unroll
+    for (int ks = 0; ks < C / 32; ++ks) {
+        a[ks] = *reinterpret_cast<const float4*>(p + 32 * ks);
+        b[ks] = *reinterpret_cast<const float4*>(p + 32 * ks + 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < C / 32; ++ks) {
+        const float v[8] = {a[ks].x, a[ks].y, a[ks].z, a[ks].w, b[ks].x, b[ks].y, b[ks].z, b[ks].w};
+        rc_u4 h, l;
+        rc_split8(v, h, l);
+        hi[ks] = __builtin_bit_cast(rc_bf16x8, h);
+        lo[ks] = __builtin_bit_cast(rc_bf16x8, l);
+    }
+}
+
+// forward on the same tiles: y = res + rowscale * drop2( drop1(gelu(x W1^T + b1)) W2^T + b2 ), the hidden chunk chained in registers; STORE also
+// writes h = drop1(gelu(u)) [tokens, hidden] once (C = 128: the fc2 weight-gradient GEMM reads it; the forward itself never re-reads it)
+template <int C, int NW, int OCC, bool DROP, bool STORE>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc16_fwd_kernel(RcArgs p) {
+    constexpr int KS = C / 32, CT = C / 16;
+    constexpr int RB1 = C * 2;
+    constexpr int T1 = 32 * RB1, T2 = C * 64;
+    constexpr int PIECES = (2 * T1 + 2 * T2) / 1024;
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* sW1 = smem;
+    char* sW2 = sW1 + 3 * 2 * T1;
+    float* sB1 = reinterpret_cast<float*>(sW2 + 3 * 2 * T2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g = lane >> 4;
+    const int row = blockIdx.x * (NW * 16) + wave * 16 + c16;
+    const int n = p.Hd >> 5;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1, k2a = p.k2a ^ s0, k2b = p.k2b + s1;
+    const long wplane = (long)p.Hd * C;
+    auto issue_group = [&](int gi) __attribute__((always_inline)) {
+        const int gs = min(gi, n - 1), slot = gi % 3;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + i * NW;
+            if (pc < 2 * T1 / 1024) {
+                constexpr int PP = T1 / 1024;
+                const int pl = pc / PP, q = pc % PP;
+                rc16_glds_piece<RB1>(p.W1p + pl * wplane + (long)(gs * 32) * C, C, q, lane, sW1 + (slot * 2 + pl) * T1);
+            } else {
+                constexpr int PP = T2 / 1024;
+                const int pc2 = pc - 2 * T1 / 1024, pl = pc2 / PP, q = pc2 % PP;
+                rc16_glds_piece<64>(p.W2p + pl * wplane + gs * 32, p.Hd, q, lane, sW2 + (slot * 2 + pl) * T2);
+            }
+        }
+    };
+    issue_group(0);
+    issue_group(1);
+    for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    rc_bf16x8 xh[KS], xl[KS];
+    rc16_load_rows<C>(p.x, row, p.M, g, xh, xl);
+    rc_f32x4 yacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) yacc[ct] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int t = 0; t < n; ++t) {
+        RC_WAIT_VM(PPW);
+        __builtin_amdgcn_s_barrier();
+        issue_group(t + 2);
+        const int slot = t % 3;
+        const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
+        const char* w2h = sW2 + (slot * 2) * T2; const char* w2l = w2h + T2;
+        float hv[8];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const int hd = t * 32 + 16 * ht + 4 * g;              // this lane's four hidden units of the tile
+            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + hd);
+            rc_f32x4 u = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const rc_bf16x8 ah = rc16_frag<RB1>(w1h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w1l, 16 * ht + c16, 4 * ks + g);
+                RC16_MFMA3(u, ah, al, xh[ks], xl[ks]);
+            }
+            float4 v = make_float4(rc_gelu(u[0]), rc_gelu(u[1]), rc_gelu(u[2]), rc_gelu(u[3]));
+            if (DROP) {
+                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = v; }
+            hv[4 * ht + 0] = v.x; hv[4 * ht + 1] = v.y; hv[4 * ht + 2] = v.z; hv[4 * ht + 3] = v.w;
+        }
+        rc_u4 hh4, hl4;
+        rc_split8(hv, hh4, hl4);
+        const rc_bf16x8 hh = __builtin_bit_cast(rc_bf16x8, hh4), hl = __builtin_bit_cast(rc_bf16x8, hl4);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const rc_bf16x8 ah = rc16_frag_perm(w2h, 16 * ct + c16, g), al = rc16_frag_perm(w2l, 16 * ct + c16, g);
+            RC16_MFMA3(yacc[ct], ah, al, hh, hl);
+        }
+    }
+    RC_WAIT_VM(0);
+
+    {   // epilogue: lane (token c16) holds output channels 16 ct + 4 g .. +3
+        const int rowc = min(row, p.M - 1);
+        float4 b2q[CT], rq[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = 16 * ct + 4 * g;
+            b2q[ct] = *reinterpret_cast<const float4*>(p.b2 + col);
+            rq[ct] = *reinterpret_cast<const float4*>(p.res + (long)rowc * C + col);
+        }
+        const float rsc = p.rowscale ? p.rowscale[rowc / p.rows_per_scale] : 1.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = 16 * ct + 4 * g;
+            const float4 b4 = b2q[ct];
+            float4 v = make_float4(yacc[ct][0] + b4.x, yacc[ct][1] + b4.y, yacc[ct][2] + b4.z, yacc[ct][3] + b4.w);
+            if (DROP) {
+                const float4 ds = mdvit_drop_scale4(k2a, k2b, (uint32_t)((long)row * C + col), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+            const float4 r4 = rq[ct];
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            if (row < p.M) *reinterpret_cast<float4*>(p.y + (long)row * C + col) = v;
+        }
+    }
+}
+
+template <int C, int NW, int OCC, bool DROP, bool STORE>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc16_dgrad_kernel(RcArgs p) {
+    constexpr int KS = C / 32, CT = C / 16;
+    constexpr int RB1 = C * 2;                       // row bytes of the [32 hidden][C] sub-tiles of W1 and W2^T
+    constexpr int T1 = 32 * RB1, T3 = C * 64;        // bytes of one plane of a [32][C] sub-tile and of the W1^T sub-tile [C][32 hidden]
+    constexpr int PIECES = (4 * T1 + 2 * T3) / 1024; // per hidden step: W1 hi, lo, W2^T hi, lo, W1^T hi, lo
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* sW1 = smem;                                // [3 slots][2 planes][T1]
+    char* sW2 = sW1 + 3 * 2 * T1;                    // [3 slots][2 planes][T1]   (W2^T)
+    char* sW3 = sW2 + 3 * 2 * T1;                    // [3 slots][2 planes][T3]   (W1^T)
+    float* sB1 = reinterpret_cast<float*>(sW3 + 3 * 2 * T3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g = lane >> 4;
+    const int row = blockIdx.x * (NW * 16) + wave * 16 + c16;
+    const int n = p.Hd >> 5;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1;
+    const long wplane = (long)p.Hd * C;
+    // group gi = the three weight sub-tiles of hidden step gi (past the end: the last step again, into the free slot -- the counted waits
+    // below then see the same number of loads per group)
+    auto issue_group = [&](int gi) __attribute__((always_inline)) {
+        const int gs = min(gi, n - 1), slot = gi % 3;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + i * NW;            // uniform per wave
+            constexpr int PP1 = T1 / 1024, PP3 = T3 / 1024;
+            if (pc < 2 * PP1) {
+                const int pl = pc / PP1, q = pc % PP1;
+                rc16_glds_piece<RB1>(p.W1p + pl * wplane + (long)(gs * 32) * C, C, q, lane, sW1 + (slot * 2 + pl) * T1);
+            } else if (pc < 4 * PP1) {
+                const int pc2 = pc - 2 * PP1, pl = pc2 / PP1, q = pc2 % PP1;
+                rc16_glds_piece<RB1>(p.W2tp + pl * wplane + (long)(gs * 32) * C, C, q, lane, sW2 + (slot * 2 + pl) * T1);
+            } else {
+                const int pc3 = pc - 4 * PP1, pl = pc3 / PP3, q = pc3 % PP3;
+                rc16_glds_piece<64>(p.W1tp + pl * wplane + gs * 32, p.Hd, q, lane, sW3 + (slot * 2 + pl) * T3);
+            }
+        }
+    };
+    issue_group(0);
+    issue_group(1);
+    for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    rc_bf16x8 xh[KS], xl[KS], mh[KS], ml[KS];
+    rc16_load_rows<C>(p.x, row, p.M, g, xh, xl);
+    rc16_load_rows<C>(p.gm, row, p.M, g, mh, ml);
+    rc_f32x4 dacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dacc[ct] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int t = 0; t < n; ++t) {
+        // group t is the older of the two groups in flight (the du stores of the previous steps are older still: vmcnt is conservative)
+        RC_WAIT_VM(PPW);
+        __builtin_amdgcn_s_barrier();
+        issue_group(t + 2);
+        const int slot = t % 3;
+        const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
+        const char* w2h = sW2 + (slot * 2) * T1; const char* w2l = w2h + T1;
+        const char* w3h = sW3 + (slot * 2) * T3; const char* w3l = w3h + T3;
+        float dv[8];
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const int hd = t * 32 + 16 * ht + 4 * g;              // this lane's four hidden units of the tile
+            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + hd);
+            rc_f32x4 u = {b4.x, b4.y, b4.z, b4.w}, d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const rc_bf16x8 ah = rc16_frag<RB1>(w1h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w1l, 16 * ht + c16, 4 * ks + g);
+                RC16_MFMA3(u, ah, al, xh[ks], xl[ks]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const rc_bf16x8 ah = rc16_frag<RB1>(w2h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w2l, 16 * ht + c16, 4 * ks + g);
+                RC16_MFMA3(d, ah, al, mh[ks], ml[ks]);
+            }
+            float4 v = make_float4(d[0] * rc_gelu_grad(u[0]), d[1] * rc_gelu_grad(u[1]), d[2] * rc_gelu_grad(u[2]), d[3] * rc_gelu_grad(u[3]));
+            if (DROP) {
+                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.du + (long)row * p.Hd + hd) = v; }
+            dv[4 * ht + 0] = v.x; dv[4 * ht + 1] = v.y; dv[4 * ht + 2] = v.z; dv[4 * ht + 3] = v.w;
+        }
+        rc_u4 dh4, dl4;
+        rc_split8(dv, dh4, dl4);
+        const rc_bf16x8 dh = __builtin_bit_cast(rc_bf16x8, dh4), dl = __builtin_bit_cast(rc_bf16x8, dl4);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const rc_bf16x8 ah = rc16_frag_perm(w3h, 16 * ct + c16, g), al = rc16_frag_perm(w3l, 16 * ct + c16, g);
+            RC16_MFMA3(dacc[ct], ah, al, dh, dl);
+        }
+    }
+    RC_WAIT_VM(0);
+    if (row < p.M) {       // lane (token c16) holds the input channels 16 ct + 4 g .. +3
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            *reinterpret_cast<float4*>(p.dx + (long)row * C + 16 * ct + 4 * g) = make_float4(dacc[ct][0], dacc[ct][1], dacc[ct][2], dacc[ct][3]);
+    }
+}
+
 // out_j[i] (+)= sum_g part[g][off_j + i] for the three segments, groups added in order: one float4 column per thread
 __global__ __launch_bounds__(256) void rc_reduce_kernel(const float* __restrict__ part, int groups, long stride, int n0, float* o0, int n1, float* o1, int n2, float* o2,
                                                         int accumulate) {
@@ -910,6 +1189,85 @@ static int rc_wgrad_groups(int M) {
     int g = (ntiles + 3) / 4;                      // >= 4 tiles per group where the problem allows it
     g = ((g + 7) / 8) * 8;
     return g < 8 ? 8 : (g > 128 ? 128 : g);
+}
+
+/* The MLP forward on 16-token waves, built for C = 64 and C = 128 (mpvit.py:71-78 inside mdvit.py:357-360); h != NULL also writes
+ * h = drop1(gelu(x W1^T + b1)) [M, hidden] for the fc2 weight-gradient GEMM (the forward never re-reads it). */
+extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
+                                  int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                                  uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(C == 64 || C == 128, MDVIT_E_SHAPE, "mlp_rc16_fwd: built for C = 64 / 128 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd >= 64 && Hd % 32 == 0 && Hd <= 4096, MDVIT_E_SHAPE, "mlp_rc16_fwd: need M > 0, hidden %% 32 == 0, hidden <= 4096 (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(x && W1p && b1 && W2p && b2 && res && y, MDVIT_E_SHAPE, "mlp_rc16_fwd: null operand");
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(W1p) && aligned16(b1) && aligned16(W2p) && aligned16(b2) && aligned16(res) && aligned16(y) && aligned16(h), MDVIT_E_ALIGN,
+                    "mlp_rc16_fwd: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_rc16_fwd: dropout index space exceeds 2^32");
+    RcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2p = (const uint16_t*)W2p; a.b2 = b2; a.res = res; a.rowscale = rowscale; a.y = y; a.h = h;
+    a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    rc_fill(a, M, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed);
+    constexpr int NW = 8;
+    const int smem = 3 * 2 * (32 * C * 2) + 3 * 2 * (C * 64) + Hd * 4;
+    const dim3 grid(cdiv(M, NW * 16)), block(NW * 64);
+    hipStream_t s = (hipStream_t)stream;
+#define RC16_FWD_LAUNCH(CV, OCCV, DROPV, STOREV)                                                                                     \
+    do {                                                                                                                             \
+        static bool fl[64] = {false};                                                                                                \
+        const int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV>),                  \
+                                  3 * 2 * (32 * CV * 2) + 3 * 2 * (CV * 64) + 4096 * 4, fl);                                         \
+        if (rc != MDVIT_OK) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV>), grid, block, smem, s, a);                             \
+    } while (0)
+    if (C == 128) {
+        if (a.drop) { if (h) RC16_FWD_LAUNCH(128, 2, true, true); else RC16_FWD_LAUNCH(128, 2, true, false); }
+        else { if (h) RC16_FWD_LAUNCH(128, 2, false, true); else RC16_FWD_LAUNCH(128, 2, false, false); }
+    } else {
+        if (a.drop) { if (h) RC16_FWD_LAUNCH(64, 4, true, true); else RC16_FWD_LAUNCH(64, 4, true, false); }
+        else { if (h) RC16_FWD_LAUNCH(64, 4, false, true); else RC16_FWD_LAUNCH(64, 4, false, false); }
+    }
+#undef RC16_FWD_LAUNCH
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+/* The C = 128 (and C = 64) MLP's backward data path on 16-token waves: dx = ((gm W2) * gelu'(x W1^T + b1) * mask1) W1 in one kernel; du != NULL
+ * also writes the hidden-layer gradient [M, hidden] (the operand of the two weight-gradient GEMMs of the full sweep). */
+extern "C" int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
+                                    int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(C == 64 || C == 128, MDVIT_E_SHAPE, "mlp_rc16_dgrad: built for C = 64 / 128 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd >= 64 && Hd % 32 == 0 && Hd <= 4096, MDVIT_E_SHAPE, "mlp_rc16_dgrad: need M > 0, hidden %% 32 == 0, hidden <= 4096 (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(gm && x && W1p && b1 && W2tp && W1tp && dx, MDVIT_E_SHAPE, "mlp_rc16_dgrad: null operand");
+    MDVIT_CHECK_ARG(aligned16(gm) && aligned16(x) && aligned16(W1p) && aligned16(b1) && aligned16(W2tp) && aligned16(W1tp) && aligned16(dx) && aligned16(du), MDVIT_E_ALIGN,
+                    "mlp_rc16_dgrad: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_rc16_dgrad: dropout index space exceeds 2^32");
+    RcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gm = gm; a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2tp = (const uint16_t*)W2tp; a.W1tp = (const uint16_t*)W1tp; a.dx = dx; a.du = du;
+    rc_fill(a, M, Hd, drop_p, key1_0, key1_1, 0, 0, drop_seed);
+    constexpr int NW = 8;
+    const int wbytes = 3 * 4 * (32 * C * 2) + 3 * 2 * (C * 64);
+    const int smem = wbytes + Hd * 4;
+    const dim3 grid(cdiv(M, NW * 16)), block(NW * 64);
+    hipStream_t s = (hipStream_t)stream;
+#define RC16_DGRAD_LAUNCH(CV, OCCV, DROPV, STOREV)                                                                                   \
+    do {                                                                                                                             \
+        static bool fl[64] = {false};                                                                                                \
+        const int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc16_dgrad_kernel<CV, NW, OCCV, DROPV, STOREV>),                \
+                                  3 * 4 * (32 * CV * 2) + 3 * 2 * (CV * 64) + 4096 * 4, fl);                                         \
+        if (rc != MDVIT_OK) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_rc16_dgrad_kernel<CV, NW, OCCV, DROPV, STOREV>), grid, block, smem, s, a);                           \
+    } while (0)
+    if (C == 128) {
+        if (a.drop) { if (du) RC16_DGRAD_LAUNCH(128, 2, true, true); else RC16_DGRAD_LAUNCH(128, 2, true, false); }
+        else { if (du) RC16_DGRAD_LAUNCH(128, 2, false, true); else RC16_DGRAD_LAUNCH(128, 2, false, false); }
+    } else {
+        if (a.drop) { if (du) RC16_DGRAD_LAUNCH(64, 4, true, true); else RC16_DGRAD_LAUNCH(64, 4, true, false); }
+        else { if (du) RC16_DGRAD_LAUNCH(64, 4, false, true); else RC16_DGRAD_LAUNCH(64, 4, false, false); }
+    }
+#undef RC16_DGRAD_LAUNCH
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
 }
 
 extern "C" size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t Hd) {

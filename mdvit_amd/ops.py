@@ -907,11 +907,17 @@ _mlp_recompute = os.environ.get("MDVIT_MLP_RECOMPUTE", "1") != "0"
 _mlp_fused = os.environ.get("MDVIT_MLP_FUSED", "1") != "0"
 _mlp_recompute_maxc = int(os.environ.get("MDVIT_MLP_RECOMPUTE_MAXC", "128"))
 _mlp_rc = os.environ.get("MDVIT_MLP_RC", "1") != "0"      # csrc/mlp_rc.hip: no [tokens, hidden] tensor in HBM in either pass (0: round 2's kernels, A/B)
+_mlp_rc16 = os.environ.get("MDVIT_MLP_RC16", "1") != "0"  # C = 128: the backward data path in one kernel on 16-token waves (0: the two data-gradient GEMMs, A/B)
 
 
 def _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M) -> bool:
     return (_mlp_rc and _mlp_recompute and _gemm_precision == 1 and Cin == 64 and Hd % 256 == 0 and Hd <= 4096 and b1 is not None and b2 is not None and res is not None
             and W1.is_contiguous() and W2.is_contiguous() and M * Hd < (1 << 32))
+
+
+def _mlp_rc16_ok(Cin, Hd, b1, W1, W2, M) -> bool:
+    return (_mlp_rc16 and _gemm_precision == 1 and Cin == 128 and Hd % 32 == 0 and Hd <= 4096 and b1 is not None and W1.is_contiguous() and W2.is_contiguous()
+            and M * Hd < (1 << 32))
 
 
 class _MlpResidual(torch.autograd.Function):
@@ -945,6 +951,17 @@ class _MlpResidual(torch.autograd.Function):
             out = _empty((M, Cin), device=x.device, dtype=torch.float32)
             call("mdvit_mlp_fwd_f32", _p(x), _p(W1), _p(b1), _p(W2), _p(b2), _p(res), _p(rowscale), rows_per_scale, _p(h), _p(out), M, Cin, Hd,
                  drop_p, k1[0], k1[1], k2[0], k2[1], _seed_ptr() if drop_p > 0 else None, _stream())
+            ctx.save_for_backward(x, None, h, W1, W2, rowscale)
+            ctx.meta = (drop_p, k1, k2, rows_per_scale)
+            ctx.b1_ref, ctx.b2_ref = b1, b2
+            return out
+        if _mlp_recompute and _mlp_recompute_maxc >= 128 and b2 is not None and res is not None and _mlp_rc16_ok(Cin, Hd, b1, W1, W2, M):
+            # C = 128: both GEMMs in ONE kernel on 16-token waves, the hidden chunk chained in registers; h goes to HBM once, for the fc2 weight gradient
+            out = _empty((M, Cin), device=x.device, dtype=torch.float32)
+            W1p, W2p = _wplanes(W1, False), _wplanes(W2, False)
+            call("mdvit_mlp_rc16_fwd", _p(x), _p(W1p), _p(b1), _p(W2p), _p(b2), _p(res), _p(rowscale), rows_per_scale, _p(h), _p(out), M, Cin, Hd,
+                 drop_p, k1[0], k1[1], k2[0], k2[1], _seed_ptr() if drop_p > 0 else None, _stream())
+            del W1p, W2p
             ctx.save_for_backward(x, None, h, W1, W2, rowscale)
             ctx.meta = (drop_p, k1, k2, rows_per_scale)
             ctx.b1_ref, ctx.b2_ref = b1, b2
@@ -1035,6 +1052,13 @@ class _MlpResidual(torch.autograd.Function):
             call("mdvit_mlp_bwd_dgrad_f32", _p(gm), _p(x), _p(W1), _p(ctx.b1_ref), _p(W2t), _p(W1t), _p(du), _p(dx), M, Cin, Hd,
                  drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, _stream())
             del W2t, W1t
+        elif u is None and _mlp_rc16_ok(Cin, Hd, ctx.b1_ref, W1, W2, M):
+            # C = 128: u recomputed, du = (gm W2) * gelu'(u) * mask1 and dx = du W1 in ONE kernel; du reaches HBM only for the weight gradients
+            du = None if _dgrad_only else _empty_like(h)
+            W1p, W2tp, W1tp = _wplanes(W1, False), _wplanes(W2, True), _wplanes(W1, True)
+            call("mdvit_mlp_rc16_dgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(W1tp), _p(du), _p(dx), M, Cin, Hd,
+                 drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, _stream())
+            del W1p, W2tp, W1tp
         else:
             du = _empty_like(h)
             if u is None and (_plane_rc or _gemm_precision == 2) and _use_plane_gemm and Cin % 32 == 0 and W1.is_contiguous() and W2.is_contiguous():
@@ -2055,7 +2079,8 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
         setattr(d, name, _p(t))
     keep = []
     W1, W2 = params[20], params[22]
-    if d.precision == 1 and _mlp_rc_ok(Cn, d.hidden, params[21], params[23], x, W1, W2, B * N):
+    rc16 = d.precision == 1 and _mlp_recompute and _mlp_recompute_maxc >= 128 and params[23] is not None and _mlp_rc16_ok(Cn, d.hidden, params[21], W1, W2, B * N)
+    if (d.precision == 1 and _mlp_rc_ok(Cn, d.hidden, params[21], params[23], x, W1, W2, B * N)) or rc16:
         p1, p2 = _wplanes(W1, False), _wplanes(W2, False)
         d.fc1_p, d.fc2_p = _p(p1), _p(p2)
         keep += [p1, p2]

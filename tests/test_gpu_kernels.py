@@ -217,8 +217,8 @@ def test_mlp_residual(M, C, r, gemm_precision):
         check(a, r_, tol=tol, name=n)
 
 
-@pytest.mark.parametrize("M,C,r,drop", [(512, 64, 8, 0.0), (1030, 64, 8, 0.25), (130, 128, 8, 0.1), (70, 32, 4, 0.0), (37, 64, 8, 0.1), (200, 64, 16, 0.0),
-                                        (8192, 64, 8, 0.1)])
+@pytest.mark.parametrize("M,C,r,drop", [(512, 64, 8, 0.0), (1030, 64, 8, 0.25), (130, 128, 8, 0.1), (131, 128, 8, 0.1), (70, 32, 4, 0.0), (37, 64, 8, 0.1),
+                                        (200, 64, 16, 0.0), (8192, 64, 8, 0.1)])
 def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatch):
     """C <= 128 (bf16x3): the forward keeps gelu(u) only and the fc2 data-gradient GEMM recomputes u = x W1^T + b1 per output
     tile -- same slab / MFMA sequence as the forward, so every output and gradient equals the stored-u path bit for bit.
@@ -228,6 +228,8 @@ def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatc
     if ops.gemm_precision() != "bf16x3":
         pytest.skip("the recomputing epilogue is the bf16x3 path's")
     Hd = C * r
+    if C == 128 and M == 131:
+        monkeypatch.setattr(ops, "_mlp_rc16", False)      # the recomputing GEMM epilogue itself (MDVIT_MLP_RC16=0): bit for bit
     ins = [rnd(M, C, seed=120), rnd(M, C, seed=121), rnd(Hd, C, seed=122, scale=C ** -0.5), rnd(Hd, seed=123, scale=0.1),
            rnd(C, Hd, seed=124, scale=Hd ** -0.5), rnd(C, seed=125, scale=0.1)]
     g = rnd(M, C, seed=126)
@@ -246,9 +248,9 @@ def test_mlp_recomputed_preactivation_is_bit_identical(M, C, r, drop, monkeypatc
         if name == "dx" and C == 64:      # the fused backward sums the hidden axis in order; the GEMM form may split K at this small M
             check(a, b, tol=1e-5, name=name)
             continue
-        if C == 64:       # fused MLP kernels (mlp_rc.hip; hidden % 256 != 0: mlp.hip) against the GEMM path: the same products in the same k order, but
-            check(a, b, tol=5e-6, name=name)      # other compilations of the GELU epilogue (fma contraction) and, for the recomputing weight-gradient kernel,
-            continue                              # another summation order over the tokens: equal to a few ulp, not bit for bit
+        if C == 64 or (C == 128 and ops._mlp_rc16):   # fused MLP kernels (mlp_rc.hip; C = 64 with hidden % 256 != 0: mlp.hip) against the GEMM path: the same
+            check(a, b, tol=5e-6, name=name)      # products, but other compilations of the GELU epilogue (fma contraction), 16-token tiles at C = 128 and, for the
+            continue                              # recomputing weight-gradient kernel, another summation order over the tokens: equal to a few ulp, not bit for bit
         assert torch.equal(a, b), f"{name}: recomputed-u path differs from the stored-u path (max {float((a - b).abs().max()):.3e})"
 
 
@@ -304,6 +306,44 @@ def test_mlp_rc_kernels_vs_round2_kernels_and_fp64(M, r, drop, monkeypatch):
     for name, p_, want in zip(("dW1", "db1", "dW2", "db2"), params, res[0][3:]):
         assert p_.grad is None
         check(sinks[p_] - 0.5, want, tol=2e-6, name=name + " (sink)")
+
+
+@pytest.mark.parametrize("M,r,drop", [(37, 8, 0.1), (4173, 8, 0.25), (1030, 4, 0.0), (9000, 8, 0.1)])
+def test_mlp_rc16_kernels_vs_the_gemm_path_and_fp64(M, r, drop, monkeypatch):
+    """mdvit_mlp_rc16_fwd / _dgrad (C = 128, bf16x3, 16-token waves: the MLP forward and the backward data path as ONE kernel each) against the
+    GEMM path they replace (fc1 + GELU GEMM, fc2 GEMM; recomputing fc2 data-gradient GEMM, fc1 data-gradient GEMM) on the same dropout keys,
+    and -- without dropout -- an fp64 restatement of mpvit.py:71-78; the data-gradient-only sweep writes no du and returns the same dx"""
+    from mdvit_amd import ops
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("mlp_rc.hip is the bf16x3 path's")
+    C, Hd = 128, 128 * r
+    ins = [rnd(M, C, seed=240), rnd(M, C, seed=241), rnd(Hd, C, seed=242, scale=C ** -0.5), rnd(Hd, seed=243, scale=0.1),
+           rnd(C, Hd, seed=244, scale=Hd ** -0.5), rnd(C, seed=245, scale=0.1)]
+    g = rnd(M, C, seed=246)
+    rowscale = (torch.rand(3, generator=torch.Generator().manual_seed(7)) < 0.7).float().div(0.7).to(dev()) if drop > 0 else None
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "_mlp_rc16", flag)
+        monkeypatch.setattr(ops, "_key_counter", __import__("itertools").count(93))
+        out, go = grads_of(lambda *a: ops.mlp_residual(*a, rowscale=rowscale, drop_p=drop, rows_per_scale=(M + 2) // 3), [t.to(dev()) for t in ins], g)
+        res.append([out.detach()] + go)
+    for name, a, b in zip(("y", "dx", "dres", "dW1", "db1", "dW2", "db2"), res[0], res[1]):
+        check(a, b, tol=5e-6, name=name)
+    monkeypatch.setattr(ops, "_mlp_rc16", True)
+    if drop == 0.0:
+        def ref_fn(x, res_, W1, b1, W2, b2):
+            return res_.double() + F.linear(F.gelu(F.linear(x.double(), W1.double(), b1.double())), W2.double(), b2.double())
+        ref, gr = grads_of(ref_fn, ins, g.double())
+        for name, a, b in zip(("y", "dx", "dres", "dW1", "db1", "dW2", "db2"), res[0], [ref] + gr):
+            check(a, b, tol=3e-4, name=name + " vs fp64")
+    monkeypatch.setattr(ops, "_key_counter", __import__("itertools").count(93))
+    ops.set_dgrad_only(True)
+    try:
+        _, go = grads_of(lambda *a: ops.mlp_residual(*a, rowscale=rowscale, drop_p=drop, rows_per_scale=(M + 2) // 3), [t.to(dev()) for t in ins], g)
+    finally:
+        ops.set_dgrad_only(False)
+    check(go[0], res[0][1], tol=2e-6, name="dx of the data-gradient-only sweep")      # (another instantiation: no du store, the activation compiled again)
+    assert all(t is None for t in go[2:])
 
 
 def test_mlp_rc_keeps_no_hidden_sized_tensor(monkeypatch):
