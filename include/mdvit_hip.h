@@ -216,6 +216,15 @@ int mdvit_mlp_rc_fwd(const float* x, const void* W1p, const float* b1, const voi
                      float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
 int mdvit_mlp_rc_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx,
                        int32_t M, int32_t C, int32_t hidden, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
+/* Streaming Linear for the short-K, output-heavy layers (K = 64 / 128): qkv and proj of the C = 64 / 128 stages (mdvit.py:288,310) and their data
+ * gradients, the 64 / 128 -> 512 projections of the peer heads (Decoders.py:320-331).  y[M, N] = x[M, K] Wp^T (+ bias); with `residual` != NULL
+ * also x dropout(key0, key1) x rowscale[row / rows_per_scale] + residual (mdvit_gemm_f32's FULL epilogue, same mask indices).  Wp: the bf16 hi / lo
+ * planes [2][N][K] of the weight (or of its transpose for a data gradient; mdvit_split_planes_t), plane stride `wplane` elements.  A wave owns 32
+ * tokens for the whole output row: x goes straight into MFMA operand registers, the weight planes stream through LDS, the kernel is a stream
+ * of 16-byte stores.  N % 32 == 0. */
+int mdvit_linear_rc(const float* x, int64_t lda, const void* Wp, int64_t wplane, const float* bias, float* y, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                    float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, const float* residual, int64_t ldr,
+                    const uint32_t* drop_seed, void* stream);
 /* The MLP forward on 16-token waves (16x16x32 MFMA tiles), built for C = 64 and C = 128: fc1 + GELU + Dropout + fc2 + Dropout + DropPath + residual
  * (mpvit.py:71-78 inside mdvit.py:357-360) in ONE kernel with the hidden chunk chained in registers; h != NULL also writes
  * h = drop1(gelu(x W1^T + b1)) [M, hidden] once for the fc2 weight-gradient GEMM (C = 128, where recomputing it there costs more than it saves). */
@@ -259,6 +268,7 @@ typedef struct MdvitBlockDesc {
         *fc2_w, *fc2_b;
     const float *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;
     const void *fc1_p, *fc2_p, *fc2t_p, *fc1t_p;
+    const void *qkv_p, *proj_p, *projt_p;      /* optional bf16 planes of Wqkv, Wproj, Wproj^T: C = 64 / 128 run qkv / proj / proj's data gradient on mdvit_linear_rc */
 } MdvitBlockDesc;
 /* Gradient outputs of the backward.  The sixteen "weight-class" outputs (cpe, qkv, crpe windows, proj, fc1, fc2) are overwritten
  * (accumulate == 0: fresh buffers) or added into (accumulate != 0: gradient buckets; the weight-gradient kernels then run on the side

@@ -121,7 +121,10 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
     // cur1 = LN1(x1)
     BLK_RUN(mdvit_layernorm_fwd(sv.x1, d.n1_g, d.n1_b, sv.cur1, sv.mean1, sv.rstd1, M, C, d.ln_groups, d.eps, s));
     // qkv = cur1 Wqkv^T + b                    (mdvit.py:288)
-    {
+    const bool lin_rc = d.precision == 1 && (C == 64 || C == 128) && d.qkv_p && d.proj_p && M >= 1024;       // the streaming short-K Linear (mlp_rc.hip)
+    if (lin_rc) {
+        BLK_RUN(mdvit_linear_rc(sv.cur1, C, d.qkv_p, 3L * C * C, d.qkv_b, sv.qkv, 3 * C, M, 3 * C, C, 0.f, 0, 0, nullptr, 1, nullptr, 0, nullptr, s));
+    } else {
         MdvitGemmDesc g;
         gemm_init(g, d);
         g.A = sv.cur1; g.B = d.qkv_w; g.C = sv.qkv; g.M = M; g.N = 3 * C; g.K = C; g.lda = C; g.ldb = C; g.ldc = 3 * C; g.bias = d.qkv_b;
@@ -137,7 +140,10 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
                                     d.s3, d.s5, d.s7, s));
     }
     // x2 = x1 + droppath(drop(att Wproj^T + b))      (mdvit.py:310-311,353)
-    {
+    if (lin_rc) {
+        BLK_RUN(mdvit_linear_rc(sv.att, C, d.proj_p, (long)C * C, d.proj_b, sv.x2, C, M, C, C, d.drop_p, d.key_proj[0], d.key_proj[1], d.rowscale1, N_tok, sv.x1, C,
+                                d.drop_p > 0.f ? d.drop_seed : nullptr, s));
+    } else {
         MdvitGemmDesc g;
         gemm_init(g, d);
         g.A = sv.att; g.B = d.proj_w; g.C = sv.x2; g.M = M; g.N = C; g.K = C; g.lda = C; g.ldb = C; g.ldc = C; g.bias = d.proj_b;
@@ -271,8 +277,13 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         MdvitGemmDesc g;
         gemm_init(g, d);
         g.allow_split = 1;
-        int rc = gemm_dgrad(A, d, g, gm1, d.proj_w, d.proj_wt, datt, M, C, C, s);
-        if (rc != MDVIT_OK) return rc;
+        int rc = MDVIT_OK;
+        if (d.precision == 1 && (C == 64 || C == 128) && d.projt_p && M >= 1024) {
+            BLK_RUN(mdvit_linear_rc(gm1, C, d.projt_p, (long)C * C, nullptr, datt, C, M, C, C, 0.f, 0, 0, nullptr, 1, nullptr, 0, nullptr, s));
+        } else {
+            rc = gemm_dgrad(A, d, g, gm1, d.proj_w, d.proj_wt, datt, M, C, C, s);
+            if (rc != MDVIT_OK) return rc;
+        }
         if (want_w) {
             if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
             rc = gemm_wgrad(S, d, gm1, sv.att, G.proj_w, G.proj_b, M, C, C, acc, side);

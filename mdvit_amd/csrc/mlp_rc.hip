@@ -909,7 +909,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     __syncthreads();
 
     for (int t = 0; t < n; ++t) {
-        RC_WAIT_VM(PPW);
+        if (STORE && t > 0) RC_WAIT_VM(PPW + 2);      // (younger than group t: group t + 1 and the two h stores of step t - 1)
+        else RC_WAIT_VM(PPW);
         __builtin_amdgcn_s_barrier();
         issue_group(t + 2);
         const int slot = t % 3;
@@ -1024,8 +1025,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     __syncthreads();
 
     for (int t = 0; t < n; ++t) {
-        // group t is the older of the two groups in flight (the du stores of the previous steps are older still: vmcnt is conservative)
-        RC_WAIT_VM(PPW);
+        // group t is the older of the two groups in flight; vector-memory operations retire in issue order, and younger than group t are group
+        // t + 1 and (STORE) the two du stores of step t - 1
+        if (STORE && t > 0) RC_WAIT_VM(PPW + 2);
+        else RC_WAIT_VM(PPW);
         __builtin_amdgcn_s_barrier();
         issue_group(t + 2);
         const int slot = t % 3;
@@ -1071,6 +1074,115 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         for (int ct = 0; ct < CT; ++ct)
             *reinterpret_cast<float4*>(p.dx + (long)row * C + 16 * ct + 4 * g) = make_float4(dacc[ct][0], dacc[ct][1], dacc[ct][2], dacc[ct][3]);
     }
+}
+
+// ==============================================================================================================================
+// Streaming Linear for the short-K layers (K = 64 / 128: qkv and proj of the C = 64 / 128 stages, mdvit.py:288,310, their data gradients, and the
+// 64 / 128 -> 512 projections of the peer heads, Decoders.py:320-331): y = x W^T (+ bias, dropout, DropPath scale, residual).  These products
+// are HBM-bound and OUTPUT-heavy; the tiled GEMM (gemm.hip) runs them at 1.8-2.5 TB/s because every 64 / 128-row tile pays its own
+// load -> LDS -> MFMA -> store latency chain.  Here a wave owns 32 tokens for the whole output row: x is loaded ONCE straight into MFMA operand
+// registers (no LDS for activations), the weight arrives pre-split (the per-step bf16 planes) by global_load_lds through a three-slot ring,
+// 32 output features per step, and every step ends in 16-byte stores -- the kernel is a stream of stores with the next weights in flight.
+// Same bf16x3 arithmetic as the GEMM (lo*hi, hi*lo, hi*hi per k step, k ascending), same dropout keys / indices.
+// ==============================================================================================================================
+struct LinArgs {
+    const float* x; long lda; const uint16_t* Wp; long wplane; const float* bias; float* y; long ldc;
+    const float* residual; long ldr; const float* rowscale; int rows_per_scale;
+    int M, N; uint32_t k0, k1, thresh; float inv_keep; const uint32_t* seed;
+};
+
+template <int K, int NW, bool FULL, bool DROP>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4))) void lin_rc_kernel(LinArgs p) {
+    constexpr int KB = K / 16;
+    constexpr int RB = K * 2;                        // row bytes of a weight sub-tile [32 features][K]
+    constexpr int T1 = 32 * RB;                      // bytes of one plane of it
+    constexpr int PIECES = 2 * T1 / 1024;            // hi, lo
+    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+    constexpr int PPW = PIECES / NW;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* sW = smem;                                 // [3 slots][2 planes][T1]
+    float* sB = reinterpret_cast<float*>(sW + 3 * 2 * T1);      // [N] bias (zeros without one)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
+    const int row = blockIdx.x * (NW * 32) + wave * 32 + l31, rowc = min(row, p.M - 1);
+    const int n = p.N >> 5;
+    uint32_t s0 = 0, s1 = 0;
+    if (DROP && p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t k0 = p.k0 ^ s0, k1 = p.k1 + s1;
+    auto issue_group = [&](int gi) __attribute__((always_inline)) {
+        const int gs = min(gi, n - 1), slot = gi % 3;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + i * NW;            // uniform per wave
+            constexpr int PP = T1 / 1024;
+            const int pl = pc / PP, q = pc % PP;
+            rc_glds_piece<RB>(p.Wp + pl * p.wplane + (long)(gs * 32) * K, K, q, lane, sW + (slot * 2 + pl) * T1);
+        }
+    };
+    issue_group(0);
+    issue_group(1);
+    for (int i = tid; i < p.N / 4; i += NW * 64)
+        reinterpret_cast<float4*>(sB)[i] = p.bias ? reinterpret_cast<const float4*>(p.bias)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    rc_bf16x8 xh[KB], xl[KB];
+    {
+        const float* px = p.x + (long)rowc * p.lda + 8 * lhi;
+        float4 a[KB], b[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            a[kb] = *reinterpret_cast<const float4*>(px + 16 * kb);
+            b[kb] = *reinterpret_cast<const float4*>(px + 16 * kb + 4);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const float v[8] = {a[kb].x, a[kb].y, a[kb].z, a[kb].w, b[kb].x, b[kb].y, b[kb].z, b[kb].w};
+            rc_u4 h, l;
+            rc_split8(v, h, l);
+            xh[kb] = __builtin_bit_cast(rc_bf16x8, h);
+            xl[kb] = __builtin_bit_cast(rc_bf16x8, l);
+        }
+    }
+    const float rsc = (FULL && p.rowscale) ? p.rowscale[rowc / p.rows_per_scale] : 1.f;
+    __syncthreads();
+
+    for (int t = 0; t < n; ++t) {
+        // the residual quads of this step are requested BEFORE the next weight group: the wait the compiler puts in front of their use then
+        // leaves that group in flight
+        float4 rq[4];
+        if (FULL) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rq[q] = *reinterpret_cast<const float4*>(p.residual + (long)rowc * p.ldr + t * 32 + 8 * q + 4 * lhi);
+        }
+        // weight group t must have landed.  Vector-memory operations retire in issue order; younger than group t are group t + 1 (PPW loads), the
+        // four stores of step t - 1 and the four residual loads just requested
+        if (t == 0) RC_WAIT_VM(PPW + (FULL ? 4 : 0));
+        else RC_WAIT_VM(PPW + 4 + (FULL ? 4 : 0));
+        __builtin_amdgcn_s_barrier();
+        issue_group(t + 2);
+        const char* hi = sW + ((t % 3) * 2) * T1; const char* lo = hi + T1;
+        rc_f32x16 u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const rc_bf16x8 ah = rc_frag<RB>(hi, l31, 2 * kb + lhi), al = rc_frag<RB>(lo, l31, 2 * kb + lhi);
+            RC_MFMA3(u, ah, al, xh[kb], xl[kb]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = t * 32 + 8 * q + 4 * lhi;
+            const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB + col);
+            float4 v = make_float4(u[4 * q + 0] + b4.x, u[4 * q + 1] + b4.y, u[4 * q + 2] + b4.z, u[4 * q + 3] + b4.w);
+            if (DROP) {
+                const float4 ds = mdvit_drop_scale4(k0, k1, (uint32_t)((long)row * p.N + col), p.thresh, p.inv_keep);
+                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+            }
+            if (FULL) {
+                v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+                v.x += rq[q].x; v.y += rq[q].y; v.z += rq[q].z; v.w += rq[q].w;
+            }
+            if (row < p.M) *reinterpret_cast<float4*>(p.y + (long)row * p.ldc + col) = v;
+        }
+    }
+    RC_WAIT_VM(0);
 }
 
 // out_j[i] (+)= sum_g part[g][off_j + i] for the three segments, groups added in order: one float4 column per thread
@@ -1266,6 +1378,46 @@ extern "C" int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void*
         else { if (du) RC16_DGRAD_LAUNCH(64, 4, false, true); else RC16_DGRAD_LAUNCH(64, 4, false, false); }
     }
 #undef RC16_DGRAD_LAUNCH
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+/* y[M, N] = x[M, K] Wp^T (+ bias) for K = 64 / 128, N % 32 == 0; with `residual` also x dropout(key) x rowscale[row / rows_per_scale] + residual
+ * (the GEMM's FULL epilogue, same mask indices row * N + col).  Wp: the bf16 hi / lo planes [2][N][K] of the weight (or of its transpose, for a
+ * data gradient), plane stride wplane elements. */
+extern "C" int mdvit_linear_rc(const float* x, int64_t lda, const void* Wp, int64_t wplane, const float* bias, float* y, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                               float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, const float* residual, int64_t ldr,
+                               const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(K == 64 || K == 128, MDVIT_E_SHAPE, "linear_rc: built for K = 64 / 128 (got %d)", K);
+    MDVIT_CHECK_ARG(M > 0 && N >= 32 && N % 32 == 0 && N <= 4096, MDVIT_E_SHAPE, "linear_rc: need M > 0, N %% 32 == 0, N <= 4096 (M=%d N=%d)", M, N);
+    MDVIT_CHECK_ARG(x && Wp && y && lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0 && (!residual || (ldr >= N && ldr % 4 == 0)), MDVIT_E_SHAPE, "linear_rc: bad operands");
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(Wp) && aligned16(y) && aligned16(bias) && aligned16(residual), MDVIT_E_ALIGN, "linear_rc: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (!(drop_p > 0.f) || (long)M * N < (1L << 32)), MDVIT_E_SHAPE, "linear_rc: bad dropout arguments");
+    MDVIT_CHECK_ARG(residual || (drop_p == 0.f && rowscale == nullptr), MDVIT_E_SHAPE, "linear_rc: dropout / row scale come with the residual epilogue");
+    LinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.lda = lda; a.Wp = (const uint16_t*)Wp; a.wplane = wplane; a.bias = bias; a.y = y; a.ldc = ldc; a.residual = residual; a.ldr = ldr;
+    a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.M = M; a.N = N;
+    a.k0 = key0; a.k1 = key1; a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.seed = drop_seed;
+    const int smem = 3 * 2 * (32 * K * 2) + N * 4;
+    hipStream_t s = (hipStream_t)stream;
+    const bool full = residual != nullptr, drop = drop_p > 0.f;
+    // 128 tokens per workgroup; 64 while that leaves the chip short of two workgroups per CU (each workgroup streams the whole weight once)
+    const int nw = cdiv(M, 128) >= 512 ? 4 : 2;
+    const dim3 grid(cdiv(M, nw * 32)), block(nw * 64);
+#define LIN_RC_LAUNCH(KV, FULLV, DROPV)                                                                          \
+    do {                                                                                                         \
+        if (nw == 4) hipLaunchKernelGGL((lin_rc_kernel<KV, 4, FULLV, DROPV>), grid, block, smem, s, a);          \
+        else hipLaunchKernelGGL((lin_rc_kernel<KV, 2, FULLV, DROPV>), grid, block, smem, s, a);                  \
+    } while (0)
+    if (K == 64) {
+        if (full) { if (drop) LIN_RC_LAUNCH(64, true, true); else LIN_RC_LAUNCH(64, true, false); }
+        else LIN_RC_LAUNCH(64, false, false);
+    } else {
+        if (full) { if (drop) LIN_RC_LAUNCH(128, true, true); else LIN_RC_LAUNCH(128, true, false); }
+        else LIN_RC_LAUNCH(128, false, false);
+    }
+#undef LIN_RC_LAUNCH
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -661,8 +661,26 @@ def gemm_nt(x, W, out, M, N, K, *, w_transposed=False, bias=None, epi=_lib.EPI_N
     _events.append((name, 2.0 * M * N * K, nbytes, e0, e1))
 
 
+_lin_rc = os.environ.get("MDVIT_LINEAR_RC", "1") != "0"     # short-K Linear layers on the streaming kernel (mlp_rc.hip: mdvit_linear_rc); 0: the tiled GEMM (A/B)
+
+
+def _lin_rc_ok(M, N, K) -> bool:
+    """y[M,N] = x[M,K] W^T runs on mdvit_linear_rc: bf16x3 mode, K = 64 / 128, N % 32 == 0 (bit-identical to the tiled GEMM: same products, same order)"""
+    return _lin_rc and _gemm_precision == 1 and K in (64, 128) and N % 32 == 0 and 32 <= N <= 4096 and M >= 1024
+
+
+def _linear_rc(x, W, transposed, bias, y, M, N, K, drop_p=0.0, key=(0, 0), rowscale=None, rows_per_scale=1, residual=None):
+    Wp = _wplanes(W, transposed)            # [2, N, K]
+    call("mdvit_linear_rc", _p(x), K, _p(Wp), N * K, _p(bias), _p(y), N, M, N, K, drop_p, key[0], key[1], _p(rowscale), rows_per_scale, _p(residual), N,
+         _seed_ptr() if drop_p > 0 else None, _stream())
+    del Wp
+
+
 def _dgrad(g, W, dx, M, K, N, ldb, **kw):
     """dx[M,K] = g[M,N] @ W[N,K]: NN on the fp32 path; NT against the cached W^T (planes) on the bf16x3 / bf16 paths."""
+    if _lin_rc_ok(M, K, N) and ldb == K and not (set(kw) - {"allow_split"}) and _events is None:
+        _linear_rc(g, W, True, None, dx, M, K, N)
+        return
     if _plane_ok(M, K, N) and "rc" not in kw and "precision" not in kw:
         gemm_nt(g, W, dx, M, K, N, w_transposed=True, **kw)
         return
@@ -789,7 +807,9 @@ class _Linear(torch.autograd.Function):
         assert K == K2
         y = _empty((M, N), device=x.device, dtype=torch.float32)
         key = _next_key() if drop_p > 0 else (0, 0)
-        if _plane_ok(M, N, K):
+        if _lin_rc_ok(M, N, K) and ldb == K and _events is None and (residual is not None or (drop_p == 0 and rowscale is None)):
+            _linear_rc(x, W, False, b, y, M, N, K, drop_p, key, rowscale, rows_per_scale, residual)
+        elif _plane_ok(M, N, K):
             gemm_nt(x, W, y, M, N, K, bias=b, e_drop=drop_p, e_key=key, e_rowscale=rowscale, e_rows_per_scale=rows_per_scale,
                     residual=residual, allow_split=True)
         else:
@@ -2091,6 +2111,12 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
         rc = True
     else:
         rc = False
+    if _lin_rc_ok(B * N, Cn, Cn) and params[4].is_contiguous() and params[16].is_contiguous():
+        ps = [_wplanes(params[4], False), _wplanes(params[16], False)] + ([_wplanes(params[16], True)] if backward else [])
+        d.qkv_p, d.proj_p = _p(ps[0]), _p(ps[1])
+        if backward:
+            d.projt_p = _p(ps[2])
+        keep += ps
     if backward and d.precision == 1:
         ts = [wt(params[4]), wt(params[16])] + ([] if rc else [wt(W1), wt(W2)])
         d.qkv_wt, d.proj_wt = _p(ts[0]), _p(ts[1])
