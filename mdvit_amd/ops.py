@@ -678,7 +678,7 @@ def _linear_rc(x, W, transposed, bias, y, M, N, K, drop_p=0.0, key=(0, 0), rowsc
 
 def _dgrad(g, W, dx, M, K, N, ldb, **kw):
     """dx[M,K] = g[M,N] @ W[N,K]: NN on the fp32 path; NT against the cached W^T (planes) on the bf16x3 / bf16 paths."""
-    if _lin_rc_ok(M, K, N) and ldb == K and not (set(kw) - {"allow_split"}) and _events is None:
+    if _lin_rc_ok(M, K, N) and ldb == K and not (set(kw) - {"allow_split"}):
         _linear_rc(g, W, True, None, dx, M, K, N)
         return
     if _plane_ok(M, K, N) and "rc" not in kw and "precision" not in kw:
@@ -807,7 +807,7 @@ class _Linear(torch.autograd.Function):
         assert K == K2
         y = _empty((M, N), device=x.device, dtype=torch.float32)
         key = _next_key() if drop_p > 0 else (0, 0)
-        if _lin_rc_ok(M, N, K) and ldb == K and _events is None and (residual is not None or (drop_p == 0 and rowscale is None)):
+        if _lin_rc_ok(M, N, K) and ldb == K and (residual is not None or (drop_p == 0 and rowscale is None)):
             _linear_rc(x, W, False, b, y, M, N, K, drop_p, key, rowscale, rows_per_scale, residual)
         elif _plane_ok(M, N, K):
             gemm_nt(x, W, y, M, N, K, bias=b, e_drop=drop_p, e_key=key, e_rowscale=rowscale, e_rows_per_scale=rows_per_scale,

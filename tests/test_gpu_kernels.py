@@ -308,6 +308,64 @@ def test_mlp_rc_kernels_vs_round2_kernels_and_fp64(M, r, drop, monkeypatch):
         check(sinks[p_] - 0.5, want, tol=2e-6, name=name + " (sink)")
 
 
+@pytest.mark.parametrize("M,N,K,full,drop", [(4173, 192, 64, False, 0.0), (70000, 64, 64, True, 0.1), (1030, 384, 128, False, 0.0), (2500, 128, 128, True, 0.25),
+                                             (33, 512, 64, True, 0.0), (20000, 512, 128, False, 0.0), (1, 32, 64, True, 0.1)])
+def test_linear_rc_streaming_kernel_is_the_tiled_gemm_bit_for_bit(M, N, K, full, drop):
+    """mdvit_linear_rc (a wave owns 32 tokens, x in MFMA operand registers, weight planes streamed through LDS): the same bf16x3 products in the
+    same order as mdvit_gemm_f32 -- bias, dropout mask, DropPath row scale and residual included -- so the outputs are EQUAL; and within the
+    bf16x3 bound of an fp64 product"""
+    from mdvit_amd import ops
+    from mdvit_amd.ops import call, _p, _stream
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("mdvit_linear_rc is the bf16x3 path's")
+    d = dev()
+    x, W, b = rnd(M, K, seed=260).to(d), rnd(N, K, seed=261, scale=K ** -0.5).to(d), rnd(N, seed=262, scale=0.1).to(d)
+    res = rnd(M, N, seed=263).to(d) if full else None
+    rps = max(1, (M + 2) // 3)
+    rs = ((torch.rand(3, generator=torch.Generator().manual_seed(8)) < 0.7).float() / 0.7).to(d) if full else None
+    y0, y1 = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
+    Wp = torch.empty(2, N, K, device=d, dtype=torch.bfloat16)
+    call("mdvit_split_planes_t", _p(W), K, _p(Wp), K, N * K, N, K, 0, 2, _stream())
+    ops.gemm(_p(x), _p(W), _p(y0), M, N, K, lda=K, ldb=K, ldc=N, bias=_p(b), e_drop=drop, e_key=(11, 22), e_rowscale=_p(rs), e_rows_per_scale=rps,
+             residual=_p(res), ldr=N)
+    call("mdvit_linear_rc", _p(x), K, _p(Wp), N * K, _p(b), _p(y1), N, M, N, K, drop, 11, 22, _p(rs), rps, _p(res), N, None, _stream())
+    assert torch.equal(y0, y1)
+    if drop == 0.0:
+        ref = x.double() @ W.double().t() + b.double()
+        if full:
+            ref = ref * rs.double().repeat_interleave(rps)[:M, None] + res.double()
+        check(y1, ref, tol=2e-5, name="y vs fp64")
+    # the data-gradient form: planes of W^T, no bias
+    if not full:
+        g = rnd(M, N, seed=264).to(d)
+        dx0, dx1 = torch.empty(M, K, device=d), torch.empty(M, K, device=d)
+        if N in (64, 128) and K % 32 == 0:
+            Wtp = torch.empty(2, K, N, device=d, dtype=torch.bfloat16)
+            call("mdvit_split_planes_t", _p(W), K, _p(Wtp), N, K * N, N, K, 1, 2, _stream())
+            Wt = W.t().contiguous()
+            ops.gemm(_p(g), _p(Wt), _p(dx0), M, K, N, lda=N, ldb=N, ldc=K, trans_b=True)
+            call("mdvit_linear_rc", _p(g), N, _p(Wtp), K * N, None, _p(dx1), K, M, K, N, 0.0, 0, 0, None, 1, None, 0, None, _stream())
+            assert torch.equal(dx0, dx1)
+
+
+def test_linear_layers_route_to_the_streaming_kernel_with_equal_results(monkeypatch):
+    """ops.linear with MDVIT_LINEAR_RC on / off: forward, data gradient, weight and bias gradients equal (the weight gradient is the same TN GEMM)"""
+    from mdvit_amd import ops
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("mdvit_linear_rc is the bf16x3 path's")
+    M, K, N = 5000, 64, 64
+    ins = [rnd(M, K, seed=270), rnd(N, K, seed=271, scale=K ** -0.5), rnd(N, seed=272, scale=0.1), rnd(M, N, seed=273)]
+    g = rnd(M, N, seed=274)
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "_lin_rc", flag)
+        monkeypatch.setattr(ops, "_key_counter", __import__("itertools").count(97))
+        out, go = grads_of(lambda x, W, b, r: ops.linear(x, W, b, residual=r, drop_p=0.1), [t.to(dev()) for t in ins], g)
+        res.append([out.detach()] + go)
+    for name, a, b in zip(("y", "dx", "dW", "db", "dres"), res[0], res[1]):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("M,r,drop", [(37, 8, 0.1), (4173, 8, 0.25), (1030, 4, 0.0), (9000, 8, 0.1)])
 def test_mlp_rc16_kernels_vs_the_gemm_path_and_fp64(M, r, drop, monkeypatch):
     """mdvit_mlp_rc16_fwd / _dgrad (C = 128, bf16x3, 16-token waves: the MLP forward and the backward data path as ONE kernel each) against the
