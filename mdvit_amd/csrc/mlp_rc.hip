@@ -333,8 +333,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // per CU); the overlap of one wave's MFMAs with another's activation VALU comes from the third wave instead.  Group g = {W1 sub g, W2 sub g},
 // issued two steps ahead into a three-slot ring.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int C, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_rc_fwd3_kernel(RcArgs p) {
+template <int C, int NW, bool DROP, int OCC = 3, bool STORE = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc_fwd3_kernel(RcArgs p) {
     constexpr int KB = C / 16, CB = C / 32;
     constexpr int RB1 = C * 2;
     constexpr int T1 = 32 * RB1, T2 = C * 64;
@@ -381,7 +381,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     __syncthreads();                                   // sB1 visible (the group waits below cover the weight tiles)
 
     for (int t = 0; t < n; ++t) {
-        RC_WAIT_VM(PPW);                               // group t landed (group t + 1 may still be in flight)
+        if (STORE && t > 0) RC_WAIT_VM(PPW + 4);       // group t landed (younger: group t + 1 and the four h stores of step t - 1)
+        else RC_WAIT_VM(PPW);                          // group t landed (group t + 1 may still be in flight)
         __builtin_amdgcn_s_barrier();
         issue_group(t + 2);                            // into the slot step t - 1 read
         const int slot = t % 3;
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + t * 32 + 8 * q + 4 * lhi), p.thresh, p.inv_keep);
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
             }
+            if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + t * 32 + 8 * q + 4 * lhi) = v; }
             hv[4 * q + 0] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
         }
 #pragma unroll
@@ -1232,8 +1234,10 @@ void rc_fill(RcArgs& a, int M, int Hd, float drop_p, uint32_t k10, uint32_t k11,
 }  // namespace
 
 int g_rc_fwd_variant = 3;       // 2: software-pipelined wave, 2 waves per SIMD; 3: plain wave, 3 waves per SIMD (tuning hook: mdvit_mlp_rc_config)
+int g_rc_fwd128_variant = 16;   // C = 128 forward: 16-token waves (16x16x32 tiles; 327-352 us at 131072 tokens) or 32-token waves (32x32x16; 388-431 us: measured, not the default)
 extern "C" int mdvit_mlp_rc_config(int32_t fwd_variant) {
-    g_rc_fwd_variant = fwd_variant;
+    if (fwd_variant == 16 || fwd_variant == 32) g_rc_fwd128_variant = fwd_variant;
+    else g_rc_fwd_variant = fwd_variant;
     return MDVIT_OK;
 }
 
@@ -1331,7 +1335,23 @@ extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* 
         if (rc != MDVIT_OK) return rc;                                                                                               \
         hipLaunchKernelGGL((mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV>), grid, block, smem, s, a);                             \
     } while (0)
-    if (C == 128) {
+    if (C == 128 && g_rc_fwd128_variant == 32) {
+        // 32-token waves on 32x32x16 tiles: the forward's registers allow it (x fragments 64 + y accumulator 64), and every weight fragment read
+        // from LDS then serves twice the tokens of the 16-token form
+        const int smem32 = 3 * 2 * (32 * 256) + 3 * 2 * (128 * 64) + Hd * 4;
+        const dim3 grid32(cdiv(M, 8 * 32)), block32(512);
+#define RC32_FWD_LAUNCH(DROPV, STOREV)                                                                                               \
+    do {                                                                                                                             \
+        static bool fl[64] = {false};                                                                                                \
+        const int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<128, 8, DROPV, 2, STOREV>),                      \
+                                  3 * 2 * (32 * 256) + 3 * 2 * (128 * 64) + 4096 * 4, fl);                                           \
+        if (rc != MDVIT_OK) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_rc_fwd3_kernel<128, 8, DROPV, 2, STOREV>), grid32, block32, smem32, s, a);                           \
+    } while (0)
+        if (a.drop) { if (h) RC32_FWD_LAUNCH(true, true); else RC32_FWD_LAUNCH(true, false); }
+        else { if (h) RC32_FWD_LAUNCH(false, true); else RC32_FWD_LAUNCH(false, false); }
+#undef RC32_FWD_LAUNCH
+    } else if (C == 128) {
         if (a.drop) { if (h) RC16_FWD_LAUNCH(128, 2, true, true); else RC16_FWD_LAUNCH(128, 2, true, false); }
         else { if (h) RC16_FWD_LAUNCH(128, 2, false, true); else RC16_FWD_LAUNCH(128, 2, false, false); }
     } else {

@@ -53,3 +53,14 @@ for M in sizes:
         print(f"   {name}: rc16 vs GEMM path max rel diff {err:.2e}   finite {bool(torch.isfinite(b).all())}")
     # against fp64 (p = 0.1 masks are the same in both paths: compare the two errors)
 ops._mlp_rc16 = True
+# forward variants at C = 128 (32-token waves on 32x32x16 tiles against 16-token waves), interleaved in one process
+from mdvit_amd._lib import call
+M = sizes[-1]
+x = torch.randn(M, C, device="cuda", requires_grad=True); res = torch.randn(M, C, device="cuda")
+for rnd_ in range(3):
+    for var in (16, 32):
+        call("mdvit_mlp_rc_config", var)
+        for dp in (0.1, 0.0):
+            t = timed(lambda: ops.mlp_residual(x, res, W1, b1, W2, b2, rowscale=None, drop_p=dp, rows_per_scale=M))
+            print(f"round {rnd_} fwd variant {var} drop {dp}: {t:8.1f} us (h stored)", flush=True)
+call("mdvit_mlp_rc_config", 16)
