@@ -123,6 +123,90 @@ __global__ __launch_bounds__(256) void fa_conv_tile_kernel(const float* __restri
     conv_tile_body<WIN, FLIP>(sx, sw, blockIdx.y, x, ldx, xoff, w, bias, y, ldy, yoff, H, W, ncls, tiles_w, add_center);
 }
 
+// ---- two output rows per thread on packed fp32 FMAs -----------------------------------------------------------------------------
+// The stencil is VALU-bound (16 * WIN FMAs per window row and thread against ~WIN + 22 LDS reads).  Here a thread owns TWO adjacent output
+// rows of its channel: window row i of the upper output row and window row i of the lower one are the LDS rows r + i and r + i + 1, read as
+// ONE register pair per position (two LDS words a whole window row apart), and every tap is one v_pk_fma_f32 on (upper, lower) -- half the
+// FMA instructions per output.  Tile: 16 rows x TW2 columns x 32 channels (8 row pairs x 32 channels = 256 threads); the taller tile also
+// re-reads less halo (7x7: 1.9 instead of 2.4 input positions per output at 16 x 16).
+typedef float ct_f2 __attribute__((ext_vector_type(2)));
+constexpr int CT2_TH = 16, CT2_TW = 16;
+
+template <int WIN, bool FLIP>
+__device__ __forceinline__ void conv_tile2_body(float* __restrict__ sx, float* __restrict__ sw, int cblock,
+                                                const float* __restrict__ x, long ldx, int xoff,
+                                                const float* __restrict__ w, const float* __restrict__ bias,
+                                                float* __restrict__ y, long ldy, int yoff,
+                                                int H, int W, int ncls, int tiles_w, int add_center) {
+    constexpr int R = WIN / 2, LH = CT2_TH + 2 * R, LW = CT2_TW + 2 * R;
+    const int b = blockIdx.z, c0 = cblock * CT_CL;
+    const int th0 = (blockIdx.x / tiles_w) * CT2_TH, tw0 = (blockIdx.x % tiles_w) * CT2_TW;
+    const int cl = threadIdx.x & 31, rp = threadIdx.x >> 5;
+    const long img = (long)b * H * W;
+    CtWindow<LH, LW> win;
+    win.load(x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
+    constexpr int NWQ = (CT_CL * WIN * WIN + 255) / 256;
+    float wq[NWQ];
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+        const int i = threadIdx.x + 256 * j, c = i / (WIN * WIN), t = i % (WIN * WIN);
+        const bool ok = i < CT_CL * WIN * WIN && c0 + c < ncls;
+        const float wv = w[ok ? (long)(c0 + c) * WIN * WIN + (FLIP ? WIN * WIN - 1 - t : t) : 0];
+        wq[j] = ok ? wv : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NWQ; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < CT_CL * WIN * WIN) sw[i] = wq[j];
+    }
+    win.store(sx);
+    __syncthreads();
+    const int h = th0 + 2 * rp;
+    if (c0 + cl >= ncls || h >= H) return;
+    ct_f2 acc[CT2_TW];
+    const float b0 = (!FLIP && bias) ? bias[c0 + cl] : 0.f;
+#pragma unroll
+    for (int t = 0; t < CT2_TW; ++t) acc[t] = ct_f2{b0, b0};
+    // (one window row at a time for the wide windows: fully unrolled, hipcc hoists every row's LDS reads and needs 400 registers)
+#pragma unroll(WIN > 3 ? 1 : WIN)
+    for (int i = 0; i < WIN; ++i) {
+        ct_f2 row[LW];
+        float wr[WIN];
+#pragma unroll
+        for (int t = 0; t < LW; ++t) row[t] = ct_f2{sx[((2 * rp + i) * LW + t) * CT_CL + cl], sx[((2 * rp + i + 1) * LW + t) * CT_CL + cl]};
+        if (i == R && add_center) {          // y = x + conv(x)  (ConvPosEnc) / dx = g + conv^T(g): both rows' centre positions sit in window row R of the pair
+#pragma unroll
+            for (int t = 0; t < CT2_TW; ++t) acc[t] += row[t + R];
+        }
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) wr[j] = sw[cl * WIN * WIN + i * WIN + j];
+#pragma unroll
+        for (int t = 0; t < CT2_TW; ++t)
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) acc[t] = __builtin_elementwise_fma(ct_f2{wr[j], wr[j]}, row[t + j], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < CT2_TW; ++t)
+        if (tw0 + t < W) y[(img + (long)h * W + tw0 + t) * ldy + yoff + c0 + cl] = acc[t].x;
+    if (h + 1 < H) {
+#pragma unroll
+        for (int t = 0; t < CT2_TW; ++t)
+            if (tw0 + t < W) y[(img + (long)(h + 1) * W + tw0 + t) * ldy + yoff + c0 + cl] = acc[t].y;
+    }
+}
+
+template <int WIN, bool FLIP>
+__global__ __launch_bounds__(256) void fa_conv_tile2_kernel(const float* __restrict__ x, long ldx, int xoff,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long ldy, int yoff,
+                                                            int H, int W, int ncls, int tiles_w, int add_center) {
+    constexpr int R = WIN / 2, LH = CT2_TH + 2 * R, LW = CT2_TW + 2 * R;
+    extern __shared__ __attribute__((aligned(16))) float ct2_smem[];
+    float* sx = ct2_smem;
+    float* sw = sx + LH * LW * CT_CL;
+    conv_tile2_body<WIN, FLIP>(sx, sw, blockIdx.y, x, ldx, xoff, w, bias, y, ldy, yoff, H, W, ncls, tiles_w, add_center);
+}
+
 // The three window classes of ConvRelPosEnc (3x3 / 5x5 / 7x7 head groups, mpvit.py:296-318) in ONE launch: blockIdx.y walks the
 // 32-channel blocks of class 3, then 5, then 7 (a third of the launches of the attention's forward and data-gradient passes).
 struct Conv3Args {
@@ -144,6 +228,25 @@ __global__ __launch_bounds__(256) void fa_conv3_kernel(Conv3Args p) {
 }
 
 template <bool FLIP>
+__global__ __launch_bounds__(256) void fa_conv3v2_kernel(Conv3Args p) {
+    extern __shared__ __attribute__((aligned(16))) float ct2_smem[];
+    float* sx = ct2_smem;
+    float* sw = sx + (CT2_TH + 6) * (CT2_TW + 6) * CT_CL;
+    int yb = blockIdx.y;
+    if (yb < p.yb[0]) { conv_tile2_body<3, FLIP>(sx, sw, yb, p.x, p.ldx, p.xoff[0], p.w[0], p.bias[0], p.y, p.ldy, p.yoff[0], p.H, p.W, p.ncls[0], p.tiles_w, 0); return; }
+    yb -= p.yb[0];
+    if (yb < p.yb[1]) { conv_tile2_body<5, FLIP>(sx, sw, yb, p.x, p.ldx, p.xoff[1], p.w[1], p.bias[1], p.y, p.ldy, p.yoff[1], p.H, p.W, p.ncls[1], p.tiles_w, 0); return; }
+    yb -= p.yb[1];
+    conv_tile2_body<7, FLIP>(sx, sw, yb, p.x, p.ldx, p.xoff[2], p.w[2], p.bias[2], p.y, p.ldy, p.yoff[2], p.H, p.W, p.ncls[2], p.tiles_w, 0);
+}
+
+// 1: two rows per thread on packed FMAs (16 x 16 tiles); 0: one row per thread (8 x 16 tiles) -- MDVIT_CONV_TILE2=0 for A/B
+inline bool conv_tile_v2() {
+    static const bool on = [] { const char* e = getenv("MDVIT_CONV_TILE2"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+template <bool FLIP>
 void launch_conv3(const float* x, long ldx, const int xoff[3], const float* const w[3], const float* const bias[3], float* y, long ldy,
                   const int yoff[3], const CtGeom& g, const int ncls[3], hipStream_t s) {
     Conv3Args a;
@@ -155,6 +258,17 @@ void launch_conv3(const float* x, long ldx, const int xoff[3], const float* cons
         total += a.yb[i];
     }
     if (total == 0) return;
+    // measured (tools/conv_tile_check.py, block_roofline at bs=32): the packed two-row tiles win on the 128 x 128 / 64 x 64 token images of stages 0 / 1
+    // (block forward 1.158 -> 1.108 ms, backward 2.419 -> 2.398 ms at stage 0) and lose a little on 32 x 32 and 16 x 16, where a 16 x 16 tile is a
+    // quarter or all of the image
+    if (conv_tile_v2() && (long)g.H * g.W >= 4096) {
+        a.tiles_w = cdiv(g.W, CT2_TW);
+        constexpr int smem = ((CT2_TH + 6) * (CT2_TW + 6) * CT_CL + CT_CL * 49) * 4;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_conv3v2_kernel<FLIP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+        hipLaunchKernelGGL((fa_conv3v2_kernel<FLIP>), dim3(a.tiles_w * cdiv(g.H, CT2_TH), total, g.B), dim3(256), smem, s, a);
+        return;
+    }
     hipLaunchKernelGGL((fa_conv3_kernel<FLIP>), dim3(a.tiles_w * cdiv(g.H, CT_TH), total, g.B), dim3(256), 0, s, a);
 }
 
@@ -222,6 +336,16 @@ template <int WIN, bool FLIP>
 void launch_conv_tile(const float* x, long ldx, int xoff, const float* w, const float* bias, float* y, long ldy, int yoff,
                       const CtGeom& g, int ncls, hipStream_t s, int add_center = 0) {
     if (ncls <= 0) return;
+    if (WIN > 3 && conv_tile_v2() && (long)g.H * g.W >= 4096) {        // (3x3: 9 taps per output do not repay the taller tile's staging -- measured neutral to slower)
+        constexpr int R = WIN / 2;
+        constexpr int smem = ((CT2_TH + 2 * R) * (CT2_TW + 2 * R) * CT_CL + CT_CL * WIN * WIN) * 4;
+        const int tw2 = cdiv(g.W, CT2_TW), th2 = cdiv(g.H, CT2_TH);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_conv_tile2_kernel<WIN, FLIP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+        hipLaunchKernelGGL((fa_conv_tile2_kernel<WIN, FLIP>), dim3(tw2 * th2, cdiv(ncls, CT_CL), g.B), dim3(256), smem, s,
+                           x, ldx, xoff, w, bias, y, ldy, yoff, g.H, g.W, ncls, tw2, add_center);
+        return;
+    }
     const int tiles_w = cdiv(g.W, CT_TW), tiles_h = cdiv(g.H, CT_TH);
     hipLaunchKernelGGL((fa_conv_tile_kernel<WIN, FLIP>), dim3(tiles_w * tiles_h, cdiv(ncls, CT_CL), g.B), dim3(256), 0, s,
                        x, ldx, xoff, w, bias, y, ldy, yoff, g.H, g.W, ncls, tiles_w, add_center);
