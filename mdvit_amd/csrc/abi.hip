@@ -1,6 +1,7 @@
 // Error plumbing and version of libmdvit_hip.so.
 #include <stdarg.h>
 
+#include <stdlib.h>
 #include "common.h"
 
 thread_local char g_mdvit_err[512] = {0};
@@ -140,10 +141,60 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// Many partial rows (>= 64) of whole quads: one workgroup per 32-column slice, 8 column lanes x 32 row lanes -- every row access of a wavefront is
+// full 128-byte lines (the row-per-lane walk above touches one 16-byte piece per line: 8x the bytes; the ~1000-row reductions behind the
+// LayerNorm / mask-pass / row-dot backward kernels took 21 us each, 41 of them per step on the main stream).  Row lanes keep four loads in
+// flight; the 32 row-lane sums are folded in a fixed order through LDS: deterministic.
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ part, int nblk, long stride, int n0,
+                                                                   float* __restrict__ out0, int n1, float* __restrict__ out1, int accumulate) {
+    __shared__ float4 s_red[32][8];
+    const int n = n0 + n1;
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 32 + cl * 4;
+    part += (long)blockIdx.y * nblk * stride;
+    out0 += (long)blockIdx.y * n0;
+    if (out1) out1 += (long)blockIdx.y * n1;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n) {
+        int b = rl;
+        for (; b + 96 < nblk; b += 128) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (long)b * stride + c);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(b + 32) * stride + c);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (long)(b + 64) * stride + c);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (long)(b + 96) * stride + c);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; b < nblk; b += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (long)b * stride + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    s_red[rl][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < 8 && c < n) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) { const float4 v = s_red[r][cl]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c + j;
+            float* dst = col < n0 ? out0 + col : (out1 ? out1 + (col - n0) : nullptr);
+            if (dst) *dst = accumulate ? *dst + v[j] : v[j];
+        }
+    }
+}
+
 int launch_reduce(const float* part, int batches, int nblk, long stride, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream) {
     const int n = n0 + n1, nq = (n + 3) / 4;
     const int vec = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0) && (((long)nblk * stride) % 4 == 0);
-    if (nblk >= 256)
+    static const bool wide = [] { const char* e = getenv("MDVIT_REDUCE_WIDE"); return !(e && e[0] == '0'); }();
+    if (wide && vec && nblk >= 64 && n % 4 == 0)
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((n + 31) / 32, batches), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate);
+    else if (nblk >= 256)
         hipLaunchKernelGGL((reduce_partials_kernel<256>), dim3(nq, batches), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate, vec);
     else if (nblk >= 16)
         hipLaunchKernelGGL((reduce_partials_kernel<32>), dim3((nq + 7) / 8, batches), dim3(256), 0, stream, part, nblk, stride, n0, out0, n1, out1, accumulate, vec);

@@ -204,10 +204,9 @@ def _sink_of(t):
 # ---- peer streams: the G peer heads of a domain-batched forward are independent chains of small kernels --------------------
 # Each head (its forward, and -- because autograd runs a node's backward on the stream its forward ran on -- its backward too) goes
 # to a stream of its own, so the heads overlap each other instead of queueing behind each other on the main stream.
-# Round 2 switched them off: with the host as the limit of the step their event traffic cost more than they overlapped (-7 %).  Since round 3 the
-# step is GPU-bound (one C call per transformer-block pass) and two peer streams are worth +2.5 % at bs=4 (362-364 -> 370-375 images/s,
-# interleaved A/B); four are no better, and at bs=32 they buy nothing while every extra stream grows the caching allocator's reserved pool
-# (180 -> 276 GiB).  Default "auto": two peer streams when the domain-batched forward holds at most 32 images; MDVIT_PEER_STREAMS=0 / 1 force.
+# Round 2 switched them off (host-bound step: their event traffic cost more than they overlapped).  Round 3 first re-enabled two of them
+# ("+2.5 %", measured against a step whose aux sweep was ALREADY serialised by a fifth stream) and then found the real cost: see peer_stream.
+# MDVIT_PEER_STREAMS=1 forces dedicated streams (A/B), 0 / auto: none.
 _peer_streams = []
 _peer_mode = os.environ.get("MDVIT_PEER_STREAMS", "auto")
 _use_peer_streams = _peer_mode != "0"
@@ -220,7 +219,12 @@ def peer_stream(i: int, n_images: int = 0):
     """the i-th peer stream, or None when disabled / capturing (a captured graph keeps the single-stream order) / in auto mode for large batches"""
     if not _use_peer_streams or (torch.cuda.is_current_stream_capturing() and not _graph_peers):
         return None
-    if _peer_mode == "auto" and n_images > _peer_auto_max_images:
+    if _peer_mode == "auto":
+        # The GPU runs FOUR hardware queues.  main + weight-gradient stream + aux-sweep stream + two peer streams = five: the stream created last
+        # (the aux sweep's) then SHARES the main stream's queue and the whole data-gradient-only sweep runs behind the full sweep instead of next
+        # to it (tools/sweep_timeline.py: aux sweep runnable at 28.5 ms instead of 10.4; step 40.4 ms with two peer streams, 38.0 with one, 37.3
+        # without -- 396 -> 429 images/s).  Letting the peer heads borrow the two streams that idle during the forward keeps four queues but puts the
+        # full sweep's peer-head backward in front of the aux sweep on its stream: 40.3 ms.  So: no peer streams next to the two-stream sweeps.
         return None
     i %= _peer_stream_count
     while len(_peer_streams) <= i:
@@ -439,9 +443,11 @@ def wt(W):
     if out is None:
         out = torch.empty((K, N), device=W.device, dtype=torch.float32)
     call("mdvit_transpose_f32", _p(W), ld, _p(out), N, K, _stream())
-    global _cache_filled
-    _cache_filled = True
     if leaf:
+        # (only a CACHED entry can be hit from another stream later; the transpose of a non-leaf weight -- the peer heads' composed weights, every
+        # step -- is a temporary of the sweep that made it.  Raising the flag for those serialised the aux sweep behind the full one in every step.)
+        global _cache_filled
+        _cache_filled = True
         key = id(W)
         _wt_cache[key] = (weakref.ref(W, lambda _r, key=key: _wt_cache.pop(key, None)),) + tag + (out,)
     return out
@@ -484,7 +490,7 @@ def refresh_transposes():
 # AND a global epoch that optimizers writing through raw pointers (optim.FusedAdamW) bump after every update.
 _weights_epoch = 0
 _wp_cache = {}       # id(leaf weight) -> {"ref": weakref, "planes": {transposed: tensor}, "tags": {transposed: tag}}
-_wp_table = None
+_wp_table = {}       # plane count -> (signature, device table, tiles)
 
 
 def mark_weights_updated():
@@ -493,63 +499,66 @@ def mark_weights_updated():
     _weights_epoch += 1
 
 
-def _wplanes(W, transposed: bool):
-    """bf16 planes [P, rows, cols] of W (rows, cols = N, K) or of W^T (K, N)."""
+def _wplanes(W, transposed: bool, planes: Optional[int] = None):
+    """bf16 planes [P, rows, cols] of W (rows, cols = N, K) or of W^T (K, N).  P = the GEMM mode's plane count (bf16x3: hi + lo, bf16: hi), or
+    `planes` = 2 for the register-chained kernels of mlp_rc.hip, which compute in bf16x3 in either mode."""
     N, K, ld = _ld_view(W)
-    P = _nplanes()
+    P = _nplanes() if planes is None else planes
     rows, cols = (K, N) if transposed else (N, K)
     leaf = W.grad_fn is None and W.requires_grad
     buf = None
+    slot = (transposed, P)
     if leaf:
         tag = (W._version, _weights_epoch, W.data_ptr(), N, K, ld, P)
         ent = _wp_cache.get(id(W))
         if ent is None or ent["ref"]() is not W:
             key = id(W)
             ent = _wp_cache[key] = {"ref": weakref.ref(W, lambda _r, key=key: _wp_cache.pop(key, None)), "planes": {}, "tags": {}}
-        buf = ent["planes"].get(transposed)
-        if buf is not None and ent["tags"].get(transposed) == tag:
+        buf = ent["planes"].get(slot)
+        if buf is not None and ent["tags"].get(slot) == tag:
             return buf
         if buf is not None and tuple(buf.shape) != (P, rows, cols):
             buf = None
     if buf is None:
         buf = torch.empty((P, rows, cols), device=W.device, dtype=torch.bfloat16)
     call("mdvit_split_planes_t", _p(W), ld, _p(buf), cols, rows * cols, N, K, int(transposed), P, _stream())
-    global _cache_filled
-    _cache_filled = True
     if leaf:
-        ent["planes"][transposed] = buf
-        ent["tags"][transposed] = tag
+        global _cache_filled
+        _cache_filled = True
+        ent["planes"][slot] = buf
+        ent["tags"][slot] = tag
     return buf
 
 
 def refresh_weight_planes():
-    """Re-split EVERY cached weight orientation in one launch (start of a step, after the optimizer update)."""
-    global _wp_table
-    items, live = [], []
-    P = _nplanes()
-    for key, ent in list(_wp_cache.items()):
-        W = ent["ref"]()
-        if W is None:
-            continue
-        N, K, ld = _ld_view(W)
-        for tr, buf in ent["planes"].items():
-            rows, cols = (K, N) if tr else (N, K)
-            if tuple(buf.shape) != (P, rows, cols):
+    """Re-split EVERY cached weight orientation in one launch per plane count (start of a step, after the optimizer update)."""
+    for P in (1, 2):
+        items, live = [], []
+        for key, ent in list(_wp_cache.items()):
+            W = ent["ref"]()
+            if W is None:
                 continue
-            items.append((W.data_ptr(), buf.data_ptr(), ld, N, K, int(tr), cols, rows * cols))
-            live.append((ent, tr, (W._version, _weights_epoch, W.data_ptr(), N, K, ld, P)))
-    if not items:
-        return
-    sig = tuple(items)
-    if _wp_table is None or _wp_table[0] != sig:
-        if torch.cuda.is_current_stream_capturing():
-            return                            # host-built table: must exist before capture (warm-up steps build it)
-        dev = torch.device("cuda", torch.cuda.current_device())
-        tiles = max(((it[3] + 31) // 32) * ((it[4] + 31) // 32) for it in items)
-        _wp_table = (sig, torch.tensor([list(it) for it in items], dtype=torch.int64, device=dev), int(min(tiles, 64)))
-    call("mdvit_split_planes_many", _p(_wp_table[1]), len(items), _wp_table[2], P, _stream())
-    for ent, tr, tag in live:
-        ent["tags"][tr] = tag
+            N, K, ld = _ld_view(W)
+            for slot, buf in ent["planes"].items():
+                tr, Ps = slot
+                rows, cols = (K, N) if tr else (N, K)
+                if Ps != P or tuple(buf.shape) != (P, rows, cols):
+                    continue
+                items.append((W.data_ptr(), buf.data_ptr(), ld, N, K, int(tr), cols, rows * cols))
+                live.append((ent, slot, (W._version, _weights_epoch, W.data_ptr(), N, K, ld, P)))
+        if not items:
+            continue
+        sig = tuple(items)
+        tab = _wp_table.get(P)
+        if tab is None or tab[0] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                continue                          # host-built table: must exist before capture (warm-up steps build it)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            tiles = max(((it[3] + 31) // 32) * ((it[4] + 31) // 32) for it in items)
+            tab = _wp_table[P] = (sig, torch.tensor([list(it) for it in items], dtype=torch.int64, device=dev), int(min(tiles, 64)))
+        call("mdvit_split_planes_many", _p(tab[1]), len(items), tab[2], P, _stream())
+        for ent, slot, tag in live:
+            ent["tags"][slot] = tag
 
 
 class Planes:
@@ -666,11 +675,11 @@ _lin_rc = os.environ.get("MDVIT_LINEAR_RC", "1") != "0"     # short-K Linear lay
 
 def _lin_rc_ok(M, N, K) -> bool:
     """y[M,N] = x[M,K] W^T runs on mdvit_linear_rc: bf16x3 mode, K = 64 / 128, N % 32 == 0 (bit-identical to the tiled GEMM: same products, same order)"""
-    return _lin_rc and _gemm_precision == 1 and K in (64, 128) and N % 32 == 0 and 32 <= N <= 4096 and M >= 1024
+    return _lin_rc and _gemm_precision >= 1 and K in (64, 128) and N % 32 == 0 and 32 <= N <= 4096 and M >= 1024
 
 
 def _linear_rc(x, W, transposed, bias, y, M, N, K, drop_p=0.0, key=(0, 0), rowscale=None, rows_per_scale=1, residual=None):
-    Wp = _wplanes(W, transposed)            # [2, N, K]
+    Wp = _wplanes(W, transposed, 2)         # [2, N, K]
     call("mdvit_linear_rc", _p(x), K, _p(Wp), N * K, _p(bias), _p(y), N, M, N, K, drop_p, key[0], key[1], _p(rowscale), rows_per_scale, _p(residual), N,
          _seed_ptr() if drop_p > 0 else None, _stream())
     del Wp
@@ -931,12 +940,12 @@ _mlp_rc16 = os.environ.get("MDVIT_MLP_RC16", "1") != "0"  # C = 128: the backwar
 
 
 def _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M) -> bool:
-    return (_mlp_rc and _mlp_recompute and _gemm_precision == 1 and Cin == 64 and Hd % 256 == 0 and Hd <= 4096 and b1 is not None and b2 is not None and res is not None
+    return (_mlp_rc and _mlp_recompute and _gemm_precision >= 1 and Cin == 64 and Hd % 256 == 0 and Hd <= 4096 and b1 is not None and b2 is not None and res is not None
             and W1.is_contiguous() and W2.is_contiguous() and M * Hd < (1 << 32))
 
 
 def _mlp_rc16_ok(Cin, Hd, b1, W1, W2, M) -> bool:
-    return (_mlp_rc16 and _gemm_precision == 1 and Cin == 128 and Hd % 32 == 0 and Hd <= 4096 and b1 is not None and W1.is_contiguous() and W2.is_contiguous()
+    return (_mlp_rc16 and _gemm_precision >= 1 and Cin == 128 and Hd % 32 == 0 and Hd <= 4096 and b1 is not None and W1.is_contiguous() and W2.is_contiguous()
             and M * Hd < (1 << 32))
 
 
@@ -952,7 +961,7 @@ class _MlpResidual(torch.autograd.Function):
         if _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M):
             # C = 64: the hidden activation stays in registers; NOTHING of size [tokens, hidden] is kept for the backward (it recomputes)
             out = _empty((M, Cin), device=x.device, dtype=torch.float32)
-            W1p, W2p = _wplanes(W1, False), _wplanes(W2, False)
+            W1p, W2p = _wplanes(W1, False, 2), _wplanes(W2, False, 2)
             call("mdvit_mlp_rc_fwd", _p(x), _p(W1p), _p(b1), _p(W2p), _p(b2), _p(res), _p(rowscale), rows_per_scale, _p(out), M, Cin, Hd,
                  drop_p, k1[0], k1[1], k2[0], k2[1], _seed_ptr() if drop_p > 0 else None, _stream())
             del W1p, W2p
@@ -978,7 +987,7 @@ class _MlpResidual(torch.autograd.Function):
         if _mlp_recompute and _mlp_recompute_maxc >= 128 and b2 is not None and res is not None and _mlp_rc16_ok(Cin, Hd, b1, W1, W2, M):
             # C = 128: both GEMMs in ONE kernel on 16-token waves, the hidden chunk chained in registers; h goes to HBM once, for the fc2 weight gradient
             out = _empty((M, Cin), device=x.device, dtype=torch.float32)
-            W1p, W2p = _wplanes(W1, False), _wplanes(W2, False)
+            W1p, W2p = _wplanes(W1, False, 2), _wplanes(W2, False, 2)
             call("mdvit_mlp_rc16_fwd", _p(x), _p(W1p), _p(b1), _p(W2p), _p(b2), _p(res), _p(rowscale), rows_per_scale, _p(h), _p(out), M, Cin, Hd,
                  drop_p, k1[0], k1[1], k2[0], k2[1], _seed_ptr() if drop_p > 0 else None, _stream())
             del W1p, W2p
@@ -1035,7 +1044,7 @@ class _MlpResidual(torch.autograd.Function):
                 wsp, wsb, _keep = _partials_ws(Cin, dev) if want_w else (None, 0, None)
                 call("mdvit_colsum_f32", _p(g), Cin, _p(sinks[3] if sunk else db2) if want_w else None, _p(gm) if masked else None, wsp, wsb, M, Cin,
                      drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
-            W1p, W2tp, W1tp = _wplanes(W1, False), _wplanes(W2, True), _wplanes(W1, True)
+            W1p, W2tp, W1tp = _wplanes(W1, False, 2), _wplanes(W2, True, 2), _wplanes(W1, True, 2)
             dx = _empty_like(x)
             call("mdvit_mlp_rc_dgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(W1tp), _p(dx), M, Cin, Hd,
                  drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, _stream())
@@ -1075,7 +1084,7 @@ class _MlpResidual(torch.autograd.Function):
         elif u is None and _mlp_rc16_ok(Cin, Hd, ctx.b1_ref, W1, W2, M):
             # C = 128: u recomputed, du = (gm W2) * gelu'(u) * mask1 and dx = du W1 in ONE kernel; du reaches HBM only for the weight gradients
             du = None if _dgrad_only else _empty_like(h)
-            W1p, W2tp, W1tp = _wplanes(W1, False), _wplanes(W2, True), _wplanes(W1, True)
+            W1p, W2tp, W1tp = _wplanes(W1, False, 2), _wplanes(W2, True, 2), _wplanes(W1, True, 2)
             call("mdvit_mlp_rc16_dgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(W1tp), _p(du), _p(dx), M, Cin, Hd,
                  drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, _stream())
             del W1p, W2tp, W1tp
@@ -1328,9 +1337,9 @@ def _conv_weight(w, mode: int):
         return hit[2]
     out = hit[2] if (hit is not None and hit[0]() is w) else torch.empty(((Cout, 9 * Cin) if mode == 0 else (Cin, 9 * Cout)), device=w.device, dtype=torch.float32)
     call("mdvit_conv_weight_relayout", _p(w), _p(out), Cout, Cin, mode, _stream())
-    global _cache_filled
-    _cache_filled = True
     if w.grad_fn is None:
+        global _cache_filled
+        _cache_filled = True
         _conv_w_cache[key] = (weakref.ref(w, lambda _r, key=key: _conv_w_cache.pop(key, None)), tag, out)
     return out
 
@@ -2101,18 +2110,18 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
     W1, W2 = params[20], params[22]
     rc16 = d.precision == 1 and _mlp_recompute and _mlp_recompute_maxc >= 128 and params[23] is not None and _mlp_rc16_ok(Cn, d.hidden, params[21], W1, W2, B * N)
     if (d.precision == 1 and _mlp_rc_ok(Cn, d.hidden, params[21], params[23], x, W1, W2, B * N)) or rc16:
-        p1, p2 = _wplanes(W1, False), _wplanes(W2, False)
+        p1, p2 = _wplanes(W1, False, 2), _wplanes(W2, False, 2)
         d.fc1_p, d.fc2_p = _p(p1), _p(p2)
         keep += [p1, p2]
         if backward:
-            p3, p4 = _wplanes(W2, True), _wplanes(W1, True)
+            p3, p4 = _wplanes(W2, True, 2), _wplanes(W1, True, 2)
             d.fc2t_p, d.fc1t_p = _p(p3), _p(p4)
             keep += [p3, p4]
         rc = True
     else:
         rc = False
     if _lin_rc_ok(B * N, Cn, Cn) and params[4].is_contiguous() and params[16].is_contiguous():
-        ps = [_wplanes(params[4], False), _wplanes(params[16], False)] + ([_wplanes(params[16], True)] if backward else [])
+        ps = [_wplanes(params[4], False, 2), _wplanes(params[16], False, 2)] + ([_wplanes(params[16], True, 2)] if backward else [])
         d.qkv_p, d.proj_p = _p(ps[0]), _p(ps[1])
         if backward:
             d.projt_p = _p(ps[2])
@@ -2201,13 +2210,16 @@ def serial_block(x, label, rs1, rs2, meta, params):
 
 def block_entry_ok(Cn, hidden, params) -> bool:
     """the C-level block covers this configuration (otherwise: the operator-level path)"""
-    if not _block_entry or _gemm_precision > 1 or Cn % 4:
+    if not _block_entry or Cn % 4:
         return False
+    if _gemm_precision > 1 and Cn > 128:
+        return False           # bf16 mode: the MFMA-bound C >= 320 blocks stay on the operator path (single-plane GEMMs); the HBM- / VALU-bound C <= 128
+        #                        blocks run the same bf16x3 register-chained kernels as the parity mode (the "mixed" mode of BASELINE configs[3])
     if not all(p is None or (p.is_contiguous() and p.dtype == torch.float32) for p in params):
         return False
-    if Cn == 64 and _gemm_precision == 1 and not (_mlp_rc and _mlp_recompute and hidden % 256 == 0 and hidden <= 4096):
+    if Cn == 64 and _gemm_precision >= 1 and not (_mlp_rc and _mlp_recompute and hidden % 256 == 0 and hidden <= 4096):
         return False                                   # round 2's fused C = 64 MLP kernels are reachable through the operator path only
-    if _gemm_precision == 1 and Cn <= 128 and not _mlp_recompute:
+    if _gemm_precision >= 1 and Cn <= 128 and not _mlp_recompute:
         return False
     return True
 
@@ -2329,6 +2341,9 @@ def set_sweep_stream(stream):
 
 _sweep_stream_obj = None
 _ones = {}
+# Dispatch priority of the data-gradient-only sweep's stream (torch: 0 normal, -1 high).  Measured: high priority is a LOSS (the step goes from
+# 40.7 to 51.8 ms: the aux sweep then starves the main stream's forward of the next step and the full sweep).
+_aux_priority = int(os.environ.get("MDVIT_AUX_PRIORITY", "0"))
 
 
 def sweep_stream():
@@ -2337,7 +2352,7 @@ def sweep_stream():
     if torch.cuda.is_current_stream_capturing():
         return None
     if _sweep_stream_obj is None:
-        _sweep_stream_obj = torch.cuda.Stream()
+        _sweep_stream_obj = torch.cuda.Stream(priority=_aux_priority)
     return _sweep_stream_obj
 
 

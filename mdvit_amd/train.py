@@ -79,6 +79,7 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
             # the whole sweep on a stream of its own (ops.set_sweep_stream): every node of it is one of our Functions (ops.fork at the
             # trunk's multi-consumer tensors) and the root gradient is handed in, so nothing of it is launched on the main stream
             main = ops.current_stream_obj()
+            _tl("aux sweep: runnable (its stream)", on_stream)
             ops.set_sweep_stream(on_stream)
             try:
                 _backward(loss, retain_graph=retain, gradient=ops.one_like(loss))
