@@ -272,13 +272,15 @@ typedef struct MdvitBlockDesc {
 } MdvitBlockDesc;
 /* Gradient outputs of the backward.  The sixteen "weight-class" outputs (cpe, qkv, crpe windows, proj, fc1, fc2) are overwritten
  * (accumulate == 0: fresh buffers) or added into (accumulate != 0: gradient buckets; the weight-gradient kernels then run on the side
- * stream).  The LayerNorm and adapter gradients are always overwritten.  dgrad_only: the data-gradient-only sweep of the merged two-sweep
+ * stream).  The adapter gradients are always overwritten, the LayerNorm gradients too unless ln_accumulate.  dgrad_only: the data-gradient-only sweep of the merged two-sweep
  * step (multi_train_MDViT.py:198-207): no parameter gradient except the adapter's, NEGATED; aux_first: this block holds the first adapter of
  * the network -- that sweep ends here (dx is not produced). */
 typedef struct MdvitBlockGrads {
     float *cpe_w, *cpe_b, *n1_g, *n1_b, *qkv_w, *qkv_b, *w3, *b3, *w5, *b5, *w7, *b7, *da_w1, *da_b1, *da_w2, *da_b2, *proj_w, *proj_b, *n2_g, *n2_b, *fc1_w, *fc1_b, *fc2_w,
         *fc2_b;
     int32_t accumulate, dgrad_only, aux_first;
+    int32_t ln_accumulate;      /* != 0 (needs accumulate != 0 and a side stream): n1_g / n1_b / n2_g / n2_b and fc2_b are gradient buckets too -- their
+                                   second-stage reductions ADD into them, on the side stream */
 } MdvitBlockGrads;
 /* main: the stream of the data-gradient chain; side: the stream of the weight-gradient kernels (NULL or == main: everything on main).
  * events: n_events HIP events owned by the caller (mdvit_event_create) for the main -> side ordering, used round robin from *next_event. */

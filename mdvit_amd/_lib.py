@@ -84,7 +84,7 @@ BLOCK_PARAMS = ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", 
 
 
 class BlockGrads(C.Structure):
-    _fields_ = [(n, vp) for n in BLOCK_PARAMS] + [("accumulate", i32), ("dgrad_only", i32), ("aux_first", i32)]
+    _fields_ = [(n, vp) for n in BLOCK_PARAMS] + [("accumulate", i32), ("dgrad_only", i32), ("aux_first", i32), ("ln_accumulate", i32)]
 
 
 class BlockStreams(C.Structure):

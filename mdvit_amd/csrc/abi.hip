@@ -220,6 +220,11 @@ int mdvit_reduce_partials_batched2(const float* part, int batches, int nblk, int
     return launch_reduce(part, batches, nblk, (long)(n0 + n1), n0, out0, n1, out1, 0, stream);
 }
 
+int mdvit_reduce_partials_batched2_acc(const float* part, int batches, int nblk, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream) {
+    if (n0 + n1 <= 0 || nblk <= 0 || batches <= 0) return MDVIT_OK;
+    return launch_reduce(part, batches, nblk, (long)(n0 + n1), n0, out0, n1, out1, accumulate, stream);
+}
+
 extern "C" size_t mdvit_partials_ws_bytes(int32_t n_outputs) {
     return n_outputs > 0 ? sizeof(float) * (size_t)MDVIT_MAX_PARTIAL_ROWS * (size_t)n_outputs : 0;
 }

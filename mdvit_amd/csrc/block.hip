@@ -196,6 +196,13 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
     const bool fast_ln = C == 64 || C == 128 || C == 320 || C == 512;
 
     const bool have_side = st.side != nullptr && st.side != st.main;
+    // Second stages of the parameter-gradient reductions (LayerNorm dgamma / dbeta, the fc2 bias column sums): ~20 us each of latency-bound work on four
+    // workgroups.  When the gradients ACCUMULATE into buckets nobody reads them before the side stream is joined, so those passes run there (their
+    // partial rows live in the side arena) instead of sitting on the data-gradient chain of the main stream.
+    const bool defer = want_w && acc != 0 && G.ln_accumulate != 0 && have_side && fast_ln;
+    struct Late { const float* part; int batches, nblk, n0; float* out0; int n1; float* out1; };
+    Late late[4];
+    int n_late = 0;
     if (want_w && acc == 0) {       // bias gradients ride on column sums that ACCUMULATE: clear the fresh buffers first
         const MdvitZeroItem z[4] = {{G.qkv_b, sizeof(float) * 3 * C}, {G.proj_b, sizeof(float) * C}, {mode == MLP_RC ? nullptr : G.fc1_b, sizeof(float) * Hd},
                                     {mode == MLP_RC ? nullptr : G.fc2_b, sizeof(float) * C}};
@@ -211,9 +218,15 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
     if (mode == MLP_RC) {
         if (masked || want_w) {
             const size_t pb = want_w ? mdvit_partials_ws_bytes(C) : 0;
-            void* pw = want_w ? A.take_bytes(pb) : nullptr;
-            BLK_RUN(mdvit_colsum_f32(dy, C, want_w ? G.fc2_b : nullptr, masked ? gm2 : nullptr, pw, pb, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok,
-                                     acc, seed, s));
+            void* pw = want_w ? (defer ? S.take_bytes(pb) : A.take_bytes(pb)) : nullptr;
+            if (want_w && defer) {
+                int nb = 0;
+                BLK_RUN(mdvit_colsum_parts(dy, C, masked ? gm2 : nullptr, pw, pb, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok, seed, s, &nb));
+                late[n_late++] = Late{(const float*)pw, 1, nb, C, G.fc2_b, 0, nullptr};
+            } else {
+                BLK_RUN(mdvit_colsum_f32(dy, C, want_w ? G.fc2_b : nullptr, masked ? gm2 : nullptr, pw, pb, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok,
+                                         acc, seed, s));
+            }
         }
         BLK_RUN(mdvit_mlp_rc_dgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
         if (want_w) {
@@ -263,7 +276,13 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         void* pw = lnw ? A.take_bytes(pb) : nullptr;
         float* dg = want_w ? G.n2_g : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
         float* db = want_w ? G.n2_b : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
-        if (masked1 && fast_ln) {
+        if (defer) {
+            void* pws = S.take_bytes(pb);
+            int nb = 0;
+            BLK_RUN(mdvit_layernorm_bwd_parts(dcur2, sv.x2, d.n2_g, sv.mean2, sv.rstd2, dy, dx2, masked1 ? gm1 : nullptr, pws, pb, M, C, d.ln_groups, d.drop_p, d.key_proj[0],
+                                              d.key_proj[1], d.rowscale1, N_tok, seed, s, &nb));
+            late[n_late++] = Late{(const float*)pws, d.ln_groups, nb, C, dg, C, db};
+        } else if (masked1 && fast_ln) {
             BLK_RUN(mdvit_layernorm_bwd_masked(dcur2, sv.x2, d.n2_g, sv.mean2, sv.rstd2, dy, dx2, gm1, dg, db, pw, pb, M, C, d.ln_groups, d.drop_p, d.key_proj[0],
                                                d.key_proj[1], d.rowscale1, N_tok, seed, s));
         } else {
@@ -347,7 +366,23 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         void* pw = lnw ? A.take_bytes(pb) : nullptr;
         float* dg = want_w ? G.n1_g : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
         float* db = want_w ? G.n1_b : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
-        BLK_RUN(mdvit_layernorm_bwd(dcur1, sv.x1, d.n1_g, sv.mean1, sv.rstd1, dx2, dx1, dg, db, pw, pb, M, C, d.ln_groups, s));
+        if (defer) {
+            void* pws = S.take_bytes(pb);
+            int nb = 0;
+            BLK_RUN(mdvit_layernorm_bwd_parts(dcur1, sv.x1, d.n1_g, sv.mean1, sv.rstd1, dx2, dx1, nullptr, pws, pb, M, C, d.ln_groups, 0.f, 0, 0, nullptr, 1, nullptr, s, &nb));
+            late[n_late++] = Late{(const float*)pws, d.ln_groups, nb, C, dg, C, db};
+        } else {
+            BLK_RUN(mdvit_layernorm_bwd(dcur1, sv.x1, d.n1_g, sv.mean1, sv.rstd1, dx2, dx1, dg, db, pw, pb, M, C, d.ln_groups, s));
+        }
+    }
+    if (n_late > 0 && !A.dry) {          // one fork for the block's deferred second stages: they ACCUMULATE into the LayerNorm / bias buckets
+        const int rcf = fork_side(d, st, side);
+        if (rcf != MDVIT_OK) return rcf;
+        for (int i = 0; i < n_late; ++i) {
+            const Late& L = late[i];
+            const int rc = mdvit_reduce_partials_batched2_acc(L.part, L.batches, L.nblk, L.n0, L.out0, L.n1, L.out1, 1, side);
+            if (rc != MDVIT_OK) return rc;
+        }
     }
     // ---- ConvPosEnc -----------------------------------------------------------------------------------------------------------------
     if (dx) BLK_RUN(mdvit_dwconv3x3_bwd(dx1, x, d.cpe_w, dx, nullptr, nullptr, nullptr, 0, B, H, W, C, 1, 1, 0, s));

@@ -62,6 +62,13 @@ int mdvit_reduce_partials(const float* part, int nblk, long stride, int n0, floa
 int mdvit_reduce_partials_batched(const float* part, int batches, int nblk, int n, float* out, hipStream_t stream);
 // batched with two outputs per batch: out0 [batch][n0], out1 [batch][n1]; partial rows are [n0 | n1] wide
 int mdvit_reduce_partials_batched2(const float* part, int batches, int nblk, int n0, float* out0, int n1, float* out1, hipStream_t stream);
+int mdvit_reduce_partials_batched2_acc(const float* part, int batches, int nblk, int n0, float* out0, int n1, float* out1, int accumulate, hipStream_t stream);
+// first stages alone (norm.hip): the partial rows stay in `ws`, *nblk of them per batch; the caller runs the second stage on a stream of its choice
+int mdvit_layernorm_bwd_parts(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* add, float* dx,
+                              float* dx_masked, void* ws, size_t ws_bytes, int M, int C, int groups, float drop_p, uint32_t key0, uint32_t key1,
+                              const float* rowscale, int rows_per_scale, const uint32_t* seed, hipStream_t stream, int* nblk);
+int mdvit_colsum_parts(const float* A, long lda, float* masked, void* ws, size_t ws_bytes, int M, int N, float drop_p, uint32_t key0, uint32_t key1,
+                       const float* rowscale, int rows_per_scale, const uint32_t* seed, hipStream_t stream, int* nblk);
 constexpr int MDVIT_MAX_PARTIAL_ROWS = 2048;        // every partial-row reduction launches at most this many workgroups
 #define MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, n, what)                                                              \
     MDVIT_CHECK_ARG((ws) != nullptr && (ws_bytes) >= sizeof(float) * (size_t)(nblk) * (size_t)(n), MDVIT_E_WORKSPACE,    \

@@ -748,7 +748,7 @@ extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const flo
 
 static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream);
+                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream, int* defer_nblk = nullptr);
 
 // dgamma / dbeta: [groups, C] each
 extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
@@ -772,9 +772,26 @@ extern "C" int mdvit_layernorm_bwd_masked(const float* dy, const float* x, const
     return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
 }
 
+// The LayerNorm backward WITHOUT its second stage: the partial rows [groups][*nblk][dgamma | dbeta] stay in `ws`; the caller adds them up
+// (mdvit_reduce_partials_batched2_acc), on any stream ordered after this one -- block.hip does it on the weight-gradient stream.
+int mdvit_layernorm_bwd_parts(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* add, float* dx,
+                              float* dx_masked, void* ws, size_t ws_bytes, int M, int C, int groups, float drop_p, uint32_t key0, uint32_t key1,
+                              const float* rowscale, int rows_per_scale, const uint32_t* seed, hipStream_t stream, int* nblk) {
+    MDVIT_CHECK_ARG(C == 64 || C == 128 || C == 320 || C == 512, MDVIT_E_SHAPE, "layernorm_bwd_parts: C=%d not built (64/128/320/512)", C);
+    MDVIT_CHECK_ARG(nblk != nullptr && ws != nullptr, MDVIT_E_SHAPE, "layernorm_bwd_parts: null argument");
+    LnMasked mk; memset(&mk, 0, sizeof(mk));
+    if (dx_masked) {
+        MDVIT_CHECK_ARG((long)M * C < (1L << 32), MDVIT_E_SHAPE, "layernorm_bwd_parts: dropout index space exceeds 2^32");
+        mk.out = dx_masked; mk.drop_p = drop_p; mk.k0 = key0; mk.k1 = key1; mk.thresh = (uint32_t)((double)drop_p * 4294967296.0);
+        mk.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; mk.rowscale = rowscale; mk.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; mk.seed = seed;
+    }
+    float dummy;
+    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, &dummy, &dummy, ws, ws_bytes, M, C, groups, mk, stream, nblk);
+}
+
 static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream) {
+                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream, int* defer_nblk) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
     MDVIT_CHECK_ARG(groups > 0 && groups <= 64 && M % groups == 0, MDVIT_E_SHAPE, "layernorm_bwd: M=%d is not a multiple of groups=%d", M, groups);
@@ -799,6 +816,7 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamm
     }
     MDVIT_LAUNCH_CHECK();
     if (!want_params) return MDVIT_OK;
+    if (defer_nblk) { *defer_nblk = nblk; return MDVIT_OK; }                                  // the caller runs the second stage
     return mdvit_reduce_partials_batched2(part, groups, nblk, C, dgamma, C, dbeta, s);      // fixed-order sums of the per-workgroup rows
 }
 
@@ -924,9 +942,25 @@ extern "C" int mdvit_bn_rowdot_bwd(const float* g, const float* y, const float* 
     return MDVIT_OK;
 }
 
+static int colsum_impl(const float* A, int64_t lda, float* out, float* masked, void* ws, size_t ws_bytes, int32_t M, int32_t N, float drop_p,
+                       uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, int32_t accumulate, const uint32_t* seed, void* stream, int* defer_nblk);
+
+// column sums WITHOUT the second stage: the partial rows [*nblk][N] stay in `ws` (see mdvit_layernorm_bwd_parts)
+int mdvit_colsum_parts(const float* A, long lda, float* masked, void* ws, size_t ws_bytes, int M, int N, float drop_p, uint32_t key0, uint32_t key1,
+                       const float* rowscale, int rows_per_scale, const uint32_t* seed, hipStream_t stream, int* nblk) {
+    float dummy;
+    return colsum_impl(A, lda, &dummy, masked, ws, ws_bytes, M, N, drop_p, key0, key1, rowscale, rows_per_scale, 0, seed, stream, nblk);
+}
+
 extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* masked, void* ws, size_t ws_bytes, int32_t M, int32_t N, float drop_p,
                                 uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, int32_t accumulate,
                                 const uint32_t* seed, void* stream) {
+    return colsum_impl(A, lda, out, masked, ws, ws_bytes, M, N, drop_p, key0, key1, rowscale, rows_per_scale, accumulate, seed, stream, nullptr);
+}
+
+static int colsum_impl(const float* A, int64_t lda, float* out, float* masked, void* ws, size_t ws_bytes, int32_t M, int32_t N, float drop_p,
+                       uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, int32_t accumulate, const uint32_t* seed, void* stream,
+                       int* defer_nblk) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(M > 0 && N > 0 && N % 4 == 0 && N <= 8192 && lda % 4 == 0, MDVIT_E_SHAPE, "colsum: need N %% 4 == 0 (M=%d N=%d)", M, N);
     MDVIT_CHECK_ARG(out || masked, MDVIT_E_SHAPE, "colsum: nothing to produce (out and masked are both NULL)");
@@ -940,6 +974,7 @@ extern "C" int mdvit_colsum_f32(const float* A, int64_t lda, float* out, float* 
     a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     hipLaunchKernelGGL((chan_reduce_kernel<2>), dim3(nblk), dim3(256), sizeof(float) * (2 * N + 256 * 4), s, a);
     MDVIT_LAUNCH_CHECK();
+    if (defer_nblk) { *defer_nblk = nblk; return MDVIT_OK; }
     return out ? mdvit_reduce_partials((const float*)ws, nblk, (long)N, N, out, 0, nullptr, accumulate, s) : MDVIT_OK;
 }
 

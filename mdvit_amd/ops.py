@@ -224,7 +224,8 @@ def peer_stream(i: int, n_images: int = 0):
         # (the aux sweep's) then SHARES the main stream's queue and the whole data-gradient-only sweep runs behind the full sweep instead of next
         # to it (tools/sweep_timeline.py: aux sweep runnable at 28.5 ms instead of 10.4; step 40.4 ms with two peer streams, 38.0 with one, 37.3
         # without -- 396 -> 429 images/s).  Letting the peer heads borrow the two streams that idle during the forward keeps four queues but puts the
-        # full sweep's peer-head backward in front of the aux sweep on its stream: 40.3 ms.  So: no peer streams next to the two-stream sweeps.
+        # full sweep's peer-head backward in front of the aux sweep on its stream: 40.3 ms (all four heads on the aux stream: 41.7 ms; all four on the weight-gradient stream: 37.3 against 36.6 without) -- whenever the aux
+        # stream carries anything of the full sweep, the aux sweep ends up behind it.  So: no peer streams next to the two-stream sweeps.
         return None
     i %= _peer_stream_count
     while len(_peer_streams) <= i:
@@ -2051,7 +2052,9 @@ def domain_adapter(label, W1, b1, W2, b2, heads):
 # operator calls.  The host was the limit of the bs=4 step (30-38 ms of enqueue work against 31 ms of main-stream kernel time).
 _block_entry = os.environ.get("MDVIT_BLOCK_ENTRY", "1") != "0"
 _BLOCK_SINKABLE = (0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 20, 21, 22, 23)        # indices into _lib.BLOCK_PARAMS: cpe, qkv, crpe windows, proj, fc1, fc2
-_BLOCK_FRESH = (2, 3, 12, 13, 14, 15, 18, 19)                                      # LayerNorm and adapter gradients: always handed to autograd
+_BLOCK_FRESH = (2, 3, 12, 13, 14, 15, 18, 19)                                      # LayerNorm and adapter gradients: handed to autograd ...
+_BLOCK_LN = (2, 3, 18, 19)                                                         # ... unless the LayerNorm parameters have bucket sinks too (ln_accumulate)
+_block_ln_sinks = os.environ.get("MDVIT_BLOCK_LN_SINKS", "1") != "0"
 _blk_events = None
 
 
@@ -2175,7 +2178,9 @@ class _SerialBlock(torch.autograd.Function):
         if want_w:
             sinks = [_sink_of(params[i]) if params[i] is not None else None for i in _BLOCK_SINKABLE]
             acc = _side_stream is not None and all((s is not None) or (params[i] is None) for s, i in zip(sinks, _BLOCK_SINKABLE))
-        fresh_idx = [i for i in _BLOCK_FRESH if params[i] is not None and (want_w or 12 <= i <= 15)]
+        ln_sinks = [_sink_of(params[i]) for i in _BLOCK_LN] if (acc and _block_ln_sinks and d.C in (64, 128, 320, 512)) else None
+        ln_acc = ln_sinks is not None and all(s_ is not None for s_ in ln_sinks)
+        fresh_idx = [i for i in _BLOCK_FRESH if params[i] is not None and (want_w or 12 <= i <= 15) and not (ln_acc and i in _BLOCK_LN)]
         if want_w and not acc:
             fresh_idx = sorted(fresh_idx + [i for i in _BLOCK_SINKABLE if params[i] is not None])
         bufs = _flat_like(*[params[i] for i in fresh_idx]) if fresh_idx else []
@@ -2187,6 +2192,12 @@ class _SerialBlock(torch.autograd.Function):
                 if s_ is not None:
                     setattr(G, _lib.BLOCK_PARAMS[i], _p(s_))
         G.accumulate = int(acc)
+        if ln_acc:
+            # the LayerNorm gradients (and the fc2 bias sums) ADD into their buckets too: their second-stage reductions leave the data-gradient chain
+            # and run on the weight-gradient stream
+            for s_, i in zip(ln_sinks, _BLOCK_LN):
+                setattr(G, _lib.BLOCK_PARAMS[i], _p(s_))
+            G.ln_accumulate = 1
         stop_here = _dgrad_only and aux_first and label is not None
         dx = _empty_like(x) if (ctx.needs_input_grad[0] and not stop_here) else None
         side = _side_stream if (acc and want_w) else None
