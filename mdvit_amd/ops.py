@@ -233,6 +233,22 @@ def peer_stream(i: int, n_images: int = 0):
     return _peer_streams[i]
 
 
+_branch_stream_obj = None
+_use_branch_stream = os.environ.get("MDVIT_BRANCH_STREAM", "1") != "0"
+
+
+def branch_stream():
+    """ONE extra stream for a model with two independent trunks (TransFuse: the DeiT branch next to the ResNet branch, forward and -- autograd runs a
+    node's backward on its forward's stream -- backward).  With the main and the weight-gradient stream that is three of the four hardware queues.
+    None while a HIP graph is captured or when switched off (MDVIT_BRANCH_STREAM=0)."""
+    global _branch_stream_obj
+    if not _use_branch_stream or torch.cuda.is_current_stream_capturing():
+        return None
+    if _branch_stream_obj is None:
+        _branch_stream_obj = torch.cuda.Stream()
+    return _branch_stream_obj
+
+
 _side_keepalive = []     # tensors the side stream still reads; holding a reference also stops autograd from
                          # accumulating into them IN PLACE on the main stream (it only does so when it is the sole owner)
 _side_blocks = []        # (event recorded on the side stream after a block's launches, number of keep-alive entries up to there)
