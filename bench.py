@@ -212,6 +212,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # Data-parallel ranks: RCCL's communicator brings streams of its own.  With the default four hardware queues they share queues with the
+        # step's three streams and one RCCL kernel in flight stalls the stream that shares its queue (tools/probe/rccl_timeline_probe.py, one rank
+        # with the collectives forced: 42.0 ms per step at 4 queues, 37.6 at 8 -- and the step's own streams bind their queues FIRST, see
+        # ops.reserve_streams below).  Must be in the environment before the first HIP call of the process.  (Single-GPU runs keep the default:
+        # without RCCL, 8 queues are no faster and more streams than queues is what cost 8 % -- DESIGN.md section 4.)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` typed as is: start one fresh process per GPU (torch.distributed.run, rendezvous on
         # 127.0.0.1) BEFORE anything in this process touches the GPU, relay rank 0's JSON line, exit with the job's code.
@@ -230,12 +237,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
     import mdvit_amd
     from mdvit_amd import ops
+    if world > 1:
+        # the step's own streams bind their hardware queues BEFORE RCCL's communicator brings its streams (four queues: see ops.reserve_streams)
+        if not args.no_side_stream:
+            ops.reserve_streams(side=True, sweep=args.model in ("mdvit", "mdvit_dsn"), branch=args.model == "transfuse")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
     from mdvit_amd.parallel import GradAccumulator, broadcast_parameters
     from mdvit_amd.synthetic import make_step_batches
     from mdvit_amd.train import base_train_step, mdvit_train_step
