@@ -28,8 +28,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=5)      # (the allocator, the derived-weight caches and the GEMM planner settle over the first 3-4 steps)
     ap.add_argument("--batch", type=int, default=4, help="images per domain per GPU (BASELINE configs[1]: 4)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", choices=["mdvit", "mdvit_dsn", "base", "transfuse"], default="mdvit",
