@@ -2368,8 +2368,9 @@ def set_sweep_stream(stream):
 
 _sweep_stream_obj = None
 _ones = {}
-# Dispatch priority of the data-gradient-only sweep's stream (torch: 0 normal, -1 high).  Measured: high priority is a LOSS (the step goes from
-# 40.7 to 51.8 ms: the aux sweep then starves the main stream's forward of the next step and the full sweep).
+# Dispatch priority of the data-gradient-only sweep's stream (torch: 0 normal, -1 high).  Measured with every stream on a hardware queue of its own
+# (tools/probe/main_priority_probe.py): priorities move the step by < 1 % either way (aux high 37.1-37.2 ms, main high 36.7-36.9, both normal 37.3-38.0
+# on one box).  (With FIVE streams on four queues a high-priority aux stream took the step from 40.7 to 51.8 ms.)
 _aux_priority = int(os.environ.get("MDVIT_AUX_PRIORITY", "0"))
 
 
