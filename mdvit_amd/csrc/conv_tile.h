@@ -286,7 +286,11 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
     __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
     __shared__ __attribute__((aligned(16))) float sg[CT_TH * CT_TW * CT_CL];
     const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;          // rl = window row i (threads with rl >= WIN only help loading)
+    const int cl = threadIdx.x & 31, rl8 = threadIdx.x >> 5;
+    // thread <-> (channel, window row i [, half of the tile's rows]): WIN = 3 would leave five of the eight row lanes idle, so there two lanes
+    // share a window row, each over four of the tile's eight rows, and are added through LDS at the end; lanes past WIN * HS only help loading
+    constexpr int HS = WIN == 3 ? 2 : 1, RPH = CT_TH / HS;
+    const int rl = HS == 2 ? (rl8 < 6 ? rl8 % 3 : WIN) : rl8, half = HS == 2 ? rl8 / 3 : 0;
     const long img = (long)b * H * W;
     const bool chan_ok = c0 + cl < ncls;
     float acc[WIN];
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
         __syncthreads();
         if (rl < WIN && chan_ok) {
 #pragma unroll 2
-            for (int h = 0; h < CT_TH; ++h) {
+            for (int h = half * RPH; h < (half + 1) * RPH; ++h) {
                 float row[LW], gr[CT_TW];
 #pragma unroll
                 for (int t = 0; t < LW; ++t) row[t] = sx[((h + rl) * LW + t) * CT_CL + cl];
@@ -323,9 +327,23 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
         }
         __syncthreads();
     }
+    if (HS == 2) {               // the upper row half's sums join the lower half's (sx is free: the tile loop ended with a barrier)
+        float* s_h = sx;         // [3 window rows][WIN + 1][32 channels]
+        if (rl < WIN && half == 1) {
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) s_h[(rl * (WIN + 1) + j) * CT_CL + cl] = acc[j];
+            s_h[(rl * (WIN + 1) + WIN) * CT_CL + cl] = accb;
+        }
+        __syncthreads();
+        if (rl < WIN && half == 0) {
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) acc[j] += s_h[(rl * (WIN + 1) + j) * CT_CL + cl];
+            accb += s_h[(rl * (WIN + 1) + WIN) * CT_CL + cl];
+        }
+    }
     constexpr int ROW = CT_CL * (WIN * WIN + 1);
     float* prow = part + ((long)blockIdx.y * gridDim.z * gridDim.x + (long)blockIdx.z * gridDim.x + blockIdx.x) * ROW + cl * (WIN * WIN + 1);
-    if (rl < WIN) {              // channels past ncls hold zeros
+    if (rl < WIN && half == 0) { // channels past ncls hold zeros
 #pragma unroll
         for (int j = 0; j < WIN; ++j) prow[rl * WIN + j] = acc[j];
         if (rl == 0) prow[WIN * WIN] = accb;
