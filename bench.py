@@ -212,13 +212,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        # Data-parallel ranks: RCCL's communicator brings streams of its own.  With the default four hardware queues they share queues with the
-        # step's three streams and one RCCL kernel in flight stalls the stream that shares its queue (tools/probe/rccl_timeline_probe.py, one rank
-        # with the collectives forced: 42.0 ms per step at 4 queues, 37.6 at 8 -- and the step's own streams bind their queues FIRST, see
-        # ops.reserve_streams below).  Must be in the environment before the first HIP call of the process.  (Single-GPU runs keep the default:
-        # without RCCL, 8 queues are no faster and more streams than queues is what cost 8 % -- DESIGN.md section 4.)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` typed as is: start one fresh process per GPU (torch.distributed.run, rendezvous on
         # 127.0.0.1) BEFORE anything in this process touches the GPU, relay rank 0's JSON line, exit with the job's code.

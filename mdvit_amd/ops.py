@@ -175,11 +175,18 @@ def set_dgrad_only(flag: bool):
 # they use a fraction of the 256 CUs, so they are issued on a side HIP stream and overlap with the dgrad chain on
 # the main stream.  Whoever consumes the gradients calls join_side_stream() first (mdvit_amd.train does).
 _side_stream = None
+_side_stream_obj = None
 
 
 def enable_side_stream(flag: bool = True):
-    global _side_stream
-    _side_stream = torch.cuda.Stream() if flag else None
+    """the weight-gradient stream; enabling twice keeps the stream (reserve_streams may have bound its hardware queue already)"""
+    global _side_stream, _side_stream_obj
+    if not flag:
+        _side_stream = None
+        return
+    if _side_stream_obj is None:
+        _side_stream_obj = torch.cuda.Stream()          # ONE stream object for the life of the process: every new stream wants a hardware queue
+    _side_stream = _side_stream_obj
 
 
 # ---- gradient sinks: leaf parameter -> persistent accumulation buffer ---------------------------------------
