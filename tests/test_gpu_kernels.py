@@ -896,9 +896,11 @@ def _attn_ref(qkv, crpe, a, H, W, heads):
     return y.permute(0, 2, 1, 3).reshape(B, N, C)
 
 
-@pytest.mark.parametrize("B,H,W,C,use_a", [(2, 16, 16, 64, True), (1, 9, 14, 128, True), (2, 8, 8, 320, True), (2, 4, 4, 512, True), (2, 12, 12, 64, False), (1, 40, 40, 64, True)])
+@pytest.mark.parametrize("B,H,W,C,use_a", [(2, 16, 16, 64, True), (1, 9, 14, 128, True), (2, 8, 8, 320, True), (2, 4, 4, 512, True), (2, 12, 12, 64, False), (1, 40, 40, 64, True),
+                                              (1, 64, 64, 64, True), (1, 70, 66, 128, False)])
 def test_factor_att_core(B, H, W, C, use_a):
-    """attention core + domain adapter node: forward, dqkv, crpe gradients and the adapter's parameter gradients"""
+    """attention core + domain adapter node: forward, dqkv, crpe gradients and the adapter's parameter gradients
+    (the last two shapes have >= 4096 tokens per image: the packed two-row stencil tiles of conv_tile.h, the second with ragged tile edges)"""
     from mdvit_amd import ops
     heads, Ch, N, hid = 8, C // 8, H * W, max(C // 2, 4)
     qkv = rnd(B, N, 3 * C, seed=130, scale=1.5)
