@@ -938,6 +938,58 @@ def test_aux_sweep_on_its_own_stream_equals_single_stream_step():
             assert d <= 1e-5, f"{n}: two-stream vs single-stream gradients differ by {d:.2e}"
 
 
+def test_aux_sweep_runs_next_to_the_full_sweep_not_behind_it():
+    """The GPU has four hardware queues.  With a fifth stream in the process the aux sweep's stream shares the main stream's queue and the whole
+    data-gradient-only sweep runs BEHIND the full sweep (it cost 8 % of the step for half a round).  Guard: in the bench step the aux sweep's stream
+    becomes runnable right after the forward -- long before the full sweep's last kernel.  (Skipped when the host is the limit of the step on
+    this box: the aux sweep is then enqueued late whatever the queues do.)"""
+    import time
+    import mdvit_amd
+    from mdvit_amd import ops, train
+    from mdvit_amd.optim import FusedAdamW
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.synthetic import make_step_batches
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("timing property of the default (bf16x3) step")
+    torch.manual_seed(0)
+    model = mdvit_amd.MDViT(img_size=512, drop_rate=0.1, drop_path_rate=0.1, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4,
+                            decoder_name="MLPFM").to(dev()).train()
+    ops.enable_side_stream(True)
+    accum = GradAccumulator(model.parameters(), late=[p for n, p in model.named_parameters() if "domain_layer" in n])
+    accum.attach_sinks()
+    opt = FusedAdamW(accum, lr=1e-4, weight_decay=0.05)
+    pool = [make_step_batches(4, 512, rank=0, step=s_, device=dev()) for s_ in range(2)]
+    try:
+        def step(i, evs=None):
+            return train.mdvit_train_step(model, pool[i % 2], optimizer=opt, accumulator=accum, merged_sweeps=True, fuse_domains=4, phase_events=evs)
+        for i in range(4):
+            step(i)
+        torch.cuda.synchronize()
+        best = None
+        for rep in range(3):
+            step(0)
+            train._timeline = []
+            evs = []
+            h0 = time.perf_counter()
+            step(1, evs)
+            host_ms = 1e3 * (time.perf_counter() - h0)
+            tl, train._timeline = train._timeline, None
+            torch.cuda.synchronize()
+            e0 = evs[0][1]
+            t = {tag: e0.elapsed_time(e) for tag, e, _ in tl}
+            t.update({tag: e0.elapsed_time(e) for tag, e in evs[1:]})
+            best = (host_ms, t)
+    finally:
+        train._timeline = None
+        ops.set_grad_sinks(None); ops.enable_side_stream(False)
+    host_ms, t = best
+    fwd, runnable, main_last, opt_t = t["fwd"], t["aux sweep: runnable (its stream)"], t["sweep on main: last kernel"], t["opt"]
+    if host_ms > 0.8 * opt_t:
+        pytest.skip(f"host-bound on this box (enqueue {host_ms:.1f} ms of a {opt_t:.1f} ms step)")
+    assert runnable < fwd + 0.25 * (main_last - fwd), \
+        f"the aux sweep's stream became runnable at {runnable:.1f} ms: forward ends at {fwd:.1f}, the full sweep at {main_last:.1f} -- a stream too many?"
+
+
 def test_peer_heads_on_their_own_streams_equal_heads_on_the_main_stream():
     """MDVIT_PEER_STREAMS=1 (opt-in since the aux sweep has its own stream): the four peer heads of a domain-batched forward, and
     their backward chains, on a stream each == the default (heads on the main stream) -- identical losses, gradients to the last bits;
