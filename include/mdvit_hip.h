@@ -225,6 +225,12 @@ int mdvit_mlp_rc_dgrad(const float* gm, const float* x, const void* W1p, const f
 int mdvit_linear_rc(const float* x, int64_t lda, const void* Wp, int64_t wplane, const float* bias, float* y, int64_t ldc, int32_t M, int32_t N, int32_t K,
                     float drop_p, uint32_t key0, uint32_t key1, const float* rowscale, int32_t rows_per_scale, const float* residual, int64_t ldr,
                     const uint32_t* drop_seed, void* stream);
+/* mdvit_linear_rc with the LayerNorm in front of it fused into its prologue (LN1 -> qkv of SerialBlock_adapt, mdvit.py:286-288,352): x is the
+ * LayerNorm's INPUT [M, K] (contiguous, K = 64 / 128), gamma / beta [groups, K] (group = row / (M / groups)).  Writes mean / rstd [M] and the normalised rows
+ * ln_out [M, K] (the operand of the qkv weight-gradient GEMM) and y = ln_out Wp^T + bias -- mdvit_layernorm_fwd's arithmetic sum for sum (equal results),
+ * one launch and one pass over x less. */
+int mdvit_linear_rc_ln(const float* x, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+                       const void* Wp, int64_t wplane, const float* bias, float* y, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream);
 /* The MLP forward on 16-token waves (16x16x32 MFMA tiles), built for C = 64 and C = 128: fc1 + GELU + Dropout + fc2 + Dropout + DropPath + residual
  * (mpvit.py:71-78 inside mdvit.py:357-360) in ONE kernel with the hidden chunk chained in registers; h != NULL also writes
  * h = drop1(gelu(x W1^T + b1)) [M, hidden] once for the fc2 weight-gradient GEMM (C = 128, where recomputing it there costs more than it saves). */

@@ -5,6 +5,7 @@
 // was bound by the enqueue rate, and the 16 blocks are half of its launches.
 // The kernels and their order are exactly those of the operator-level path (mdvit_amd/ops.py: dwconv3x3 + layer_norm + linear + factor_att +
 // linear + layer_norm + mlp_residual and their backward), so both paths give bit-identical results (tests/test_gpu_block.py).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -118,13 +119,18 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
     layout_saved(d, SV, sv);
     // x1 = x + dwconv3x3(x) + bias            (ConvPosEnc, mpvit.py:239-248)
     BLK_RUN(mdvit_dwconv3x3_fwd(x, d.cpe_w, d.cpe_b, sv.x1, B, H, W, C, 1, 1, s));
-    // cur1 = LN1(x1)
-    BLK_RUN(mdvit_layernorm_fwd(sv.x1, d.n1_g, d.n1_b, sv.cur1, sv.mean1, sv.rstd1, M, C, d.ln_groups, d.eps, s));
-    // qkv = cur1 Wqkv^T + b                    (mdvit.py:288)
+    // cur1 = LN1(x1);  qkv = cur1 Wqkv^T + b                    (mdvit.py:286-288)
     const bool lin_rc = d.precision == 1 && (C == 64 || C == 128) && d.qkv_p && d.proj_p && M >= 1024;       // the streaming short-K Linear (mlp_rc.hip)
-    if (lin_rc) {
+    static const bool ln_prologue = [] { const char* e = getenv("MDVIT_LN_PROLOGUE"); return !(e && e[0] == '0'); }();
+    if (lin_rc && ln_prologue) {
+        // LN1 in the qkv kernel's prologue: the rows are normalised in the registers they are multiplied from; cur1 is still written (the qkv
+        // weight-gradient GEMM reads it), x1 is read once instead of twice and one launch is gone
+        BLK_RUN(mdvit_linear_rc_ln(sv.x1, d.n1_g, d.n1_b, d.ln_groups, d.eps, sv.mean1, sv.rstd1, sv.cur1, d.qkv_p, 3L * C * C, d.qkv_b, sv.qkv, 3 * C, M, 3 * C, C, s));
+    } else if (lin_rc) {
+        BLK_RUN(mdvit_layernorm_fwd(sv.x1, d.n1_g, d.n1_b, sv.cur1, sv.mean1, sv.rstd1, M, C, d.ln_groups, d.eps, s));
         BLK_RUN(mdvit_linear_rc(sv.cur1, C, d.qkv_p, 3L * C * C, d.qkv_b, sv.qkv, 3 * C, M, 3 * C, C, 0.f, 0, 0, nullptr, 1, nullptr, 0, nullptr, s));
     } else {
+        BLK_RUN(mdvit_layernorm_fwd(sv.x1, d.n1_g, d.n1_b, sv.cur1, sv.mean1, sv.rstd1, M, C, d.ln_groups, d.eps, s));
         MdvitGemmDesc g;
         gemm_init(g, d);
         g.A = sv.cur1; g.B = d.qkv_w; g.C = sv.qkv; g.M = M; g.N = 3 * C; g.K = C; g.lda = C; g.ldb = C; g.ldc = 3 * C; g.bias = d.qkv_b;

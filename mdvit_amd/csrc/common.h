@@ -108,6 +108,24 @@ __device__ __forceinline__ float4 mdvit_drop_scale4(uint32_t k0, uint32_t k1, ui
                        __builtin_rotateright32(h, 24) >= thresh ? inv_keep : 0.0f);
 }
 
+// LayerNorm pieces with EXPLICIT rounding (no fma contraction left to the compiler): two kernels that normalise the same row -- ln_fwd16_kernel and
+// the LayerNorm prologue of lin_rc_kernel -- must agree bit for bit whatever surrounds the expression
+__device__ __forceinline__ float mdvit_ln_sq4(const float4 v) {
+#pragma clang fp contract(off)
+    // every fused multiply-add is written out (HIP's __fmul_rn / __fadd_rn are plain operators: the compiler contracts them as it likes)
+    const float yy = v.y * v.y, ww = v.w * v.w;
+    return __builtin_fmaf(v.x, v.x, yy) + __builtin_fmaf(v.z, v.z, ww);
+}
+__device__ __forceinline__ float4 mdvit_ln_affine4(const float4 v, float rs, const float4 g, const float4 b) {
+#pragma clang fp contract(off)
+    const float tx = v.x * rs, ty = v.y * rs, tz = v.z * rs, tw = v.w * rs;
+    return make_float4(__builtin_fmaf(tx, g.x, b.x), __builtin_fmaf(ty, g.y, b.y), __builtin_fmaf(tz, g.z, b.z), __builtin_fmaf(tw, g.w, b.w));
+}
+// (1 / sqrt as ONE v_rsq_f32, 1 ulp: `1.0f / sqrtf(x)` compiles to different instruction sequences in different translation units)
+__device__ __forceinline__ float mdvit_ln_rstd(float sumsq, float inv_c, float eps) { return __builtin_amdgcn_rsqf(__builtin_fmaf(sumsq, inv_c, eps)); }
+#define ln_sq4 mdvit_ln_sq4
+#define ln_affine4 mdvit_ln_affine4
+
 // ---- bf16 "planes": x = hi + lo with hi = RNE bf16(x), lo = RNE bf16(x - hi)  (|x - hi - lo| <= 2^-18 |x|) -------------------
 typedef __bf16 mdvit_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float mdvit_f32x2 __attribute__((ext_vector_type(2)));

@@ -1091,9 +1091,22 @@ struct LinArgs {
     const float* x; long lda; const uint16_t* Wp; long wplane; const float* bias; float* y; long ldc;
     const float* residual; long ldr; const float* rowscale; int rows_per_scale;
     int M, N; uint32_t k0, k1, thresh; float inv_keep; const uint32_t* seed;
+    // LN prologue (LNP): x is the LayerNorm's INPUT; the kernel normalises its 32 rows in registers, writes the statistics and the normalised rows
+    // (the weight-gradient GEMM's operand) and multiplies those
+    const float* ln_g; const float* ln_b; float* ln_mean; float* ln_rstd; float* ln_out; float ln_eps; int ln_rows_per_group;
 };
 
-template <int K, int NW, bool FULL, bool DROP>
+// sum over the 16 channel quads of a row in the order of norm.hip's sum16 (xor 8, 4, 2, 1 over the quad index): a lane of this kernel holds the quads
+// 4 kb + 2 lhi + {0, 1} -- the steps over bit 3 and bit 2 (kb) are in-lane, bit 1 (lhi) is the partner lane, bit 0 is in-lane.  q[kb][b]: per-quad
+// sums (C = 128: quads Q and Q + 16 of ln_fwd16's lane are kb and kb + 4 here, already added in ITS order by the caller).
+__device__ __forceinline__ float lin_sum16(const float (&q)[4][2]) {
+    const float p00 = q[0][0] + q[2][0], p01 = q[0][1] + q[2][1], p10 = q[1][0] + q[3][0], p11 = q[1][1] + q[3][1];     // xor 8
+    float r0 = p00 + p10, r1 = p01 + p11;                                                                             // xor 4
+    r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64);                                                        // xor 2
+    return r0 + r1;                                                                                                    // xor 1
+}
+
+template <int K, int NW, bool FULL, bool DROP, bool LNP = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4))) void lin_rc_kernel(LinArgs p) {
     constexpr int KB = K / 16;
     constexpr int RB = K * 2;                        // row bytes of a weight sub-tile [32 features][K]
@@ -1132,6 +1145,55 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4)))
         for (int kb = 0; kb < KB; ++kb) {
             a[kb] = *reinterpret_cast<const float4*>(px + 16 * kb);
             b[kb] = *reinterpret_cast<const float4*>(px + 16 * kb + 4);
+        }
+        if (LNP) {
+            // ln_fwd16_kernel's arithmetic, sum for sum (norm.hip): mean, then the centred squares, both through the same 16-quad tree; C = K
+            constexpr int VPL = K / 64;
+            const int grp = rowc / p.ln_rows_per_group;
+            const float* gg = p.ln_g + (long)grp * K + 8 * lhi;
+            const float* gb = p.ln_b + (long)grp * K + 8 * lhi;
+            float q[4][2];
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {          // (C = 128: quad Q + 16 of ln_fwd16's lane <-> kb + 4 here)
+                    const float4 va = a[kq + 4 * j], vb = b[kq + 4 * j];
+                    s0 += (va.x + va.y) + (va.z + va.w);
+                    s1 += (vb.x + vb.y) + (vb.z + vb.w);
+                }
+                q[kq][0] = s0; q[kq][1] = s1;
+            }
+            const float mu = lin_sum16(q) * (1.0f / K);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                a[kb].x -= mu; a[kb].y -= mu; a[kb].z -= mu; a[kb].w -= mu;
+                b[kb].x -= mu; b[kb].y -= mu; b[kb].z -= mu; b[kb].w -= mu;
+            }
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const float4 va = a[kq + 4 * j], vb = b[kq + 4 * j];
+                    s0 += mdvit_ln_sq4(va);
+                    s1 += mdvit_ln_sq4(vb);
+                }
+                q[kq][0] = s0; q[kq][1] = s1;
+            }
+            const float rs = mdvit_ln_rstd(lin_sum16(q), 1.0f / K, p.ln_eps);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const float4 ga = *reinterpret_cast<const float4*>(gg + 16 * kb), gb4 = *reinterpret_cast<const float4*>(gg + 16 * kb + 4);
+                const float4 ba = *reinterpret_cast<const float4*>(gb + 16 * kb), bb4 = *reinterpret_cast<const float4*>(gb + 16 * kb + 4);
+                a[kb] = mdvit_ln_affine4(a[kb], rs, ga, ba);
+                b[kb] = mdvit_ln_affine4(b[kb], rs, gb4, bb4);
+                if (row < p.M) {
+                    *reinterpret_cast<float4*>(p.ln_out + (long)row * K + 8 * lhi + 16 * kb) = a[kb];
+                    *reinterpret_cast<float4*>(p.ln_out + (long)row * K + 8 * lhi + 16 * kb + 4) = b[kb];
+                }
+            }
+            if (lhi == 0 && row < p.M) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
         }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
@@ -1305,6 +1367,35 @@ static int rc_wgrad_groups(int M) {
     int g = (ntiles + 3) / 4;                      // >= 4 tiles per group where the problem allows it
     g = ((g + 7) / 8) * 8;
     return g < 8 ? 8 : (g > 128 ? 128 : g);
+}
+
+/* mdvit_linear_rc with the LayerNorm in front of it fused into the prologue (LN1 -> qkv of SerialBlock_adapt, mdvit.py:286-288,352): x is the
+ * LayerNorm's input [M, K] (contiguous), gamma / beta [groups, K] (group = row / (M / groups)); the kernel writes mean / rstd [M] and the
+ * normalised rows ln_out [M, K] (the qkv weight-gradient GEMM's operand) and multiplies them -- mdvit_layernorm_fwd's arithmetic, sum for sum. */
+extern "C" int mdvit_linear_rc_ln(const float* x, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+                                  const void* Wp, int64_t wplane, const float* bias, float* y, int64_t ldc, int32_t M, int32_t N, int32_t K, void* stream) {
+    MDVIT_CHECK_ARG(K == 64 || K == 128, MDVIT_E_SHAPE, "linear_rc_ln: built for K = 64 / 128 (got %d)", K);
+    MDVIT_CHECK_ARG(M > 0 && N >= 32 && N % 32 == 0 && N <= 4096 && groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "linear_rc_ln: bad shape M=%d N=%d groups=%d", M, N, groups);
+    MDVIT_CHECK_ARG(x && gamma && beta && mean && rstd && ln_out && Wp && y && ldc >= N && ldc % 4 == 0, MDVIT_E_SHAPE, "linear_rc_ln: bad operands");
+    MDVIT_CHECK_ARG(aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(ln_out) && aligned16(Wp) && aligned16(y) && aligned16(bias), MDVIT_E_ALIGN,
+                    "linear_rc_ln: operands must be 16-byte aligned");
+    LinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.lda = K; a.Wp = (const uint16_t*)Wp; a.wplane = wplane; a.bias = bias; a.y = y; a.ldc = ldc; a.M = M; a.N = N; a.rows_per_scale = 1; a.inv_keep = 1.f;
+    a.ln_g = gamma; a.ln_b = beta; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_out = ln_out; a.ln_eps = eps; a.ln_rows_per_group = M / groups;
+    const int smem = 3 * 2 * (32 * K * 2) + N * 4;
+    hipStream_t s = (hipStream_t)stream;
+    const int nw = cdiv(M, 128) >= 512 ? 4 : 2;
+    const dim3 grid(cdiv(M, nw * 32)), block(nw * 64);
+    if (K == 64) {
+        if (nw == 4) hipLaunchKernelGGL((lin_rc_kernel<64, 4, false, false, true>), grid, block, smem, s, a);
+        else hipLaunchKernelGGL((lin_rc_kernel<64, 2, false, false, true>), grid, block, smem, s, a);
+    } else {
+        if (nw == 4) hipLaunchKernelGGL((lin_rc_kernel<128, 4, false, false, true>), grid, block, smem, s, a);
+        else hipLaunchKernelGGL((lin_rc_kernel<128, 2, false, false, true>), grid, block, smem, s, a);
+    }
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
 }
 
 /* The MLP forward on 16-token waves, built for C = 64 and C = 128 (mpvit.py:71-78 inside mdvit.py:357-360); h != NULL also writes

@@ -116,6 +116,7 @@ __device__ __forceinline__ float sum16(float v) {
     return v;
 }
 
+// (ln_sq4 / ln_affine4 of common.h: explicitly rounded, so that the LayerNorm prologue of mdvit_linear_rc_ln reproduces this kernel bit for bit)
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_fwd16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ y,
@@ -141,14 +142,12 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
-            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            q += ln_sq4(v[j]);
         }
-        const float rs = 1.0f / sqrtf(sum16(q) * (1.0f / C) + eps);
+        const float rs = mdvit_ln_rstd(sum16(q), 1.0f / C, eps);
         float* yr = y + row * C;
 #pragma unroll
-        for (int j = 0; j < VPL; ++j)
-            *reinterpret_cast<float4*>(yr + 4 * (sub + 16 * j)) =
-                make_float4(v[j].x * rs * ga[j].x + be[j].x, v[j].y * rs * ga[j].y + be[j].y, v[j].z * rs * ga[j].z + be[j].z, v[j].w * rs * ga[j].w + be[j].w);
+        for (int j = 0; j < VPL; ++j) *reinterpret_cast<float4*>(yr + 4 * (sub + 16 * j)) = ln_affine4(v[j], rs, ga[j], be[j]);
         if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
