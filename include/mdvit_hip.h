@@ -237,6 +237,14 @@ int mdvit_linear_rc_ln(const float* x, const float* gamma, const float* beta, in
 int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
                        int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
                        uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
+/* The MLP forward with the LayerNorm in front of it fused into its prologue (LN2 -> Mlp of SerialBlock_adapt, mdvit.py:356-360): x2 [M, C] is the LayerNorm's
+ * INPUT and the residual.  Writes mean / rstd [M], the normalised rows ln_out [M, C] (operand of the backward kernels) and y = x2 + rowscale * drop2(fc2(drop1(gelu(
+ * fc1(ln_out))))).  C = 64: no [tokens, hidden] tensor (h must be NULL); C = 128: h != NULL written as by mdvit_mlp_rc16_fwd.  mdvit_layernorm_fwd's arithmetic
+ * sum for sum: equal results, one launch and one pass over x2 less. */
+int mdvit_mlp_rc_fwd_ln(const float* x2, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+                        const void* W1p, const float* b1, const void* W2p, const float* b2, const float* rowscale, int32_t rows_per_scale, float* h, float* y,
+                        int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1,
+                        const uint32_t* drop_seed, void* stream);
 /* The same data gradient on 16-token waves (16x16x32 MFMA tiles), built for C = 64 and C = 128: the C = 128 stages' MLP backward data path
  * (mpvit.py:71-78 with hidden = 8 C, mdvit.py:357-360) in ONE kernel instead of the recomputing fc2 data-gradient GEMM + the fc1 data-gradient
  * GEMM.  du != NULL additionally writes the hidden-layer gradient [M, hidden] (operand of the two weight-gradient GEMMs of the full sweep);

@@ -158,9 +158,15 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
         const int rc = gemm_fwd(A, g, s);
         if (rc != MDVIT_OK) return rc;
     }
-    BLK_RUN(mdvit_layernorm_fwd(sv.x2, d.n2_g, d.n2_b, sv.cur2, sv.mean2, sv.rstd2, M, C, d.ln_groups, d.eps, s));
-    // y = x2 + droppath(drop(fc2(drop(gelu(fc1(cur2))))))                                             (mpvit.py:71-78, mdvit.py:357-360)
+    // cur2 = LN2(x2);  y = x2 + droppath(drop(fc2(drop(gelu(fc1(cur2))))))                           (mpvit.py:71-78, mdvit.py:356-360)
     const uint32_t* seed = d.drop_p > 0.f ? d.drop_seed : nullptr;
+    if (ln_prologue && (mode == MLP_RC || mlp_rc16(d)) && d.hidden % 64 == 0) {
+        // LN2 in the MLP kernel's prologue: the rows are normalised in the registers they are multiplied from (cur2 is still written: the backward kernels read it)
+        BLK_RUN(mdvit_mlp_rc_fwd_ln(sv.x2, d.n2_g, d.n2_b, d.ln_groups, d.eps, sv.mean2, sv.rstd2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, d.rowscale2, N_tok,
+                                    mode == MLP_RC ? nullptr : sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], d.key_fc2[0], d.key_fc2[1], seed, s));
+        return MDVIT_OK;
+    }
+    BLK_RUN(mdvit_layernorm_fwd(sv.x2, d.n2_g, d.n2_b, sv.cur2, sv.mean2, sv.rstd2, M, C, d.ln_groups, d.eps, s));
     if (mode == MLP_RC) {
         BLK_RUN(mdvit_mlp_rc_fwd(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1],
                                  d.key_fc2[0], d.key_fc2[1], seed, s));

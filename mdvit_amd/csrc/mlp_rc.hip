@@ -80,8 +80,15 @@ __device__ __forceinline__ rc_bf16x8 rc_natural_order(rc_u4 v) {
 }
 
 // the x / gm operand fragments of a wave's 32 tokens (rows past M re-read the last row: they only feed outputs that are never stored)
-template <int C>
-__device__ __forceinline__ void rc_load_rows(const float* __restrict__ src, int row, int M, int lhi, rc_bf16x8 (&hi)[C / 16], rc_bf16x8 (&lo)[C / 16]) {
+// LayerNorm prologue parameters: x is the LayerNorm's INPUT; the kernel normalises its rows in registers, writes the statistics and the normalised rows
+// (operands of the backward kernels) and multiplies those
+struct LnPro { const float* g; const float* b; float* mean; float* rstd; float* out; float eps; int rows_per_group; };
+template <int K>
+__device__ __forceinline__ void rc_ln_rows32(float4 (&a)[K / 16], float4 (&b)[K / 16], int row, int rowc, int M, int lhi, const LnPro ln);
+
+template <int C, bool LNP = false>
+__device__ __forceinline__ void rc_load_rows(const float* __restrict__ src, int row, int M, int lhi, rc_bf16x8 (&hi)[C / 16], rc_bf16x8 (&lo)[C / 16],
+                                             const LnPro* ln = nullptr) {
     const float* p = src + (long)min(row, M - 1) * C + 8 * lhi;
     float4 a[C / 16], b[C / 16];
 #pragma unroll
@@ -89,6 +96,7 @@ __device__ __forceinline__ void rc_load_rows(const float* __restrict__ src, int 
         a[kb] = *reinterpret_cast<const float4*>(p + 16 * kb);
         b[kb] = *reinterpret_cast<const float4*>(p + 16 * kb + 4);
     }
+    if constexpr (LNP) rc_ln_rows32<C>(a, b, row, min(row, M - 1), M, lhi, *ln);
 #pragma unroll
     for (int kb = 0; kb < C / 16; ++kb) {
         const float v[8] = {a[kb].x, a[kb].y, a[kb].z, a[kb].w, b[kb].x, b[kb].y, b[kb].z, b[kb].w};
@@ -123,6 +131,67 @@ __device__ __forceinline__ float rc_gelu_grad(float x) {
     return fmaf(x, pdf, cdf);
 }
 
+// sum over the 16 channel quads of a row in the order of norm.hip's sum16 (xor 8, 4, 2, 1 over the quad index): a lane of the 32-token layout holds the
+// quads 4 kq + 2 lhi + {0, 1} -- the steps over bit 3 and bit 2 (kq) are in-lane, bit 1 (lhi) is the partner lane, bit 0 is in-lane.  q[kq][b]: per-quad
+// sums (C = 128: quads Q and Q + 16 of ln_fwd16's lane are kb and kb + 4 here, already added in ITS order by the caller).
+__device__ __forceinline__ float lin_sum16(const float (&q)[4][2]) {
+    const float p00 = q[0][0] + q[2][0], p01 = q[0][1] + q[2][1], p10 = q[1][0] + q[3][0], p11 = q[1][1] + q[3][1];     // xor 8
+    float r0 = p00 + p10, r1 = p01 + p11;                                                                             // xor 4
+    r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64);                                                        // xor 2
+    return r0 + r1;                                                                                                    // xor 1
+}
+
+// In place on the raw rows of the 32-token layout (lane (token l & 31, lhi = l >> 5): a[kb] = channels 16 kb + 8 lhi .. +3, b[kb] = .. +4 .. +7):
+// ln_fwd16_kernel's arithmetic, sum for sum (norm.hip) -- mean, then the centred squares, both through the same 16-quad tree; C = K in {64, 128}
+template <int K>
+__device__ __forceinline__ void rc_ln_rows32(float4 (&a)[K / 16], float4 (&b)[K / 16], int row, int rowc, int M, int lhi, const LnPro ln) {
+    constexpr int KB = K / 16, VPL = K / 64;
+    const int grp = rowc / ln.rows_per_group;
+    const float* gg = ln.g + (long)grp * K + 8 * lhi;
+    const float* gb = ln.b + (long)grp * K + 8 * lhi;
+    float q[4][2];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {          // (C = 128: quad Q + 16 of ln_fwd16's lane <-> kb + 4 here)
+            const float4 va = a[kq + 4 * j], vb = b[kq + 4 * j];
+            s0 += (va.x + va.y) + (va.z + va.w);
+            s1 += (vb.x + vb.y) + (vb.z + vb.w);
+        }
+        q[kq][0] = s0; q[kq][1] = s1;
+    }
+    const float mu = lin_sum16(q) * (1.0f / K);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        a[kb].x -= mu; a[kb].y -= mu; a[kb].z -= mu; a[kb].w -= mu;
+        b[kb].x -= mu; b[kb].y -= mu; b[kb].z -= mu; b[kb].w -= mu;
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            s0 += mdvit_ln_sq4(a[kq + 4 * j]);
+            s1 += mdvit_ln_sq4(b[kq + 4 * j]);
+        }
+        q[kq][0] = s0; q[kq][1] = s1;
+    }
+    const float rs = mdvit_ln_rstd(lin_sum16(q), 1.0f / K, ln.eps);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const float4 ga = *reinterpret_cast<const float4*>(gg + 16 * kb), gb4 = *reinterpret_cast<const float4*>(gg + 16 * kb + 4);
+        const float4 ba = *reinterpret_cast<const float4*>(gb + 16 * kb), bb4 = *reinterpret_cast<const float4*>(gb + 16 * kb + 4);
+        a[kb] = mdvit_ln_affine4(a[kb], rs, ga, ba);
+        b[kb] = mdvit_ln_affine4(b[kb], rs, gb4, bb4);
+        if (row < M) {
+            *reinterpret_cast<float4*>(ln.out + (long)row * K + 8 * lhi + 16 * kb) = a[kb];
+            *reinterpret_cast<float4*>(ln.out + (long)row * K + 8 * lhi + 16 * kb + 4) = b[kb];
+        }
+    }
+    if (lhi == 0 && row < M) { ln.mean[row] = mu; ln.rstd[row] = rs; }
+}
+
 struct RcArgs {
     const float* x; const float* gm; const float* res; const float* rowscale; const float* b1; const float* b2;
     const uint16_t* W1p;    // planes of W1   [2][Hd][C]   rows = hidden, k = c         u = x W1^T
@@ -132,6 +201,7 @@ struct RcArgs {
     float* y; float* dx;
     float* du;              // rc16 dgrad: optional [tokens, hidden] copy of the hidden-layer gradient (the two weight-gradient GEMMs' operand)
     float* h;               // rc16 forward: optional [tokens, hidden] copy of drop1(gelu(u)) (the fc2 weight-gradient GEMM's operand)
+    LnPro ln;               // forward kernels with the LayerNorm prologue (LNP): x is the LayerNorm's input
     float* part;            // wgrad: per-workgroup partial sums
     int M, Hd, rows_per_scale;
     int drop; uint32_t k1a, k1b, k2a, k2b, thresh; float inv_keep;
@@ -333,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // per CU); the overlap of one wave's MFMAs with another's activation VALU comes from the third wave instead.  Group g = {W1 sub g, W2 sub g},
 // issued two steps ahead into a three-slot ring.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int C, int NW, bool DROP, int OCC = 3, bool STORE = false>
+template <int C, int NW, bool DROP, int OCC = 3, bool STORE = false, bool LNP = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc_fwd3_kernel(RcArgs p) {
     constexpr int KB = C / 16, CB = C / 32;
     constexpr int RB1 = C * 2;
@@ -372,7 +442,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     issue_group(1);
     for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     rc_bf16x8 xh[KB], xl[KB];
-    rc_load_rows<C>(p.x, row, p.M, lhi, xh, xl);
+    rc_load_rows<C, LNP>(p.x, row, p.M, lhi, xh, xl, &p.ln);
     rc_f32x16 yacc[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -844,8 +914,11 @@ __device__ __forceinline__ rc_bf16x8 rc16_frag_perm(const char* tile, int row, i
     } while (0)
 
 // x / gm operand fragments of a wave's 16 tokens: lane (token l & 15, g = l >> 4) holds c = 32 ks + 8 g ..+7 for every k step
-template <int C>
-__device__ __forceinline__ void rc16_load_rows(const float* __restrict__ src, int row, int M, int g, rc_bf16x8 (&hi)[C / 32], rc_bf16x8 (&lo)[C / 32]) {
+__device__ __forceinline__ void rc16_ln_rows128(float4 (&a)[4], float4 (&b)[4], int row, int rowc, int M, int g, const LnPro ln);
+
+template <int C, bool LNP = false>
+__device__ __forceinline__ void rc16_load_rows(const float* __restrict__ src, int row, int M, int g, rc_bf16x8 (&hi)[C / 32], rc_bf16x8 (&lo)[C / 32],
+                                               const LnPro* ln = nullptr) {
     const float* p = src + (long)min(row, M - 1) * C + 8 * g;
     float4 a[C / 32], b[C / 32];
 #pragma unroll
@@ -853,6 +926,7 @@ __device__ __forceinline__ void rc16_load_rows(const float* __restrict__ src, in
         a[ks] = *reinterpret_cast<const float4*>(p + 32 * ks);
         b[ks] = *reinterpret_cast<const float4*>(p + 32 * ks + 4);
     }
+    if constexpr (LNP && C == 128) rc16_ln_rows128(a, b, row, min(row, M - 1), M, g, *ln);
 #pragma unroll
     for (int ks = 0; ks < C / 32; ++ks) {
         const float v[8] = {a[ks].x, a[ks].y, a[ks].z, a[ks].w, b[ks].x, b[ks].y, b[ks].z, b[ks].w};
@@ -865,7 +939,64 @@ __device__ __forceinline__ void rc16_load_rows(const float* __restrict__ src, in
 
 // forward on the same tiles: y = res + rowscale * drop2( drop1(gelu(x W1^T + b1)) W2^T + b2 ), the hidden chunk chained in registers; STORE also
 // writes h = drop1(gelu(u)) [tokens, hidden] once (C = 128: the fc2 weight-gradient GEMM reads it; the forward itself never re-reads it)
-template <int C, int NW, int OCC, bool DROP, bool STORE>
+// The LayerNorm prologue in the 16-token layout, C = 128: lane (token l & 15, g = l >> 4) holds the channel quads 8 ks + 2 g + {0, 1} of the k steps ks = 0..3;
+// ln_fwd16's lane `sub` holds the quads sub and sub + 16, i.e. ks and ks + 2 here; its tree over sub = 8 ks' + 2 g + b: bit 3 (ks') in-lane, bit 2 (g bit 1)
+// lane ^ 32, bit 1 (g bit 0) lane ^ 16, bit 0 in-lane.
+__device__ __forceinline__ float rc16_sum16(const float (&q)[2][2]) {
+    float r0 = q[0][0] + q[1][0], r1 = q[0][1] + q[1][1];                          // xor 8
+    r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64);                     // xor 4
+    r0 += __shfl_xor(r0, 16, 64); r1 += __shfl_xor(r1, 16, 64);                     // xor 2
+    return r0 + r1;                                                                 // xor 1
+}
+__device__ __forceinline__ void rc16_ln_rows128(float4 (&a)[4], float4 (&b)[4], int row, int rowc, int M, int g, const LnPro ln) {
+    constexpr int K = 128;
+    const int grp = rowc / ln.rows_per_group;
+    const float* gg = ln.g + (long)grp * K + 8 * g;
+    const float* gb = ln.b + (long)grp * K + 8 * g;
+    float q[2][2];
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 va = a[kq + 2 * j], vb = b[kq + 2 * j];
+            s0 += (va.x + va.y) + (va.z + va.w);
+            s1 += (vb.x + vb.y) + (vb.z + vb.w);
+        }
+        q[kq][0] = s0; q[kq][1] = s1;
+    }
+    const float mu = rc16_sum16(q) * (1.0f / K);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a[ks].x -= mu; a[ks].y -= mu; a[ks].z -= mu; a[ks].w -= mu;
+        b[ks].x -= mu; b[ks].y -= mu; b[ks].z -= mu; b[ks].w -= mu;
+    }
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s0 += mdvit_ln_sq4(a[kq + 2 * j]);
+            s1 += mdvit_ln_sq4(b[kq + 2 * j]);
+        }
+        q[kq][0] = s0; q[kq][1] = s1;
+    }
+    const float rs = mdvit_ln_rstd(rc16_sum16(q), 1.0f / K, ln.eps);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const float4 ga = *reinterpret_cast<const float4*>(gg + 32 * ks), gb4 = *reinterpret_cast<const float4*>(gg + 32 * ks + 4);
+        const float4 ba = *reinterpret_cast<const float4*>(gb + 32 * ks), bb4 = *reinterpret_cast<const float4*>(gb + 32 * ks + 4);
+        a[ks] = mdvit_ln_affine4(a[ks], rs, ga, ba);
+        b[ks] = mdvit_ln_affine4(b[ks], rs, gb4, bb4);
+        if (row < M) {
+            *reinterpret_cast<float4*>(ln.out + (long)row * K + 8 * g + 32 * ks) = a[ks];
+            *reinterpret_cast<float4*>(ln.out + (long)row * K + 8 * g + 32 * ks + 4) = b[ks];
+        }
+    }
+    if (g == 0 && row < M) { ln.mean[row] = mu; ln.rstd[row] = rs; }
+}
+
+template <int C, int NW, int OCC, bool DROP, bool STORE, bool LNP = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc16_fwd_kernel(RcArgs p) {
     constexpr int KS = C / 32, CT = C / 16;
     constexpr int RB1 = C * 2;
@@ -904,7 +1035,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     issue_group(1);
     for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     rc_bf16x8 xh[KS], xl[KS];
-    rc16_load_rows<C>(p.x, row, p.M, g, xh, xl);
+    rc16_load_rows<C, LNP>(p.x, row, p.M, g, xh, xl, &p.ln);
     rc_f32x4 yacc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) yacc[ct] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1096,16 +1227,6 @@ struct LinArgs {
     const float* ln_g; const float* ln_b; float* ln_mean; float* ln_rstd; float* ln_out; float ln_eps; int ln_rows_per_group;
 };
 
-// sum over the 16 channel quads of a row in the order of norm.hip's sum16 (xor 8, 4, 2, 1 over the quad index): a lane of this kernel holds the quads
-// 4 kb + 2 lhi + {0, 1} -- the steps over bit 3 and bit 2 (kb) are in-lane, bit 1 (lhi) is the partner lane, bit 0 is in-lane.  q[kb][b]: per-quad
-// sums (C = 128: quads Q and Q + 16 of ln_fwd16's lane are kb and kb + 4 here, already added in ITS order by the caller).
-__device__ __forceinline__ float lin_sum16(const float (&q)[4][2]) {
-    const float p00 = q[0][0] + q[2][0], p01 = q[0][1] + q[2][1], p10 = q[1][0] + q[3][0], p11 = q[1][1] + q[3][1];     // xor 8
-    float r0 = p00 + p10, r1 = p01 + p11;                                                                             // xor 4
-    r0 += __shfl_xor(r0, 32, 64); r1 += __shfl_xor(r1, 32, 64);                                                        // xor 2
-    return r0 + r1;                                                                                                    // xor 1
-}
-
 template <int K, int NW, bool FULL, bool DROP, bool LNP = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4))) void lin_rc_kernel(LinArgs p) {
     constexpr int KB = K / 16;
@@ -1146,55 +1267,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4)))
             a[kb] = *reinterpret_cast<const float4*>(px + 16 * kb);
             b[kb] = *reinterpret_cast<const float4*>(px + 16 * kb + 4);
         }
-        if (LNP) {
-            // ln_fwd16_kernel's arithmetic, sum for sum (norm.hip): mean, then the centred squares, both through the same 16-quad tree; C = K
-            constexpr int VPL = K / 64;
-            const int grp = rowc / p.ln_rows_per_group;
-            const float* gg = p.ln_g + (long)grp * K + 8 * lhi;
-            const float* gb = p.ln_b + (long)grp * K + 8 * lhi;
-            float q[4][2];
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) {          // (C = 128: quad Q + 16 of ln_fwd16's lane <-> kb + 4 here)
-                    const float4 va = a[kq + 4 * j], vb = b[kq + 4 * j];
-                    s0 += (va.x + va.y) + (va.z + va.w);
-                    s1 += (vb.x + vb.y) + (vb.z + vb.w);
-                }
-                q[kq][0] = s0; q[kq][1] = s1;
-            }
-            const float mu = lin_sum16(q) * (1.0f / K);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                a[kb].x -= mu; a[kb].y -= mu; a[kb].z -= mu; a[kb].w -= mu;
-                b[kb].x -= mu; b[kb].y -= mu; b[kb].z -= mu; b[kb].w -= mu;
-            }
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    const float4 va = a[kq + 4 * j], vb = b[kq + 4 * j];
-                    s0 += mdvit_ln_sq4(va);
-                    s1 += mdvit_ln_sq4(vb);
-                }
-                q[kq][0] = s0; q[kq][1] = s1;
-            }
-            const float rs = mdvit_ln_rstd(lin_sum16(q), 1.0f / K, p.ln_eps);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const float4 ga = *reinterpret_cast<const float4*>(gg + 16 * kb), gb4 = *reinterpret_cast<const float4*>(gg + 16 * kb + 4);
-                const float4 ba = *reinterpret_cast<const float4*>(gb + 16 * kb), bb4 = *reinterpret_cast<const float4*>(gb + 16 * kb + 4);
-                a[kb] = mdvit_ln_affine4(a[kb], rs, ga, ba);
-                b[kb] = mdvit_ln_affine4(b[kb], rs, gb4, bb4);
-                if (row < p.M) {
-                    *reinterpret_cast<float4*>(p.ln_out + (long)row * K + 8 * lhi + 16 * kb) = a[kb];
-                    *reinterpret_cast<float4*>(p.ln_out + (long)row * K + 8 * lhi + 16 * kb + 4) = b[kb];
-                }
-            }
-            if (lhi == 0 && row < p.M) { p.ln_mean[row] = mu; p.ln_rstd[row] = rs; }
-        }
+        if (LNP) rc_ln_rows32<K>(a, b, row, rowc, p.M, lhi, LnPro{p.ln_g, p.ln_b, p.ln_mean, p.ln_rstd, p.ln_out, p.ln_eps, p.ln_rows_per_group});
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const float v[8] = {a[kb].x, a[kb].y, a[kb].z, a[kb].w, b[kb].x, b[kb].y, b[kb].z, b[kb].w};
@@ -1450,6 +1523,55 @@ extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* 
         else { if (h) RC16_FWD_LAUNCH(64, 4, false, true); else RC16_FWD_LAUNCH(64, 4, false, false); }
     }
 #undef RC16_FWD_LAUNCH
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+/* The MLP forward with the LayerNorm in front of it fused into the prologue (LN2 -> Mlp of SerialBlock_adapt, mdvit.py:356-360): x2 [M, C] is the LayerNorm's
+ * INPUT and the residual; writes mean / rstd [M], the normalised rows ln_out [M, C] (operand of the backward kernels) and y.  C = 64: mlp_rc_fwd3 (no
+ * [tokens, hidden] tensor); C = 128: the 16-token kernel, h != NULL written as in mdvit_mlp_rc16_fwd.  mdvit_layernorm_fwd's arithmetic, sum for sum. */
+extern "C" int mdvit_mlp_rc_fwd_ln(const float* x2, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+                                   const void* W1p, const float* b1, const void* W2p, const float* b2, const float* rowscale, int32_t rows_per_scale, float* h,
+                                   float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1,
+                                   const uint32_t* drop_seed, void* stream) {
+    MDVIT_CHECK_ARG(C == 64 || C == 128, MDVIT_E_SHAPE, "mlp_rc_fwd_ln: built for C = 64 / 128 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && Hd >= 64 && Hd % 64 == 0 && Hd <= 4096 && groups > 0 && M % groups == 0, MDVIT_E_SHAPE, "mlp_rc_fwd_ln: bad shape M=%d hidden=%d groups=%d", M, Hd, groups);
+    MDVIT_CHECK_ARG(x2 && gamma && beta && mean && rstd && ln_out && W1p && b1 && W2p && b2 && y && (C == 128 || h == nullptr), MDVIT_E_SHAPE, "mlp_rc_fwd_ln: bad operands");
+    MDVIT_CHECK_ARG(aligned16(x2) && aligned16(gamma) && aligned16(beta) && aligned16(ln_out) && aligned16(W1p) && aligned16(b1) && aligned16(W2p) && aligned16(b2) &&
+                        aligned16(y) && aligned16(h), MDVIT_E_ALIGN, "mlp_rc_fwd_ln: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_rc_fwd_ln: dropout index space exceeds 2^32");
+    RcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x2; a.res = x2; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2p = (const uint16_t*)W2p; a.b2 = b2; a.rowscale = rowscale; a.y = y; a.h = h;
+    a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    a.ln = LnPro{gamma, beta, mean, rstd, ln_out, eps, M / groups};
+    rc_fill(a, M, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64) {
+        constexpr int NW = 4;
+        const int smem = 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + Hd * 4;
+        static bool f0[64] = {false}, f1[64] = {false};
+        int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, false, 3, false, true>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f0);
+        if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, true, 3, false, true>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f1);
+        if (rc != MDVIT_OK) return rc;
+        if (a.drop) hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, true, 3, false, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, s, a);
+        else hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, false, 3, false, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, s, a);
+    } else {
+        constexpr int NW = 8;
+        const int smem = 3 * 2 * (32 * 128 * 2) + 3 * 2 * (128 * 64) + Hd * 4;
+        const dim3 grid(cdiv(M, NW * 16)), block(NW * 64);
+#define RC16_FWD_LN_LAUNCH(DROPV, STOREV)                                                                                            \
+    do {                                                                                                                             \
+        static bool fl[64] = {false};                                                                                                \
+        const int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc16_fwd_kernel<128, NW, 2, DROPV, STOREV, true>),              \
+                                  3 * 2 * (32 * 128 * 2) + 3 * 2 * (128 * 64) + 4096 * 4, fl);                                       \
+        if (rc != MDVIT_OK) return rc;                                                                                               \
+        hipLaunchKernelGGL((mlp_rc16_fwd_kernel<128, NW, 2, DROPV, STOREV, true>), grid, block, smem, s, a);                         \
+    } while (0)
+        if (a.drop) { if (h) RC16_FWD_LN_LAUNCH(true, true); else RC16_FWD_LN_LAUNCH(true, false); }
+        else { if (h) RC16_FWD_LN_LAUNCH(false, true); else RC16_FWD_LN_LAUNCH(false, false); }
+#undef RC16_FWD_LN_LAUNCH
+    }
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
