@@ -348,6 +348,58 @@ def test_linear_rc_streaming_kernel_is_the_tiled_gemm_bit_for_bit(M, N, K, full,
             assert torch.equal(dx0, dx1)
 
 
+@pytest.mark.parametrize("M,K,G,drop", [(1024, 64, 1, 0.1), (5000, 64, 1, 0.0), (4096, 128, 4, 0.1), (33, 128, 1, 0.0), (70000, 64, 2, 0.1)])
+def test_layernorm_prologues_equal_the_separate_layernorm_bit_for_bit(M, K, G, drop):
+    """mdvit_linear_rc_ln (LN1 -> qkv) and mdvit_mlp_rc_fwd_ln (LN2 -> Mlp): the LayerNorm in the consuming kernel's prologue reproduces
+    mdvit_layernorm_fwd sum for sum -- statistics, normalised rows and the consumer's output are EQUAL to LayerNorm kernel + consumer kernel"""
+    from mdvit_amd import ops
+    from mdvit_amd.ops import call, _p, _stream
+    if ops.gemm_precision() != "bf16x3":
+        pytest.skip("the register-chained kernels are the bf16x3 path's")
+    d = dev()
+    Mg = (M // G) * G
+    x = (rnd(Mg, K, seed=280, scale=2.0) + 0.3).to(d)
+    ga, be = (1 + 0.5 * rnd(G, K, seed=281)).to(d).contiguous(), rnd(G, K, seed=282, scale=0.1).to(d).contiguous()
+
+    def planes(W, transposed=0):
+        N, Kk = W.shape
+        out = torch.empty((2, Kk, N) if transposed else (2, N, Kk), device=d, dtype=torch.bfloat16)
+        call("mdvit_split_planes_t", _p(W), Kk, _p(out), N if transposed else Kk, N * Kk, N, Kk, transposed, 2, _stream())
+        return out
+    # LN1 -> qkv
+    N = 3 * K
+    W, b = rnd(N, K, seed=283, scale=K ** -0.5).to(d), rnd(N, seed=284, scale=0.1).to(d)
+    Wp = planes(W)
+    cur0, mean0, rstd0, y0 = torch.empty(Mg, K, device=d), torch.empty(Mg, device=d), torch.empty(Mg, device=d), torch.empty(Mg, N, device=d)
+    cur1, mean1, rstd1, y1 = torch.empty(Mg, K, device=d), torch.empty(Mg, device=d), torch.empty(Mg, device=d), torch.empty(Mg, N, device=d)
+    call("mdvit_layernorm_fwd", _p(x), _p(ga), _p(be), _p(cur0), _p(mean0), _p(rstd0), Mg, K, G, 1e-6, _stream())
+    call("mdvit_linear_rc", _p(cur0), K, _p(Wp), N * K, _p(b), _p(y0), N, Mg, N, K, 0.0, 0, 0, None, 1, None, 0, None, _stream())
+    call("mdvit_linear_rc_ln", _p(x), _p(ga), _p(be), G, 1e-6, _p(mean1), _p(rstd1), _p(cur1), _p(Wp), N * K, _p(b), _p(y1), N, Mg, N, K, _stream())
+    for name, a0, a1 in (("mean", mean0, mean1), ("rstd", rstd0, rstd1), ("cur", cur0, cur1), ("qkv", y0, y1)):
+        assert torch.equal(a0, a1), name
+    check(cur1, F.layer_norm(x.double(), (K,), None, None, 1e-6) * ga.double().repeat_interleave(Mg // G, 0) + be.double().repeat_interleave(Mg // G, 0),
+          tol=5e-6, name="normalised rows vs fp64")
+    # LN2 -> Mlp
+    Hd = 8 * K
+    W1, b1 = rnd(Hd, K, seed=285, scale=K ** -0.5).to(d), rnd(Hd, seed=286, scale=0.1).to(d)
+    W2, b2 = rnd(K, Hd, seed=287, scale=Hd ** -0.5).to(d), rnd(K, seed=288, scale=0.1).to(d)
+    W1p, W2p = planes(W1), planes(W2)
+    rps = max(1, Mg // 4)
+    rs = ((torch.rand(4 + 1, generator=torch.Generator().manual_seed(9)) < 0.8).float() / 0.8).to(d)
+    h0 = torch.empty(Mg, Hd, device=d) if K == 128 else None
+    h1 = torch.empty(Mg, Hd, device=d) if K == 128 else None
+    z0, z1 = torch.empty(Mg, K, device=d), torch.empty(Mg, K, device=d)
+    if K == 64:
+        call("mdvit_mlp_rc_fwd", _p(cur0), _p(W1p), _p(b1), _p(W2p), _p(b2), _p(x), _p(rs), rps, _p(z0), Mg, K, Hd, drop, 3, 4, 5, 6, None, _stream())
+    else:
+        call("mdvit_mlp_rc16_fwd", _p(cur0), _p(W1p), _p(b1), _p(W2p), _p(b2), _p(x), _p(rs), rps, _p(h0), _p(z0), Mg, K, Hd, drop, 3, 4, 5, 6, None, _stream())
+    cur2, mean2, rstd2 = torch.empty(Mg, K, device=d), torch.empty(Mg, device=d), torch.empty(Mg, device=d)
+    call("mdvit_mlp_rc_fwd_ln", _p(x), _p(ga), _p(be), G, 1e-6, _p(mean2), _p(rstd2), _p(cur2), _p(W1p), _p(b1), _p(W2p), _p(b2), _p(rs), rps, _p(h1), _p(z1),
+         Mg, K, Hd, drop, 3, 4, 5, 6, None, _stream())
+    for name, a0, a1 in (("mean", mean0, mean2), ("rstd", rstd0, rstd2), ("cur", cur0, cur2), ("y", z0, z1)) + ((("h", h0, h1),) if K == 128 else ()):
+        assert torch.equal(a0, a1), name
+
+
 def test_linear_layers_route_to_the_streaming_kernel_with_equal_results(monkeypatch):
     """ops.linear with MDVIT_LINEAR_RC on / off: forward, data gradient, weight and bias gradients equal (the weight gradient is the same TN GEMM)"""
     from mdvit_amd import ops
