@@ -560,16 +560,21 @@ __global__ __launch_bounds__(256) void upsample_multi_fwd_kernel(UpMulti p, cons
     }
 }
 
-// width folds of all sources: work item = (dy row o, source column j in [0, Wi_0 + Wi_1 + Wi_2), channel quad)
-__global__ __launch_bounds__(256) void upsample_multi_bwd_w_kernel(UpMulti p, const float* __restrict__ dy, long outer, int Wo, int C) {
+// width folds of all sources: work item = (dy row o, source column j in [0, Wi_0 + Wi_1 + Wi_2), channel quad).  A dy row (Wo x C floats: 256 KB in the
+// peer heads) is read by every output column it overlaps -- ~6 times in all -- so the workgroups of ONE row must share an L2: consecutive workgroup
+// ids go round robin over the 8 XCDs, and a row's `bpr` workgroups were spread over all of them (PMC: 632 MB per launch for 134 MB of dy); the bijective
+// remap below puts consecutive LOGICAL ids on one XCD.
+__global__ __launch_bounds__(256) void upsample_multi_bwd_w_kernel(UpMulti p, const float* __restrict__ dy, long outer, int Wo, int C, int bpr) {
     const int QC = C >> 2;
     const int Wsum = p.Wi[0] + (p.n > 1 ? p.Wi[1] : 0) + (p.n > 2 ? p.Wi[2] : 0);
-    const long total = outer * Wsum * QC;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int nwg = (int)gridDim.x, qx = nwg >> 3, rx = nwg & 7, xcd = blockIdx.x & 7, ix = blockIdx.x >> 3;
+    const int lb = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + ix;
+    const long o = lb / bpr;
+    {
+        const long e = (long)(lb % bpr) * blockDim.x + threadIdx.x;
+        if (e >= (long)Wsum * QC) return;
         const int c = (int)(e % QC) * 4;
-        long r = e / QC;
-        int j = (int)(r % Wsum);
-        const long o = r / Wsum;
+        int j = (int)(e / QC);
         int src = 0;
         if (j >= p.Wi[0]) { j -= p.Wi[0]; src = 1; if (j >= p.Wi[1]) { j -= p.Wi[1]; src = 2; } }
         const int Wi = p.Wi[src];
@@ -827,7 +832,9 @@ extern "C" int mdvit_upsample_multi_bwd(const float* dy, float* const* dxs, cons
         wsum += Wi[i];
     }
     const long cq = C / 4;
-    hipLaunchKernelGGL(upsample_multi_bwd_w_kernel, dim3(ew_grid((long)B * Ho * wsum * cq)), dim3(256), 0, s, p, dy, (long)B * Ho, Wo, C);
+    const int bpr = (int)cdiv((long)wsum * cq, 256L);
+    MDVIT_CHECK_ARG((long)B * Ho * bpr < (1L << 31), MDVIT_E_SHAPE, "upsample_multi_bwd: too many workgroups");
+    hipLaunchKernelGGL(upsample_multi_bwd_w_kernel, dim3((unsigned)((long)B * Ho * bpr)), dim3(256), 0, s, p, dy, (long)B * Ho, Wo, C, bpr);
     for (int i = 0; i < n; ++i)          // pass H per source: tmp_i [B][Ho][Wi*C] -> dx_i [B][Hi][Wi*C]
         hipLaunchKernelGGL((upsample_bwd_pass_kernel<false>), dim3(ew_grid((long)B * Hi[i] * Wi[i] * cq)), dim3(256), 0, s, p.d[i], dxs[i], (long)B, Hi[i], Ho,
                            (long)Wi[i] * cq, 1);
