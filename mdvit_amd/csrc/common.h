@@ -108,6 +108,13 @@ __device__ __forceinline__ float4 mdvit_drop_scale4(uint32_t k0, uint32_t k1, ui
                        __builtin_rotateright32(h, 24) >= thresh ? inv_keep : 0.0f);
 }
 
+// Workgroup ids go round robin over the 8 XCDs (each with its own L2): consecutive LOGICAL ids on ONE XCD, bijectively.  For kernels whose neighbouring
+// workgroups re-read the same lines (bilinear taps, row folds): with the raw id every XCD fetches them from HBM once more.
+__device__ __forceinline__ unsigned mdvit_xcd_logical_block() {
+    const unsigned nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // LayerNorm pieces with EXPLICIT rounding (no fma contraction left to the compiler): two kernels that normalise the same row -- ln_fwd16_kernel and
 // the LayerNorm prologue of lin_rc_kernel -- must agree bit for bit whatever surrounds the expression
 __device__ __forceinline__ float mdvit_ln_sq4(const float4 v) {
