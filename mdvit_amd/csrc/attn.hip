@@ -478,7 +478,8 @@ size_t fa_ws_floats(int B, int N, int C, int heads) {
     const long NT = (N + FA_T - 1) / FA_T;
     const long fwd = (long)B * NT * C * (2 + Ch);
     // + the partial rows of the window-weight gradients: <= max(1024, C/32 * B) workgroups x 32 channels x (49 taps + bias)
-    const long wg_rows = (long)cdiv(C, 32) * B > 1024 ? (long)cdiv(C, 32) * B : 1024;
+    // (the three classes together: fa_conv3_wgrad_kernel -- at most C/32 + 2 channel blocks, and the tile chunks keep blocks x images x chunks < 1024)
+    const long wg_rows = (long)(cdiv(C, 32) + 2) * B > 1024 ? (long)(cdiv(C, 32) + 2) * B : 1024;
     const long part = wg_rows * 32 * 50 > 1024L * B * C ? wg_rows * 32 * 50 : 1024L * B * C;       // ... or the e partial rows [B][<=1024][C]
     const long bwd = 2L * B * N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch + part;
     return (size_t)(fwd > bwd ? fwd : bwd);
@@ -630,9 +631,10 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     const CtGeom cg{B, g.H, g.W};
     if (want_wgrad) {
         float* wg_part = ws_P + (long)B * NT * C * Ch;          // partial rows, reduced by the finish kernel of each class
-        launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, wg_part, cg, s3 * Ch, s);
-        launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, wg_part, cg, s5 * Ch, s);
-        launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, wg_part, cg, s7 * Ch, s);
+        const int goff[3] = {0, c5, c7}, xoff3[3] = {2 * C, 2 * C + c5, 2 * C + c7}, ncls3[3] = {s3 * Ch, s5 * Ch, s7 * Ch};
+        float* const dws[3] = {dw3, dw5, dw7};
+        float* const dbs[3] = {db3, db5, db7};
+        launch_conv3_wgrad(dU, (long)C, goff, qkv, 3L * C, xoff3, dws, dbs, wg_part, cg, ncls3, s, 0);
     }
     // conv^T(dU) = correlation with the flipped window
     {   // transposed (flipped-tap) windows of the three classes in one launch
@@ -676,9 +678,10 @@ extern "C" int mdvit_factoratt_wgrad(const float* qkv, void* ws, size_t ws_bytes
     float* wg_part = (float*)ws + 2L * B * g.N * C + (long)B * C * (1 + Ch) + (long)B * NT * C * Ch;
     const int c5 = s3 * Ch, c7 = (s3 + s5) * Ch;
     const CtGeom cg{B, g.H, g.W};
-    launch_conv_tile_wgrad<3>(dU, (long)C, 0, qkv, 3L * C, 2 * C, dw3, db3, wg_part, cg, s3 * Ch, s, accumulate);
-    launch_conv_tile_wgrad<5>(dU, (long)C, c5, qkv, 3L * C, 2 * C + c5, dw5, db5, wg_part, cg, s5 * Ch, s, accumulate);
-    launch_conv_tile_wgrad<7>(dU, (long)C, c7, qkv, 3L * C, 2 * C + c7, dw7, db7, wg_part, cg, s7 * Ch, s, accumulate);
+    const int goff[3] = {0, c5, c7}, xoff3[3] = {2 * C, 2 * C + c5, 2 * C + c7}, ncls3[3] = {s3 * Ch, s5 * Ch, s7 * Ch};
+    float* const dws[3] = {dw3, dw5, dw7};
+    float* const dbs[3] = {db3, db5, db7};
+    launch_conv3_wgrad(dU, (long)C, goff, qkv, 3L * C, xoff3, dws, dbs, wg_part, cg, ncls3, s, accumulate);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -277,15 +277,15 @@ void launch_conv3(const float* x, long ldx, const int xoff[3], const float* cons
 // which writes its partial into the block's row of `part` ([y][z*x][32*(WIN*WIN+1)]); mdvit_reduce_partials adds the
 // rows in a fixed order (deterministic; ~1000 same-address float atomics per tap cost more than the whole kernel).
 // GDIV = 2: channel c of x pairs with gradient channel c / 2 (the grouped decoder conv on (skip, up): output group g reads inputs 2g, 2g+1)
-template <int WIN, int GDIV = 1>
-__global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __restrict__ g, long ldg, int goff,
-                                                                 const float* __restrict__ x, long ldx, int xoff,
-                                                                 float* __restrict__ part,
-                                                                 int H, int W, int ncls, int tiles_w, int tiles_total, int tiles_per_block) {
+// (bx, gx: this workgroup's tile chunk and the number of chunks; cb: 32-channel block inside the class; b, nb: image and image count)
+template <int WIN, int GDIV>
+__device__ __forceinline__ void conv_tile_wgrad_body(float* __restrict__ sx, float* __restrict__ sg, int bx, int gx, int cb, int b, int nb,
+                                                     const float* __restrict__ g, long ldg, int goff,
+                                                     const float* __restrict__ x, long ldx, int xoff,
+                                                     float* __restrict__ part,
+                                                     int H, int W, int ncls, int tiles_w, int tiles_total, int tiles_per_block) {
     constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
-    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
-    __shared__ __attribute__((aligned(16))) float sg[CT_TH * CT_TW * CT_CL];
-    const int b = blockIdx.z, c0 = blockIdx.y * CT_CL;
+    const int c0 = cb * CT_CL;
     const int cl = threadIdx.x & 31, rl8 = threadIdx.x >> 5;
     // thread <-> (channel, window row i [, half of the tile's rows]): WIN = 3 would leave five of the eight row lanes idle, so there two lanes
     // share a window row, each over four of the tile's eight rows, and are added through LDS at the end; lanes past WIN * HS only help loading
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
     float accb = 0.f;
 #pragma unroll
     for (int j = 0; j < WIN; ++j) acc[j] = 0.f;
-    const int t_beg = blockIdx.x * tiles_per_block, t_end = min(tiles_total, t_beg + tiles_per_block);
+    const int t_beg = bx * tiles_per_block, t_end = min(tiles_total, t_beg + tiles_per_block);
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int th0 = (tile / tiles_w) * CT_TH, tw0 = (tile % tiles_w) * CT_TW;
         {   // both windows requested before either is stored
@@ -342,12 +342,49 @@ __global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __
         }
     }
     constexpr int ROW = CT_CL * (WIN * WIN + 1);
-    float* prow = part + ((long)blockIdx.y * gridDim.z * gridDim.x + (long)blockIdx.z * gridDim.x + blockIdx.x) * ROW + cl * (WIN * WIN + 1);
+    float* prow = part + ((long)cb * nb * gx + (long)b * gx + bx) * ROW + cl * (WIN * WIN + 1);
     if (rl < WIN && half == 0) { // channels past ncls hold zeros
 #pragma unroll
         for (int j = 0; j < WIN; ++j) prow[rl * WIN + j] = acc[j];
         if (rl == 0) prow[WIN * WIN] = accb;
     }
+}
+
+template <int WIN, int GDIV = 1>
+__global__ __launch_bounds__(256) void fa_conv_tile_wgrad_kernel(const float* __restrict__ g, long ldg, int goff,
+                                                                 const float* __restrict__ x, long ldx, int xoff,
+                                                                 float* __restrict__ part,
+                                                                 int H, int W, int ncls, int tiles_w, int tiles_total, int tiles_per_block) {
+    constexpr int R = WIN / 2, LH = CT_TH + 2 * R, LW = CT_TW + 2 * R;
+    __shared__ __attribute__((aligned(16))) float sx[LH * LW * CT_CL];
+    __shared__ __attribute__((aligned(16))) float sg[CT_TH * CT_TW * CT_CL];
+    conv_tile_wgrad_body<WIN, GDIV>(sx, sg, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z, gridDim.z, g, ldg, goff, x, ldx, xoff, part, H, W, ncls, tiles_w, tiles_total,
+                                    tiles_per_block);
+}
+
+// The window-weight gradients of the three ConvRelPosEnc classes in ONE launch.  Each class reads its own channel range of the same dU / v rows (64 /
+// 96 / 96 bytes of a 256-byte row at C = 64): as three launches every 128-byte line was fetched from HBM up to three times (PMC at the stage-0 shape
+// of bs=32: 1.7 + 2.8 + 1.5 units of [tokens, C] for 2 units of data).  Here the class blocks of one tile chunk are neighbours in a LOGICAL workgroup
+// order that the XCD remap keeps on one L2.
+struct Conv3WArgs {
+    const float* g; long ldg; int goff[3];
+    const float* x; long ldx; int xoff[3];
+    float* part[3];
+    int H, W, ncls[3], cbs[3], tiles_w, tiles_total, tpb, gx, B;
+};
+__global__ __launch_bounds__(256) void fa_conv3_wgrad_kernel(Conv3WArgs p) {
+    __shared__ __attribute__((aligned(16))) float sx[(CT_TH + 6) * (CT_TW + 6) * CT_CL];
+    __shared__ __attribute__((aligned(16))) float sg[CT_TH * CT_TW * CT_CL];
+    const unsigned lb = mdvit_xcd_logical_block();
+    const int tcb = p.cbs[0] + p.cbs[1] + p.cbs[2];
+    int cb = (int)(lb % tcb);
+    const unsigned r = lb / tcb;
+    const int bx = (int)(r % p.gx), b = (int)(r / p.gx);
+    if (cb < p.cbs[0]) { conv_tile_wgrad_body<3, 1>(sx, sg, bx, p.gx, cb, b, p.B, p.g, p.ldg, p.goff[0], p.x, p.ldx, p.xoff[0], p.part[0], p.H, p.W, p.ncls[0], p.tiles_w, p.tiles_total, p.tpb); return; }
+    cb -= p.cbs[0];
+    if (cb < p.cbs[1]) { conv_tile_wgrad_body<5, 1>(sx, sg, bx, p.gx, cb, b, p.B, p.g, p.ldg, p.goff[1], p.x, p.ldx, p.xoff[1], p.part[1], p.H, p.W, p.ncls[1], p.tiles_w, p.tiles_total, p.tpb); return; }
+    cb -= p.cbs[1];
+    conv_tile_wgrad_body<7, 1>(sx, sg, bx, p.gx, cb, b, p.B, p.g, p.ldg, p.goff[2], p.x, p.ldx, p.xoff[2], p.part[2], p.H, p.W, p.ncls[2], p.tiles_w, p.tiles_total, p.tpb);
 }
 
 template <int WIN, bool FLIP>
@@ -416,6 +453,39 @@ int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x
     // second stage, per 32-channel block y: rows [y][gx*B] of 32*(WIN^2+1) floats -> dw [c][WIN^2], db [c]
     constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
     hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<WIN>), dim3(cdiv(ROW, 32), gy), dim3(256), 0, s, part, gx * g.B, dw, db, ncls, accumulate);
+    return MDVIT_OK;
+}
+
+// the three classes' weight gradients: one tile launch (see fa_conv3_wgrad_kernel) + a finish per class; part: >= conv3_wgrad_part_floats floats
+inline long conv3_wgrad_rows(const CtGeom& g, const int ncls[3], int& tpb, int& gx) {
+    const int tiles = cdiv(g.W, CT_TW) * cdiv(g.H, CT_TH);
+    const int tcb = cdiv(ncls[0], CT_CL) + cdiv(ncls[1], CT_CL) + cdiv(ncls[2], CT_CL);
+    tpb = 1;
+    while (tpb < tiles && (long)cdiv(tiles, tpb * 2) * tcb * g.B >= 512) tpb *= 2;
+    gx = cdiv(tiles, tpb);
+    return (long)gx * g.B;           // partial rows per 32-channel block
+}
+inline int launch_conv3_wgrad(const float* gsrc, long ldg, const int goff[3], const float* x, long ldx, const int xoff[3], float* const dw[3], float* const db[3],
+                              float* part, const CtGeom& g, const int ncls[3], hipStream_t s, int accumulate) {
+    int tpb, gx;
+    const long rows = conv3_wgrad_rows(g, ncls, tpb, gx);
+    Conv3WArgs a;
+    a.g = gsrc; a.ldg = ldg; a.x = x; a.ldx = ldx; a.H = g.H; a.W = g.W; a.tiles_w = cdiv(g.W, CT_TW); a.tiles_total = a.tiles_w * cdiv(g.H, CT_TH);
+    a.tpb = tpb; a.gx = gx; a.B = g.B;
+    const int T[3] = {10, 26, 50};
+    float* pp = part;
+    int tcb = 0;
+    for (int i = 0; i < 3; ++i) {
+        a.goff[i] = goff[i]; a.xoff[i] = xoff[i]; a.ncls[i] = ncls[i]; a.cbs[i] = ncls[i] > 0 ? cdiv(ncls[i], CT_CL) : 0;
+        a.part[i] = pp;
+        pp += (long)a.cbs[i] * rows * CT_CL * T[i];
+        tcb += a.cbs[i];
+    }
+    if (tcb == 0) return MDVIT_OK;
+    hipLaunchKernelGGL(fa_conv3_wgrad_kernel, dim3((unsigned)((long)g.B * gx * tcb)), dim3(256), 0, s, a);
+    if (a.cbs[0]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<3>), dim3(cdiv(CT_CL * 10, 32), a.cbs[0]), dim3(256), 0, s, a.part[0], (int)rows, dw[0], db[0], ncls[0], accumulate);
+    if (a.cbs[1]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<5>), dim3(cdiv(CT_CL * 26, 32), a.cbs[1]), dim3(256), 0, s, a.part[1], (int)rows, dw[1], db[1], ncls[1], accumulate);
+    if (a.cbs[2]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<7>), dim3(cdiv(CT_CL * 50, 32), a.cbs[2]), dim3(256), 0, s, a.part[2], (int)rows, dw[2], db[2], ncls[2], accumulate);
     return MDVIT_OK;
 }
 
