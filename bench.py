@@ -459,7 +459,7 @@ def main():
             common = ["--precision", args.precision] + (["--no-side-stream"] if args.no_side_stream else [])
             b32 = _child_json([sys.executable, os.path.abspath(__file__), "--batch", "32", "--steps", "4", "--warmup", "4", "--no-cpu-baseline",
                                "--no-extra-legs", "--no-kernel-events"] + common, 600)
-            extra["bs32"] = {k: b32.get(k) for k in ("value", "unit", "ms_per_step", "phase_ms", "steps", "warmup", "error") if k in b32}
+            extra["bs32"] = {k: b32.get(k) for k in ("value", "unit", "ms_per_step", "phase_ms", "steps", "warmup", "memory", "host_enqueue_ms_per_step", "error") if k in b32}
             if "config" in b32:
                 extra["bs32"]["workload"] = b32["config"]["workload"]
             if args.precision == "bf16x3":
