@@ -349,7 +349,8 @@ def main():
     # on a box 395 images/s, the second 433, the third and later 435-438).  The settle loop repeats untimed steps, five at a time, until the host's enqueue
     # time sits comfortably under the step time (the GPU is the limit again), for at most --settle-seconds; what it did is reported in the JSON (`settle`).
     settle = {"steps": 0, "seconds": 0.0, "host_ms_first": None, "host_ms_last": None}
-    if args.settle_seconds > 0 and not args.graph and world == 1:
+    if args.settle_seconds > 0 and not args.graph and world == 1 and args.model in ("mdvit", "mdvit_dsn") and args.decoder != "Transformer":
+        # (the configurations whose step is GPU-bound on a warm box; TransFuse / BASE / the Transformer peers are host-bound by nature and would only burn the budget)
         ts0 = time.perf_counter()
         hist = []
         while time.perf_counter() - ts0 < args.settle_seconds:
