@@ -54,13 +54,19 @@ def parse():
                     help="untimed settling before the warm-up steps: repeat the step until the host's enqueue time is stable (a fresh box pages the image in); 0: off")
     ap.add_argument("--by-shape", action="store_true", help="key the GEMM event table by (variant, M, N, K) -- for tools/gemm_shapes.py")
     ap.add_argument("--detail", default="", help="write the per-kernel table to this JSON file")
-    ap.add_argument("--max-inflight", type=int, default=2,
+    ap.add_argument("--max-inflight", type=int, default=0,
                     help="steps the host may have enqueued ahead of the GPU (a training loop that reads its loss every step has 1-2): bounds the "
-                         "memory that cross-stream tensors hold until their events complete -- at bs=32 an unbounded run-ahead grows the pool "
-                         "past 288 GB and the allocator's free-and-retry path takes over")
+                         "memory that cross-stream tensors hold until their events complete.  0 (default): 2 below batch 16, 1 from batch 16 up -- "
+                         "the tensors the weight-gradient stream still reads stay allocated until that stream has passed them (52 GiB of them at "
+                         "bs=32), so every extra step of run-ahead costs another such set: measured at bs=32, reserved memory is flat at 142 GiB "
+                         "with 1 step ahead and climbs 8 GiB per step to 260 GiB with 2 (tools/probe/bs32_memory_probe.py), at an equal rate "
+                         "(the host needs 22 ms for a 250 ms step)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the bs=32 leg and the MHSA+DA block roofline at bs=32 that the default N=1 run appends to its JSON line")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.max_inflight <= 0:
+        args.max_inflight = 2 if args.batch < 16 else 1
+    return args
 
 
 def _cpu_model():
