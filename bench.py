@@ -55,12 +55,10 @@ def parse():
     ap.add_argument("--by-shape", action="store_true", help="key the GEMM event table by (variant, M, N, K) -- for tools/gemm_shapes.py")
     ap.add_argument("--detail", default="", help="write the per-kernel table to this JSON file")
     ap.add_argument("--max-inflight", type=int, default=0,
-                    help="steps the host may have enqueued ahead of the GPU (a training loop that reads its loss every step has 1-2): bounds the "
-                         "memory that cross-stream tensors hold until their events complete.  0 (default): 2 below batch 16, 1 from batch 16 up -- "
-                         "the tensors the weight-gradient stream still reads stay allocated until that stream has passed them (52 GiB of them at "
-                         "bs=32), so every extra step of run-ahead costs another such set: measured at bs=32, reserved memory is flat at 142 GiB "
-                         "with 1 step ahead and climbs 8 GiB per step to 260 GiB with 2 (tools/probe/bs32_memory_probe.py), at an equal rate "
-                         "(the host needs 22 ms for a 250 ms step)")
+                    help="steps the host may have enqueued ahead of the GPU (a training loop that reads its loss every step has 1-2).  0 (default): 2 below "
+                         "batch 16, 1 from batch 16 up -- there the host needs 22 ms for a 250 ms step, and every step of run-ahead keeps one more step's "
+                         "cross-stream tensors in the RESERVED pool (bs=32: 105.9 GiB reserved with 1, 116.5 with 2; peak allocated 86.9 GiB either way since "
+                         "ops._side_protect bounds what the weight-gradient stream holds)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the bs=32 leg and the MHSA+DA block roofline at bs=32 that the default N=1 run appends to its JSON line")
     args = ap.parse_args()

@@ -275,9 +275,15 @@ def _release_finished_side_blocks():
 
 def join_side_stream():
     if _side_stream is not None:
-        stream_wait(current_stream_obj(), _side_stream)
+        cur = current_stream_obj()
+        stream_wait(cur, _side_stream)
         _side_keepalive.clear()
         _side_blocks.clear()
+        for ev, owner, _ts, _n in _side_groups:           # tensors of ANOTHER stream (a branch stream's blocks): that stream waits too before they go back to its pool
+            if owner != cur:
+                owner.wait_event(ev)
+        _side_groups.clear()
+        _side_held[0] = 0
 
 
 class _on_side:
@@ -2100,18 +2106,45 @@ def _block_streams(side):
     return st
 
 
+_side_groups = []       # (event on the side stream behind a block's weight-gradient launches, the stream that owns the tensors, the tensors, bytes); oldest first
+_side_held = [0]
+# Bound on what the block entries keep allocated for the weight-gradient stream.  Past it the OWNING stream waits (on the GPU) for the side stream to pass the
+# oldest blocks and their tensors are released in stream order -- the footprint no longer depends on how far the side stream lags or the host runs ahead
+# (bs=32: 52 GiB of such tensors per backward sweep).  0: no bound (release on completed events only).
+_side_hold_limit = int(float(os.environ.get("MDVIT_SIDE_HOLD_GIB", "16")) * 2 ** 30)
+
+
+def _trim_side_groups(limit):
+    while _side_groups and _side_groups[0][0].query():
+        _side_held[0] -= _side_groups.pop(0)[3]
+    while _side_groups and _side_held[0] > limit:
+        ev, owner, _ts, n = _side_groups.pop(0)
+        owner.wait_event(ev)          # whatever the owner enqueues from here on runs after the side stream's reads: the memory may be reused in stream order
+        _side_held[0] -= n
+
+
 def _side_protect(*tensors):
-    """main-stream tensors the side stream reads: keep them from being reused until the side work is done (what _on_side does)"""
+    """tensors of the current stream that weight-gradient launches on the side stream read: kept allocated (and safe from autograd's in-place accumulation,
+    which needs sole ownership) until the side stream has passed those launches -- known either from the completed event or because the owning stream
+    was made to wait for it (the hold bound)."""
     ts = [t for t in tensors if t is not None]
-    for t in ts:
-        t.record_stream(_side_stream)
-    _side_keepalive.extend(ts)
-    marked = _side_blocks[-1][1] if _side_blocks else 0
-    if len(_side_keepalive) - marked >= 32 and not torch.cuda.is_current_stream_capturing():
-        ev = torch.cuda.Event()
-        ev.record(_side_stream)
-        _side_blocks.append((ev, len(_side_keepalive)))
-        _release_finished_side_blocks()
+    if torch.cuda.is_current_stream_capturing() or not _side_hold_limit:
+        for t in ts:
+            t.record_stream(_side_stream)
+        _side_keepalive.extend(ts)
+        marked = _side_blocks[-1][1] if _side_blocks else 0
+        if len(_side_keepalive) - marked >= 32 and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record(_side_stream)
+            _side_blocks.append((ev, len(_side_keepalive)))
+            _release_finished_side_blocks()
+        return
+    ev = torch.cuda.Event()
+    ev.record(_side_stream)
+    n = sum(t.numel() * t.element_size() for t in ts)
+    _side_groups.append((ev, current_stream_obj(), ts, n))
+    _side_held[0] += n
+    _trim_side_groups(_side_hold_limit)
 
 
 def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):

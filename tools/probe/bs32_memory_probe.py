@@ -20,7 +20,10 @@ opt = FusedAdamW(accum, lr=1e-4, weight_decay=0.05)
 pool = [make_step_batches(32, 512, rank=0, step=s, device=dev) for s in range(2)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 ev = []
+t_run = None
 for i in range(n):
+    if i == 3:
+        torch.cuda.synchronize(); t_run = time.perf_counter()
     while len(ev) >= INFL:
         ev.pop(0).synchronize()
     train.mdvit_train_step(model, pool[i % 2], optimizer=opt, accumulator=accum, merged_sweeps=True, fuse_domains=4)
@@ -30,6 +33,9 @@ for i in range(n):
           "inactive split %.1f GiB  segments %d  retries %d" % (torch.cuda.memory_stats()["inactive_split_bytes.all.current"] / 2**30,
                                                                    torch.cuda.memory_stats()["segment.all.current"], torch.cuda.memory_stats()["num_alloc_retries"]), flush=True)
 torch.cuda.synchronize()
+if t_run is not None and n > 3:
+    print("steps 3..%d: %.1f ms per step, %.1f images/s  (MDVIT_SIDE_HOLD_GIB=%s, run-ahead %d)" % (n - 1, 1e3 * (time.perf_counter() - t_run) / (n - 3),
+          128 * (n - 3) / (time.perf_counter() - t_run), os.environ.get("MDVIT_SIDE_HOLD_GIB", "default"), INFL), flush=True)
 import collections
 for tag in ('final',):
     snap = torch.cuda.memory_snapshot()
