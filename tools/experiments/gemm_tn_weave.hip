@@ -1,3 +1,13 @@
+// EXPERIMENT (round 3; measured, not kept): gemm_tn.hip with (a) FAST loads for the full slabs -- a uniform base pointer stepping one slab at a time plus a
+// constant per-thread 32-bit byte offset, no row clamp, no tail selects (the address arithmetic was 92 of the 221 VALU instructions of a slab period) -- and
+// (b) the split of slab i+1 WOVEN into the MFMAs of slab i in a fixed order (scheduling barriers MFMA by MFMA; inline-asm pins keep instruction selection
+// from splitting a slab in the half period that loads it).  The ISA comes out as designed (per k-step: 16 fragment reads, then 3 MFMA | 12 VALU | ...), VGPRs
+// 228 -> 250-256, and the kernel is 2-5 % faster on the large shapes, equal on the small ones (tools/tn_check.py --time, one MI355X):
+//     [65536 x 1024]^T [65536 x 128]  102.0 us (104.4)      [16384 x 1280]^T [16384 x 320]  80.5 (84.4)      [262144 x 192]^T [262144 x 64]  66.0 (69.9)
+// One bf16 plane instead of three MFMAs per product moves the same shapes by < 5 % too: a slab period takes ~4900 cycles next to ~770 cycles of MFMA and
+// ~900 of VALU -- the wave waits for the loads it issued ONE period earlier (two register-staged slabs in flight per workgroup: 64 of 228 VGPRs), which
+// neither fewer VALU instructions nor a better instruction order changes.  Not adopted: 3 % of a kernel family that is 9 % of the step's kernel time.
+// Build: replace mdvit_amd/csrc/gemm_tn.hip with this file (same entry points).
 // Weight-gradient GEMM (TN): C[M,N] (+)= A^T B with A [K,M] and B [K,N] both TOKEN-major (k = token index, the long axis), fp32 in HBM,
 // bf16x3 arithmetic (x = hi + lo bf16 planes; hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) or one bf16 plane.
 // Replaces autograd's `grad_out.t() @ input` of every nn.Linear / 1x1 nn.Conv2d of the reference (mdvit.py:288,310, mpvit.py:73,76,
@@ -63,11 +73,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round robin to the 8 XCDs in launch order (x fastest).  The tiles of ONE K-split read the same token rows -- every A column block
-    // once per tile column, every B column block once per tile row.  Remapping inside a split (tile) puts neighbouring tiles of a split on one XCD when a
-    // split has many tiles; with <= 8 tiles per split it degenerates to "tile m of EVERY split on XCD m", and all eight L2s fetch all of the narrow operand.
-    // grid_xcd (the launcher sets it for <= 8 tiles per split): the logical (split, tile) pair comes from the XCD-contiguous order of the WHOLE grid, so the
-    // tiles of a split are neighbours on one XCD.  Measured (tools/tn_check.py --time): [262144 x 192]^T [262144 x 64] 67.9 -> 55.3 us, 64 x 512 134 -> 126,
-    // 1024 x 128 over 65536 tokens 102 -> 98; with 16 tiles per split (512 x 512 over 4096 tokens) it loses (25.8 -> 29.7 us), hence the threshold.
+    // once per tile column, every B column block once per tile row -- so they belong on one XCD, next to each other in time: the logical (split, tile) pair
+    // is taken from the XCD-contiguous order of the WHOLE grid.  (Remapping inside a split only, as before, put tile m of every split on XCD m whenever a
+    // split has <= 8 tiles: all eight L2s fetched all of the narrow operand -- 537 MB for the 302 MB of a [65536 x 1024]^T [65536 x 128] product.)
     const int ntile = p.tiles_m * p.tiles_n;
     int tile, split;
     if (p.grid_xcd) {
@@ -116,14 +124,41 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
     // Loads are UNCONDITIONAL (addresses clamped into the matrix, rows past the end of the K range zeroed by a select): a load under
     // a branch makes the compiler drain the whole vector-memory queue (s_waitcnt vmcnt(0)) at every join, which serialises the
     // slabs.  Columns past M / N read real elements of the last column quad: they only reach output rows / columns that are never stored.
-    auto load = [&](int slab, auto setc) __attribute__((always_inline)) {
+    //
+    // FAST loads (slabs wholly inside [kbeg, kend), i.e. all but the last one or two of a workgroup): a UNIFORM base pointer that steps one slab at a time
+    // plus a per-thread 32-bit byte offset that never changes -- no vector address arithmetic in the loop.  Computing the address from the slab index
+    // (64-bit multiply-add per float4, row clamp) was 92 of the 221 VALU instructions of a slab period, the quarter-rate v_mul_lo_u32 among them, next to
+    // 24 MFMAs of 32 cycles each: the period was VALU-bound in the wave.
+    uint32_t offa[AV], offb[CONVB ? 1 : BV];
+#pragma unroll
+    for (int v = 0; v < AV; ++v) {
+        const int u = wave + 4 * v, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
+        offa[v] = (uint32_t)(((long)(4 * (u & 7) + kr) * p.lda + m) * 4);
+    }
+    if (!CONVB) {
+#pragma unroll
+        for (int v = 0; v < BV; ++v) {
+            const int u = wave + 4 * v, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
+            offb[v] = (uint32_t)(((long)(4 * (u & 7) + kr) * p.ldb + n) * 4);
+        }
+    }
+    const char* abase = reinterpret_cast<const char*>(p.A + (long)(kbeg + 2 * BK) * p.lda);      // slab 2: the first FAST load of the loop
+    const char* bbase = reinterpret_cast<const char*>(p.B + (long)(kbeg + 2 * BK) * p.ldb);
+    const long a_step = (long)BK * p.lda * 4, b_step = (long)BK * p.ldb * 4;
+    auto load = [&](int slab, auto setc, auto fastc) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value;
+        constexpr bool FAST = decltype(fastc)::value;
         const int k0 = kbeg + slab * BK;
 #pragma unroll
         for (int v = 0; v < AV; ++v) {
-            const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
-            ra[S][v] = *reinterpret_cast<const float4*>(p.A + (long)min(k, kend - 1) * p.lda + m);
+            if (FAST) {
+                ra[S][v] = *reinterpret_cast<const float4*>(abase + offa[v]);
+            } else {
+                const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
+                ra[S][v] = *reinterpret_cast<const float4*>(p.A + (long)min(k, kend - 1) * p.lda + m);
+            }
         }
+        if (FAST) abase += a_step;
         if (CONVB) {
             uint32_t ok = 0;
             const int hw = p.cv_ho * p.cv_wo;
@@ -141,40 +176,59 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
         } else {
 #pragma unroll
             for (int v = 0; v < BV; ++v) {
-                const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
-                rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+                if (FAST) {
+                    rb[S][v] = *reinterpret_cast<const float4*>(bbase + offb[v]);
+                } else {
+                    const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
+                    rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+                }
             }
+            if (FAST) bbase += b_step;
         }
         __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE: the scheduler otherwise sinks them next to their LDS stores
     };
-    auto store = [&](int slab, auto setc) __attribute__((always_inline)) {
+    // one staged float4 (chunk c: A quads first, then B quads) of register set S: zero what lies outside, column sums, split into the two bf16 planes
+    constexpr int NCH = AV + BV;
+    uint2 shi[NCH], slo[NCH];
+    auto split_chunk = [&](int c, int slab, auto setc, auto fastc) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value;
-        char* base = smem + (slab & 1) * STAGE;
+        const bool tail = !decltype(fastc)::value && slab >= full_slabs;               // (uniform; FAST: a full slab by construction, no row selects)
         const int k0 = kbeg + slab * BK;
-        const bool tail = slab >= full_slabs;               // (uniform)
-#pragma unroll
-        for (int v = 0; v < AV; ++v) {
-            const int u = wave + 4 * v;
-            const int off = (((u & 7) * MB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
+        // the staged quad becomes "defined" HERE: the split is pure arithmetic, and without the pin instruction selection places it right behind the load
+        // (every wave then sits on the latency of the load it has just issued)
+        if (c < AV) asm volatile("" : "+v"(ra[S][c].x), "+v"(ra[S][c].y), "+v"(ra[S][c].z), "+v"(ra[S][c].w));
+        else asm volatile("" : "+v"(rb[S][c - AV].x), "+v"(rb[S][c - AV].y), "+v"(rb[S][c - AV].z), "+v"(rb[S][c - AV].w));
+        if (c < AV) {
+            const int v = c, u = wave + 4 * v;
             if (tail && k0 + 4 * (u & 7) + kr >= kend) ra[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (CS) { float4& c = cs[(4 * v) >> 3]; c.x += ra[S][v].x; c.y += ra[S][v].y; c.z += ra[S][v].z; c.w += ra[S][v].w; }
-            uint2 hi, lo;
-            split4(ra[S][v], hi, lo);
-            *reinterpret_cast<uint2*>(base + off) = hi;
-            if (P == 2) *reinterpret_cast<uint2*>(base + A_PLANE + off) = lo;
-        }
-        char* bb = base + P * A_PLANE;
-#pragma unroll
-        for (int v = 0; v < BV; ++v) {
-            const int u = wave + 4 * v;
-            const int off = (((u & 7) * NB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
+            if (CS) { float4& q = cs[(4 * v) >> 3]; q.x += ra[S][v].x; q.y += ra[S][v].y; q.z += ra[S][v].z; q.w += ra[S][v].w; }
+            split4(ra[S][v], shi[c], slo[c]);
+        } else {
+            const int v = c - AV, u = wave + 4 * v;
             if (tail && k0 + 4 * (u & 7) + kr >= kend) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (CONVB && !((bmask[S] >> v) & 1u)) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint2 hi, lo;
-            split4(rb[S][v], hi, lo);
-            *reinterpret_cast<uint2*>(bb + off) = hi;
-            if (P == 2) *reinterpret_cast<uint2*>(bb + B_PLANE + off) = lo;
+            split4(rb[S][v], shi[c], slo[c]);
         }
+    };
+    auto write_chunk = [&](int c, int slab) __attribute__((always_inline)) {
+        char* base = smem + (slab & 1) * STAGE;
+        if (c < AV) {
+            const int u = wave + 4 * c;
+            const int off = (((u & 7) * MB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
+            *reinterpret_cast<uint2*>(base + off) = shi[c];
+            if (P == 2) *reinterpret_cast<uint2*>(base + A_PLANE + off) = slo[c];
+        } else {
+            const int u = wave + 4 * (c - AV);
+            const int off = (((u & 7) * NB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
+            char* bb = base + P * A_PLANE;
+            *reinterpret_cast<uint2*>(bb + off) = shi[c];
+            if (P == 2) *reinterpret_cast<uint2*>(bb + B_PLANE + off) = slo[c];
+        }
+    };
+    auto store = [&](int slab, auto setc) __attribute__((always_inline)) {      // (prologue only)
+        using SLOWT = std::integral_constant<bool, false>;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { split_chunk(c, slab, setc, SLOWT{}); write_chunk(c, slab); }
     };
     // fragment addresses (bytes inside a plane) of this lane for k-step 0, read 0, tile 0
     const int a_off = ((2 * lhi) * MB + wm0 / 16 + ((lane >> 4) & 1)) * 128 + l15 * 8;
@@ -186,12 +240,17 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
         const v8i16 r = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         return __builtin_bit_cast(bf16x8_t, r);
     };
-    auto mma = [&](int stage) __attribute__((always_inline)) {
+    // One slab period: the MFMAs of the slab in LDS stage `stage` WOVEN with the split of the next slab (register set S, LDS stage `stage ^ 1`).  A wave can
+    // issue VALU work while its own MFMA runs its 8 passes, and with ~1.5 workgroups per CU there is often no second wave on the SIMD to fill either phase:
+    // the order is fixed here, MFMA by MFMA (scheduling barriers), with the NCH float4 splits spread evenly over the 2 x NM MFMAs.  The LDS stores of the
+    // new slab follow the period's last fragment read (k-step 1); what was split before that waits in the registers its float4 came in.
+    auto period = [&](int stage, int slab, auto setc, auto fastc) __attribute__((always_inline)) {
         const char* base = smem + stage * STAGE;
         const char* Ahi = base; const char* Alo = base + A_PLANE;
         const char* Bhi = base + P * A_PLANE; const char* Blo = Bhi + B_PLANE;
+        constexpr int NP = P == 2 ? 3 : 1, NM = NP * WTM * WTN, KS = BK / 16;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8_t ah[WTM], al[WTM], bh[WTN], bl[WTN];
 #pragma unroll
             for (int i = 0; i < WTM; ++i) {
@@ -205,39 +264,57 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
                 bh[j] = read8(Bhi, off, NB);
                 if (P == 2) bl[j] = read8(Blo, off, NB);
             }
-            if (P == 2) {
+            if (ks == KS - 1) {              // the last fragment reads are issued: the chunks split so far may go to the other stage
 #pragma unroll
-                for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                for (int c = 0; c < NCH; ++c)
+                    if (((KS - 1) * NM * NCH) / (KS * NM) > c) write_chunk(c, slab);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < WTM; ++i)
+            for (int m = 0; m < NM; ++m) {
+                const int pass = m / (WTM * WTN), ij = m % (WTM * WTN), i = ij / WTN, j = ij % WTN;
+                // pass order as before: lo*hi, hi*lo, hi*hi (same-accumulator MFMAs stay WTM x WTN apart)
+                if (P == 2 && pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                else if (P == 2 && pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                const int g = ks * NM + m;                                   // MFMAs issued before this one
+                const int c0 = (g * NCH) / (KS * NM), c1 = ((g + 1) * NCH) / (KS * NM);      // chunks [c0, c1) ride behind this MFMA
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                for (int c = 0; c < NCH; ++c)
+                    if (c >= c0 && c < c1) {
+                        split_chunk(c, slab, setc, fastc);
+                        if (ks == KS - 1) write_chunk(c, slab);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    using FAST = std::integral_constant<bool, true>;
+    using SLOW = std::integral_constant<bool, false>;
     // branch-free pipeline over an EVEN number of slabs (an odd count gets one phantom slab of zeros): slab i in LDS stage i & 1,
     // the loads of slab i+2 in flight while slab i is multiplied and slab i+1 is split into the other stage; one barrier per slab
-    load(0, S0{});
-    load(1, S1{});
+    load(0, S0{}, SLOW{});
+    load(1, S1{}, SLOW{});
     store(0, S0{});
     __syncthreads();
-    for (int i = 0; i < nslab; i += 2) {
-        load(i + 2, S0{});
-        mma(0);
-        store(i + 1, S1{});
+    int it = 0;
+    for (; it + 3 < full_slabs; it += 2) {          // full slabs only: the period touches slabs it+1 .. it+3 (splits it+1, it+2; loads it+2, it+3)
+        load(it + 2, S0{}, FAST{});
+        period(0, it + 1, S1{}, FAST{});
         __syncthreads();
-        load(i + 3, S1{});
-        mma(1);
-        store(i + 2, S0{});
+        load(it + 3, S1{}, FAST{});
+        period(1, it + 2, S0{}, FAST{});
+        __syncthreads();
+    }
+    for (; it < nslab; it += 2) {                   // the end of the K range: clamped addresses, rows past the end zeroed
+        load(it + 2, S0{}, SLOW{});
+        period(0, it + 1, S1{}, SLOW{});
+        __syncthreads();
+        load(it + 3, S1{}, SLOW{});
+        period(1, it + 2, S0{}, SLOW{});
         __syncthreads();
     }
 
@@ -282,7 +359,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
 }
 
 int g_tn_enable = 1, g_tn_force_cfg = -1, g_tn_force_splits = 0;
-int g_tn_grid_xcd = -1;          // -1: from MDVIT_TN_GRID_XCD at the first launch (unset / 1: whole-grid XCD order for <= 8 tiles per split; 0: never; 2: always)
+int g_tn_grid_xcd = -1;          // -1: from MDVIT_TN_GRID_XCD (default 1) at the first launch
 
 struct TnPlan { int cfg, tiles_m, tiles_n, splits, kps; };
 const int TN_BM[4] = {128, 128, 64, 64}, TN_BN[4] = {128, 64, 128, 64};
@@ -342,8 +419,8 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
     a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum_a; a.bias = d->bias;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K;
     a.kps = pl.kps; a.splits = pl.splits; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.accumulate = d->accumulate;
-    if (g_tn_grid_xcd < 0) { const char* e = getenv("MDVIT_TN_GRID_XCD"); g_tn_grid_xcd = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
-    a.grid_xcd = g_tn_grid_xcd == 2 || (g_tn_grid_xcd == 1 && pl.tiles_m * pl.tiles_n <= 8 && pl.splits > 1);
+    if (g_tn_grid_xcd < 0) { const char* e = getenv("MDVIT_TN_GRID_XCD"); g_tn_grid_xcd = (e && e[0] == '0') ? 0 : 1; }
+    a.grid_xcd = g_tn_grid_xcd;
     if (d->conv_c > 0) {
         a.cv_c = d->conv_c; a.cv_h = d->conv_h; a.cv_w = d->conv_w; a.cv_ho = d->conv_ho; a.cv_wo = d->conv_wo; a.cv_s = d->conv_stride; a.cv_d = d->conv_dilation;
     }
