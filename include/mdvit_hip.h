@@ -124,6 +124,10 @@ int mdvit_gemm_kernel_name(const MdvitGemmDesc* d, char* out, int32_t cap);
  * kernel (gemm_tn.hip: k-major LDS image read through ds_read_b64_tr_b16).  enable = 0 routes them through the general template
  * again; cfg 0..3 = tile 128x128 / 128x64 / 64x128 / 64x64 (-1: planner), splits > 0 forces the K-split (A/B and sweep hook). */
 int mdvit_gemm_tn_config(int32_t enable, int32_t cfg, int32_t splits);
+/* Workgroup order of the same kernel over the 8 XCDs: 1 (default; also env MDVIT_TN_GRID_XCD) = the tiles of one K-split are neighbours on one XCD when a
+ * split has <= 8 tiles (they read the same token rows), 0 = XCD-contiguous inside a split only, 2 = whole-grid order always, -1 = back to the environment's
+ * choice.  Results do not depend on it (tile arithmetic and the slab reduction order are the same): A/B and test hook. */
+int mdvit_gemm_tn_grid_order(int32_t mode);
 int mdvit_gemm_f32(const MdvitGemmDesc* desc, void* stream);
 /* Weight layouts of the implicit 3x3 convolution: w [Cout, Cin, 3, 3] (PyTorch) ->
  *   mode 0: out [Cout][tap][Cin]                    (forward:        y = conv(x, w))

@@ -149,6 +149,7 @@ _SIGS = {
     "mdvit_conv_weight_relayout_many": [vp, i32, i32, vp],
     "mdvit_gemm_kernel_name": [vp, C.c_char_p, i32],
     "mdvit_gemm_tn_config": [i32, i32, i32],
+    "mdvit_gemm_tn_grid_order": [i32],
     "mdvit_transpose_f32": [vp, i64, vp, i32, i32, vp],
     "mdvit_mlp_bwd_dgrad_f32": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
     "mdvit_mlp_fwd_f32": [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],

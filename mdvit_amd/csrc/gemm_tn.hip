@@ -381,6 +381,11 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
     return MDVIT_OK;
 }
 
+extern "C" int mdvit_gemm_tn_grid_order(int32_t mode) {
+    g_tn_grid_xcd = (mode >= 0 && mode <= 2) ? mode : -1;
+    return MDVIT_OK;
+}
+
 extern "C" int mdvit_gemm_tn_config(int32_t enable, int32_t cfg, int32_t splits) {
     g_tn_enable = enable != 0;
     g_tn_force_cfg = (cfg >= 0 && cfg <= 3) ? cfg : -1;

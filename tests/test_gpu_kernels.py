@@ -1232,6 +1232,39 @@ def test_wgrad_tn_kernel_every_tile_and_split_vs_fp64_and_bitwise_repeatable(sha
         lib.mdvit_gemm_tn_config(1, -1, 0)
 
 
+@pytest.mark.parametrize("shape", [(192, 64, 8192), (1024, 128, 4096), (64, 512, 5000), (320, 320, 3000), (512, 512, 4096), (100, 36, 2050)])
+def test_wgrad_tn_workgroup_order_over_the_xcds_does_not_change_a_bit(shape):
+    """mdvit_gemm_tn_grid_order: the logical (K-split, tile) pair of a workgroup taken from the XCD-contiguous order of the whole grid (the tiles of a split
+    share one L2) or from the order inside a split -- the same tiles, the same slab reduction order: C and the column sums are identical to the last bit,
+    with the planner's splits and with forced ones (ragged last split included)."""
+    from mdvit_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M + 5 * N + K)
+    A = torch.randn((K, M), generator=g).to(dev()); B = torch.randn((K, N), generator=g).to(dev())
+    out0 = torch.randn((M, N), generator=g).to(dev()); cs0 = torch.randn((M,), generator=g).to(dev())
+
+    def run():
+        out, cs = out0.clone(), cs0.clone()
+        ops.gemm(ops._p(A), ops._p(B), ops._p(out), M, N, K, lda=M, ldb=N, ldc=N, trans_a=True, trans_b=False, allow_split=True,
+                 accumulate=True, precision=1, colsum_a=ops._p(cs))
+        return out, cs
+    try:
+        for sp in (0, 5, 16):
+            lib.mdvit_gemm_tn_config(1, -1, sp)
+            res = []
+            for mode in (0, 2, 1):
+                lib.mdvit_gemm_tn_grid_order(mode)
+                res.append(run())
+            for (o, c), mode in zip(res[1:], (2, 1)):
+                assert torch.equal(o, res[0][0]) and torch.equal(c, res[0][1]), f"splits {sp}: grid order {mode} differs from order 0"
+        ref = out0.double() + A.double().t() @ B.double()
+        check(res[0][0], ref.float(), tol=2e-5, name="vs fp64")
+    finally:
+        lib.mdvit_gemm_tn_config(1, -1, 0)
+        lib.mdvit_gemm_tn_grid_order(-1)
+
+
 def test_wgrad_tn_kernel_strided_operands_and_single_plane():
     """operands that are column blocks of wider tensors (lda > M, ldb > N), overwrite (no accumulate), and the one-bf16-plane mode"""
     from mdvit_amd import ops
