@@ -297,9 +297,23 @@ TnPlan plan_tn(int M, int N, int K, int allow_split) {
         if (cost < best_cost) { best_cost = cost; best.cfg = c; best.tiles_m = (int)tm; best.tiles_n = (int)tn; }
     }
     const long tiles = (long)best.tiles_m * best.tiles_n;
-    // 1.5 workgroups per CU in total (tools/tn_check.py --sweep: 256 .. 512 workgroups is the optimum on every shape of the model),
-    // at least 8 slabs of 32 tokens each per workgroup
-    long want = g_tn_force_splits > 0 ? g_tn_force_splits : (384 + tiles - 1) / tiles;
+    // Workgroups in total: ~1.5 per CU (384).  ALONE on the GPU the kernel prefers a whole multiple of the 256 CUs from below (tools/tn_plan_sweep.py, every
+    // shape of the model x every tile x 128 .. 1024 workgroups: minima at <= 256 and <= 512, 320 - 384 are 8 - 15 % slower -- the CUs that get a second
+    // workgroup set the kernel's time), but the weight gradients run on the side stream NEXT to the data-gradient chain, and there the rule that wins alone
+    // loses: three interleaved A/B pairs of the bench step, 384: 431.7 / 430.5 / 430.4 images/s, CU multiples: 429.2 / 427.7 / 428.7
+    // (MDVIT_TN_WORKGROUPS=-1 selects the CU-multiple rule, N > 0 another total: A/B hook).  At least 8 slabs of 32 tokens each per workgroup.
+    static const int total_env = [] { const char* e = getenv("MDVIT_TN_WORKGROUPS"); return e ? atoi(e) : 0; }();
+    long want;
+    if (total_env < 0) {
+        const long target = (best.cfg == 0 || tiles == 1) ? 256 : 512;       // 128 x 128 tiles (two fit a CU) and single-tile outputs: one per CU; smaller tiles: two
+        want = target / tiles;
+        if (want * tiles * 4 < target * 3) want = 2 * target / tiles;
+        if (want < 1) want = 1;
+    } else {
+        const long total = total_env > 0 ? total_env : 384;
+        want = (total + tiles - 1) / tiles;
+    }
+    if (g_tn_force_splits > 0) want = g_tn_force_splits;
     const long max_sp = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
     if (want > max_sp) want = max_sp;
     if (want > 1024) want = 1024;
