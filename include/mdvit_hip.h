@@ -104,6 +104,10 @@ typedef struct MdvitGemmDesc {
      * divisible, else contributes 0: the data gradient of a stride-conv_up convolution (a transposed convolution) as the same
      * implicit GEMM over the INPUT pixels (conv_ho x conv_wo), image = dy (conv_h x conv_w), conv_stride = 1.  0 / 1 = off. */
     int32_t conv_up;
+    /* TN, precision 1 only: that operand is stored as bf16 ([K, M] / [K, N] of 2-byte elements behind the float pointer, leading dimension in elements,
+     * % 4 == 0): the saved hidden activations of the "mixed" mode (MdvitBlockDesc.store_bf16).  It enters the product as its single bf16 plane (two
+     * MFMAs per product instead of three); at most one of the two. */
+    int32_t a_bf16, b_bf16;
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
@@ -255,6 +259,18 @@ int mdvit_mlp_rc_fwd_ln(const float* x2, const float* gamma, const float* beta, 
  * du == NULL (data-gradient-only sweep) moves no [tokens, hidden] tensor.  hidden % 32 == 0. */
 int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
                          int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
+/* The three kernels above with the [tokens, hidden] tensor they leave for the weight-gradient GEMMs -- h = drop1(gelu(u)) of the forward, du of the backward --
+ * stored as bf16 (2-byte elements behind the float pointer; what is stored is the hi plane the kernel forms for its own second product, so y / dx do not
+ * change by a bit).  The "mixed" mode of BASELINE configs[3] (MdvitBlockDesc.store_bf16); consumed by mdvit_gemm_f32 with MdvitGemmDesc.a_bf16 / b_bf16. */
+int mdvit_mlp_rc16_fwd_hbf16(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
+                             int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                             uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream);
+int mdvit_mlp_rc_fwd_ln_hbf16(const float* x2, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+                              const void* W1p, const float* b1, const void* W2p, const float* b2, const float* rowscale, int32_t rows_per_scale, float* h, float* y,
+                              int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1,
+                              const uint32_t* drop_seed, void* stream);
+int mdvit_mlp_rc16_dgrad_hbf16(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
+                               int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
 size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
 /* tuning hook (tools/mlp_rc_check.py): forward kernel variant -- 2: software-pipelined waves at 2 per SIMD, 3: plain waves at 3 per SIMD */
 int mdvit_mlp_rc_config(int32_t fwd_variant);
@@ -287,6 +303,10 @@ typedef struct MdvitBlockDesc {
     const float *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;
     const void *fc1_p, *fc2_p, *fc2t_p, *fc1t_p;
     const void *qkv_p, *proj_p, *projt_p;      /* optional bf16 planes of Wqkv, Wproj, Wproj^T: C = 64 / 128 run qkv / proj / proj's data gradient on mdvit_linear_rc */
+    int32_t store_bf16;                        /* "mixed" mode (BASELINE configs[3]): the C = 128 MLP's saved hidden activation h and its gradient du -- the two
+                                                * [tokens, hidden] tensors the block still moves, operands of weight-gradient GEMMs only -- are stored as bf16:
+                                                * y and dx do not change by a bit, the fc1 / fc2 weight (and fc1 bias) gradients see bf16-rounded operands
+                                                * (~2e-3 relative).  Ignored where the block has no such tensor (C = 64) or the 16-token MLP kernels do not run. */
 } MdvitBlockDesc;
 /* Gradient outputs of the backward.  The sixteen "weight-class" outputs (cpe, qkv, crpe windows, proj, fc1, fc2) are overwritten
  * (accumulate == 0: fresh buffers) or added into (accumulate != 0: gradient buckets; the weight-gradient kernels then run on the side

@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("rc_a", vp), ("rc_lda", i64), ("rc_b", vp), ("rc_ldb", i64), ("rc_bias", vp), ("rc_k", i32),
         ("conv_c", i32), ("conv_h", i32), ("conv_w", i32), ("conv_ho", i32), ("conv_wo", i32), ("conv_stride", i32), ("conv_dilation", i32),
         ("conv_up", i32),
+        ("a_bf16", i32), ("b_bf16", i32),
     ]
 
 
@@ -76,7 +77,8 @@ class BlockDesc(C.Structure):
                    ("rowscale1", vp), ("rowscale2", vp), ("label", vp)]
                 + [(n, vp) for n in ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",
                                      "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
-                + [(n, vp) for n in ("qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "fc1_p", "fc2_p", "fc2t_p", "fc1t_p", "qkv_p", "proj_p", "projt_p")])
+                + [(n, vp) for n in ("qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "fc1_p", "fc2_p", "fc2t_p", "fc1t_p", "qkv_p", "proj_p", "projt_p")]
+                + [("store_bf16", i32)])
 
 
 BLOCK_PARAMS = ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",
@@ -106,6 +108,9 @@ _SIGS = {
     "mdvit_mlp_rc16_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
     "mdvit_mlp_rc_dgrad": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
     "mdvit_mlp_rc16_dgrad": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
+    "mdvit_mlp_rc_fwd_ln_hbf16": [vp, vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
+    "mdvit_mlp_rc16_fwd_hbf16": [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
+    "mdvit_mlp_rc16_dgrad_hbf16": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
     "mdvit_mlp_rc_wgrad": [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_imgconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_imgconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],

@@ -35,6 +35,9 @@ inline bool mlp_rc16(const MdvitBlockDesc& d) {
            (long)d.B * d.H * d.W * d.hidden < (1L << 32);
 }
 
+// "mixed" mode: h and du of the C = 128 MLP as bf16 (they exist only on the 16-token kernels' path)
+inline bool hbf16(const MdvitBlockDesc& d) { return d.store_bf16 && mlp_rc16(d); }
+
 struct Saved {        // the block's saved-for-backward tensors inside the caller's `save` buffer
     float *x1, *mean1, *rstd1, *cur1, *qkv, *a, *att, *U, *kmax, *ksum, *Mmat, *x2, *mean2, *rstd2, *cur2, *h, *u;
 };
@@ -48,7 +51,7 @@ void layout_saved(const MdvitBlockDesc& d, Arena& A, Saved& s) {
     s.att = A.take(T * C); s.U = A.take(T * C);
     s.kmax = A.take((long)d.B * C); s.ksum = A.take((long)d.B * C); s.Mmat = A.take((long)d.B * C * Ch);
     s.x2 = A.take(T * C); s.mean2 = A.take(T); s.rstd2 = A.take(T); s.cur2 = A.take(T * C);
-    s.h = mode != MLP_RC ? A.take(T * d.hidden) : nullptr;
+    s.h = mode != MLP_RC ? A.take(hbf16(d) ? (T * d.hidden + 1) / 2 : T * d.hidden) : nullptr;
     s.u = mode == MLP_STORED ? A.take(T * d.hidden) : nullptr;
 }
 
@@ -87,9 +90,11 @@ int gemm_dgrad(Arena& A, const MdvitBlockDesc& d, MdvitGemmDesc& g, const float*
 }
 
 // dW[N,K] (+)= gy[M,N]^T x[M,K], db[N] += colsum(gy)  -- the TN launch of ops._Linear.backward
-int gemm_wgrad(Arena& A, const MdvitBlockDesc& d, const float* gy, const float* x, float* dW, float* db, int M, int N, int K, int accumulate, hipStream_t s) {
+int gemm_wgrad(Arena& A, const MdvitBlockDesc& d, const float* gy, const float* x, float* dW, float* db, int M, int N, int K, int accumulate, hipStream_t s,
+               int gy_bf16 = 0, int x_bf16 = 0) {
     MdvitGemmDesc g;
     gemm_init(g, d);
+    g.a_bf16 = gy_bf16; g.b_bf16 = x_bf16;
     g.A = gy; g.B = x; g.C = dW; g.M = N; g.N = K; g.K = M; g.lda = N; g.ldb = K; g.ldc = K;
     g.trans_a = 1; g.trans_b = 0; g.allow_split = 1; g.accumulate = accumulate; g.colsum_a = db;
     const size_t need = mdvit_gemm_ws_bytes(&g);
@@ -162,8 +167,12 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
     const uint32_t* seed = d.drop_p > 0.f ? d.drop_seed : nullptr;
     if (ln_prologue && (mode == MLP_RC || mlp_rc16(d)) && d.hidden % 64 == 0) {
         // LN2 in the MLP kernel's prologue: the rows are normalised in the registers they are multiplied from (cur2 is still written: the backward kernels read it)
-        BLK_RUN(mdvit_mlp_rc_fwd_ln(sv.x2, d.n2_g, d.n2_b, d.ln_groups, d.eps, sv.mean2, sv.rstd2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, d.rowscale2, N_tok,
-                                    mode == MLP_RC ? nullptr : sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], d.key_fc2[0], d.key_fc2[1], seed, s));
+        if (hbf16(d))
+            BLK_RUN(mdvit_mlp_rc_fwd_ln_hbf16(sv.x2, d.n2_g, d.n2_b, d.ln_groups, d.eps, sv.mean2, sv.rstd2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, d.rowscale2, N_tok,
+                                              sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], d.key_fc2[0], d.key_fc2[1], seed, s));
+        else
+            BLK_RUN(mdvit_mlp_rc_fwd_ln(sv.x2, d.n2_g, d.n2_b, d.ln_groups, d.eps, sv.mean2, sv.rstd2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, d.rowscale2, N_tok,
+                                        mode == MLP_RC ? nullptr : sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], d.key_fc2[0], d.key_fc2[1], seed, s));
         return MDVIT_OK;
     }
     BLK_RUN(mdvit_layernorm_fwd(sv.x2, d.n2_g, d.n2_b, sv.cur2, sv.mean2, sv.rstd2, M, C, d.ln_groups, d.eps, s));
@@ -171,8 +180,12 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
         BLK_RUN(mdvit_mlp_rc_fwd(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1],
                                  d.key_fc2[0], d.key_fc2[1], seed, s));
     } else if (mlp_rc16(d)) {
-        BLK_RUN(mdvit_mlp_rc16_fwd(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1],
-                                   d.key_fc2[0], d.key_fc2[1], seed, s));
+        if (hbf16(d))
+            BLK_RUN(mdvit_mlp_rc16_fwd_hbf16(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0],
+                                             d.key_fc1[1], d.key_fc2[0], d.key_fc2[1], seed, s));
+        else
+            BLK_RUN(mdvit_mlp_rc16_fwd(sv.cur2, d.fc1_p, d.fc1_b, d.fc2_p, d.fc2_b, sv.x2, d.rowscale2, N_tok, sv.h, y, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1],
+                                       d.key_fc2[0], d.key_fc2[1], seed, s));
     } else {
         MdvitGemmDesc g;
         gemm_init(g, d);
@@ -252,10 +265,13 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         if (masked) BLK_RUN(mdvit_colsum_f32(dy, C, nullptr, gm2, nullptr, 0, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok, 0, seed, s));
         MdvitGemmDesc g;
         int rc = MDVIT_OK;
+        const bool hb = hbf16(d);
+        if (hb && !(d.fc2t_p && d.fc1t_p)) return mdvit_set_error(MDVIT_E_SHAPE, "block_bwd: store_bf16 needs the transposed fc weight planes (the 16-token MLP backward)");
         if (mlp_rc16(d) && d.fc2t_p && d.fc1t_p) {
             // u recomputed, du = (gm W2) * gelu'(u) * mask and dcur2 = du W1 in one kernel; du reaches HBM only for the weight gradients
-            du = want_w ? S.take(T * Hd) : nullptr;
-            BLK_RUN(mdvit_mlp_rc16_dgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, du, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
+            du = want_w ? S.take(hb ? (T * Hd + 1) / 2 : T * Hd) : nullptr;
+            if (hb) BLK_RUN(mdvit_mlp_rc16_dgrad_hbf16(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, du, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
+            else BLK_RUN(mdvit_mlp_rc16_dgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, du, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
         } else {
             du = S.take(T * Hd);
             gemm_init(g, d);
@@ -272,8 +288,8 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
         if (want_w) {
             if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
-            rc = gemm_wgrad(S, d, gm2, sv.h, G.fc2_w, G.fc2_b, M, C, Hd, acc, side);
-            if (rc == MDVIT_OK) rc = gemm_wgrad(S, d, du, sv.cur2, G.fc1_w, G.fc1_b, M, Hd, C, acc, side);
+            rc = gemm_wgrad(S, d, gm2, sv.h, G.fc2_w, G.fc2_b, M, C, Hd, acc, side, 0, hb);
+            if (rc == MDVIT_OK) rc = gemm_wgrad(S, d, du, sv.cur2, G.fc1_w, G.fc1_b, M, Hd, C, acc, side, hb, 0);
             if (rc != MDVIT_OK) return rc;
         }
     }

@@ -305,6 +305,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
         }
     }
     if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_launch(d, s);
+    MDVIT_CHECK_ARG(!d->a_bf16 && !d->b_bf16, MDVIT_E_SHAPE, "gemm: bf16-stored operands are a layout of the weight-gradient (TN, precision 1) kernel only");
 
     const GemmPlan pl = plan_gemm(d);
     a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;

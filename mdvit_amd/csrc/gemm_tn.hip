@@ -52,8 +52,11 @@ __device__ __forceinline__ void split4(const float4 x, uint2& hi, uint2& lo) {
 
 typedef __attribute__((address_space(3))) v4i16* lds_v4i16_ptr;
 
-template <int BM, int BN, int P, bool CS, bool CONVB>
+// ABF / BBF: that operand is stored as bf16 in HBM ([K, M] / [K, N] of 2-byte elements, leading dimension in elements) -- the "mixed" mode's saved hidden
+// activations of the C = 128 MLP (block.hip: store_bf16).  Its quads are loaded as 8 bytes, go to the hi plane unchanged, and its lo-plane MFMA is skipped.
+template <int BM, int BN, int P, bool CS, bool CONVB, bool ABF = false, bool BBF = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 16384 ? 2 : (BM * BN == 8192 ? 3 : 4), 8))) void gemm_tn_kernel(TnArgs p) {
+    static_assert(!(CONVB && BBF) && (P == 2 || !(ABF || BBF)), "bf16-stored operands: plain TN products of the bf16x3 mode");
     constexpr int MB = BM / 16, NB = BN / 16;                     // 16-column blocks per k-quad
     constexpr int A_PLANE = BK * BM * 2, B_PLANE = BK * BN * 2;   // bytes of one bf16 plane of one slab
     constexpr int STAGE = P * (A_PLANE + B_PLANE);
@@ -122,7 +125,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
 #pragma unroll
         for (int v = 0; v < AV; ++v) {
             const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
-            ra[S][v] = *reinterpret_cast<const float4*>(p.A + (long)min(k, kend - 1) * p.lda + m);
+            if (ABF) {
+                const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.A) + (long)min(k, kend - 1) * p.lda + m);
+                ra[S][v] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), 0.f, 0.f);          // (bit containers)
+            } else {
+                ra[S][v] = *reinterpret_cast<const float4*>(p.A + (long)min(k, kend - 1) * p.lda + m);
+            }
         }
         if (CONVB) {
             uint32_t ok = 0;
@@ -142,7 +150,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
 #pragma unroll
             for (int v = 0; v < BV; ++v) {
                 const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
-                rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+                if (BBF) {
+                    const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.B) + (long)min(k, kend - 1) * p.ldb + n);
+                    rb[S][v] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), 0.f, 0.f);
+                } else {
+                    rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);          // keep the loads HERE: the scheduler otherwise sinks them next to their LDS stores
@@ -157,6 +170,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
             const int u = wave + 4 * v;
             const int off = (((u & 7) * MB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
             if (tail && k0 + 4 * (u & 7) + kr >= kend) ra[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ABF) {
+                const uint32_t b0 = __float_as_uint(ra[S][v].x), b1 = __float_as_uint(ra[S][v].y);
+                if (CS) {
+                    float4& c = cs[(4 * v) >> 3];
+                    c.x += __uint_as_float(b0 << 16); c.y += __uint_as_float(b0 & 0xffff0000u); c.z += __uint_as_float(b1 << 16); c.w += __uint_as_float(b1 & 0xffff0000u);
+                }
+                *reinterpret_cast<uint2*>(base + off) = make_uint2(b0, b1);
+                continue;
+            }
             if (CS) { float4& c = cs[(4 * v) >> 3]; c.x += ra[S][v].x; c.y += ra[S][v].y; c.z += ra[S][v].z; c.w += ra[S][v].w; }
             uint2 hi, lo;
             split4(ra[S][v], hi, lo);
@@ -170,6 +192,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
             const int off = (((u & 7) * NB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
             if (tail && k0 + 4 * (u & 7) + kr >= kend) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (CONVB && !((bmask[S] >> v) & 1u)) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BBF) {
+                *reinterpret_cast<uint2*>(bb + off) = make_uint2(__float_as_uint(rb[S][v].x), __float_as_uint(rb[S][v].y));
+                continue;
+            }
             uint2 hi, lo;
             split4(rb[S][v], hi, lo);
             *reinterpret_cast<uint2*>(bb + off) = hi;
@@ -197,19 +223,21 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
             for (int i = 0; i < WTM; ++i) {
                 const int off = a_off + (4 * ks * MB + 2 * i) * 128;
                 ah[i] = read8(Ahi, off, MB);
-                if (P == 2) al[i] = read8(Alo, off, MB);
+                if (P == 2 && !ABF) al[i] = read8(Alo, off, MB);
             }
 #pragma unroll
             for (int j = 0; j < WTN; ++j) {
                 const int off = b_off + (4 * ks * NB + 2 * j) * 128;
                 bh[j] = read8(Bhi, off, NB);
-                if (P == 2) bl[j] = read8(Blo, off, NB);
+                if (P == 2 && !BBF) bl[j] = read8(Blo, off, NB);
             }
-            if (P == 2) {
+            if (P == 2 && !BBF) {
 #pragma unroll
                 for (int i = 0; i < WTM; ++i)
 #pragma unroll
                     for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            }
+            if (P == 2 && !ABF) {
 #pragma unroll
                 for (int i = 0; i < WTM; ++i)
 #pragma unroll
@@ -345,11 +373,19 @@ void mdvit_gemm_tn_plan(const MdvitGemmDesc* d, int* tile_m, int* tile_n, int* s
 
 void mdvit_gemm_tn_name(const MdvitGemmDesc* d, char* out, int cap) {
     const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
+    if (d->a_bf16 || d->b_bf16) {
+        snprintf(out, cap, "gemm_tn_kernel<%d, %d, 2, %s, false, %s, %s>%s", TN_BM[pl.cfg], TN_BN[pl.cfg], d->colsum_a ? "true" : "false", d->a_bf16 ? "true" : "false",
+                 d->b_bf16 ? "true" : "false", pl.splits > 1 ? "+splitk_reduce" : "");
+        return;
+    }
     snprintf(out, cap, "gemm_tn_kernel<%d, %d, %d, %s, %s>%s", TN_BM[pl.cfg], TN_BN[pl.cfg], (d->precision == 2 && d->conv_c <= 0) ? 1 : 2,
              d->colsum_a ? "true" : "false", d->conv_c > 0 ? "true" : "false", pl.splits > 1 ? "+splitk_reduce" : "");
 }
 
 int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
+    if (d->a_bf16 || d->b_bf16)
+        MDVIT_CHECK_ARG(!(d->a_bf16 && d->b_bf16) && d->conv_c <= 0 && d->precision == 1 && d->lda % 4 == 0 && d->ldb % 4 == 0, MDVIT_E_SHAPE,
+                        "gemm (wgrad): a bf16-stored operand needs precision 1, no convolution, the other operand in fp32, leading dimensions %% 4 == 0");
     const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
     TnArgs a;
     memset(&a, 0, sizeof(a));
@@ -375,6 +411,12 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
         if (a.cv_c > 0) {                                                                                           \
             if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, true, true>), grid, block, 0, s, a);      \
             else MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, false, true>), grid, block, 0, s, a);              \
+        } else if (d->a_bf16) {                                                                                     \
+            if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, true, false, true, false>), grid, block, 0, s, a);      \
+            else MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, false, false, true, false>), grid, block, 0, s, a);              \
+        } else if (d->b_bf16) {                                                                                     \
+            if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, true, false, false, true>), grid, block, 0, s, a);      \
+            else MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, false, false, false, true>), grid, block, 0, s, a);              \
         } else if (one) { if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 1, true, false>), grid, block, 0, s, a);     \
                    else MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 1, false, false>), grid, block, 0, s, a); }           \
         else { if (a.colsum) MDVIT_TIMED_LAUNCH((gemm_tn_kernel<BM_, BN_, 2, true, false>), grid, block, 0, s, a);         \

@@ -200,6 +200,7 @@ struct RcArgs {
     const uint16_t* W1tp;   // planes of W1^T [2][C][Hd]   rows = c,      k = hidden    dx = du W1
     float* y; float* dx;
     float* du;              // rc16 dgrad: optional [tokens, hidden] copy of the hidden-layer gradient (the two weight-gradient GEMMs' operand)
+    int hbf;                // h / du are stored as bf16 (2-byte elements behind the float pointers)
     float* h;               // rc16 forward: optional [tokens, hidden] copy of drop1(gelu(u)) (the fc2 weight-gradient GEMM's operand)
     LnPro ln;               // forward kernels with the LayerNorm prologue (LNP): x is the LayerNorm's input
     float* part;            // wgrad: per-workgroup partial sums
@@ -1065,11 +1066,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
             }
-            if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = v; }
+            if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = v; }
             hv[4 * ht + 0] = v.x; hv[4 * ht + 1] = v.y; hv[4 * ht + 2] = v.z; hv[4 * ht + 3] = v.w;
         }
         rc_u4 hh4, hl4;
         rc_split8(hv, hh4, hl4);
+        if (STORE && p.hbf && row < p.M) {         // the hi plane IS bf16(h): two 8-byte stores (the two 4-unit groups of this lane) instead of two 16-byte ones
+            uint16_t* hb = reinterpret_cast<uint16_t*>(p.h) + (long)row * p.Hd + t * 32 + 4 * g;
+            *reinterpret_cast<uint2*>(hb) = make_uint2(hh4[0], hh4[1]);
+            *reinterpret_cast<uint2*>(hb + 16) = make_uint2(hh4[2], hh4[3]);
+        }
         const rc_bf16x8 hh = __builtin_bit_cast(rc_bf16x8, hh4), hl = __builtin_bit_cast(rc_bf16x8, hl4);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -1189,11 +1195,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
             }
-            if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.du + (long)row * p.Hd + hd) = v; }
+            if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.du + (long)row * p.Hd + hd) = v; }
             dv[4 * ht + 0] = v.x; dv[4 * ht + 1] = v.y; dv[4 * ht + 2] = v.z; dv[4 * ht + 3] = v.w;
         }
         rc_u4 dh4, dl4;
         rc_split8(dv, dh4, dl4);
+        if (STORE && p.hbf && row < p.M) {
+            uint16_t* db = reinterpret_cast<uint16_t*>(p.du) + (long)row * p.Hd + t * 32 + 4 * g;
+            *reinterpret_cast<uint2*>(db) = make_uint2(dh4[0], dh4[1]);
+            *reinterpret_cast<uint2*>(db + 16) = make_uint2(dh4[2], dh4[3]);
+        }
         const rc_bf16x8 dh = __builtin_bit_cast(rc_bf16x8, dh4), dl = __builtin_bit_cast(rc_bf16x8, dl4);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -1473,7 +1484,7 @@ extern "C" int mdvit_linear_rc_ln(const float* x, const float* gamma, const floa
 
 /* The MLP forward on 16-token waves, built for C = 64 and C = 128 (mpvit.py:71-78 inside mdvit.py:357-360); h != NULL also writes
  * h = drop1(gelu(x W1^T + b1)) [M, hidden] for the fc2 weight-gradient GEMM (the forward never re-reads it). */
-extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
+static int rc16_fwd_impl(int hbf, const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
                                   int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
                                   uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream) {
     MDVIT_CHECK_ARG(C == 64 || C == 128, MDVIT_E_SHAPE, "mlp_rc16_fwd: built for C = 64 / 128 (got %d)", C);
@@ -1485,6 +1496,7 @@ extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* 
     RcArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2p = (const uint16_t*)W2p; a.b2 = b2; a.res = res; a.rowscale = rowscale; a.y = y; a.h = h;
+    a.hbf = hbf && h;
     a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     rc_fill(a, M, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed);
     constexpr int NW = 8;
@@ -1499,7 +1511,7 @@ extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* 
         if (rc != MDVIT_OK) return rc;                                                                                               \
         hipLaunchKernelGGL((mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV>), grid, block, smem, s, a);                             \
     } while (0)
-    if (C == 128 && g_rc_fwd128_variant == 32) {
+    if (C == 128 && g_rc_fwd128_variant == 32 && !a.hbf) {
         // 32-token waves on 32x32x16 tiles: the forward's registers allow it (x fragments 64 + y accumulator 64), and every weight fragment read
         // from LDS then serves twice the tokens of the 16-token form
         const int smem32 = 3 * 2 * (32 * 256) + 3 * 2 * (128 * 64) + Hd * 4;
@@ -1526,11 +1538,22 @@ extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* 
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
+extern "C" int mdvit_mlp_rc16_fwd(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
+                                  int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                                  uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream) {
+    return rc16_fwd_impl(0, x, W1p, b1, W2p, b2, res, rowscale, rows_per_scale, h, y, M, C, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed, stream);
+}
+/* the same with h stored as bf16 ([M, hidden] 2-byte elements behind the float pointer: the hi plane the kernel forms anyway) */
+extern "C" int mdvit_mlp_rc16_fwd_hbf16(const float* x, const void* W1p, const float* b1, const void* W2p, const float* b2, const float* res, const float* rowscale,
+                                  int32_t rows_per_scale, float* h, float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                                  uint32_t key2_0, uint32_t key2_1, const uint32_t* drop_seed, void* stream) {
+    return rc16_fwd_impl(1, x, W1p, b1, W2p, b2, res, rowscale, rows_per_scale, h, y, M, C, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed, stream);
+}
 
 /* The MLP forward with the LayerNorm in front of it fused into the prologue (LN2 -> Mlp of SerialBlock_adapt, mdvit.py:356-360): x2 [M, C] is the LayerNorm's
  * INPUT and the residual; writes mean / rstd [M], the normalised rows ln_out [M, C] (operand of the backward kernels) and y.  C = 64: mlp_rc_fwd3 (no
  * [tokens, hidden] tensor); C = 128: the 16-token kernel, h != NULL written as in mdvit_mlp_rc16_fwd.  mdvit_layernorm_fwd's arithmetic, sum for sum. */
-extern "C" int mdvit_mlp_rc_fwd_ln(const float* x2, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+static int rc_fwd_ln_impl(int hbf, const float* x2, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
                                    const void* W1p, const float* b1, const void* W2p, const float* b2, const float* rowscale, int32_t rows_per_scale, float* h,
                                    float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1,
                                    const uint32_t* drop_seed, void* stream) {
@@ -1543,6 +1566,7 @@ extern "C" int mdvit_mlp_rc_fwd_ln(const float* x2, const float* gamma, const fl
     RcArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x2; a.res = x2; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2p = (const uint16_t*)W2p; a.b2 = b2; a.rowscale = rowscale; a.y = y; a.h = h;
+    a.hbf = hbf && h;
     a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     a.ln = LnPro{gamma, beta, mean, rstd, ln_out, eps, M / groups};
     rc_fill(a, M, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed);
@@ -1575,10 +1599,23 @@ extern "C" int mdvit_mlp_rc_fwd_ln(const float* x2, const float* gamma, const fl
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
+extern "C" int mdvit_mlp_rc_fwd_ln(const float* x2, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+                                   const void* W1p, const float* b1, const void* W2p, const float* b2, const float* rowscale, int32_t rows_per_scale, float* h,
+                                   float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1,
+                                   const uint32_t* drop_seed, void* stream) {
+    return rc_fwd_ln_impl(0, x2, gamma, beta, groups, eps, mean, rstd, ln_out, W1p, b1, W2p, b2, rowscale, rows_per_scale, h, y, M, C, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed, stream);
+}
+/* the same with h (C = 128) stored as bf16 */
+extern "C" int mdvit_mlp_rc_fwd_ln_hbf16(const float* x2, const float* gamma, const float* beta, int32_t groups, float eps, float* mean, float* rstd, float* ln_out,
+                                   const void* W1p, const float* b1, const void* W2p, const float* b2, const float* rowscale, int32_t rows_per_scale, float* h,
+                                   float* y, int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, uint32_t key2_0, uint32_t key2_1,
+                                   const uint32_t* drop_seed, void* stream) {
+    return rc_fwd_ln_impl(1, x2, gamma, beta, groups, eps, mean, rstd, ln_out, W1p, b1, W2p, b2, rowscale, rows_per_scale, h, y, M, C, Hd, drop_p, key1_0, key1_1, key2_0, key2_1, drop_seed, stream);
+}
 
 /* The C = 128 (and C = 64) MLP's backward data path on 16-token waves: dx = ((gm W2) * gelu'(x W1^T + b1) * mask1) W1 in one kernel; du != NULL
  * also writes the hidden-layer gradient [M, hidden] (the operand of the two weight-gradient GEMMs of the full sweep). */
-extern "C" int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
+static int rc16_dgrad_impl(int hbf, const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
                                     int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream) {
     MDVIT_CHECK_ARG(C == 64 || C == 128, MDVIT_E_SHAPE, "mlp_rc16_dgrad: built for C = 64 / 128 (got %d)", C);
     MDVIT_CHECK_ARG(M > 0 && Hd >= 64 && Hd % 32 == 0 && Hd <= 4096, MDVIT_E_SHAPE, "mlp_rc16_dgrad: need M > 0, hidden %% 32 == 0, hidden <= 4096 (M=%d hidden=%d)", M, Hd);
@@ -1589,6 +1626,7 @@ extern "C" int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void*
     RcArgs a;
     memset(&a, 0, sizeof(a));
     a.gm = gm; a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2tp = (const uint16_t*)W2tp; a.W1tp = (const uint16_t*)W1tp; a.dx = dx; a.du = du;
+    a.hbf = hbf && du;
     rc_fill(a, M, Hd, drop_p, key1_0, key1_1, 0, 0, drop_seed);
     constexpr int NW = 8;
     const int wbytes = 3 * 4 * (32 * C * 2) + 3 * 2 * (C * 64);
@@ -1613,6 +1651,15 @@ extern "C" int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void*
 #undef RC16_DGRAD_LAUNCH
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
+}
+extern "C" int mdvit_mlp_rc16_dgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
+                                    int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream) {
+    return rc16_dgrad_impl(0, gm, x, W1p, b1, W2tp, W1tp, du, dx, M, C, Hd, drop_p, key1_0, key1_1, drop_seed, stream);
+}
+/* the same with du stored as bf16 */
+extern "C" int mdvit_mlp_rc16_dgrad_hbf16(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
+                                    int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream) {
+    return rc16_dgrad_impl(1, gm, x, W1p, b1, W2tp, W1tp, du, dx, M, C, Hd, drop_p, key1_0, key1_1, drop_seed, stream);
 }
 
 /* y[M, N] = x[M, K] Wp^T (+ bias) for K = 64 / 128, N % 32 == 0; with `residual` also x dropout(key) x rowscale[row / rows_per_scale] + residual

@@ -182,6 +182,8 @@ def enable_side_stream(flag: bool = True):
     """the weight-gradient stream; enabling twice keeps the stream (reserve_streams may have bound its hardware queue already)"""
     global _side_stream, _side_stream_obj
     if not flag:
+        if _side_stream is not None:
+            join_side_stream()          # nothing it still reads may be released behind its back (and the keep-alive lists do not outlive it)
         _side_stream = None
         return
     if _side_stream_obj is None:
@@ -2147,6 +2149,9 @@ def _side_protect(*tensors):
     _trim_side_groups(_side_hold_limit)
 
 
+_store_bf16 = os.environ.get("MDVIT_STORE_BF16", "1") != "0"      # 0: fp32 storage in the bf16 mode too (A/B)
+
+
 def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
     H, W_, heads, splits, eps, drop_p, ln_groups = meta[:7]
     B, N, Cn = x.shape
@@ -2155,6 +2160,7 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
     d.s3, d.s5, d.s7 = splits
     d.ln_groups = ln_groups
     d.precision = min(_gemm_precision, 1)
+    d.store_bf16 = int(_gemm_precision == 2 and _store_bf16)      # the mixed mode: h / du of the C = 128 MLP as bf16 (include/mdvit_hip.h: MdvitBlockDesc.store_bf16)
     d.eps, d.drop_p = eps, drop_p
     d.key_proj[0], d.key_proj[1] = keys[0]
     d.key_fc1[0], d.key_fc1[1] = keys[1]

@@ -1265,6 +1265,52 @@ def test_wgrad_tn_workgroup_order_over_the_xcds_does_not_change_a_bit(shape):
         lib.mdvit_gemm_tn_grid_order(-1)
 
 
+@pytest.mark.parametrize("shape", [(1024, 128, 4096), (128, 1024, 3000), (64, 64, 777), (320, 192, 2050)])
+@pytest.mark.parametrize("which", ["a", "b"])
+def test_wgrad_tn_kernel_with_a_bf16_stored_operand(shape, which):
+    """MdvitGemmDesc.a_bf16 / b_bf16: one operand of the weight-gradient product lives in HBM as bf16 (the mixed mode's saved hidden activations).  It is
+    EXACTLY its single bf16 plane, so against fp64 on the same (rounded) values the product keeps the bf16x3 accuracy; the column sums of a bf16 A are the
+    sums of the rounded values; every tile config and forced split, repeatable to the bit."""
+    import ctypes as C
+    from mdvit_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + K)
+    A = torch.randn((K, M), generator=g).to(dev()); B = torch.randn((K, N), generator=g).to(dev())
+    Ab, Bb = A.to(torch.bfloat16), B.to(torch.bfloat16)
+    Aeff, Beff = (Ab.float(), B) if which == "a" else (A, Bb.float())
+    out0 = torch.randn((M, N), generator=g).to(dev()); cs0 = torch.randn((M,), generator=g).to(dev())
+    ref = out0.double() + Aeff.double().t() @ Beff.double()
+    cref = cs0.double() + Aeff.double().sum(0)
+
+    def run():
+        out, cs = out0.clone(), cs0.clone()
+        d = _lib.GemmDesc()
+        d.A, d.B, d.C = ops._p(Ab if which == "a" else A), ops._p(Bb if which == "b" else B), ops._p(out)
+        d.lda, d.ldb, d.ldc = M, N, N
+        d.M, d.N, d.K = M, N, K
+        d.trans_a, d.trans_b, d.allow_split, d.accumulate, d.precision = 1, 0, 1, 1, 1
+        d.colsum_a = ops._p(cs)
+        d.a_bf16, d.b_bf16 = int(which == "a"), int(which == "b")
+        need = lib.mdvit_gemm_ws_bytes(C.byref(d))
+        ws = torch.empty((max(need // 4, 1),), device=dev())
+        d.ws, d.ws_bytes = ops._p(ws), need
+        ops.call("mdvit_gemm_f32", C.byref(d), ops._stream())
+        torch.cuda.synchronize()
+        return out, cs
+    try:
+        for cfg in (-1, 0, 1, 2, 3):
+            for sp in (0, 1, 5):
+                lib.mdvit_gemm_tn_config(1, cfg, sp)
+                out, cs = run()
+                check(out, ref.float(), tol=2e-5, name=f"{which} bf16, cfg {cfg} splits {sp}")
+                check(cs, cref.float(), tol=1e-5, name=f"colsum, {which} bf16, cfg {cfg} splits {sp}")
+                out2, cs2 = run()
+                assert torch.equal(out, out2) and torch.equal(cs, cs2)
+    finally:
+        lib.mdvit_gemm_tn_config(1, -1, 0)
+
+
 def test_wgrad_tn_kernel_strided_operands_and_single_plane():
     """operands that are column blocks of wider tensors (lda > M, ldb > N), overwrite (no accumulate), and the one-bf16-plane mode"""
     from mdvit_amd import ops
