@@ -553,7 +553,7 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (fp32 storage; GEMM operands split hi+lo bf16, fp32 accumulate)",
-                      "bf16": "bf16 (GEMM operands one bf16 plane, one MFMA per product, fp32 accumulate; fp32 storage, norms and losses)"}[args.precision], "data": "synthetic" + (" (inputs cross PCIe inside the timed region)" if args.host_inputs else ""),
+                      "bf16": "mixed bf16 / fp32 (C >= 320 GEMMs: one bf16 plane per operand; C <= 128 blocks: bf16x3 register-chained kernels with the C = 128 MLP's [tokens, hidden] tensors h / du STORED as bf16; fp32 accumulate, norms, losses and everything else in HBM)"}[args.precision], "data": "synthetic" + (" (inputs cross PCIe inside the timed region)" if args.host_inputs else ""),
             "config": {"workload": f"{ {'mdvit': 'MDViT Sup+' + args.decoder, 'mdvit_dsn': 'MDViT_DSN Sup+' + args.decoder, 'base': 'BASE', 'transfuse': 'TransFuse_S_adapt'}[args.model] } train step, {len(domains)} domain(s) x bs={args.batch} per GPU, "
                                    f"{args.size}x{args.size}, drop_rate=0.1 drop_path=0.1, {args.precision} GEMMs, data-parallel x{world}",
                        "images_per_step": imgs_per_step, "algorithmic_gflop_per_image": flop_per_img / 1e9, "final_loss": round(loss_val, 4)},
