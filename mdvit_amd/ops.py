@@ -2420,10 +2420,15 @@ _ones = {}
 _aux_priority = int(os.environ.get("MDVIT_AUX_PRIORITY", "0"))
 
 
+# A replayed HIP graph runs its parallel branches concurrently (tools/probe/graph_branch_probe.py: two captured streams of ten 100-us kernels replay in
+# 1.05 ms, 2.01 ms on one stream), so the whole-step graph may keep the aux sweep's stream: 1 = fork it inside the capture too
+_graph_streams = os.environ.get("MDVIT_GRAPH_STREAMS", "0") != "0"
+
+
 def sweep_stream():
     """the stream the second backward sweep runs on (created once); None while a HIP graph is being captured"""
     global _sweep_stream_obj
-    if torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing() and not _graph_streams:
         return None
     if _sweep_stream_obj is None:
         _sweep_stream_obj = torch.cuda.Stream(priority=_aux_priority)
