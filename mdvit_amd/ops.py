@@ -251,7 +251,7 @@ def branch_stream():
     node's backward on its forward's stream -- backward).  With the main and the weight-gradient stream that is three of the four hardware queues.
     None while a HIP graph is captured or when switched off (MDVIT_BRANCH_STREAM=0)."""
     global _branch_stream_obj
-    if not _use_branch_stream or torch.cuda.is_current_stream_capturing():
+    if not _use_branch_stream or (torch.cuda.is_current_stream_capturing() and not _graph_streams):
         return None
     if _branch_stream_obj is None:
         _branch_stream_obj = torch.cuda.Stream()
