@@ -5,8 +5,9 @@
 // 228 -> 250-256, and the kernel is 2-5 % faster on the large shapes, equal on the small ones (tools/tn_check.py --time, one MI355X):
 //     [65536 x 1024]^T [65536 x 128]  102.0 us (104.4)      [16384 x 1280]^T [16384 x 320]  80.5 (84.4)      [262144 x 192]^T [262144 x 64]  66.0 (69.9)
 // One bf16 plane instead of three MFMAs per product moves the same shapes by < 5 % too: a slab period takes ~4900 cycles next to ~770 cycles of MFMA and
-// ~900 of VALU -- the wave waits for the loads it issued ONE period earlier (two register-staged slabs in flight per workgroup: 64 of 228 VGPRs), which
-// neither fewer VALU instructions nor a better instruction order changes.  Not adopted: 3 % of a kernel family that is 9 % of the step's kernel time.
+// ~900 of VALU -- and it is not memory either (tools/probe/tn_cached_operands_probe.py: cache-resident operands, same time).  SQ counters: 45 % of a wave's
+// cycles wait for instruction results, 16 % at barriers, with one or two waves per SIMD (profiles/r03_pmc_tn_stalls.txt).  Not adopted: 3 % of a kernel family
+// that is 9 % of the step's kernel time.
 // Build: replace mdvit_amd/csrc/gemm_tn.hip with this file (same entry points).
 // Weight-gradient GEMM (TN): C[M,N] (+)= A^T B with A [K,M] and B [K,N] both TOKEN-major (k = token index, the long axis), fp32 in HBM,
 // bf16x3 arithmetic (x = hi + lo bf16 planes; hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) or one bf16 plane.
