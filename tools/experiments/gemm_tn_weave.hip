@@ -7,7 +7,8 @@
 // One bf16 plane instead of three MFMAs per product moves the same shapes by < 5 % too: a slab period takes ~4900 cycles next to ~770 cycles of MFMA and
 // ~900 of VALU -- and it is not memory either (tools/probe/tn_cached_operands_probe.py: cache-resident operands, same time).  SQ counters: 45 % of a wave's
 // cycles wait for instruction results, 16 % at barriers, with one or two waves per SIMD (profiles/r03_pmc_tn_stalls.txt).  Not adopted: 3 % of a kernel family
-// that is 9 % of the step's kernel time.
+// that is 9 % of the step's kernel time.  With the split's packed subtractions written as scalar v_sub_f32 and -fno-slp-vectorize (beside MFMAs a v_pk_add_f32
+// costs ~13 cycles more than the pair it replaces): 1280 x 320 over 16384 tokens 77.8 us (84.9), 960 x 320 66.4 (71.1), 1024 x 128 over 65536 94.9 (96.5).
 // Build: replace mdvit_amd/csrc/gemm_tn.hip with this file (same entry points).
 // Weight-gradient GEMM (TN): C[M,N] (+)= A^T B with A [K,M] and B [K,N] both TOKEN-major (k = token index, the long axis), fp32 in HBM,
 // bf16x3 arithmetic (x = hi + lo bf16 planes; hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) or one bf16 plane.
