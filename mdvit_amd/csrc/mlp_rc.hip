@@ -1324,6 +1324,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4)))
                 v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
             }
             if (FULL) {
+                // (a multiply and an add, never fused: the tiled GEMM's FULL epilogue -- gemm_body.inc -- is the same arithmetic, bit for bit)
+#pragma clang fp contract(off)
                 v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
                 v.x += rq[q].x; v.y += rq[q].y; v.z += rq[q].z; v.w += rq[q].w;
             }
