@@ -38,6 +38,48 @@ def test_bad_arguments_return_error_codes_without_gpu():
     assert b"in_chans" in lib.mdvit_last_error()
 
 
+def test_bf16_stored_operands_are_validated_before_any_launch():
+    """MdvitGemmDesc.a_bf16 / b_bf16 (the mixed mode's saved hidden activations): a layout of the weight-gradient (TN, precision 1) kernel only -- any other
+    product, both operands at once, or a leading dimension that breaks the 8-byte quads is refused with MDVIT_E_SHAPE before anything touches a GPU."""
+    import ctypes as C
+    from mdvit_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+
+    def desc(**kw):
+        d = _lib.GemmDesc()
+        d.A, d.B, d.C = p, p, p
+        d.M, d.N, d.K = 8, 8, 8
+        d.lda, d.ldb, d.ldc = 8, 8, 8
+        d.trans_a, d.trans_b, d.precision = 1, 0, 1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    d = desc(a_bf16=1, trans_a=0, trans_b=1)                       # NT: not the weight-gradient layout
+    assert lib.mdvit_gemm_f32(C.byref(d), None) == 1 and b"bf16-stored" in lib.mdvit_last_error()
+    d = desc(a_bf16=1, b_bf16=1)                                   # both operands
+    assert lib.mdvit_gemm_f32(C.byref(d), None) == 1 and b"bf16-stored" in lib.mdvit_last_error()
+    d = desc(b_bf16=1, ldb=10)                                     # quads would straddle (the general alignment check catches it first)
+    assert lib.mdvit_gemm_f32(C.byref(d), None) == 3 and b"leading dimensions" in lib.mdvit_last_error()
+    d = desc(a_bf16=1, precision=0)                                # fp32 mode: the general template
+    assert lib.mdvit_gemm_f32(C.byref(d), None) == 1 and b"bf16-stored" in lib.mdvit_last_error()
+    assert lib.mdvit_gemm_tn_grid_order(2) == 0 and lib.mdvit_gemm_tn_grid_order(-1) == 0
+
+
+def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
+    """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
+    tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
+    import importlib, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    for argv, want in ((["bench.py"], 2), (["bench.py", "--batch", "8"], 2), (["bench.py", "--batch", "16"], 1), (["bench.py", "--batch", "32"], 1),
+                       (["bench.py", "--batch", "32", "--max-inflight", "3"], 3)):
+        monkeypatch.setattr(sys, "argv", argv)
+        assert bench.parse().max_inflight == want, argv
+
+
 def test_ops_refuse_cpu_tensors():
     from mdvit_amd import ops, _lib
     with pytest.raises(_lib.MdvitHipError):
