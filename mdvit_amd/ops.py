@@ -286,11 +286,28 @@ def join_side_stream():
                 owner.wait_event(ev)
         _side_groups.clear()
         _side_held[0] = 0
+        for owner, _ts, _n in _side_open.values():
+            if owner != cur:
+                owner.wait_stream(_side_stream)           # (enqueued after the join above: the side stream holds nothing newer)
+        _side_open.clear()
+
+
+_side_open = {}      # owner stream handle -> [owner stream, tensors, bytes]: protected tensors that have no event yet (a group closes every 16 tensors / 1 GiB)
+
+
+def _close_side_group(key):
+    """record the side stream's event behind an open group (every launch that reads its tensors is enqueued by now) and apply the hold bound"""
+    owner, ts, n = _side_open.pop(key)
+    ev = torch.cuda.Event()
+    ev.record(_side_stream)
+    _side_groups.append((ev, owner, ts, n))
+    _side_held[0] += n
+    _trim_side_groups(_side_hold_limit)
 
 
 class _on_side:
     """with _on_side(t1, t2, ...): launches go to the side stream, ordered after everything already enqueued on the
-    main stream; the listed main-stream tensors are protected from reuse until the side work is done."""
+    main stream; the listed main-stream tensors are protected from reuse until the side work is done (bounded: _side_protect)."""
 
     def __init__(self, *tensors):
         self.tensors = [t for t in tensors if t is not None]
@@ -299,22 +316,39 @@ class _on_side:
     def __enter__(self):
         if _side_stream is None:
             return self
-        stream_wait(_side_stream, current_stream_obj())
-        for t in self.tensors:
-            t.record_stream(_side_stream)
-        _side_keepalive.extend(self.tensors)
+        owner = current_stream_obj()
+        stream_wait(_side_stream, owner)
+        self.bounded = bool(_side_hold_limit) and not torch.cuda.is_current_stream_capturing()
+        if self.bounded:
+            # one open group per owning stream (TransFuse's two trunks alternate in the backward: their tensors go back to different pools)
+            self.key = key = owner.cuda_stream
+            grp = _side_open.get(key)
+            if grp is None:
+                grp = _side_open[key] = [owner, [], 0]
+            grp[1].extend(self.tensors)
+            for t in self.tensors:
+                grp[2] += t.numel() * t.element_size()
+        else:
+            for t in self.tensors:
+                t.record_stream(_side_stream)
+            _side_keepalive.extend(self.tensors)
         self.ctx = use_stream(_side_stream)
         self.ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
         if self.ctx is not None:
-            marked = _side_blocks[-1][1] if _side_blocks else 0
-            if len(_side_keepalive) - marked >= 32 and not torch.cuda.is_current_stream_capturing():
-                ev = torch.cuda.Event()                 # one marker per ~32 protected tensors: host cost stays negligible
-                ev.record(_side_stream)
-                _side_blocks.append((ev, len(_side_keepalive)))
-                _release_finished_side_blocks()
+            if self.bounded:
+                grp = _side_open[self.key]
+                if len(grp[1]) >= 16 or grp[2] >= (1 << 30):
+                    _close_side_group(self.key)
+            else:
+                marked = _side_blocks[-1][1] if _side_blocks else 0
+                if len(_side_keepalive) - marked >= 32 and not torch.cuda.is_current_stream_capturing():
+                    ev = torch.cuda.Event()                 # one marker per ~32 protected tensors: host cost stays negligible
+                    ev.record(_side_stream)
+                    _side_blocks.append((ev, len(_side_keepalive)))
+                    _release_finished_side_blocks()
             self.ctx.__exit__(*exc)
         return False
 
