@@ -67,6 +67,36 @@ def test_bf16_stored_operands_are_validated_before_any_launch():
     assert lib.mdvit_gemm_tn_grid_order(2) == 0 and lib.mdvit_gemm_tn_grid_order(-1) == 0
 
 
+def test_weight_gradient_planner_without_gpu():
+    """mdvit_gemm_plan on weight-gradient (TN, bf16x3) descriptors -- host-side logic only: the K-split leaves every workgroup at least 8 slabs of 32 tokens,
+    the launch has ~1.5 workgroups per CU in total when K allows it, a bf16-stored operand does not change the plan, and a tiny K is not split at all."""
+    import ctypes as C
+    from mdvit_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+
+    def plan(M, N, K, **kw):
+        d = _lib.GemmDesc()
+        d.A, d.B, d.C = p, p, p
+        d.M, d.N, d.K = M, N, K
+        d.lda, d.ldb, d.ldc = M, N, N
+        d.trans_a, d.trans_b, d.precision, d.allow_split = 1, 0, 1, 1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.mdvit_gemm_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp)) == 0
+        return tm.value, tn.value, sp.value
+    for (M, N, K) in ((1024, 128, 65536), (64, 512, 262144), (1280, 320, 16384), (512, 2048, 4096), (192, 64, 2097152)):
+        tm, tn, sp = plan(M, N, K)
+        tiles = -(-M // tm) * -(-N // tn)
+        assert sp >= 1 and K // sp >= 256, (M, N, K, tm, tn, sp)              # >= 8 slabs of 32 tokens per workgroup
+        assert 256 <= tiles * sp <= 768, (M, N, K, tm, tn, sp)                # ~384 workgroups in total
+        assert plan(M, N, K, b_bf16=1) == (tm, tn, sp) and plan(M, N, K, a_bf16=1) == (tm, tn, sp)
+    assert plan(128, 128, 200)[2] == 1                                        # fewer than 8 slabs: no split
+    assert plan(128, 128, 65536, allow_split=0)[2] == 1
+
+
 def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
     """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
     tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
