@@ -97,6 +97,31 @@ def test_weight_gradient_planner_without_gpu():
     assert plan(128, 128, 65536, allow_split=0)[2] == 1
 
 
+def test_block_roofline_bounds_are_what_the_bench_line_divides_by():
+    """tools/block_roofline.py (the denominator of `block_bs32` in the bench line): per encoder stage at bs=32 the operator-sum bound of one SerialBlock_adapt
+    forward + backward (every operator's max(bytes / 8 TB/s, flops / MFMA roof), fp32 storage), the STRICT bound without any T x hidden traffic (fused MLP), and
+    SURVEY 8(d)'s whole-block fused-bf16 bound.  Pinned: strict <= operator-sum, SURVEY's figure below both, and the stage-0 values DESIGN.md quotes."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("block_roofline", os.path.join(root, "tools", "block_roofline.py"))
+    br = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(br)
+    B = 32
+    for C, r, N in ((64, 8, 128 * 128), (128, 8, 64 * 64), (320, 4, 32 * 32), (512, 4, 16 * 16)):
+        T, Hd = B * N, C * r
+        f, b = br.block_ops(T, C, Hd, 8)
+        fs, bs = br.block_ops_strict(T, C, Hd, 8)
+        bf, bb = br.bound_seconds(f, "bf16x3")[0], br.bound_seconds(b, "bf16x3")[0]
+        sf, sb = br.bound_seconds(fs, "bf16x3")[0], br.bound_seconds(bs, "bf16x3")[0]
+        vf, vb = br.survey_bound(B, N, C, r, 8)
+        assert 0 < sf <= bf and 0 < sb <= bb, (C, sf, bf, sb, bb)
+        assert vf < sf and vb < sb, (C, vf, sf, vb, sb)
+        assert not any(name.startswith("fc") for name, *_ in fs + bs)
+        if C == 64:
+            assert abs(bf * 1e3 - 0.604) < 2e-3 and abs(bb * 1e3 - 1.225) < 2e-3, (bf, bb)          # the "bound" column of profiles/r03*_block_roofline_bs32.txt
+            assert abs(vf * 1e6 - 67) < 1 and abs(vb * 1e6 - 201) < 1, (vf, vb)
+
+
 def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
     """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
     tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
