@@ -122,6 +122,29 @@ def test_block_roofline_bounds_are_what_the_bench_line_divides_by():
             assert abs(vf * 1e6 - 67) < 1 and abs(vb * 1e6 - 201) < 1, (vf, vb)
 
 
+def test_pmc_summary_applies_the_gfx950_corrections(tmp_path):
+    """tools/pmc_summary.py on two synthetic rocprofv3 --pmc passes: counters are KiB, averaged per launch of a kernel name (template arguments kept,
+    argument list and namespace dropped), HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- the gfx950 read-side correction of MI355X_MICROARCH.md;
+    this file is what bench.py reads for `roofline.traffic`."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = "Kernel_Name,Counter_Name,Counter_Value\n"
+    k = '"void (anonymous namespace)::gemm_f32_kernel<64, 64, 2, 2, false, true, 0, true>((anonymous namespace)::GemmArgs)"'
+    for d, counter, vals in (("fetch", "FETCH_SIZE", (100.0, 300.0)), ("write", "WRITE_SIZE", (50.0, 70.0))):
+        os.makedirs(tmp_path / d / "x")
+        with open(tmp_path / d / "x" / "pmc_counter_collection.csv", "w") as f:
+            f.write(hdr + "".join(f"{k},{counter},{v}\n" for v in vals) + f'"other_kernel(int)",{counter},8.0\n')
+    out = tmp_path / "traffic.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(tmp_path / "fetch"), str(tmp_path / "write"), str(out)],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    ks = json.load(open(out))["kernels"]
+    g = ks["gemm_f32_kernel<64, 64, 2, 2, false, true, 0, true>"]
+    assert g["launches_sampled"] == 2 and g["fetch_kib_raw_per_launch"] == 200.0 and g["write_kib_per_launch"] == 60.0
+    assert g["hbm_bytes_per_launch"] == (2 * 200 + 60) * 1024
+    assert ks["other_kernel"]["hbm_bytes_per_launch"] == (2 * 8 + 8) * 1024
+
+
 def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
     """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
     tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
