@@ -339,8 +339,8 @@ class _on_side:
     def __exit__(self, *exc):
         if self.ctx is not None:
             if self.bounded:
-                grp = _side_open[self.key]
-                if len(grp[1]) >= 16 or grp[2] >= (1 << 30):
+                grp = _side_open.get(self.key)
+                if grp is not None and (len(grp[1]) >= 16 or grp[2] >= (1 << 30)):
                     _close_side_group(self.key)
             else:
                 marked = _side_blocks[-1][1] if _side_blocks else 0
