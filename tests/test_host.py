@@ -145,6 +145,39 @@ def test_pmc_summary_applies_the_gfx950_corrections(tmp_path):
     assert ks["other_kernel"]["hbm_bytes_per_launch"] == (2 * 8 + 8) * 1024
 
 
+def test_side_stream_hold_bookkeeping_without_gpu(monkeypatch):
+    """ops._trim_side_groups (the bound on what the weight-gradient stream keeps allocated), on stand-in events and streams: groups whose event has completed
+    are dropped first, oldest first; past the bound the OWNING stream is made to wait for the oldest group's event before that group is dropped; the byte
+    count follows; nothing is dropped while under the bound and incomplete."""
+    from mdvit_amd import ops
+
+    class Ev:
+        def __init__(self, done):
+            self.done = done
+
+        def query(self):
+            return self.done
+
+    class St:
+        def __init__(self):
+            self.waited = []
+
+        def wait_event(self, ev):
+            self.waited.append(ev)
+
+    main, branch = St(), St()
+    e = [Ev(True), Ev(False), Ev(False), Ev(False)]
+    groups = [(e[0], main, ["a"], 10), (e[1], main, ["b"], 20), (e[2], branch, ["c"], 30), (e[3], main, ["d"], 5)]
+    monkeypatch.setattr(ops, "_side_groups", list(groups))
+    monkeypatch.setattr(ops, "_side_held", [65])
+    ops._trim_side_groups(100)                       # under the bound: only the completed head goes
+    assert [g[2] for g in ops._side_groups] == [["b"], ["c"], ["d"]] and ops._side_held[0] == 55 and not main.waited and not branch.waited
+    ops._trim_side_groups(40)                        # 55 > 40: the oldest group's owner waits for its event, 35 <= 40 stops it
+    assert [g[2] for g in ops._side_groups] == [["c"], ["d"]] and ops._side_held[0] == 35 and main.waited == [e[1]] and not branch.waited
+    ops._trim_side_groups(1)                         # the branch stream's group waits on ITS stream; the last group on main's
+    assert ops._side_groups == [] and ops._side_held[0] == 0 and branch.waited == [e[2]] and main.waited == [e[1], e[3]]
+
+
 def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
     """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
     tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
