@@ -178,6 +178,33 @@ def test_side_stream_hold_bookkeeping_without_gpu(monkeypatch):
     assert ops._side_groups == [] and ops._side_held[0] == 0 and branch.waited == [e[2]] and main.waited == [e[1], e[3]]
 
 
+def test_block_entry_routing_predicates_without_gpu():
+    """ops.block_entry_ok / _lin_rc_ok / _mlp_rc16_ok (pure host logic): which SerialBlock_adapt configurations take the one-call C entry, and which of their
+    layers the streaming kernels.  Parity (bf16x3) mode: every encoder width; the bf16 ("mixed") mode: the C <= 128 blocks keep the bf16x3 register-chained
+    kernels (with bf16-stored h / du at C = 128), the MFMA-bound C >= 320 blocks go to the operator path and its single-plane GEMMs."""
+    from mdvit_amd import ops
+    prev = ops.gemm_precision()
+
+    def params(C, hidden):
+        t = lambda *sh: torch.zeros(*sh)
+        return [t(C, 1, 3, 3), t(C), t(C), t(C), t(3 * C, C), t(3 * C), t(C // 4, 1, 3, 3), t(C // 4), t(3 * C // 8, 1, 5, 5), t(3 * C // 8), t(3 * C // 8, 1, 7, 7),
+                t(3 * C // 8), None, None, None, None, t(C, C), t(C), t(C), t(C), t(hidden, C), t(hidden), t(C, hidden), t(C)]
+    try:
+        ops.set_gemm_precision("bf16x3")
+        for C, r in ((64, 8), (128, 8), (320, 4), (512, 4)):
+            assert ops.block_entry_ok(C, C * r, params(C, C * r)), C
+        assert not ops.block_entry_ok(66, 528, params(64, 512))                       # C % 4
+        assert ops._lin_rc_ok(65536, 192, 64) and ops._lin_rc_ok(4096, 128, 128)          # short-K Linear layers of the C = 64 / 128 blocks: the streaming kernel
+        assert not ops._lin_rc_ok(4096, 960, 320) and not ops._lin_rc_ok(512, 192, 64)    # K = 320: the tiled GEMM; fewer than 1024 rows: not worth a launch shape of its own
+        ops.set_gemm_precision("bf16")
+        assert ops.block_entry_ok(64, 512, params(64, 512)) and ops.block_entry_ok(128, 1024, params(128, 1024))
+        assert not ops.block_entry_ok(320, 1280, params(320, 1280)) and not ops.block_entry_ok(512, 2048, params(512, 2048))
+        ops.set_gemm_precision("fp32")
+        assert not ops._lin_rc_ok(65536, 192, 64)                                     # the fp32 mode has no plane kernels
+    finally:
+        ops.set_gemm_precision(prev)
+
+
 def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
     """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
     tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
