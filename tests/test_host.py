@@ -205,6 +205,35 @@ def test_block_entry_routing_predicates_without_gpu():
         ops.set_gemm_precision(prev)
 
 
+def test_ctypes_mirrors_have_the_layout_of_the_public_header(tmp_path):
+    """include/mdvit_hip.h is plain C: compile it with gcc and compare sizeof and every field offset of the five ABI structs with their ctypes mirrors in
+    mdvit_amd/_lib.py -- a field added on one side only (this round: a_bf16 / b_bf16, store_bf16, ln_accumulate, the plane pointers) would otherwise
+    shift everything behind it silently."""
+    import ctypes as C, shutil, subprocess
+    from mdvit_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = (("MdvitGemmDesc", _lib.GemmDesc), ("MdvitPlaneGemmDesc", _lib.PlaneGemmDesc), ("MdvitBlockDesc", _lib.BlockDesc),
+             ("MdvitBlockGrads", _lib.BlockGrads), ("MdvitBlockStreams", _lib.BlockStreams))
+    lines = ['#include <stdio.h>', '#include "mdvit_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'    printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _t in cls._fields_:
+            lines.append(f'    printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['    return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]          # (a ctypes field the header does not have fails HERE)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, timeout=30).stdout.strip().splitlines())
+    for cname, cls in pairs:
+        assert int(out[cname]) == C.sizeof(cls), (cname, out[cname], C.sizeof(cls))
+        for fname, _t in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname, out[f"{cname}.{fname}"], getattr(cls, fname).offset)
+
+
 def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
     """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
     tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
