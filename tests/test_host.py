@@ -234,6 +234,22 @@ def test_ctypes_mirrors_have_the_layout_of_the_public_header(tmp_path):
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname, out[f"{cname}.{fname}"], getattr(cls, fname).offset)
 
 
+def test_ctypes_prototypes_have_the_arity_of_the_header_declarations():
+    """every function mdvit_amd/_lib.py gives argtypes to: as many arguments as its declaration in include/mdvit_hip.h (a parameter added to one side only
+    would pass garbage for everything behind it); and every declared function that the Python side calls has a prototype"""
+    import re
+    from mdvit_amd import _lib
+    with open(_lib.HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    decl = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\s*\*)\s+(mdvit_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        decl[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    assert len(decl) >= 90, len(decl)
+    bad = [(n, len(sig), decl.get(n)) for n, sig in _lib._SIGS.items() if decl.get(n) != len(sig)]
+    assert not bad, f"argtypes vs header declarations (name, ctypes, header): {bad}"
+
+
 def test_bench_bounds_the_host_run_ahead_by_batch(monkeypatch):
     """bench.py --max-inflight: two steps of run-ahead below batch 16, one from batch 16 up (every step of run-ahead keeps one more step's cross-stream
     tensors in the reserved pool; the host needs 22 ms for a 250 ms step there), an explicit value wins"""
