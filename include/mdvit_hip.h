@@ -179,6 +179,9 @@ size_t mdvit_gemm_planes_ws_bytes(const MdvitPlaneGemmDesc* desc);
 int mdvit_gemm_planes_plan(const MdvitPlaneGemmDesc* desc, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
 int mdvit_gemm_planes_force_plan(int32_t cfg, int32_t splits);      /* tuning hook: cfg 0: 128x128, 1: 128x64, 2: 64x64; -1 / 0: planner */
 int mdvit_gemm_planes(const MdvitPlaneGemmDesc* desc, void* stream);
+/* tuning / A-B hook of the 256-wide phase-split kernels (csrc/gemm_ph.hip; mdvit_gemm_planes picks them for the MFMA-bound layers -- mdvit.py:267,307,
+ * mpvit.py:71-78 at C >= 320): main-loop variant, 0 = global_load_lds issued in a phase's load part, 1 (default) = behind the phase's first MFMAs */
+int mdvit_gemm_ph_config(int32_t variant);
 /* fp32 [rows, cols] (ld_in) -> planes [planes][rows][ld_out]; cols % 8 == 0 */
 int mdvit_split_planes(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t plane_stride, int64_t rows, int32_t cols, int32_t planes, void* stream);
 /* one tensor, any shape, optionally transposed (out = planes of in^T, [cols][rows]): non-leaf / sliced weights */

@@ -15,6 +15,7 @@
 // the fragment reads; with it the four 16-lane groups of a ds_read_b128 hit 16 distinct bank slots (64-byte rows, no padding).
 // Replaces the same reference call sites as gemm.hip: mdvit.py:288,310-311, mpvit.py:71-78, Decoders.py:196,319-331.
 #include "common.h"
+#include "gemm_bp.h"
 
 typedef float bp_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bp_bf16x8 __attribute__((ext_vector_type(8)));
@@ -24,26 +25,6 @@ namespace {
 constexpr int BK = 32;            // bf16 elements per K slab (64-byte rows)
 constexpr int NT_THREADS = 256;
 
-struct BpArgs {
-    const void* A; long lda; long a_plane; int a_f32;       // bf16 planes (lda, a_plane in elements) or fp32 [M,K]
-    const uint16_t* B; long ldb; long b_plane;
-    int M, N, K;
-    float* C; long ldc;                                       // fp32 result (optional)
-    uint16_t* Cp; long ldcp; long c_plane;                    // bf16-plane result (optional)
-    float* U; long ldu_out;                                   // GELU: the pre-activation, fp32 (optional)
-    const float* bias;
-    int e_drop; uint32_t e_k0, e_k1, e_thresh; float e_inv_keep;
-    const float* e_rowscale; int e_rows_per_scale;
-    const float* residual; long ldr;
-    const float* gelu_u; long ldu;
-    const uint16_t* rc_a; long rc_lda; long rc_a_plane; const uint16_t* rc_b; long rc_ldb; long rc_b_plane; const float* rc_bias; int rc_k;
-    int splits; int k_per_split; float* slab;
-    int accumulate;
-    const uint32_t* seed;
-    int tiles_m, tiles_n;
-};
-
-enum { BEPI_PLAIN = 0, BEPI_GELU = 1, BEPI_DGELU = 2, BEPI_FULL = 3, BEPI_DGELU_RC = 4 };
 
 __device__ __forceinline__ int bp_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -337,7 +318,31 @@ struct BpPlan { int cfg, tiles_m, tiles_n, splits, kps; };
 int g_bp_force_cfg = -1, g_bp_force_splits = 0;
 
 // cfg 0: 128x128 (2 workgroups / CU: 64 KB of LDS each)   1: 128x64   2: 64x64 (5 workgroups / CU)
+// cfg 3: 256x256, eight phase-split waves, one workgroup per CU (gemm_ph.hip)
+BpPlan plan_ph(const MdvitPlaneGemmDesc* d, int cfg) {
+    static const int SPLITS[] = {1, 2, 3, 4, 6, 8};
+    const int kt = d->planes == 2 ? 32 : 64;
+    const bool plain = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual && !d->Cp;
+    const bool can_split = d->allow_split && plain && d->K >= 512;
+    const long tm = cdiv(d->M, 256), tn = cdiv(d->N, 256);
+    BpPlan best{cfg, (int)tm, (int)tn, 1, d->K};
+    double best_cost = 1e300;
+    for (int si = 0; si < (int)(sizeof(SPLITS) / sizeof(int)); ++si) {
+        const int want = SPLITS[si];
+        if (want > 1 && (!can_split || want > d->K / 256)) break;
+        if (g_bp_force_splits > 0 && can_split && want != g_bp_force_splits) continue;
+        const int kps = cdiv(cdiv(d->K, want), kt) * kt;
+        const int splits = cdiv(d->K, kps);
+        const double rounds = (double)cdiv(tm * tn * splits, 256);
+        double cost = rounds * (256.0 * 256.0 * kps * (d->planes == 2 ? 3.0 : 1.0) / (1024.0 * 4.0) / 0.7 + 6000.0);
+        if (splits > 1) cost += 12000.0 + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;
+        if (cost < best_cost) { best_cost = cost; best = BpPlan{cfg, (int)tm, (int)tn, splits, kps}; }
+    }
+    return best;
+}
+
 BpPlan plan_bp(const MdvitPlaneGemmDesc* d) {
+    if (g_bp_force_cfg >= 3) return plan_ph(d, g_bp_force_cfg);
     static const int BMs[3] = {128, 128, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 3, 5};
     static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const bool plain = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual && !d->Cp;
@@ -405,7 +410,7 @@ extern "C" size_t mdvit_gemm_planes_ws_bytes(const MdvitPlaneGemmDesc* d) {
 }
 
 extern "C" int mdvit_gemm_planes_force_plan(int32_t cfg, int32_t splits) {
-    g_bp_force_cfg = (cfg >= 0 && cfg <= 2) ? cfg : -1;
+    g_bp_force_cfg = (cfg >= 0 && cfg <= 5) ? cfg : -1;
     g_bp_force_splits = splits > 0 ? splits : 0;
     return MDVIT_OK;
 }
@@ -413,8 +418,8 @@ extern "C" int mdvit_gemm_planes_force_plan(int32_t cfg, int32_t splits) {
 extern "C" int mdvit_gemm_planes_plan(const MdvitPlaneGemmDesc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits) {
     MDVIT_CHECK_ARG(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0, MDVIT_E_SHAPE, "gemm_planes_plan: bad descriptor");
     const BpPlan pl = plan_bp(d);
-    if (tile_m) *tile_m = pl.cfg == 2 ? 64 : 128;
-    if (tile_n) *tile_n = pl.cfg == 0 ? 128 : 64;
+    if (tile_m) *tile_m = pl.cfg >= 3 ? 256 : (pl.cfg == 2 ? 64 : 128);
+    if (tile_n) *tile_n = pl.cfg >= 3 ? 256 : (pl.cfg == 0 ? 128 : 64);
     if (splits) *splits = pl.splits;
     return MDVIT_OK;
 }
@@ -476,7 +481,13 @@ extern "C" int mdvit_gemm_planes(const MdvitPlaneGemmDesc* d, void* stream) {
         a.slab = (float*)d->ws;
     }
     int rc;
-    if (pl.cfg == 0) rc = launch_nt<128, 128>(a, d->planes, epi, s);
+    if (pl.cfg >= 3) {
+        MDVIT_CHECK_ARG(mdvit_gemm_ph_ok(a, pl.cfg, d->planes, epi, pl.kps), MDVIT_E_SHAPE,
+                        "gemm_planes: the 256-wide phase-split kernel needs plane operands, K (per split) a multiple of %d and >= %d (K=%d, per split %d)",
+                        d->planes == 2 ? 32 : 64, d->planes == 2 ? 64 : 128, d->K, pl.kps);
+        rc = mdvit_gemm_ph_launch(a, pl.cfg, d->planes, epi, s);
+    }
+    else if (pl.cfg == 0) rc = launch_nt<128, 128>(a, d->planes, epi, s);
     else if (pl.cfg == 1) rc = launch_nt<128, 64>(a, d->planes, epi, s);
     else rc = launch_nt<64, 64>(a, d->planes, epi, s);
     MDVIT_CHECK_ARG(rc == 0, MDVIT_E_SHAPE, "gemm_planes: this (a_f32=%d, epilogue=%d) combination is not built", d->a_f32, epi);
