@@ -179,9 +179,13 @@ size_t mdvit_gemm_planes_ws_bytes(const MdvitPlaneGemmDesc* desc);
 int mdvit_gemm_planes_plan(const MdvitPlaneGemmDesc* desc, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
 int mdvit_gemm_planes_force_plan(int32_t cfg, int32_t splits);      /* tuning hook: cfg 0: 128x128, 1: 128x64, 2: 64x64; -1 / 0: planner */
 int mdvit_gemm_planes(const MdvitPlaneGemmDesc* desc, void* stream);
-/* tuning / A-B hook of the 256-wide phase-split kernels (csrc/gemm_ph.hip; mdvit_gemm_planes picks them for the MFMA-bound layers -- mdvit.py:267,307,
- * mpvit.py:71-78 at C >= 320): main-loop variant, 0 = global_load_lds issued in a phase's load part, 1 (default) = behind the phase's first MFMAs */
-int mdvit_gemm_ph_config(int32_t variant);
+/* The 256 x 256 phase-split kernels (csrc/gemm_ph.hip: eight waves, one workgroup per CU, global_load_lds ring with counted waits; same arithmetic and
+ * results as the other tiles) serve the MFMA-bound NT products -- qkv / fc1 / the fc2 data gradient of the C >= 320 blocks (mdvit.py:267,307, mpvit.py:71-78),
+ * the wide projections of Decoders.py:319-331.  mdvit_gemm_ph_prefers: 1 when mdvit_gemm_planes routes [M, K] x [N, K]^T to them (the share of real output in
+ * the chip's rounds of 256 x 256 tiles decides; K % 32 == 0 (planes = 2) / % 64 (planes = 1), at least two K tiles).  mdvit_gemm_ph_config: -1 never, 0 that
+ * rule (default), 1 whenever legal (A/B and test hook). */
+int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes);
+int mdvit_gemm_ph_config(int32_t mode);
 /* fp32 [rows, cols] (ld_in) -> planes [planes][rows][ld_out]; cols % 8 == 0 */
 int mdvit_split_planes(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t plane_stride, int64_t rows, int32_t cols, int32_t planes, void* stream);
 /* one tensor, any shape, optionally transposed (out = planes of in^T, [cols][rows]): non-leaf / sliced weights */
@@ -305,7 +309,10 @@ typedef struct MdvitBlockDesc {
         *fc2_w, *fc2_b;
     const float *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;
     const void *fc1_p, *fc2_p, *fc2t_p, *fc1t_p;
-    const void *qkv_p, *proj_p, *projt_p;      /* optional bf16 planes of Wqkv, Wproj, Wproj^T: C = 64 / 128 run qkv / proj / proj's data gradient on mdvit_linear_rc */
+    const void *qkv_p, *proj_p, *projt_p, *qkvt_p;      /* optional bf16 planes of Wqkv, Wproj, Wproj^T: C = 64 / 128 run qkv / proj / proj's data gradient on mdvit_linear_rc;
+                                                * wider blocks run every product mdvit_gemm_ph_prefers accepts on the 256-wide plane kernel (fp32 activations split
+                                                * while staged) when the weight's planes are given (forward: qkv_p, proj_p, fc1_p, fc2_p; data gradients: the transposed
+                                                * planes fc2t_p, fc1t_p, projt_p, qkvt_p = planes of Wqkv^T [C, 3C]) */
     int32_t store_bf16;                        /* "mixed" mode (BASELINE configs[3]): the C = 128 MLP's saved hidden activation h and its gradient du -- the two
                                                 * [tokens, hidden] tensors the block still moves, operands of weight-gradient GEMMs only -- are stored as bf16:
                                                 * y and dx do not change by a bit, the fc1 / fc2 weight (and fc1 bias) gradients see bf16-rounded operands

@@ -69,8 +69,30 @@ void gemm_init(MdvitGemmDesc& g, const MdvitBlockDesc& d) {
         }                                     \
     } while (0)
 
+// An NT product of the block on the 256-wide plane kernel (gemm_ph.hip through mdvit_gemm_planes: fp32 activations split while staged, the weight as its
+// per-step bf16 planes [2][N][K]) -- when the weight's planes were handed in and mdvit_gemm_ph_prefers takes the shape.  Same arithmetic, same results.
+bool ph_takes(const MdvitBlockDesc& d, const void* planes, int M, int N, int K) {
+    return d.precision == 1 && planes != nullptr && mdvit_gemm_ph_prefers(M, N, K, 2) != 0;
+}
+int gemm_planes_nt(Arena& A, const MdvitGemmDesc& g, const void* planes, hipStream_t s) {
+    MdvitPlaneGemmDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.A = g.A; pd.lda = g.lda; pd.a_f32 = 1;
+    pd.B = planes; pd.ldb = g.K; pd.b_plane = (int64_t)g.N * g.K;
+    pd.planes = 2; pd.M = g.M; pd.N = g.N; pd.K = g.K;
+    if (g.epi == MDVIT_EPI_GELU_DUAL && g.C2) { pd.U = g.C; pd.ldu_out = g.ldc; pd.C = g.C2; pd.ldc = g.ldc; }
+    else { pd.C = g.C; pd.ldc = g.ldc; }
+    pd.bias = g.bias; pd.epi = g.epi;
+    pd.e_drop_p = g.e_drop_p; pd.e_key0 = g.e_key0; pd.e_key1 = g.e_key1; pd.e_rowscale = g.e_rowscale; pd.e_rows_per_scale = g.e_rows_per_scale;
+    pd.residual = g.residual; pd.ldr = g.ldr; pd.gelu_u = g.gelu_u; pd.ldu = g.ldu;
+    pd.drop_seed = g.drop_seed;
+    BLK_RUN(mdvit_gemm_planes(&pd, s));
+    return MDVIT_OK;
+}
+
 // C = A W^T (+ epilogue): the forward layers
-int gemm_fwd(Arena& A, MdvitGemmDesc& g, hipStream_t s) {
+int gemm_fwd(Arena& A, MdvitGemmDesc& g, hipStream_t s, const MdvitBlockDesc* d = nullptr, const void* planes = nullptr) {
+    if (d && ph_takes(*d, planes, g.M, g.N, g.K)) return gemm_planes_nt(A, g, planes, s);
     g.trans_a = 0; g.trans_b = 1; g.allow_split = 1;
     const size_t need = mdvit_gemm_ws_bytes(&g);
     g.ws = need ? A.take_bytes(need) : nullptr; g.ws_bytes = need;
@@ -79,8 +101,10 @@ int gemm_fwd(Arena& A, MdvitGemmDesc& g, hipStream_t s) {
 }
 
 // dx[M,K] = g[M,N] W[N,K]: NT against the cached W^T (bf16x3) or NN (fp32)  -- ops._dgrad
-int gemm_dgrad(Arena& A, const MdvitBlockDesc& d, MdvitGemmDesc& g, const float* gy, const float* W, const float* Wt, float* dx, int M, int K, int N, hipStream_t s) {
+int gemm_dgrad(Arena& A, const MdvitBlockDesc& d, MdvitGemmDesc& g, const float* gy, const float* W, const float* Wt, float* dx, int M, int K, int N, hipStream_t s,
+               const void* planes_t = nullptr) {
     g.A = gy; g.C = dx; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldc = K;
+    if (ph_takes(d, planes_t, M, K, N) && !g.rc_a) return gemm_planes_nt(A, g, planes_t, s);
     if (d.precision >= 1) { g.B = Wt; g.ldb = N; g.trans_a = 0; g.trans_b = 1; g.precision = 1; }
     else { g.B = W; g.ldb = K; g.trans_a = 0; g.trans_b = 0; g.precision = 0; }
     const size_t need = g.allow_split ? mdvit_gemm_ws_bytes(&g) : 0;
@@ -139,7 +163,7 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
         MdvitGemmDesc g;
         gemm_init(g, d);
         g.A = sv.cur1; g.B = d.qkv_w; g.C = sv.qkv; g.M = M; g.N = 3 * C; g.K = C; g.lda = C; g.ldb = C; g.ldc = 3 * C; g.bias = d.qkv_b;
-        const int rc = gemm_fwd(A, g, s);
+        const int rc = gemm_fwd(A, g, s, &d, d.qkv_p);
         if (rc != MDVIT_OK) return rc;
     }
     // a = softmax_heads(MLP(one_hot));  att = a * (scale * q (softmax_tokens(k)^T v) + q * crpe(v))      (mdvit.py:293-304)
@@ -160,7 +184,7 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
         g.A = sv.att; g.B = d.proj_w; g.C = sv.x2; g.M = M; g.N = C; g.K = C; g.lda = C; g.ldb = C; g.ldc = C; g.bias = d.proj_b;
         g.e_drop_p = d.drop_p; g.e_key0 = d.key_proj[0]; g.e_key1 = d.key_proj[1]; g.e_rowscale = d.rowscale1; g.e_rows_per_scale = N_tok;
         g.residual = sv.x1; g.ldr = C; g.drop_seed = d.drop_p > 0.f ? d.drop_seed : nullptr;
-        const int rc = gemm_fwd(A, g, s);
+        const int rc = gemm_fwd(A, g, s, &d, d.proj_p);
         if (rc != MDVIT_OK) return rc;
     }
     // cur2 = LN2(x2);  y = x2 + droppath(drop(fc2(drop(gelu(fc1(cur2))))))                           (mpvit.py:71-78, mdvit.py:356-360)
@@ -194,13 +218,15 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
         if (mode == MLP_RECOMP) { g.C = sv.h; g.C2 = nullptr; }            // gelu(u) only: the backward recomputes u
         else { g.C = sv.u; g.C2 = sv.h; }
         g.trans_a = 0; g.trans_b = 1; g.allow_split = 0;
-        BLK_RUN(mdvit_gemm_f32(&g, s));
+        if (ph_takes(d, d.fc1_p, M, Hd, C)) { const int rc = gemm_planes_nt(A, g, d.fc1_p, s); if (rc != MDVIT_OK) return rc; }
+        else BLK_RUN(mdvit_gemm_f32(&g, s));
         gemm_init(g, d);
         g.A = sv.h; g.B = d.fc2_w; g.C = y; g.M = M; g.N = C; g.K = Hd; g.lda = Hd; g.ldb = Hd; g.ldc = C; g.bias = d.fc2_b;
         g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc2[0]; g.e_key1 = d.key_fc2[1]; g.e_rowscale = d.rowscale2; g.e_rows_per_scale = N_tok;
         g.residual = sv.x2; g.ldr = C; g.drop_seed = seed;
         g.trans_a = 0; g.trans_b = 1; g.allow_split = 0;
-        BLK_RUN(mdvit_gemm_f32(&g, s));
+        if (ph_takes(d, d.fc2_p, M, C, Hd)) { const int rc = gemm_planes_nt(A, g, d.fc2_p, s); if (rc != MDVIT_OK) return rc; }
+        else BLK_RUN(mdvit_gemm_f32(&g, s));
     }
     return MDVIT_OK;
 }
@@ -279,11 +305,11 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
             if (mode == MLP_RECOMP) { g.rc_a = sv.cur2; g.rc_lda = C; g.rc_b = d.fc1_w; g.rc_ldb = C; g.rc_bias = d.fc1_b; g.rc_k = C; }
             else { g.gelu_u = sv.u; g.ldu = Hd; }
             g.allow_split = 0;
-            rc = gemm_dgrad(A, d, g, gm2, d.fc2_w, d.fc2_wt, du, M, Hd, C, s);            // du = (gm W2) * gelu'(u) * mask
+            rc = gemm_dgrad(A, d, g, gm2, d.fc2_w, d.fc2_wt, du, M, Hd, C, s, d.fc2t_p);  // du = (gm W2) * gelu'(u) * mask
             if (rc != MDVIT_OK) return rc;
             gemm_init(g, d);
             g.allow_split = 1;
-            rc = gemm_dgrad(A, d, g, du, d.fc1_w, d.fc1_wt, dcur2, M, C, Hd, s);               // dx = du W1
+            rc = gemm_dgrad(A, d, g, du, d.fc1_w, d.fc1_wt, dcur2, M, C, Hd, s, d.fc1t_p);     // dx = du W1
             if (rc != MDVIT_OK) return rc;
         }
         if (want_w) {
@@ -328,7 +354,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         if (d.precision == 1 && (C == 64 || C == 128) && d.projt_p && M >= 1024) {
             BLK_RUN(mdvit_linear_rc(gm1, C, d.projt_p, (long)C * C, nullptr, datt, C, M, C, C, 0.f, 0, 0, nullptr, 1, nullptr, 0, nullptr, s));
         } else {
-            rc = gemm_dgrad(A, d, g, gm1, d.proj_w, d.proj_wt, datt, M, C, C, s);
+            rc = gemm_dgrad(A, d, g, gm1, d.proj_w, d.proj_wt, datt, M, C, C, s, d.projt_p);
             if (rc != MDVIT_OK) return rc;
         }
         if (want_w) {
@@ -378,7 +404,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         MdvitGemmDesc g;
         gemm_init(g, d);
         g.allow_split = 1;
-        int rc = gemm_dgrad(A, d, g, dqkv, d.qkv_w, d.qkv_wt, dcur1, M, C, 3 * C, s);
+        int rc = gemm_dgrad(A, d, g, dqkv, d.qkv_w, d.qkv_wt, dcur1, M, C, 3 * C, s, d.qkvt_p);
         if (rc != MDVIT_OK) return rc;
         if (want_w) {
             if (!A.dry) { rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }

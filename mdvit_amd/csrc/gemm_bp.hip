@@ -341,8 +341,14 @@ BpPlan plan_ph(const MdvitPlaneGemmDesc* d, int cfg) {
     return best;
 }
 
+extern "C" int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes);
+
 BpPlan plan_bp(const MdvitPlaneGemmDesc* d) {
     if (g_bp_force_cfg >= 3) return plan_ph(d, g_bp_force_cfg);
+    if (g_bp_force_cfg < 0 && !d->rc_a && mdvit_gemm_ph_prefers(d->M, d->N, d->K, d->planes)) {
+        BpPlan pl = plan_ph(d, 3);
+        if (pl.splits == 1) return pl;
+    }
     static const int BMs[3] = {128, 128, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 3, 5};
     static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const bool plain = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual && !d->Cp;

@@ -58,6 +58,10 @@ __device__ __forceinline__ int ph_xcd_remap(int bid, int nwg) {
 // L(s) ends with s_waitcnt vmcnt(what M(s-3) .. M(s-1) issued): everything issued in M(s-4) or earlier has landed -- which covers every unit L(s+1) reads and
 // every register M(s) converts.  RAW (guide, two staggered wave groups): data is waited for / written one phase before the phase that reads it.  WAR: a slot is
 // re-staged no earlier than the MFMA part of the phase after its last read (all waves have passed the lgkmcnt(0) behind that read by then).
+//
+// (A two-tile-deep prefetch of the fp32 A rows -- two register sets per unit -- was built and does not fit: 128 accumulator + 48 fragment + 32 in-flight registers
+//  plus the conversion's temporaries exceed 256, and what hipcc spills are the in-flight registers themselves.  The streamed operand is what holds this loop:
+//  tools/probe/gemm_ph_cached_probe.py, with the A rows cached the same launch runs 25 % faster, with B cached 8 %.)
 template <int P, bool AF32, int EPI>
 __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_ph_kernel(BpArgs p) {
     constexpr int KT = P == 2 ? 32 : 64;
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
     const uint32_t ek0 = p.e_k0 ^ s0, ek1 = p.e_k1 + s1;
     const int tile = ph_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;           // the column tiles of a row panel are neighbours on one XCD (the other order -- row panels
+    //                                                                    of a column tile adjacent -- measured slower on 14 of 17 shapes: tools/probe/gemm_ph_order_probe.py history)
     const int m0 = tm * 256, n0 = tn * 256;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -97,20 +102,20 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // k half of the single-plane mode)
     const int qrow = tid >> 2, qc = tid & 3;
     const float* ga[2];
-    ph_f32x4 rga[2][LA];              // in-flight A0 / A1 rows
+    ph_f32x4 rga[2][1][LA];           // in-flight A0 / A1 rows
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int ra = min(m0 + u * 128 + qrow, p.M - 1);
         ga[u] = AF32 ? reinterpret_cast<const float*>(p.A) + (long)ra * p.lda + kbeg + qc * 8 : nullptr;
     }
     const int woff = qrow * 64 + ((qc ^ ((qrow >> 2) & 3)) << 4);
-    auto load_regs = [&](int u, int t) __attribute__((always_inline)) {
+    auto load_regs = [&](int u, int t, int set = 0) __attribute__((always_inline)) {
         const float* g = ga[u] + (long)t * KT;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rga[u][0]) : "v"(g) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rga[u][1]) : "v"(g) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rga[u][set][0]) : "v"(g) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rga[u][set][1]) : "v"(g) : "memory");
         if constexpr (LA == 4) {
-            asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(rga[u][2]) : "v"(g) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:144" : "=v"(rga[u][3]) : "v"(g) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(rga[u][set][2]) : "v"(g) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:144" : "=v"(rga[u][set][3]) : "v"(g) : "memory");
         }
     };
     // (the LDS stores are inline asm too: hipcc orders a ds_write it can see behind EVERY outstanding global_load_lds -- s_waitcnt vmcnt(0) -- as a possible
@@ -119,20 +124,21 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const ph_u32x4 v = {v4.x, v4.y, v4.z, v4.w};
         asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
     };
-    auto write_regs = [&](int u, int t) __attribute__((always_inline)) {
+    auto write_regs = [&](int u, int t, int set = 0) __attribute__((always_inline)) {
+        const ph_f32x4 (&rg)[LA] = rga[u][set];
         const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (t & 1) * STAGE + u * UNIT + woff;
         if constexpr (P == 2) {
             uint2 h0, l0, h1, l1;
-            mdvit_split_bf16x3(make_float4(rga[u][0][0], rga[u][0][1], rga[u][0][2], rga[u][0][3]), h0, l0);
-            mdvit_split_bf16x3(make_float4(rga[u][1][0], rga[u][1][1], rga[u][1][2], rga[u][1][3]), h1, l1);
+            mdvit_split_bf16x3(make_float4(rg[0][0], rg[0][1], rg[0][2], rg[0][3]), h0, l0);
+            mdvit_split_bf16x3(make_float4(rg[1][0], rg[1][1], rg[1][2], rg[1][3]), h1, l1);
             lds_store16(dst, make_uint4(h0.x, h0.y, h1.x, h1.y));
             lds_store16(dst + UP, make_uint4(l0.x, l0.y, l1.x, l1.y));
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint2 h0, l0, h1, l1;
-                mdvit_split_bf16x3(make_float4(rga[u][2 * h][0], rga[u][2 * h][1], rga[u][2 * h][2], rga[u][2 * h][3]), h0, l0);
-                mdvit_split_bf16x3(make_float4(rga[u][2 * h + 1][0], rga[u][2 * h + 1][1], rga[u][2 * h + 1][2], rga[u][2 * h + 1][3]), h1, l1);
+                mdvit_split_bf16x3(make_float4(rg[2 * h][0], rg[2 * h][1], rg[2 * h][2], rg[2 * h][3]), h0, l0);
+                mdvit_split_bf16x3(make_float4(rg[2 * h + 1][0], rg[2 * h + 1][1], rg[2 * h + 1][2], rg[2 * h + 1][3]), h1, l1);
                 lds_store16(dst + h * UP, make_uint4(h0.x, h0.y, h1.x, h1.y));
             }
         }
@@ -257,50 +263,88 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     tile_body(nt - 1, F_{}, F_{}, PH_I(0), PH_I(0), PH_I(0), PH_I(0));
     if (wave < 4) PH_BAR();
 
-    // ---- epilogue (gemm_bp.hip's, on this kernel's block map): D[row = n][col = m] per 32x32 block -- for each register quad q a lane holds FOUR CONSECUTIVE
-    // output columns n = 8 q + 4 (lane >> 5) + (r & 3) of output row m = lane & 31
+    // ---- epilogue (gemm_bp.hip's arithmetic on this kernel's block map): D[row = n][col = m] per 32x32 block -- for each register quad q a lane holds FOUR
+    // CONSECUTIVE output columns n = 8 q + 4 (lane >> 5) + (r & 3) of output row m = lane & 31.
+    // Every LOAD is unconditional (clamped address, the value dropped by a select): hipcc puts s_waitcnt vmcnt(0) behind a branch that holds a load, and vmcnt
+    // counts the stores too -- a bias / residual / gelu_u quad fetched under `if` made every store wait for all the stores before it.  The operand rows of
+    // row block i + 1 are requested before block i is stored (the wait for them leaves block i's stores in flight).
     const bool split = (EPI == BEPI_PLAIN) && p.splits > 1;
     float* slab = split ? p.slab + (long)blockIdx.y * p.M * p.N : nullptr;
+    constexpr bool HAS_IN = EPI == BEPI_PLAIN || EPI == BEPI_DGELU || EPI == BEPI_FULL;       // an [M, N] fp32 operand read in the epilogue (old C | gelu_u | residual)
+    const bool use_in = EPI == BEPI_PLAIN ? (p.accumulate != 0 && !split) : (EPI == BEPI_DGELU ? true : p.residual != nullptr);
+    const float* in_p = EPI == BEPI_PLAIN ? p.C : (EPI == BEPI_DGELU ? p.gelu_u : p.residual);
+    const long in_ld = EPI == BEPI_PLAIN ? p.ldc : (EPI == BEPI_DGELU ? p.ldu : p.ldr);
+    if (!use_in || in_p == nullptr) in_p = reinterpret_cast<const float*>(p.B);               // any readable address: the value is dropped
+    const bool use_bias = p.bias != nullptr && !split;
+    const float* bias_p = use_bias ? p.bias : reinterpret_cast<const float*>(p.B);
+    float4 bq[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = min(n0 + j * 128 + wc * 32 + 8 * q + 4 * lhi, p.N - 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_p + (use_bias ? col : 0));
+            bq[j][q] = use_bias ? b4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    float rsc[4];
+    if constexpr (EPI == BEPI_FULL) {
+        const bool use_rs = p.e_rowscale != nullptr;
+        const float* rs_p = use_rs ? p.e_rowscale : reinterpret_cast<const float*>(p.B);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + l31, p.M - 1);
+            const float v = rs_p[use_rs ? row / p.e_rows_per_scale : 0];
+            rsc[i] = use_rs ? v : 1.f;
+        }
+    }
+    float4 inq[2][4];
+    auto load_in = [&](int ij) __attribute__((always_inline)) {
+        if constexpr (HAS_IN) {
+            const int i = ij >> 1, j = ij & 1;
+            const int row = min(m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + l31, p.M - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = min(n0 + j * 128 + wc * 32 + 8 * q + 4 * lhi, p.N - 4);
+                inq[ij & 1][q] = *reinterpret_cast<const float4*>(in_p + (use_in ? (long)row * in_ld + col : 0L));
+            }
+        }
+    };
+    load_in(0);
+#pragma unroll
+    for (int ij = 0; ij < 8; ++ij) {
+        const int i = ij >> 1, j = ij & 1;
+        if (ij + 1 < 8) load_in(ij + 1);
         const int row = m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + l31;
-        if (row >= p.M) continue;
-        float rsc = 1.f;
-        if (EPI == BEPI_FULL) rsc = p.e_rowscale ? p.e_rowscale[row / p.e_rows_per_scale] : 1.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        const bool row_ok = row < p.M;
+        {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = n0 + j * 128 + wc * 32 + 8 * q + 4 * lhi;
-                if (col >= p.N) continue;
+                const bool ok = row_ok && col < p.N;
                 float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                if (split) { *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = v; continue; }
-                if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                if (split) { if (ok) *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = v; continue; }
+                { const float4 b4 = bq[j][q]; v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
                 const uint32_t didx = (uint32_t)((long)row * p.N + col);
-                if (EPI == BEPI_PLAIN) {
-                    if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(p.C + (long)row * p.ldc + col); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                }
+                float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HAS_IN) { o4 = inq[ij & 1][q]; if (EPI != BEPI_DGELU && !use_in) o4 = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if (EPI == BEPI_PLAIN) { v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w; }
                 if (EPI == BEPI_GELU) {
-                    if (p.U) *reinterpret_cast<float4*>(p.U + (long)row * p.ldu_out + col) = v;
+                    if (p.U && ok) *reinterpret_cast<float4*>(p.U + (long)row * p.ldu_out + col) = v;
                     v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
                 }
-                if (EPI == BEPI_DGELU) {
-                    const float4 u4 = *reinterpret_cast<const float4*>(p.gelu_u + (long)row * p.ldu + col);
-                    v.x *= gelu_grad_f(u4.x); v.y *= gelu_grad_f(u4.y); v.z *= gelu_grad_f(u4.z); v.w *= gelu_grad_f(u4.w);
-                }
+                if (EPI == BEPI_DGELU) { v.x *= gelu_grad_f(o4.x); v.y *= gelu_grad_f(o4.y); v.z *= gelu_grad_f(o4.z); v.w *= gelu_grad_f(o4.w); }
                 if (EPI != BEPI_PLAIN && p.e_drop) {
                     const float4 ds = mdvit_drop_scale4(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
                     v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
                 }
                 if (EPI == BEPI_FULL) {
-                    v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
-                    if (p.residual) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col);
-                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                    }
+#pragma clang fp contract(off)
+                    const float rs = rsc[i];       // (a multiply and an add, never fused: gemm_bp.hip / gemm_body.inc / lin_rc_kernel do the same arithmetic, bit for bit)
+                    v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+                    v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
                 }
-                if (p.C) *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col) = v;
-                if (p.Cp) {
+                if (p.C && ok) *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col) = v;
+                if (p.Cp && ok) {
                     uint2 hi, lo;
                     mdvit_split_bf16x3(v, hi, lo);
                     uint16_t* d = p.Cp + (long)row * p.ldcp + col;
@@ -311,8 +355,6 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
 }
-
-int g_ph_variant = 1;
 
 template <int P, bool AF32>
 int launch_ph(const BpArgs& a, int epi, hipStream_t s) {
@@ -345,7 +387,21 @@ int mdvit_gemm_ph_launch(const BpArgs& a, int cfg, int planes, int epi, hipStrea
     return planes == 2 ? launch_ph<2, false>(a, epi, s) : launch_ph<1, false>(a, epi, s);
 }
 
-extern "C" int mdvit_gemm_ph_config(int32_t variant) {
-    g_ph_variant = variant;
+// Does the 256-wide kernel take this NT product?  Its workgroups own a whole CU: what decides is how much of the chip's round(s) of 256 x 256 tiles is real
+// output.  Measured against the 64 / 128 tiles at 2-5 workgroups per CU (tools/gemm_ph_check.py, fp32 A, one MI355X): it wins from ~0.72 (8192 x 1536 x 512:
+// 43.7 against 46.5 us at 0.75; 32768 x 960 x 320: 69.9 / 74.5 at 0.94; 8192 x 2048 x 512: 51.5 / 61.0 at 1.0) and loses below (16384 x 1280 x 320:
+// 63.9 / 49.1 at 0.625; 4096 x 2048 x 512: 38.4 / 32.0 at 0.5).  mode -1: never, 0: by that rule, 1: whenever the shape is legal.
+int g_ph_mode = 0;
+extern "C" int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes) {
+    const int kt = planes == 2 ? 32 : 64;
+    if (g_ph_mode < 0 || M <= 0 || N <= 0 || K < 2 * kt || K % kt != 0 || N % 4 != 0) return 0;
+    if (g_ph_mode > 0) return 1;
+    const long tiles = (long)cdiv(M, 256) * cdiv(N, 256), rounds = (tiles + 255) / 256;
+    const double eff = (double)M * N / ((double)rounds * 256.0 * 65536.0);
+    return eff >= 0.72 ? 1 : 0;
+}
+
+extern "C" int mdvit_gemm_ph_config(int32_t mode) {
+    g_ph_mode = mode;
     return MDVIT_OK;
 }

@@ -458,6 +458,9 @@ _plane_min_k = int(os.environ.get("MDVIT_PLANE_MIN_K", "1000000"))
 _tn_kernel = os.environ.get("MDVIT_TN_KERNEL", "1") != "0"
 if not _tn_kernel:                                                      # A/B: weight-gradient GEMMs on the general template instead of gemm_tn.hip
     _lib.load().mdvit_gemm_tn_config(0, -1, 0)                          # (the implicit-convolution weight gradient lives in gemm_tn.hip: conv3x3_dense then takes im2col + GEMM)
+_ph_gemm = os.environ.get("MDVIT_PH_GEMM", "1") != "0"                # the 256-wide phase-split kernel for the products it prefers (0: A/B switch)
+if not _ph_gemm:
+    _lib.load().mdvit_gemm_ph_config(-1)
 _plane_rc = os.environ.get("MDVIT_PLANE_RC", "0") != "0"              # the recomputing fc2 data gradient of the C = 128 MLPs on the plane kernel
 
 
@@ -650,11 +653,24 @@ def to_planes(x2d):
     return out
 
 
+_ph_cache = {}
+
+
+def _ph_prefers(M, N, K, planes=2) -> bool:
+    """the 256-wide phase-split plane kernel (csrc/gemm_ph.hip) takes [M, K] x [N, K]^T (mdvit_gemm_ph_prefers)"""
+    k = (M, N, K, planes)
+    r = _ph_cache.get(k)
+    if r is None:
+        r = _ph_cache[k] = bool(_lib.load().mdvit_gemm_ph_prefers(M, N, K, planes))
+    return r
+
+
 def _plane_ok(M, N, K) -> bool:
-    """the plane kernels cover this product (otherwise: the split-while-staging kernels of gemm.hip)"""
+    """the plane kernels cover this product (otherwise: the split-while-staging kernels of gemm.hip).  bf16x3: the products the 256-wide kernel
+    takes (the 64 / 128 plane tiles lose to gemm.hip in the step: profiles/r02_gemm_step_ab.txt); bf16: every legal one."""
     if not (_use_plane_gemm and _gemm_precision >= 1 and K % 32 == 0 and N % 4 == 0):
         return False
-    return _gemm_precision == 2 or K >= _plane_min_k
+    return _gemm_precision == 2 or K >= _plane_min_k or (_ph_gemm and _ph_prefers(M, N, K, 2))
 
 
 def _pp(v):
@@ -717,7 +733,10 @@ def gemm_nt(x, W, out, M, N, K, *, w_transposed=False, bias=None, epi=_lib.EPI_N
         tm, tn, sp = C.c_int32(), C.c_int32(), C.c_int32()
         call("mdvit_gemm_planes_plan", C.byref(d), C.byref(tm), C.byref(tn), C.byref(sp))
         plan = _plan_cache[pkey] = (tm.value, tn.value, sp.value)
-    name = "gemm_bp_nt_kernel<%d, %d, %d, %s, %d>%s" % (plan[0], plan[1], P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
+    if plan[0] == 256:       # csrc/gemm_ph.hip, as rocprofv3 prints it
+        name = "gemm_ph_kernel<%d, %s, %d>%s" % (P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
+    else:
+        name = "gemm_bp_nt_kernel<%d, %d, %d, %s, %d>%s" % (plan[0], plan[1], P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
     if _events_by_shape:
         name += " M=%d N=%d K=%d sp=%d" % (M, N, K, plan[2])
     if not _event_wanted(name):
@@ -1061,7 +1080,8 @@ class _MlpResidual(torch.autograd.Function):
             ctx.meta = (drop_p, k1, k2, rows_per_scale)
             ctx.b1_ref, ctx.b2_ref = b1, b2
             return out
-        plane = _plane_ok(M, Hd, Cin) and _plane_ok(M, Cin, Hd) and W1.is_contiguous() and W2.is_contiguous()
+        plane = _plane_ok(M, Hd, Cin) and W1.is_contiguous()
+        plane2 = _plane_ok(M, Cin, Hd) and W2.is_contiguous()
         if _mlp_recompute and _gemm_precision >= 1 and Cin <= _mlp_recompute_maxc and Cin % 32 == 0 and Hd % 4 == 0:
             u = None
             if plane:
@@ -1076,7 +1096,7 @@ class _MlpResidual(torch.autograd.Function):
                 gemm(_p(x), _p(W1), _p(u), M, Hd, Cin, lda=Cin, ldb=Cin, ldc=Hd, bias=_p(b1), out2=_p(h),
                      epi=_lib.EPI_GELU_DUAL, e_drop=drop_p, e_key=k1)
         out = _empty((M, Cin), device=x.device, dtype=torch.float32)
-        if plane:
+        if plane2:
             gemm_nt(h, W2, out, M, Cin, Hd, bias=b2, e_drop=drop_p, e_key=k2, e_rowscale=rowscale, e_rows_per_scale=rows_per_scale, residual=res)
         else:
             gemm(_p(h), _p(W2), _p(out), M, Cin, Hd, lda=Hd, ldb=Hd, ldc=Cin, bias=_p(b2),
@@ -2225,6 +2245,19 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
         if backward:
             d.projt_p = _p(ps[2])
         keep += ps
+    if d.precision == 1 and _ph_gemm and Cn >= 256 and not rc and W1.is_contiguous() and W2.is_contiguous() and params[4].is_contiguous() and params[16].is_contiguous():
+        # wide blocks: every NT product the 256-wide plane kernel prefers runs on it (block.hip: ph_takes) -- hand in the planes of the weights it may want
+        M_ = B * N
+        want = [("qkv_p", params[4], False, (M_, 3 * Cn, Cn)), ("proj_p", params[16], False, (M_, Cn, Cn)), ("fc1_p", W1, False, (M_, d.hidden, Cn)),
+                ("fc2_p", W2, False, (M_, Cn, d.hidden))]
+        if backward:
+            want = [("fc2t_p", W2, True, (M_, d.hidden, Cn)), ("fc1t_p", W1, True, (M_, Cn, d.hidden)), ("projt_p", params[16], True, (M_, Cn, Cn)),
+                    ("qkvt_p", params[4], True, (M_, Cn, 3 * Cn))]
+        for name, Wx, tr, shp in want:
+            if _ph_prefers(*shp, 2):
+                pl = _wplanes(Wx, tr, 2)
+                setattr(d, name, _p(pl))
+                keep.append(pl)
     if backward and d.precision == 1:
         ts = [wt(params[4]), wt(params[16])] + ([] if rc else [wt(W1), wt(W2)])
         d.qkv_wt, d.proj_wt = _p(ts[0]), _p(ts[1])

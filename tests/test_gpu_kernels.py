@@ -1140,6 +1140,48 @@ def test_plane_gemm_all_epilogues_vs_fp64():
     assert mod.correctness()
 
 
+def test_phase_split_256_tile_is_the_128_tile_bit_for_bit_in_every_epilogue():
+    """csrc/gemm_ph.hip (round 4: 256 x 256 tile, eight phase-split waves, global_load_lds ring with counted waits) through mdvit_gemm_planes with the plan
+    forced: plane A and fp32 A (split while staged through hidden asm loads), one and two planes, ragged M / N, K from two tiles up, every epilogue
+    (bias, GELU + u + dropout, DropPath + residual + dropout, gelu' x u, plane output, split-K + accumulate) -- against fp64 AND bit for bit against the
+    128 x 128 plane tile; 20 repeats of every shape must agree bit for bit (a race in the hand-counted vmcnt / barrier protocol shows up as rare wrong tiles)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gemm_ph_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gemm_ph_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.correctness([3])
+
+
+def test_linear_on_the_256_tile_equals_the_split_while_staging_kernel_bit_for_bit():
+    """ops.linear routes the products mdvit_gemm_ph_prefers accepts to the 256-wide plane kernel (MDVIT_PH_GEMM); forward, data gradient and the fused
+    FULL epilogue equal gemm.hip's results bit for bit (same products, same order), so a block may mix the two freely."""
+    from mdvit_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = 8192, 1536, 512
+    assert lib.mdvit_gemm_ph_prefers(M, N, K, 2) == 1 and lib.mdvit_gemm_ph_prefers(4096, 2048, 512, 2) == 0 and lib.mdvit_gemm_ph_prefers(M, N, 32, 2) == 0
+    x, W, b, g = rnd(M, K, seed=1).to(dev()), rnd(N, K, seed=2, scale=K ** -0.5).to(dev()), rnd(N, seed=3).to(dev()), rnd(M, N, seed=4).to(dev())
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision("bf16x3")
+    try:
+        res = {}
+        for mode in (0, -1):
+            lib.mdvit_gemm_ph_config(mode); ops._ph_cache.clear()
+            ops.kernel_events_begin()
+            out, go = grads_of(lambda x, W, b: ops.linear(x, W, b), [x, W, b], g)
+            names = list(ops.kernel_events_end())
+            res[mode] = (out, go, names)
+    finally:
+        lib.mdvit_gemm_ph_config(0); ops._ph_cache.clear()
+        ops.set_gemm_precision(prev)
+    assert any(n.startswith("gemm_ph_kernel<2, true") for n in res[0][2]), res[0][2]
+    assert not any(n.startswith("gemm_ph_kernel") or n.startswith("gemm_bp_nt_kernel") for n in res[-1][2]), res[-1][2]
+    assert torch.equal(res[0][0], res[-1][0])
+    for a, r in zip(res[0][1], res[-1][1]):
+        assert torch.equal(a, r)
+    ref, gr = grads_of(lambda x, W, b: F.linear(x.double(), W.double(), b.double()), [x.cpu(), W.cpu(), b.cpu()], g.cpu().double())
+    check(res[0][0], ref, tol=1e-4, name="y")
+
+
 def test_weight_plane_cache_follows_updates_and_the_optimizer_epoch():
     """the cached weight planes (W and W^T) are rebuilt when the parameter's version moves, and when an optimizer that writes
     through raw pointers says so (ops.mark_weights_updated: FusedAdamW.step does)"""

@@ -476,3 +476,22 @@ def test_reducer_single_process_is_a_noop_average():
     lin(torch.ones(2, 4)).sum().backward()
     red.finish()
     assert torch.allclose(lin.weight.grad, torch.full((4, 4), 2.0))
+
+
+def test_the_256_tile_takes_the_shapes_that_fill_whole_rounds_of_the_chip():
+    """mdvit_gemm_ph_prefers (host logic, csrc/gemm_ph.hip): the share of real output in the chip's rounds of 256 x 256 tiles decides; K must hold two K tiles of
+    the mode (32 k for two planes, 64 k for one); the A/B hook switches it off / forces it."""
+    from mdvit_amd import _lib
+    lib = _lib.load()
+    f = lib.mdvit_gemm_ph_prefers
+    assert f(32768, 960, 320, 2) == 1 and f(8192, 2048, 512, 2) == 1 and f(8192, 1536, 512, 2) == 1 and f(32768, 1280, 320, 2) == 1
+    assert f(16384, 1280, 320, 2) == 0 and f(4096, 2048, 512, 2) == 0 and f(32768, 320, 1280, 2) == 0 and f(8192, 512, 2048, 2) == 0
+    assert f(32768, 512, 2048, 2) == 1                      # the stage-3 shapes of the 128-image step
+    assert f(32768, 960, 48, 2) == 0 and f(32768, 960, 64, 2) == 1 and f(32768, 960, 64, 1) == 0 and f(32768, 960, 128, 1) == 1 and f(32768, 962, 320, 2) == 0
+    try:
+        lib.mdvit_gemm_ph_config(-1)
+        assert f(32768, 960, 320, 2) == 0
+        lib.mdvit_gemm_ph_config(1)
+        assert f(4096, 2048, 512, 2) == 1 and f(4096, 2048, 32, 2) == 0
+    finally:
+        lib.mdvit_gemm_ph_config(0)

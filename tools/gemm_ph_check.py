@@ -151,6 +151,52 @@ def timing(quick, cfgs, variants=(1,)):
               + " | ".join(cols) + f" | {fl / best / 1e6:5.0f}", flush=True)
 
 
+
+
+def timing_epilogues():
+    """the fused-epilogue launches of a C >= 320 block (fp32 A, weight planes): old split-while-staging kernel vs the 128 plane tiles vs the 256 tile"""
+    print("\nepilogue timing (fp32 A):   gemm.hip | plane 128 tiles (best) | cfg 3", flush=True)
+    cases = [("fc1 gelu dual s2", 32768, 1280, 320, "gelu"), ("fc2 dgrad dgelu s2", 32768, 1280, 320, "dgelu"), ("qkv plain s2", 32768, 960, 320, "plain"),
+             ("fc2 full s2", 32768, 320, 1280, "full"), ("fc1 gelu dual s3", 8192, 2048, 512, "gelu"), ("fc2 dgrad dgelu s3", 8192, 2048, 512, "dgelu"),
+             ("qkv plain s3", 8192, 1536, 512, "plain"), ("fc2 full s3", 8192, 512, 2048, "full"),
+             ("fc1 gelu dual s2 bs4", 16384, 1280, 320, "gelu"), ("fc1 gelu dual s3 bs4", 4096, 2048, 512, "gelu"),
+             ("fc1 gelu dual s2 step32", 131072, 1280, 320, "gelu")]
+    for note, M, N, K, kind in cases:
+        x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.1; b = torch.randn(N, device="cuda")
+        wp = planes_of(w)
+        out = torch.empty((M, N), device="cuda"); U = torch.empty((M, N), device="cuda"); res = torch.randn(M, N, device="cuda")
+        rs = torch.rand((M + 1023) // 1024, device="cuda")
+
+        def old():
+            if kind == "gelu":
+                ops.gemm(ops._p(x), ops._p(w), ops._p(U), M, N, K, lda=K, ldb=K, ldc=N, precision=1, bias=ops._p(b), out2=ops._p(out), epi=_lib.EPI_GELU_DUAL, e_drop=0.1, e_key=(1, 2))
+            elif kind == "dgelu":
+                ops.gemm(ops._p(x), ops._p(w), ops._p(out), M, N, K, lda=K, ldb=K, ldc=N, precision=1, epi=_lib.EPI_DGELU, gelu_u=ops._p(U), ldu=N, e_drop=0.1, e_key=(1, 2))
+            elif kind == "full":
+                ops.gemm(ops._p(x), ops._p(w), ops._p(out), M, N, K, lda=K, ldb=K, ldc=N, precision=1, bias=ops._p(b), residual=ops._p(res), ldr=N, e_drop=0.1, e_key=(1, 2),
+                         e_rowscale=ops._p(rs), e_rows_per_scale=1024)
+            else:
+                ops.gemm(ops._p(x), ops._p(w), ops._p(out), M, N, K, lda=K, ldb=K, ldc=N, precision=1, bias=ops._p(b))
+
+        def new():
+            if kind == "gelu":
+                run_bp(x, wp, M, N, K, a_f32=True, bias=b, epi=_lib.EPI_GELU_DUAL, C_out=out, U=U, drop=0.1, key=(1, 2))
+            elif kind == "dgelu":
+                run_bp(x, wp, M, N, K, a_f32=True, epi=_lib.EPI_DGELU, C_out=out, gelu_u=U, drop=0.1, key=(1, 2))
+            elif kind == "full":
+                run_bp(x, wp, M, N, K, a_f32=True, bias=b, C_out=out, residual=res, rowscale=rs, rps=1024, drop=0.1, key=(1, 2))
+            else:
+                run_bp(x, wp, M, N, K, a_f32=True, bias=b, C_out=out)
+        force(-1)
+        t_old = time_it(old)
+        t128 = 1e9
+        for cfg in (0, 1, 2):
+            force(cfg); t128 = min(t128, time_it(new))
+        force(3); t3 = time_it(new); force(-1)
+        fl = 2.0 * M * N * K
+        print(f"{note:24s} {M:6d}x{N:5d}x{K:5d}  {t_old:7.1f} us | {t128:7.1f} us | {t3:7.1f} us ({fl / t3 / 1e6:5.0f} TF)", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -158,6 +204,7 @@ if __name__ == "__main__":
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--cfgs", default="3")
     ap.add_argument("--variants", default="1")
+    ap.add_argument("--epilogues", action="store_true")
     a = ap.parse_args()
     cfgs = [int(c) for c in a.cfgs.split(",")]
     good = True
@@ -171,4 +218,6 @@ if __name__ == "__main__":
         print("CORRECTNESS", "PASS" if good else "FAIL", flush=True)
     if not a.no_timing:
         timing(a.quick, cfgs, variants)
+    if a.epilogues:
+        timing_epilogues()
     sys.exit(0 if good else 1)
