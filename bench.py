@@ -112,7 +112,7 @@ def cpu_baseline(size: int, budget_s: float = 80.0):
     from oracle.params import make_params
     from mdvit_amd.synthetic import make_domain_batch
     phys = _physical_cores()
-    cores = min(phys, 64)                   # oneDNN's thread pool stops scaling (and collapses when oversubscribed) well before that
+    cores = phys                            # all physical cores (rounds 1-3 capped at 64; the 64-thread figure is still printed: `mdvit_1img_64_threads`)
     torch.set_num_threads(cores)
 
     def timed(step, imgs):
@@ -141,6 +141,31 @@ def cpu_baseline(size: int, budget_s: float = 80.0):
         return tm.get("fwd_ms", 0.0), tm.get("bwd_ms", 0.0)
 
     mdvit = timed(mdvit_step, 1)
+    mdvit64 = None
+    if phys > 64:
+        torch.set_num_threads(64)
+        mdvit64 = timed(mdvit_step, 1)
+        torch.set_num_threads(cores)
+    # (3) the headline workload's own shape (BASELINE configs[1]): 4 domains x bs=4, one cold + one timed step (~1 minute each on the pool's host)
+    cfg2 = None
+    try:
+        batches = [make_domain_batch(4, size, d, 1234) for d in range(4)]
+        def cfg2_step():
+            st = R.RefState(training=True, drop_rate=0.1, drop_path_rate=0.1, aux_drop=0.1)
+            tm = {}
+            R.mdvit_train_step(P, [(b_[0], b_[1], d_) for d_, b_ in enumerate(batches)], st, timing=tm)
+            return tm.get("fwd_ms", 0.0), tm.get("bwd_ms", 0.0)
+        t0 = time.perf_counter(); cfg2_step(); cold = time.perf_counter() - t0
+        if cold <= 75.0:
+            t0 = time.perf_counter(); f_ms, b_ms = cfg2_step(); warm = time.perf_counter() - t0
+            cfg2 = {"images_per_s": round(16 / warm, 4), "step_s": round(warm, 3), "fwd_ms": round(f_ms, 1), "bwd_ms": round(b_ms, 1), "warmup": 1, "timed": 1,
+                    "first_cold_step_s": round(cold, 3)}
+        else:
+            cfg2 = {"images_per_s": round(16 / cold, 4), "step_s": round(cold, 3), "warmup": 0, "timed": 1, "note": "one COLD step only (it took more than 75 s)"}
+        cfg2["sample"] = f"BASELINE configs[1] shape: MDViT Sup, 4 domains x bs=4 {size}x{size}, fwd + BCE/Dice/KT + two-sweep bwd, {cores} threads"
+        del batches
+    except Exception as e:           # the baseline is a report, never a reason to lose the bench line
+        cfg2 = {"error": repr(e)}
     del P
     # (1) BASELINE configs[0]: BASE (no DA, no MKD) bs=4, single domain
     PB = R.to_torch(make_params(0, model="BASE", adapt_method=False))
@@ -157,7 +182,7 @@ def cpu_baseline(size: int, budget_s: float = 80.0):
             "cpu_model": _cpu_model(), "physical_cores": phys, "logical_cpus": os.cpu_count(),
             "sample": f"MDViT Sup: 1 domain x 1 image {size}x{size}, fwd + BCE/Dice/KT + two-sweep bwd, fp32 torch CPU oracle, "
                       f"{mdvit['warmup']} warm-up + {mdvit['timed']} timed steps, median {mdvit['median_step_s']} s",
-            "mdvit_1img": mdvit,
+            "mdvit_1img": mdvit, "mdvit_1img_64_threads": mdvit64, "mdvit_cfg2_4x4": cfg2,
             "base_bs4": dict(base, sample=f"BASELINE configs[0]: BASE bs=4 {size}x{size}, 1 domain, fwd + BCE/Dice + bwd, "
                                           f"{base['warmup']} warm-up + {base['timed']} timed steps, median")}
 
@@ -489,7 +514,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             common = ["--precision", args.precision] + (["--no-side-stream"] if args.no_side_stream else [])
-            b32 = _child_json([sys.executable, os.path.abspath(__file__), "--batch", "32", "--steps", "4", "--warmup", "4", "--no-cpu-baseline",
+            b32 = _child_json([sys.executable, os.path.abspath(__file__), "--batch", "32", "--steps", "8", "--warmup", "3", "--no-cpu-baseline",
                                "--no-extra-legs", "--no-kernel-events"] + common, 600)
             extra["bs32"] = {k: b32.get(k) for k in ("value", "unit", "ms_per_step", "phase_ms", "steps", "warmup", "memory", "host_enqueue_ms_per_step", "error") if k in b32}
             if "config" in b32:
@@ -527,14 +552,13 @@ def main():
                     blk = json.load(f)
                 extra["block_bs32"] = {
                     "what": "one SerialBlock_adapt (MHSA + Domain Adapter + MLP) forward + backward at bs=32, 512x512, per encoder stage; "
-                            "frac = operator-sum roofline bound / measured (tools/block_roofline.py); frac_survey = SURVEY 8(d) whole-block fused-bf16 bound / measured",
+                            "frac = STRICT operator-sum roofline bound (the MLP fused: no T x hidden bytes -- x, res -> y; gm, x -> dx; gm, x -> dW) / measured "
+                            "(tools/block_roofline.py); frac_unfused = the same operator list with the MLP as two GEMMs per pass (rounds 1-3 quoted that one as frac); "
+                            "frac_survey = SURVEY 8(d) whole-block fused-bf16 bound / measured",
                     "stages": [{"stage": r["stage"], "C": r["C"], "rows": r["rows"], "fwd_ms": round(r["fwd_ms"], 3), "bwd_ms": round(r["bwd_ms"], 3),
-                                "frac": round(r["frac"], 4), "frac_survey": round(r["frac_of_survey_fused_bf16_bound"], 4),
+                                "frac": round(r.get("frac_strict", 0.0), 4), "frac_unfused": round(r["frac"], 4), "frac_survey": round(r["frac_of_survey_fused_bf16_bound"], 4),
                                 "achieved_TBps": round(r["achieved_TBps"], 3), "achieved_TFLOPs": round(r["achieved_TFLOPs"], 1)} for r in blk["stages"]],
-                    "all_stages_frac": round(blk["all_stages"]["frac"], 4), "all_stages_frac_strict": round(blk["all_stages"].get("frac_strict", 0.0), 4),
-                    "strict": "frac_strict = the same bound with the MLP fused (no T x hidden bytes: x, res -> y; gm, x -> dx; gm, x -> dW) / measured"}
-                for r_, o_ in zip(blk["stages"], extra["block_bs32"]["stages"]):
-                    o_["frac_strict"] = round(r_.get("frac_strict", 0.0), 4)
+                    "all_stages_frac": round(blk["all_stages"].get("frac_strict", 0.0), 4), "all_stages_frac_unfused": round(blk["all_stages"]["frac"], 4)}
                 if "stage0_mlp_kernels" in blk and "largest" in blk["stage0_mlp_kernels"]:
                     big = blk["stage0_mlp_kernels"]["largest"]
                     extra["roofline_block_bs32"] = {

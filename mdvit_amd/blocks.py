@@ -424,6 +424,8 @@ class SerialBlock_adapt(nn.Module):
         att, mlp = self.factoratt_crpe, self.mlp
         if not x.is_cuda or att.proj_drop_p != mlp.drop_p or att.qkv.bias is None:
             return None
+        if not torch.is_grad_enabled():
+            return None        # inference: the block entry lays out the whole save buffer (~17 T C floats) at once; the operator path frees intermediates as it goes
         n1, n2 = _pick(self, "norm1", "norm1s"), _pick(self, "norm2", "norm2s")
         if isinstance(n1, _BankLN):
             (g1, b1), (g2, b2) = n1._params(), n2._params()

@@ -132,7 +132,9 @@ int fork_side(const MdvitBlockDesc& d, const MdvitBlockStreams& st, hipStream_t&
     side = (hipStream_t)st.side;
     if (side == nullptr || side == (hipStream_t)st.main) { side = (hipStream_t)st.main; return MDVIT_OK; }
     if (st.n_events <= 0 || st.events == nullptr) return mdvit_set_error(MDVIT_E_SHAPE, "block: a side stream needs events");
-    hipEvent_t ev = (hipEvent_t)st.events[(*st.next_event)++ % st.n_events];
+    const int ei = *st.next_event;                 // wrapped explicitly: the counter only ever moved up, and a signed overflow indexed out of bounds
+    *st.next_event = (ei + 1) % st.n_events;
+    hipEvent_t ev = (hipEvent_t)st.events[(ei % st.n_events + st.n_events) % st.n_events];
     hipError_t e = hipEventRecord(ev, (hipStream_t)st.main);
     if (e == hipSuccess) e = hipStreamWaitEvent(side, ev, 0);
     if (e != hipSuccess) return mdvit_set_error(MDVIT_E_HIP, "block: side-stream fork failed: %s", hipGetErrorString(e));

@@ -309,8 +309,9 @@ class _on_side:
     """with _on_side(t1, t2, ...): launches go to the side stream, ordered after everything already enqueued on the
     main stream; the listed main-stream tensors are protected from reuse until the side work is done (bounded: _side_protect)."""
 
-    def __init__(self, *tensors):
+    def __init__(self, *tensors, foreign=True):
         self.tensors = [t for t in tensors if t is not None]
+        self.foreign = foreign and bool(tensors) and tensors[0] is not None
         self.ctx = None
 
     def __enter__(self):
@@ -328,6 +329,10 @@ class _on_side:
             grp[1].extend(self.tensors)
             for t in self.tensors:
                 grp[2] += t.numel() * t.element_size()
+            if self.tensors and self.foreign:
+                # the FIRST tensor is the upstream gradient: the one protected tensor a node of ANOTHER stream may have allocated (a peer-head / branch-stream
+                # join).  Its block goes back to THAT stream's pool, which never waits for the side stream -- so the allocator is told.
+                self.tensors[0].record_stream(_side_stream)
         else:
             for t in self.tensors:
                 t.record_stream(_side_stream)
@@ -1138,8 +1143,7 @@ class _MlpResidual(torch.autograd.Function):
                 wsb = _lib.load().mdvit_mlp_rc_wgrad_ws_bytes(M, Cin, Hd)
                 if sunk:
                     with _on_side(gm, x, W1p, W2tp):
-                        ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
-                        _side_keepalive.append(ws)
+                        ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)     # allocated on the side stream: freed in its order, nothing to protect
                         call("mdvit_mlp_rc_wgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(sinks[0]), _p(sinks[1]), _p(sinks[2]), _p(ws), wsb,
                              M, Cin, Hd, drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, 1, _stream())
                     db2 = None
@@ -1307,7 +1311,6 @@ class _DwConv3x3(torch.autograd.Function):
                 # weight gradient on the side stream, accumulated straight into the gradient buckets
                 with _on_side(g, x) as _:
                     wsp, wsb, keep = _partials_ws(10 * Cn, x.device)
-                    _side_keepalive.append(keep)
                     call("mdvit_dwconv3x3_bwd", _p(g), _p(x), _p(w), None, _p(sw), _p(sb), wsp, wsb, B, H, W_, Cn, stride, int(add_input), 1, _stream())
             else:
                 dw, db = _flat_like(w, (Cn,) if has_b else None)
@@ -1346,7 +1349,6 @@ class _GConv2(torch.autograd.Function):
         if sw is not None:      # weight gradient on the side stream, into the gradient bucket
             with _on_side(g, skip, up):
                 wsp, wsb, keep = _partials_ws(18 * Cn, g.device)
-                _side_keepalive.append(keep)
                 call("mdvit_gconv2_3x3_bwd", _p(g), _p(skip), _p(up), _p(w), None, None, _p(sw), wsp, wsb, B, H, W_, Cn, 1, _stream())
         return dskip, dup, dw
 
@@ -1560,6 +1562,10 @@ def _ones_flat(n, device):
     k = (str(device), n)
     t = _ones_cache.get(k)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a fill captured into a graph only runs at replay and lives in the graph's private pool: never cache it (an eager caller before the first
+            # replay would read uninitialised "ones") -- a per-call tensor inside the capture instead
+            return torch.ones((n,), device=device, dtype=torch.float32)
         t = _ones_cache[k] = torch.ones((n,), device=device, dtype=torch.float32)
     return t
 
@@ -1628,7 +1634,6 @@ class _StemConv(torch.autograd.Function):
         if sw is not None:
             with _on_side(g, img):
                 wsp, wsb, keep = _partials_ws(27 * w.shape[0], g.device)
-                _side_keepalive.append(keep)
                 call("mdvit_stemconv_wgrad", _p(img), _p(g), _p(sw), wsp, wsb, B, H, W_, Cin, w.shape[0], 1, _stream())
             return None, None
         dw = _empty_like(w)
@@ -2075,7 +2080,7 @@ class _FactorAtt(torch.autograd.Function):
              _p(Mmat), _p(dqkv), _p(e), *[_p(t) for t in dws], _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2],
              _stream())
         if deferred:
-            with _on_side(ws, qkv):
+            with _on_side(ws, qkv, foreign=False):
                 call("mdvit_factoratt_wgrad", _p(qkv), _p(ws), wsb, *[_p(t) for t in sinks], B, H, W_, Cn, heads,
                      splits[0], splits[1], splits[2], 1, _stream())
         dW1 = db1 = dW2 = db2 = None
@@ -2179,7 +2184,7 @@ def _trim_side_groups(limit):
         _side_held[0] -= n
 
 
-def _side_protect(*tensors):
+def _side_protect(*tensors, foreign=None):
     """tensors of the current stream that weight-gradient launches on the side stream read: kept allocated (and safe from autograd's in-place accumulation,
     which needs sole ownership) until the side stream has passed those launches -- known either from the completed event or because the owning stream
     was made to wait for it (the hold bound)."""
@@ -2195,6 +2200,8 @@ def _side_protect(*tensors):
             _side_blocks.append((ev, len(_side_keepalive)))
             _release_finished_side_blocks()
         return
+    if foreign is not None:
+        foreign.record_stream(_side_stream)       # the upstream gradient: possibly allocated by another stream's node (see _on_side)
     ev = torch.cuda.Event()
     ev.record(_side_stream)
     n = sum(t.numel() * t.element_size() for t in ts)
@@ -2337,7 +2344,7 @@ class _SerialBlock(torch.autograd.Function):
         ws_side = _empty((sbytes.value // 4,), device=dev, dtype=torch.float32)   # what the weight-gradient kernels read: kept until the side stream is done
         call("mdvit_block_bwd", C.byref(d), C.byref(G), C.byref(st), _p(x), _p(save), save.numel() * 4, _p(g), _p(dx), _p(ws), wb, _p(ws_side), sbytes.value)
         if side is not None:
-            _side_protect(ws_side, save, g, x, *keep)
+            _side_protect(ws_side, save, g, x, *keep, foreign=g)
         del keep
         return (dx, None, None, None, None, *out)
 
