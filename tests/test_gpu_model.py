@@ -769,6 +769,85 @@ def test_data_parallel_code_path_on_one_gpu(tmp_path):
     assert r.returncode == 0 and "dp-path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+_DP2_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(rank)
+dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", device_id=dev)
+import mdvit_amd
+from mdvit_amd import ops
+from mdvit_amd.parallel import GradAccumulator, broadcast_parameters
+from mdvit_amd.synthetic import make_step_batches
+from mdvit_amd.train import mdvit_train_step
+
+def model():
+    torch.manual_seed(0)
+    m = mdvit_amd.MDViT(img_size=64, drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4,
+                        decoder_name="MLPFM").to(dev).train()
+    for d in range(1, 5):
+        getattr(m, f"debranch{d}").dropout.p = 0.0
+    return m
+
+def dp_step(global_losses):
+    ops.set_global_batch_losses(global_losses)
+    ops._force_collectives = world == 1       # (a one-rank dry run of this script still takes the collective code paths)
+    m = model()
+    broadcast_parameters(m)
+    ops.enable_side_stream(True)
+    da = [p for n, p in m.named_parameters() if "domain_layer" in n]
+    acc = GradAccumulator(m.parameters(), bucket_bytes=4 << 20, late=da); acc.attach_sinks()
+    out = mdvit_train_step(m, make_step_batches(2, 64, rank=rank, step=0, device=dev), optimizer=None, accumulator=acc, merged_sweeps=True, fuse_domains=4)
+    torch.cuda.synchronize()
+    assert acc.overlapped_buckets == acc._n_early > 0, (acc.overlapped_buckets, acc._n_early)       # on the wire underneath the aux sweep
+    g = [p.grad.clone() for p in m.parameters()]
+    ops.set_grad_sinks(None); ops.enable_side_stream(False); ops._force_collectives = False
+    return [float(out[k]) for k in ("loss", "aux_loss", "kt_loss")], g
+
+# (1) per-rank losses: the DP gradient is the mean of the ranks' own gradients -- the reference is two plain single-process steps, no collective in them
+l_dp, g_dp = dp_step(False)
+ops.set_global_batch_losses(False)
+ref = None
+for r in range(world):
+    m = model()
+    mdvit_train_step(m, make_step_batches(2, 64, rank=r, step=0, device=dev), optimizer=None, merged_sweeps=True, fuse_domains=4)
+    torch.cuda.synchronize()
+    g = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in m.parameters()]
+    ref = g if ref is None else [a + b for a, b in zip(ref, g)]
+ref = [a / world for a in ref]
+worst = max(float((x - y).norm() / (y.norm() + 1e-20)) for x, y in zip(g_dp, ref) if float(y.norm()) > 0)
+assert worst < 2e-3, worst
+# (2) global-batch losses (the 16 loss sums per domain all-reduced): every rank ends with the SAME averaged gradients and the SAME losses
+l_g, g_g = dp_step(True)
+flat = torch.cat([t.reshape(-1) for t in g_g]); other = flat.clone()
+dist.broadcast(other, src=0)
+assert torch.equal(flat, other) and bool(torch.isfinite(flat).all())
+lt = torch.tensor(l_g, device=dev); l0 = lt.clone(); dist.broadcast(l0, src=0)
+assert torch.equal(lt, l0), (lt, l0)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "dp2 ok", worst)
+"""
+
+
+def test_data_parallel_two_ranks_over_rccl(tmp_path):
+    """World size 2 over RCCL (skipped below two devices -- the builder's pool has one; the first multi-GPU box runs it): the product DP step (gradient
+    buckets with the adapters late, every other bucket all-reduced from the side stream's context underneath the aux sweep, loss sums all-reduced) against
+    single-process references -- the DataParallel replacement of multi_train_MDViT.py:72-74."""
+    import subprocess, sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    script = tmp_path / "dp2_worker.py"
+    script.write_text(_DP2_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} dp2 ok" in o, f"rank {r}:\n{o[-3000:]}"
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # round 2: the optimizer owns the invalidation of the cached W^T / weight planes; parity at the benchmark's own size
 # ------------------------------------------------------------------------------------------------------------------------
