@@ -185,6 +185,9 @@ int mdvit_gemm_planes(const MdvitPlaneGemmDesc* desc, void* stream);
  * the chip's rounds of 256 x 256 tiles decides; K % 32 == 0 (planes = 2) / % 64 (planes = 1), at least two K tiles).  mdvit_gemm_ph_config: -1 never, 0 that
  * rule (default), 1 whenever legal (A/B and test hook). */
 int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes);
+/* the same for a launch whose epilogue READS an [M, N] operand (epi_reads != 0: gelu_u of the fc2 data gradient -- mpvit.py:75's backward --, the residual of
+ * mdvit.py:353,357-360, an accumulating C): one workgroup per CU hides no load latency, such launches are taken only when the tiles fill whole rounds */
+int mdvit_gemm_ph_prefers_epi(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t epi_reads);
 int mdvit_gemm_ph_config(int32_t mode);
 /* fp32 [rows, cols] (ld_in) -> planes [planes][rows][ld_out]; cols % 8 == 0 */
 int mdvit_split_planes(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t plane_stride, int64_t rows, int32_t cols, int32_t planes, void* stream);

@@ -101,6 +101,7 @@ _SIGS = {
     "mdvit_gemm_planes_force_plan": [i32, i32],
     "mdvit_gemm_ph_config": [i32],
     "mdvit_gemm_ph_prefers": [i32, i32, i32, i32],
+    "mdvit_gemm_ph_prefers_epi": [i32, i32, i32, i32, i32],
     "mdvit_mlp_config": [i32, i32],
     "mdvit_mlp_rc_config": [i32],
     "mdvit_mlp_rc_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],

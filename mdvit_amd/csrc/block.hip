@@ -71,9 +71,10 @@ void gemm_init(MdvitGemmDesc& g, const MdvitBlockDesc& d) {
 
 // An NT product of the block on the 256-wide plane kernel (gemm_ph.hip through mdvit_gemm_planes: fp32 activations split while staged, the weight as its
 // per-step bf16 planes [2][N][K]) -- when the weight's planes were handed in and mdvit_gemm_ph_prefers takes the shape.  Same arithmetic, same results.
-bool ph_takes(const MdvitBlockDesc& d, const void* planes, int M, int N, int K) {
-    return d.precision == 1 && planes != nullptr && mdvit_gemm_ph_prefers(M, N, K, 2) != 0;
+bool ph_takes(const MdvitBlockDesc& d, const void* planes, int M, int N, int K, int epi_reads) {
+    return d.precision == 1 && planes != nullptr && mdvit_gemm_ph_prefers_epi(M, N, K, 2, epi_reads) != 0;
 }
+int epi_reads_of(const MdvitGemmDesc& g) { return g.gelu_u != nullptr || g.residual != nullptr || g.accumulate != 0; }
 int gemm_planes_nt(Arena& A, const MdvitGemmDesc& g, const void* planes, hipStream_t s) {
     MdvitPlaneGemmDesc pd;
     memset(&pd, 0, sizeof(pd));
@@ -92,7 +93,7 @@ int gemm_planes_nt(Arena& A, const MdvitGemmDesc& g, const void* planes, hipStre
 
 // C = A W^T (+ epilogue): the forward layers
 int gemm_fwd(Arena& A, MdvitGemmDesc& g, hipStream_t s, const MdvitBlockDesc* d = nullptr, const void* planes = nullptr) {
-    if (d && ph_takes(*d, planes, g.M, g.N, g.K)) return gemm_planes_nt(A, g, planes, s);
+    if (d && ph_takes(*d, planes, g.M, g.N, g.K, epi_reads_of(g))) return gemm_planes_nt(A, g, planes, s);
     g.trans_a = 0; g.trans_b = 1; g.allow_split = 1;
     const size_t need = mdvit_gemm_ws_bytes(&g);
     g.ws = need ? A.take_bytes(need) : nullptr; g.ws_bytes = need;
@@ -104,7 +105,7 @@ int gemm_fwd(Arena& A, MdvitGemmDesc& g, hipStream_t s, const MdvitBlockDesc* d 
 int gemm_dgrad(Arena& A, const MdvitBlockDesc& d, MdvitGemmDesc& g, const float* gy, const float* W, const float* Wt, float* dx, int M, int K, int N, hipStream_t s,
                const void* planes_t = nullptr) {
     g.A = gy; g.C = dx; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldc = K;
-    if (ph_takes(d, planes_t, M, K, N) && !g.rc_a) return gemm_planes_nt(A, g, planes_t, s);
+    if (ph_takes(d, planes_t, M, K, N, epi_reads_of(g)) && !g.rc_a) return gemm_planes_nt(A, g, planes_t, s);
     if (d.precision >= 1) { g.B = Wt; g.ldb = N; g.trans_a = 0; g.trans_b = 1; g.precision = 1; }
     else { g.B = W; g.ldb = K; g.trans_a = 0; g.trans_b = 0; g.precision = 0; }
     const size_t need = g.allow_split ? mdvit_gemm_ws_bytes(&g) : 0;
@@ -220,14 +221,14 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
         if (mode == MLP_RECOMP) { g.C = sv.h; g.C2 = nullptr; }            // gelu(u) only: the backward recomputes u
         else { g.C = sv.u; g.C2 = sv.h; }
         g.trans_a = 0; g.trans_b = 1; g.allow_split = 0;
-        if (ph_takes(d, d.fc1_p, M, Hd, C)) { const int rc = gemm_planes_nt(A, g, d.fc1_p, s); if (rc != MDVIT_OK) return rc; }
+        if (ph_takes(d, d.fc1_p, M, Hd, C, 0)) { const int rc = gemm_planes_nt(A, g, d.fc1_p, s); if (rc != MDVIT_OK) return rc; }
         else BLK_RUN(mdvit_gemm_f32(&g, s));
         gemm_init(g, d);
         g.A = sv.h; g.B = d.fc2_w; g.C = y; g.M = M; g.N = C; g.K = Hd; g.lda = Hd; g.ldb = Hd; g.ldc = C; g.bias = d.fc2_b;
         g.e_drop_p = d.drop_p; g.e_key0 = d.key_fc2[0]; g.e_key1 = d.key_fc2[1]; g.e_rowscale = d.rowscale2; g.e_rows_per_scale = N_tok;
         g.residual = sv.x2; g.ldr = C; g.drop_seed = seed;
         g.trans_a = 0; g.trans_b = 1; g.allow_split = 0;
-        if (ph_takes(d, d.fc2_p, M, C, Hd)) { const int rc = gemm_planes_nt(A, g, d.fc2_p, s); if (rc != MDVIT_OK) return rc; }
+        if (ph_takes(d, d.fc2_p, M, C, Hd, 1)) { const int rc = gemm_planes_nt(A, g, d.fc2_p, s); if (rc != MDVIT_OK) return rc; }
         else BLK_RUN(mdvit_gemm_f32(&g, s));
     }
     return MDVIT_OK;

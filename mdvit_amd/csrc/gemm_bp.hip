@@ -341,11 +341,11 @@ BpPlan plan_ph(const MdvitPlaneGemmDesc* d, int cfg) {
     return best;
 }
 
-extern "C" int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes);
 
 BpPlan plan_bp(const MdvitPlaneGemmDesc* d) {
     if (g_bp_force_cfg >= 3) return plan_ph(d, g_bp_force_cfg);
-    if (g_bp_force_cfg < 0 && !d->rc_a && mdvit_gemm_ph_prefers(d->M, d->N, d->K, d->planes)) {
+    const int epi_reads = d->gelu_u != nullptr || d->residual != nullptr || d->accumulate != 0;
+    if (g_bp_force_cfg < 0 && !d->rc_a && mdvit_gemm_ph_prefers_epi(d->M, d->N, d->K, d->planes, epi_reads)) {
         BpPlan pl = plan_ph(d, 3);
         if (pl.splits == 1) return pl;
     }

@@ -297,7 +297,8 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             rsc[i] = use_rs ? v : 1.f;
         }
     }
-    float4 inq[2][4];
+    constexpr int IND = 3;            // blocks of the epilogue operand in flight (one workgroup per CU: nothing else hides their latency)
+    float4 inq[IND][4];
     auto load_in = [&](int ij) __attribute__((always_inline)) {
         if constexpr (HAS_IN) {
             const int i = ij >> 1, j = ij & 1;
@@ -305,15 +306,16 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = min(n0 + j * 128 + wc * 32 + 8 * q + 4 * lhi, p.N - 4);
-                inq[ij & 1][q] = *reinterpret_cast<const float4*>(in_p + (use_in ? (long)row * in_ld + col : 0L));
+                inq[ij % IND][q] = *reinterpret_cast<const float4*>(in_p + (use_in ? (long)row * in_ld + col : 0L));
             }
         }
     };
-    load_in(0);
+#pragma unroll
+    for (int ij = 0; ij < IND - 1; ++ij) load_in(ij);
 #pragma unroll
     for (int ij = 0; ij < 8; ++ij) {
         const int i = ij >> 1, j = ij & 1;
-        if (ij + 1 < 8) load_in(ij + 1);
+        if (ij + IND - 1 < 8) load_in(ij + IND - 1);
         const int row = m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + l31;
         const bool row_ok = row < p.M;
         {
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 { const float4 b4 = bq[j][q]; v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
                 const uint32_t didx = (uint32_t)((long)row * p.N + col);
                 float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (HAS_IN) { o4 = inq[ij & 1][q]; if (EPI != BEPI_DGELU && !use_in) o4 = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if constexpr (HAS_IN) { o4 = inq[ij % IND][q]; if (EPI != BEPI_DGELU && !use_in) o4 = make_float4(0.f, 0.f, 0.f, 0.f); }
                 if (EPI == BEPI_PLAIN) { v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w; }
                 if (EPI == BEPI_GELU) {
                     if (p.U && ok) *reinterpret_cast<float4*>(p.U + (long)row * p.ldu_out + col) = v;
@@ -391,15 +393,20 @@ int mdvit_gemm_ph_launch(const BpArgs& a, int cfg, int planes, int epi, hipStrea
 // output.  Measured against the 64 / 128 tiles at 2-5 workgroups per CU (tools/gemm_ph_check.py, fp32 A, one MI355X): it wins from ~0.72 (8192 x 1536 x 512:
 // 43.7 against 46.5 us at 0.75; 32768 x 960 x 320: 69.9 / 74.5 at 0.94; 8192 x 2048 x 512: 51.5 / 61.0 at 1.0) and loses below (16384 x 1280 x 320:
 // 63.9 / 49.1 at 0.625; 4096 x 2048 x 512: 38.4 / 32.0 at 0.5).  mode -1: never, 0: by that rule, 1: whenever the shape is legal.
+// epi_reads != 0: the epilogue READS an [M, N] operand (gelu_u of the fc2 data gradient, the residual of proj / fc2, the old C of an accumulating launch).  With
+// one workgroup per CU nothing hides those loads' latency (the 64 / 128 tiles overlap them with a neighbour's main loop): 32768 x 1280 x 320 with the gelu'
+// epilogue runs 174-177 us here against 153-158 us on gemm.hip although the plain product ties (0.83 of three rounds); 8192 x 2048 x 512 (one full round) wins
+// 61-62 against 76-77.  Such launches are taken from 0.9.
 int g_ph_mode = 0;
-extern "C" int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes) {
+extern "C" int mdvit_gemm_ph_prefers_epi(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t epi_reads) {
     const int kt = planes == 2 ? 32 : 64;
     if (g_ph_mode < 0 || M <= 0 || N <= 0 || K < 2 * kt || K % kt != 0 || N % 4 != 0) return 0;
     if (g_ph_mode > 0) return 1;
     const long tiles = (long)cdiv(M, 256) * cdiv(N, 256), rounds = (tiles + 255) / 256;
     const double eff = (double)M * N / ((double)rounds * 256.0 * 65536.0);
-    return eff >= 0.72 ? 1 : 0;
+    return eff >= (epi_reads ? 0.9 : 0.72) ? 1 : 0;
 }
+extern "C" int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes) { return mdvit_gemm_ph_prefers_epi(M, N, K, planes, 0); }
 
 extern "C" int mdvit_gemm_ph_config(int32_t mode) {
     g_ph_mode = mode;

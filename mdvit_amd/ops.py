@@ -661,21 +661,21 @@ def to_planes(x2d):
 _ph_cache = {}
 
 
-def _ph_prefers(M, N, K, planes=2) -> bool:
-    """the 256-wide phase-split plane kernel (csrc/gemm_ph.hip) takes [M, K] x [N, K]^T (mdvit_gemm_ph_prefers)"""
-    k = (M, N, K, planes)
+def _ph_prefers(M, N, K, planes=2, reads=False) -> bool:
+    """the 256-wide phase-split plane kernel (csrc/gemm_ph.hip) takes [M, K] x [N, K]^T (mdvit_gemm_ph_prefers_epi; reads: the epilogue reads an [M, N] operand)"""
+    k = (M, N, K, planes, bool(reads))
     r = _ph_cache.get(k)
     if r is None:
-        r = _ph_cache[k] = bool(_lib.load().mdvit_gemm_ph_prefers(M, N, K, planes))
+        r = _ph_cache[k] = bool(_lib.load().mdvit_gemm_ph_prefers_epi(M, N, K, planes, int(bool(reads))))
     return r
 
 
-def _plane_ok(M, N, K) -> bool:
+def _plane_ok(M, N, K, reads=False) -> bool:
     """the plane kernels cover this product (otherwise: the split-while-staging kernels of gemm.hip).  bf16x3: the products the 256-wide kernel
     takes (the 64 / 128 plane tiles lose to gemm.hip in the step: profiles/r02_gemm_step_ab.txt); bf16: every legal one."""
     if not (_use_plane_gemm and _gemm_precision >= 1 and K % 32 == 0 and N % 4 == 0):
         return False
-    return _gemm_precision == 2 or K >= _plane_min_k or (_ph_gemm and _ph_prefers(M, N, K, 2))
+    return _gemm_precision == 2 or K >= _plane_min_k or (_ph_gemm and _ph_prefers(M, N, K, 2, reads))
 
 
 def _pp(v):
@@ -780,7 +780,7 @@ def _dgrad(g, W, dx, M, K, N, ldb, **kw):
     if _lin_rc_ok(M, K, N) and ldb == K and not (set(kw) - {"allow_split"}):
         _linear_rc(g, W, True, None, dx, M, K, N)
         return
-    if _plane_ok(M, K, N) and "rc" not in kw and "precision" not in kw:
+    if _plane_ok(M, K, N, kw.get("gelu_u") is not None) and "rc" not in kw and "precision" not in kw:
         gemm_nt(g, W, dx, M, K, N, w_transposed=True, **kw)
         return
     if _gemm_precision:
@@ -908,7 +908,7 @@ class _Linear(torch.autograd.Function):
         key = _next_key() if drop_p > 0 else (0, 0)
         if _lin_rc_ok(M, N, K) and ldb == K and (residual is not None or (drop_p == 0 and rowscale is None)):
             _linear_rc(x, W, False, b, y, M, N, K, drop_p, key, rowscale, rows_per_scale, residual)
-        elif _plane_ok(M, N, K):
+        elif _plane_ok(M, N, K, residual is not None):
             gemm_nt(x, W, y, M, N, K, bias=b, e_drop=drop_p, e_key=key, e_rowscale=rowscale, e_rows_per_scale=rows_per_scale,
                     residual=residual, allow_split=True)
         else:
@@ -1086,7 +1086,7 @@ class _MlpResidual(torch.autograd.Function):
             ctx.b1_ref, ctx.b2_ref = b1, b2
             return out
         plane = _plane_ok(M, Hd, Cin) and W1.is_contiguous()
-        plane2 = _plane_ok(M, Cin, Hd) and W2.is_contiguous()
+        plane2 = _plane_ok(M, Cin, Hd, res is not None) and W2.is_contiguous()
         if _mlp_recompute and _gemm_precision >= 1 and Cin <= _mlp_recompute_maxc and Cin % 32 == 0 and Hd % 4 == 0:
             u = None
             if plane:
@@ -2255,13 +2255,13 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
     if d.precision == 1 and _ph_gemm and Cn >= 256 and not rc and W1.is_contiguous() and W2.is_contiguous() and params[4].is_contiguous() and params[16].is_contiguous():
         # wide blocks: every NT product the 256-wide plane kernel prefers runs on it (block.hip: ph_takes) -- hand in the planes of the weights it may want
         M_ = B * N
-        want = [("qkv_p", params[4], False, (M_, 3 * Cn, Cn)), ("proj_p", params[16], False, (M_, Cn, Cn)), ("fc1_p", W1, False, (M_, d.hidden, Cn)),
-                ("fc2_p", W2, False, (M_, Cn, d.hidden))]
+        want = [("qkv_p", params[4], False, (M_, 3 * Cn, Cn), 0), ("proj_p", params[16], False, (M_, Cn, Cn), 1), ("fc1_p", W1, False, (M_, d.hidden, Cn), 0),
+                ("fc2_p", W2, False, (M_, Cn, d.hidden), 1)]
         if backward:
-            want = [("fc2t_p", W2, True, (M_, d.hidden, Cn)), ("fc1t_p", W1, True, (M_, Cn, d.hidden)), ("projt_p", params[16], True, (M_, Cn, Cn)),
-                    ("qkvt_p", params[4], True, (M_, Cn, 3 * Cn))]
-        for name, Wx, tr, shp in want:
-            if _ph_prefers(*shp, 2):
+            want = [("fc2t_p", W2, True, (M_, d.hidden, Cn), 1), ("fc1t_p", W1, True, (M_, Cn, d.hidden), 0), ("projt_p", params[16], True, (M_, Cn, Cn), 0),
+                    ("qkvt_p", params[4], True, (M_, Cn, 3 * Cn), 0)]
+        for name, Wx, tr, shp, rd in want:
+            if _ph_prefers(*shp, 2, rd):
                 pl = _wplanes(Wx, tr, 2)
                 setattr(d, name, _p(pl))
                 keep.append(pl)
