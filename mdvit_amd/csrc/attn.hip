@@ -34,69 +34,24 @@ struct FaGeom {
 // fixed order -- and only the head-diagonal Ch x Ch blocks are written out.
 typedef float fap_f32x16 __attribute__((ext_vector_type(16)));
 
+// Round 4: a workgroup walks NSUB consecutive 64-token tiles and keeps ONE partial result for all of them (online softmax across its tiles: running column
+// max / exp-sum in LDS, the accumulators rescaled by exp(m_old - m_new) per tile) -- NSUB times fewer partial rows for the combine pass to walk (it was
+// latency-bound on 256 rows per image at the stage-0 shape: 40 us), NSUB times less workspace traffic, the four-wave LDS reduction once per NSUB tiles.
 template <int CH, bool SOFTMAX>
 __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
                                                          const float* __restrict__ ysc, float yscale,
                                                          float* __restrict__ ws_m, float* __restrict__ ws_s, float* __restrict__ ws_P,
-                                                         FaGeom g, int NT) {
+                                                         FaGeom g, int NT, int NSUB) {
     constexpr int GW = CH < 32 ? 32 : CH, NB = (GW + 31) / 32, GQ = GW / 4;
     constexpr int STAGE = 2 * FA_T * GW, RED = 4 * NB * 32 * NB * 32;
-    __shared__ __attribute__((aligned(16))) float sm[STAGE > RED ? STAGE : RED];
+    __shared__ __attribute__((aligned(16))) float sm[(STAGE > RED ? STAGE : RED) + 3 * NB * 32];
     float* xs = sm;                        // [FA_T][GW]
     float* ys = sm + FA_T * GW;            // [FA_T][GW]
-    const int tile = blockIdx.x, c0 = blockIdx.y * GW, b = blockIdx.z;
-    const int n0 = tile * FA_T, nt = min(FA_T, g.N - n0);
-    // ---- stage (rows past the sequence end are zeros)
-    {
-        constexpr int NV = (FA_T * GQ + 255) / 256;
-        float4 xv[NV], yv[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
-            xv[v] = make_float4(0.f, 0.f, 0.f, 0.f); yv[v] = xv[v];
-            if (i < FA_T * GQ && n < nt) {
-                const long tok = (long)b * g.N + n0 + n;
-                xv[v] = *reinterpret_cast<const float4*>(X + tok * ldx + c0 + 4 * q);
-                yv[v] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0 + 4 * q);
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
-            if (i < FA_T * GQ) {
-                float4 y4 = yv[v];
-                if (!SOFTMAX) {
-                    float4 sc = make_float4(yscale, yscale, yscale, yscale);
-                    if (ysc) { const float4 a4 = *reinterpret_cast<const float4*>(ysc + (long)b * g.C + c0 + 4 * q); sc.x *= a4.x; sc.y *= a4.y; sc.z *= a4.z; sc.w *= a4.w; }
-                    y4.x *= sc.x; y4.y *= sc.y; y4.z *= sc.z; y4.w *= sc.w;
-                }
-                *reinterpret_cast<float4*>(xs + n * GW + 4 * q) = xv[v];
-                *reinterpret_cast<float4*>(ys + n * GW + 4 * q) = y4;
-            }
-        }
-    }
-    __syncthreads();
-    if (SOFTMAX) {
-        // column max / exp over the tile's tokens: `per` threads per column
-        constexpr int per = GW <= 64 ? 4 : 2;
-        const int c = threadIdx.x / per, sub = threadIdx.x % per;
-        float m = -INFINITY;
-        if (c < GW)
-            for (int n = sub; n < nt; n += per) m = fmaxf(m, xs[n * GW + c]);
-        for (int o = 1; o < per; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float ssum = 0.f;
-        if (c < GW) {
-            for (int n = sub; n < nt; n += per) { const float e = expf(xs[n * GW + c] - m); xs[n * GW + c] = e; ssum += e; }
-            for (int n = nt + sub; n < FA_T; n += per) xs[n * GW + c] = 0.f;          // padded rows must not contribute exp(0 - m)
-        }
-        for (int o = 1; o < per; o <<= 1) ssum += __shfl_xor(ssum, o, 64);
-        if (c < GW && sub == 0) {
-            const long o = ((long)b * NT + tile) * g.C + c0 + c;
-            ws_m[o] = m; ws_s[o] = ssum;
-        }
-        __syncthreads();
-    }
-    // ---- D[c][e] += X[n][c] * Y[n][e] over this wavefront's quarter of the tokens
+    float* s_m = sm + (STAGE > RED ? STAGE : RED);     // running column max
+    float* s_s = s_m + NB * 32;                        // running column exp-sum
+    float* s_f = s_s + NB * 32;                        // this tile's rescale factor exp(m_old - m_new)
+    const int stile = blockIdx.x, c0 = blockIdx.y * GW, b = blockIdx.z;
+    const int NTS = (NT + NSUB - 1) / NSUB;            // partial rows per image
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
     fap_f32x16 acc[NB][NB];
 #pragma unroll
@@ -105,21 +60,96 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int TPW = FA_T / 4;
+    if (SOFTMAX && threadIdx.x < NB * 32) { s_m[threadIdx.x] = -INFINITY; s_s[threadIdx.x] = 0.f; s_f[threadIdx.x] = 1.f; }
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int tile = stile * NSUB + sub;
+        if (tile >= NT) break;                         // (uniform)
+        const int n0 = tile * FA_T, nt = min(FA_T, g.N - n0);
+        // ---- stage (rows past the sequence end are zeros)
+        {
+            constexpr int NV = (FA_T * GQ + 255) / 256;
+            float4 xv[NV], yv[NV];
 #pragma unroll
-    for (int kk = 0; kk < TPW / 2; ++kk) {
-        const int n = wave * TPW + 2 * kk + lhi;
-        float xa[NB], yb[NB];
+            for (int v = 0; v < NV; ++v) {
+                const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
+                xv[v] = make_float4(0.f, 0.f, 0.f, 0.f); yv[v] = xv[v];
+                if (i < FA_T * GQ && n < nt) {
+                    const long tok = (long)b * g.N + n0 + n;
+                    xv[v] = *reinterpret_cast<const float4*>(X + tok * ldx + c0 + 4 * q);
+                    yv[v] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0 + 4 * q);
+                }
+            }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) { const int c = 32 * i + l31; xa[i] = c < GW ? xs[n * GW + c] : 0.f; }
+            for (int v = 0; v < NV; ++v) {
+                const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
+                if (i < FA_T * GQ) {
+                    float4 y4 = yv[v];
+                    if (!SOFTMAX) {
+                        float4 sc = make_float4(yscale, yscale, yscale, yscale);
+                        if (ysc) { const float4 a4 = *reinterpret_cast<const float4*>(ysc + (long)b * g.C + c0 + 4 * q); sc.x *= a4.x; sc.y *= a4.y; sc.z *= a4.z; sc.w *= a4.w; }
+                        y4.x *= sc.x; y4.y *= sc.y; y4.z *= sc.z; y4.w *= sc.w;
+                    }
+                    *reinterpret_cast<float4*>(xs + n * GW + 4 * q) = xv[v];
+                    *reinterpret_cast<float4*>(ys + n * GW + 4 * q) = y4;
+                }
+            }
+        }
+        __syncthreads();
+        if (SOFTMAX) {
+            // column max / exp over the tile's tokens against the RUNNING max: `per` threads per column
+            constexpr int per = GW <= 64 ? 4 : 2;
+            const int c = threadIdx.x / per, sb = threadIdx.x % per;
+            float m = -INFINITY;
+            if (c < GW)
+                for (int n = sb; n < nt; n += per) m = fmaxf(m, xs[n * GW + c]);
+            for (int o = 1; o < per; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float m_old = c < GW ? s_m[c] : 0.f;
+            const float m_new = fmaxf(m_old, m);
+            float ssum = 0.f;
+            if (c < GW) {
+                for (int n = sb; n < nt; n += per) { const float e = expf(xs[n * GW + c] - m_new); xs[n * GW + c] = e; ssum += e; }
+                for (int n = nt + sb; n < FA_T; n += per) xs[n * GW + c] = 0.f;          // padded rows must not contribute exp(0 - m)
+            }
+            for (int o = 1; o < per; o <<= 1) ssum += __shfl_xor(ssum, o, 64);
+            if (c < GW && sb == 0) {
+                const float f = expf(m_old - m_new);                                      // 0 on the first tile (m_old = -inf)
+                s_f[c] = f; s_m[c] = m_new; s_s[c] = fmaf(s_s[c], f, ssum);
+            }
+            __syncthreads();
+            if (sub > 0) {                 // rescale what the earlier tiles accumulated: rows c of the D[c][e] blocks
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const int c = 32 * j + l31; yb[j] = c < GW ? ys[n * GW + c] : 0.f; }
+                for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 f4 = *reinterpret_cast<const float4*>(s_f + 32 * i + 8 * q + 4 * lhi);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NB; ++j) {
+                            acc[i][j][4 * q + 0] *= f4.x; acc[i][j][4 * q + 1] *= f4.y; acc[i][j][4 * q + 2] *= f4.z; acc[i][j][4 * q + 3] *= f4.w;
+                        }
+                    }
+            }
+        }
+        // ---- D[c][e] += X[n][c] * Y[n][e] over this wavefront's quarter of the tokens
+        constexpr int TPW = FA_T / 4;
+#pragma unroll
+        for (int kk = 0; kk < TPW / 2; ++kk) {
+            const int n = wave * TPW + 2 * kk + lhi;
+            float xa[NB], yb[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { const int c = 32 * i + l31; xa[i] = c < GW ? xs[n * GW + c] : 0.f; }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const int c = 32 * j + l31; yb[j] = c < GW ? ys[n * GW + c] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                       // the operand tiles are dead: the next tile may be staged / the partial results may meet in LDS
     }
-    __syncthreads();                       // the operand tiles are dead: reuse the LDS for the four partial results
+    if (SOFTMAX && threadIdx.x < GW) {
+        const long o = ((long)b * NTS + stile) * g.C + c0 + threadIdx.x;
+        ws_m[o] = s_m[threadIdx.x]; ws_s[o] = s_s[threadIdx.x];
+    }
     constexpr int RW = NB * 32;            // padded row width of a partial result
     float* red = sm + wave * RW * RW;
 #pragma unroll
@@ -135,7 +165,7 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
     for (int o = threadIdx.x; o < GW * CH; o += 256) {
         const int c = o / CH, el = o % CH, e = (c / CH) * CH + el;       // head-diagonal entry (c, e) of the group
         const float v = (sm[c * RW + e] + sm[RW * RW + c * RW + e]) + (sm[2 * RW * RW + c * RW + e] + sm[3 * RW * RW + c * RW + e]);
-        ws_P[(((long)b * NT + tile) * g.C + c0 + c) * CH + el] = v;
+        ws_P[(((long)b * NTS + stile) * g.C + c0 + c) * CH + el] = v;
     }
 }
 
@@ -485,6 +515,11 @@ size_t fa_ws_floats(int B, int N, int C, int heads) {
     return (size_t)(fwd > bwd ? fwd : bwd);
 }
 
+// 64-token tiles a workgroup of the partial kernels walks.  A function of the IMAGE's token count alone -- never of the batch: an image's arithmetic (which
+// tiles meet in which partial row, in which order) must not depend on how many images share the launch, or the domain-batched forward stops being the
+// per-domain forwards bit for bit (tests/test_gpu_model.py: test_bench_step_fused_forward_equals_per_domain_at_512).
+int fa_nsub(int NT, int /*groups*/, int /*B*/) { return NT >= 128 ? 8 : (NT >= 64 ? 4 : (NT >= 16 ? 2 : 1)); }
+
 int quad_grid(long work_quads, int QC, int max_blocks) {
     // smallest grid >= wanted with (grid*256) % QC == 0
     int a = QC, b = 256;
@@ -511,7 +546,9 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     FaGeom g;
     MDVIT_CHECK_ARG(make_geom(g, B, H, W, C, heads, s3, s5, s7), MDVIT_E_SHAPE, "factoratt_fwd: bad geometry B=%d H=%d W=%d C=%d heads=%d splits=%d/%d/%d", B, H, W, C, heads, s3, s5, s7);
     MDVIT_CHECK_ARG(ws_bytes >= fa_ws_floats(B, g.N, C, heads) * sizeof(float), MDVIT_E_WORKSPACE, "factoratt_fwd: workspace too small (%zu bytes)", ws_bytes);
-    const int NT = cdiv(g.N, FA_T);
+    const int NT0 = cdiv(g.N, FA_T);
+    const int NSUB = fa_nsub(NT0, C / (g.Ch < 32 ? 32 : g.Ch), B);
+    const int NT = cdiv(NT0, NSUB);                    // partial rows per image
     float* ws_m = (float*)ws;
     float* ws_s = ws_m + (long)B * NT * C;
     float* ws_P = ws_s + (long)B * NT * C;
@@ -519,7 +556,7 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
         const int GW = g.Ch < 32 ? 32 : g.Ch;
         MDVIT_CHECK_ARG(C % GW == 0, MDVIT_E_SHAPE, "factoratt_fwd: C=%d is not a multiple of the %d-channel group", C, GW);
 #define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, true>), dim3(NT, C / GW, B), dim3(256), 0, s, \
-                       qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, NT)
+                       qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, NT0, NSUB)
         switch (g.Ch) {
             case 8: FA_PART_LAUNCH(8); break;
             case 16: FA_PART_LAUNCH(16); break;
@@ -608,11 +645,13 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         }
     }
     // 2: dM = Q^T (scale * a * G)
+    int NSUBb = 1;
     {
         const int GWp = Ch < 32 ? 32 : Ch;
         MDVIT_CHECK_ARG(C % GWp == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GWp);
-#define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, false>), dim3(NT, C / GWp, B), dim3(256), 0, s, \
-                       qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, NT)
+        NSUBb = fa_nsub(NT, C / GWp, B);
+#define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, false>), dim3(cdiv(NT, NSUBb), C / GWp, B), dim3(256), 0, s, \
+                       qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, NT, NSUBb)
         switch (Ch) {
             case 8: FA_PART_LAUNCH(8); break;
             case 16: FA_PART_LAUNCH(16); break;
@@ -623,7 +662,7 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
 #undef FA_PART_LAUNCH
     }
     {       // dM[b] = sum over the token tiles of ws_P[b][tile]  (fixed order)
-        const int rc = mdvit_reduce_partials_batched(ws_P, B, NT, C * Ch, dM, s);
+        const int rc = mdvit_reduce_partials_batched(ws_P, B, cdiv(NT, NSUBb), C * Ch, dM, s);
         if (rc != MDVIT_OK) return rc;
     }
     // 3: crpe weight gradients

@@ -160,7 +160,9 @@ def timing_epilogues():
              ("fc2 full s2", 32768, 320, 1280, "full"), ("fc1 gelu dual s3", 8192, 2048, 512, "gelu"), ("fc2 dgrad dgelu s3", 8192, 2048, 512, "dgelu"),
              ("qkv plain s3", 8192, 1536, 512, "plain"), ("fc2 full s3", 8192, 512, 2048, "full"),
              ("fc1 gelu dual s2 bs4", 16384, 1280, 320, "gelu"), ("fc1 gelu dual s3 bs4", 4096, 2048, 512, "gelu"),
-             ("fc1 gelu dual s2 step32", 131072, 1280, 320, "gelu")]
+             ("fc1 gelu dual s2 step32", 131072, 1280, 320, "gelu"), ("fc2 dgrad dgelu s2 step32", 131072, 1280, 320, "dgelu"), ("qkv plain s2 step32", 131072, 960, 320, "plain"),
+             ("fc1 gelu dual s3 step32", 32768, 2048, 512, "gelu"), ("fc2 dgrad dgelu s3 step32", 32768, 2048, 512, "dgelu"), ("fc2 full s3 step32", 32768, 512, 2048, "full"),
+             ("proj full s3 step32", 32768, 512, 512, "full"), ("qkv plain s3 step32", 32768, 1536, 512, "plain"), ("fc1 dgrad plain s3 step32", 32768, 512, 2048, "plain")]
     for note, M, N, K, kind in cases:
         x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.1; b = torch.randn(N, device="cuda")
         wp = planes_of(w)

@@ -3,10 +3,11 @@
 #     bash tools/pmc_stalls.sh <kernel-name substring> <out file under gpurun_out/> <python script> [args...]
 # UNITS (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count QUAD-cycles summed over
 # the resident waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles (= 32 x SQ_INSTS_MFMA for v_mfma_f32_32x32x16_bf16); GRBM_GUI_ACTIVE = the launch's
-# duration in shader cycles at the clock the chip actually ran.  Printed:
+# duration in shader cycles at the clock the chip actually ran, SUMMED over the 8 XCDs.  Printed:
 #   * the wait / issue buckets as a share of SQ_WAVE_CYCLES (quad-cycles against quad-cycles),
 #   * "MFMA busy, per wave"  = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_WAVE_CYCLES): the share of a wave's life with one of ITS MFMAs in the pipe,
-#   * "MFMA pipe utilisation" = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE): what the matrix pipes of the chip did during the launch.
+#   * "MFMA pipe utilisation" = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): what the matrix pipes of the chip did during the launch
+#     (rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs: 4.68e6 for a 290 us launch = 8 x 585k cycles at 2.02 GHz).
 set -u
 PAT=$1; NAME=$2; SCRIPT=$3; shift 3
 REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"
@@ -40,7 +41,8 @@ for k, v in agg.items():
     if wc:
         print(f"   MFMA busy, per wave                  = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_WAVE_CYCLES)       = {100 * mf / (4 * wc):5.1f} %")
     if gui:
-        print(f"   MFMA pipe utilisation (chip)         = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE)   = {100 * mf / (1024 * gui):5.1f} %")
+        print(f"   MFMA pipe utilisation (chip)         = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8) = {100 * mf / (1024 * gui / 8):5.1f} %")
+        print(f"   launch duration                      = GRBM_GUI_ACTIVE / 8                                  = {gui / 8:9.0f} shader cycles")
     if ins:
         print(f"   cycles per MFMA instruction          = SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA             = {mf / ins:5.1f}")
         print(f"   VALU instructions per MFMA           = SQ_INSTS_VALU / SQ_INSTS_MFMA                        = {a.get('SQ_INSTS_VALU', 0.0) / ins:5.2f}")
