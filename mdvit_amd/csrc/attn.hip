@@ -41,7 +41,11 @@ template <int CH, bool SOFTMAX>
 __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
                                                          const float* __restrict__ ysc, float yscale,
                                                          float* __restrict__ ws_m, float* __restrict__ ws_s, float* __restrict__ ws_P,
-                                                         FaGeom g, int NT, int NSUB) {
+                                                         FaGeom g, int NT, int NSUB,
+                                                         const float* __restrict__ outp = nullptr, float* __restrict__ dU = nullptr, float* __restrict__ e_part = nullptr) {
+    // (!SOFTMAX, round 4) the backward's first pass rides on this one: X = q and Y = G are exactly what dU = a G q and e = sum_n G out need, so the tile that is
+    // staged for dM = Q^T (scale a G) also writes dU (its channel group's columns) and one row of e partials per workgroup -- fa_bwd_prep_kernel's launch and its
+    // second read of q and G are gone from the full backward (it stays for the adapter-only call).
     constexpr int GW = CH < 32 ? 32 : CH, NB = (GW + 31) / 32, GQ = GW / 4;
     constexpr int STAGE = 2 * FA_T * GW, RED = 4 * NB * 32 * NB * 32;
     __shared__ __attribute__((aligned(16))) float sm[(STAGE > RED ? STAGE : RED) + 3 * NB * 32];
@@ -50,6 +54,7 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
     float* s_m = sm + (STAGE > RED ? STAGE : RED);     // running column max
     float* s_s = s_m + NB * 32;                        // running column exp-sum
     float* s_f = s_s + NB * 32;                        // this tile's rescale factor exp(m_old - m_new)
+    float* s_e = s_s;                                  // !SOFTMAX: the workgroup's e sums (the softmax state is not used then)
     const int stile = blockIdx.x, c0 = blockIdx.y * GW, b = blockIdx.z;
     const int NTS = (NT + NSUB - 1) / NSUB;            // partial rows per image
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -61,6 +66,11 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (SOFTMAX && threadIdx.x < NB * 32) { s_m[threadIdx.x] = -INFINITY; s_s[threadIdx.x] = 0.f; s_f[threadIdx.x] = 1.f; }
+    if (!SOFTMAX && e_part && threadIdx.x < NB * 32) s_e[threadIdx.x] = 0.f;
+    constexpr int NVE = (FA_T * GQ + 255) / 256;
+    float4 eacc[(!SOFTMAX) ? NVE : 1];                  // e sums of this thread's staging slots (slot v always carries channel quad (tid + 256 v) % GQ)
+#pragma unroll
+    for (int v = 0; v < ((!SOFTMAX) ? NVE : 1); ++v) eacc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int sub = 0; sub < NSUB; ++sub) {
         const int tile = stile * NSUB + sub;
         if (tile >= NT) break;                         // (uniform)
@@ -68,15 +78,17 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
         // ---- stage (rows past the sequence end are zeros)
         {
             constexpr int NV = (FA_T * GQ + 255) / 256;
-            float4 xv[NV], yv[NV];
+            float4 xv[NV], yv[NV], ov[(!SOFTMAX) ? NV : 1];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
                 xv[v] = make_float4(0.f, 0.f, 0.f, 0.f); yv[v] = xv[v];
+                if (!SOFTMAX) ov[v] = xv[v];
                 if (i < FA_T * GQ && n < nt) {
                     const long tok = (long)b * g.N + n0 + n;
                     xv[v] = *reinterpret_cast<const float4*>(X + tok * ldx + c0 + 4 * q);
                     yv[v] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0 + 4 * q);
+                    if (!SOFTMAX && e_part) ov[v] = *reinterpret_cast<const float4*>(outp + tok * (long)g.C + c0 + 4 * q);
                 }
             }
 #pragma unroll
@@ -86,7 +98,15 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
                     float4 y4 = yv[v];
                     if (!SOFTMAX) {
                         float4 sc = make_float4(yscale, yscale, yscale, yscale);
-                        if (ysc) { const float4 a4 = *reinterpret_cast<const float4*>(ysc + (long)b * g.C + c0 + 4 * q); sc.x *= a4.x; sc.y *= a4.y; sc.z *= a4.z; sc.w *= a4.w; }
+                        float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (ysc) { a4 = *reinterpret_cast<const float4*>(ysc + (long)b * g.C + c0 + 4 * q); sc.x *= a4.x; sc.y *= a4.y; sc.z *= a4.z; sc.w *= a4.w; }
+                        if (dU && n < nt)          // dU = a G q   (fa_bwd_prep_kernel's product, term for term)
+                            *reinterpret_cast<float4*>(dU + ((long)b * g.N + n0 + n) * g.C + c0 + 4 * q) =
+                                make_float4(a4.x * y4.x * xv[v].x, a4.y * y4.y * xv[v].y, a4.z * y4.z * xv[v].z, a4.w * y4.w * xv[v].w);
+                        if (e_part) {
+                            eacc[v].x = fmaf(y4.x, ov[v].x, eacc[v].x); eacc[v].y = fmaf(y4.y, ov[v].y, eacc[v].y);
+                            eacc[v].z = fmaf(y4.z, ov[v].z, eacc[v].z); eacc[v].w = fmaf(y4.w, ov[v].w, eacc[v].w);
+                        }
                         y4.x *= sc.x; y4.y *= sc.y; y4.z *= sc.z; y4.w *= sc.w;
                     }
                     *reinterpret_cast<float4*>(xs + n * GW + 4 * q) = xv[v];
@@ -149,6 +169,19 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
     if (SOFTMAX && threadIdx.x < GW) {
         const long o = ((long)b * NTS + stile) * g.C + c0 + threadIdx.x;
         ws_m[o] = s_m[threadIdx.x]; ws_s[o] = s_s[threadIdx.x];
+    }
+    if (!SOFTMAX && e_part) {                          // (the loop ended with a barrier; s_e was cleared before it)
+#pragma unroll
+        for (int v = 0; v < NVE; ++v) {
+            const int i = threadIdx.x + 256 * v, q = i % GQ;
+            if (i < FA_T * GQ) {
+                atomicAdd(&s_e[4 * q + 0], eacc[v].x); atomicAdd(&s_e[4 * q + 1], eacc[v].y);
+                atomicAdd(&s_e[4 * q + 2], eacc[v].z); atomicAdd(&s_e[4 * q + 3], eacc[v].w);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < GW) e_part[((long)b * NTS + stile) * g.C + c0 + threadIdx.x] = s_e[threadIdx.x];
+        __syncthreads();                               // (s_e aliases nothing the reduction below touches, but keep the phases apart)
     }
     constexpr int RW = NB * 32;            // padded row width of a partial result
     float* red = sm + wave * RW * RW;
@@ -279,8 +312,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 
                                                            const float* __restrict__ U, const float* __restrict__ dVc,
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
-                                                           const float* __restrict__ dM, const float* __restrict__ tcol,
+                                                           const float* __restrict__ dMp, int NTS,
                                                            float* __restrict__ dqkv, FaGeom g, int tiles_per_block) {
+    // dMp: the NTS partial rows [B][NTS][C][CH] of dM = Q^T dFA straight from fa_partial_kernel -- summed here in a fixed order while the block-diagonal
+    // matrices are staged (round 4: the separate reduction launch per block and sweep is gone; each workgroup re-adds GW x CH x NTS floats, a few KB)
     constexpr int GW = CH < 32 ? 32 : CH;          // channels per group
     constexpr int NB = (GW + 31) / 32;             // 32-channel MFMA row blocks
     constexpr int NQ = GW / 8;                     // float4 quads per lane
@@ -295,13 +330,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 
         const bool same = (r / CH) == (cc / CH);
         const long src = ((long)b * C + g0 + r) * CH + (cc % CH);
         sKV[r * LD + cc] = same ? Mmat[src] : 0.f;
-        sD[r * LD + cc] = same ? dM[src] : 0.f;
+        float dm = 0.f;
+        if (same) {                       // eight independent loads at a time (a chain of NTS dependent loads cost a workgroup ~30 us of start-up)
+            const float* pp = dMp + (((long)b * NTS) * C + g0 + r) * CH + (cc % CH);
+            const long rs = (long)C * CH;
+            for (int t0 = 0; t0 < NTS; t0 += 8) {
+                float v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int t = t0 + u; v8[u] = pp[(long)(t < NTS ? t : NTS - 1) * rs]; if (t >= NTS) v8[u] = 0.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dm += v8[u];
+            }
+        }
+        sD[r * LD + cc] = dm;
     }
     for (int i = threadIdx.x; i < GW; i += 256) {
         const long ci = (long)b * C + g0 + i;
         s_a[i] = a ? a[ci] : 1.f; s_km[i] = kmax[ci]; s_ks[i] = 1.0f / ksum[ci];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GW; i += 256) {
         float tc = 0.f;                   // t[c] = sum_e dM[c][e] * M[c][e]  (= sum_n P[n,c] dP[n,c], the column-softmax correction)
-        for (int e = 0; e < CH; ++e) tc = fmaf(dM[ci * CH + e], Mmat[ci * CH + e], tc);
+        const int h0 = (i / CH) * CH;
+        for (int e = 0; e < CH; ++e) tc = fmaf(sD[i * LD + h0 + e], sKV[i * LD + h0 + e], tc);
         s_tc[i] = tc;
     }
     __syncthreads();
@@ -633,25 +684,14 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         MDVIT_LAUNCH_CHECK();
         return mdvit_reduce_partials_batched(e_part, B, gx, C, e, s);
     }
-    // 1: dU, e
-    const int QC = C / 4;
+    // 1 + 2: dM = Q^T (scale * a * G) as tile partials, and on the same staged tiles dU = a G q and the e partial rows
+    const int GWp = Ch < 32 ? 32 : Ch;
+    MDVIT_CHECK_ARG(C % GWp == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GWp);
+    const int NSUBb = fa_nsub(NT, C / GWp, B), NTS = cdiv(NT, NSUBb);
+    float* e_part = ws_P + (long)B * NT * C * Ch;               // [B][NTS][C] partial rows (the region is reused by the window-weight gradients below)
     {
-        const int gx = quad_grid((long)g.N * QC, QC, 512);
-        float* e_part = ws_P + (long)B * NT * C * Ch;               // [B][gx][C] partial rows (the region is reused by the window-weight gradients below)
-        hipLaunchKernelGGL(fa_bwd_prep_kernel, dim3(gx, B), dim3(256), sizeof(float) * C, s, dout, qkv, out, a, dU, e ? e_part : nullptr, g);
-        if (e) {
-            const int rc = mdvit_reduce_partials_batched(e_part, B, gx, C, e, s);
-            if (rc != MDVIT_OK) return rc;
-        }
-    }
-    // 2: dM = Q^T (scale * a * G)
-    int NSUBb = 1;
-    {
-        const int GWp = Ch < 32 ? 32 : Ch;
-        MDVIT_CHECK_ARG(C % GWp == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GWp);
-        NSUBb = fa_nsub(NT, C / GWp, B);
-#define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, false>), dim3(cdiv(NT, NSUBb), C / GWp, B), dim3(256), 0, s, \
-                       qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, NT, NSUBb)
+#define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, false>), dim3(NTS, C / GWp, B), dim3(256), 0, s, \
+                       qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, NT, NSUBb, out, dU, e ? e_part : (float*)nullptr)
         switch (Ch) {
             case 8: FA_PART_LAUNCH(8); break;
             case 16: FA_PART_LAUNCH(16); break;
@@ -661,8 +701,8 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         }
 #undef FA_PART_LAUNCH
     }
-    {       // dM[b] = sum over the token tiles of ws_P[b][tile]  (fixed order)
-        const int rc = mdvit_reduce_partials_batched(ws_P, B, cdiv(NT, NSUBb), C * Ch, dM, s);
+    if (e) {
+        const int rc = mdvit_reduce_partials_batched(e_part, B, NTS, C, e, s);
         if (rc != MDVIT_OK) return rc;
     }
     // 3: crpe weight gradients
@@ -688,7 +728,7 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     int tpb = 4;                                   // 32-token tiles per block (one per wavefront), doubled while the grid stays large
     while (tpb < 64 && (long)cdiv(ntiles, tpb * 2) * (C / GW) * B >= 2048) tpb *= 2;
     dim3 grid(cdiv(ntiles, tpb), C / GW, B);
-#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, dM, tcol, dqkv, g, tpb)
+#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb)
     switch (Ch) {
         case 8: FA_BWD_LAUNCH(8); break;
         case 16: FA_BWD_LAUNCH(16); break;
