@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void fa_combine_softmax_kernel(const float* __
 }
 
 // ---- fwd C': out = a * (Ch^-0.5 * q.M + q * U)    (U from the tiled conv; q rows staged in LDS) -----------
+constexpr int FA_OUT_U = 4;
 template <int CH>
 __global__ __launch_bounds__(512) void fa_out_kernel(const float* __restrict__ qkv, const float* __restrict__ U,
                                                      const float* __restrict__ Mmat, const float* __restrict__ a,
@@ -243,21 +244,41 @@ __global__ __launch_bounds__(512) void fa_out_kernel(const float* __restrict__ q
     const int c = threadIdx.x % C, tl = threadIdx.x / C, b = blockIdx.y;
     const int head = c / CH, ch = c % CH, hb = head * CH;
     const float ac = a ? a[(long)b * C + c] : 1.f;
-    const float* Mb = Mmat + ((long)b * C + hb) * CH + ch;       // M[hb+j][ch], stride CH
+    // this thread's column of the head's matrix, M[hb + j][ch], lives in registers for the whole token run (round 4: it was re-read from the L1 for
+    // every token -- CH vector-memory instructions per output element, and the texture-address unit, not HBM, held the kernel: 94 -> 3x us at C = 320)
+    float mcol[CH];
+    {
+        const float* Mb = Mmat + ((long)b * C + hb) * CH + ch;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) mcol[j] = Mb[(long)j * CH];
+    }
     const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
-    for (int base = n_beg; base < n_end; base += TLN) {
-        const int n = base + tl;
-        const bool ok = n < n_end;
-        const long tok = (long)b * g.N + (ok ? n : n_beg);
-        float qc = 0.f;
-        if (ok) { qc = qkv[tok * C3 + c]; s_q[tl * C + c] = qc; }
+    // FA_OUT_U tokens per thread and barrier pair: their loads are in flight together (one token per pair left the kernel latency-bound at ~3 TB/s)
+    for (int base = n_beg; base < n_end; base += FA_OUT_U * TLN) {
+        float qc[FA_OUT_U], uc[FA_OUT_U];
+        long tok[FA_OUT_U];
+        bool ok[FA_OUT_U];
+#pragma unroll
+        for (int u = 0; u < FA_OUT_U; ++u) {
+            const int n = base + u * TLN + tl;
+            ok[u] = n < n_end;
+            tok[u] = (long)b * g.N + (ok[u] ? n : n_beg);
+            qc[u] = qkv[tok[u] * C3 + c]; uc[u] = U[tok[u] * C + c];          // (unconditional, clamped: no branch around loads)
+        }
+#pragma unroll
+        for (int u = 0; u < FA_OUT_U; ++u) s_q[(u * TLN + tl) * C + c] = qc[u];
         __syncthreads();
-        if (ok) {
+#pragma unroll
+        for (int u = 0; u < FA_OUT_U; ++u) {
             float fa = 0.f;
-            const float* qr = &s_q[tl * C + hb];
-#pragma unroll 8
-            for (int j = 0; j < CH; ++j) fa = fmaf(qr[j], Mb[(long)j * CH], fa);
-            out[tok * C + c] = ac * (g.scale * fa + qc * U[tok * C + c]);
+            const float4* qr = reinterpret_cast<const float4*>(&s_q[(u * TLN + tl) * C + hb]);      // (C and CH are multiples of 4: 16-byte aligned; a wave-wide broadcast read)
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j) {                                           // same order of fused multiply-adds as before: same bits
+                const float4 q4 = qr[j];
+                fa = fmaf(q4.x, mcol[4 * j + 0], fa); fa = fmaf(q4.y, mcol[4 * j + 1], fa);
+                fa = fmaf(q4.z, mcol[4 * j + 2], fa); fa = fmaf(q4.w, mcol[4 * j + 3], fa);
+            }
+            if (ok[u]) out[tok[u] * C + c] = ac * (g.scale * fa + qc[u] * uc[u]);
         }
         __syncthreads();
     }
@@ -429,6 +450,146 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 
             }
         }
     }
+}
+
+// role 0: dq = a*scale*G . KV^T (+ G*a*U);  1: dk = P * (v . dM^T - t);  2: dv = P . dM + conv^T(dU)      -- fa_bwd_apply3_kernel's wave roles
+template <int CH, int ROLE>
+__device__ __forceinline__ void fa_apply3_tiles(const float* __restrict__ dout, const float* __restrict__ qkv, const float* __restrict__ U, const float* __restrict__ dVc,
+                                                float* __restrict__ dqkv, const FaGeom& g, const float* sKV, const float* sD, const float* s_a, const float* s_km,
+                                                const float* s_ks, const float* s_tc, int b, int g0, int slot, int tiles_per_block) {
+    constexpr int GW = CH, NB = (GW + 31) / 32, NQ = GW / 8, KS = GW / 2, LD = GW + 1;
+    const int C = g.C, C3 = 3 * C;
+    const int lane = threadIdx.x & 63;
+    const int t = lane & 31, half = lane >> 5;
+    const int ntiles = (g.N + 31) / 32;
+    const int tile_beg = blockIdx.x * tiles_per_block, tile_end = min(ntiles, tile_beg + tiles_per_block);
+    const float inv_scale = 1.0f / g.scale;
+    for (int tile = tile_beg + slot; tile < tile_end; tile += 2) {
+        const int n = tile * 32 + t;
+        const bool ok = n < g.N;
+        const float z = ok ? 1.f : 0.f;                  // out-of-range tokens contribute zeros (their results are not stored)
+        const long tok = (long)b * g.N + (ok ? n : g.N - 1);
+        // A: dout | k | k;  B: U | v | conv^T(dU)
+        const float* arow = ROLE == 0 ? dout + tok * C + g0 : qkv + tok * C3 + C + g0;
+        const float* brow = ROLE == 0 ? U + tok * C + g0 : (ROLE == 1 ? qkv + tok * C3 + 2 * C + g0 : dVc + tok * C + g0);
+        float xo[NQ][4], el[NQ][4];                      // the product's token operand; its element-wise companion
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
+            const float4 a4 = *reinterpret_cast<const float4*>(arow + cq);
+            const float4 b4 = *reinterpret_cast<const float4*>(brow + cq);
+            if (ROLE == 0) {
+                const float4 s4 = *reinterpret_cast<const float4*>(s_a + cq);
+                xo[q][0] = z * g.scale * s4.x * a4.x; xo[q][1] = z * g.scale * s4.y * a4.y;
+                xo[q][2] = z * g.scale * s4.z * a4.z; xo[q][3] = z * g.scale * s4.w * a4.w;
+                el[q][0] = b4.x; el[q][1] = b4.y; el[q][2] = b4.z; el[q][3] = b4.w;
+            } else {
+                const float4 m4 = *reinterpret_cast<const float4*>(s_km + cq);
+                const float4 i4 = *reinterpret_cast<const float4*>(s_ks + cq);
+                const float p0 = z * expf(a4.x - m4.x) * i4.x, p1 = z * expf(a4.y - m4.y) * i4.y;
+                const float p2 = z * expf(a4.z - m4.z) * i4.z, p3 = z * expf(a4.w - m4.w) * i4.w;
+                if (ROLE == 1) {
+                    xo[q][0] = z * b4.x; xo[q][1] = z * b4.y; xo[q][2] = z * b4.z; xo[q][3] = z * b4.w;
+                    el[q][0] = p0; el[q][1] = p1; el[q][2] = p2; el[q][3] = p3;
+                } else {
+                    xo[q][0] = p0; xo[q][1] = p1; xo[q][2] = p2; xo[q][3] = p3;
+                    el[q][0] = b4.x; el[q][1] = b4.y; el[q][2] = b4.z; el[q][3] = b4.w;
+                }
+            }
+        }
+        fa_f32x16 acc[NB];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            const int orow = 32 * ob + t;
+            const bool rok = orow < GW;
+            const int orc = rok ? orow : 0;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int q = kk / 4, j = kk % 4;
+                const int kc = 32 * (q / 4) + 8 * (q % 4) + 4 * half + j;
+                float w = ROLE == 0 ? sKV[orc * LD + kc] : (ROLE == 1 ? sD[orc * LD + kc] : sD[kc * LD + orc]);     // W[orow][kc]: KV | dM | dM^T
+                if (!rok) w = 0.f;
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, xo[q][j], acc[ob], 0, 0, 0);
+            }
+        }
+        if (ok) {
+            float* drow = dqkv + tok * C3 + ROLE * C + g0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ob = q / 4, r0 = 4 * (q % 4);
+                const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
+                float4 d;
+                if (ROLE == 0) {
+                    d.x = fmaf(xo[q][0] * inv_scale, el[q][0], acc[ob][r0 + 0]); d.y = fmaf(xo[q][1] * inv_scale, el[q][1], acc[ob][r0 + 1]);
+                    d.z = fmaf(xo[q][2] * inv_scale, el[q][2], acc[ob][r0 + 2]); d.w = fmaf(xo[q][3] * inv_scale, el[q][3], acc[ob][r0 + 3]);
+                } else if (ROLE == 1) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(s_tc + cq);
+                    d.x = el[q][0] * (acc[ob][r0 + 0] - t4.x); d.y = el[q][1] * (acc[ob][r0 + 1] - t4.y);
+                    d.z = el[q][2] * (acc[ob][r0 + 2] - t4.z); d.w = el[q][3] * (acc[ob][r0 + 3] - t4.w);
+                } else {
+                    d.x = acc[ob][r0 + 0] + el[q][0]; d.y = acc[ob][r0 + 1] + el[q][1];
+                    d.z = acc[ob][r0 + 2] + el[q][2]; d.w = acc[ob][r0 + 3] + el[q][3];
+                }
+                *reinterpret_cast<float4*>(drow + cq) = d;
+            }
+        }
+    }
+}
+
+// The same three products for Ch >= 32 (one head per channel group) with the PRODUCTS dealt to wavefronts: wave role 0 forms dq, 1 dk, 2 dv of a 32-token
+// tile -- each with one accumulator set and the two operands its product needs (~1/3 of the registers: three waves per SIMD instead of the one that the
+// all-in-one wave above gets at Ch = 40 / 64, where 396 / 512 registers left the loads of a tile nothing to hide behind: 1.9 TB/s).  k is read by two roles
+// (the second read hits the L2).  Per output element the same MFMA sequence as above: same bits.
+template <int CH>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void fa_bwd_apply3_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                           const float* __restrict__ U, const float* __restrict__ dVc,
+                                                           const float* __restrict__ Mmat, const float* __restrict__ a,
+                                                           const float* __restrict__ kmax, const float* __restrict__ ksum,
+                                                           const float* __restrict__ dMp, int NTS,
+                                                           float* __restrict__ dqkv, FaGeom g, int tiles_per_block) {
+    static_assert(CH >= 32 && CH % 8 == 0, "one head per channel group");
+    constexpr int GW = CH, NB = (GW + 31) / 32, NQ = GW / 8, KS = GW / 2, LD = GW + 1, NTH = 384;
+    __shared__ float sKV[GW * LD], sD[GW * LD];
+    __shared__ __attribute__((aligned(16))) float s_a[GW], s_km[GW], s_ks[GW], s_tc[GW];
+    const int C = g.C, C3 = 3 * C;
+    const int b = blockIdx.z, g0 = blockIdx.y * GW;
+    for (int i = threadIdx.x; i < GW * GW; i += NTH) {
+        const int r = i / GW, cc = i % GW;
+        sKV[r * LD + cc] = Mmat[((long)b * C + g0 + r) * CH + cc];
+        float dm = 0.f;
+        const float* pp = dMp + (((long)b * NTS) * C + g0 + r) * CH + cc;
+        const long rs = (long)C * CH;
+        for (int t0 = 0; t0 < NTS; t0 += 8) {          // (the summation order of fa_bwd_apply_kernel)
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = t0 + u; v8[u] = pp[(long)(t < NTS ? t : NTS - 1) * rs]; if (t >= NTS) v8[u] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dm += v8[u];
+        }
+        sD[r * LD + cc] = dm;
+    }
+    for (int i = threadIdx.x; i < GW; i += NTH) {
+        const long ci = (long)b * C + g0 + i;
+        s_a[i] = a ? a[ci] : 1.f; s_km[i] = kmax[ci]; s_ks[i] = 1.0f / ksum[ci];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GW; i += NTH) {
+        float tc = 0.f;
+        for (int e = 0; e < CH; ++e) tc = fmaf(sD[i * LD + e], sKV[i * LD + e], tc);
+        s_tc[i] = tc;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const int role = wave % 3, slot = wave / 3;
+    // one straight-line tile loop per role (a role test INSIDE the loop put every load under a branch, and the compiler drains the vector-memory queue at
+    // each join: five serialised load round trips per tile)
+    if (role == 0) fa_apply3_tiles<CH, 0>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block);
+    else if (role == 1) fa_apply3_tiles<CH, 1>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block);
+    else fa_apply3_tiles<CH, 2>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block);
 }
 
 // ---- Domain Adapter -----------------------------------------------------------------------------
@@ -635,10 +796,11 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
     }
     {
         const int TLN = max(1, 256 / C), block = TLN * C;
-        int tpb = TLN * 8;
+        int tpb = TLN * 32;                       // >= 32 tokens per thread: the CH-register column preload is amortised
+        while (tpb > TLN * 8 && (long)cdiv(g.N, tpb) * B < 1024) tpb /= 2;
         while ((long)cdiv(g.N, tpb) * B > 8192) tpb *= 2;
         dim3 grid(cdiv(g.N, tpb), B);
-#define FA_OUT_LAUNCH(CHV) hipLaunchKernelGGL((fa_out_kernel<CHV>), grid, dim3(block), sizeof(float) * TLN * C, s, qkv, U, Mmat, a, out, g, TLN, tpb)
+#define FA_OUT_LAUNCH(CHV) hipLaunchKernelGGL((fa_out_kernel<CHV>), grid, dim3(block), sizeof(float) * FA_OUT_U * TLN * C, s, qkv, U, Mmat, a, out, g, TLN, tpb)
         switch (Ch) {
             case 8: FA_OUT_LAUNCH(8); break;
             case 16: FA_OUT_LAUNCH(16); break;
@@ -725,6 +887,18 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     const int GW = Ch < 32 ? 32 : Ch;
     MDVIT_CHECK_ARG(C % GW == 0, MDVIT_E_SHAPE, "factoratt_bwd: C=%d is not a multiple of the %d-channel group", C, GW);
     const int ntiles = cdiv(g.N, 32);
+    if (Ch >= 32) {                                // products dealt to wavefronts: 2 tiles x 3 roles per workgroup pass
+        // 8 tiles per workgroup (4 per wave slot) amortise the staging of the two Ch x Ch matrices; fewer only while the grid would not reach one workgroup per CU
+        // (measured at 32 images, C = 320 / 512: 2 tiles 227 / 157 us, 4: 163 / 97, 8: 144 / 71, 32: 140 / 71)
+        int tpb = 8;
+        while (tpb > 2 && (long)cdiv(ntiles, tpb) * (C / GW) * B < 256) tpb /= 2;
+        dim3 grid(cdiv(ntiles, tpb), C / GW, B);
+        if (Ch == 40) hipLaunchKernelGGL((fa_bwd_apply3_kernel<40>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb);
+        else if (Ch == 64) hipLaunchKernelGGL((fa_bwd_apply3_kernel<64>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb);
+        else return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_bwd: head dim %d not built (8/16/40/64)", Ch);
+        MDVIT_LAUNCH_CHECK();
+        return MDVIT_OK;
+    }
     int tpb = 4;                                   // 32-token tiles per block (one per wavefront), doubled while the grid stays large
     while (tpb < 64 && (long)cdiv(ntiles, tpb * 2) * (C / GW) * B >= 2048) tpb *= 2;
     dim3 grid(cdiv(ntiles, tpb), C / GW, B);
@@ -732,8 +906,6 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     switch (Ch) {
         case 8: FA_BWD_LAUNCH(8); break;
         case 16: FA_BWD_LAUNCH(16); break;
-        case 40: FA_BWD_LAUNCH(40); break;
-        case 64: FA_BWD_LAUNCH(64); break;
         default: return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_bwd: head dim %d not built (8/16/40/64)", Ch);
     }
 #undef FA_BWD_LAUNCH
