@@ -45,7 +45,7 @@ struct GemmArgs {
     int vec;                       // output rows can take 16-byte vector accesses
     const uint32_t* seed;          // optional device-side dropout seed {s0, s1}: key0 ^= s0, key1 += s1 (graph replays draw fresh masks)
     int tiles_m, tiles_n;
-    int conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dil, conv_up;     // CONV kernels: A is an NHWC image gathered on the fly
+    int conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dil, conv_up, conv_phase;     // CONV kernels: A is an NHWC image gathered on the fly
 };
 
 // Bijective XCD-aware remap (guide T1): consecutive logical tiles share an XCD's L2.
@@ -330,6 +330,11 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     } else if (d->bias && !aligned16(d->bias)) {
         a.vec = 0;
     }
+    // stride-2 data gradient (conv_up == 2, even extents): tiles in parity-class order, dead taps skipped (gemm_body.inc); an internal schedule, same output rows
+    bool conv_phase_on = d->conv_c > 0 && a.conv_up == 2;
+    if (conv_phase_on) { const char* e = getenv("MDVIT_CONV_PHASE"); conv_phase_on = !(e && e[0] == '0'); }       // (read per call: the A/B switch of the parity test)
+    a.conv_phase = (conv_phase_on && a.conv_ho == 2 * a.conv_h && a.conv_wo == 2 * a.conv_w && (d->M & 3) == 0 && (d->M >> 2) % 256 == 0 &&
+                    pl.splits == 1 && a.vec && !d->accumulate) ? 1 : 0;
     int rc;
     if (pl.cfg == 0) rc = launch_cfg<128, 128, 2, 2>(a, d->trans_a, d->trans_b, epi, d->precision, s);
     else if (pl.cfg == 1) rc = launch_cfg<256, 64, 4, 1>(a, d->trans_a, d->trans_b, epi, d->precision, s);

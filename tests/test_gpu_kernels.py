@@ -578,7 +578,8 @@ def test_gconv2(B, H, W, C):
     check(go[2], gr[2], name="dw")
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,bias", [(2, 16, 16, 32, 64, 2, False), (1, 8, 8, 512, 512, 1, True), (2, 5, 6, 64, 128, 1, True), (1, 9, 9, 32, 64, 2, False)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,bias", [(2, 16, 16, 32, 64, 2, False), (1, 8, 8, 512, 512, 1, True), (2, 5, 6, 64, 128, 1, True), (1, 9, 9, 32, 64, 2, False),
+                                                        (2, 32, 32, 32, 64, 2, False), (1, 64, 32, 64, 32, 2, True)])       # (the last two: the parity-class order of the strided data gradient)
 def test_conv3x3_dense(B, H, W, Cin, Cout, stride, bias):
     from mdvit_amd import ops
     x, w = rnd(B, Cin, H, W, seed=60), rnd(Cout, Cin, 3, 3, seed=61, scale=(Cin * 9) ** -0.5)
@@ -594,6 +595,21 @@ def test_conv3x3_dense(B, H, W, Cin, Cout, stride, bias):
     check(go[1], gr[1], name="dw")
     if bias:
         check(go[2], gr[2], name="db")
+
+
+def test_strided_conv_data_gradient_in_parity_class_order_equals_the_zero_upsampled_walk(monkeypatch):
+    """dx of a stride-2 3x3 convolution (the stem's second convolution, mpvit.py:172-187; torchvision's strided BasicBlocks): tiles ordered by the parity class of
+    their input pixels skip the taps that fall between the gradient's samples -- the same sums without the zero terms: bit-for-bit the full nine-tap walk"""
+    from mdvit_amd import ops
+    for (B, H, W, Cin, Cout) in [(2, 32, 32, 32, 64), (1, 64, 64, 64, 32), (4, 32, 64, 128, 128)]:
+        x, w = nhwc(rnd(B, Cin, H, W, seed=260)).to(dev()), rnd(Cout, Cin, 3, 3, seed=261, scale=(Cin * 9) ** -0.5).to(dev())
+        g = nhwc(rnd(B, Cout, H // 2, W // 2, seed=263))
+        res = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MDVIT_CONV_PHASE", mode)
+            _, go = grads_of(lambda x, w: ops.conv3x3_dense(x, w, None, 2), [x, w], g)
+            res.append(go[0])
+        assert torch.equal(res[0], res[1]), (B, H, W, Cin, Cout, float((res[0] - res[1]).abs().max()))
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,dil", [(2, 16, 16, 32, 64, 6), (1, 8, 8, 64, 32, 12), (2, 5, 7, 32, 32, 18), (1, 20, 13, 32, 64, 2)])
