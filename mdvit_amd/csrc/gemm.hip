@@ -189,6 +189,9 @@ struct GemmPlan { int cfg, tiles_m, tiles_n, splits, kps; };
 // is split into slabs -- the fixed-order slab reduction (a second, HBM-bound kernel).
 int g_force_cfg = -1, g_force_splits = 0;      // tuning hook (mdvit_gemm_force_plan); -1 / 0 = planner decides
 
+// cycles charged for the second launch of a split K range (the reduction kernel + the gap in front of it on the stream)
+static const double g_split_penalty = [] { const char* e = getenv("MDVIT_SPLIT_PENALTY"); return e ? atof(e) : 30000.0; }();
+
 GemmPlan plan_gemm(const MdvitGemmDesc* d) {
     static const int BMs[3] = {128, 256, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 2, 4};
     static const double EFF[3] = {0.8, 0.8, 1.0};       // measured (tools/gemm_sweep.py): the 64x64 tile at 4 workgroups / CU wins almost everywhere
@@ -222,7 +225,7 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
                 ? 0.0015 * BMs[c] * BNs[c] * (double)kps + (d->trans_a ? 0.12 : 0.06) * (BMs[c] + BNs[c]) * (double)kps + 800.0 + epi_cycles
                 : 2.0 * BMs[c] * BNs[c] * (double)kps / (180.0 * EFF[c]) + 800.0 + epi_cycles;
             double cost = rounds * OCC[c] * wg_cycles;
-            if (splits > 1) cost += 12000.0 + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;
+            if (splits > 1) cost += g_split_penalty + (double)(splits + 1) * d->M * d->N * 8.0 / 1250.0;
             if (cost < best_cost) {
                 best_cost = cost;
                 best.cfg = c; best.tiles_m = (int)tm; best.tiles_n = (int)tn; best.splits = splits; best.kps = kps;
