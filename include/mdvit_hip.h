@@ -102,7 +102,10 @@ typedef struct MdvitGemmDesc {
     int32_t conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dilation;
     /* conv_up > 1 (NT only): the image is read as if zero-upsampled by conv_up -- tap position p maps to source pixel p / conv_up when
      * divisible, else contributes 0: the data gradient of a stride-conv_up convolution (a transposed convolution) as the same
-     * implicit GEMM over the INPUT pixels (conv_ho x conv_wo), image = dy (conv_h x conv_w), conv_stride = 1.  0 / 1 = off. */
+     * implicit GEMM over the INPUT pixels (conv_ho x conv_wo), image = dy (conv_h x conv_w), conv_stride = 1.  0 / 1 = off.
+     * conv_up == 2 with conv_ho == 2 conv_h, conv_wo == 2 conv_w and M / 4 a multiple of 256: the kernel deals its tiles by the parity class (y % 2, x % 2)
+     * of the input pixels and walks only the class's 1 / 2 / 2 / 4 live taps (an internal schedule: same rows of C, same sums without their zero terms;
+     * MDVIT_CONV_PHASE=0 keeps the nine-tap walk). */
     int32_t conv_up;
     /* TN, precision 1 only: that operand is stored as bf16 ([K, M] / [K, N] of 2-byte elements behind the float pointer, leading dimension in elements,
      * % 4 == 0): the saved hidden activations of the "mixed" mode (MdvitBlockDesc.store_bf16).  It enters the product as its single bf16 plane (two
