@@ -1,0 +1,44 @@
+"""Which host call sites issue the small launches of a TransFuse_S_adapt train step (hipMemcpyAsync = __amd_rocclr_copyBuffer, fills, adds)?
+torch.profiler with Python stacks over one step of `bench.py --model transfuse --batch 8 --size 256`.   python tools/probe/transfuse_launch_sources.py"""
+import collections, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from mdvit_amd import ops
+from mdvit_amd.optim import FusedAdamW
+from mdvit_amd.parallel import GradAccumulator
+from mdvit_amd.synthetic import make_step_batches
+from mdvit_amd.transfuse import TransFuse_S_adapt, transfuse_train_step
+from torch.profiler import profile, ProfilerActivity
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = TransFuse_S_adapt(num_classes=1, drop_rate=0.2, pretrained=False, num_domains=4).to(dev).train()
+ops.enable_side_stream(True)
+accum = GradAccumulator(model.parameters(), late=[p for n, p in model.named_parameters() if "domain_layer" in n])
+accum.attach_sinks()
+opt = FusedAdamW(accum, lr=1e-4, weight_decay=0.05)
+pool = [make_step_batches(8, 256, rank=0, step=s, device=dev, domains=(0, 1, 2, 3)) for s in range(2)]
+for i in range(3):
+    transfuse_train_step(model, pool[i % 2], optimizer=opt, accumulator=accum, fuse_domains=True)
+torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    transfuse_train_step(model, pool[1], optimizer=opt, accumulator=accum, fuse_domains=True)
+    torch.cuda.synchronize()
+names = collections.Counter(ev.name for ev in prof.events())
+print("events mentioning copies, sets, fills:")
+for n, c in names.most_common():
+    if any(s in n.lower() for s in ("memcpy", "memset", "copy", "fill", "zero", "aten::add", "aten::cat", "aten::stack", "aten::mul", "aten::sum")):
+        print(f"{c:5d}  {n}")
+agg = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::cat", "aten::stack", "aten::_to_copy", "aten::clone", "aten::mul", "aten::sum"):
+        site = "(engine)"
+        for fr in (ev.stack or []):
+            if "mdvit_amd" in fr or "bench.py" in fr:
+                site = fr.strip()[-80:]
+                break
+        par = ev.cpu_parent.name if ev.cpu_parent is not None else "-"
+        agg[(ev.name, par[:50], site)] += 1
+for k, v in agg.most_common(45):
+    print(f"{v:4d}  {k}")
