@@ -386,41 +386,68 @@ __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* __restr
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ ws, float* mean, float* rstd, float* rmean, float* rvar,
-                                   int64_t* nbt, int M, int C, float eps, float momentum, int groups, int per_group) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (per_group) {                            // domain-specific banks: group g updates running-stat row g once
-        if (c < C)
-            for (int g = 0; g < groups; ++g) {
-                const double m = ws[(long)g * 2 * C + c] / M;
-                double var = ws[(long)g * 2 * C + C + c] / M - m * m;
-                if (var < 0.0) var = 0.0;
-                mean[g * C + c] = (float)m;
-                rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-                const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-                if (rmean) {
-                    rmean[g * C + c] = (1.f - momentum) * rmean[g * C + c] + momentum * (float)m;
-                    rvar[g * C + c] = (1.f - momentum) * rvar[g * C + c] + momentum * (float)unb;
-                }
+// chan_finalize_kernel's column sums + the statistics' finalisation as ONE launch (BatchNorm forward statistics; one launch less per BatchNorm on the main stream): a workgroup owns
+// 16 channels = the 32 columns {S1[c], S2[c]}; per group the partial rows are summed in double by 32 row lanes per column (lane r adds rows r, r + 32, ...,
+// then the 32 lane sums are added 0..31: a FIXED order), then 16 threads turn the sums into mean / rstd / running statistics for their channel, group after group (the
+// running statistics see the same update sequence as `groups` consecutive forwards).
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ part, double* __restrict__ ws, int nblk, float* mean, float* rstd,
+                                                                  float* rmean, float* rvar, int64_t* nbt, int M, int C, float eps, float momentum, int groups,
+                                                                  int per_group) {
+    __shared__ double s_sum[32][33];
+    __shared__ double s_tot[32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 16;
+    const int c = c0 + (cl & 15);
+    const int col = (cl < 16 ? 0 : C) + c;             // column of the partial rows: S1 | S2
+    const int C2 = 2 * C;
+    float rm = 0.f, rv = 0.f;
+    const bool owner = threadIdx.x < 16 && c < C;
+    if (owner && !per_group) { rm = rmean ? rmean[c] : 0.f; rv = rvar ? rvar[c] : 0.f; }
+    for (int g = 0; g < groups; ++g) {
+        const float* pg = part + (long)g * nblk * C2;
+        double s = 0.0;
+        if (c < C) {
+            int b = rl;
+            for (; b + 96 < nblk; b += 128) {       // 4 independent loads in flight
+                const float v0 = pg[(long)b * C2 + col], v1 = pg[(long)(b + 32) * C2 + col];
+                const float v2 = pg[(long)(b + 64) * C2 + col], v3 = pg[(long)(b + 96) * C2 + col];
+                s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
             }
-        if (c < groups && nbt) nbt[c] += 1;
-        return;
-    }
-    if (c < C) {
-        float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
-        for (int g = 0; g < groups; ++g) {      // running statistics: the same update sequence as `groups` consecutive forwards
-            const double m = ws[(long)g * 2 * C + c] / M;
-            double var = ws[(long)g * 2 * C + C + c] / M - m * m;
+            for (; b < nblk; b += 32) s += (double)pg[(long)b * C2 + col];
+        }
+        s_sum[rl][cl] = s;
+        __syncthreads();
+        if (rl == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) t += s_sum[r][cl];
+            s_tot[cl] = t;
+            if (c < C) ws[(long)g * C2 + col] = t;
+        }
+        __syncthreads();
+        if (owner) {
+            const double m = s_tot[cl] / M;
+            double var = s_tot[cl + 16] / M - m * m;
             if (var < 0.0) var = 0.0;
             mean[g * C + c] = (float)m;
             rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
             const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-            rm = (1.f - momentum) * rm + momentum * (float)m;
-            rv = (1.f - momentum) * rv + momentum * (float)unb;
+            if (per_group) {
+                if (rmean) {
+                    rmean[g * C + c] = (1.f - momentum) * rmean[g * C + c] + momentum * (float)m;
+                    rvar[g * C + c] = (1.f - momentum) * rvar[g * C + c] + momentum * (float)unb;
+                }
+            } else {
+                rm = (1.f - momentum) * rm + momentum * (float)m;
+                rv = (1.f - momentum) * rv + momentum * (float)unb;
+            }
         }
-        if (rmean) { rmean[c] = rm; rvar[c] = rv; }
     }
-    if (c == 0 && nbt) *nbt += groups;
+    if (owner && !per_group && rmean) { rmean[c] = rm; rvar[c] = rv; }
+    if (blockIdx.x == 0 && nbt) {
+        if (per_group) { if ((int)threadIdx.x < groups) nbt[threadIdx.x] += 1; }
+        else if (threadIdx.x == 0) *nbt += groups;
+    }
 }
 
 __global__ void bn_eval_prep_kernel(const float* rm, const float* rv, float* mean, float* rstd, int C, float eps) {
@@ -843,8 +870,8 @@ extern "C" int mdvit_bn_stats(const float* y, void* ws, size_t ws_bytes, float* 
     a.ws = (double*)ws; a.part = (float*)((double*)ws + 2 * (size_t)C * groups);
     const int grid = chan_grid(Mg, C, CHAN_MAX_BLOCKS);
     hipLaunchKernelGGL((chan_reduce_kernel<0>), dim3(grid, groups), dim3(256), sizeof(float) * (2 * C + 256 * 8), s, a);
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3(cdiv(2 * C, 32), groups), dim3(256), 0, s, a.part, a.ws, grid, 2 * C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, a.ws, mean, rstd, running_mean, running_var, nbt, Mg, C, eps, momentum, groups, per_group_affine);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, s, a.part, a.ws, grid, mean, rstd, running_mean, running_var, nbt, Mg, C, eps, momentum,
+                       groups, per_group_affine);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
