@@ -33,7 +33,16 @@ struct TnArgs {
     long lda, ldb, ldc;
     int M, N, K, kps, splits, tiles_m, tiles_n, accumulate, grid_xcd;
     int cv_c, cv_h, cv_w, cv_ho, cv_wo, cv_s, cv_d;      // CONVB: B is the NHWC image x, gathered as the im2col matrix [token][tap * C + c]
+#ifdef MDVIT_TN_PHASES
+    long long* dbg;       // variant build (tools/probe/tn_phases.py): shader-cycle stamps of workgroup (tile 0, split 0), thread 0, [slab][8]
+#endif
 };
+#ifdef MDVIT_TN_PHASES
+static long long* g_tn_dbg = nullptr;
+#define TNP(slab_, k_) do { if (p.dbg && tile == 0 && split == 0 && tid == 0 && (slab_) >= 0 && (slab_) < 64) p.dbg[(slab_) * 8 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TNP(slab_, k_) do { } while (0)
+#endif
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -116,12 +125,38 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
     const bool do_cs = CS && tn == 0;
     const int full_slabs = (kend - kbeg) / BK;                  // slabs at or past this index need their rows past kend zeroed
 
+    // Row pointers of this thread's staged quads, stepped one slab at a time (round 4: the per-slab address chain -- clamp, 64-bit multiply by the leading
+    // dimension, add -- was 10 quarter-rate v_mul_lo_u32 + 5 v_mad_u64_u32 per slab and wave, a fifth of a slab period's issue time on a kernel whose
+    // waves run their phases back to back: tools/probe/tn_phases.py).  Full slabs read pa[v] + slab * BK * lda; the tail slab and the phantom
+    // slabs behind it read the CLAMPED row of the tail slab (rows past kend are zeroed at the LDS store, as before).
+    constexpr bool FASTA = !ABF, FASTB = !BBF && !CONVB;
+    const float* pa[FASTA ? AV : 1]; long la[FASTA ? AV : 1];            // la / lb: the tail slab's clamped row MINUS the unclamped one (<= 0, elements)
+    const float* pb[FASTB ? BV : 1]; long lb[FASTB ? BV : 1];
+    if (FASTA) {
+#pragma unroll
+        for (int v = 0; v < AV; ++v) {
+            const int u = wave + 4 * v, kk = 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
+            pa[v] = p.A + (long)(kbeg + kk) * p.lda + m;
+            la[v] = (long)(min(kbeg + full_slabs * BK + kk, kend - 1) - (kbeg + full_slabs * BK + kk)) * p.lda;
+        }
+    }
+    if (FASTB) {
+#pragma unroll
+        for (int v = 0; v < BV; ++v) {
+            const int u = wave + 4 * v, kk = 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
+            pb[v] = p.B + (long)(kbeg + kk) * p.ldb + n;
+            lb[v] = (long)(min(kbeg + full_slabs * BK + kk, kend - 1) - (kbeg + full_slabs * BK + kk)) * p.ldb;
+        }
+    }
+    const long stepa = (long)BK * p.lda, stepb = (long)BK * p.ldb;
     // Loads are UNCONDITIONAL (addresses clamped into the matrix, rows past the end of the K range zeroed by a select): a load under
     // a branch makes the compiler drain the whole vector-memory queue (s_waitcnt vmcnt(0)) at every join, which serialises the
     // slabs.  Columns past M / N read real elements of the last column quad: they only reach output rows / columns that are never stored.
     auto load = [&](int slab, auto setc) __attribute__((always_inline)) {
         constexpr int S = decltype(setc)::value;
         const int k0 = kbeg + slab * BK;
+        // branch-free: the scalar slab offset (frozen at the tail slab) plus the per-thread clamp delta under a scalar all-ones / zero mask
+        const long seff = (long)min(slab, full_slabs), tmask = slab >= full_slabs ? -1L : 0L;
 #pragma unroll
         for (int v = 0; v < AV; ++v) {
             const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
@@ -129,7 +164,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
                 const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.A) + (long)min(k, kend - 1) * p.lda + m);
                 ra[S][v] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), 0.f, 0.f);          // (bit containers)
             } else {
-                ra[S][v] = *reinterpret_cast<const float4*>(p.A + (long)min(k, kend - 1) * p.lda + m);
+                ra[S][v] = *reinterpret_cast<const float4*>(pa[v] + seff * stepa + (la[v] & tmask));
             }
         }
         if (CONVB) {
@@ -154,7 +189,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
                     const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.B) + (long)min(k, kend - 1) * p.ldb + n);
                     rb[S][v] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), 0.f, 0.f);
                 } else {
-                    rb[S][v] = *reinterpret_cast<const float4*>(p.B + (long)min(k, kend - 1) * p.ldb + n);
+                    rb[S][v] = *reinterpret_cast<const float4*>(pb[v] + seff * stepb + (lb[v] & tmask));
                 }
             }
         }
@@ -164,12 +199,23 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
         constexpr int S = decltype(setc)::value;
         char* base = smem + (slab & 1) * STAGE;
         const int k0 = kbeg + slab * BK;
-        const bool tail = slab >= full_slabs;               // (uniform)
+        if (slab >= full_slabs) {                           // (uniform: ONE scalar branch per slab; the per-quad tests under it run in the tail slab only)
+#pragma unroll
+            for (int v = 0; v < AV; ++v)
+                if (k0 + 4 * ((wave + 4 * v) & 7) + kr >= kend) ra[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int v = 0; v < BV; ++v)
+                if (k0 + 4 * ((wave + 4 * v) & 7) + kr >= kend) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#ifdef MDVIT_TN_PHASES
+        TNP(slab - 1, 5);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AV + BV) : "memory");       // this set's loads have landed (the younger set's AV + BV may still fly)
+        TNP(slab - 1, 6);
+#endif
 #pragma unroll
         for (int v = 0; v < AV; ++v) {
             const int u = wave + 4 * v;
             const int off = (((u & 7) * MB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
-            if (tail && k0 + 4 * (u & 7) + kr >= kend) ra[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ABF) {
                 const uint32_t b0 = __float_as_uint(ra[S][v].x), b1 = __float_as_uint(ra[S][v].y);
                 if (CS) {
@@ -190,7 +236,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
         for (int v = 0; v < BV; ++v) {
             const int u = wave + 4 * v;
             const int off = (((u & 7) * NB + 4 * (u >> 3) + (lane >> 4)) << 7) + l15 * 8;
-            if (tail && k0 + 4 * (u & 7) + kr >= kend) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (CONVB && !((bmask[S] >> v) & 1u)) rb[S][v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (BBF) {
                 *reinterpret_cast<uint2*>(bb + off) = make_uint2(__float_as_uint(rb[S][v].x), __float_as_uint(rb[S][v].y));
@@ -259,14 +304,23 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
     store(0, S0{});
     __syncthreads();
     for (int i = 0; i < nslab; i += 2) {
+        TNP(i, 0);
         load(i + 2, S0{});
+        TNP(i, 1);
         mma(0);
+        TNP(i, 2);
         store(i + 1, S1{});
+        TNP(i, 3);
         __syncthreads();
+        TNP(i, 4);
         load(i + 3, S1{});
+        TNP(i + 1, 1);
         mma(1);
+        TNP(i + 1, 2);
         store(i + 2, S0{});
+        TNP(i + 1, 3);
         __syncthreads();
+        TNP(i + 1, 4);
     }
 
     if (CS && do_cs) {              // bias gradient: column sums of the A stream, added in a FIXED order (the loop ended with a barrier)
@@ -393,6 +447,9 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K;
     a.kps = pl.kps; a.splits = pl.splits; a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.accumulate = d->accumulate;
     if (g_tn_grid_xcd < 0) { const char* e = getenv("MDVIT_TN_GRID_XCD"); g_tn_grid_xcd = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+#ifdef MDVIT_TN_PHASES
+    a.dbg = g_tn_dbg;
+#endif
     a.grid_xcd = g_tn_grid_xcd == 2 || (g_tn_grid_xcd == 1 && pl.tiles_m * pl.tiles_n <= 8 && pl.splits > 1);
     if (d->conv_c > 0) {
         a.cv_c = d->conv_c; a.cv_h = d->conv_h; a.cv_w = d->conv_w; a.cv_ho = d->conv_ho; a.cv_wo = d->conv_wo; a.cv_s = d->conv_stride; a.cv_d = d->conv_dilation;
@@ -448,3 +505,7 @@ extern "C" int mdvit_gemm_tn_config(int32_t enable, int32_t cfg, int32_t splits)
     g_tn_force_splits = splits > 0 ? splits : 0;
     return MDVIT_OK;
 }
+
+#ifdef MDVIT_TN_PHASES
+extern "C" void mdvit_tn_debug_buffer(long long* buf) { g_tn_dbg = buf; }
+#endif
