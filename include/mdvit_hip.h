@@ -113,6 +113,17 @@ typedef struct MdvitGemmDesc {
     int32_t a_bf16, b_bf16;
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
+/* The same plain product (desc: shape, layout, precision of ONE group; its A / B / C, bias, epilogue and allow_split are ignored / must be off) on G <= 8 operand
+ * triples in ONE launch.  Replaces the G x 4 separate `W_fuse[:, block] @ W_linear` products (and their two gradient products each) with which the peer heads'
+ * 1x1 convolutions are composed (Decoders.py:315-339: linear_c -> interpolate -> cat -> linear_fuse, evaluated as resize((W_fuse,q W_q) x_q) by decode.py). */
+#define MDVIT_GEMM_MAX_GROUPS 8
+int mdvit_gemm_f32_grouped(const MdvitGemmDesc* desc, int32_t G, const void* const* A, const void* const* B, void* const* C, void* stream);
+/* The bias part of the same composition for n <= 16 (head, scale) items in one launch: out_i[r] = sum_c W_i[r][c] b_i[c] (W_i: [rows, cols] blocks of the fuse
+ * weight, leading dimension ldw; b_i: the linear_c bias), and its gradients: dW_i[r][c] += dout_i[r] b_i[c] (into the block gradient the grouped product wrote,
+ * leading dimension lddw; dW may be NULL), db_i[c] (+)= sum_r W_i[r][c] dout_i[r] (db may be NULL). */
+int mdvit_compose_bias(int32_t n, const void* const* W, int64_t ldw, const void* const* b, void* const* out, int32_t rows, int32_t cols, void* stream);
+int mdvit_compose_bias_bwd(int32_t n, const void* const* W, int64_t ldw, const void* const* b, const void* const* dout, void* const* dW, int64_t lddw,
+                           void* const* db, int32_t db_accumulate, int32_t rows, int32_t cols, void* stream);
 /* which kernel variant the launch will use (tile BMxBN, number of K splits): for profiling / roofline accounting */
 int mdvit_gemm_plan(const MdvitGemmDesc* desc, int32_t* tile_m, int32_t* tile_n, int32_t* splits);
 /* out[cols, rows] = in[rows, cols]^T (row-major, in may be a column slice with leading dimension ld_in).  Used on WEIGHTS

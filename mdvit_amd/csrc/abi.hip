@@ -243,3 +243,71 @@ int mdvit_zero_many(const MdvitZeroItem* items, int n, hipStream_t stream) {
     }
     return MDVIT_OK;
 }
+
+// ---- peer-head weight composition, bias part (decode.py: bc = W_fuse,q b_q for every head and scale; its gradients) -------------------------------------
+// n <= 16 items in ONE launch each way (they were 16 rowdot launches forward, 16 + 16 second stages backward).  Fixed summation orders: deterministic.
+namespace {
+constexpr int CB_MAX = 16;
+struct ComposeBiasArgs {
+    const float* W[CB_MAX]; const float* b[CB_MAX]; const float* dout[CB_MAX]; float* out[CB_MAX]; float* dW[CB_MAX]; float* db[CB_MAX];
+    long ldw, lddw; int rows, cols, db_accumulate;
+};
+// out[r] = sum_c W[r][c] b[c]: a wavefront per row, lanes stride the columns, xor-tree fold
+__global__ __launch_bounds__(256) void compose_bias_fwd_kernel(ComposeBiasArgs p) {
+    const int it = blockIdx.y, lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const float* w = p.W[it] + (long)r * p.ldw;
+    const float* b = p.b[it];
+    float s = 0.f;
+    for (int c = lane; c < p.cols; c += 64) s = fmaf(w[c], b[c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) p.out[it][r] = s;
+}
+// db[c] (+)= sum_r W[r][c] dout[r] (thread per column, rows in order);   dW[r][c] += dout[r] b[c] (grid.x beyond the column blocks: one row block each)
+__global__ __launch_bounds__(256) void compose_bias_bwd_kernel(ComposeBiasArgs p, int col_blocks) {
+    const int it = blockIdx.y;
+    if ((int)blockIdx.x < col_blocks) {
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c >= p.cols || p.db[it] == nullptr) return;
+        const float* w = p.W[it] + c;
+        const float* d = p.dout[it];
+        float s = 0.f;
+        for (int r = 0; r < p.rows; ++r) s = fmaf(w[(long)r * p.ldw], d[r], s);
+        p.db[it][c] = p.db_accumulate ? p.db[it][c] + s : s;
+        return;
+    }
+    if (p.dW[it] == nullptr) return;
+    const int r0 = ((int)blockIdx.x - col_blocks) * 8;
+    for (int r = r0; r < min(r0 + 8, p.rows); ++r) {
+        const float dr = p.dout[it][r];
+        float* o = p.dW[it] + (long)r * p.lddw;
+        for (int c = threadIdx.x; c < p.cols; c += 256) o[c] = fmaf(dr, p.b[it][c], o[c]);
+    }
+}
+}  // namespace
+
+extern "C" int mdvit_compose_bias(int32_t n, const void* const* W, int64_t ldw, const void* const* b, void* const* out, int32_t rows, int32_t cols, void* stream) {
+    MDVIT_CHECK_ARG(n >= 1 && n <= CB_MAX && rows > 0 && cols > 0 && W && b && out, MDVIT_E_SHAPE, "compose_bias: 1 <= n <= %d items", CB_MAX);
+    ComposeBiasArgs a; memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) { a.W[i] = (const float*)W[i]; a.b[i] = (const float*)b[i]; a.out[i] = (float*)out[i]; }
+    a.ldw = ldw; a.rows = rows; a.cols = cols;
+    hipLaunchKernelGGL(compose_bias_fwd_kernel, dim3(cdiv(rows, 4), n), dim3(256), 0, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_compose_bias_bwd(int32_t n, const void* const* W, int64_t ldw, const void* const* b, const void* const* dout, void* const* dW, int64_t lddw,
+                                      void* const* db, int32_t db_accumulate, int32_t rows, int32_t cols, void* stream) {
+    MDVIT_CHECK_ARG(n >= 1 && n <= CB_MAX && rows > 0 && cols > 0 && W && b && dout, MDVIT_E_SHAPE, "compose_bias_bwd: 1 <= n <= %d items", CB_MAX);
+    ComposeBiasArgs a; memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) {
+        a.W[i] = (const float*)W[i]; a.b[i] = (const float*)b[i]; a.dout[i] = (const float*)dout[i];
+        a.dW[i] = dW ? (float*)dW[i] : nullptr; a.db[i] = db ? (float*)db[i] : nullptr;
+    }
+    a.ldw = ldw; a.lddw = lddw; a.rows = rows; a.cols = cols; a.db_accumulate = db_accumulate;
+    const int cb = cdiv(cols, 256);
+    hipLaunchKernelGGL(compose_bias_bwd_kernel, dim3(cb + cdiv(rows, 8), n), dim3(256), 0, (hipStream_t)stream, a, cb);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}

@@ -20,6 +20,11 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
+// set by mdvit_gemm_f32_grouped around its call of mdvit_gemm_f32 (same thread): the operand triples of the groups
+struct GemmGroups { int n; const float* A[MDVIT_GEMM_MAX_GROUPS]; const float* B[MDVIT_GEMM_MAX_GROUPS]; float* C[MDVIT_GEMM_MAX_GROUPS]; };
+static thread_local GemmGroups g_groups = {0, {}, {}, {}};
+const GemmGroups* mdvit_gemm_groups_active() { return g_groups.n > 0 ? &g_groups : nullptr; }
+
 namespace {
 
 constexpr int BK = 32;
@@ -46,7 +51,11 @@ struct GemmArgs {
     const uint32_t* seed;          // optional device-side dropout seed {s0, s1}: key0 ^= s0, key1 += s1 (graph replays draw fresh masks)
     int tiles_m, tiles_n;
     int conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dil, conv_up, conv_phase;     // CONV kernels: A is an NHWC image gathered on the fly
+    // grouped launch (mdvit_gemm_f32_grouped): blockIdx.z = group; the same problem on ngroups operand triples (no split, plain epilogue, no bias)
+    int ngroups; const float* gA[MDVIT_GEMM_MAX_GROUPS]; const float* gB[MDVIT_GEMM_MAX_GROUPS]; float* gC[MDVIT_GEMM_MAX_GROUPS];
 };
+
+
 
 // Bijective XCD-aware remap (guide T1): consecutive logical tiles share an XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& a, int ta, int tb, int epi, int bf3, hipStream_t s) {
-    dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(NTHREADS);
+    dim3 grid(a.tiles_m * a.tiles_n, a.splits, a.ngroups > 0 ? a.ngroups : 1), block(NTHREADS);
 #define MDVIT_GEMM_LAUNCH(TA_, TB_, EPI_, BF3_) \
     MDVIT_TIMED_LAUNCH((gemm_f32_kernel<BM, BN, WM, WN, TA_, TB_, EPI_, BF3_>), grid, block, 0, s, a)
     if (a.conv_c > 0) {
@@ -314,6 +323,12 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
 
     const GemmPlan pl = plan_gemm(d);
     a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;
+    if (g_groups.n > 0) {
+        MDVIT_CHECK_ARG(pl.splits == 1 && d->epi == MDVIT_EPI_NONE && !d->bias && !d->residual && !d->rc_a && d->conv_c <= 0 && !(d->e_drop_p > 0.f) && !d->e_rowscale,
+                        MDVIT_E_SHAPE, "gemm (grouped): one K range, plain epilogue, no bias");
+        a.ngroups = g_groups.n;
+        for (int g = 0; g < g_groups.n; ++g) { a.gA[g] = g_groups.A[g]; a.gB[g] = g_groups.B[g]; a.gC[g] = g_groups.C[g]; }
+    }
     if (pl.splits > 1) {
         const size_t need = sizeof(float) * (size_t)pl.splits * d->M * d->N;
         MDVIT_CHECK_ARG(d->ws != nullptr && d->ws_bytes >= need, MDVIT_E_WORKSPACE,
@@ -512,4 +527,24 @@ extern "C" size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* d) {
     if (mdvit_gemm_tn_applies(d)) return mdvit_gemm_tn_ws_bytes(d);
     const GemmPlan pl = plan_gemm(d);
     return pl.splits > 1 ? sizeof(float) * (size_t)pl.splits * d->M * d->N : 0;
+}
+
+// The same plain product on G operand triples in ONE launch (blockIdx.z = group): the peer heads' weight compositions (Decoders.py:315-339 through
+// mdvit_amd/decode.py: W_fuse block x W_linear per head and scale) -- G x 4 small products that each paid a launch (and most a split-K reduction).
+// desc: the shape / layout / precision of ONE group (its A / B / C are ignored); allow_split is forced off; plain epilogue, no bias.  NN / NT run the
+// gemm.hip tiles, TN the weight-gradient kernel; per group the arithmetic is that of the single launch with allow_split = 0.
+extern "C" int mdvit_gemm_f32_grouped(const MdvitGemmDesc* desc, int32_t G, const void* const* A, const void* const* B, void* const* C, void* stream) {
+    MDVIT_CHECK_ARG(desc != nullptr && G >= 1 && G <= MDVIT_GEMM_MAX_GROUPS && A && B && C, MDVIT_E_SHAPE, "gemm (grouped): 1 <= G <= %d operand triples", MDVIT_GEMM_MAX_GROUPS);
+    MdvitGemmDesc d = *desc;
+    d.allow_split = 0; d.ws = nullptr; d.ws_bytes = 0;
+    d.A = (const float*)A[0]; d.B = (const float*)B[0]; d.C = (float*)C[0];
+    for (int g = 0; g < G; ++g) {
+        MDVIT_CHECK_ARG(A[g] && B[g] && C[g] && aligned16(A[g]) && aligned16(B[g]), MDVIT_E_ALIGN, "gemm (grouped): group %d: null or unaligned operand", g);
+        MDVIT_CHECK_ARG(aligned16(C[g]) == aligned16(C[0]), MDVIT_E_ALIGN, "gemm (grouped): the outputs must share their 16-byte alignment class");
+        g_groups.A[g] = (const float*)A[g]; g_groups.B[g] = (const float*)B[g]; g_groups.C[g] = (float*)C[g];
+    }
+    g_groups.n = G;
+    const int rc = mdvit_gemm_f32(&d, stream);
+    g_groups.n = 0;
+    return rc;
 }

@@ -23,6 +23,8 @@ typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef short v8i16 __attribute__((ext_vector_type(8)));
 
 int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, hipStream_t s);
+struct GemmGroups { int n; const float* A[MDVIT_GEMM_MAX_GROUPS]; const float* B[MDVIT_GEMM_MAX_GROUPS]; float* C[MDVIT_GEMM_MAX_GROUPS]; };
+const GemmGroups* mdvit_gemm_groups_active();       // gemm.hip: the operand triples of a grouped launch in flight on this thread, or NULL
 
 namespace {
 
@@ -33,6 +35,7 @@ struct TnArgs {
     long lda, ldb, ldc;
     int M, N, K, kps, splits, tiles_m, tiles_n, accumulate, grid_xcd;
     int cv_c, cv_h, cv_w, cv_ho, cv_wo, cv_s, cv_d;      // CONVB: B is the NHWC image x, gathered as the im2col matrix [token][tap * C + c]
+    int ngroups; const float* gA[MDVIT_GEMM_MAX_GROUPS]; const float* gB[MDVIT_GEMM_MAX_GROUPS]; float* gC[MDVIT_GEMM_MAX_GROUPS];      // grouped launch: blockIdx.z = group
 #ifdef MDVIT_TN_PHASES
     long long* dbg;       // variant build (tools/probe/tn_phases.py): shader-cycle stamps of workgroup (tile 0, split 0), thread 0, [slab][8]
 #endif
@@ -73,6 +76,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
     constexpr int WTM = BM / 64, WTN = BN / 64;                   // 32x32 blocks per wave (2 x 2 waves)
     __shared__ __attribute__((aligned(256))) char smem[2 * STAGE];
 
+    const float* gA = p.A; const float* gB = p.B;
+    float* gC = p.C;
+    if (p.ngroups > 0) {          // grouped launch (static indices: see gemm_body.inc)
+        const int z = blockIdx.z;
+#pragma unroll
+        for (int g = 0; g < MDVIT_GEMM_MAX_GROUPS; ++g)
+            if (z == g) { gA = p.gA[g]; gB = p.gB[g]; gC = p.gC[g]; }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round robin to the 8 XCDs in launch order (x fastest).  The tiles of ONE K-split read the same token rows -- every A column block
     // once per tile column, every B column block once per tile row.  Remapping inside a split (tile) puts neighbouring tiles of a split on one XCD when a
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
 #pragma unroll
         for (int v = 0; v < AV; ++v) {
             const int u = wave + 4 * v, kk = 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
-            pa[v] = p.A + (long)(kbeg + kk) * p.lda + m;
+            pa[v] = gA + (long)(kbeg + kk) * p.lda + m;
             la[v] = (long)(min(kbeg + full_slabs * BK + kk, kend - 1) - (kbeg + full_slabs * BK + kk)) * p.lda;
         }
     }
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
 #pragma unroll
         for (int v = 0; v < BV; ++v) {
             const int u = wave + 4 * v, kk = 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
-            pb[v] = p.B + (long)(kbeg + kk) * p.ldb + n;
+            pb[v] = gB + (long)(kbeg + kk) * p.ldb + n;
             lb[v] = (long)(min(kbeg + full_slabs * BK + kk, kend - 1) - (kbeg + full_slabs * BK + kk)) * p.ldb;
         }
     }
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
         for (int v = 0; v < AV; ++v) {
             const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, m = min(m0 + 64 * (u >> 3) + colq, p.M - 4);
             if (ABF) {
-                const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.A) + (long)min(k, kend - 1) * p.lda + m);
+                const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(gA) + (long)min(k, kend - 1) * p.lda + m);
                 ra[S][v] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), 0.f, 0.f);          // (bit containers)
             } else {
                 ra[S][v] = *reinterpret_cast<const float4*>(pa[v] + seff * stepa + (la[v] & tmask));
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
                 const int y = ho * p.cv_s + bt_dy[v], x = wo * p.cv_s + bt_dx[v];
                 const bool in = y >= 0 && y < p.cv_h && x >= 0 && x < p.cv_w;
                 const int yc = min(max(y, 0), p.cv_h - 1), xc = min(max(x, 0), p.cv_w - 1);
-                rb[S][v] = *reinterpret_cast<const float4*>(p.B + ((long)(bb * p.cv_h + yc) * p.cv_w + xc) * p.cv_c + bt_c[v]);
+                rb[S][v] = *reinterpret_cast<const float4*>(gB + ((long)(bb * p.cv_h + yc) * p.cv_w + xc) * p.cv_c + bt_c[v]);
                 ok |= (in ? 1u : 0u) << v;
             }
             bmask[S] = ok;
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
             for (int v = 0; v < BV; ++v) {
                 const int u = wave + 4 * v, k = k0 + 4 * (u & 7) + kr, n = min(n0 + 64 * (u >> 3) + colq, p.N - 4);
                 if (BBF) {
-                    const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.B) + (long)min(k, kend - 1) * p.ldb + n);
+                    const uint2 b = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(gB) + (long)min(k, kend - 1) * p.ldb + n);
                     rb[S][v] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), 0.f, 0.f);
                 } else {
                     rb[S][v] = *reinterpret_cast<const float4*>(pb[v] + seff * stepb + (lb[v] & tmask));
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
                 if (col >= p.N) continue;
                 float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 if (slab) { *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = v; continue; }
-                float* dst = p.C + (long)row * p.ldc + col;
+                float* dst = gC + (long)row * p.ldc + col;
                 if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
                 if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                 *reinterpret_cast<float4*>(dst) = v;
@@ -461,7 +472,12 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
         a.slab = (float*)d->ws;
         a.cs_part = a.slab + (size_t)pl.splits * d->M * d->N;
     }
-    const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits), block(NTH);
+    if (const GemmGroups* gg = mdvit_gemm_groups_active()) {
+        MDVIT_CHECK_ARG(pl.splits == 1 && !d->colsum_a && d->conv_c <= 0 && !d->a_bf16 && !d->b_bf16, MDVIT_E_SHAPE, "gemm (wgrad, grouped): one K range, no column sums, no gather");
+        a.ngroups = gg->n;
+        for (int g = 0; g < gg->n; ++g) { a.gA[g] = gg->A[g]; a.gB[g] = gg->B[g]; a.gC[g] = gg->C[g]; }
+    }
+    const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits, a.ngroups > 0 ? a.ngroups : 1), block(NTH);
     const bool one = d->precision == 2;
 #define MDVIT_TN_LAUNCH(BM_, BN_)                                                                                   \
     do {                                                                                                            \

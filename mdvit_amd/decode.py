@@ -12,6 +12,8 @@ parameter still receives its exact gradient.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -40,6 +42,9 @@ class UnetDecodingBlockTransformer(nn.Module):
         return t.view(B, H, W, Cout)
 
 
+_COMPOSE_GROUPED = os.environ.get("MDVIT_COMPOSE_GROUPED", "1") != "0"
+
+
 class MLPDecoderFM(nn.Module):
     def __init__(self, in_channels, out_channel, hidden_channel=256, outfeature_channel=64, dropout_ratio=0.1, conv_norm=nn.BatchNorm2d):
         super().__init__()
@@ -56,23 +61,39 @@ class MLPDecoderFM(nn.Module):
         self.hidden = hidden_channel
         self.with_fm = outfeature_channel > 0
 
-    def forward(self, features, img_size, out_feat=False):
+    def fuse_blocks(self):
+        """the fuse weight as (its leading [hid, 4*hid] columns, the main-decoder feature's block or None)"""
+        hid = self.hidden
+        Wf = self.linear_fuse[0].weight.view(hid, -1)          # [hid, 4*hid + C5]
+        if not self.with_fm:
+            return Wf, None
+        return ops.split_cols(Wf, [4 * hid, Wf.shape[1] - 4 * hid])
+
+    @staticmethod
+    def compose_many(heads):
+        """the composed weights of SEVERAL heads in grouped launches (ops.compose_heads): per head (W5 block, [(Wc_q, bc_q)] * 4)"""
+        blocks = [h.fuse_blocks() for h in heads]
+        lins = [(h.linear1, h.linear2, h.linear3, h.linear4) for h in heads]
+        if not _COMPOSE_GROUPED:        # A/B: one product + one row-dot launch per head and scale (rounds 2-3)
+            hid = heads[0].hidden
+            return [(blocks[g][1], [(ops.matmul(blocks[g][0][:, q * hid:(q + 1) * hid], l.weight.view(hid, -1)), ops.rowdot(blocks[g][0][:, q * hid:(q + 1) * hid], l.bias))
+                                    for q, l in enumerate(lins[g])]) for g in range(len(heads))]
+        comp = ops.compose_heads([b[0] for b in blocks], [[l.weight for l in ls] for ls in lins], [[l.bias for l in ls] for ls in lins])
+        return [(blocks[g][1], comp[g]) for g in range(len(heads))]
+
+    def forward(self, features, img_size, out_feat=False, composed=None):
         if out_feat:
             raise NotImplementedError("out_feat=True of the aux head is unused by the train path")
         x1 = features[0]
         B, h, w, _ = x1.shape
         hid = self.hidden
-        Wf = self.linear_fuse[0].weight.view(hid, -1)          # [hid, 4*hid + C5]
         bias = self.linear_fuse[0].bias
-        lins = (self.linear1, self.linear2, self.linear3, self.linear4)
         # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)      (MLPDecoder: no x5 term, bf rides on q = 0)
-        blocks = ops.split_cols(Wf, [hid] * 4 + ([Wf.shape[1] - 4 * hid] if self.with_fm else []))      # column blocks of the fuse weight
-        acc = ops.linear(features[4], blocks[4], bias) if self.with_fm else None              # [B,h,w,hid]
+        W5, comp = composed if composed is not None else MLPDecoderFM.compose_many([self])[0]
+        acc = ops.linear(features[4], W5, bias) if self.with_fm else None                      # [B,h,w,hid]
         lows = []                                                                              # the projected lower-resolution features
-        for q, lin in enumerate(lins):
-            Wf_q = blocks[q]
-            Wc = ops.matmul(Wf_q, lin.weight.view(hid, -1))                                    # [hid, C_q]
-            bc = ops.rowdot(Wf_q, lin.bias)                                                    # [hid]
+        for q in range(4):
+            Wc, bc = comp[q]                                                                   # [hid, C_q], [hid]
             fq = features[q]
             if acc is None:
                 assert fq.shape[1] == h and fq.shape[2] == w

@@ -178,7 +178,15 @@ class MDViT(_EncoderDecoder):
                                         nn.Sequential(ConvParams(1, E[0], 1, 1))]))
         self.debranchs = nn.ModuleList(peers)
 
-    def _peer_out(self, dd, feats, bridge_out, img_size):
+    _HEADS = {"0": "debranch1", "1": "debranch2", "2": "debranch3", "3": "debranch4"}
+
+    def _compose_peers(self, ds):
+        """the composed 1x1-conv weights of the MLP-style heads of domains ds in grouped launches (MLPDecoderFM.compose_many), or None per head"""
+        if self.decoder_name not in ("MLPFM", "MLP") or any(dd not in self._HEADS for dd in ds) or len(set(ds)) != len(ds):
+            return [None] * len(ds)
+        return MLPDecoderFM.compose_many([getattr(self, self._HEADS[dd]) for dd in ds])
+
+    def _peer_out(self, dd, feats, bridge_out, img_size, composed=None):
         """the peer head of domain id string dd on (a batch group of) the trunk's features"""
         if self.decoder_name == "Transformer":
             peer = self.debranchs[int(dd)]
@@ -188,9 +196,11 @@ class MDViT(_EncoderDecoder):
             B, h, w, _ = a.shape
             low = ops.rowdot(a, peer[4][0].weight, peer[4][0].bias)                        # 1x1 conv at H/4, then upsample
             return ops.upsample_bilinear(low.view(B, h, w, 1), int(img_size[0]), int(img_size[1])).view(B, 1, int(img_size[0]), int(img_size[1]))
-        heads = {"0": "debranch1", "1": "debranch2", "2": "debranch3", "3": "debranch4"}
+        heads = self._HEADS
         if dd not in heads:
             return None
+        if composed is not None:
+            return getattr(self, heads[dd])(feats, img_size=img_size, composed=composed)
         return getattr(self, heads[dd])(feats, img_size=img_size)
 
     def forward(self, x, domain_label=None, d=None, out_feat=False, out_seg=True):
@@ -216,7 +226,8 @@ class MDViT(_EncoderDecoder):
         G = len(ds)
         streams = [ops.peer_stream(g, G * parts[0][0].shape[0]) for g in range(G)] if (G > 1 and parts[0][0].is_cuda) else [None] * G
         if any(s is None for s in streams):
-            return [self._peer_out(dd, [pf[g] for pf in parts], bparts[g], img_size) for g, dd in enumerate(ds)]
+            comp = self._compose_peers(ds)             # G x 4 weight compositions: grouped launches, ahead of the heads
+            return [self._peer_out(dd, [pf[g] for pf in parts], bparts[g], img_size, comp[g]) for g, dd in enumerate(ds)]
         main = torch.cuda.current_stream()
         aux = []
         for g, dd in enumerate(ds):

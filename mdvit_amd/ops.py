@@ -1019,6 +1019,121 @@ def matmul(A, B):
     return _MatMul.apply(A, B)
 
 
+def _vp_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*ptrs)
+
+
+def gemm_grouped(As, Bs, outs, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, accumulate=False, precision=None):
+    """the same plain product on len(As) operand triples in ONE launch (mdvit_gemm_f32_grouped: no K split, no bias)"""
+    if precision is None:
+        precision = min(_gemm_precision, 1) if (bool(trans_b) != bool(trans_a)) else 0
+    d = GemmDesc()
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.M, d.N, d.K = M, N, K
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+    d.accumulate = int(accumulate)
+    d.precision = int(precision)
+    call("mdvit_gemm_f32_grouped", C.byref(d), len(As), _vp_array([_p(t) for t in As]), _vp_array([_p(t) for t in Bs]), _vp_array([_p(t) for t in outs]), _stream())
+
+
+class _ComposeHeads(torch.autograd.Function):
+    """The weight composition of G peer heads x Q scales as grouped launches (decode.MLPDecoderFM: linear_fuse o cat o resize o linear_q evaluated as
+    resize((Wf_q W_q) x_q + Wf_q b_q)):  Wc[g][q] = Wf[g][:, q*hid:(q+1)*hid] @ W[g][q],  bc[g][q] = Wf[g][:, q-block] . b[g][q].
+    Inputs: G matrices Wf_g [hid, Q*hid] (row-contiguous 2-D views, e.g. the leading columns of the fuse weight), then G*Q weights W[g][q] [hid, C_q], then G*Q
+    biases [hid].  Outputs: G*Q composed weights, then G*Q composed biases.  Q products forward and 2 Q backward, each ONE launch over the G heads
+    (instead of G each, most with a split-K second stage), the bias parts ONE launch each way."""
+
+    @staticmethod
+    def forward(ctx, G, Q, *ts):
+        ctx.set_materialize_grads(False)
+        Wf, W, b = ts[:G], ts[G:G + G * Q], ts[G + G * Q:]
+        _chk(*W, *b)                                            # (Wf: row-contiguous column-slice views; W: the 1x1 conv weights [hid, C_q, 1, 1] or [hid, C_q])
+        hid, _, ldf = _ld_view(Wf[0])
+        assert all(w.is_cuda and w.dtype == torch.float32 and _ld_view(w)[0] == hid and _ld_view(w)[2] == ldf and w.shape[1] == Q * hid for w in Wf)
+        dev = Wf[0].device
+        Wc, bc = [None] * (G * Q), [None] * (G * Q)
+        for q in range(Q):
+            Cq = W[q].numel() // hid
+            for g in range(G):
+                assert W[g * Q + q].shape[0] == hid and W[g * Q + q].numel() == hid * Cq
+                Wc[g * Q + q] = _empty((hid, Cq), device=dev, dtype=torch.float32)
+                bc[g * Q + q] = _empty((hid,), device=dev, dtype=torch.float32)
+            gemm_grouped([Wf[g][:, q * hid:] for g in range(G)], [W[g * Q + q] for g in range(G)], [Wc[g * Q + q] for g in range(G)],
+                         hid, Cq, hid, lda=ldf, ldb=Cq, ldc=Cq, trans_b=False)
+        items = [(g, q) for g in range(G) for q in range(Q)]
+        call("mdvit_compose_bias", len(items), _vp_array([_p(Wf[g][:, q * hid:]) for g, q in items]), ldf, _vp_array([_p(b[g * Q + q]) for g, q in items]),
+             _vp_array([_p(bc[g * Q + q]) for g, q in items]), hid, hid, _stream())
+        ctx.save_for_backward(*ts)
+        ctx.meta = (G, Q, hid, ldf)
+        return tuple(Wc) + tuple(bc)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        G, Q, hid, ldf = ctx.meta
+        none = (None,) * (2 + G + 2 * G * Q)
+        if _dgrad_only or all(g is None for g in gs):          # (all operands are weights: nothing to do in the data-gradient-only sweep)
+            return none
+        ts = ctx.saved_tensors
+        Wf, W, b = ts[:G], ts[G:G + G * Q], ts[G + G * Q:]
+        dev = Wf[0].device
+        dWc = [None if g is None else _c(g) for g in gs[:G * Q]]
+        dbc = [None if g is None else _c(g) for g in gs[G * Q:]]
+        for i in range(G * Q):                                 # (a head whose output was not used hands None: treat as zeros)
+            if dWc[i] is None:
+                dWc[i] = torch.zeros((hid, W[i].numel() // hid), device=dev, dtype=torch.float32)
+            if dbc[i] is None:
+                dbc[i] = torch.zeros_like(b[i])
+        dWf = [_empty((hid, Q * hid), device=dev, dtype=torch.float32) for _ in range(G)]
+        sW = [_sink_of(w) for w in W]
+        sb = [_sink_of(t) for t in b]
+        sunk = all(t is not None for t in sW) and all(t is not None for t in sb)
+        dW = list(sW) if sunk else [_empty_like(w) for w in W]
+        db = list(sb) if sunk else [_empty_like(t) for t in b]
+        items = [(g, q) for g in range(G) for q in range(Q)]
+        A_blocks = _vp_array([_p(Wf[g][:, q * hid:]) for g, q in items])
+        b_ptrs, dbc_ptrs = _vp_array([_p(b[g * Q + q]) for g, q in items]), _vp_array([_p(dbc[g * Q + q]) for g, q in items])
+        for q in range(Q):
+            Cq = W[q].numel() // hid
+            # dWf[g][:, q-block] = dWc[g][q] @ W[g][q]^T          (NT: W[g][q] is the "weight [N = hid, K = C_q]")
+            gemm_grouped([dWc[g * Q + q] for g in range(G)], [W[g * Q + q] for g in range(G)], [dWf[g][:, q * hid:] for g in range(G)],
+                         hid, hid, Cq, lda=Cq, ldb=Cq, ldc=Q * hid, trans_b=True)
+        # dWf[g][:, q-block] += dbc[g][q] (x) b[g][q]
+        call("mdvit_compose_bias_bwd", len(items), A_blocks, ldf, b_ptrs, dbc_ptrs, _vp_array([_p(dWf[g][:, q * hid:]) for g, q in items]), Q * hid,
+             None, 0, hid, hid, _stream())
+
+        def param_grads():
+            for q in range(Q):
+                Cq = W[q].numel() // hid
+                # dW[g][q] (+)= Wf[g][:, q-block]^T @ dWc[g][q]
+                gemm_grouped([Wf[g][:, q * hid:] for g in range(G)], [dWc[g * Q + q] for g in range(G)], [dW[g * Q + q] for g in range(G)],
+                             hid, Cq, hid, lda=ldf, ldb=Cq, ldc=Cq, trans_a=True, trans_b=False, accumulate=sunk)
+            # db[g][q] (+)= Wf[g][:, q-block]^T dbc[g][q]
+            call("mdvit_compose_bias_bwd", len(items), A_blocks, ldf, b_ptrs, dbc_ptrs, None, 0, _vp_array([_p(db[g * Q + q]) for g, q in items]), int(sunk),
+                 hid, hid, _stream())
+
+        if sunk:
+            # into the gradient buckets, like every other sunk weight gradient: on the weight-gradient stream (joined before the buckets are read);
+            # a sink written on whatever stream this node runs on -- a peer stream, the sweep stream -- is ordered with nothing
+            with _on_side(*dWc, *dbc):
+                param_grads()
+        else:
+            param_grads()
+        if sunk:
+            return (None, None) + tuple(dWf) + (None,) * (2 * G * Q)
+        return (None, None) + tuple(dWf) + tuple(dW) + tuple(db)
+
+
+def compose_heads(Wf_list, W_lists, b_lists):
+    """Wf_list[g]: [hid, Q*hid]; W_lists[g][q]: [hid, C_q] (or the 1x1 conv weight [hid, C_q, 1, 1] itself: a leaf finds its gradient sink); b_lists[g][q]: [hid]
+    ->  (Wc[g][q], bc[g][q]) nested lists"""
+    G, Q = len(Wf_list), len(W_lists[0])
+    flatW = [W_lists[g][q] for g in range(G) for q in range(Q)]
+    flatb = [b_lists[g][q] for g in range(G) for q in range(Q)]
+    out = _ComposeHeads.apply(G, Q, *Wf_list, *flatW, *flatb)
+    Wc, bc = out[:G * Q], out[G * Q:]
+    return [[(Wc[g * Q + q], bc[g * Q + q]) for q in range(Q)] for g in range(G)]
+
+
 # ------------------------------------------------------------------------------------------------
 # MLP with residual:  out = res + DropPath(Dropout(fc2(Dropout(GELU(fc1(x))))))      mpvit.py:71-78
 # ------------------------------------------------------------------------------------------------

@@ -625,6 +625,47 @@ def test_conv3x3_dense_dilated(B, H, W, Cin, Cout, dil):
     check(go[1], gr[1], name="dw")
 
 
+@pytest.mark.parametrize("G", [1, 4])
+def test_grouped_weight_composition_of_the_peer_heads(G):
+    """Decoders.py:315-339 evaluated as resize((Wf_q W_q) x_q + Wf_q b_q) (decode.MLPDecoderFM): the G x 4 compositions Wf[:, q-block] @ W_q and Wf[:, q-block] . b_q as
+    grouped launches (ops.compose_heads) against fp64, values and all three gradient families; a head composed alone equals the same head inside a group of four, bit for bit"""
+    from mdvit_amd import ops
+    hid, Cs = 128, (64, 128, 320, 512)
+    Wf = [rnd(hid, 4 * hid + 64, seed=400 + g, scale=hid ** -0.5) for g in range(G)]          # (the fuse weight with its extra feature block: column-slice views below)
+    W = [[rnd(hid, c, 1, 1, seed=410 + 7 * g + q, scale=c ** -0.5) for q, c in enumerate(Cs)] for g in range(G)]
+    b = [[rnd(hid, seed=440 + 7 * g + q) for q in range(4)] for g in range(G)]
+    gW = [[rnd(hid, c, seed=470 + 7 * g + q) for q, c in enumerate(Cs)] for g in range(G)]
+    gb = [[rnd(hid, seed=500 + 7 * g + q) for q in range(4)] for g in range(G)]
+
+    def run(Wf, W, b, f64):
+        Wf = [t.clone().to(torch.float64 if f64 else torch.float32).to("cpu" if f64 else dev()).requires_grad_(True) for t in Wf]
+        W = [[t.clone().to(Wf[0].dtype).to(Wf[0].device).requires_grad_(True) for t in ws] for ws in W]
+        b = [[t.clone().to(Wf[0].dtype).to(Wf[0].device).requires_grad_(True) for t in bs] for bs in b]
+        if f64:
+            comp = [[(Wf[g][:, q * hid:(q + 1) * hid] @ W[g][q].view(hid, -1), Wf[g][:, q * hid:(q + 1) * hid] @ b[g][q]) for q in range(4)] for g in range(len(Wf))]
+        else:
+            comp = ops.compose_heads([w[:, :4 * hid] for w in Wf], W, b)
+        loss = sum((comp[g][q][0] * gW[g][q].to(Wf[0])).sum() + (comp[g][q][1] * gb[g][q].to(Wf[0])).sum() for g in range(len(Wf)) for q in range(4))
+        loss.backward()
+        return comp, Wf, W, b
+
+    ref, rWf, rW, rb = run(Wf, W, b, True)
+    out, oWf, oW, ob = run(Wf, W, b, False)
+    for g in range(G):
+        check(oWf[g].grad, rWf[g].grad, name=f"dWf[{g}]")
+        for q in range(4):
+            check(out[g][q][0], ref[g][q][0], name=f"Wc[{g}][{q}]")
+            check(out[g][q][1], ref[g][q][1], name=f"bc[{g}][{q}]")
+            check(oW[g][q].grad, rW[g][q].grad, name=f"dW[{g}][{q}]")
+            check(ob[g][q].grad, rb[g][q].grad, name=f"db[{g}][{q}]")
+    if G > 1:        # head 2 alone
+        one, aWf, aW, ab = run(Wf[2:3], W[2:3], b[2:3], False)
+        gW[0], gb[0] = gW[2], gb[2]
+        one, aWf, aW, ab = run(Wf[2:3], W[2:3], b[2:3], False)
+        assert all(torch.equal(one[0][q][0], out[2][q][0]) and torch.equal(one[0][q][1], out[2][q][1]) for q in range(4))
+        assert torch.equal(aWf[0].grad, oWf[2].grad) and all(torch.equal(aW[0][q].grad, oW[2][q].grad) and torch.equal(ab[0][q].grad, ob[2][q].grad) for q in range(4))
+
+
 def test_elementwise_dropout_and_global_avg_pool(monkeypatch):
     from mdvit_amd import ops
     x = rnd(3, 11, 13, 64, seed=170).to(dev()).requires_grad_(True)
