@@ -545,7 +545,7 @@ __device__ __forceinline__ void fa_apply3_tiles(const float* __restrict__ dout, 
 // all-in-one wave above gets at Ch = 40 / 64, where 396 / 512 registers left the loads of a tile nothing to hide behind: 1.9 TB/s).  k is read by two roles
 // (the second read hits the L2).  Per output element the same MFMA sequence as above: same bits.
 template <int CH>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void fa_bwd_apply3_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(CH >= 64 ? 2 : 3, CH >= 64 ? 2 : 3))) void fa_bwd_apply3_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
                                                            const float* __restrict__ U, const float* __restrict__ dVc,
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
