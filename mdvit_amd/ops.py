@@ -937,17 +937,17 @@ class _Linear(torch.autograd.Function):
             sb = _sink_of(ctx.bias_ref) if has_b else None
         sunk = want_w and sW is not None and (not has_b or sb is not None)
         want_b = want_w and has_b and (sunk or ctx.needs_input_grad[2])
+        ride = want_b and (sunk or ctx.needs_input_grad[1])
         if want_b and not sunk:
-            db = _empty((N,), device=x.device, dtype=torch.float32)
+            # (the bias gradient of a NON-leaf bias -- the peer heads' composed biases, 20 per step -- rides on the weight-gradient GEMM's column sums, which
+            #  accumulate: it starts from a slice of a pre-zeroed slab instead of paying a fill launch of its own)
+            db = _zeros_once(N, x.device) if ride else _empty((N,), device=x.device, dtype=torch.float32)
         # ONE pass over the upstream gradient: gm = g * dropmask * droppath scale (only if there is a mask) and the bias
         # gradient (column sums of gm); the dgrad / wgrad GEMMs below read gm with no prologue of their own
         masked = drop_p > 0 or rowscale is not None
         gm = _empty_like(g) if masked else g
         # the bias gradient (column sums of gm) rides on the wgrad GEMM's own pass over gm (colsum_a) whenever that GEMM runs: the
         # mask pass then only masks -- no partial sums, no second-stage reduction launch on the main stream
-        ride = want_b and (sunk or ctx.needs_input_grad[1])
-        if want_b and not sunk and ride:
-            db.zero_()
         if masked or (want_b and not ride):
             sums = want_b and not ride
             wsp, wsb, _keep = _partials_ws(N, g.device) if sums else (None, 0, None)
@@ -1017,6 +1017,32 @@ class _MatMul(torch.autograd.Function):
 
 def matmul(A, B):
     return _MatMul.apply(A, B)
+
+
+_zero_slab = [None, 0, None, None]        # a zero-filled slab, the offset of its first unused element, the event behind its fill, the stream that filled it
+
+
+def _zeros_once(n: int, device):
+    """n fresh zeros without a fill launch per call: slices of a 64K-float slab that is zero-filled once (one fill per ~100 calls); every slice is handed out
+    ONCE.  A consumer on ANOTHER stream than the one that filled the slab waits for the fill's event (until it is seen complete).  Under HIP-graph capture a
+    replay would see the slices dirty: the plain fill is captured instead."""
+    if torch.cuda.is_current_stream_capturing() or n > 16384:
+        return torch.zeros((n,), device=device, dtype=torch.float32)
+    slab, off, ev, fs = _zero_slab
+    n4 = (n + 3) & ~3
+    cur = current_stream_obj()
+    if slab is None or slab.device != device or off + n4 > slab.numel():
+        slab, off = torch.zeros((65536,), device=device, dtype=torch.float32), 0
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        fs = cur.cuda_stream
+    elif ev is not None:
+        if ev.query():
+            ev = None
+        elif cur.cuda_stream != fs:
+            cur.wait_event(ev)
+    _zero_slab[:] = [slab, off + n4, ev, fs]
+    return slab[off:off + n]
 
 
 def _vp_array(ptrs):
