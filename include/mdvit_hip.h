@@ -129,6 +129,9 @@ int mdvit_gemm_plan(const MdvitGemmDesc* desc, int32_t* tile_m, int32_t* tile_n,
 /* out[cols, rows] = in[rows, cols]^T (row-major, in may be a column slice with leading dimension ld_in).  Used on WEIGHTS
  * only: with precision = 1 the data-gradient GEMM  dX = dY W  reads W^T so that both operands are k-contiguous. */
 int mdvit_transpose_f32(const float* in, int64_t ld_in, float* out, int32_t rows, int32_t cols, void* stream);
+/* n <= 24 transposes out_i[cols_i][rows_i] = in_i[rows_i][cols_i]^T (row-contiguous inputs, leading dimension ld_in_i) in ONE launch, the items in the kernel's
+ * arguments: the W^T of the peer heads' composed weights (per-step temporaries that every data-gradient product of both sweeps reads). */
+int mdvit_transpose_batch(int32_t n, const void* const* in, const int64_t* ld_in, void* const* out, const int32_t* rows, const int32_t* cols, void* stream);
 /* n transposes in one launch (the per-step refresh of every cached W^T after the optimizer update).  items_dev: device array
  * [n][5] of int64 {in pointer, out pointer, ld_in, rows, cols}; blocks_per_item workgroups walk each item's 32x32 tiles. */
 int mdvit_transpose_many(const void* items_dev, int32_t n, int32_t blocks_per_item, void* stream);

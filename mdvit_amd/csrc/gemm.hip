@@ -478,6 +478,52 @@ extern "C" int mdvit_transpose_many(const void* items_dev, int32_t n, int32_t bl
     return MDVIT_OK;
 }
 
+// up to 24 transposes in ONE launch with the items in the kernel ARGUMENTS (no device table: the operands are per-step temporaries -- the peer heads'
+// composed weights, whose W^T every data-gradient product of both sweeps reads); grid.y = item, static-index select (no scratch)
+namespace {
+constexpr int TB_MAX = 24;
+struct TransposeBatchArgs { const float* in[TB_MAX]; float* out[TB_MAX]; long ld[TB_MAX]; int rows[TB_MAX]; int cols[TB_MAX]; };
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatchArgs a) {
+    __shared__ float tile[32][33];
+    const float* in = a.in[0]; float* out = a.out[0]; long ld_in = a.ld[0]; int rows = a.rows[0], cols = a.cols[0];
+    const int y = blockIdx.y;
+#pragma unroll
+    for (int i = 1; i < TB_MAX; ++i)
+        if (y == i) { in = a.in[i]; out = a.out[i]; ld_in = a.ld[i]; rows = a.rows[i]; cols = a.cols[i]; }
+    const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tidx = blockIdx.x; tidx < tiles_x * tiles_y; tidx += gridDim.x) {
+        const int r0 = (tidx / tiles_x) * 32, c0 = (tidx % tiles_x) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ty + 8 * i, c = c0 + tx;
+            tile[ty + 8 * i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;
+            if (c < cols && r < rows) out[(long)c * rows + r] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int mdvit_transpose_batch(int32_t n, const void* const* in, const int64_t* ld_in, void* const* out, const int32_t* rows, const int32_t* cols, void* stream) {
+    MDVIT_CHECK_ARG(n >= 1 && n <= TB_MAX && in && ld_in && out && rows && cols, MDVIT_E_SHAPE, "transpose_batch: 1 <= n <= %d items", TB_MAX);
+    TransposeBatchArgs a; memset(&a, 0, sizeof(a));
+    int tiles = 1;
+    for (int i = 0; i < n; ++i) {
+        MDVIT_CHECK_ARG(in[i] && out[i] && rows[i] > 0 && cols[i] > 0 && ld_in[i] >= cols[i], MDVIT_E_SHAPE, "transpose_batch: item %d: bad shape", i);
+        a.in[i] = (const float*)in[i]; a.out[i] = (float*)out[i]; a.ld[i] = (long)ld_in[i]; a.rows[i] = rows[i]; a.cols[i] = cols[i];
+        tiles = max(tiles, cdiv(rows[i], 32) * cdiv(cols[i], 32));
+    }
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(min(tiles, 64), n), dim3(256), 0, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
 extern "C" int mdvit_transpose_f32(const float* in, int64_t ld_in, float* out, int32_t rows, int32_t cols, void* stream) {
     MDVIT_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_in >= cols, MDVIT_E_SHAPE, "transpose: bad shape rows=%d cols=%d ld=%ld", rows, cols, (long)ld_in);
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, in, (long)ld_in, out, rows, cols);

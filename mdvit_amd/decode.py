@@ -43,6 +43,7 @@ class UnetDecodingBlockTransformer(nn.Module):
 
 
 _COMPOSE_GROUPED = os.environ.get("MDVIT_COMPOSE_GROUPED", "1") != "0"
+_WT_BATCH = os.environ.get("MDVIT_WT_BATCH", "1") != "0"      # A/B: 0 = one transpose per use of a composed weight
 
 
 class MLPDecoderFM(nn.Module):
@@ -79,6 +80,9 @@ class MLPDecoderFM(nn.Module):
             return [(blocks[g][1], [(ops.matmul(blocks[g][0][:, q * hid:(q + 1) * hid], l.weight.view(hid, -1)), ops.rowdot(blocks[g][0][:, q * hid:(q + 1) * hid], l.bias))
                                     for q, l in enumerate(lins[g])]) for g in range(len(heads))]
         comp = ops.compose_heads([b[0] for b in blocks], [[l.weight for l in ls] for ls in lins], [[l.bias for l in ls] for ls in lins])
+        if _WT_BATCH and ops._gemm_precision >= 1 and torch.is_grad_enabled():
+            # the W^T every data-gradient product of the heads' 1x1 convolutions reads (both sweeps): one launch for all heads instead of one per use
+            ops.transpose_weights_batch([w for g in range(len(heads)) for (w, _) in comp[g]] + [blocks[g][1] for g in range(len(heads))])
         return [(blocks[g][1], comp[g]) for g in range(len(heads))]
 
     def forward(self, features, img_size, out_feat=False, composed=None):

@@ -503,6 +503,9 @@ def wt(W):
     """W [N,K] (2-D view, or a contiguous conv weight read as [out, in*kh*kw]) -> contiguous W^T [K,N].  Cached per leaf
     parameter; refreshed (into the same buffer) when the parameter's version counter moves -- normally for all weights
     at once by refresh_transposes() at the start of a step."""
+    pre = getattr(W, "_mdvit_wt", None)       # a per-step temporary whose W^T was produced with it (transpose_weights_batch: the peer heads' composed weights)
+    if pre is not None and pre[0] == W._version:
+        return pre[1]
     N, K, ld = _ld_view(W)
     leaf = W.grad_fn is None and W.requires_grad
     tag = (W._version + (_weights_epoch << 32), W.data_ptr(), N, K, ld)      # the epoch moves when an optimizer writes through raw pointers
@@ -525,6 +528,21 @@ def wt(W):
         key = id(W)
         _wt_cache[key] = (weakref.ref(W, lambda _r, key=key: _wt_cache.pop(key, None)),) + tag + (out,)
     return out
+
+
+def transpose_weights_batch(Ws):
+    """W^T of up to 24 non-leaf weights [N, K] (row-contiguous views) in ONE launch, attached to the tensors: wt(W) finds it in either sweep instead of
+    transposing per use (the peer heads' composed weights: 20 per sweep)."""
+    Ws = [W for W in Ws if W is not None and W.is_cuda and W.dtype == torch.float32]
+    for i in range(0, len(Ws), 24):
+        chunk = Ws[i:i + 24]
+        views = [_ld_view(W) for W in chunk]
+        outs = [torch.empty((K, N), device=W.device, dtype=torch.float32) for W, (N, K, _) in zip(chunk, views)]
+        n = len(chunk)
+        call("mdvit_transpose_batch", n, _vp_array([_p(W) for W in chunk]), (C.c_int64 * n)(*[v[2] for v in views]), _vp_array([_p(o) for o in outs]),
+             (C.c_int32 * n)(*[v[0] for v in views]), (C.c_int32 * n)(*[v[1] for v in views]), _stream())
+        for W, o in zip(chunk, outs):
+            W._mdvit_wt = (W._version, o)
 
 
 _wt_table = None     # (signature, device int64 table [n,5], blocks per item)
