@@ -118,6 +118,8 @@ size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
  * 1x1 convolutions are composed (Decoders.py:315-339: linear_c -> interpolate -> cat -> linear_fuse, evaluated as resize((W_fuse,q W_q) x_q) by decode.py). */
 #define MDVIT_GEMM_MAX_GROUPS 8
 int mdvit_gemm_f32_grouped(const MdvitGemmDesc* desc, int32_t G, const void* const* A, const void* const* B, void* const* C, void* stream);
+/* ... NN / NT with a bias vector per group: the peer heads' low-resolution linear_c products (Decoders.py:319-328) of all G heads in one launch. */
+int mdvit_gemm_f32_grouped_bias(const MdvitGemmDesc* desc, int32_t G, const void* const* A, const void* const* B, void* const* C, const void* const* bias, void* stream);
 /* The bias part of the same composition for n <= 16 (head, scale) items in one launch: out_i[r] = sum_c W_i[r][c] b_i[c] (W_i: [rows, cols] blocks of the fuse
  * weight, leading dimension ldw; b_i: the linear_c bias), and its gradients: dW_i[r][c] += dout_i[r] b_i[c] (into the block gradient the grouped product wrote,
  * leading dimension lddw; dW may be NULL), db_i[c] (+)= sum_r W_i[r][c] dout_i[r] (db may be NULL). */

@@ -101,6 +101,7 @@ _SIGS = {
     "mdvit_gemm_planes_force_plan": [i32, i32],
     "mdvit_gemm_ph_config": [i32],
     "mdvit_gemm_f32_grouped": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
+    "mdvit_gemm_f32_grouped_bias": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
     "mdvit_transpose_batch": [i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp],
     "mdvit_compose_bias": [i32, C.POINTER(vp), i64, C.POINTER(vp), C.POINTER(vp), i32, i32, vp],
     "mdvit_compose_bias_bwd": [i32, C.POINTER(vp), i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, C.POINTER(vp), i32, i32, i32, vp],

@@ -21,8 +21,8 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 // set by mdvit_gemm_f32_grouped around its call of mdvit_gemm_f32 (same thread): the operand triples of the groups
-struct GemmGroups { int n; const float* A[MDVIT_GEMM_MAX_GROUPS]; const float* B[MDVIT_GEMM_MAX_GROUPS]; float* C[MDVIT_GEMM_MAX_GROUPS]; };
-static thread_local GemmGroups g_groups = {0, {}, {}, {}};
+struct GemmGroups { int n; const float* A[MDVIT_GEMM_MAX_GROUPS]; const float* B[MDVIT_GEMM_MAX_GROUPS]; float* C[MDVIT_GEMM_MAX_GROUPS]; const float* bias[MDVIT_GEMM_MAX_GROUPS]; };
+static thread_local GemmGroups g_groups = {0, {}, {}, {}, {}};
 const GemmGroups* mdvit_gemm_groups_active() { return g_groups.n > 0 ? &g_groups : nullptr; }
 
 namespace {
@@ -52,7 +52,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int conv_c, conv_h, conv_w, conv_ho, conv_wo, conv_stride, conv_dil, conv_up, conv_phase;     // CONV kernels: A is an NHWC image gathered on the fly
     // grouped launch (mdvit_gemm_f32_grouped): blockIdx.z = group; the same problem on ngroups operand triples (no split, plain epilogue, no bias)
-    int ngroups; const float* gA[MDVIT_GEMM_MAX_GROUPS]; const float* gB[MDVIT_GEMM_MAX_GROUPS]; float* gC[MDVIT_GEMM_MAX_GROUPS];
+    int ngroups; const float* gA[MDVIT_GEMM_MAX_GROUPS]; const float* gB[MDVIT_GEMM_MAX_GROUPS]; float* gC[MDVIT_GEMM_MAX_GROUPS]; const float* gBias[MDVIT_GEMM_MAX_GROUPS];
 };
 
 
@@ -324,10 +324,10 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     const GemmPlan pl = plan_gemm(d);
     a.tiles_m = pl.tiles_m; a.tiles_n = pl.tiles_n; a.splits = pl.splits; a.k_per_split = pl.kps;
     if (g_groups.n > 0) {
-        MDVIT_CHECK_ARG(pl.splits == 1 && d->epi == MDVIT_EPI_NONE && !d->bias && !d->residual && !d->rc_a && d->conv_c <= 0 && !(d->e_drop_p > 0.f) && !d->e_rowscale,
-                        MDVIT_E_SHAPE, "gemm (grouped): one K range, plain epilogue, no bias");
+        MDVIT_CHECK_ARG(pl.splits == 1 && d->epi == MDVIT_EPI_NONE && !d->residual && !d->rc_a && d->conv_c <= 0 && !(d->e_drop_p > 0.f) && !d->e_rowscale,
+                        MDVIT_E_SHAPE, "gemm (grouped): one K range, plain epilogue");
         a.ngroups = g_groups.n;
-        for (int g = 0; g < g_groups.n; ++g) { a.gA[g] = g_groups.A[g]; a.gB[g] = g_groups.B[g]; a.gC[g] = g_groups.C[g]; }
+        for (int g = 0; g < g_groups.n; ++g) { a.gA[g] = g_groups.A[g]; a.gB[g] = g_groups.B[g]; a.gC[g] = g_groups.C[g]; a.gBias[g] = g_groups.bias[g]; }
     }
     if (pl.splits > 1) {
         const size_t need = sizeof(float) * (size_t)pl.splits * d->M * d->N;
@@ -588,6 +588,26 @@ extern "C" int mdvit_gemm_f32_grouped(const MdvitGemmDesc* desc, int32_t G, cons
         MDVIT_CHECK_ARG(A[g] && B[g] && C[g] && aligned16(A[g]) && aligned16(B[g]), MDVIT_E_ALIGN, "gemm (grouped): group %d: null or unaligned operand", g);
         MDVIT_CHECK_ARG(aligned16(C[g]) == aligned16(C[0]), MDVIT_E_ALIGN, "gemm (grouped): the outputs must share their 16-byte alignment class");
         g_groups.A[g] = (const float*)A[g]; g_groups.B[g] = (const float*)B[g]; g_groups.C[g] = (float*)C[g];
+    }
+    for (int g = 0; g < G; ++g) g_groups.bias[g] = nullptr;
+    g_groups.n = G;
+    const int rc = mdvit_gemm_f32(&d, stream);
+    g_groups.n = 0;
+    return rc;
+}
+
+// ... with a bias vector per group (NN / NT only: the peer heads' low-resolution 1x1 convolutions, one launch over the G heads)
+extern "C" int mdvit_gemm_f32_grouped_bias(const MdvitGemmDesc* desc, int32_t G, const void* const* A, const void* const* B, void* const* C, const void* const* bias,
+                                           void* stream) {
+    MDVIT_CHECK_ARG(desc != nullptr && G >= 1 && G <= MDVIT_GEMM_MAX_GROUPS && A && B && C && bias, MDVIT_E_SHAPE, "gemm (grouped): 1 <= G <= %d operand triples", MDVIT_GEMM_MAX_GROUPS);
+    MDVIT_CHECK_ARG(!desc->trans_a, MDVIT_E_SHAPE, "gemm (grouped, bias): NN / NT only");
+    MdvitGemmDesc d = *desc;
+    d.allow_split = 0; d.ws = nullptr; d.ws_bytes = 0; d.bias = nullptr;
+    d.A = (const float*)A[0]; d.B = (const float*)B[0]; d.C = (float*)C[0];
+    for (int g = 0; g < G; ++g) {
+        MDVIT_CHECK_ARG(A[g] && B[g] && C[g] && bias[g] && aligned16(A[g]) && aligned16(B[g]) && aligned16(bias[g]), MDVIT_E_ALIGN, "gemm (grouped): group %d: null or unaligned operand", g);
+        MDVIT_CHECK_ARG(aligned16(C[g]) == aligned16(C[0]), MDVIT_E_ALIGN, "gemm (grouped): the outputs must share their 16-byte alignment class");
+        g_groups.A[g] = (const float*)A[g]; g_groups.B[g] = (const float*)B[g]; g_groups.C[g] = (float*)C[g]; g_groups.bias[g] = (const float*)bias[g];
     }
     g_groups.n = G;
     const int rc = mdvit_gemm_f32(&d, stream);

@@ -23,7 +23,7 @@ typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef short v8i16 __attribute__((ext_vector_type(8)));
 
 int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, hipStream_t s);
-struct GemmGroups { int n; const float* A[MDVIT_GEMM_MAX_GROUPS]; const float* B[MDVIT_GEMM_MAX_GROUPS]; float* C[MDVIT_GEMM_MAX_GROUPS]; };
+struct GemmGroups { int n; const float* A[MDVIT_GEMM_MAX_GROUPS]; const float* B[MDVIT_GEMM_MAX_GROUPS]; float* C[MDVIT_GEMM_MAX_GROUPS]; const float* bias[MDVIT_GEMM_MAX_GROUPS]; };
 const GemmGroups* mdvit_gemm_groups_active();       // gemm.hip: the operand triples of a grouped launch in flight on this thread, or NULL
 
 namespace {

@@ -43,6 +43,7 @@ class UnetDecodingBlockTransformer(nn.Module):
 
 
 _COMPOSE_GROUPED = os.environ.get("MDVIT_COMPOSE_GROUPED", "1") != "0"
+_LOWS_GROUPED = os.environ.get("MDVIT_LOWS_GROUPED", "1") != "0"      # A/B: 0 = one launch per head for the low-resolution projections
 _WT_BATCH = os.environ.get("MDVIT_WT_BATCH", "1") != "0"      # A/B: 0 = one transpose per use of a composed weight
 
 
@@ -85,6 +86,24 @@ class MLPDecoderFM(nn.Module):
             ops.transpose_weights_batch([w for g in range(len(heads)) for (w, _) in comp[g]] + [blocks[g][1] for g in range(len(heads))])
         return [(blocks[g][1], comp[g]) for g in range(len(heads))]
 
+    @staticmethod
+    def grouped_lows(composed, feats_per_head):
+        """the low-resolution projections that run on the general GEMM (C_q not in {64, 128}: the streaming short-K Linear keeps the others) for ALL heads in one
+        launch per scale (ops.linear_grouped); returns composed with a third entry per head: {q: projected feature}"""
+        G = len(composed)
+        if G < 2 or not _LOWS_GROUPED or any(c is None for c in composed):
+            return composed
+        h, w = feats_per_head[0][0].shape[1:3]
+        out = [dict() for _ in range(G)]
+        for q in range(4):
+            f0 = feats_per_head[0][q]
+            if (f0.shape[1] == h and f0.shape[2] == w) or f0.shape[-1] in (64, 128) or not f0.is_cuda:
+                continue
+            ys = ops.linear_grouped([feats_per_head[g][q] for g in range(G)], [composed[g][1][q][0] for g in range(G)], [composed[g][1][q][1] for g in range(G)])
+            for g in range(G):
+                out[g][q] = ys[g]
+        return [(composed[g][0], composed[g][1], out[g]) for g in range(G)]
+
     def forward(self, features, img_size, out_feat=False, composed=None):
         if out_feat:
             raise NotImplementedError("out_feat=True of the aux head is unused by the train path")
@@ -93,7 +112,8 @@ class MLPDecoderFM(nn.Module):
         hid = self.hidden
         bias = self.linear_fuse[0].bias
         # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)      (MLPDecoder: no x5 term, bf rides on q = 0)
-        W5, comp = composed if composed is not None else MLPDecoderFM.compose_many([self])[0]
+        W5, comp = (composed if composed is not None else MLPDecoderFM.compose_many([self])[0])[:2]
+        pre = composed[2] if (composed is not None and len(composed) > 2) else {}       # q -> this head's projected feature, computed with the other heads' (grouped_lows)
         acc = ops.linear(features[4], W5, bias) if self.with_fm else None                      # [B,h,w,hid]
         lows = []                                                                              # the projected lower-resolution features
         for q in range(4):
@@ -104,6 +124,8 @@ class MLPDecoderFM(nn.Module):
                 acc = ops.linear(fq, Wc, bc + bias)
             elif fq.shape[1] == h and fq.shape[2] == w:
                 acc = ops.linear(fq, Wc, bc, residual=acc)
+            elif q in pre:
+                lows.append(pre[q])
             else:
                 lows.append(ops.linear(fq, Wc, bc))
         if lows:

@@ -227,6 +227,8 @@ class MDViT(_EncoderDecoder):
         streams = [ops.peer_stream(g, G * parts[0][0].shape[0]) for g in range(G)] if (G > 1 and parts[0][0].is_cuda) else [None] * G
         if any(s is None for s in streams):
             comp = self._compose_peers(ds)             # G x 4 weight compositions: grouped launches, ahead of the heads
+            if self.decoder_name in ("MLPFM", "MLP") and all(c is not None for c in comp):
+                comp = MLPDecoderFM.grouped_lows(comp, [[pf[g] for pf in parts] for g in range(G)])
             return [self._peer_out(dd, [pf[g] for pf in parts], bparts[g], img_size, comp[g]) for g, dd in enumerate(ds)]
         main = torch.cuda.current_stream()
         aux = []

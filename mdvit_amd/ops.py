@@ -1080,6 +1080,73 @@ def gemm_grouped(As, Bs, outs, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b
     call("mdvit_gemm_f32_grouped", C.byref(d), len(As), _vp_array([_p(t) for t in As]), _vp_array([_p(t) for t in Bs]), _vp_array([_p(t) for t in outs]), _stream())
 
 
+def gemm_grouped_bias(As, Bs, outs, biases, M, N, K, *, lda, ldb, ldc, trans_b=True, precision=None):
+    """gemm_grouped with a bias vector per group (NN / NT)"""
+    if precision is None:
+        precision = min(_gemm_precision, 1) if bool(trans_b) else 0
+    d = GemmDesc()
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.M, d.N, d.K = M, N, K
+    d.trans_a, d.trans_b = 0, int(trans_b)
+    d.precision = int(precision)
+    call("mdvit_gemm_f32_grouped_bias", C.byref(d), len(As), _vp_array([_p(t) for t in As]), _vp_array([_p(t) for t in Bs]), _vp_array([_p(t) for t in outs]),
+         _vp_array([_p(t) for t in biases]), _stream())
+
+
+class _LinearGrouped(torch.autograd.Function):
+    """y_g = x_g W_g^T + b_g for G groups (same shapes, own weights: the peer heads' low-resolution 1x1 convolutions) -- forward ONE launch, data gradients ONE launch
+    (blockIdx.z = group, per group the arithmetic of the single launch without a K split); weight / bias gradients per group as in _Linear."""
+
+    @staticmethod
+    def forward(ctx, G, *ts):
+        ctx.set_materialize_grads(False)
+        xs, Ws, bs = ts[:G], ts[G:2 * G], ts[2 * G:]
+        _chk(*xs, *bs)
+        M, K = xs[0].shape
+        N, K2, ldb = _ld_view(Ws[0])
+        assert K == K2 and all(tuple(x.shape) == (M, K) for x in xs) and all(_ld_view(W) == (N, K, ldb) for W in Ws)
+        ys = [_empty((M, N), device=xs[0].device, dtype=torch.float32) for _ in range(G)]
+        gemm_grouped_bias(xs, Ws, ys, bs, M, N, K, lda=K, ldb=ldb, ldc=N, trans_b=True)
+        ctx.save_for_backward(*xs, *Ws)
+        ctx.meta = (G, M, N, K, ldb)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        G, M, N, K, ldb = ctx.meta
+        if all(g is None for g in gs):
+            return (None,) * (1 + 3 * G)
+        sv = ctx.saved_tensors
+        xs, Ws = sv[:G], sv[G:]
+        dev = xs[0].device
+        gs = [_c(g) if g is not None else torch.zeros((M, N), device=dev, dtype=torch.float32) for g in gs]
+        dxs = [None] * G
+        if any(ctx.needs_input_grad[1:1 + G]):
+            dxs = [_empty((M, K), device=dev, dtype=torch.float32) for _ in range(G)]
+            if _gemm_precision:
+                Wts = [wt(W) for W in Ws]           # (held until the launch is enqueued)
+                gemm_grouped(gs, Wts, dxs, M, K, N, lda=N, ldb=N, ldc=K, trans_b=True)
+                del Wts
+            else:
+                gemm_grouped(gs, list(Ws), dxs, M, K, N, lda=N, ldb=ldb, ldc=K, trans_b=False)
+        dWs, dbs = [None] * G, [None] * G
+        if not _dgrad_only:
+            for i in range(G):
+                if ctx.needs_input_grad[1 + G + i] or ctx.needs_input_grad[1 + 2 * G + i]:
+                    dWs[i] = _empty((N, K), device=dev, dtype=torch.float32)
+                    dbs[i] = _zeros_once(N, dev)
+                    gemm(_p(gs[i]), _p(xs[i]), _p(dWs[i]), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, colsum_a=_p(dbs[i]))
+        return (None, *dxs, *dWs, *dbs)
+
+
+def linear_grouped(xs, Ws, bs):
+    """xs[g]: [..., K] (equal shapes), Ws[g]: [N, K], bs[g]: [N]  ->  list of [..., N]"""
+    shp = xs[0].shape
+    x2 = [_c(x).view(-1, shp[-1]) for x in xs]
+    ys = _LinearGrouped.apply(len(xs), *x2, *Ws, *bs)
+    return [y.view(*shp[:-1], Ws[0].shape[0]) for y in ys]
+
+
 class _ComposeHeads(torch.autograd.Function):
     """The weight composition of G peer heads x Q scales as grouped launches (decode.MLPDecoderFM: linear_fuse o cat o resize o linear_q evaluated as
     resize((Wf_q W_q) x_q + Wf_q b_q)):  Wc[g][q] = Wf[g][:, q*hid:(q+1)*hid] @ W[g][q],  bc[g][q] = Wf[g][:, q-block] . b[g][q].
