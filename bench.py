@@ -219,11 +219,15 @@ def _child_json(cmd, timeout):
         return {"error": repr(e)}
 
 
-def _rocprof_avg_us(name):
-    """the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/): the
-    event-timed figure also holds the time a launch waits for CUs that the other streams' kernels occupy, rocprofv3's does not"""
+def _rocprof_avg_us(name, model="mdvit"):
+    """the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of THIS leg's command (profiles/): the
+    event-timed figure also holds the time a launch waits for CUs that the other streams' kernels occupy, rocprofv3's does not.
+    (Round 4: the TransFuse leg used to read the MDViT summary -- the same kernel name over other shapes: its frac_rocprof was not about its launches.)"""
     import csv, glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_bs4_kernel_stats.csv")))
+    pattern = {"mdvit": "r*_bench_bs4_kernel_stats.csv", "transfuse": "r*_transfuse_bs8_kernel_stats.csv"}.get(model)
+    if pattern is None:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return None
     want = name.split("+")[0].replace(" ", "")
@@ -478,19 +482,21 @@ def main():
                     pmc = json.load(f).get("kernels", {})
             except Exception:
                 pass
-            traffic = pmc.get(name.split("+")[0], {}).get("hbm_bytes_per_launch")
+            default_leg = args.model == "mdvit" and args.batch == 4 and args.size == 512        # the command the committed --pmc passes ran
+            traffic = pmc.get(name.split("+")[0], {}).get("hbm_bytes_per_launch") if default_leg else None
             if frac_hbm > frac_mfma:
                 roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
             else:
                 roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak_mfma, 1), "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
             launches = rec.get("launches", rec["n"])
-            rp_us = _rocprof_avg_us(name)
+            rp_us = _rocprof_avg_us(name, args.model) if (args.model != "mdvit" or default_leg) else None
             if rp_us:
                 rp_gbs, rp_tf = rec["bytes"] / rec["n"] / (rp_us * 1e-6) / 1e9, rec["flop"] / rec["n"] / (rp_us * 1e-6) / 1e12
                 roof["frac_rocprof"] = round(rp_gbs / PEAK_HBM_GBS if roof["bound"] == "hbm" else rp_tf / peak_mfma, 4)
                 roof["frac_live"] = roof["frac"]
             roof["traffic_source"] = ("profiles/pmc_traffic.json: HBM bytes per launch of this kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                      "command (FETCH x2, gfx950) -- read from the file, NOT measured in this run")
+                                      "command (FETCH x2, gfx950) -- read from the file, NOT measured in this run") if default_leg else \
+                "none: the committed --pmc passes ran the default MDViT bs=4 command, not this leg"
             roof.update({"traffic": traffic, "launches": launches, "timed_launches": rec["n"], "avg_launch_us": round(secs * 1e6 / rec["n"], 2),
                          "avg_launch_us_raw_events": round(rec["ms"] * 1e3 / rec["n"], 2), "event_pair_overhead_us": round(ovh_ms * 1e3, 2),
                          "timer": rec.get("timer"),
