@@ -111,6 +111,10 @@ typedef struct MdvitGemmDesc {
      * % 4 == 0): the saved hidden activations of the "mixed" mode (MdvitBlockDesc.store_bf16).  It enters the product as its single bf16 plane (two
      * MFMAs per product instead of three); at most one of the two. */
     int32_t a_bf16, b_bf16;
+    /* TN with conv_c > 0 (the weight gradient of a 3x3 convolution): write / accumulate C in the PyTorch layout [M = Cout][conv_c][3][3] (ldc = 9 conv_c) instead of the
+     * tap-major [M][9][conv_c] the product is formed in -- the relayout pass of round 2-3 (one launch and one round trip of the gradient per convolution) folded into the
+     * kernel's / the slab reduction's stores. */
+    int32_t conv_wgrad_nchw;
 } MdvitGemmDesc;
 size_t mdvit_gemm_ws_bytes(const MdvitGemmDesc* desc);
 /* The same plain product (desc: shape, layout, precision of ONE group; its A / B / C, bias, epilogue and allow_split are ignored / must be off) on G <= 8 operand

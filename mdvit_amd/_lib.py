@@ -45,7 +45,7 @@ class GemmDesc(C.Structure):
         ("rc_a", vp), ("rc_lda", i64), ("rc_b", vp), ("rc_ldb", i64), ("rc_bias", vp), ("rc_k", i32),
         ("conv_c", i32), ("conv_h", i32), ("conv_w", i32), ("conv_ho", i32), ("conv_wo", i32), ("conv_stride", i32), ("conv_dilation", i32),
         ("conv_up", i32),
-        ("a_bf16", i32), ("b_bf16", i32),
+        ("a_bf16", i32), ("b_bf16", i32), ("conv_wgrad_nchw", i32),
     ]
 
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3, 8))
 // partial sums are folded by a shuffle tree -- a fixed order for a given shape, so the result is deterministic.
 template <int R>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
-                                                                 float* __restrict__ C, long ldc, int M, int N, int splits, int accumulate) {
+                                                                 float* __restrict__ C, long ldc, int M, int N, int splits, int accumulate, int perm_cin) {
     const int NQ = N >> 2;
     const long total = (long)M * NQ, MN = (long)M * N;
     const int r = threadIdx.x % R;
@@ -139,6 +139,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
         }
         if (r == 0) {
             if (bias) { acc.x += bias[n]; acc.y += bias[n + 1]; acc.z += bias[n + 2]; acc.w += bias[n + 3]; }
+            if (perm_cin > 0) {            // conv weight gradient: column n = (tap, ci) of the tap-major product goes to [ci][tap] of the PyTorch [Cout, Cin, 3, 3] row
+                const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nn = n + j, tap = nn / perm_cin, ci = nn - tap * perm_cin;
+                    float* d1 = C + m * ldc + (long)ci * 9 + tap;
+                    *d1 = accumulate ? *d1 + a4[j] : a4[j];
+                }
+                continue;
+            }
             float* dst = C + m * ldc + n;
             if (accumulate) { acc.x += dst[0]; acc.y += dst[1]; acc.z += dst[2]; acc.w += dst[3]; }
             if (((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) *reinterpret_cast<float4*>(dst) = acc;
@@ -249,11 +259,16 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
 }  // namespace
 
 // the slab reduction as a library-internal entry (gemm_bp.hip's split-K launches share it)
+int mdvit_gemm_splitk_reduce_perm(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, int perm_cin, hipStream_t s);
 int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, hipStream_t s) {
+    return mdvit_gemm_splitk_reduce_perm(slab, bias, C, ldc, M, N, splits, accumulate, 0, s);
+}
+// perm_cin > 0: the columns are (tap, ci) pairs of a 3x3 convolution's weight gradient and land at [ci][tap] (the PyTorch layout) -- the relayout launch folded in
+int mdvit_gemm_splitk_reduce_perm(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, int perm_cin, hipStream_t s) {
     const long total = (long)M * N / 4;
 #define MDVIT_REDUCE_LAUNCH(R_) \
     hipLaunchKernelGGL((gemm_splitk_reduce_kernel<R_>), dim3((int)min((total * R_ + 255) / 256, 4096L)), dim3(256), 0, s, \
-                       slab, bias, C, ldc, M, N, splits, accumulate)
+                       slab, bias, C, ldc, M, N, splits, accumulate, perm_cin)
     if (total >= 65536 || splits < 4) MDVIT_REDUCE_LAUNCH(1);
     else if (total >= 16384 || splits < 16) MDVIT_REDUCE_LAUNCH(4);
     else if (total >= 4096 || splits < 64) MDVIT_REDUCE_LAUNCH(16);
@@ -364,7 +379,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
         const long total = (long)d->M * d->N / 4;
 #define MDVIT_REDUCE_LAUNCH(R_) \
     hipLaunchKernelGGL((gemm_splitk_reduce_kernel<R_>), dim3((int)min((total * R_ + 255) / 256, 4096L)), dim3(256), 0, s, \
-                       a.slab, d->bias, d->C, (long)d->ldc, d->M, d->N, pl.splits, d->accumulate)
+                       a.slab, d->bias, d->C, (long)d->ldc, d->M, d->N, pl.splits, d->accumulate, 0)
         if (total >= 65536 || pl.splits < 4) MDVIT_REDUCE_LAUNCH(1);
         else if (total >= 16384 || pl.splits < 16) MDVIT_REDUCE_LAUNCH(4);
         else if (total >= 4096 || pl.splits < 64) MDVIT_REDUCE_LAUNCH(16);

@@ -22,7 +22,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef short v8i16 __attribute__((ext_vector_type(8)));
 
-int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, hipStream_t s);
+int mdvit_gemm_splitk_reduce_perm(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, int perm_cin, hipStream_t s);
 struct GemmGroups { int n; const float* A[MDVIT_GEMM_MAX_GROUPS]; const float* B[MDVIT_GEMM_MAX_GROUPS]; float* C[MDVIT_GEMM_MAX_GROUPS]; const float* bias[MDVIT_GEMM_MAX_GROUPS]; };
 const GemmGroups* mdvit_gemm_groups_active();       // gemm.hip: the operand triples of a grouped launch in flight on this thread, or NULL
 
@@ -33,7 +33,7 @@ constexpr int BK = 32, NTH = 256;
 struct TnArgs {
     const float* A; const float* B; float* C; float* slab; float* colsum; float* cs_part; const float* bias;
     long lda, ldb, ldc;
-    int M, N, K, kps, splits, tiles_m, tiles_n, accumulate, grid_xcd;
+    int M, N, K, kps, splits, tiles_m, tiles_n, accumulate, grid_xcd, perm_cin;
     int cv_c, cv_h, cv_w, cv_ho, cv_wo, cv_s, cv_d;      // CONVB: B is the NHWC image x, gathered as the im2col matrix [token][tap * C + c]
     int ngroups; const float* gA[MDVIT_GEMM_MAX_GROUPS]; const float* gB[MDVIT_GEMM_MAX_GROUPS]; float* gC[MDVIT_GEMM_MAX_GROUPS];      // grouped launch: blockIdx.z = group
 #ifdef MDVIT_TN_PHASES
@@ -366,6 +366,16 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
                 if (col >= p.N) continue;
                 float4 v = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 if (slab) { *reinterpret_cast<float4*>(slab + (long)row * p.N + col) = v; continue; }
+                if (p.perm_cin > 0) {          // conv weight gradient straight into the [Cout, Cin, 3, 3] layout (see mdvit_gemm_splitk_reduce_perm)
+                    const float a4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const int nn = col + t4, tap = nn / p.perm_cin, ci = nn - tap * p.perm_cin;
+                        float* d1 = gC + (long)row * p.ldc + (long)ci * 9 + tap;
+                        *d1 = p.accumulate ? *d1 + a4[t4] : a4[t4];
+                    }
+                    continue;
+                }
                 float* dst = gC + (long)row * p.ldc + col;
                 if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
                 if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
@@ -462,6 +472,10 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
     a.dbg = g_tn_dbg;
 #endif
     a.grid_xcd = g_tn_grid_xcd == 2 || (g_tn_grid_xcd == 1 && pl.tiles_m * pl.tiles_n <= 8 && pl.splits > 1);
+    if (d->conv_c > 0 && d->conv_wgrad_nchw) {
+        MDVIT_CHECK_ARG(!d->bias && d->N == 9 * d->conv_c, MDVIT_E_SHAPE, "gemm (wgrad): conv_wgrad_nchw needs N == 9 conv_c and no bias");
+        a.perm_cin = d->conv_c;
+    }
     if (d->conv_c > 0) {
         a.cv_c = d->conv_c; a.cv_h = d->conv_h; a.cv_w = d->conv_w; a.cv_ho = d->conv_ho; a.cv_wo = d->conv_wo; a.cv_s = d->conv_stride; a.cv_d = d->conv_dilation;
     }
@@ -502,7 +516,7 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
 #undef MDVIT_TN_LAUNCH
     MDVIT_LAUNCH_CHECK();
     if (pl.splits > 1) {
-        int rc = mdvit_gemm_splitk_reduce(a.slab, d->bias, d->C, d->ldc, d->M, d->N, pl.splits, d->accumulate, s);
+        int rc = mdvit_gemm_splitk_reduce_perm(a.slab, d->bias, d->C, d->ldc, d->M, d->N, pl.splits, d->accumulate, a.perm_cin, s);
         if (rc == MDVIT_OK && d->colsum_a)        // the K-splits' column-sum rows, added in slab order
             rc = mdvit_reduce_partials(a.cs_part, pl.splits, d->M, d->M, d->colsum_a, 0, nullptr, 1, s);
         return rc;

@@ -381,7 +381,7 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias=None, out2=None, epi=_lib.EPI_NONE,
          e_drop=0.0, e_key=(0, 0), e_rowscale=None, e_rows_per_scale=1,
-         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None, rc=None, conv=None):
+         residual=None, ldr=0, gelu_u=None, ldu=0, allow_split=False, accumulate=False, precision=None, colsum_a=None, rc=None, conv=None, conv_wgrad_nchw=False):
     """rc = (a, lda, b, ldb, bias, k): DGELU with the pre-activation recomputed in the kernel (include/mdvit_hip.h).
     conv = (C, H, W, Ho, Wo, stride, dilation): A is the NHWC image, gathered as the implicit im2col operand of a 3x3 convolution."""
     if precision is None:
@@ -407,6 +407,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
     if conv is not None:
         d.conv_c, d.conv_h, d.conv_w, d.conv_ho, d.conv_wo, d.conv_stride, d.conv_dilation = conv[:7]
         d.conv_up = conv[7] if len(conv) > 7 else 0
+        d.conv_wgrad_nchw = int(bool(conv_wgrad_nchw))
     ws = None
     if allow_split:
         need = _lib.load().mdvit_gemm_ws_bytes(C.byref(d))
@@ -1715,20 +1716,18 @@ class _Conv3x3(torch.autograd.Function):
             sunk = sW is not None and (not has_b or sb is not None)
             g2 = g.view(M, Cout)
             cv = (Cin, H, W_, Ho, Wo, stride, dilation)
+            # (round 4: the product's / the slab reduction's stores write the PyTorch layout themselves -- conv_wgrad_nchw -- so the tap-major temporary and
+            #  its relayout launch per convolution are gone)
             if sunk:
                 with _on_side(g, x):
-                    dWt = _empty((Cout, 9 * Cin), device=g.device, dtype=torch.float32)
-                    gemm(_p(g2), _p(x), _p(dWt), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
-                         colsum_a=_p(sb) if has_b else None, conv=cv)
-                    call("mdvit_conv_weight_relayout", _p(dWt), _p(sW), Cout, Cin, 3, _stream())
+                    gemm(_p(g2), _p(x), _p(sW), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True, accumulate=True,
+                         colsum_a=_p(sb) if has_b else None, conv=cv, conv_wgrad_nchw=True)
             else:
-                dWt = _empty((Cout, 9 * Cin), device=g.device, dtype=torch.float32)
                 if has_b and ctx.needs_input_grad[2]:
                     db = torch.zeros((Cout,), device=g.device, dtype=torch.float32)
-                gemm(_p(g2), _p(x), _p(dWt), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
-                     colsum_a=_p(db) if db is not None else None, conv=cv)
                 dW = _empty_like(w)
-                call("mdvit_conv_weight_relayout", _p(dWt), _p(dW), Cout, Cin, 2, _stream())
+                gemm(_p(g2), _p(x), _p(dW), Cout, 9 * Cin, M, lda=Cout, ldb=9 * Cin, ldc=9 * Cin, trans_a=True, trans_b=False, allow_split=True,
+                     colsum_a=_p(db) if db is not None else None, conv=cv, conv_wgrad_nchw=True)
         return dx, dW, db, None, None
 
 
