@@ -666,6 +666,39 @@ def test_grouped_weight_composition_of_the_peer_heads(G):
         assert torch.equal(aWf[0].grad, oWf[2].grad) and all(torch.equal(aW[0][q].grad, oW[2][q].grad) and torch.equal(ab[0][q].grad, ob[2][q].grad) for q in range(4))
 
 
+def test_grouped_linear_equals_one_linear_per_group():
+    """ops.linear_grouped (the peer heads' low-resolution linear_c products of all heads in ONE launch, forward and data gradient) against one ops.linear per group:
+    same values and gradients (fp64 bound), for two of the model's shapes"""
+    from mdvit_amd import ops
+    for (G, B, h, K, N) in [(4, 2, 8, 320, 128), (3, 1, 16, 512, 256)]:
+        xs = [rnd(B, h, h, K, seed=600 + g) for g in range(G)]
+        Ws = [rnd(N, K, seed=610 + g, scale=K ** -0.5) for g in range(G)]
+        bs = [rnd(N, seed=620 + g) for g in range(G)]
+        gs = [rnd(B, h, h, N, seed=630 + g) for g in range(G)]
+
+        def run(grouped, f64=False):
+            dt, dv = (torch.float64, "cpu") if f64 else (torch.float32, dev())
+            x = [t.clone().to(dt).to(dv).requires_grad_(True) for t in xs]
+            W = [t.clone().to(dt).to(dv).requires_grad_(True) for t in Ws]
+            b = [t.clone().to(dt).to(dv).requires_grad_(True) for t in bs]
+            if f64:
+                ys = [F.linear(x[g], W[g], b[g]) for g in range(G)]
+            elif grouped:
+                ys = ops.linear_grouped(x, W, b)
+            else:
+                ys = [ops.linear(x[g], W[g], b[g]) for g in range(G)]
+            sum((ys[g] * gs[g].to(dt).to(dv)).sum() for g in range(G)).backward()
+            return ys, x, W, b
+
+        ref, rx, rW, rb = run(False, True)
+        out, ox, oW, ob = run(True)
+        one, px, pW, pb = run(False)
+        for g in range(G):
+            check(out[g], ref[g], name=f"y[{g}]"); check(ox[g].grad, rx[g].grad, name=f"dx[{g}]")
+            check(oW[g].grad, rW[g].grad, name=f"dW[{g}]"); check(ob[g].grad, rb[g].grad, name=f"db[{g}]")
+            check(out[g], one[g], tol=2e-6, name=f"y[{g}] vs per-group launch"); check(ox[g].grad, px[g].grad, tol=2e-6, name=f"dx[{g}] vs per-group launch")
+
+
 def test_elementwise_dropout_and_global_avg_pool(monkeypatch):
     from mdvit_amd import ops
     x = rnd(3, 11, 13, 64, seed=170).to(dev()).requires_grad_(True)
