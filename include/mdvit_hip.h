@@ -577,6 +577,9 @@ int mdvit_resize_ac_bwd(const float* dy, float* dx, int32_t B, int32_t Hi, int32
 /* element-wise, n elements.  mode 0: y = relu(a + b) (b optional)   1: y = a * b   2: y = a * (b > 0)   3: y = a + b
  * (BasicBlock / DoubleConv / Attention_block add+ReLU: TransFuse.py:598,573; W_g*W_x: :57; their backward) */
 int mdvit_ew(const float* a, const float* b, float* y, int64_t n, int32_t mode, void* stream);
+/* y = (a + b) + c: the sum of the three gradients of a tensor with three consumers (autograd's accumulation at a fan-out, mdvit.py:640-700: every encoder stage's
+ * output feeds the next stage, the decoder's skip path and the peer heads) in one pass. */
+int mdvit_add3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);
 /* y[b, r] = x[b, r] + pe[r] (DeiT_adapt.forward x + pos_embed, DeiT.py:63-65); out[r] = sum_b g[b, r] (its gradient) */
 int mdvit_add_bcast(const float* x, const float* pe, float* y, int32_t B, int64_t R, void* stream);
 int mdvit_sum_batch(const float* g, float* out, int32_t B, int64_t R, void* stream);

@@ -217,6 +217,15 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
         y[e] = r;
     }
 }
+// y = (a + b) + c: the three gradients of a tensor with three consumers (every encoder stage's output: next stage, decoder skip, peer heads) in ONE pass
+// (two passes of ew_kernel mode 3 before: one launch and a third of the bytes fewer; the same two additions in the same order)
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ y, long n4, long n) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const float4 av = reinterpret_cast<const float4*>(a)[e], bv = reinterpret_cast<const float4*>(b)[e], cv = reinterpret_cast<const float4*>(c)[e];
+        reinterpret_cast<float4*>(y)[e] = make_float4((av.x + bv.x) + cv.x, (av.y + bv.y) + cv.y, (av.z + bv.z) + cv.z, (av.w + bv.w) + cv.w);
+    }
+    for (long e = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) y[e] = (a[e] + b[e]) + c[e];
+}
 // y[b, r] = x[b, r] + pe[r]   (positional embedding, broadcast over the batch)
 __global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ y, long R, long n) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) y[e] = x[e] + pe[e % R];
@@ -737,6 +746,13 @@ extern "C" int mdvit_resize_ac_bwd(const float* dy, float* dx, int32_t B, int32_
 extern "C" int mdvit_ew(const float* a, const float* b, float* y, int64_t n, int32_t mode, void* stream) {
     MDVIT_CHECK_ARG(a && y && n > 0 && mode >= 0 && mode <= 3 && (b || mode == 0), MDVIT_E_SHAPE, "ew: bad arguments");
     TF_LAUNCH(ew_kernel, (tf_grid(n)), 256, 0, (hipStream_t)stream, a, b, y, (long)n, mode);
+    return MDVIT_OK;
+}
+extern "C" int mdvit_add3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream) {
+    MDVIT_CHECK_ARG(a && b && c && y && n > 0, MDVIT_E_SHAPE, "add3: bad arguments");
+    const bool vec = aligned16(a) && aligned16(b) && aligned16(c) && aligned16(y);
+    const long n4 = vec ? (long)n / 4 : 0;
+    TF_LAUNCH(add3_kernel, (tf_grid(vec ? (long)n / 4 + 3 : (long)n)), 256, 0, (hipStream_t)stream, a, b, c, y, n4, (long)n);
     return MDVIT_OK;
 }
 extern "C" int mdvit_add_bcast(const float* x, const float* pe, float* y, int32_t B, int64_t R, void* stream) {

@@ -2025,10 +2025,15 @@ class _Fork(torch.autograd.Function):
         if not gs:
             return None, None
         acc = _c(gs[0])
-        for g in gs[1:]:
-            g = _c(g)
+        rest = [_c(g) for g in gs[1:]]
+        while rest:
             out = _empty_like(acc)
-            call("mdvit_ew", _p(acc), _p(g), _p(out), acc.numel(), 3, _stream())          # mode 3: y = a + b
+            if len(rest) >= 2:          # three at a time: (a + b) + c in one pass (the same additions in the same order as two passes)
+                call("mdvit_add3", _p(acc), _p(rest[0]), _p(rest[1]), _p(out), acc.numel(), _stream())
+                rest = rest[2:]
+            else:
+                call("mdvit_ew", _p(acc), _p(rest[0]), _p(out), acc.numel(), 3, _stream())          # mode 3: y = a + b
+                rest = rest[1:]
             acc = out
         return acc, None
 
