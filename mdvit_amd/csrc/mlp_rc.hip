@@ -225,6 +225,13 @@ __device__ __forceinline__ void rc_interleave() {
 }
 
 #define RC_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// The ring barriers.  A slot is re-filled (LDS-DMA, issued right behind a barrier) while other waves may still have ds_reads of that slot QUEUED: the reads
+// were issued before the barrier, but nothing orders an LDS-DMA write behind another wave's pending ds_read, and hipcc sinks the reads' s_waitcnt lgkmcnt
+// below the barrier (to the first MFMA that uses them).  With the LDS pipeline of the CU congested -- a co-resident kernel of another stream issuing LDS
+// atomics, e.g. the depthwise-convolution weight gradients next to the first C = 64 block backward of the sweep -- the DMA overtook the last reads of a phase
+// (the lo-plane rows 32..63 of W1^T in mlp_rc_dgrad_kernel: single waves came out ~1e-3 off, in a few steps out of ten).  So every wave drains ITS LDS reads
+// before it arrives: the barrier then also means "nobody reads the slots that are re-filled behind it".
+#define RC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // forward
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     rc_bf16x8 hh[2], hl[2], gh[2], gl[2];
     prod1(0, ucur);
     {   // phase 0
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(1);
         prod1(1, unext);
         act(0, ucur, hh, hl);
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     for (int t = 1; t + 1 < n; ++t) {
         RC_WAIT_VM(PPW);
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(t + 1);
         prod1(t + 1, unext);
         prod2(t - 1, hh, hl);
@@ -358,12 +365,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     {   // phase n - 1
         RC_WAIT_VM(PPW);
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         prod2(n - 2, hh, hl);
         act(n - 1, ucur, hh, hl);
     }
     RC_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
+    RC_BARRIER();
     prod2(n - 1, hh, hl);
 
     // epilogue: + b2, dropout, DropPath scale, + residual (operands requested together)
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     for (int t = 0; t < n; ++t) {
         if (STORE && t > 0) RC_WAIT_VM(PPW + 4);       // group t landed (younger: group t + 1 and the four h stores of step t - 1)
         else RC_WAIT_VM(PPW);                          // group t landed (group t + 1 may still be in flight)
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(t + 2);                            // into the slot step t - 1 read
         const int slot = t % 3;
         const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     auto phase = [&](int t, rc_f32x16& ucur, rc_f32x16& dcur, rc_f32x16& unext, rc_f32x16& dnext, const rc_bf16x8 (&ph)[2], const rc_bf16x8 (&pl)[2],
                      rc_bf16x8 (&oh)[2], rc_bf16x8 (&ol)[2]) __attribute__((always_inline)) {
         RC_WAIT_VM(PPW);
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(t + 1);
         prod1(t + 1, unext, dnext);
         prod3(t - 1, ph, pl);
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     };
     prod1(0, uA, dA);
     {
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(1);
         prod1(1, uB, dB);
         act(0, uA, dA, dh, dl);
@@ -665,12 +672,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     {
         RC_WAIT_VM(PPW);
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         prod3(n - 2, dh, dl);
         act(n - 1, uB, dB, eh, el);
     }
     RC_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
+    RC_BARRIER();
     prod3(n - 1, eh, el);
 
     if (row < p.M) {
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     for (int t = 0; t < n; ++t) {
         if (STORE && t > 0) RC_WAIT_VM(PPW + 2);      // (younger than group t: group t + 1 and the two h stores of step t - 1)
         else RC_WAIT_VM(PPW);
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(t + 2);
         const int slot = t % 3;
         const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         // t + 1 and (STORE) the two du stores of step t - 1
         if (STORE && t > 0) RC_WAIT_VM(PPW + 2);
         else RC_WAIT_VM(PPW);
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(t + 2);
         const int slot = t % 3;
         const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
@@ -1303,7 +1310,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 4)))
         // four stores of step t - 1 and the four residual loads just requested
         if (t == 0) RC_WAIT_VM(PPW + (FULL ? 4 : 0));
         else RC_WAIT_VM(PPW + 4 + (FULL ? 4 : 0));
-        __builtin_amdgcn_s_barrier();
+        RC_BARRIER();
         issue_group(t + 2);
         const char* hi = sW + ((t % 3) * 2) * T1; const char* lo = hi + T1;
         rc_f32x16 u;
