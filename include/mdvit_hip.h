@@ -580,6 +580,9 @@ int mdvit_ew(const float* a, const float* b, float* y, int64_t n, int32_t mode, 
 /* y = (a + b) + c: the sum of the three gradients of a tensor with three consumers (autograd's accumulation at a fan-out, mdvit.py:640-700: every encoder stage's
  * output feeds the next stage, the decoder's skip path and the peer heads) in one pass. */
 int mdvit_add3(const float* a, const float* b, const float* c, float* y, int64_t n, void* stream);
+/* ... where the third gradient arrives as G <= 8 equal consecutive parts (one per peer head: multi_train_MDViT.py:137-153 runs one forward per domain, the domain-batched
+ * forward hands each head its batch group): y = (a + b) + concat(parts), the concatenation never written; b may be NULL. */
+int mdvit_add_parts(const float* a, const float* b, const void* const* parts, int32_t G, int64_t part_elems, float* y, void* stream);
 /* y[b, r] = x[b, r] + pe[r] (DeiT_adapt.forward x + pos_embed, DeiT.py:63-65); out[r] = sum_b g[b, r] (its gradient) */
 int mdvit_add_bcast(const float* x, const float* pe, float* y, int32_t B, int64_t R, void* stream);
 int mdvit_sum_batch(const float* g, float* out, int32_t B, int64_t R, void* stream);

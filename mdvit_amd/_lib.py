@@ -128,6 +128,7 @@ _SIGS = {
     "mdvit_resize_ac_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_ew": [vp, vp, vp, i64, i32, vp],
     "mdvit_add3": [vp, vp, vp, vp, i64, vp],
+    "mdvit_add_parts": [vp, vp, C.POINTER(vp), i32, i64, vp, vp],
     "mdvit_add_bcast": [vp, vp, vp, i32, i64, vp],
     "mdvit_sum_batch": [vp, vp, i32, i64, vp],
     "mdvit_gate_fwd": [vp, vp, vp, i32, i64, i32, i32, vp],

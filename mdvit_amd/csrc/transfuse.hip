@@ -226,6 +226,23 @@ __global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, 
     }
     for (long e = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) y[e] = (a[e] + b[e]) + c[e];
 }
+// y = (a + b) + [p_0 | p_1 | ...]: the same fan-in where the third gradient arrives as G equal row-range parts (the peer heads' gradients of one encoder feature): the
+// concatenation of the parts is never written (b may be null: y = a + parts).  Static-index select of the part pointer (no scratch).
+struct AddPartsArgs { const float* p[8]; };
+__global__ __launch_bounds__(256) void add_parts_kernel(const float* __restrict__ a, const float* __restrict__ b, AddPartsArgs parts, float* __restrict__ y, long part4, long n4) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(e / part4);
+        const long o = e - (long)g * part4;
+        const float* pp = parts.p[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (g == i) pp = parts.p[i];
+        const float4 av = reinterpret_cast<const float4*>(a)[e], cv = reinterpret_cast<const float4*>(pp)[o];
+        float4 r = av;
+        if (b) { const float4 bv = reinterpret_cast<const float4*>(b)[e]; r = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w); }
+        reinterpret_cast<float4*>(y)[e] = make_float4(r.x + cv.x, r.y + cv.y, r.z + cv.z, r.w + cv.w);
+    }
+}
 // y[b, r] = x[b, r] + pe[r]   (positional embedding, broadcast over the batch)
 __global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ y, long R, long n) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) y[e] = x[e] + pe[e % R];
@@ -753,6 +770,15 @@ extern "C" int mdvit_add3(const float* a, const float* b, const float* c, float*
     const bool vec = aligned16(a) && aligned16(b) && aligned16(c) && aligned16(y);
     const long n4 = vec ? (long)n / 4 : 0;
     TF_LAUNCH(add3_kernel, (tf_grid(vec ? (long)n / 4 + 3 : (long)n)), 256, 0, (hipStream_t)stream, a, b, c, y, n4, (long)n);
+    return MDVIT_OK;
+}
+extern "C" int mdvit_add_parts(const float* a, const float* b, const void* const* parts, int32_t G, int64_t part_elems, float* y, void* stream) {
+    MDVIT_CHECK_ARG(a && parts && y && G >= 1 && G <= 8 && part_elems > 0 && part_elems % 4 == 0, MDVIT_E_SHAPE, "add_parts: 1 <= G <= 8 parts of a multiple of 4 elements");
+    MDVIT_CHECK_ARG(aligned16(a) && (!b || aligned16(b)) && aligned16(y), MDVIT_E_ALIGN, "add_parts: operands must be 16-byte aligned");
+    AddPartsArgs pa; memset(&pa, 0, sizeof(pa));
+    for (int g = 0; g < G; ++g) { MDVIT_CHECK_ARG(parts[g] && aligned16(parts[g]), MDVIT_E_ALIGN, "add_parts: part %d null or unaligned", g); pa.p[g] = (const float*)parts[g]; }
+    const long part4 = (long)part_elems / 4, n4 = part4 * G;
+    TF_LAUNCH(add_parts_kernel, (tf_grid(n4)), 256, 0, (hipStream_t)stream, a, b, pa, y, part4, n4);
     return MDVIT_OK;
 }
 extern "C" int mdvit_add_bcast(const float* x, const float* pe, float* y, int32_t B, int64_t R, void* stream) {

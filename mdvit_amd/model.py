@@ -10,6 +10,7 @@ Inputs NCHW fp32 on the GPU; outputs (B,1,H,W) fp32 logits.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -20,6 +21,8 @@ from ._lib import ACT_RELU
 from .blocks import (droppath_pool, dsn_domain, BatchNormAct, Conv2d_BN, ConvParams, DWCPatchEmbed, MHSA_stage_adapt, _NoParams, _check_norm,
                      init_weights_)
 from .decode import DeepLabV3Decoder, MLPDecoder, MLPDecoderFM, UnetDecodingBlockTransformer
+
+_FORK_GROUPS = os.environ.get("MDVIT_FORK_GROUPS", "1") != "0"      # the peer heads' feature copies as batch-group views of the fork itself (0: fork + split_groups, A/B)
 
 
 class _EncoderDecoder(nn.Module):
@@ -72,16 +75,18 @@ class _EncoderDecoder(nn.Module):
         self.decoder4 = UnetDecodingBlockTransformer(E[1], E[0], self.mhsa_list[0], conv_norm=conv_norm, dsn=dsn)
         self.finalconv = nn.Sequential(ConvParams(1, E[0], 1, 1))
 
-    def _trunk(self, x, domain_label, groups: int = 1):
+    def _trunk(self, x, domain_label, groups: int = 1, split_for_heads: bool = False):
         """x NCHW image -> (logits (B,1,H,W), encoder_outs NHWC list, decoder4 output NHWC, image size, bridge output NHWC).
         groups > 1: x is `groups` equal consecutive domain batches; BatchNorm statistics stay per domain batch."""
         blocks = [blk for st in list(self.mhsa_stages) + list(self.mhsa_list) for blk in st.mhca_blks]
         keep = 1.0 - blocks[0].drop_path_p
         uniform = all(blk.drop_path_p == blocks[0].drop_path_p for blk in blocks)
         with ops.bn_groups(groups), droppath_pool(len(blocks), x.shape[0], keep, x.device, enabled=self.training and uniform):
-            return self._trunk_impl(x, domain_label)
+            return self._trunk_impl(x, domain_label, groups if split_for_heads else 1)
 
-    def _trunk_impl(self, x, domain_label):
+    def _trunk_impl(self, x, domain_label, head_groups: int = 1):
+        """head_groups > 1: the peer-head copies of the stage outputs / the decoder output come back as tuples of `head_groups` batch-group views whose gradients
+        are summed with the trunk's in one pass (ops.fork_groups), not as whole tensors"""
         if x.dim() != 4:
             raise ValueError("expected a (B,C,H,W) image batch")
         B, _, Hi, Wi = x.shape
@@ -93,7 +98,10 @@ class _EncoderDecoder(nn.Module):
             if idx == 0 and self._has_aux_first:
                 x = ops.aux_stop(x)          # the aux (data-gradient-only) sweep ends at the first adapter: the stem / patch embed carry none
             x = self.mhsa_stages[idx](x.view(B, H * W, Cn), H, W, domain_label).view(B, H, W, Cn)
-            x, s_, e_ = ops.fork(x, 3)
+            if head_groups > 1:
+                x, s_, e_ = ops.fork_groups(x, 2, head_groups)
+            else:
+                x, s_, e_ = ops.fork(x, 3)
             skip.append(s_); enc.append(e_)
         if self._dsn:
             from .blocks import _bank_select
@@ -112,8 +120,11 @@ class _EncoderDecoder(nn.Module):
         out = self.decoder2(out, skip[2], domain_label)
         out = self.decoder3(out, skip[1], domain_label)
         out = self.decoder4(out, skip[0], domain_label)
-        out, dec4 = ops.fork(out, 2)                     # the final 1x1 conv and the peer heads' fifth feature
-        _, h, w, _ = dec4.shape
+        if head_groups > 1:
+            out, dec4 = ops.fork_groups(out, 1, head_groups)
+        else:
+            out, dec4 = ops.fork(out, 2)                 # the final 1x1 conv and the peer heads' fifth feature
+        _, h, w, _ = out.shape
         low = ops.rowdot(out, self.finalconv[0].weight, self.finalconv[0].bias)          # 1x1 conv (1 channel) at H/4
         logits = ops.upsample_bilinear(low.view(B, h, w, 1), Hi, Wi).view(B, 1, Hi, Wi)
         return logits, enc, dec4, (Hi, Wi), bridge_out
@@ -251,15 +262,17 @@ class MDViT(_EncoderDecoder):
         G = len(ds)
         if x.shape[0] % G:
             raise ValueError(f"batch {x.shape[0]} is not {G} equal domain batches")
-        logits, enc, dec4, img_size, bridge_out = self._trunk(x, domain_label, groups=G)
         if not out_seg:
+            logits, enc, dec4, img_size, bridge_out = self._trunk(x, domain_label, groups=G)
             return {"seg": None, "feat": self._pooled_feat(enc[3])}
-        parts = [ops.split_groups(f, G) for f in enc + [dec4]]          # per feature: G batch views
+        logits, enc, dec4, img_size, bridge_out = self._trunk(x, domain_label, groups=G, split_for_heads=G > 1 and _FORK_GROUPS)
+        parts = [f if isinstance(f, tuple) else ops.split_groups(f, G) for f in enc + [dec4]]          # per feature: G batch views
         bparts = ops.split_groups(bridge_out, G) if self.decoder_name == "Transformer" else [None] * G
         aux = self._peer_heads(ds, parts, bparts, img_size)
         aux_out = None if any(a is None for a in aux) else torch.cat(aux, 0)
         if out_feat:
-            return {"seg": [logits, aux_out], "feat": self._pooled_feat(enc[3])}
+            e3 = enc[3] if not isinstance(enc[3], tuple) else torch.cat([t.detach() for t in enc[3]], 0)
+            return {"seg": [logits, aux_out], "feat": self._pooled_feat(e3)}
         return [logits, aux_out]
 
 

@@ -2038,6 +2038,51 @@ class _Fork(torch.autograd.Function):
         return acc, None
 
 
+class _ForkGroups(torch.autograd.Function):
+    """x -> n full aliases + G equal batch-group views (the peer heads' inputs); the backward adds the n full gradients and the G part gradients in ONE pass
+    (_Fork + _SplitGroups paid a concatenation of the parts and one or two additions)."""
+
+    @staticmethod
+    def forward(ctx, x, n, G):
+        ctx.set_materialize_grads(False)
+        ctx.meta = (n, G, tuple(x.shape))
+        return tuple(x.view_as(x) for _ in range(n)) + tuple(x.view((G, x.shape[0] // G) + tuple(x.shape[1:])).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, G, shape = ctx.meta
+        full = [_c(g) for g in gs[:n] if g is not None]
+        parts = gs[n:]
+        if all(p is None for p in parts):
+            parts = None
+        elif any(p is None for p in parts) or len(full) == 0 or len(full) > 2 or parts[0].numel() % 4:
+            ref = next(p for p in parts if p is not None)          # unusual: fall back to a materialised concatenation
+            full.append(torch.cat([p if p is not None else torch.zeros_like(ref) for p in parts], 0).view(shape))
+            parts = None
+        if parts is None:
+            if not full:
+                return None, None, None
+            acc = full[0]
+            for g in full[1:]:
+                out = _empty_like(acc)
+                call("mdvit_ew", _p(acc), _p(g), _p(out), acc.numel(), 3, _stream())
+                acc = out
+            return acc, None, None
+        parts = [_c(p) for p in parts]
+        out = _empty_like(full[0])
+        call("mdvit_add_parts", _p(full[0]), _p(full[1]) if len(full) > 1 else None, _vp_array([_p(p) for p in parts]), G, parts[0].numel(), _p(out), _stream())
+        return out, None, None
+
+
+def fork_groups(x, n: int, G: int):
+    """n aliases of x + its G batch-group views (see _ForkGroups); -> (aliases..., parts tuple)"""
+    if not x.requires_grad or G <= 1:
+        al = fork(x, n)
+        return tuple(al) + (split_groups(x, G),)
+    out = _ForkGroups.apply(_c(x), int(n), int(G))
+    return tuple(out[:n]) + (tuple(out[n:]),)
+
+
 def fork(x, n: int):
     """n aliases of x, one per consumer (see _Fork)"""
     return _Fork.apply(x, int(n)) if (n > 1 and x.requires_grad) else (x,) * n

@@ -666,6 +666,31 @@ def test_grouped_weight_composition_of_the_peer_heads(G):
         assert torch.equal(aWf[0].grad, oWf[2].grad) and all(torch.equal(aW[0][q].grad, oW[2][q].grad) and torch.equal(ab[0][q].grad, ob[2][q].grad) for q in range(4))
 
 
+@pytest.mark.parametrize("n,G", [(2, 4), (1, 4), (2, 2)])
+def test_fork_with_batch_group_views_sums_every_consumer_gradient_in_one_pass(n, G):
+    """ops.fork_groups(x, n, G): n aliases + G batch-group views of x (the peer heads' inputs of the domain-batched forward); the backward is the sum of the n
+    full gradients and the concatenation of the G part gradients (mdvit_add_parts) == autograd's own accumulation over aliases and torch.chunk, bit for bit
+    ((a + b) + part in that order)."""
+    from mdvit_amd import ops
+    torch.manual_seed(n * 10 + G)
+    x = torch.randn(8, 6, 6, 32, device=dev(), requires_grad=True)
+    ws = [torch.randn_like(x) for _ in range(n)] + [torch.randn(8 // G, 6, 6, 32, device=dev()) for _ in range(G)]
+    outs = ops.fork_groups(x, n, G)
+    full, parts = outs[:n], outs[n]
+    assert len(parts) == G and all(torch.equal(p, c) for p, c in zip(parts, x.detach().chunk(G, 0)))
+    loss = sum((a * w).sum() for a, w in zip(full, ws[:n])) + sum((p * w).sum() for p, w in zip(parts, ws[n:]))
+    (got,) = torch.autograd.grad(loss, x)
+    want = ws[0] if n == 1 else ws[0] + ws[1]
+    want = want + torch.cat(ws[n:], 0)
+    assert torch.equal(got, want)
+    # a part that no consumer used: the materialised path
+    outs = ops.fork_groups(x, n, G)
+    loss = sum((a * w).sum() for a, w in zip(outs[:n], ws[:n])) + (outs[n][0] * ws[n]).sum()
+    (got,) = torch.autograd.grad(loss, x)
+    want = (ws[0] if n == 1 else ws[0] + ws[1]) + torch.cat([ws[n]] + [torch.zeros_like(ws[n])] * (G - 1), 0)
+    assert torch.allclose(got, want, rtol=0, atol=1e-6)
+
+
 def test_grouped_linear_equals_one_linear_per_group():
     """ops.linear_grouped (the peer heads' low-resolution linear_c products of all heads in ONE launch, forward and data gradient) against one ops.linear per group:
     same values and gradients (fp64 bound), for two of the model's shapes"""
