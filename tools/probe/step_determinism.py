@@ -1,7 +1,7 @@
 """Run-to-run reproducibility of the exact bench step (4 domains x bs=4, 512 x 512, one fused forward, merged sweeps, weight gradients on the side stream into
 the bucket sinks): RUNS fresh models from the same seed, the same batches; per run the largest relative L2 difference of any gradient tensor against the run
 most others agree with, and the names of the tensors past 1e-4.
-    python tools/probe/step_determinism.py [RUNS=10] [TWO_STREAM_SWEEPS=0|1]
+    python tools/probe/step_determinism.py [RUNS=10] [TWO_STREAM_SWEEPS=0|1] [bs4|bs32|transfuse]
 What differs legitimately: ~4e-7 (LDS float atomics in the attention partial sums / depthwise-convolution weight gradients add in arrival order).
 Round 4 found 1e-3 .. 6e-3 on all 46 tensors below the last stage-0 block's MLP in about every second run: an LDS-DMA write overtaking another wave's queued
 ds_read in mlp_rc.hip's weight rings (see RC_BARRIER there) whenever the first C = 64 block backward ran next to LDS-atomic kernels of the side stream."""
@@ -16,21 +16,50 @@ def rel(a, b):
     return float((a.double() - b.double()).norm()) / max(float(b.double().norm()), 1e-30)
 
 
+def transfuse_runs(runs):
+    """bench.py --model transfuse --batch 8: the 32-image domain-batched step, buckets + side stream"""
+    import tests.test_gpu_transfuse as TT
+    from mdvit_amd import ops
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.transfuse import transfuse_train_step
+    from oracle.gen_golden import synth_image, synth_label
+    batches = [(synth_image(5200 + d, 8, 256, 256).to(T.dev()), synth_label(5300 + d, 8, 256, 256).to(T.dev()), torch.full((8,), d, dtype=torch.long)) for d in range(4)]
+    res = []
+    for _ in range(runs):
+        m, _unused = TT._build(11)
+        m.train()
+        acc = GradAccumulator(m.parameters()); acc.attach_sinks(); ops.enable_side_stream(True)
+        try:
+            transfuse_train_step(m, batches, accumulator=acc, fuse_domains=True)
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            res.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            ops.enable_side_stream(False); ops.set_grad_sinks(None)
+        del m, acc
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     two = len(sys.argv) > 2 and sys.argv[2] == "1"
-    batches = make_step_batches(4, 512, rank=0, step=0, device=T.dev())
+    what = sys.argv[3] if len(sys.argv) > 3 else "bs4"          # bs4 | bs32 | transfuse   (MDVIT_GEMM_PRECISION=bf16 in the environment: the speed mode)
     train._two_stream_sweeps = two
-    res = []
-    for _ in range(runs):
-        m = T.build_mdvit(23, 512).train()
-        res.append(T._bench_step(m, batches, 4, True)[1])
-        del m
-        torch.cuda.empty_cache()
+    if what == "transfuse":
+        res = transfuse_runs(runs)
+    else:
+        batches = make_step_batches(32 if what == "bs32" else 4, 512, rank=0, step=0, device=T.dev())
+        res = []
+        for _ in range(runs):
+            m = T.build_mdvit(23, 512).train()
+            res.append(T._bench_step(m, batches, 4, True)[1])
+            del m
+            torch.cuda.empty_cache()
     names = list(res[0])
     agree = [sum(1 for j in range(runs) if j != i and max(rel(res[i][n], res[j][n]) for n in names) < 1e-4) for i in range(runs)]
     ref = max(range(runs), key=lambda i: agree[i])
-    print(f"two-stream sweeps {two}: runs agreeing with each run {agree}; reference run {ref}", flush=True)
+    print(f"{what}, two-stream sweeps {two}: runs agreeing with each run {agree}; reference run {ref}", flush=True)
     bad = 0
     for i in range(runs):
         if i == ref:
