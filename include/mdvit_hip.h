@@ -539,6 +539,17 @@ int mdvit_seg_losses_sums(const float* out, const float* aux, const float* label
 int mdvit_seg_losses_final(const double* sums, float* losses, int64_t n_total, int32_t has_aux, void* stream);
 int mdvit_seg_losses_bwd(const float* out, const float* aux, const float* label, const double* sums, const float* g,
                          float* dout, float* daux, int64_t n, float dice_gain, void* stream);
+/* the same with the three upstream gradients (d total / d loss_out, d loss_aux, d loss_kt: 0-dim device tensors as autograd hands them) as separate pointers, NULL = that loss
+ * takes no part in this sweep (the aux sweep of multi_train_MDViT.py:198-207 back-propagates loss_aux + kt only): no host-side stacking of the three into one buffer */
+int mdvit_seg_losses_bwd3(const float* out, const float* aux, const float* label, const double* sums, const float* g0, const float* g1, const float* g2,
+                          float* dout, float* daux, int64_t n, float dice_gain, void* stream);
+/* The G domain batches of ONE domain-batched forward (multi_train_MDViT.py:137-169 computes the three losses per domain and adds them up): out / aux / label hold G consecutive
+ * batches of n elements; sums [G][16]; losses [3] = the per-batch losses added in batch order (fp32, as the step's own additions were), per_group [G][3] optional.  Data parallel:
+ * _groups_sums on the local elements, all-reduce the G x 16 doubles, _groups_final with n_total = n * world; in _groups_bwd n stays the local count per batch (see above). */
+int mdvit_seg_losses_groups_sums(const float* out, const float* aux, const float* label, double* sums, int64_t n, int32_t G, void* stream);
+int mdvit_seg_losses_groups_final(const double* sums, float* losses, float* per_group, int64_t n_total, int32_t has_aux, int32_t G, void* stream);
+int mdvit_seg_losses_groups_bwd(const float* out, const float* aux, const float* label, const double* sums, const float* g0, const float* g1, const float* g2,
+                                float* dout, float* daux, int64_t n, int32_t G, float dice_gain, void* stream);
 
 /* ---- on-device metrics and input pipeline --------------------------------------------------------------
  * Dice / IoU of the thresholded outputs, multi_train_MDViT.py:172-179,275-288 (medpy.metric.binary dc / jc, v0.4.0:

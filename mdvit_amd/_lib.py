@@ -206,6 +206,10 @@ _SIGS = {
     "mdvit_seg_losses_sums": [vp, vp, vp, vp, i64, vp],
     "mdvit_seg_losses_final": [vp, vp, i64, i32, vp],
     "mdvit_seg_losses_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, f32, vp],
+    "mdvit_seg_losses_bwd3": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, vp],
+    "mdvit_seg_losses_groups_sums": [vp, vp, vp, vp, i64, i32, vp],
+    "mdvit_seg_losses_groups_final": [vp, vp, vp, i64, i32, i32, vp],
+    "mdvit_seg_losses_groups_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
 }
 
 _lib = None

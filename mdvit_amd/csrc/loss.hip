@@ -14,6 +14,9 @@ __device__ __forceinline__ float bce_term(float p, float y) {
 
 __global__ __launch_bounds__(256) void seg_losses_sums_kernel(const float* __restrict__ out, const float* __restrict__ aux,
                                                               const float* __restrict__ label, double* __restrict__ sums, long n) {
+    // blockIdx.y = domain batch of a domain-batched forward: n elements each, 16 sums each
+    out += (long)blockIdx.y * n; label += (long)blockIdx.y * n; sums += 16 * blockIdx.y;
+    if (aux) aux += (long)blockIdx.y * n;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float y = label[i], o = sigmoid_f(out[i]);
@@ -42,13 +45,38 @@ __global__ void seg_losses_final_kernel(const double* __restrict__ sums, float* 
     }
 }
 
+// G domain batches: per-batch losses (per_group [G][3], optional) and their sums in batch order -- ((l_0 + l_1) + l_2) + ... in fp32, what the step's own
+// additions of the per-domain losses produced
+__global__ void seg_losses_groups_final_kernel(const double* __restrict__ sums, float* __restrict__ losses, float* __restrict__ per_group, long n, int has_aux, int G) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double eps = 1e-5, N = (double)n;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const double* s = sums + 16 * g;
+            const float l0 = (float)(s[0] / N + 1.0 - (2.0 * s[1] + eps) / (s[2] + s[3] + eps));
+            float l1 = 0.f, l2 = 0.f;
+            if (has_aux) {
+                l1 = (float)(s[4] / N + 1.0 - (2.0 * s[5] + eps) / (s[6] + s[3] + eps));
+                l2 = (float)(1.0 - (2.0 * s[7] + eps) / (s[6] + s[2] + eps));
+            }
+            if (per_group) { per_group[3 * g] = l0; per_group[3 * g + 1] = l1; per_group[3 * g + 2] = l2; }
+            t0 = g ? t0 + l0 : l0; t1 = g ? t1 + l1 : l1; t2 = g ? t2 + l2 : l2;
+        }
+        losses[0] = t0; losses[1] = t1; losses[2] = t2;
+    }
+}
+
 // d/ds Dice(s,t) = -(2 t D - (2I+eps) 2 s) / D^2,  D = sum s^2 + sum t^2 + eps
 __global__ __launch_bounds__(256) void seg_losses_bwd_kernel(const float* __restrict__ out, const float* __restrict__ aux,
                                                              const float* __restrict__ label, const double* __restrict__ sums,
-                                                             const float* __restrict__ g, float* __restrict__ dout, float* __restrict__ daux, long n,
-                                                             float dice_gain) {
+                                                             const float* __restrict__ gp0, const float* __restrict__ gp1, const float* __restrict__ gp2,
+                                                             float* __restrict__ dout, float* __restrict__ daux, long n, float dice_gain) {
+    out += (long)blockIdx.y * n; label += (long)blockIdx.y * n; sums += 16 * blockIdx.y;      // blockIdx.y = domain batch (see the sums kernel)
+    if (aux) aux += (long)blockIdx.y * n;
+    if (dout) dout += (long)blockIdx.y * n;
+    if (daux) daux += (long)blockIdx.y * n;
     const float eps = 1e-5f, invN = 1.0f / (float)n;
-    const float g0 = g[0], g1 = g[1], g2 = g[2] * dice_gain;
+    const float g0 = gp0 ? gp0[0] : 0.f, g1 = gp1 ? gp1[0] : 0.f, g2 = (gp2 ? gp2[0] : 0.f) * dice_gain;      // a NULL upstream gradient: that loss takes no part in this sweep
     const float D_o = (float)(sums[2] + sums[3]) + eps, I_o = 2.f * (float)sums[1] + eps;
     const float D_a = (float)(sums[6] + sums[3]) + eps, I_a = 2.f * (float)sums[5] + eps;
     const float D_k = (float)(sums[6] + sums[2]) + eps, I_k = 2.f * (float)sums[7] + eps;
@@ -184,7 +212,43 @@ extern "C" int mdvit_seg_losses_bwd(const float* out, const float* aux, const fl
                                     float* dout, float* daux, int64_t n, float dice_gain, void* stream) {
     MDVIT_CHECK_ARG(out && label && sums && g && n > 0, MDVIT_E_SHAPE, "seg_losses_bwd: bad arguments");
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, aux, label, sums, g, dout, daux, (long)n, dice_gain);
+    hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, aux, label, sums, g, g + 1, g + 2, dout, daux, (long)n, dice_gain);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_seg_losses_bwd3(const float* out, const float* aux, const float* label, const double* sums, const float* g0, const float* g1, const float* g2,
+                                     float* dout, float* daux, int64_t n, float dice_gain, void* stream) {
+    MDVIT_CHECK_ARG(out && label && sums && (g0 || g1 || g2) && n > 0, MDVIT_E_SHAPE, "seg_losses_bwd3: bad arguments");
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, aux, label, sums, g0, g1, g2, dout, daux, (long)n, dice_gain);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+/* The G domain batches of a domain-batched forward in one launch each way: out / aux / label hold G consecutive batches of n elements, sums [G][16]. */
+extern "C" int mdvit_seg_losses_groups_sums(const float* out, const float* aux, const float* label, double* sums, int64_t n, int32_t G, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MDVIT_CHECK_ARG(out && label && sums && n > 0 && G > 0 && G <= 64, MDVIT_E_SHAPE, "seg_losses_groups_sums: bad arguments (n=%ld G=%d)", (long)n, G);
+    MDVIT_ZERO(sums, sizeof(double) * 16 * G, s);
+    const int grid = (int)((n + 256L * 8 - 1) / (256L * 8) < 1024 ? (n + 256L * 8 - 1) / (256L * 8) : 1024);
+    hipLaunchKernelGGL(seg_losses_sums_kernel, dim3(grid, G), dim3(256), 0, s, out, aux, label, sums, (long)n);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_seg_losses_groups_final(const double* sums, float* losses, float* per_group, int64_t n_total, int32_t has_aux, int32_t G, void* stream) {
+    MDVIT_CHECK_ARG(sums && losses && n_total > 0 && G > 0 && G <= 64, MDVIT_E_SHAPE, "seg_losses_groups_final: bad arguments");
+    hipLaunchKernelGGL(seg_losses_groups_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, losses, per_group, (long)n_total, has_aux, G);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_seg_losses_groups_bwd(const float* out, const float* aux, const float* label, const double* sums, const float* g0, const float* g1, const float* g2,
+                                           float* dout, float* daux, int64_t n, int32_t G, float dice_gain, void* stream) {
+    MDVIT_CHECK_ARG(out && label && sums && (g0 || g1 || g2) && n > 0 && G > 0 && G <= 64, MDVIT_E_SHAPE, "seg_losses_groups_bwd: bad arguments");
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(grid, G), dim3(256), 0, (hipStream_t)stream, out, aux, label, sums, g0, g1, g2, dout, daux, (long)n, dice_gain);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

@@ -2691,28 +2691,64 @@ class _SegLosses(torch.autograd.Function):
         ctx.dice_gain = float(world)
         ctx.save_for_backward(out, aux, label, sums)
         ctx.set_materialize_grads(False)
-        return losses[0].clone(), losses[1].clone(), losses[2].clone()
+        return losses[0], losses[1], losses[2]          # (three views of one fresh buffer: nothing writes them in place; the clones were three copy launches per domain)
 
     @staticmethod
     def backward(ctx, g0, g1, g2):
         out, aux, label, sums = ctx.saved_tensors
         n = out.numel()
-        zero = None
-        gs = []
-        for gi in (g0, g1, g2):
-            if gi is None:
-                if zero is None:
-                    zero = torch.zeros((), device=out.device, dtype=torch.float32)
-                gi = zero
-            gs.append(gi.reshape(()).float())
-        g = torch.stack(gs)
+        gs = [None if gi is None else _c(gi.reshape(()).float()) for gi in (g0, g1, g2)]      # NULL = that loss takes no part (was: zeros + stack, two launches per domain and sweep)
         need_out = ctx.needs_input_grad[0] and (g0 is not None or g2 is not None)
         need_aux = aux is not None and ctx.needs_input_grad[1] and (g1 is not None or g2 is not None)
         dout = _empty_like(out) if need_out else None
         daux = _empty_like(aux) if need_aux else None
         if need_out or need_aux:
-            call("mdvit_seg_losses_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(g), _p(dout), _p(daux), n, ctx.dice_gain, _stream())
+            call("mdvit_seg_losses_bwd3", _p(out), _p(aux), _p(label), _p(sums), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(dout), _p(daux), n, ctx.dice_gain, _stream())
         return dout, daux, None
+
+
+class _SegLossesGroups(torch.autograd.Function):
+    """_SegLosses over the G domain batches of a domain-batched forward, summed over the batches: one sums launch, one final, one backward launch (it was one
+    of each per domain plus the additions of the per-domain losses and a concatenation of the per-domain logit gradients)."""
+
+    @staticmethod
+    def forward(ctx, out, aux, label, G):
+        _chk(out, aux, label)
+        n = out.numel() // G
+        sums = _empty((16 * G,), device=out.device, dtype=torch.float64)
+        losses = _empty((3,), device=out.device, dtype=torch.float32)
+        world = _loss_world()
+        call("mdvit_seg_losses_groups_sums", _p(out), _p(aux), _p(label), _p(sums), n, G, _stream())
+        if world > 1 or (_force_collectives and torch.distributed.is_initialized()):
+            torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM, group=_loss_group)      # BCE / Dice over the GLOBAL batch of every domain
+        call("mdvit_seg_losses_groups_final", _p(sums), _p(losses), None, n * world, int(aux is not None), G, _stream())
+        ctx.dice_gain = float(world)
+        ctx.G = G
+        ctx.save_for_backward(out, aux, label, sums)
+        ctx.set_materialize_grads(False)
+        return losses[0], losses[1], losses[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        out, aux, label, sums = ctx.saved_tensors
+        gs = [None if gi is None else _c(gi.reshape(()).float()) for gi in (g0, g1, g2)]
+        need_out = ctx.needs_input_grad[0] and (g0 is not None or g2 is not None)
+        need_aux = aux is not None and ctx.needs_input_grad[1] and (g1 is not None or g2 is not None)
+        dout = _empty_like(out) if need_out else None
+        daux = _empty_like(aux) if need_aux else None
+        if need_out or need_aux:
+            call("mdvit_seg_losses_groups_bwd", _p(out), _p(aux), _p(label), _p(sums), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(dout), _p(daux), out.numel() // ctx.G, ctx.G,
+                 ctx.dice_gain, _stream())
+        return dout, daux, None, None
+
+
+def seg_losses_groups(out, aux, label, G: int):
+    """the three losses of G equal consecutive domain batches, each a mean over ITS batch (multi_train_MDViT.py:147-153), summed over the batches"""
+    if G <= 1:
+        return seg_losses(out, aux, label)
+    if out.shape[0] % G:
+        raise _lib.MdvitHipError(f"seg_losses_groups: batch {out.shape[0]} is not {G} equal domain batches")
+    return _SegLossesGroups.apply(_c(out), None if aux is None else _c(aux), _c(label.float()), int(G))
 
 
 def seg_losses(out, aux, label):

@@ -10,6 +10,8 @@ order exactly.
 """
 from __future__ import annotations
 
+import functools
+import operator
 import os
 
 from typing import Dict, List, Optional, Sequence
@@ -22,6 +24,7 @@ from .losses import domain_losses, seg_loss
 from .parallel import GradAccumulator, GradBucketReducer
 
 
+_GROUPED_LOSSES = os.environ.get("MDVIT_GROUPED_LOSSES", "1") != "0"      # the G domain batches' losses in one launch each way (0: one op per domain + additions, A/B)
 _two_stream_sweeps = os.environ.get("MDVIT_SWEEP_STREAMS", "1") != "0"      # A/B switch: 0 = both sweeps on the main stream
 _timeline = None      # tools/sweep_timeline.py: a list here collects (tag, event, host seconds) at the sweeps' stream ends
 
@@ -169,9 +172,12 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
         if G == 1:
             l, la, lk = domain_losses(out, aux, label)
         else:       # per-domain BCE/Dice/KT (each a mean over ITS batch, multi_train_MDViT.py:147-153), then summed
-            og, ag = ops.split_groups(out, G), ops.split_groups(aux, G)
-            per = [domain_losses(og[g], ag[g], label[g * Bd:(g + 1) * Bd]) for g in range(G)]
-            l, la, lk = (sum(t[j] for t in per) for j in range(3))
+            if _GROUPED_LOSSES and aux is not None:
+                l, la, lk = ops.seg_losses_groups(out, aux, label, G)
+            else:
+                og, ag = ops.split_groups(out, G), ops.split_groups(aux, G)
+                per = [domain_losses(og[g], ag[g], label[g * Bd:(g + 1) * Bd]) for g in range(G)]
+                l, la, lk = (functools.reduce(operator.add, [t[j] for t in per]) for j in range(3))          # (sum() starts from the int 0: one more add launch per loss)
         tot = l.detach() if tot is None else tot + l.detach()
         tot_aux = la.detach() if tot_aux is None else tot_aux + la.detach()
         tot_kt = lk.detach() if tot_kt is None else tot_kt + lk.detach()
@@ -182,7 +188,8 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
         else:
             stash.append((l, la, lk))
     if not per_domain_backward:
-        two_sweeps(sum(s[1] for s in stash), alpha * sum(s[2] for s in stash) + (1 - alpha) * sum(s[0] for s in stash), last=True)
+        tot3 = [functools.reduce(operator.add, [s[j] for s in stash]) for j in range(3)]
+        two_sweeps(tot3[1], alpha * tot3[2] + (1 - alpha) * tot3[0], last=True)
         mark("bwd")
     if accumulator is None and reducer is not None:
         reducer.finish()

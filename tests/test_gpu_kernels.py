@@ -1141,6 +1141,38 @@ def test_seg_losses(golden):
     assert abs(float(l0[0]) - float(ref0)) < 1e-5 * abs(float(ref0))
 
 
+@pytest.mark.parametrize("G,partial", [(4, "full"), (4, "aux_only"), (2, "full")])
+def test_seg_losses_of_the_domain_batches_in_one_launch_equal_one_op_per_domain(G, partial):
+    """ops.seg_losses_groups(out, aux, label, G) (one sums / final / backward launch over the G domain batches of a domain-batched forward) == ops.seg_losses per domain
+    batch, the losses added in batch order: the three losses bit for bit, the logit gradients bit for bit -- also when only loss_aux + kt are back-propagated (the
+    aux sweep: the main logits then get their gradient through the KT term only)."""
+    from mdvit_amd import ops
+    torch.manual_seed(G)
+    B, H = 3, 40
+    out = (torch.randn(G * B, 1, H, H, device=dev()) * 2).requires_grad_(True)
+    aux = (torch.randn(G * B, 1, H, H, device=dev()) * 2).requires_grad_(True)
+    label = (torch.rand(G * B, 1, H, H, device=dev()) < 0.3).float()
+    w = torch.tensor([0.7, 1.3, 0.5], device=dev())
+
+    def total(ls):
+        return w[1] * ls[1] + w[2] * ls[2] if partial == "aux_only" else w[0] * ls[0] + w[1] * ls[1] + w[2] * ls[2]
+
+    lg = ops.seg_losses_groups(out, aux, label, G)
+    go, ga = torch.autograd.grad(total(lg), (out, aux))
+    per = [ops.seg_losses(out[g * B:(g + 1) * B], aux[g * B:(g + 1) * B], label[g * B:(g + 1) * B]) for g in range(G)]
+    ref = []
+    for j in range(3):
+        t = per[0][j]
+        for g in range(1, G):
+            t = t + per[g][j]
+        ref.append(t)
+    ro, ra = torch.autograd.grad(total(ref), (out, aux))
+    for a, b in zip(lg, ref):
+        assert torch.equal(a, b), (float(a), float(b))
+    assert torch.equal(go, ro) and torch.equal(ga, ra)
+    assert torch.isfinite(go).all() and float(go.abs().max()) > 0
+
+
 def test_seg_losses_global_batch_two_ranks_emulated():
     """Data-parallel loss semantics (nn.DataParallel: Dice / BCE over the gathered global batch): two 'ranks' on one GPU --
     each runs _sums on its half, the 16 doubles are added (the all-reduce), _final / _bwd use the global sums with
