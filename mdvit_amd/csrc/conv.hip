@@ -529,37 +529,53 @@ struct UpMulti {
 
 __global__ __launch_bounds__(256) void upsample_multi_fwd_kernel(UpMulti p, const float* base_, float* __restrict__ y, int B, int Ho, int Wo, int C) {
     const int QC = C >> 2;
-    const long total = (long)B * Ho * Wo * QC;
-    // (2-8 horizontally adjacent output pixels read the same source pixels: their workgroups on one XCD -- PMC FETCH 283 MB per launch before, for 178 MB
-    //  of base + sources)
-    for (long e = (long)mdvit_xcd_logical_block() * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % QC) * 4;
-        long r = e / QC;
-        const int wo = (int)(r % Wo); r /= Wo;
-        const int ho = (int)(r % Ho);
-        const int b = (int)(r / Ho);
-        const long oi = (((long)b * Ho + ho) * Wo + wo) * C + c;
-        float4 o = base_ ? *reinterpret_cast<const float4*>(base_ + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // Work unit = 1024 consecutive channel quads of ONE output row (four per thread): the row / chunk split is a wave-uniform division (scalar unit), the
+    // vertical taps of the row are computed once per unit, and what is left per element is one 32-bit division -- the flat 64-bit index arithmetic per element
+    // (three long divisions) is gone; 129 -> 125 us per peer head at 4 x 128 x 128 x 512: the kernel is bound by the texture-address path -- 12 tap loads (L1 / L2 hits)
+    // per 16 bytes stored, ~48 us of load issue per CU under the 62 us of HBM time for its 310 MB -- not by index arithmetic, and streaming (nontemporal) base / y
+    // accesses changed nothing; the next step would be source tiles in LDS.
+    // (2-8 horizontally adjacent output pixels read the same source pixels: consecutive logical blocks -- the chunks of a row -- sit on one XCD; PMC FETCH 283 MB
+    //  per launch before that, for 178 MB of base + sources)
+    const int row_items = Wo * QC;
+    const int cpr = (row_items + 1023) >> 10;
+    const long nunits = (long)B * Ho * cpr;
+    for (long u = mdvit_xcd_logical_block(); u < nunits; u += gridDim.x) {
+        const long row = u / cpr;
+        const int k = (int)(u - row * cpr);
+        const int ho = (int)(row % Ho), b = (int)(row / Ho);
+        int h0[3], h1[3]; float lh[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            if (i >= p.n) break;
-            const int Hi = p.Hi[i], Wi = p.Wi[i];
-            int h0, h1, w0, w1; float lh, lw;
-            bilin_src(ho, Hi, (float)Hi / (float)Ho, h0, h1, lh);
-            bilin_src(wo, Wi, (float)Wi / (float)Wo, w0, w1, lw);
-            const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
-            const float* x = p.x[i] + (long)b * Hi * Wi * C + c;
-            const float4 v00 = *reinterpret_cast<const float4*>(x + ((long)h0 * Wi + w0) * C), v01 = *reinterpret_cast<const float4*>(x + ((long)h0 * Wi + w1) * C);
-            const float4 v10 = *reinterpret_cast<const float4*>(x + ((long)h1 * Wi + w0) * C), v11 = *reinterpret_cast<const float4*>(x + ((long)h1 * Wi + w1) * C);
-            // the same four-tap expression as upsample_fwd_kernel, then added to the running sum: equal to the chained calls bit for bit
-            float4 u;
-            u.x = c00 * v00.x + c01 * v01.x + c10 * v10.x + c11 * v11.x;
-            u.y = c00 * v00.y + c01 * v01.y + c10 * v10.y + c11 * v11.y;
-            u.z = c00 * v00.z + c01 * v01.z + c10 * v10.z + c11 * v11.z;
-            u.w = c00 * v00.w + c01 * v01.w + c10 * v10.w + c11 * v11.w;
-            o = (i == 0 && !base_) ? u : f4_add(u, o);
+            h0[i] = h1[i] = 0; lh[i] = 0.f;
+            if (i < p.n) bilin_src(ho, p.Hi[i], (float)p.Hi[i] / (float)Ho, h0[i], h1[i], lh[i]);
         }
-        *reinterpret_cast<float4*>(y + oi) = o;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = (k << 10) + it * 256 + (int)threadIdx.x;
+            if (e >= row_items) break;
+            const int wo = e / QC, c = (e - wo * QC) * 4;
+            const long oi = ((row * Wo) + wo) * C + c;
+            float4 o = base_ ? *reinterpret_cast<const float4*>(base_ + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i >= p.n) break;
+                const int Hi = p.Hi[i], Wi = p.Wi[i];
+                int w0, w1; float lw;
+                bilin_src(wo, Wi, (float)Wi / (float)Wo, w0, w1, lw);
+                const float c00 = (1.f - lh[i]) * (1.f - lw), c01 = (1.f - lh[i]) * lw, c10 = lh[i] * (1.f - lw), c11 = lh[i] * lw;
+                const float* x = p.x[i] + (long)b * Hi * Wi * C + c;
+                const float4 v00 = *reinterpret_cast<const float4*>(x + ((long)h0[i] * Wi + w0) * C), v01 = *reinterpret_cast<const float4*>(x + ((long)h0[i] * Wi + w1) * C);
+                const float4 v10 = *reinterpret_cast<const float4*>(x + ((long)h1[i] * Wi + w0) * C), v11 = *reinterpret_cast<const float4*>(x + ((long)h1[i] * Wi + w1) * C);
+                // the same four-tap expression as upsample_fwd_kernel, then added to the running sum: equal to the chained calls bit for bit
+                float4 uu;
+                uu.x = c00 * v00.x + c01 * v01.x + c10 * v10.x + c11 * v11.x;
+                uu.y = c00 * v00.y + c01 * v01.y + c10 * v10.y + c11 * v11.y;
+                uu.z = c00 * v00.z + c01 * v01.z + c10 * v10.z + c11 * v11.z;
+                uu.w = c00 * v00.w + c01 * v01.w + c10 * v10.w + c11 * v11.w;
+                o = (i == 0 && !base_) ? uu : f4_add(uu, o);
+            }
+            *reinterpret_cast<float4*>(y + oi) = o;
+        }
     }
 }
 
@@ -806,8 +822,9 @@ extern "C" int mdvit_upsample_multi_fwd(const float* const* xs, const int32_t* H
         p.x[i] = xs[i]; p.Hi[i] = Hi[i]; p.Wi[i] = Wi[i];
     }
     MDVIT_CHECK_ARG(aligned16(y) && (!base || aligned16(base)), MDVIT_E_ALIGN, "upsample_multi_fwd: y / base must be 16-byte aligned");
-    const long total = (long)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(upsample_multi_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p, base, y, B, Ho, Wo, C);
+    MDVIT_CHECK_ARG((long)Wo * (C / 4) < (1L << 30), MDVIT_E_SHAPE, "upsample_multi_fwd: output row too long");
+    const long nunits = (long)B * Ho * (((long)Wo * (C / 4) + 1023) >> 10);
+    hipLaunchKernelGGL(upsample_multi_fwd_kernel, dim3((unsigned)min(nunits, 16384L)), dim3(256), 0, (hipStream_t)stream, p, base, y, B, Ho, Wo, C);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

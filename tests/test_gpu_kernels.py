@@ -978,13 +978,14 @@ def test_upsample(B, Hi, Wi, Ho, Wo, C):
     check(out2, out.detach() + base, name="accumulate")
 
 
-def test_upsample_sum_equals_chained_resizes():
+@pytest.mark.parametrize("B,Ho,Wo,C", [(2, 24, 40, 64), (3, 8, 72, 72), (1, 16, 128, 512)], ids=["row_in_one_unit", "ragged_second_unit", "peer_head_row"])
+def test_upsample_sum_equals_chained_resizes(B, Ho, Wo, C):
     """ops.upsample_sum (base + three bilinear sources in one pass; the backward's width folds in one launch) == the chained single-source calls:
-    forward and every gradient to fp32 round-off, and the forward against F.interpolate in fp64"""
+    forward and every gradient to fp32 round-off, and the forward against F.interpolate in fp64.  (The forward walks an output row in units of 1024 channel
+    quads: one unit, a ragged second unit, and the peer heads' 128 x 512 row = 16 units.)"""
     from mdvit_amd import ops
-    B, Ho, Wo, C = 2, 24, 40, 64
     base = rnd(B, Ho, Wo, C, seed=400)
-    xs = [rnd(B, 12, 20, C, seed=401), rnd(B, 6, 10, C, seed=402), rnd(B, 3, 5, C, seed=403)]
+    xs = [rnd(B, Ho // 2, Wo // 2, C, seed=401), rnd(B, Ho // 4, Wo // 4, C, seed=402), rnd(B, Ho // 8, Wo // 8, C, seed=403)]
     g = rnd(B, Ho, Wo, C, seed=404).to(dev())
     res = []
     for fused in (True, False):

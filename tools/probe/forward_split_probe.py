@@ -45,7 +45,8 @@ def two_streams():
 
 
 with torch.no_grad():
-    for name, fn in (("one 16-image pass", one), ("two 8-image passes, one stream", two_serial), ("two 8-image passes, two streams", two_streams)) * 2:
+    variants = (("one 16-image pass", one),) if os.environ.get("MDVIT_FWD_ONLY_ONE") else (("one 16-image pass", one), ("two 8-image passes, one stream", two_serial), ("two 8-image passes, two streams", two_streams))
+    for name, fn in variants * 2:
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
