@@ -166,11 +166,14 @@ class _ASPP(nn.Module):
     def forward(self, x):
         B, h, w, _ = x.shape
         oc = self.out_channels
-        res = [self.convs[0][1](ops.linear(x, self.convs[0][0].weight.view(oc, -1)))]
+        # five consumers of one tensor: behind ops.fork their gradients are added by OUR node, on whatever stream the sweep runs on (autograd's own accumulation
+        # is launched on the forward's stream -- unordered with an aux sweep that runs on a stream of its own)
+        xs = ops.fork(x, len(self.rates) + 2)
+        res = [self.convs[0][1](ops.linear(xs[0], self.convs[0][0].weight.view(oc, -1)))]
         for i, r in enumerate(self.rates, start=1):
-            res.append(self.convs[i][1](ops.conv3x3_dense(x, self.convs[i][0].weight, None, 1, dilation=r)))
+            res.append(self.convs[i][1](ops.conv3x3_dense(xs[i], self.convs[i][0].weight, None, 1, dilation=r)))
         pool = self.convs[-1]
-        pooled = ops.linear(ops.global_avg_pool(x), pool[1].weight.view(oc, -1)).view(B, 1, 1, oc)
+        pooled = ops.linear(ops.global_avg_pool(xs[-1]), pool[1].weight.view(oc, -1)).view(B, 1, 1, oc)
         res.append(ops.upsample_bilinear(pool[2](pooled), h, w))                    # a 1x1 source: the constant, broadcast
         y = self.project[1](ops.linear(torch.cat(res, dim=-1), self.project[0].weight.view(oc, -1)))
         return ops.dropout(y, self.project[3].p, self.training)

@@ -2083,6 +2083,37 @@ def fork_groups(x, n: int, G: int):
     return tuple(out[:n]) + (tuple(out[n:]),)
 
 
+# autograd nodes of torch's own whose backward launches nothing (they hand views / the same tensor on): harmless inside a sweep that runs on another stream
+_KERNEL_FREE_NATIVE = ("AddBackward0", "CatBackward0", "ViewBackward0", "UnsafeViewBackward0", "ReshapeAliasBackward0", "PermuteBackward0", "TBackward0", "TransposeBackward0",
+                       "AliasBackward0", "SqueezeBackward0", "SqueezeBackward1", "UnsqueezeBackward0", "DetachBackward0", "CloneBackward0", "AccumulateGrad")
+
+
+def audit_sweep_graph(root):
+    """Walk the autograd graph below `root` and report what would be launched by the ENGINE rather than by this package's Functions in a backward from it:
+    -> (native, fanin) -- `native`: names of torch-native nodes whose backward runs a kernel; `fanin`: names of nodes that receive more than one gradient
+    (autograd adds those itself).  Both run on the stream the FORWARD ran on: a sweep moved to another stream (set_sweep_stream) is unordered with them, so a
+    model whose aux graph reports any may not list itself in model.AUX_SWEEP_STREAM_SAFE.  (AccumulateGrad fan-in is reported by parameter name only when the
+    node can receive a gradient in the data-gradient-only sweep, i.e. never for sunk weights -- the caller filters.)"""
+    import collections
+    seen, stack, consumers = set(), [root.grad_fn], collections.Counter()
+    native = []
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        name = type(fn).__name__
+        ours = name.endswith("Backward") and name[:-len("Backward")] in globals()
+        if not ours and name not in _KERNEL_FREE_NATIVE:
+            native.append(name)
+        for nf, idx in fn.next_functions:
+            if nf is not None:
+                consumers[(nf, idx)] += 1
+                stack.append(nf)
+    fanin = sorted({type(nf).__name__ + (":" + str(idx) if idx else "") for (nf, idx), c in consumers.items() if c > 1 and type(nf).__name__ != "AccumulateGrad"})
+    return sorted(set(native)), fanin
+
+
 def fork(x, n: int):
     """n aliases of x, one per consumer (see _Fork)"""
     return _Fork.apply(x, int(n)) if (n > 1 and x.requires_grad) else (x,) * n

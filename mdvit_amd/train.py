@@ -25,6 +25,7 @@ from .parallel import GradAccumulator, GradBucketReducer
 
 
 _GROUPED_LOSSES = os.environ.get("MDVIT_GROUPED_LOSSES", "1") != "0"      # the G domain batches' losses in one launch each way (0: one op per domain + additions, A/B)
+_AUX_STREAM_FORCE = os.environ.get("MDVIT_AUX_SWEEP_STREAM_FORCE", "0") == "1"      # probes only: the aux sweep on its own stream whatever the model declares
 _two_stream_sweeps = os.environ.get("MDVIT_SWEEP_STREAMS", "1") != "0"      # A/B switch: 0 = both sweeps on the main stream
 _timeline = None      # tools/sweep_timeline.py: a list here collects (tag, event, host seconds) at the sweeps' stream ends
 
@@ -110,7 +111,8 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
                 # step every other gradient bucket is final after this sweep and its all-reduce is issued underneath the aux sweep.
                 # Two streams: the data-gradient-only aux sweep does not depend on the full sweep, only on the forward -- it runs on a
                 # stream of its own, ordered after the forward (the event below) and joined before the gradients are folded.
-                s2 = ops.sweep_stream() if (_two_stream_sweeps and fused_forward and aux_sum.is_cuda) else None
+                # (only when the aux graph holds nothing the autograd ENGINE would launch itself -- see _aux_graph_is_ours)
+                s2 = ops.sweep_stream() if (_two_stream_sweeps and fused_forward and aux_sum.is_cuda and (_AUX_STREAM_FORCE or _aux_graph_is_ours(model, aux_sum))) else None
                 if s2 is not None:
                     ops.stream_wait(s2, ops.current_stream_obj())          # recorded BEFORE the full sweep is enqueued
                 ops.take_cache_fill_flag()
@@ -200,6 +202,24 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
     if with_metrics:
         res["metrics"] = torch.stack(metric_rows)          # [domains, 4]
     return res
+
+
+def _aux_graph_is_ours(model, aux_sum) -> bool:
+    """May the data-gradient-only aux sweep run on a stream of its own?  Only if every kernel of that backward is launched by this package's Functions (which
+    follow ops.set_sweep_stream): autograd's own gradient accumulation at a tensor with several consumers, or a torch op's backward, is launched by the engine on
+    the stream the FORWARD ran on -- unordered with a sweep that was moved elsewhere.  (Found with the DeepLabV3 peer heads before ASPP's five-consumer input went
+    behind ops.fork: the adapters' gradients ~100 % off in one of eight cold steps.)  The graph's structure does not change from step to step: audited once per
+    model object (ops.audit_sweep_graph, a Python walk of ~1000 nodes), the verdict and the findings cached on it."""
+    ok = getattr(model, "_aux_sweep_graph_ok", None)
+    if ok is None:
+        native, fanin = ops.audit_sweep_graph(aux_sum)
+        ok = not native and not fanin
+        try:
+            model._aux_sweep_graph_ok = ok
+            model._aux_sweep_graph_findings = (native, fanin)
+        except Exception:           # (an object that refuses attributes: audit every step)
+            pass
+    return ok
 
 
 def _fuse_batches(batches, fuse_domains, num_domains, use_domain_label):

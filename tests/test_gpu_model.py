@@ -964,6 +964,29 @@ def _bench_step(m, batches, fuse, side, poison_env=False):
     return {k: float(v) for k, v in res.items()}, grads
 
 
+@pytest.mark.parametrize("decoder_name", ["MLPFM", "MLP", "DeepLabV3", "Transformer"])
+def test_aux_sweep_graph_holds_nothing_the_autograd_engine_would_launch(decoder_name):
+    """The data-gradient-only aux sweep may run on a stream of its own only if every kernel of it is launched by this package's Functions: ops.audit_sweep_graph
+    finds no torch-native node with a kernel in its backward and no tensor with several consumers outside ops.fork in the aux graph of every peer-head family
+    (DeepLabV3's ASPP input -- five consumers -- was one until round 4: adapter gradients ~100 % off in one of eight cold two-stream steps); the audit itself
+    reports a planted two-consumer tensor and a planted torch op; and train._aux_graph_is_ours caches its verdict on the model."""
+    from mdvit_amd import ops, train
+    from mdvit_amd.synthetic import make_step_batches
+    batches = make_step_batches(2, 64, rank=0, step=0, device=dev())
+    img, lab, sid, dl, G = train._fuse_batches(batches, 4, 4, True)[0]
+    Bd = img.shape[0] // G
+    m = build_mdvit(23, 64, decoder_name=decoder_name).train()
+    out, aux = m(img, dl, [str(int(sid[g * Bd])) for g in range(G)])
+    l, la, lk = ops.seg_losses_groups(out, aux, lab, G)
+    assert ops.audit_sweep_graph(la) == ([], []), ops.audit_sweep_graph(la)
+    assert train._aux_graph_is_ours(m, la) and m._aux_sweep_graph_ok is True
+    # planted: a tensor with two consumers (autograd adds the two gradients itself), a torch op with a kernel in its backward
+    x = torch.randn(4, 8, 8, 16, device=dev(), requires_grad=True)
+    y = ops.upsample_bilinear(x, 16, 16)
+    native, fanin = ops.audit_sweep_graph((ops.global_avg_pool(y).sum() + ops.global_avg_pool(y).mean()))
+    assert fanin and any("Sum" in n or "Mean" in n for n in native), (native, fanin)
+
+
 @pytest.mark.parametrize("two_stream", [False, True], ids=["merged_sweeps_on_main", "aux_sweep_on_its_stream"])
 def test_bench_step_gradients_are_reproducible_run_to_run(two_stream):
     """The exact bench step (4 domains x bs=4, 512x512, fused forward, weight gradients on the side stream into the bucket sinks) four times from the same seed:

@@ -1,7 +1,7 @@
 """Run-to-run reproducibility of the exact bench step (4 domains x bs=4, 512 x 512, one fused forward, merged sweeps, weight gradients on the side stream into
 the bucket sinks): RUNS fresh models from the same seed, the same batches; per run the largest relative L2 difference of any gradient tensor against the run
 most others agree with, and the names of the tensors past 1e-4.
-    python tools/probe/step_determinism.py [RUNS=10] [TWO_STREAM_SWEEPS=0|1] [bs4|bs32|transfuse]
+    python tools/probe/step_determinism.py [RUNS=10] [TWO_STREAM_SWEEPS=0|1] [bs4|bs32|transfuse]      (DET_DECODER=MLP|DeepLabV3|Transformer, DET_DROP=0.1 in the environment: other peer heads, the dropout kernel variants)
 What differs legitimately: ~4e-7 (LDS float atomics in the attention partial sums / depthwise-convolution weight gradients add in arrival order).
 Round 4 found 1e-3 .. 6e-3 on all 46 tensors below the last stage-0 block's MLP in about every second run: an LDS-DMA write overtaking another wave's queued
 ds_read in mlp_rc.hip's weight rings (see RC_BARRIER there) whenever the first C = 64 block backward ran next to LDS-atomic kernels of the side stream."""
@@ -49,10 +49,16 @@ def main():
     if what == "transfuse":
         res = transfuse_runs(runs)
     else:
+        import itertools
+        from mdvit_amd import ops
+        decoder = os.environ.get("DET_DECODER", "MLPFM")            # MLPFM | MLP | DeepLabV3 | Transformer
+        drop = float(os.environ.get("DET_DROP", "0"))               # > 0: the dropout / DropPath kernel variants (masks re-keyed identically every run)
         batches = make_step_batches(32 if what == "bs32" else 4, 512, rank=0, step=0, device=T.dev())
         res = []
         for _ in range(runs):
-            m = T.build_mdvit(23, 512).train()
+            ops._key_counter = itertools.count(5)
+            torch.manual_seed(1234)                                  # DropPath draws
+            m = T.build_mdvit(23, 512, drop=drop, decoder_name=decoder).train()
             res.append(T._bench_step(m, batches, 4, True)[1])
             del m
             torch.cuda.empty_cache()
