@@ -63,6 +63,12 @@ def main():
             del m
             torch.cuda.empty_cache()
     names = list(res[0])
+    # tensors whose gradient is zero in exact arithmetic (a bias in front of a BatchNorm) hold round-off only: their RELATIVE difference means nothing
+    big = max(float(res[0][n].double().norm()) for n in names)
+    noise = [n for n in names if float(res[0][n].double().norm()) <= 1e-5 * big]
+    names = [n for n in names if n not in noise]
+    if noise:
+        print(f"({len(noise)} tensors below 1e-5 of the largest gradient norm left out: {noise[:4]} ...)")
     agree = [sum(1 for j in range(runs) if j != i and max(rel(res[i][n], res[j][n]) for n in names) < 1e-4) for i in range(runs)]
     ref = max(range(runs), key=lambda i: agree[i])
     print(f"{what}, two-stream sweeps {two}: runs agreeing with each run {agree}; reference run {ref}", flush=True)
