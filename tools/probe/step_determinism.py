@@ -66,7 +66,7 @@ def main():
                 torch.manual_seed(1234)
             else:
                 m = T.build_mdvit(23, 512, drop=drop, decoder_name=decoder).train()
-            res.append(T._bench_step(m, batches, 4, True)[1])
+            res.append(T._bench_step(m, batches, int(os.environ.get("DET_FUSE", "4")), True)[1])          # DET_FUSE=1: one forward per domain, 2: two domain pairs
             del m
             torch.cuda.empty_cache()
     names = list(res[0])
