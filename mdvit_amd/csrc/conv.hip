@@ -579,6 +579,75 @@ __global__ __launch_bounds__(256) void upsample_multi_fwd_kernel(UpMulti p, cons
     }
 }
 
+// The same sum with the sources' pixels staged in LDS: a workgroup owns an 8 x 16 pixel tile x 128 channels of the output; the source patch under the tile
+// (rows h0(first row) .. h1(last row), columns likewise) is read from HBM / L2 ONCE per workgroup -- 96 pixels in all for upscale factors 2 / 4 / 8 -- and the four
+// taps of every output pixel come out of LDS.  The flat kernel issues 12 tap loads (L1 / L2 hits, but texture-address work) per 16 bytes it stores and is bound by
+// that path (125 us per peer head for 310 MB: 2.5 TB/s); here a workgroup moves 32 KB of base + 24 KB of sources + 32 KB of output.  Same tap expression on the same
+// values.  Eligibility (host): Ho % 8 == 0, Wo % 16 == 0, C % 128 == 0, integer upscale factors >= 2 whose patches fit the 96-pixel pool.
+constexpr int UT_H = 8, UT_W = 16, UT_C = 128, UT_POOL = 96;
+__global__ __launch_bounds__(256) void upsample_multi_tile_kernel(UpMulti p, const float* __restrict__ base_, float* __restrict__ y, int Ho, int Wo, int C) {
+    __shared__ __attribute__((aligned(16))) float s_src[UT_POOL * UT_C];
+    const int tiles_w = Wo / UT_W;
+    const int ty = blockIdx.x / tiles_w, tx = blockIdx.x - ty * tiles_w;
+    const int ho0 = ty * UT_H, wo0 = tx * UT_W, c0 = blockIdx.y * UT_C, b = blockIdx.z;
+    int r0[3], q0[3], pw[3], off[3];
+    {
+        int used = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            r0[i] = q0[i] = pw[i] = off[i] = 0;
+            if (i >= p.n) continue;
+            const int Hi = p.Hi[i], Wi = p.Wi[i];
+            int a0, a1, b0, b1; float l;
+            bilin_src(ho0, Hi, (float)Hi / (float)Ho, a0, b0, l);
+            bilin_src(ho0 + UT_H - 1, Hi, (float)Hi / (float)Ho, a1, b1, l);
+            const int ph = b1 - a0 + 1;
+            r0[i] = a0;
+            bilin_src(wo0, Wi, (float)Wi / (float)Wo, a0, b0, l);
+            bilin_src(wo0 + UT_W - 1, Wi, (float)Wi / (float)Wo, a1, b1, l);
+            pw[i] = b1 - a0 + 1;
+            q0[i] = a0;
+            off[i] = used * UT_C;
+            // stage [ph][pw][128 channels]
+            const float* x = p.x[i] + (long)b * Hi * Wi * C + c0;
+            const int items = ph * pw[i] * (UT_C / 4);
+            for (int e = threadIdx.x; e < items; e += 256) {
+                const int cq = e & (UT_C / 4 - 1), px = e >> 5, pr = px / pw[i], pc = px - pr * pw[i];
+                *reinterpret_cast<float4*>(s_src + off[i] + px * UT_C + 4 * cq) =
+                    *reinterpret_cast<const float4*>(x + ((long)(r0[i] + pr) * Wi + (q0[i] + pc)) * C + 4 * cq);
+            }
+            used += ph * pw[i];
+        }
+    }
+    __syncthreads();
+    const int cq = threadIdx.x & 31, colh = threadIdx.x >> 5;           // 32 channel quads x 8 columns per pass
+#pragma unroll 2
+    for (int it = 0; it < UT_H * 2; ++it) {
+        const int ho = ho0 + (it >> 1), wo = wo0 + (it & 1) * 8 + colh;
+        const long oi = ((((long)b * Ho + ho) * Wo) + wo) * C + c0 + 4 * cq;
+        float4 o = base_ ? *reinterpret_cast<const float4*>(base_ + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i >= p.n) break;
+            const int Hi = p.Hi[i], Wi = p.Wi[i];
+            int h0, h1, w0, w1; float lh, lw;
+            bilin_src(ho, Hi, (float)Hi / (float)Ho, h0, h1, lh);
+            bilin_src(wo, Wi, (float)Wi / (float)Wo, w0, w1, lw);
+            const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
+            const float* sp = s_src + off[i] + 4 * cq;
+            const float4 v00 = *reinterpret_cast<const float4*>(sp + ((h0 - r0[i]) * pw[i] + (w0 - q0[i])) * UT_C), v01 = *reinterpret_cast<const float4*>(sp + ((h0 - r0[i]) * pw[i] + (w1 - q0[i])) * UT_C);
+            const float4 v10 = *reinterpret_cast<const float4*>(sp + ((h1 - r0[i]) * pw[i] + (w0 - q0[i])) * UT_C), v11 = *reinterpret_cast<const float4*>(sp + ((h1 - r0[i]) * pw[i] + (w1 - q0[i])) * UT_C);
+            float4 uu;
+            uu.x = c00 * v00.x + c01 * v01.x + c10 * v10.x + c11 * v11.x;
+            uu.y = c00 * v00.y + c01 * v01.y + c10 * v10.y + c11 * v11.y;
+            uu.z = c00 * v00.z + c01 * v01.z + c10 * v10.z + c11 * v11.z;
+            uu.w = c00 * v00.w + c01 * v01.w + c10 * v10.w + c11 * v11.w;
+            o = (i == 0 && !base_) ? uu : f4_add(uu, o);
+        }
+        *reinterpret_cast<float4*>(y + oi) = o;
+    }
+}
+
 // width folds of all sources: work item = (dy row o, source column j in [0, Wi_0 + Wi_1 + Wi_2), channel quad).  A dy row (Wo x C floats: 256 KB in the
 // peer heads) is read by every output column it overlaps -- ~6 times in all -- so the workgroups of ONE row must share an L2: consecutive workgroup
 // ids go round robin over the 8 XCDs, and a row's `bpr` workgroups were spread over all of them (PMC: 632 MB per launch for 134 MB of dy); the bijective
@@ -822,6 +891,20 @@ extern "C" int mdvit_upsample_multi_fwd(const float* const* xs, const int32_t* H
         p.x[i] = xs[i]; p.Hi[i] = Hi[i]; p.Wi[i] = Wi[i];
     }
     MDVIT_CHECK_ARG(aligned16(y) && (!base || aligned16(base)), MDVIT_E_ALIGN, "upsample_multi_fwd: y / base must be 16-byte aligned");
+    {   // the LDS-tiled kernel where the shape allows it (the peer heads: 128 x 128 x 512 from 64 / 32 / 16)
+        static const bool tile_on = !(getenv("MDVIT_UPSAMPLE_TILED") && atoi(getenv("MDVIT_UPSAMPLE_TILED")) == 0);
+        bool ok = tile_on && Ho % UT_H == 0 && Wo % UT_W == 0 && C % UT_C == 0 && (long)(Ho / UT_H) * (Wo / UT_W) < (1L << 30) && C / UT_C < 65536 && B < 65536;
+        int pool = 0;
+        for (int i = 0; i < n && ok; ++i) {
+            ok = Ho % Hi[i] == 0 && Wo % Wi[i] == 0 && Ho / Hi[i] >= 2 && Wo / Wi[i] >= 2;
+            if (ok) pool += (UT_H / (Ho / Hi[i]) + 2) * (UT_W / (Wo / Wi[i]) + 2);         // rows h0(first) .. h1(last) of the tile: at most tile / factor + 2
+        }
+        if (ok && pool <= UT_POOL) {
+            hipLaunchKernelGGL(upsample_multi_tile_kernel, dim3((Ho / UT_H) * (Wo / UT_W), C / UT_C, B), dim3(256), 0, (hipStream_t)stream, p, base, y, Ho, Wo, C);
+            MDVIT_LAUNCH_CHECK();
+            return MDVIT_OK;
+        }
+    }
     MDVIT_CHECK_ARG((long)Wo * (C / 4) < (1L << 30), MDVIT_E_SHAPE, "upsample_multi_fwd: output row too long");
     const long nunits = (long)B * Ho * (((long)Wo * (C / 4) + 1023) >> 10);
     hipLaunchKernelGGL(upsample_multi_fwd_kernel, dim3((unsigned)min(nunits, 16384L)), dim3(256), 0, (hipStream_t)stream, p, base, y, B, Ho, Wo, C);

@@ -978,11 +978,12 @@ def test_upsample(B, Hi, Wi, Ho, Wo, C):
     check(out2, out.detach() + base, name="accumulate")
 
 
-@pytest.mark.parametrize("B,Ho,Wo,C", [(2, 24, 40, 64), (3, 8, 72, 72), (1, 16, 128, 512)], ids=["row_in_one_unit", "ragged_second_unit", "peer_head_row"])
+@pytest.mark.parametrize("B,Ho,Wo,C", [(2, 24, 40, 64), (3, 8, 72, 72), (1, 16, 128, 512), (2, 24, 48, 128)], ids=["row_in_one_unit", "ragged_second_unit", "peer_head_row_lds_tiles", "lds_tiles_3x3_per_image"])
 def test_upsample_sum_equals_chained_resizes(B, Ho, Wo, C):
     """ops.upsample_sum (base + three bilinear sources in one pass; the backward's width folds in one launch) == the chained single-source calls:
     forward and every gradient to fp32 round-off, and the forward against F.interpolate in fp64.  (The forward walks an output row in units of 1024 channel
-    quads: one unit, a ragged second unit, and the peer heads' 128 x 512 row = 16 units.)"""
+    quads: one unit, a ragged second unit; shapes with Ho % 8 == Wo % 16 == C % 128 == 0 and upscale factors 2 / 4 / 8 take the LDS-tiled kernel
+    -- the peer heads' 128 x 512 rows, and 3 x 3 tiles per image over two images.)"""
     from mdvit_amd import ops
     base = rnd(B, Ho, Wo, C, seed=400)
     xs = [rnd(B, Ho // 2, Wo // 2, C, seed=401), rnd(B, Ho // 4, Wo // 4, C, seed=402), rnd(B, Ho // 8, Wo // 8, C, seed=403)]
