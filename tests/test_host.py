@@ -495,3 +495,29 @@ def test_the_256_tile_takes_the_shapes_that_fill_whole_rounds_of_the_chip():
         assert f(4096, 2048, 512, 2) == 1 and f(4096, 2048, 32, 2) == 0
     finally:
         lib.mdvit_gemm_ph_config(0)
+
+
+def test_sweep_graph_audit_reports_engine_launched_work_without_gpu():
+    """ops.audit_sweep_graph walks an autograd graph and names what the ENGINE would launch in a backward from the root -- torch-native nodes with a kernel in their
+    backward, tensors that receive more than one gradient -- i.e. the work that stays on the forward's stream when a sweep is moved to a stream of its own
+    (train._aux_graph_is_ours moves the aux sweep only when both lists are empty and caches the verdict on the model)."""
+    from mdvit_amd import ops, train
+    x = torch.randn(5, 3, requires_grad=True)
+    w = torch.randn(3, 3, requires_grad=True)
+    h = x @ w                                   # MmBackward0: a kernel in its backward
+    clean = (h.view(15).view(5, 3)).t()         # views only on top of it
+    native, fanin = ops.audit_sweep_graph(clean)
+    assert native == ["MmBackward0"] and fanin == []
+    two = h.view(15) + h.t().reshape(15)        # h has two consumers: autograd adds the two gradients itself
+    native, fanin = ops.audit_sweep_graph(two)
+    assert "MmBackward0" in native and any(n.startswith("MmBackward0") for n in fanin)
+    leaf_twice = x.view(15) + x.t().reshape(15)           # a leaf used twice: AccumulateGrad fan-in is the caller's business (sunk weights hand None)
+    assert ops.audit_sweep_graph(leaf_twice)[1] == []
+
+    class M(torch.nn.Module):
+        pass
+    m = M()
+    assert train._aux_graph_is_ours(m, two) is False and m._aux_sweep_graph_ok is False and m._aux_sweep_graph_findings[1]
+    assert train._aux_graph_is_ours(m, clean.detach().requires_grad_(True) * 1.0) is False      # cached verdict: the graph is audited once per model
+    m2 = M()
+    assert train._aux_graph_is_ours(m2, x.view(15).view(3, 5)) is True
