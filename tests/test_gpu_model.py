@@ -1012,7 +1012,9 @@ def test_bench_step_gradients_are_reproducible_run_to_run(two_stream):
     for l, g in res[1:]:
         for k in ("loss", "aux_loss", "kt_loss"):
             assert abs(l[k] - l0[k]) <= 1e-6 * abs(l0[k]), (k, l[k], l0[k])
-        d = max((float((g[n].double() - g0[n].double()).norm()) / max(float(g0[n].double().norm()), 1e-30), n) for n in g0)
+        # (a bias in front of a BatchNorm has a zero gradient in exact arithmetic: such tensors hold round-off only and are left out, as in the probe)
+        big = max(float(g0[n].double().norm()) for n in g0)
+        d = max((float((g[n].double() - g0[n].double()).norm()) / float(g0[n].double().norm()), n) for n in g0 if float(g0[n].double().norm()) > 1e-5 * big)
         worst.append(d)
     assert max(worst)[0] <= 1e-5, f"gradients differ between identical runs: {worst}"
 
