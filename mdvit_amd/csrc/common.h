@@ -95,9 +95,29 @@ __device__ __forceinline__ uint32_t mdvit_hash32(uint32_t x) {
 __device__ __forceinline__ uint32_t mdvit_drop_bits(uint32_t k0, uint32_t k1, uint32_t idx) {
     return mdvit_hash32(((idx >> 2) ^ k0) + k1);
 }
+// the same word from the group's index idx >> 2 (kernels that step a per-lane group index instead of re-deriving it from (row, column) per group)
+__device__ __forceinline__ uint32_t mdvit_drop_bits_q(uint32_t k0, uint32_t k1, uint32_t quad) { return mdvit_hash32((quad ^ k0) + k1); }
 __device__ __forceinline__ float mdvit_drop_scale(uint32_t k0, uint32_t k1, uint32_t idx, uint32_t thresh, float inv_keep) {
     const uint32_t h = __builtin_rotateright32(mdvit_drop_bits(k0, k1, idx), 8u * (idx & 3u));
     return h >= thresh ? inv_keep : 0.0f;
+}
+// The threshold every launcher hands to the kernels: p at 16-bit resolution in the TOP half, low half zero (p = 0.1 -> 6554 / 65536 = 0.100006).
+// With the low half zero `h >= thresh` is decided by the top 16 bits of h alone, so a kernel may test `(h >> 16) >= (thresh >> 16)` -- one SDWA compare on
+// a word of the hash, no rotate for two of the four elements of a group -- and still draw EXACTLY the mask of a kernel that compares all 32 bits.
+static inline uint32_t mdvit_drop_thresh(double p) {
+    double t = p * 65536.0 + 0.5;
+    if (t < 0.0) t = 0.0;
+    if (t > 65535.0) t = 65535.0;
+    return (uint32_t)t << 16;
+}
+// The four keep decisions of one hash word (elements idx4 .. idx4 + 3 of mdvit_drop_scale4), thresh16 = thresh >> 16: element j looks at the top half of
+// rotr(h, 8 j), i.e. word 1 of h, word 1 of rotr(h, 8), word 0 of h, word 0 of rotr(h, 8) -- one v_alignbit + four word compares.
+__device__ __forceinline__ void mdvit_drop_keep4(uint32_t h, uint32_t thresh16, bool (&keep)[4]) {
+    const uint32_t r = __builtin_rotateright32(h, 8);
+    keep[0] = (h >> 16) >= thresh16;
+    keep[1] = (r >> 16) >= thresh16;
+    keep[2] = (h & 0xffffu) >= thresh16;
+    keep[3] = (r & 0xffffu) >= thresh16;
 }
 // idx4 % 4 == 0: scales of elements idx4 .. idx4+3
 __device__ __forceinline__ float4 mdvit_drop_scale4(uint32_t k0, uint32_t k1, uint32_t idx4, uint32_t thresh, float inv_keep) {

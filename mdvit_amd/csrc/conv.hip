@@ -814,7 +814,7 @@ extern "C" int mdvit_dropout_f32(const float* x, float* y, int64_t n, float p, u
     MDVIT_CHECK_ARG(n > 0 && n % 4 == 0 && n < (1L << 32) && p >= 0.f && p < 1.f, MDVIT_E_SHAPE, "dropout: need 0 < n < 2^32, n %% 4 == 0, 0 <= p < 1 (n=%ld p=%g)", (long)n, p);
     MDVIT_CHECK_ARG(aligned16(x) && aligned16(y), MDVIT_E_ALIGN, "dropout: 16-byte aligned buffers");
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, (long)(n / 4), key0, key1, drop_seed,
-                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p));
+                       mdvit_drop_thresh(p), 1.f / (1.f - p));
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

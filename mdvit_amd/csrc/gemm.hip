@@ -309,7 +309,7 @@ extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     a.bias = d->bias;
     a.epi = d->epi;
     a.e_drop = d->e_drop_p > 0.f; a.e_k0 = d->e_key0; a.e_k1 = d->e_key1;
-    a.e_thresh = (uint32_t)((double)d->e_drop_p * 4294967296.0); a.e_inv_keep = 1.f / (1.f - d->e_drop_p);
+    a.e_thresh = mdvit_drop_thresh(d->e_drop_p); a.e_inv_keep = 1.f / (1.f - d->e_drop_p);
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
     a.rc_a = d->rc_a; a.rc_lda = d->rc_lda; a.rc_b = d->rc_b; a.rc_ldb = d->rc_ldb; a.rc_bias = d->rc_bias; a.rc_k = d->rc_k;

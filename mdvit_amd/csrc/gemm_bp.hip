@@ -464,7 +464,7 @@ extern "C" int mdvit_gemm_planes(const MdvitPlaneGemmDesc* d, void* stream) {
     a.U = d->U; a.ldu_out = d->ldu_out;
     a.bias = d->bias;
     a.e_drop = d->e_drop_p > 0.f; a.e_k0 = d->e_key0; a.e_k1 = d->e_key1;
-    a.e_thresh = (uint32_t)((double)d->e_drop_p * 4294967296.0); a.e_inv_keep = 1.f / (1.f - d->e_drop_p);
+    a.e_thresh = mdvit_drop_thresh(d->e_drop_p); a.e_inv_keep = 1.f / (1.f - d->e_drop_p);
     a.e_rowscale = d->e_rowscale; a.e_rows_per_scale = d->e_rows_per_scale > 0 ? d->e_rows_per_scale : 1;
     a.residual = d->residual; a.ldr = d->ldr; a.gelu_u = d->gelu_u; a.ldu = d->ldu;
     a.rc_a = (const uint16_t*)d->rc_a; a.rc_lda = d->rc_lda; a.rc_a_plane = d->rc_a_plane;

@@ -356,7 +356,7 @@ extern "C" int mdvit_mlp_fwd_f32(const float* x, const float* W1, const float* b
     a.x = x; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.res = res; a.rowscale = rowscale; a.h = h; a.y = y;
     a.M = M; a.Hd = Hd; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     a.drop = drop_p > 0.f; a.k1a = key1_0; a.k1b = key1_1; a.k2a = key2_0; a.k2b = key2_1;
-    a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
+    a.thresh = mdvit_drop_thresh(drop_p); a.inv_keep = 1.f / (1.f - drop_p);
     a.seed = drop_seed;
     a.abl = g_mlp_abl;
     constexpr size_t smem64 = (size_t)(2 + 2 + 2 + 2) * 2 * 64 * LDKB;         // X, W1c, Hc, W2c at 64 tokens: 80 KB
@@ -391,7 +391,7 @@ extern "C" int mdvit_mlp_bwd_dgrad_f32(const float* gm, const float* x, const fl
     memset(&a, 0, sizeof(a));
     a.gm = gm; a.x = x; a.W1 = W1; a.b1 = b1; a.W2t = W2t; a.W1t = W1t; a.du = du; a.dx = dx; a.M = M; a.Hd = Hd;
     a.drop = drop_p > 0.f; a.k1a = key1_0; a.k1b = key1_1;
-    a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
+    a.thresh = mdvit_drop_thresh(drop_p); a.inv_keep = 1.f / (1.f - drop_p);
     a.seed = drop_seed;
     constexpr size_t smem = (size_t)4 * 2 * 2 * 64 * LDKB;                    // W1c, W2tc, W1tc, d chunk: 80 KB
     {

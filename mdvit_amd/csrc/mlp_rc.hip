@@ -11,11 +11,17 @@
 // PRE-SPLIT (the per-step bf16 planes of mdvit_split_planes_many) by global_load_lds through three-slot rings with counted vmcnt and a raw
 // s_barrier per 32-wide hidden step -- no conversion work on weights, two steps of prefetch in flight, no ordinary global load inside the
 // loop (biases sit in LDS).  Product 1 runs as D[hidden][token], so a lane holds 16 hidden values of ITS token: after bias / GELU /
-// dropout / hi-lo split, two v_permlane32_swap per operand register pair put them into the natural k order of product 2's operand --
-// the hidden chunk never leaves the register file and the arithmetic is the bf16x3 GEMM's, element for element and k step for k step
-// (y is bit-identical to mdvit_mlp_fwd_f32 / the two-GEMM path).  The loop is software-pipelined across hidden steps: the MFMAs of
-// product 1 (step i+1) and product 2 (step i-1) are issued around the GELU VALU work of step i.
+// dropout / hi-lo split they ARE product 2's operand, in a permuted k order that the weight operand is read in as well (rc_frag_perm;
+// round 3 restored the natural order with v_permlane32_swap -- the GEMM's summation order bit for bit, at 8 slow VALU instructions per
+// step) -- the hidden chunk never leaves the register file and the arithmetic is the bf16x3 GEMM's products (y equals mdvit_mlp_fwd_f32 /
+// the two-GEMM path to a few ulp).  Round 5: on one SIMD an MFMA does not run beside a saturated VALU pipe (the forward's time is its
+// VALU-only time + its MFMA-only time, profiles/r05_mlp_rc_fwd_ablations.txt), so the kernels are priced in VALU CYCLES: see the
+// activation helpers below.
 #include "common.h"
+#include <type_traits>
+#ifndef RC_ABL
+#define RC_ABL 0        // development ablations of mlp_rc_fwd3_kernel (tools/build_variant.py): 1 no activation, 2 no product 1, 3 no product 2, 4 no MFMA, 6 dropout only
+#endif
 
 typedef float rc_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 rc_bf16x8 __attribute__((ext_vector_type(8)));
@@ -51,6 +57,21 @@ __device__ __forceinline__ void rc_glds_piece(const uint16_t* __restrict__ src, 
 template <int ROWB>
 __device__ __forceinline__ rc_bf16x8 rc_frag(const char* tile, int row, int chunk) {
     return __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(tile + row * ROWB + ((chunk ^ rc_swz<ROWB>(row)) << 4)));
+}
+
+// The k-permuted operand fragment of a [rows][32 k] tile (64-byte rows) for the CHAINED products: product 1's accumulator leaves lane (token, g = lane >> 5) with the
+// hidden units 4 g + {0..3} + 8 j (j = register quad); taken as they are, the registers of a 16-wide half hf are the k slots 0..3 <- k = 16 hf + 4 g ..+3 and
+// 4..7 <- k = 16 hf + 8 + 4 g ..+3 -- so the WEIGHT operand is read in that order (two 8-byte reads) and the chained operand needs no lane exchange (8
+// v_permlane32_swap per hidden step at ~8 cycles each; the two ds_read_b64 are 2-way bank conflicted, LDS is idle here).  (Round 3 put the values into the natural k
+// order instead: the GEMM's summation order bit for bit; this order differs from it in the last bits.)
+__device__ __forceinline__ rc_bf16x8 rc_frag_perm(const char* tile, int row, int hf, int g) {
+    const int f = rc_swz<64>(row);
+    // (volatile: hipcc otherwise pairs the reads of DIFFERENT fragments -- hi / lo plane, the two 32-row blocks -- into ds_read2st64_b64 and pays 24 v_mov per hidden step
+    //  to put the operand quads back together)
+    typedef __attribute__((address_space(3))) const volatile rc_u2* lds_u2_ptr;
+    const rc_u2 a = *(lds_u2_ptr)(tile + row * 64 + (((2 * hf) ^ f) << 4) + 8 * g);
+    const rc_u2 b = *(lds_u2_ptr)(tile + row * 64 + (((2 * hf + 1) ^ f) << 4) + 8 * g);
+    return __builtin_bit_cast(rc_bf16x8, (rc_u4{a[0], a[1], b[0], b[1]}));
 }
 
 #define RC_MFMA3(acc, ah, al, bh, bl)                                           \
@@ -107,28 +128,60 @@ __device__ __forceinline__ void rc_load_rows(const float* __restrict__ src, int 
     }
 }
 
-// erf-GELU parts as common.h's gelu_parts (Abramowitz-Stegun 7.1.26), one multiply shorter: exp(-x^2 / 2) = exp2(x * x * (-0.5 log2 e)) on v_exp_f32
-// directly.  cdf and pdf agree with gelu_parts to an ulp of the exponential's argument.
-__device__ __forceinline__ void rc_gelu_parts(float x, float& cdf, float& pdf) {
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+// ---- the activation of the fused kernels (round 5) -----------------------------------------------------------------------------------------
+// What an instruction costs here (tools/probe/valu_rates.hip, profiles/r05_valu_rates.txt; cycles per wave-instruction per SIMD, >= 2 waves per SIMD): f32 mul / add / fma and
+// VOP2 integer logic ~2.5, everything VOP3-only or SDWA / DPP (v_bfi, v_alignbit, v_cvt_pk_bf16, v_cmp + v_cndmask, v_mul_lo_u32, v_pk_*_f32) ~4.5, v_exp / v_rcp and
+// v_permlane32_swap ~8.2 -- so v_pk_fma_f32 buys nothing (two elements for the price of two v_fma), and an MFMA does NOT run beside a saturated VALU pipe of the same SIMD
+// (tools/probe/mfma_valu_overlap.hip, profiles/r05_mfma_valu_overlap.txt; profiles/r05_mlp_rc_fwd_ablations.txt: the forward's time = its VALU-only time + its MFMA-only
+// time): every VALU cycle removed is a cycle off the kernel.  Hence: no copysign (v_bfi), no separate dropout multiply, no re-derived indices.
+//
+// erf by Abramowitz-Stegun 7.1.26 (common.h's gelu_parts): q = erf(|x| / sqrt 2) = 1 - P(t) t e, t = 1 / (1 + p |x|), e = exp(-x^2 / 2) = exp2(x * x * (-0.5 log2 e)).
+__device__ __forceinline__ void rc_erf_parts(float x, float& e, float& q) {
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float erf_abs = 1.0f - poly * t * e;
-    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-    pdf = 0.39894228040143268f * e;
+    q = fmaf(-(poly * t), e, 1.0f);
 }
-__device__ __forceinline__ float rc_gelu(float x) {
-    float cdf, pdf;
-    rc_gelu_parts(x, cdf, pdf);
-    return x * cdf;
+// forward: hk = half the dropout keep-scale of the element (0.5 without dropout, 0.5 / keep kept, 0 dropped).  2 hk x Phi(x) with Phi(x) = 0.5 (1 + sign(x) q):
+// hx + |hx| q, hx = hk x -- 13 instructions (2 transcendental) instead of 16 + the dropout multiply; the rounding of x Phi(x) moves by an ulp against the GEMM epilogue's form
+__device__ __forceinline__ float rc_gelu_k(float x, float hk) {
+    float e, q;
+    rc_erf_parts(x, e, q);
+    const float hx = x * hk;
+    return fmaf(fabsf(hx), q, hx);
 }
-__device__ __forceinline__ float rc_gelu_grad(float x) {
-    float cdf, pdf;
-    rc_gelu_parts(x, cdf, pdf);
-    return fmaf(x, pdf, cdf);
+// backward: d gelu'(x) ks with gelu'(x) = Phi(x) + x phi(x), the keep-scale ks folded into the constants (hks = 0.5 ks, pks = ks / sqrt(2 pi)); d = 0 for a dropped element
+__device__ __forceinline__ float rc_dgelu_k(float x, float d, float hks, float pks) {
+    float e, q;
+    rc_erf_parts(x, e, q);
+    const float cdf = fmaf(copysignf(q, x), hks, hks);
+    return d * fmaf(x * e, pks, cdf);
+}
+// the weight-gradient kernel wants both from one evaluation: h = 2 hk x Phi(x) (hk as rc_gelu_k) and du = d gelu'(x) ks (d, hks, pks as rc_dgelu_k)
+__device__ __forceinline__ void rc_gelu_both_k(float x, float hk, float d, float hks, float pks, float& h, float& du) {
+    float e, q;
+    rc_erf_parts(x, e, q);
+    const float hx = x * hk;
+    h = fmaf(fabsf(hx), q, hx);
+    const float cdf = fmaf(copysignf(q, x), hks, hks);
+    du = d * fmaf(x * e, pks, cdf);
+}
+typedef float rc_f2 __attribute__((ext_vector_type(2)));
+// hi / lo bf16 planes of a pair of values: mdvit_split_bf16x3's arithmetic (RNE hi, RNE (x - hi))
+__device__ __forceinline__ void rc_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((rc_f2{a, b}), mdvit_bf16x2));
+    const rc_f2 l = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(l, mdvit_bf16x2));
+}
+// The keep decisions of the four elements of an aligned group from the group's hash word (mdvit_drop_keep4), as select results: on / off per element
+__device__ __forceinline__ void rc_keep_sel4(uint32_t h, uint32_t thresh16, float on, float off, float (&k)[4]) {
+    bool keep[4];
+    mdvit_drop_keep4(h, thresh16, keep);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = keep[j] ? on : off;
 }
 
 // sum over the 16 channel quads of a row in the order of norm.hip's sum16 (xor 8, 4, 2, 1 over the quad index): a lane of the 32-token layout holds the
@@ -317,24 +370,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
     };
     auto act = [&](int s, const rc_f32x16& u, rc_bf16x8 (&hh)[2], rc_bf16x8 (&hl)[2]) __attribute__((always_inline)) {
-        float hv[16];
+        uint32_t ph[8], pl[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int hd = s * 32 + 8 * q + 4 * lhi;
             const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + hd);          // (ext_vector load: a HIP float4 LDS read makes hipcc drain the glds ring)
-            float4 v = make_float4(rc_gelu(u[4 * q + 0] + b4.x), rc_gelu(u[4 * q + 1] + b4.y), rc_gelu(u[4 * q + 2] + b4.z), rc_gelu(u[4 * q + 3] + b4.w));
-            if (DROP) {
-                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
-                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
-            }
-            hv[4 * q + 0] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+            float hk[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+            if (DROP) rc_keep_sel4(mdvit_drop_bits(k1a, k1b, (uint32_t)((long)row * p.Hd + hd)), p.thresh >> 16, 0.5f * p.inv_keep, 0.f, hk);
+            const float h0 = rc_gelu_k(u[4 * q + 0] + b4.x, hk[0]), h1 = rc_gelu_k(u[4 * q + 1] + b4.y, hk[1]);
+            const float h2 = rc_gelu_k(u[4 * q + 2] + b4.z, hk[2]), h3 = rc_gelu_k(u[4 * q + 3] + b4.w, hk[3]);
+            rc_split2(h0, h1, ph[2 * q], pl[2 * q]);
+            rc_split2(h2, h3, ph[2 * q + 1], pl[2 * q + 1]);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            rc_u4 h, l;
-            rc_split8(hv + 8 * half, h, l);
-            hh[half] = rc_natural_order(h);
-            hl[half] = rc_natural_order(l);
+            hh[half] = rc_natural_order(rc_u4{ph[4 * half], ph[4 * half + 1], ph[4 * half + 2], ph[4 * half + 3]});
+            hl[half] = rc_natural_order(rc_u4{pl[4 * half], pl[4 * half + 1], pl[4 * half + 2], pl[4 * half + 3]});
         }
     };
 
@@ -416,9 +467,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     constexpr int KB = C / 16, CB = C / 32;
     constexpr int RB1 = C * 2;
     constexpr int T1 = 32 * RB1, T2 = C * 64;
-    constexpr int PIECES = (2 * T1 + 2 * T2) / 1024;
-    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
-    constexpr int PPW = PIECES / NW;
+    static_assert(T1 == T2 && T1 / 1024 == NW, "one 1 KiB piece of each of the four planes (W1 hi, lo, W2 hi, lo) per wave and hidden step");
+    constexpr int PPW = 4;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* sW1 = smem;
     char* sW2 = sW1 + 3 * 2 * T1;
@@ -429,25 +479,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     uint32_t s0 = 0, s1 = 0;
     if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
     const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1, k2a = p.k2a ^ s0, k2b = p.k2b + s1;
+    const uint32_t dq0 = (uint32_t)((long)row * p.Hd + 4 * lhi) >> 2, thresh16 = p.thresh >> 16;      // dropout: this lane's first group index (Hd % 32 == 0)
+    const float hki = 0.5f * p.inv_keep;
     const long wplane = (long)p.Hd * C;
-    auto issue_group = [&](int g) __attribute__((always_inline)) {
-        const int gs = min(g, n - 1), slot = g % 3;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int pc = wave + i * NW;
-            if (pc < 2 * T1 / 1024) {
-                constexpr int PP = T1 / 1024;
-                const int pl = pc / PP, q = pc % PP;
-                rc_glds_piece<RB1>(p.W1p + pl * wplane + (long)(gs * 32) * C, C, q, lane, sW1 + (slot * 2 + pl) * T1);
-            } else {
-                constexpr int PP = T2 / 1024;
-                const int pc2 = pc - 2 * T1 / 1024, pl = pc2 / PP, q = pc2 % PP;
-                rc_glds_piece<64>(p.W2p + pl * wplane + gs * 32, p.Hd, q, lane, sW2 + (slot * 2 + pl) * T2);
-            }
-        }
+    // Weight ring.  Group g = the four planes of hidden step g -> slot g % 3; wave w brings piece w of each plane.  A lane's SOURCE offset inside a sub-tile never changes
+    // (rc_glds_piece's map: row, swizzled 16-byte chunk), the sub-tile's base is wave-uniform: base in SGPRs + one 32-bit lane offset per tile kind, nothing to compute per step.
+    uint32_t voff1, voff2;
+    {
+        constexpr int LPR = RB1 / 16, RPP = 1024 / RB1;
+        const int r1 = wave * RPP + lane / LPR;
+        voff1 = (uint32_t)(r1 * C + (((lane % LPR) ^ rc_swz<RB1>(r1)) << 3)) * 2u;
+        const int r2 = wave * 16 + (lane >> 2);
+        voff2 = (uint32_t)(r2 * p.Hd + (((lane & 3) ^ rc_swz<64>(r2)) << 3)) * 2u;
+    }
+    const char* gW1 = reinterpret_cast<const char*>(p.W1p);
+    const char* gW2 = reinterpret_cast<const char*>(p.W2p);
+    auto issue_group = [&](int g, int slot) __attribute__((always_inline)) {
+        const int gs = min(g, n - 1);
+        const char* b1p = gW1 + (long)gs * (32 * C * 2);
+        const char* b2p = gW2 + (long)gs * (32 * 2);
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        __builtin_amdgcn_global_load_lds(b1p + voff1, (lds_ptr)(sW1 + (slot * 2 + 0) * T1 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b1p + wplane * 2 + voff1, (lds_ptr)(sW1 + (slot * 2 + 1) * T1 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b2p + voff2, (lds_ptr)(sW2 + (slot * 2 + 0) * T2 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b2p + wplane * 2 + voff2, (lds_ptr)(sW2 + (slot * 2 + 1) * T2 + wave * 1024), 16, 0, 0);
     };
-    issue_group(0);
-    issue_group(1);
+    issue_group(0, 0);
+    issue_group(1, 1);
     for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     rc_bf16x8 xh[KB], xl[KB];
     rc_load_rows<C, LNP>(p.x, row, p.M, lhi, xh, xl, &p.ln);
@@ -458,12 +516,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         for (int r = 0; r < 16; ++r) yacc[cb][r] = 0.f;
     __syncthreads();                                   // sB1 visible (the group waits below cover the weight tiles)
 
-    for (int t = 0; t < n; ++t) {
+    // one hidden step; the ring slot is a compile-time constant (the loop below is unrolled by three), so every LDS address of a step is a loop-invariant register + an
+    // immediate: no address arithmetic per step
+    auto step = [&](auto slot_c, int t) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_c)::value;
         if (STORE && t > 0) RC_WAIT_VM(PPW + 4);       // group t landed (younger: group t + 1 and the four h stores of step t - 1)
         else RC_WAIT_VM(PPW);                          // group t landed (group t + 1 may still be in flight)
         RC_BARRIER();
-        issue_group(t + 2);                            // into the slot step t - 1 read
-        const int slot = t % 3;
+        issue_group(t + 2, (slot + 2) % 3);            // into the slot step t - 1 read
         const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
         const char* w2h = sW2 + (slot * 2) * T2; const char* w2l = w2h + T2;
         // u = bias + x W1s^T as D[hidden][token]: the accumulator starts from the bias quads
@@ -473,33 +533,49 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             const rc_f4 b4 = *reinterpret_cast<const rc_f4*>(sB1 + t * 32 + 8 * q + 4 * lhi);
             u[4 * q + 0] = b4.x; u[4 * q + 1] = b4.y; u[4 * q + 2] = b4.z; u[4 * q + 3] = b4.w;
         }
+#if RC_ABL != 2 && RC_ABL != 4
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const rc_bf16x8 ah = rc_frag<RB1>(w1h, l31, 2 * kb + lhi), al = rc_frag<RB1>(w1l, l31, 2 * kb + lhi);
             RC_MFMA3(u, ah, al, xh[kb], xl[kb]);
         }
-        float hv[16];
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] += __builtin_bit_cast(float, (uint32_t)xh[r & 3][0] << 16);        // ablation: no product 1
+#endif
+        uint32_t ph[8], pl[8];                          // hi / lo planes of the pairs (2 i, 2 i + 1) of this lane's 16 hidden values
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 v = make_float4(rc_gelu(u[4 * q + 0]), rc_gelu(u[4 * q + 1]), rc_gelu(u[4 * q + 2]), rc_gelu(u[4 * q + 3]));
-            if (DROP) {
-                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + t * 32 + 8 * q + 4 * lhi), p.thresh, p.inv_keep);
-                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
-            }
-            if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + t * 32 + 8 * q + 4 * lhi) = v; }
-            hv[4 * q + 0] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+            float hk[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+            if (DROP) rc_keep_sel4(mdvit_drop_bits_q(k1a, k1b, dq0 + t * 8 + 2 * q), thresh16, hki, 0.f, hk);
+#if RC_ABL == 1
+            const float h0 = u[4 * q + 0] * hk[0], h1 = u[4 * q + 1] * hk[1], h2 = u[4 * q + 2] * hk[2], h3 = u[4 * q + 3] * hk[3];      // ablation: no GELU
+#else
+            const float h0 = rc_gelu_k(u[4 * q + 0], hk[0]), h1 = rc_gelu_k(u[4 * q + 1], hk[1]), h2 = rc_gelu_k(u[4 * q + 2], hk[2]), h3 = rc_gelu_k(u[4 * q + 3], hk[3]);
+#endif
+            if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + t * 32 + 8 * q + 4 * lhi) = make_float4(h0, h1, h2, h3); }
+            rc_split2(h0, h1, ph[2 * q], pl[2 * q]);
+            rc_split2(h2, h3, ph[2 * q + 1], pl[2 * q + 1]);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            rc_u4 h, l;
-            rc_split8(hv + 8 * half, h, l);
-            const rc_bf16x8 hh = rc_natural_order(h), hl = rc_natural_order(l);
+            const rc_bf16x8 hh = __builtin_bit_cast(rc_bf16x8, (rc_u4{ph[4 * half], ph[4 * half + 1], ph[4 * half + 2], ph[4 * half + 3]}));
+            const rc_bf16x8 hl = __builtin_bit_cast(rc_bf16x8, (rc_u4{pl[4 * half], pl[4 * half + 1], pl[4 * half + 2], pl[4 * half + 3]}));
+#if RC_ABL != 3 && RC_ABL != 4
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const rc_bf16x8 ah = rc_frag<64>(w2h, cb * 32 + l31, 2 * half + lhi), al = rc_frag<64>(w2l, cb * 32 + l31, 2 * half + lhi);
+                const rc_bf16x8 ah = rc_frag_perm(w2h, cb * 32 + l31, half, lhi), al = rc_frag_perm(w2l, cb * 32 + l31, half, lhi);
                 RC_MFMA3(yacc[cb], ah, al, hh, hl);
             }
+#else
+            asm volatile("" ::"v"(hh), "v"(hl));       // ablation: no product 2
+#endif
         }
+    };
+    for (int t = 0; t < n; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < n) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < n) step(std::integral_constant<int, 2>{}, t + 2);
     }
     RC_WAIT_VM(0);                                     // the clamped dummy fetches of the last two steps
 
@@ -558,6 +634,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     uint32_t s0 = 0, s1 = 0;
     if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
     const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1;
+    const uint32_t dq0 = (uint32_t)((long)row * p.Hd + 4 * lhi) >> 2, thresh16 = p.thresh >> 16;      // dropout: this lane's first group index (Hd % 32 == 0)
+    const float hks = 0.5f * p.inv_keep, pks = 0.39894228040143268f * p.inv_keep;
     const long wplane = (long)p.Hd * C;
 
     auto issue_a = [&](int slot_s, int src_s, int pc) __attribute__((always_inline)) {       // pc in [0, 4 T1 / 1024): W1 hi, lo, W2^T hi, lo
@@ -621,29 +699,30 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const rc_bf16x8 ah = rc_frag<64>(hi, cb * 32 + l31, 2 * half + lhi), al = rc_frag<64>(lo, cb * 32 + l31, 2 * half + lhi);
+                const rc_bf16x8 ah = rc_frag_perm(hi, cb * 32 + l31, half, lhi), al = rc_frag_perm(lo, cb * 32 + l31, half, lhi);
                 RC_MFMA3(dxacc[cb], ah, al, dh[half], dl[half]);
             }
     };
     auto act = [&](int s, const rc_f32x16& u, const rc_f32x16& d, rc_bf16x8 (&dh)[2], rc_bf16x8 (&dl)[2]) __attribute__((always_inline)) {
-        float dv[16];
+        uint32_t ph[8], pl[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int hd = s * 32 + 8 * q + 4 * lhi;
-            float4 v = make_float4(d[4 * q + 0] * rc_gelu_grad(u[4 * q + 0]), d[4 * q + 1] * rc_gelu_grad(u[4 * q + 1]),
-                                   d[4 * q + 2] * rc_gelu_grad(u[4 * q + 2]), d[4 * q + 3] * rc_gelu_grad(u[4 * q + 3]));
+            float dm[4] = {d[4 * q + 0], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
             if (DROP) {
-                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
-                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+                bool keep[4];
+                mdvit_drop_keep4(mdvit_drop_bits_q(k1a, k1b, dq0 + s * 8 + 2 * q), thresh16, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dm[j] = keep[j] ? dm[j] : 0.f;
             }
-            dv[4 * q + 0] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+            const float g0 = rc_dgelu_k(u[4 * q + 0], dm[0], hks, pks), g1 = rc_dgelu_k(u[4 * q + 1], dm[1], hks, pks);
+            const float g2 = rc_dgelu_k(u[4 * q + 2], dm[2], hks, pks), g3 = rc_dgelu_k(u[4 * q + 3], dm[3], hks, pks);
+            rc_split2(g0, g1, ph[2 * q], pl[2 * q]);
+            rc_split2(g2, g3, ph[2 * q + 1], pl[2 * q + 1]);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            rc_u4 h, l;
-            rc_split8(dv + 8 * half, h, l);
-            dh[half] = rc_natural_order(h);
-            dl[half] = rc_natural_order(l);
+            dh[half] = __builtin_bit_cast(rc_bf16x8, (rc_u4{ph[4 * half], ph[4 * half + 1], ph[4 * half + 2], ph[4 * half + 3]}));
+            dl[half] = __builtin_bit_cast(rc_bf16x8, (rc_u4{pl[4 * half], pl[4 * half + 1], pl[4 * half + 2], pl[4 * half + 3]}));
         }
     };
 
@@ -767,6 +846,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) { aw1[cb][r] = 0.f; aw2[cb][r] = 0.f; }
     float db1 = 0.f;
+    const uint32_t drot = 8u * (lane & 3), thresh16 = p.thresh >> 16;
+    const float hks = 0.5f * p.inv_keep, pks = 0.39894228040143268f * p.inv_keep;
 
     // staging map: thread -> (token row tid >> 4, float4 column tid & 15)
     const int srow = tid >> 4, sc4 = tid & 15;
@@ -825,25 +906,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            float hv[8], dv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = 8 * ks + i;
-                const float uu = u[r];
-                float cdf, pdf;
-                rc_gelu_parts(uu, cdf, pdf);
-                float hval = uu * cdf, g = d[r] * fmaf(uu, pdf, cdf);
-                if (DROP) {
-                    const uint32_t w = rc_quad_bcast(hb[r & 3], r >> 2);
-                    const float ds = __builtin_rotateright32(w, 8u * (lane & 3)) >= p.thresh ? p.inv_keep : 0.0f;
-                    hval *= ds; g *= ds;
-                }
-                hv[i] = hval; dv[i] = g;
-                db1 += g;
-            }
             rc_u4 hh, hl, dh, dl;
-            rc_split8(hv, hh, hl);
-            rc_split8(dv, dh, dl);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {              // pairs of token rows (r, r + 1)
+                const int r = 8 * ks + 2 * i;
+                float hv[2], gv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float hk = 0.5f, dm = d[r + e];
+                    if (DROP) {
+                        // the word of row r comes from lane r >> 2 of the quad; this lane's hidden unit is element lane & 3 of the group: the top half of rotr(word, 8 (lane & 3))
+                        const uint32_t w = rc_quad_bcast(hb[(r + e) & 3], (r + e) >> 2);
+                        const bool keep = (__builtin_amdgcn_alignbit(w, w, drot) >> 16) >= thresh16;
+                        hk = keep ? hks : 0.f; dm = keep ? dm : 0.f;
+                    }
+                    rc_gelu_both_k(u[r + e], hk, dm, hks, pks, hv[e], gv[e]);
+                    db1 += gv[e];
+                }
+                uint32_t a0, a1, a2, a3;
+                rc_split2(hv[0], hv[1], a0, a1);
+                rc_split2(gv[0], gv[1], a2, a3);
+                hh[i] = a0; hl[i] = a1; dh[i] = a2; dl[i] = a3;
+            }
             const rc_bf16x8 hhf = __builtin_bit_cast(rc_bf16x8, hh), hlf = __builtin_bit_cast(rc_bf16x8, hl);
             const rc_bf16x8 dhf = __builtin_bit_cast(rc_bf16x8, dh), dlf = __builtin_bit_cast(rc_bf16x8, dl);
             const int t0 = 16 * ks + 4 * lhi;
@@ -1022,6 +1106,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     uint32_t s0 = 0, s1 = 0;
     if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
     const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1, k2a = p.k2a ^ s0, k2b = p.k2b + s1;
+    const uint32_t dq0 = (uint32_t)((long)row * p.Hd + 4 * g) >> 2, thresh16 = p.thresh >> 16;        // dropout: this lane's first group index (Hd % 32 == 0)
+    const float hki = 0.5f * p.inv_keep;
     const long wplane = (long)p.Hd * C;
     auto issue_group = [&](int gi) __attribute__((always_inline)) {
         const int gs = min(gi, n - 1), slot = gi % 3;
@@ -1057,7 +1143,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const int slot = t % 3;
         const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
         const char* w2h = sW2 + (slot * 2) * T2; const char* w2l = w2h + T2;
-        float hv[8];
+        rc_u4 hh4, hl4;
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
             const int hd = t * 32 + 16 * ht + 4 * g;              // this lane's four hidden units of the tile
@@ -1068,16 +1154,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 const rc_bf16x8 ah = rc16_frag<RB1>(w1h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w1l, 16 * ht + c16, 4 * ks + g);
                 RC16_MFMA3(u, ah, al, xh[ks], xl[ks]);
             }
-            float4 v = make_float4(rc_gelu(u[0]), rc_gelu(u[1]), rc_gelu(u[2]), rc_gelu(u[3]));
-            if (DROP) {
-                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
-                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
-            }
-            if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = v; }
-            hv[4 * ht + 0] = v.x; hv[4 * ht + 1] = v.y; hv[4 * ht + 2] = v.z; hv[4 * ht + 3] = v.w;
+            float hk[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+            if (DROP) rc_keep_sel4(mdvit_drop_bits_q(k1a, k1b, dq0 + t * 8 + 4 * ht), thresh16, hki, 0.f, hk);
+            const float h0 = rc_gelu_k(u[0], hk[0]), h1 = rc_gelu_k(u[1], hk[1]), h2 = rc_gelu_k(u[2], hk[2]), h3 = rc_gelu_k(u[3], hk[3]);
+            if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = make_float4(h0, h1, h2, h3); }
+            uint32_t a0, a1, a2, a3;
+            rc_split2(h0, h1, a0, a1);
+            rc_split2(h2, h3, a2, a3);
+            hh4[2 * ht] = a0; hl4[2 * ht] = a1; hh4[2 * ht + 1] = a2; hl4[2 * ht + 1] = a3;
         }
-        rc_u4 hh4, hl4;
-        rc_split8(hv, hh4, hl4);
         if (STORE && p.hbf && row < p.M) {         // the hi plane IS bf16(h): two 8-byte stores (the two 4-unit groups of this lane) instead of two 16-byte ones
             uint16_t* hb = reinterpret_cast<uint16_t*>(p.h) + (long)row * p.Hd + t * 32 + 4 * g;
             *reinterpret_cast<uint2*>(hb) = make_uint2(hh4[0], hh4[1]);
@@ -1138,6 +1223,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     uint32_t s0 = 0, s1 = 0;
     if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
     const uint32_t k1a = p.k1a ^ s0, k1b = p.k1b + s1;
+    const uint32_t dq0 = (uint32_t)((long)row * p.Hd + 4 * g) >> 2, thresh16 = p.thresh >> 16;
+    const float hks = 0.5f * p.inv_keep, pks = 0.39894228040143268f * p.inv_keep;
     const long wplane = (long)p.Hd * C;
     // group gi = the three weight sub-tiles of hidden step gi (past the end: the last step again, into the free slot -- the counted waits
     // below then see the same number of loads per group)
@@ -1181,7 +1268,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         const char* w1h = sW1 + (slot * 2) * T1; const char* w1l = w1h + T1;
         const char* w2h = sW2 + (slot * 2) * T1; const char* w2l = w2h + T1;
         const char* w3h = sW3 + (slot * 2) * T3; const char* w3l = w3h + T3;
-        float dv[8];
+        rc_u4 dh4, dl4;
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
             const int hd = t * 32 + 16 * ht + 4 * g;              // this lane's four hidden units of the tile
@@ -1197,16 +1284,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                 const rc_bf16x8 ah = rc16_frag<RB1>(w2h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w2l, 16 * ht + c16, 4 * ks + g);
                 RC16_MFMA3(d, ah, al, mh[ks], ml[ks]);
             }
-            float4 v = make_float4(d[0] * rc_gelu_grad(u[0]), d[1] * rc_gelu_grad(u[1]), d[2] * rc_gelu_grad(u[2]), d[3] * rc_gelu_grad(u[3]));
+            float dm[4] = {d[0], d[1], d[2], d[3]};
             if (DROP) {
-                const float4 ds = mdvit_drop_scale4(k1a, k1b, (uint32_t)((long)row * p.Hd + hd), p.thresh, p.inv_keep);
-                v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+                bool keep[4];
+                mdvit_drop_keep4(mdvit_drop_bits_q(k1a, k1b, dq0 + t * 8 + 4 * ht), thresh16, keep);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dm[j] = keep[j] ? dm[j] : 0.f;
             }
-            if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.du + (long)row * p.Hd + hd) = v; }
-            dv[4 * ht + 0] = v.x; dv[4 * ht + 1] = v.y; dv[4 * ht + 2] = v.z; dv[4 * ht + 3] = v.w;
+            const float g0 = rc_dgelu_k(u[0], dm[0], hks, pks), g1 = rc_dgelu_k(u[1], dm[1], hks, pks), g2 = rc_dgelu_k(u[2], dm[2], hks, pks), g3 = rc_dgelu_k(u[3], dm[3], hks, pks);
+            if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.du + (long)row * p.Hd + hd) = make_float4(g0, g1, g2, g3); }
+            uint32_t a0, a1, a2, a3;
+            rc_split2(g0, g1, a0, a1);
+            rc_split2(g2, g3, a2, a3);
+            dh4[2 * ht] = a0; dl4[2 * ht] = a1; dh4[2 * ht + 1] = a2; dl4[2 * ht + 1] = a3;
         }
-        rc_u4 dh4, dl4;
-        rc_split8(dv, dh4, dl4);
         if (STORE && p.hbf && row < p.M) {
             uint16_t* db = reinterpret_cast<uint16_t*>(p.du) + (long)row * p.Hd + t * 32 + 4 * g;
             *reinterpret_cast<uint2*>(db) = make_uint2(dh4[0], dh4[1]);
@@ -1382,7 +1473,7 @@ int rc_set_lds(const void* k, int bytes, bool (&flags)[64]) {
 void rc_fill(RcArgs& a, int M, int Hd, float drop_p, uint32_t k10, uint32_t k11, uint32_t k20, uint32_t k21, const uint32_t* seed) {
     a.M = M; a.Hd = Hd;
     a.drop = drop_p > 0.f; a.k1a = k10; a.k1b = k11; a.k2a = k20; a.k2b = k21;
-    a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = 1.f / (1.f - drop_p);
+    a.thresh = mdvit_drop_thresh(drop_p); a.inv_keep = 1.f / (1.f - drop_p);
     a.seed = seed;
 }
 
@@ -1687,7 +1778,7 @@ extern "C" int mdvit_linear_rc(const float* x, int64_t lda, const void* Wp, int6
     memset(&a, 0, sizeof(a));
     a.x = x; a.lda = lda; a.Wp = (const uint16_t*)Wp; a.wplane = wplane; a.bias = bias; a.y = y; a.ldc = ldc; a.residual = residual; a.ldr = ldr;
     a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.M = M; a.N = N;
-    a.k0 = key0; a.k1 = key1; a.thresh = (uint32_t)((double)drop_p * 4294967296.0); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.seed = drop_seed;
+    a.k0 = key0; a.k1 = key1; a.thresh = mdvit_drop_thresh(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.seed = drop_seed;
     const int smem = 3 * 2 * (32 * K * 2) + N * 4;
     hipStream_t s = (hipStream_t)stream;
     const bool full = residual != nullptr, drop = drop_p > 0.f;

@@ -735,7 +735,7 @@ int chan_grid(long M, int C, int max_blocks) {
 
 void fill_drop(ChanArgs& a, float p, uint32_t k0, uint32_t k1, int rows_per_sample) {
     a.drop_p = p; a.k0 = k0; a.k1 = k1;
-    a.thresh = (uint32_t)((double)p * 4294967296.0);
+    a.thresh = mdvit_drop_thresh(p);
     a.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
 }
@@ -793,7 +793,7 @@ extern "C" int mdvit_layernorm_bwd_masked(const float* dy, const float* x, const
                     "layernorm_bwd_masked: bad mask arguments");
     MDVIT_CHECK_ARG((long)M * C < (1L << 32), MDVIT_E_SHAPE, "layernorm_bwd_masked: dropout index space exceeds 2^32");
     LnMasked mk; memset(&mk, 0, sizeof(mk));
-    mk.out = dx_masked; mk.drop_p = drop_p; mk.k0 = key0; mk.k1 = key1; mk.thresh = (uint32_t)((double)drop_p * 4294967296.0);
+    mk.out = dx_masked; mk.drop_p = drop_p; mk.k0 = key0; mk.k1 = key1; mk.thresh = mdvit_drop_thresh(drop_p);
     mk.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; mk.rowscale = rowscale; mk.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; mk.seed = seed;
     return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
 }
@@ -808,7 +808,7 @@ int mdvit_layernorm_bwd_parts(const float* dy, const float* x, const float* gamm
     LnMasked mk; memset(&mk, 0, sizeof(mk));
     if (dx_masked) {
         MDVIT_CHECK_ARG((long)M * C < (1L << 32), MDVIT_E_SHAPE, "layernorm_bwd_parts: dropout index space exceeds 2^32");
-        mk.out = dx_masked; mk.drop_p = drop_p; mk.k0 = key0; mk.k1 = key1; mk.thresh = (uint32_t)((double)drop_p * 4294967296.0);
+        mk.out = dx_masked; mk.drop_p = drop_p; mk.k0 = key0; mk.k1 = key1; mk.thresh = mdvit_drop_thresh(drop_p);
         mk.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; mk.rowscale = rowscale; mk.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; mk.seed = seed;
     }
     float dummy;

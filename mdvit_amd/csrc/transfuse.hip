@@ -860,7 +860,7 @@ extern "C" int mdvit_patchify(const float* img, float* out, int32_t B, int32_t C
 extern "C" int mdvit_dropout2d(const float* x, float* y, int32_t B, int64_t P, int32_t C, float p, uint32_t key0, uint32_t key1, const uint32_t* drop_seed, void* stream) {
     MDVIT_CHECK_ARG(x && y && B > 0 && P > 0 && C > 0 && p >= 0.f && p < 1.f, MDVIT_E_SHAPE, "dropout2d: bad arguments");
     TF_LAUNCH(dropout2d_kernel, (tf_grid((long)B * P * C)), 256, 0, (hipStream_t)stream, x, y, (long)P, C, (long)B * P * C, key0, key1,
-              (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), drop_seed);
+              mdvit_drop_thresh(p), 1.f / (1.f - p), drop_seed);
     return MDVIT_OK;
 }
 static int tf_set_lds(const void* k, int& mask) {
