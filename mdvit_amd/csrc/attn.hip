@@ -48,13 +48,15 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
     // second read of q and G are gone from the full backward (it stays for the adapter-only call).
     constexpr int GW = CH < 32 ? 32 : CH, NB = (GW + 31) / 32, GQ = GW / 4;
     constexpr int STAGE = 2 * FA_T * GW, RED = 4 * NB * 32 * NB * 32;
-    __shared__ __attribute__((aligned(16))) float sm[(STAGE > RED ? STAGE : RED) + 3 * NB * 32];
+    __shared__ __attribute__((aligned(16))) float sm[(STAGE > RED ? STAGE : RED) + 3 * NB * 32 + (SOFTMAX ? 2 * 256 : 0)];
     float* xs = sm;                        // [FA_T][GW]
     float* ys = sm + FA_T * GW;            // [FA_T][GW]
     float* s_m = sm + (STAGE > RED ? STAGE : RED);     // running column max
     float* s_s = s_m + NB * 32;                        // running column exp-sum
     float* s_f = s_s + NB * 32;                        // this tile's rescale factor exp(m_old - m_new)
     float* s_e = s_s;                                  // !SOFTMAX: the workgroup's e sums (the softmax state is not used then)
+    float* s_pm = s_f + NB * 32;                       // SOFTMAX: [256 / GW token phases][GW] column maxima of the tile, and
+    float* s_ps = s_pm + 256;                          //          the running exp-sums per phase
     const int stile = blockIdx.x, c0 = blockIdx.y * GW, b = blockIdx.z;
     const int NTS = (NT + NSUB - 1) / NSUB;            // partial rows per image
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -66,29 +68,40 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (SOFTMAX && threadIdx.x < NB * 32) { s_m[threadIdx.x] = -INFINITY; s_s[threadIdx.x] = 0.f; s_f[threadIdx.x] = 1.f; }
+    if (SOFTMAX) s_ps[threadIdx.x] = 0.f;
     if (!SOFTMAX && e_part && threadIdx.x < NB * 32) s_e[threadIdx.x] = 0.f;
     constexpr int NVE = (FA_T * GQ + 255) / 256;
     float4 eacc[(!SOFTMAX) ? NVE : 1];                  // e sums of this thread's staging slots (slot v always carries channel quad (tid + 256 v) % GQ)
 #pragma unroll
     for (int v = 0; v < ((!SOFTMAX) ? NVE : 1); ++v) eacc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Round 5: the operands of sub-tile s + 1 are REQUESTED while sub-tile s is reduced (the loop was load -> LDS -> softmax -> MFMA, one exposed HBM round trip per
+    // 64 tokens at 2 workgroups per CU: 2.7 TB/s).  Loads are unconditional (clamped row, zeroed afterwards): a load under a branch drains the queue at the join.
+    constexpr int NV = (FA_T * GQ + 255) / 256;
+    float4 xv[NV], yv[NV], ov[(!SOFTMAX) ? NV : 1];
+    auto request = [&](int tile) __attribute__((always_inline)) {
+        const int n0r = min(tile, NT - 1) * FA_T;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = min((int)threadIdx.x + 256 * v, FA_T * GQ - 1), n = i / GQ, q = i % GQ;
+            const long tok = (long)b * g.N + min(n0r + n, g.N - 1);
+            xv[v] = *reinterpret_cast<const float4*>(X + tok * ldx + c0 + 4 * q);
+            yv[v] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0 + 4 * q);
+            if (!SOFTMAX && e_part) ov[v] = *reinterpret_cast<const float4*>(outp + tok * (long)g.C + c0 + 4 * q);
+        }
+    };
+    request(stile * NSUB);
     for (int sub = 0; sub < NSUB; ++sub) {
         const int tile = stile * NSUB + sub;
         if (tile >= NT) break;                         // (uniform)
         const int n0 = tile * FA_T, nt = min(FA_T, g.N - n0);
         // ---- stage (rows past the sequence end are zeros)
         {
-            constexpr int NV = (FA_T * GQ + 255) / 256;
-            float4 xv[NV], yv[NV], ov[(!SOFTMAX) ? NV : 1];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const int i = threadIdx.x + 256 * v, n = i / GQ, q = i % GQ;
-                xv[v] = make_float4(0.f, 0.f, 0.f, 0.f); yv[v] = xv[v];
-                if (!SOFTMAX) ov[v] = xv[v];
-                if (i < FA_T * GQ && n < nt) {
-                    const long tok = (long)b * g.N + n0 + n;
-                    xv[v] = *reinterpret_cast<const float4*>(X + tok * ldx + c0 + 4 * q);
-                    yv[v] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0 + 4 * q);
-                    if (!SOFTMAX && e_part) ov[v] = *reinterpret_cast<const float4*>(outp + tok * (long)g.C + c0 + 4 * q);
+                const int i = threadIdx.x + 256 * v, n = i / GQ;
+                if (!(i < FA_T * GQ && n < nt)) {
+                    xv[v] = make_float4(0.f, 0.f, 0.f, 0.f); yv[v] = xv[v];
+                    if (!SOFTMAX) ov[v] = xv[v];
                 }
             }
 #pragma unroll
@@ -114,28 +127,36 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
                 }
             }
         }
+        if (sub + 1 < NSUB) request(tile + 1);         // in flight across the softmax and the MFMAs of this sub-tile
         __syncthreads();
         if (SOFTMAX) {
-            // column max / exp over the tile's tokens against the RUNNING max: `per` threads per column
-            constexpr int per = GW <= 64 ? 4 : 2;
-            const int c = threadIdx.x / per, sb = threadIdx.x % per;
+            // Column max / exp over the tile's tokens against the RUNNING max.  Round 5: thread (column c = tid % GW, token phase sb = tid / GW) -- a 32-lane group reads 32
+            // consecutive columns of ONE token row: no bank conflicts.  (Before: c = tid / 4, sb = tid % 4 -- the four lanes of a column read four rows of the same bank,
+            // 4-way conflicts on ~48 LDS operations per thread and tile; the pass was half of the kernel's LDS time, fa_partial<8> at 2.7 TB/s.)  The column maxima of the PER
+            // token phases meet in LDS (one more barrier); the exp-sums stay per phase (each rescaled by the same factor) and are added once at the end.
+            constexpr int PER = 256 / GW;
+            const int c = threadIdx.x % GW, sb = threadIdx.x / GW;
+            const bool act = sb < PER;
             float m = -INFINITY;
-            if (c < GW)
-                for (int n = sb; n < nt; n += per) m = fmaxf(m, xs[n * GW + c]);
-            for (int o = 1; o < per; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-            const float m_old = c < GW ? s_m[c] : 0.f;
-            const float m_new = fmaxf(m_old, m);
-            float ssum = 0.f;
-            if (c < GW) {
-                for (int n = sb; n < nt; n += per) { const float e = expf(xs[n * GW + c] - m_new); xs[n * GW + c] = e; ssum += e; }
-                for (int n = nt + sb; n < FA_T; n += per) xs[n * GW + c] = 0.f;          // padded rows must not contribute exp(0 - m)
-            }
-            for (int o = 1; o < per; o <<= 1) ssum += __shfl_xor(ssum, o, 64);
-            if (c < GW && sb == 0) {
-                const float f = expf(m_old - m_new);                                      // 0 on the first tile (m_old = -inf)
-                s_f[c] = f; s_m[c] = m_new; s_s[c] = fmaf(s_s[c], f, ssum);
-            }
+            if (act)
+                for (int n = sb; n < nt; n += PER) m = fmaxf(m, xs[n * GW + c]);
+            if (act) s_pm[sb * GW + c] = m;
             __syncthreads();
+            float m_old = 0.f, m_new = 0.f;
+            if (act) {
+                m_old = s_m[c];
+                m_new = m_old;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) m_new = fmaxf(m_new, s_pm[j * GW + c]);
+                float ssum = 0.f;
+                for (int n = sb; n < nt; n += PER) { const float e = expf(xs[n * GW + c] - m_new); xs[n * GW + c] = e; ssum += e; }
+                for (int n = nt + sb; n < FA_T; n += PER) xs[n * GW + c] = 0.f;              // padded rows must not contribute exp(0 - m)
+                const float f = expf(m_old - m_new);                                          // 0 on the first tile (m_old = -inf)
+                s_ps[sb * GW + c] = fmaf(s_ps[sb * GW + c], f, ssum);
+                if (sb == 0) s_f[c] = f;
+            }
+            __syncthreads();                   // every phase has read s_m / s_pm
+            if (act && sb == 0) s_m[c] = m_new;
             if (sub > 0) {                 // rescale what the earlier tiles accumulated: rows c of the D[c][e] blocks
 #pragma unroll
                 for (int i = 0; i < NB; ++i)
@@ -166,9 +187,12 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
         }
         __syncthreads();                       // the operand tiles are dead: the next tile may be staged / the partial results may meet in LDS
     }
-    if (SOFTMAX && threadIdx.x < GW) {
+    if (SOFTMAX && threadIdx.x < GW) {           // (the tile loop ended with a barrier: s_m and the phase sums are final)
         const long o = ((long)b * NTS + stile) * g.C + c0 + threadIdx.x;
-        ws_m[o] = s_m[threadIdx.x]; ws_s[o] = s_s[threadIdx.x];
+        float ssum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 256 / GW; ++j) ssum += s_ps[j * GW + threadIdx.x];
+        ws_m[o] = s_m[threadIdx.x]; ws_s[o] = ssum;
     }
     if (!SOFTMAX && e_part) {                          // (the loop ended with a barrier; s_e was cleared before it)
 #pragma unroll
@@ -328,8 +352,10 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const float* __restric
 // The kernel is HBM-bound: reads dout, k, v, U, dVc, writes dq|dk|dv, each exactly once.
 typedef float fa_f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 2 : 1, CH <= 16 ? 2 : 1))) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+// MODE (round 5, A/B by mdvit_factoratt_config): 0 = a tile's rows requested right in front of it (round 4's order, U / dVc moved to the top of the tile);
+// 1 = the MFMA operand rows one tile ahead, two waves per SIMD; 2 = the same at ONE wave per SIMD (512 registers: nothing spills)
+template <int CH, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CH <= 16 && MODE != 2) ? 2 : 1, (CH <= 16 && MODE != 2) ? 2 : 1))) void fa_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
                                                            const float* __restrict__ U, const float* __restrict__ dVc,
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
@@ -382,19 +408,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 
     const int ntiles = (g.N + 31) / 32;
     const int tile_beg = blockIdx.x * tiles_per_block, tile_end = min(ntiles, tile_beg + tiles_per_block);
     const float inv_scale = 1.0f / g.scale;
-    for (int tile = tile_beg + wave; tile < tile_end; tile += 4) {
+    // Round 5: software prefetch.  The MFMA operand rows of a tile (dout, k, v) are requested one tile AHEAD and its epilogue rows (U, conv^T(dU)) at the top of the tile,
+    // all unconditionally (clamped token): they fly under the ~3000 cycles of MFMAs in front of their use; before, every tile paid its own load round trip in front of its
+    // first MFMA and a second one (U, dVc -- loaded under `if (ok)`) behind its last: 2.4-2.9 TB/s.  Two register sets alternate (the loop body holds two tiles: no copies).
+    struct Rows { float4 g[NQ], k[NQ], v[NQ]; };
+    auto request = [&](Rows& r, int tile) __attribute__((always_inline)) {
+        const long tok = (long)b * g.N + min(tile * 32 + t, g.N - 1);
+        const float* grow = dout + tok * C + g0;
+        const float* krow = qkv + tok * C3 + C + g0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
+            r.g[q] = *reinterpret_cast<const float4*>(grow + cq);
+            r.k[q] = *reinterpret_cast<const float4*>(krow + cq);
+            r.v[q] = *reinterpret_cast<const float4*>(krow + C + cq);
+        }
+    };
+    auto compute = [&](const Rows& r, int tile) __attribute__((always_inline)) {
         const int n = tile * 32 + t;
         const bool ok = n < g.N;
         const long tok = (long)b * g.N + (ok ? n : g.N - 1);
-        const float* grow = dout + tok * C + g0;
-        const float* krow = qkv + tok * C3 + C + g0;
+        float4 ru[NQ], rc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
+            ru[q] = *reinterpret_cast<const float4*>(U + tok * C + g0 + cq);
+            rc[q] = *reinterpret_cast<const float4*>(dVc + tok * C + g0 + cq);
+        }
         float dfa[NQ][4], vv[NQ][4], pp[NQ][4];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
-            const float4 g4 = *reinterpret_cast<const float4*>(grow + cq);
-            const float4 k4 = *reinterpret_cast<const float4*>(krow + cq);
-            const float4 v4 = *reinterpret_cast<const float4*>(krow + C + cq);
+            const float4 g4 = r.g[q], k4 = r.k[q], v4 = r.v[q];
             const float4 a4 = *reinterpret_cast<const float4*>(s_a + cq);
             const float4 m4 = *reinterpret_cast<const float4*>(s_km + cq);
             const float4 i4 = *reinterpret_cast<const float4*>(s_ks + cq);
@@ -409,7 +454,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc1[ob][r] = 0.f; acc2[ob][r] = 0.f; acc3[ob][r] = 0.f; }
+            for (int rr = 0; rr < 16; ++rr) { acc1[ob][rr] = 0.f; acc2[ob][rr] = 0.f; acc3[ob][rr] = 0.f; }
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
             const int orow = 32 * ob + t;                       // W row (output channel) this lane feeds
@@ -427,15 +472,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 
             }
         }
         if (ok) {
-            const float* urow = U + tok * C + g0;
-            const float* crow = dVc + tok * C + g0;
             float* drow = dqkv + tok * C3 + g0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int ob = q / 4, r0 = 4 * (q % 4);
                 const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
-                const float4 u4 = *reinterpret_cast<const float4*>(urow + cq);
-                const float4 c4 = *reinterpret_cast<const float4*>(crow + cq);
+                const float4 u4 = ru[q], c4 = rc[q];
                 const float4 t4 = *reinterpret_cast<const float4*>(s_tc + cq);
                 float4 dq, dk, dv;
                 dq.x = fmaf(dfa[q][0] * inv_scale, u4.x, acc1[ob][r0 + 0]); dq.y = fmaf(dfa[q][1] * inv_scale, u4.y, acc1[ob][r0 + 1]);
@@ -448,6 +490,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH <= 16 ? 
                 *reinterpret_cast<float4*>(drow + C + cq) = dk;
                 *reinterpret_cast<float4*>(drow + 2 * C + cq) = dv;
             }
+        }
+    };
+    Rows ra, rb;
+    int tile = tile_beg + wave;
+    if (MODE == 0) {
+        for (; tile < tile_end; tile += 4) { request(ra, tile); compute(ra, tile); }
+        return;
+    }
+    if (tile < tile_end) request(ra, tile);
+    for (; tile < tile_end; tile += 8) {
+        request(rb, min(tile + 4, ntiles - 1));
+        compute(ra, tile);
+        if (tile + 4 < tile_end) {
+            request(ra, min(tile + 8, ntiles - 1));
+            compute(rb, tile + 4);
         }
     }
 }
@@ -464,20 +521,31 @@ __device__ __forceinline__ void fa_apply3_tiles(const float* __restrict__ dout, 
     const int ntiles = (g.N + 31) / 32;
     const int tile_beg = blockIdx.x * tiles_per_block, tile_end = min(ntiles, tile_beg + tiles_per_block);
     const float inv_scale = 1.0f / g.scale;
-    for (int tile = tile_beg + slot; tile < tile_end; tile += 2) {
+    // Round 5: the tile's two operand rows are requested one tile AHEAD (unconditional, clamped token) and fly under the MFMAs of the tile in front of them -- the per-tile chain
+    // load -> exp -> CH / 2 dependent MFMAs -> store had nothing to overlap with (profiles/r04_fa_bwd_apply3_pmc_stalls.txt: a wave waited 65 % of its life)
+    struct Rows { float4 a[NQ], b[NQ]; };
+    auto request = [&](Rows& r, int tile) __attribute__((always_inline)) {
+        const long tok = (long)b * g.N + min(tile * 32 + t, g.N - 1);
+        // A: dout | k | k;  B: U | v | conv^T(dU)
+        const float* arow = ROLE == 0 ? dout + tok * C + g0 : qkv + tok * C3 + C + g0;
+        const float* brow = ROLE == 0 ? U + tok * C + g0 : (ROLE == 1 ? qkv + tok * C3 + 2 * C + g0 : dVc + tok * C + g0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
+            r.a[q] = *reinterpret_cast<const float4*>(arow + cq);
+            r.b[q] = *reinterpret_cast<const float4*>(brow + cq);
+        }
+    };
+    auto compute = [&](const Rows& r, int tile) __attribute__((always_inline)) {
         const int n = tile * 32 + t;
         const bool ok = n < g.N;
         const float z = ok ? 1.f : 0.f;                  // out-of-range tokens contribute zeros (their results are not stored)
         const long tok = (long)b * g.N + (ok ? n : g.N - 1);
-        // A: dout | k | k;  B: U | v | conv^T(dU)
-        const float* arow = ROLE == 0 ? dout + tok * C + g0 : qkv + tok * C3 + C + g0;
-        const float* brow = ROLE == 0 ? U + tok * C + g0 : (ROLE == 1 ? qkv + tok * C3 + 2 * C + g0 : dVc + tok * C + g0);
         float xo[NQ][4], el[NQ][4];                      // the product's token operand; its element-wise companion
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int cq = 32 * (q / 4) + 8 * (q % 4) + 4 * half;
-            const float4 a4 = *reinterpret_cast<const float4*>(arow + cq);
-            const float4 b4 = *reinterpret_cast<const float4*>(brow + cq);
+            const float4 a4 = r.a[q], b4 = r.b[q];
             if (ROLE == 0) {
                 const float4 s4 = *reinterpret_cast<const float4*>(s_a + cq);
                 xo[q][0] = z * g.scale * s4.x * a4.x; xo[q][1] = z * g.scale * s4.y * a4.y;
@@ -501,7 +569,9 @@ __device__ __forceinline__ void fa_apply3_tiles(const float* __restrict__ dout, 
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
+            for (int rr = 0; rr < 16; ++rr) acc[ob][rr] = 0.f;
+        // (the matrix elements are re-read from LDS for every tile: hoisted out of the tile loop -- NB x CH / 2 registers -- they and the prefetched rows do not fit)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
             const int orow = 32 * ob + t;
@@ -536,6 +606,17 @@ __device__ __forceinline__ void fa_apply3_tiles(const float* __restrict__ dout, 
                 }
                 *reinterpret_cast<float4*>(drow + cq) = d;
             }
+        }
+    };
+    Rows ra, rb;
+    int tile = tile_beg + slot;
+    if (tile < tile_end) request(ra, tile);
+    for (; tile < tile_end; tile += 4) {
+        request(rb, min(tile + 2, ntiles - 1));
+        compute(ra, tile);
+        if (tile + 2 < tile_end) {
+            request(ra, min(tile + 4, ntiles - 1));
+            compute(rb, tile + 2);
         }
     }
 }
@@ -745,6 +826,16 @@ int quad_grid(long work_quads, int QC, int max_blocks) {
 
 }  // namespace
 
+// fa_bwd_apply_kernel's MODE (tuning hook: mdvit_factoratt_config).  Measured at 32 images (tools/probe/attn_kernel_trace.sh, profiles/r05_attn_kernels_isolated.txt): Ch = 8 / 16
+// 269 / 145 us in mode 0, 460 / 240 us in mode 1 (60 registers spill), 386 / 213 us in mode 2 (4 waves per CU): a wave of these launches owns 2 tiles (the grid is kept >= 2048
+// workgroups), nothing to prefetch across; the row-ahead order pays in fa_bwd_apply3_kernel, whose waves walk 4 tiles (Ch = 64: 79 -> 43 us).
+int g_fa_apply_mode = 0;
+extern "C" int mdvit_factoratt_config(int32_t apply_mode) {
+    if (apply_mode < 0 || apply_mode > 2) return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_config: apply_mode in 0..2");
+    g_fa_apply_mode = apply_mode;
+    return MDVIT_OK;
+}
+
 extern "C" size_t mdvit_factoratt_ws_bytes(int32_t B, int32_t N, int32_t C, int32_t heads) {
     if (B <= 0 || N <= 0 || C <= 0 || heads <= 0 || C % heads) return 0;
     return fa_ws_floats(B, N, C, heads) * sizeof(float);
@@ -902,10 +993,14 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     int tpb = 4;                                   // 32-token tiles per block (one per wavefront), doubled while the grid stays large
     while (tpb < 64 && (long)cdiv(ntiles, tpb * 2) * (C / GW) * B >= 2048) tpb *= 2;
     dim3 grid(cdiv(ntiles, tpb), C / GW, B);
-#define FA_BWD_LAUNCH(CHV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV>), grid, dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb)
-    switch (Ch) {
-        case 8: FA_BWD_LAUNCH(8); break;
-        case 16: FA_BWD_LAUNCH(16); break;
+#define FA_BWD_LAUNCH(CHV, MODEV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV, MODEV>), grid, dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb)
+    switch (Ch * 4 + g_fa_apply_mode) {
+        case 8 * 4 + 0: FA_BWD_LAUNCH(8, 0); break;
+        case 8 * 4 + 1: FA_BWD_LAUNCH(8, 1); break;
+        case 8 * 4 + 2: FA_BWD_LAUNCH(8, 2); break;
+        case 16 * 4 + 0: FA_BWD_LAUNCH(16, 0); break;
+        case 16 * 4 + 1: FA_BWD_LAUNCH(16, 1); break;
+        case 16 * 4 + 2: FA_BWD_LAUNCH(16, 2); break;
         default: return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_bwd: head dim %d not built (8/16/40/64)", Ch);
     }
 #undef FA_BWD_LAUNCH
