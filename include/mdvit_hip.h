@@ -309,7 +309,7 @@ size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
 int mdvit_mlp_rc_config(int32_t fwd_variant);
 /* tuning hook (tools/attn_time.py --apply-mode): how the attention backward's apply kernel (Ch = 8 / 16) orders its loads -- 0: each 32-token tile's rows in front of
  * the tile (default), 1: the MFMA operand rows one tile ahead at two waves per SIMD, 2: the same at one wave per SIMD.  Same arithmetic in every mode. */
-int mdvit_factoratt_config(int32_t apply_mode);
+int mdvit_factoratt_config(int32_t apply_mode, int32_t apply_tiles /* 32-token tiles per workgroup of the apply kernels; 0: the launcher's rule */);
 int mdvit_mlp_rc_wgrad(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, float* dW1, float* db1, float* dW2,
                        void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t hidden, float drop_p, uint32_t key1_0, uint32_t key1_1,
                        const uint32_t* drop_seed, int32_t accumulate, void* stream);

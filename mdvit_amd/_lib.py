@@ -109,7 +109,7 @@ _SIGS = {
     "mdvit_gemm_ph_prefers_epi": [i32, i32, i32, i32, i32],
     "mdvit_mlp_config": [i32, i32],
     "mdvit_mlp_rc_config": [i32],
-    "mdvit_factoratt_config": [i32],
+    "mdvit_factoratt_config": [i32, i32],
     "mdvit_mlp_rc_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
     "mdvit_linear_rc": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, f32, u32, u32, vp, i32, vp, i64, vp, vp],
     "mdvit_linear_rc_ln": [vp, vp, vp, i32, f32, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, vp],

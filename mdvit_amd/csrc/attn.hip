@@ -830,9 +830,10 @@ int quad_grid(long work_quads, int QC, int max_blocks) {
 // 269 / 145 us in mode 0, 460 / 240 us in mode 1 (60 registers spill), 386 / 213 us in mode 2 (4 waves per CU): a wave of these launches owns 2 tiles (the grid is kept >= 2048
 // workgroups), nothing to prefetch across; the row-ahead order pays in fa_bwd_apply3_kernel, whose waves walk 4 tiles (Ch = 64: 79 -> 43 us).
 int g_fa_apply_mode = 0;
-extern "C" int mdvit_factoratt_config(int32_t apply_mode) {
-    if (apply_mode < 0 || apply_mode > 2) return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_config: apply_mode in 0..2");
-    g_fa_apply_mode = apply_mode;
+int g_fa_apply_tiles = 0;       // 32-token tiles per workgroup of the apply kernels (0: the launcher's rule)
+extern "C" int mdvit_factoratt_config(int32_t apply_mode, int32_t apply_tiles) {
+    if (apply_mode < 0 || apply_mode > 2 || apply_tiles < 0) return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_config: apply_mode in 0..2, apply_tiles >= 0");
+    g_fa_apply_mode = apply_mode; g_fa_apply_tiles = apply_tiles;
     return MDVIT_OK;
 }
 
@@ -983,6 +984,7 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         // (measured at 32 images, C = 320 / 512: 2 tiles 227 / 157 us, 4: 163 / 97, 8: 144 / 71, 32: 140 / 71)
         int tpb = 8;
         while (tpb > 2 && (long)cdiv(ntiles, tpb) * (C / GW) * B < 256) tpb /= 2;
+        if (g_fa_apply_tiles > 0) tpb = g_fa_apply_tiles;
         dim3 grid(cdiv(ntiles, tpb), C / GW, B);
         if (Ch == 40) hipLaunchKernelGGL((fa_bwd_apply3_kernel<40>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb);
         else if (Ch == 64) hipLaunchKernelGGL((fa_bwd_apply3_kernel<64>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb);
@@ -992,6 +994,7 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     }
     int tpb = 4;                                   // 32-token tiles per block (one per wavefront), doubled while the grid stays large
     while (tpb < 64 && (long)cdiv(ntiles, tpb * 2) * (C / GW) * B >= 2048) tpb *= 2;
+    if (g_fa_apply_tiles > 0) tpb = g_fa_apply_tiles;
     dim3 grid(cdiv(ntiles, tpb), C / GW, B);
 #define FA_BWD_LAUNCH(CHV, MODEV) hipLaunchKernelGGL((fa_bwd_apply_kernel<CHV, MODEV>), grid, dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb)
     switch (Ch * 4 + g_fa_apply_mode) {

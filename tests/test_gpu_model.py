@@ -1028,6 +1028,72 @@ def test_bench_step_gradients_are_reproducible_run_to_run(two_stream):
     assert max(worst)[0] <= 1e-5, f"gradients differ between identical runs: {worst}"
 
 
+def _repeat_step(make_model, batches, fuse, repeats=3, drop_seeded=False):
+    """`repeats` fresh models from one seed through the bench step; the largest relative L2 difference of any gradient tensor against the first run, and its name"""
+    import itertools
+    from mdvit_amd import ops
+    res = []
+    for _ in range(repeats):
+        ops._key_counter = itertools.count(5)          # the same dropout keys in every run
+        torch.manual_seed(1234)                         # the same DropPath draws
+        m = make_model()
+        res.append(_bench_step(m, batches, fuse, True))
+        del m
+        torch.cuda.empty_cache()
+    l0, g0 = res[0]
+    big = max(float(g0[n].double().norm()) for n in g0)
+    worst = (0.0, "")
+    for l, g in res[1:]:
+        for k in ("loss", "aux_loss", "kt_loss"):
+            assert abs(l[k] - l0[k]) <= 1e-6 * abs(l0[k]), (k, l[k], l0[k])
+        # (a bias in front of a BatchNorm has a zero gradient in exact arithmetic: such tensors hold round-off only and are left out, as in the probe)
+        worst = max(worst, max((float((g[n].double() - g0[n].double()).norm()) / float(g0[n].double().norm()), n) for n in g0 if float(g0[n].double().norm()) > 1e-5 * big))
+    return worst
+
+
+@pytest.mark.parametrize("config", ["bs32", "bf16_mode", "dropout", "MDViT_DSN", "MLP", "DeepLabV3", "Transformer"])
+def test_step_gradients_are_reproducible_in_the_other_configurations(config):
+    """the run-to-run guard of test_bench_step_gradients_are_reproducible_run_to_run where the risk is -- every configuration
+    tools/probe/step_determinism.py checked once by hand in round 4, now in the suite: the 128-image fused step (configs[2] per GPU; skipped below 200 GB of device
+    memory), the bf16 mode (its own GEMM kernels and bf16 saved tensors), the dropout / DropPath kernel variants (masks re-keyed identically per run), MDViT_DSN and
+    the MLP / DeepLabV3 / Transformer peer heads -- each three times from one seed with the aux sweep on its own stream and the weight gradients on the side stream,
+    every gradient tensor within 1e-5 relative L2 of the first run.  Every new asynchronous structure (LDS-DMA ring, stream fork) is a new chance of the class of
+    bug round 4 found twice; this is where it would show."""
+    import mdvit_amd
+    from mdvit_amd import ops, train
+    from mdvit_amd.synthetic import make_step_batches
+    bs, size, decoder, drop = 4, 512, "MLPFM", 0.0
+    if config == "bs32":
+        if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
+            pytest.skip("the 128-image step needs ~150 GB")
+        bs = 32
+    elif config == "dropout":
+        drop = 0.1
+    elif config in ("MLP", "DeepLabV3", "Transformer"):
+        decoder = config
+    batches = make_step_batches(bs, size, rank=0, step=0, device=dev())
+
+    def make_model():
+        if config == "MDViT_DSN":
+            torch.manual_seed(7)                        # MDViT_DSN: domain-specific norms, random init from one torch seed
+            m = mdvit_amd.MDViT_DSN(img_size=size, drop_rate=0.0, drop_path_rate=0.0, conv_norm=torch.nn.BatchNorm2d, adapt_method="Sup", num_domains=4,
+                                    decoder_name="MLPFM").to(dev()).train()
+            torch.manual_seed(1234)
+            return m
+        return build_mdvit(23, size, drop=drop, decoder_name=decoder).train()
+
+    old_two, old_prec = train._two_stream_sweeps, ops.gemm_precision()
+    train._two_stream_sweeps = True
+    if config == "bf16_mode":
+        ops.set_gemm_precision("bf16")
+    try:
+        worst = _repeat_step(make_model, batches, 4)
+    finally:
+        train._two_stream_sweeps = old_two
+        ops.set_gemm_precision(old_prec)
+    assert worst[0] <= 1e-5, f"{config}: gradients differ between identical runs: {worst}"
+
+
 def test_bench_step_fused_forward_equals_per_domain_at_512():
     """The exact bench step (4 domains x bs=4, 512x512, ONE 16-image domain-batched forward, merged sweeps, weight gradients on the
     side stream straight into the bucket sinks) == four per-domain forwards with the same weights: the three losses and every

@@ -424,6 +424,36 @@ def test_transfuse_bench_step_32_images_fused_equals_per_domain_at_bs8():
     assert not bad, bad[:8]
 
 
+def test_transfuse_bench_step_gradients_are_reproducible_run_to_run():
+    """the 32-image TransFuse_S_adapt bench step (its CNN branch runs on a stream of its own, weight gradients on the side stream into the
+    buckets) three times from one seed: every gradient tensor within 1e-5 relative L2 of the first run (round 4 measured it bit-identical run to run by hand,
+    tools/probe/step_determinism.py transfuse)."""
+    from mdvit_amd import ops
+    from mdvit_amd.parallel import GradAccumulator
+    from mdvit_amd.transfuse import transfuse_train_step
+    from oracle.gen_golden import synth_image, synth_label
+    B, S = 8, 256
+    batches = [(synth_image(5200 + d, B, S, S).to(dev()), synth_label(5300 + d, B, S, S).to(dev()), torch.full((B,), d, dtype=torch.long)) for d in range(4)]
+    res = []
+    for _ in range(3):
+        m, _unused = _build(11)
+        m.train()
+        acc = GradAccumulator(m.parameters()); acc.attach_sinks(); ops.enable_side_stream(True)
+        try:
+            transfuse_train_step(m, batches, accumulator=acc, fuse_domains=True)
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            res.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            ops.enable_side_stream(False); ops.set_grad_sinks(None)
+        del m, acc
+        torch.cuda.empty_cache()
+    big = max(float(v.double().norm()) for v in res[0].values())
+    worst = max((float((g[n].double() - res[0][n].double()).norm()) / float(res[0][n].double().norm()), n)
+                for g in res[1:] for n in res[0] if float(res[0][n].double().norm()) > 1e-5 * big)
+    assert worst[0] <= 1e-5, f"gradients differ between identical runs: {worst}"
+
+
 def test_transfuse_thirty_steps_on_one_batch_drive_the_loss_down():
     """end to end with everything the bench uses: domain-batched forward, implicit-GEMM convolutions, MFMA attention, weight gradients on
     the side stream straight into the buckets, the one-launch AdamW -- the summed structure loss of a fixed batch must fall and stay finite"""

@@ -71,9 +71,10 @@ if __name__ == "__main__":
     ap.add_argument("--stages", default="0,1,2,3")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--apply-tiles", type=int, default=0, help="32-token tiles per workgroup of the apply kernels (0: the launcher's rule)")
     ap.add_argument("--apply-mode", type=int, default=-1, help="mdvit_factoratt_config (load order of the backward's apply kernel, Ch = 8 / 16)")
     args = ap.parse_args()
     if args.apply_mode >= 0:
-        call("mdvit_factoratt_config", args.apply_mode)
+        call("mdvit_factoratt_config", args.apply_mode, args.apply_tiles)
     for s in (int(v) for v in args.stages.split(",")):
         run(s, args.batch, args.iters, args.warmup)
