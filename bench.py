@@ -180,9 +180,13 @@ def cpu_baseline(size: int, budget_s: float = 40.0):
         return tm.get("fwd_ms", 0.0), tm.get("bwd_ms", 0.0)
 
     base = timed(base_step, 4)
-    return {"value": mdvit["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
+    # `value` = the leg with the GPU headline's own workload (BASELINE configs[1]: 4 domains x bs=4) when it ran; the 1-image leg otherwise (the 1-image
+    # figure is the SLOWER of the two per image -- 0.137 against 0.233 images/s on the same 64 threads)
+    head = cfg2 if (cfg2 and "images_per_s" in cfg2) else None
+    return {"value": head["images_per_s"] if head else mdvit["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
             "cpu_model": _cpu_model(), "physical_cores": phys, "logical_cpus": os.cpu_count(),
-            "sample": f"MDViT Sup: 1 domain x 1 image {size}x{size}, fwd + BCE/Dice/KT + two-sweep bwd, fp32 torch CPU oracle, "
+            "sample": (head["sample"] + f", fp32 torch CPU oracle, {head['step_s']} s") if head else
+                      f"MDViT Sup: 1 domain x 1 image {size}x{size}, fwd + BCE/Dice/KT + two-sweep bwd, fp32 torch CPU oracle, "
                       f"{mdvit['warmup']} warm-up + {mdvit['timed']} timed steps, median {mdvit['median_step_s']} s",
             "mdvit_1img": mdvit, "mdvit_1img_all_physical_cores": mdvit_all, "mdvit_cfg2_4x4": cfg2,
             "base_bs4": dict(base, sample=f"BASELINE configs[0]: BASE bs=4 {size}x{size}, 1 domain, fwd + BCE/Dice + bwd, "
@@ -437,6 +441,21 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     table = ops.kernel_events_end() if use_events else {}
+    # one more, untimed step under the library's GEMM launch ledger: EVERY mdvit_gemm_f32 call of a step by kernel symbol -- the C-level block entry's included, which the
+    # event sampler above never sees -- so that the roofline line's launch count / bytes per launch and the committed rocprofv3 average describe one launch population
+    ledger = {}
+    if use_events and table:
+        import ctypes as _C
+        from mdvit_amd import _lib as _L
+        _L.call("mdvit_gemm_ledger", 1)
+        step(args.warmup + args.steps)
+        fence()
+        _L.call("mdvit_gemm_ledger", 0)
+        nm, nl, fl, by = _C.create_string_buffer(160), _C.c_int64(), _C.c_double(), _C.c_double()
+        i = 0
+        while _L.load().mdvit_gemm_ledger_read(i, nm, 160, _C.byref(nl), _C.byref(fl), _C.byref(by)) == 0:
+            ledger[nm.value.decode()] = {"launches": int(nl.value), "flop": float(fl.value), "bytes": float(by.value)}
+            i += 1
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -492,11 +511,18 @@ def main():
             else:
                 roof = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": round(peak_mfma, 1), "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
             launches = rec.get("launches", rec["n"])
+            led = ledger.get(name.split("+")[0].split(" M=")[0])
             rp_us = _rocprof_avg_us(name, args.model) if (args.model != "mdvit" or default_leg) else None
-            if rp_us:
-                rp_gbs, rp_tf = rec["bytes"] / rec["n"] / (rp_us * 1e-6) / 1e9, rec["flop"] / rec["n"] / (rp_us * 1e-6) / 1e12
+            if rp_us and led:
+                # rocprofv3's average runs over ALL launches of this symbol in a step; so do the ledger's bytes / flops per launch (round 4 divided the event SAMPLE's
+                # bytes by it: two populations -- the sample never holds the block entry's launches)
+                rp_gbs, rp_tf = led["bytes"] / led["launches"] / (rp_us * 1e-6) / 1e9, led["flop"] / led["launches"] / (rp_us * 1e-6) / 1e12
                 roof["frac_rocprof"] = round(rp_gbs / PEAK_HBM_GBS if roof["bound"] == "hbm" else rp_tf / peak_mfma, 4)
                 roof["frac_live"] = roof["frac"]
+            if led:
+                roof["all_launches_per_step"] = led["launches"]
+                roof["algorithmic_bytes_per_launch_all"] = round(led["bytes"] / led["launches"])
+                roof["flop_per_launch_all"] = round(led["flop"] / led["launches"])
             roof["traffic_source"] = ("profiles/pmc_traffic.json: HBM bytes per launch of this kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "command (FETCH x2, gfx950) -- read from the file, NOT measured in this run") if default_leg else \
                 "none: the committed --pmc passes ran the default MDViT bs=4 command, not this leg"
@@ -505,7 +531,9 @@ def main():
                          "timer": rec.get("timer"),
                          "rocprof_avg_launch_us": rp_us,
                          "flop_per_launch": round(rec["flop"] / rec["n"]), "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["n"]),
-                         "mfma_tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "share_of_step": round(secs * 1e3 * launches / rec["n"] / (dt * 1e3), 4)})
+                         "mfma_tflops": round(tf, 2), "hbm_gbs": round(gbs, 1),
+                         # the symbol's share of the step: its live average x EVERY launch of it in a step (the ledger's count; the event-visible count without one)
+                         "share_of_step": round(secs / rec["n"] * (led["launches"] if led else launches / args.steps) / (dt / args.steps), 4)})
             if args.detail:
                 with open(args.detail, "w") as f:
                     json.dump({"step_ms": dt * 1e3 / args.steps, "kernels": table}, f, indent=1)
@@ -578,7 +606,10 @@ def main():
                         "bound": big["bound"], "achieved_GBps": round(big["hbm_GBps"], 1), "frac_hbm": round(big["frac_hbm"], 4),
                         "achieved_useful_TFLOPs": round(big["useful_TFLOPs"], 1), "frac_mfma_bf16x3": round(big["frac_mfma_bf16x3"], 4),
                         "all_mlp_kernels": [{"kernel": r_["kernel"], "us": round(r_["us"], 1), "frac_hbm": round(r_["frac_hbm"], 4), "frac_mfma_bf16x3": round(r_["frac_mfma_bf16x3"], 4)}
-                                            for r_ in blk["stage0_mlp_kernels"]["kernels"]]}
+                                            for r_ in blk["stage0_mlp_kernels"]["kernels"]],
+                        # the other half of the named block: the attention core's two passes at the same shape (tools/block_roofline.py: stage0_attention_core)
+                        "attention_core": [{"kernel": r_["kernel"], "us": round(r_["us"], 1), "algorithmic_bytes": round(r_["algorithmic_bytes"]), "frac_hbm": round(r_["frac_hbm"], 4)}
+                                           for r_ in blk.get("stage0_attention_core", {}).get("passes", [])]}
                 os.remove(blk_json)
             except Exception as e:
                 extra["block_bs32"] = {"error": repr(e)}

@@ -306,6 +306,11 @@ int mdvit_mlp_rc16_dgrad_hbf16(const float* gm, const float* x, const void* W1p,
                                int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
 size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
 /* tuning hook (tools/mlp_rc_check.py): forward kernel variant -- 2: software-pipelined waves at 2 per SIMD, 3: plain waves at 3 per SIMD */
+/* Launch ledger of mdvit_gemm_f32 (measurement only, off by default; bench.py's roofline line): mdvit_gemm_ledger(1) clears and starts it, (0) stops it; while on, every
+ * mdvit_gemm_f32 call -- those of mdvit_block_fwd / _bwd included -- is counted under the kernel symbol it launches (mdvit_gemm_kernel_name, main kernel) with its algorithmic
+ * flops 2 M N K and bytes 4 (M K + N K + M N (1 + extra outputs / epilogue operands)).  mdvit_gemm_ledger_read(i, ...) returns row i, MDVIT_E_SHAPE past the last row. */
+int mdvit_gemm_ledger(int32_t enable);
+int mdvit_gemm_ledger_read(int32_t index, char* name, int32_t cap, int64_t* launches, double* flop, double* bytes);
 int mdvit_mlp_rc_config(int32_t fwd_variant);
 /* tuning hook (tools/attn_time.py --apply-mode): how the attention backward's apply kernel (Ch = 8 / 16) orders its loads -- 0: each 32-token tile's rows in front of
  * the tile (default), 1: the MFMA operand rows one tile ahead at two waves per SIMD, 2: the same at one wave per SIMD.  Same arithmetic in every mode. */

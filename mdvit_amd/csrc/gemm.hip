@@ -284,10 +284,56 @@ size_t mdvit_gemm_tn_ws_bytes(const MdvitGemmDesc* d);
 void mdvit_gemm_tn_plan(const MdvitGemmDesc* d, int* tile_m, int* tile_n, int* splits);
 int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s);
 
+// ---- launch ledger (measurement only, off by default): which kernel every mdvit_gemm_f32 call launched -- the calls of the C-level block entry (block.hip) included,
+// which never pass the Python wrapper's event sampler -- with its algorithmic flops / bytes (ops.gemm's formula).  bench.py reads it over ONE untimed step, so that the
+// roofline line's launch count and bytes per launch describe the same launch population as the rocprofv3 average it is compared with.
+#include <mutex>
+namespace {
+struct LedgerRow { char name[160]; long launches; double flop, bytes; };
+LedgerRow g_ledger[96];
+int g_ledger_n = 0;
+bool g_ledger_on = false;
+std::mutex g_ledger_mu;
+}
+extern "C" int mdvit_gemm_kernel_name(const MdvitGemmDesc* d, char* out, int32_t cap);
+extern "C" int mdvit_gemm_ledger(int32_t enable) {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    if (enable) g_ledger_n = 0;
+    g_ledger_on = enable != 0;
+    return MDVIT_OK;
+}
+extern "C" int mdvit_gemm_ledger_read(int32_t index, char* name, int32_t cap, int64_t* launches, double* flop, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    MDVIT_CHECK_ARG(name && cap > 0 && launches && flop && bytes, MDVIT_E_SHAPE, "gemm_ledger_read: null argument");
+    if (index < 0 || index >= g_ledger_n) return MDVIT_E_SHAPE;            // past the end (no message: the caller's loop condition)
+    snprintf(name, cap, "%s", g_ledger[index].name);
+    *launches = g_ledger[index].launches; *flop = g_ledger[index].flop; *bytes = g_ledger[index].bytes;
+    return MDVIT_OK;
+}
+static void ledger_note(const MdvitGemmDesc* d) {
+    char nm[160];
+    if (mdvit_gemm_kernel_name(d, nm, sizeof(nm)) != MDVIT_OK) return;
+    if (char* plus = strchr(nm, '+')) *plus = 0;                            // the main kernel (a slab reduction is its own launch)
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    int i = 0;
+    while (i < g_ledger_n && strcmp(g_ledger[i].name, nm) != 0) ++i;
+    if (i == g_ledger_n) {
+        if (g_ledger_n == 96) return;
+        snprintf(g_ledger[i].name, sizeof(g_ledger[i].name), "%s", nm);
+        g_ledger[i].launches = 0; g_ledger[i].flop = 0.0; g_ledger[i].bytes = 0.0;
+        ++g_ledger_n;
+    }
+    const double M = d->M, N = d->N, K = d->K;
+    g_ledger[i].launches += 1;
+    g_ledger[i].flop += 2.0 * M * N * K;
+    g_ledger[i].bytes += 4.0 * (M * K + N * K + M * N * (1 + (d->C2 != nullptr) + (d->residual != nullptr) + (d->gelu_u != nullptr))) + (d->rc_a ? 4.0 * (M + N) * d->rc_k : 0.0);
+}
+
 extern "C" int mdvit_gemm_f32(const MdvitGemmDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     MDVIT_CHECK_ARG(d != nullptr, MDVIT_E_SHAPE, "gemm: null descriptor");
     MDVIT_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, MDVIT_E_SHAPE, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    if (g_ledger_on) ledger_note(d);
     MDVIT_CHECK_ARG(d->A && d->B && d->C, MDVIT_E_SHAPE, "gemm: null operand");
     MDVIT_CHECK_ARG(aligned16(d->A) && aligned16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0), MDVIT_E_ALIGN,
                     "gemm: operands must be 16-byte aligned with leading dimensions %% 4 == 0 (lda=%ld ldb=%ld)", d->lda, d->ldb);

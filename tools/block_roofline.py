@@ -139,9 +139,59 @@ def stage0_mlp_kernels(B, img, drop, iters=10):
                                       ("mlp_rc_wgrad_kernel + rc_reduce (gm, x -> dW1, db1, dW2)", t_fb - t_fd, 4.0 * (2 * T * C + 2 * C * Hd), 4.0 * T * C * Hd)):
         rows.append({"kernel": name, "us": secs * 1e6, "algorithmic_bytes": nbytes, "algorithmic_flop": flops, "hbm_GBps": nbytes / secs / 1e9,
                      "frac_hbm": nbytes / secs / HBM, "useful_TFLOPs": flops / secs / 1e12, "frac_mfma_bf16x3": flops / secs / MFMA["bf16x3"],
-                     "bound": "VALU (erf-GELU / dropout hash / hi-lo split: ~30 instructions per hidden element at ~4 cycles) -- neither chip roof; see DESIGN.md section 3"})
+                     "bound": "VALU + MFMA in series (on one SIMD an MFMA does not run beside a saturated VALU pipe: profiles/r05_mfma_valu_overlap.txt; erf-GELU / dropout / "
+                              "hi-lo split ~70 VALU cycles per hidden element + 48 MFMA cycles of bf16x3 products) -- neither chip roof; see DESIGN.md section 3"})
     return {"rows": T, "C": C, "hidden": Hd, "timer": "torch events around ops.mlp_residual forward / backward on the launch stream, differences of the three passes",
             "kernels": rows, "largest": max(rows, key=lambda r: r["us"])}
+
+
+def stage0_attention_core(B, img, iters=10):
+    """The attention core of the stage-0 block (mdvit_factoratt_fwd / _bwd through the C ABI: factorised attention + ConvRelPosEnc + Domain Adapter scale, mdvit.py:281-313)
+    alone on the GPU, against the bytes a two-pass fused form must move: forward q, k, v in / out written (16 T C bytes: SURVEY 8(d)'s 8 N C B at 2 bytes, here fp32);
+    backward dout, q, k, v in / dq, dk, dv out (28 T C bytes).  What the kernels move on top of that (U written and re-read, dU, conv^T(dU), the tile partials) is the gap."""
+    from mdvit_amd import _lib
+    from mdvit_amd._lib import call
+    C, heads, H = 64, 8, img // 4
+    N, Ch, dev = H * H, C // heads, "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = torch.randn(B, N, 3 * C, device=dev, generator=g)
+    s3, s5, s7 = 2, 3, 3
+    ws_ = [torch.randn(n * Ch, 1, k, k, device=dev, generator=g) * 0.1 for n, k in ((s3, 3), (s5, 5), (s7, 7))]
+    bs_ = [torch.randn(n * Ch, device=dev, generator=g) * 0.1 for n in (s3, s5, s7)]
+    a = torch.softmax(torch.randn(B, heads, Ch, device=dev, generator=g), 1).reshape(B, C).contiguous()
+    out = torch.empty(B, N, C, device=dev); U = torch.empty_like(out)
+    kmax = torch.empty(B, C, device=dev); ksum = torch.empty_like(kmax); Mmat = torch.empty(B, C, Ch, device=dev)
+    wsb = _lib.load().mdvit_factoratt_ws_bytes(B, N, C, heads)
+    ws = torch.empty(wsb // 4, device=dev)
+    dout = torch.randn(B, N, C, device=dev, generator=g)
+    dqkv = torch.empty_like(qkv); e = torch.empty(B, C, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: None if t is None else t.data_ptr()
+
+    def fwd():
+        call("mdvit_factoratt_fwd", P(qkv), P(ws_[0]), P(bs_[0]), P(ws_[1]), P(bs_[1]), P(ws_[2]), P(bs_[2]), P(a), P(out), P(U), P(kmax), P(ksum), P(Mmat), P(ws), wsb,
+             B, H, H, C, heads, s3, s5, s7, st)
+
+    def bwd():      # the data path of the block entry (the window-weight gradients run on the side stream: mdvit_factoratt_wgrad)
+        call("mdvit_factoratt_bwd", P(dout), P(qkv), P(out), P(U), P(ws_[0]), P(bs_[0]), P(ws_[1]), P(bs_[1]), P(ws_[2]), P(bs_[2]), P(a), P(kmax), P(ksum), P(Mmat),
+             P(dqkv), P(e), None, None, None, None, None, None, P(ws), wsb, B, H, H, C, heads, s3, s5, s7, st)
+
+    res = {}
+    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(iters):
+            fn()
+        t1.record(); torch.cuda.synchronize()
+        res[name] = t0.elapsed_time(t1) / iters * 1e-3
+    T = B * N
+    rows = []
+    for name, secs, nbytes in (("factor-att + crpe + DA forward (qkv -> out)", res["fwd"], 16.0 * T * C), ("factor-att + crpe + DA backward (dout, qkv -> dqkv)", res["bwd"], 28.0 * T * C)):
+        rows.append({"kernel": name, "us": secs * 1e6, "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / secs / 1e9, "frac_hbm": nbytes / secs / HBM, "bound": "hbm"})
+    return {"rows": T, "C": C, "timer": "torch events around mdvit_factoratt_fwd / _bwd (C ABI) on the launch stream, nothing else on the GPU", "passes": rows}
 
 
 def main():
@@ -264,6 +314,12 @@ def main():
                 print(f"   {r['kernel']:62s} {r['us']:7.1f} us  {r['hbm_GBps']:7.0f} GB/s ({100 * r['frac_hbm']:4.1f}% of HBM)  {r['useful_TFLOPs']:6.1f} TF/s useful ({100 * r['frac_mfma_bf16x3']:4.1f}% of the bf16x3 roof)")
         except Exception as exc:           # a report, never a reason to lose the block figures
             out["stage0_mlp_kernels"] = {"error": repr(exc)}
+        try:
+            out["stage0_attention_core"] = stage0_attention_core(B, args.img)
+            for r in out["stage0_attention_core"]["passes"]:
+                print(f"   {r['kernel']:62s} {r['us']:7.1f} us  {r['hbm_GBps']:7.0f} GB/s ({100 * r['frac_hbm']:4.1f}% of HBM)")
+        except Exception as exc:
+            out["stage0_attention_core"] = {"error": repr(exc)}
     print(f"all four stages: {100 * out['all_stages']['frac']:.1f}% of the operator-sum bound, {100 * out['all_stages']['frac_strict']:.1f}% of the strict (fused-MLP) bound")
     if args.json:
         with open(args.json, "w") as fh:
