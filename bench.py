@@ -613,6 +613,22 @@ def main():
                 os.remove(blk_json)
             except Exception as e:
                 extra["block_bs32"] = {"error": repr(e)}
+            if args.precision == "bf16x3":
+                # the same block in the mode BASELINE configs[1] / [3] name ("bf16" / "mixed bf16 / fp32 loss"): the bf16 speed mode's kernels against the bound of bf16 STORAGE
+                # (2 bytes per element) and the dense bf16 MFMA roof (2.5 PFLOP/s) -- VERDICT r04 item 4
+                _child_json([sys.executable, os.path.join(ROOT, "tools", "block_roofline.py"), "--batch", "32", "--precision", "bf16", "--json", blk_json], 600)
+                try:
+                    with open(blk_json) as f:
+                        blk = json.load(f)
+                    extra["block_bs32_bf16"] = {
+                        "what": "block_bs32 in the bf16 speed mode (one bf16 plane per GEMM operand, h / du of the C = 128 MLP stored bf16, everything else fp32 in HBM) against the "
+                                "STRICT operator-sum bound priced for bf16 storage (2 bytes per element) and the 2.5 PFLOP/s dense bf16 roof",
+                        "stages": [{"stage": r["stage"], "C": r["C"], "fwd_ms": round(r["fwd_ms"], 3), "bwd_ms": round(r["bwd_ms"], 3), "frac": round(r.get("frac_strict", 0.0), 4),
+                                    "frac_unfused": round(r["frac"], 4)} for r in blk["stages"]],
+                        "all_stages_frac": round(blk["all_stages"].get("frac_strict", 0.0), 4)}
+                    os.remove(blk_json)
+                except Exception as e:
+                    extra["block_bs32_bf16"] = {"error": repr(e)}
         line = {
             "metric": {"mdvit": "512x512 images/sec MDViT train step (fwd+bwd, two-sweep, AdamW)", "mdvit_dsn": "512x512 images/sec MDViT_DSN train step",
                        "base": "512x512 images/sec BASE train step", "transfuse": "256x256 images/sec TransFuse_S_adapt train step (fwd+bwd, structure_loss, AdamW)"}[args.model],

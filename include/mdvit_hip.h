@@ -304,6 +304,12 @@ int mdvit_mlp_rc_fwd_ln_hbf16(const float* x2, const float* gamma, const float* 
                               const uint32_t* drop_seed, void* stream);
 int mdvit_mlp_rc16_dgrad_hbf16(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* du, float* dx,
                                int32_t M, int32_t C, int32_t Hd, float drop_p, uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, void* stream);
+/* The whole backward of the C = 64 MLP (mpvit.py:71-78 in mdvit.py:357-360) from ONE evaluation of u = x W1^T + b1, d = gm W2 and the activation: dW1, db1, dW2 as
+ * mdvit_mlp_rc_wgrad (same workspace, same fold) and the data gradient dx = du W1 as one partial per 256-wide hidden role, dx_parts [hidden / 256][M][C] -- the consumer adds
+ * them (mdvit_layernorm_bwd2's dy2, or mdvit_sum_batch).  hidden in {256, 512}.  W1tp: the planes of W1^T ([2][C][hidden], mdvit_mlp_rc_dgrad's). */
+int mdvit_mlp_rc_bwd(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx_parts, float* dW1, float* db1,
+                     float* dW2, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t hidden, float drop_p, uint32_t key1_0, uint32_t key1_1,
+                     const uint32_t* drop_seed, int32_t accumulate, void* stream);
 size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
 /* tuning hook (tools/mlp_rc_check.py): forward kernel variant -- 2: software-pipelined waves at 2 per SIMD, 3: plain waves at 3 per SIMD */
 /* Launch ledger of mdvit_gemm_f32 (measurement only, off by default; bench.py's roofline line): mdvit_gemm_ledger(1) clears and starts it, (0) stops it; while on, every
@@ -312,6 +318,9 @@ size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
 int mdvit_gemm_ledger(int32_t enable);
 int mdvit_gemm_ledger_read(int32_t index, char* name, int32_t cap, int64_t* launches, double* flop, double* bytes);
 int mdvit_mlp_rc_config(int32_t fwd_variant);
+/* tuning hook: whether mdvit_block_bwd runs the C = 64 MLP backward as ONE kernel (mdvit_mlp_rc_bwd) -- 0 never, 1 always, 2 (default) when the call has no weight-gradient
+ * stream (with one, the separate weight-gradient kernel overlaps the main stream's chain).  Set it before mdvit_block_bwd_ws_bytes: the workspace layout follows it. */
+int mdvit_block_config(int32_t mlp_bwd_fused);
 /* tuning hook (tools/attn_time.py --apply-mode): how the attention backward's apply kernel (Ch = 8 / 16) orders its loads -- 0: each 32-token tile's rows in front of
  * the tile (default), 1: the MFMA operand rows one tile ahead at two waves per SIMD, 2: the same at one wave per SIMD.  Same arithmetic in every mode. */
 int mdvit_factoratt_config(int32_t apply_mode, int32_t apply_tiles /* 32-token tiles per workgroup of the apply kernels; 0: the launcher's rule */);

@@ -109,6 +109,7 @@ _SIGS = {
     "mdvit_gemm_ph_prefers_epi": [i32, i32, i32, i32, i32],
     "mdvit_mlp_config": [i32, i32],
     "mdvit_mlp_rc_config": [i32],
+    "mdvit_block_config": [i32],
     "mdvit_gemm_ledger": [i32],
     "mdvit_gemm_ledger_read": [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "mdvit_factoratt_config": [i32, i32],
@@ -123,6 +124,7 @@ _SIGS = {
     "mdvit_mlp_rc16_fwd_hbf16": [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
     "mdvit_mlp_rc16_dgrad_hbf16": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u32, u32, vp, vp],
     "mdvit_mlp_rc_wgrad": [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, f32, u32, u32, vp, i32, vp],
+    "mdvit_mlp_rc_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, f32, u32, u32, vp, i32, vp],
     "mdvit_imgconv_fwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_imgconv_wgrad": [vp, vp, vp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp],
     "mdvit_maxpool3x3s2_fwd": [vp, vp, vp, i32, i32, i32, i32, vp],

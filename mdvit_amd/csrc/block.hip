@@ -61,6 +61,14 @@ void gemm_init(MdvitGemmDesc& g, const MdvitBlockDesc& d) {
     g.drop_seed = nullptr;
 }
 
+// the C = 64 MLP backward as ONE kernel (mdvit_mlp_rc_bwd): 0 never, 1 always, 2 (default) when the call has no weight-gradient stream (tuning hook: mdvit_block_config)
+static int g_blk_mlp_bwd = 2;
+extern "C" int mdvit_block_config(int32_t mlp_bwd_fused) {
+    if (mlp_bwd_fused < 0 || mlp_bwd_fused > 2) return mdvit_set_error(MDVIT_E_SHAPE, "block_config: mlp_bwd_fused in 0..2");
+    g_blk_mlp_bwd = mlp_bwd_fused;
+    return MDVIT_OK;
+}
+
 #define BLK_RUN(call)                         \
     do {                                      \
         if (!A.dry) {                         \
@@ -268,6 +276,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
     float* gm2 = masked ? S.take(T * C) : const_cast<float*>(dy);
     float* tmp = A.take(T * C);              // dcur2, then datt, then dcur1: consecutive lifetimes on the main stream
     float* dcur2 = tmp;
+    const float* dcur2_b = nullptr;          // the second partial of dcur2 (the fused MLP backward's role 1), added by the LayerNorm backward
     float* du = nullptr;
     if (mode == MLP_RC) {
         if (masked || want_w) {
@@ -282,6 +291,20 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
                                          acc, seed, s));
             }
         }
+        // Full sweep without a weight-gradient stream: the WHOLE MLP backward from one evaluation of u, d and the activation (mdvit_mlp_rc_bwd, round 5) -- dx arrives as one
+        // partial per 256-wide hidden role and the LayerNorm backward below adds them while it reads them.  With a side stream the separate weight-gradient kernel overlaps the
+        // main stream's chain, and the fused kernel would lengthen that chain: there the two kernels stay (g_blk_mlp_bwd: 0 never, 1 always, 2 by that rule).
+        const bool fuse_bwd = want_w && (Hd == 256 || Hd == 512) && (g_blk_mlp_bwd == 1 || (g_blk_mlp_bwd == 2 && !have_side));
+        if (fuse_bwd) {
+            const int roles = Hd / 256;
+            float* parts = roles == 1 ? dcur2 : A.take((long)roles * T * C);
+            const size_t wb = mdvit_mlp_rc_wgrad_ws_bytes(M, C, Hd);
+            void* ww = A.take_bytes(wb);
+            BLK_RUN(mdvit_mlp_rc_bwd(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, parts, G.fc1_w, G.fc1_b, G.fc2_w, ww, wb, M, C, Hd, d.drop_p, d.key_fc1[0],
+                                     d.key_fc1[1], seed, acc, s));
+            dcur2 = parts;
+            dcur2_b = roles == 2 ? parts + T * C : nullptr;
+        } else {
         BLK_RUN(mdvit_mlp_rc_dgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, d.fc1t_p, dcur2, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed, s));
         if (want_w) {
             const size_t wb = mdvit_mlp_rc_wgrad_ws_bytes(M, C, Hd);
@@ -289,6 +312,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
             if (!A.dry) { const int rc = fork_side(d, st, side); if (rc != MDVIT_OK) return rc; }
             BLK_RUN(mdvit_mlp_rc_wgrad(gm2, sv.cur2, d.fc1_p, d.fc1_b, d.fc2t_p, G.fc1_w, G.fc1_b, G.fc2_w, ww, wb, M, C, Hd, d.drop_p, d.key_fc1[0], d.key_fc1[1], seed,
                                        acc, side));
+        }
         }
     } else {
         if (masked) BLK_RUN(mdvit_colsum_f32(dy, C, nullptr, gm2, nullptr, 0, M, C, d.drop_p, d.key_fc2[0], d.key_fc2[1], d.rowscale2, N_tok, 0, seed, s));
@@ -333,6 +357,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         void* pw = lnw ? A.take_bytes(pb) : nullptr;
         float* dg = want_w ? G.n2_g : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
         float* db = want_w ? G.n2_b : (lnw ? A.take((long)d.ln_groups * C) : nullptr);
+        if (!A.dry) mdvit_layernorm_bwd_next_dy2(dcur2_b);
         if (defer) {
             void* pws = S.take_bytes(pb);
             int nb = 0;
@@ -510,6 +535,7 @@ extern "C" size_t mdvit_block_bwd_ws_bytes(const MdvitBlockDesc* d, const MdvitB
 extern "C" int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g, const MdvitBlockStreams* st, const float* x, const void* save, size_t save_bytes,
                                const float* dy, float* dx, void* ws, size_t ws_bytes, void* ws_side, size_t ws_side_bytes) {
     MDVIT_CHECK_ARG(d && g && st && x && save && dy && ws && ws_side, MDVIT_E_SHAPE, "block_bwd: null argument");
+    mdvit_layernorm_bwd_next_dy2(nullptr);       // (a call that failed between announcing a second dy partial and the LayerNorm backward must not leave it behind)
     const int rc = check_desc(*d, "block_bwd");
     if (rc != MDVIT_OK) return rc;
     MDVIT_CHECK_ARG(aligned16(x) && aligned16(dy) && (!dx || aligned16(dx)) && (reinterpret_cast<uintptr_t>(save) & 255) == 0 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0 &&

@@ -69,6 +69,8 @@ int mdvit_layernorm_bwd_parts(const float* dy, const float* x, const float* gamm
                               const float* rowscale, int rows_per_scale, const uint32_t* seed, hipStream_t stream, int* nblk);
 int mdvit_colsum_parts(const float* A, long lda, float* masked, void* ws, size_t ws_bytes, int M, int N, float drop_p, uint32_t key0, uint32_t key1,
                        const float* rowscale, int rows_per_scale, const uint32_t* seed, hipStream_t stream, int* nblk);
+// the NEXT LayerNorm backward call of this thread reads its upstream gradient as dy + dy2 (norm.hip; consumed by that call)
+void mdvit_layernorm_bwd_next_dy2(const float* dy2);
 constexpr int MDVIT_MAX_PARTIAL_ROWS = 2048;        // every partial-row reduction launches at most this many workgroups
 #define MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, n, what)                                                              \
     MDVIT_CHECK_ARG((ws) != nullptr && (ws_bytes) >= sizeof(float) * (size_t)(nblk) * (size_t)(n), MDVIT_E_WORKSPACE,    \

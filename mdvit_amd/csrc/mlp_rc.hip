@@ -811,12 +811,31 @@ __device__ __forceinline__ rc_bf16x8 rc_tr8(const char* plane, int t0, int col0,
     return __builtin_bit_cast(rc_bf16x8, r);
 }
 
-template <int C, bool DROP>
+// DX (round 5, mdvit_mlp_rc_bwd): the same kernel ALSO forms the data gradient dx = du W1 -- the whole MLP backward from one evaluation of u, d and the activation (the
+// separate mlp_rc_dgrad_kernel recomputes both: 24 of its 36 MFMAs per hidden step and all of its VALU work are this kernel's over again).  du leaves the registers with
+// lane <-> hidden unit, but dx contracts over hidden: every wave writes its du^T [32 hidden][32 tokens] (hi / lo planes) to LDS, and after a barrier wave (cblk, tblk) forms
+// the 16 x 16 block dx^T[16 cblk ..][16 tblk ..] over ALL 256 hidden units of the role on v_mfma_f32_16x16x32_bf16 -- A = W1^T rows (the role's [64][256] slice, resident
+// in LDS), B = du^T read back with ds_read_b64_tr_b16 (k = hidden down the rows) -- so no partial sums cross waves.  Roles (256-wide hidden ranges) write their own
+// dx partial [role][tokens][C]; the consumer adds them (mdvit_layernorm_bwd's dy2, or rc_sum_parts_kernel).
+#define RC16_MFMA3_BWD(acc, ah, al, bh, bl)                                     \
+    do {                                                                        \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);    \
+    } while (0)
+typedef float rc_acc4 __attribute__((ext_vector_type(4)));
+constexpr int RC_WT_ROW = 528;                       // bytes per row of the W1^T slice in LDS: 256 hidden x 2 bytes + 16 (rows 4 banks apart)
+constexpr int RC_BWD_LDS = 2 * 64 * RC_WT_ROW + 8 * 2 * 2048;
+
+template <int C, bool DROP, bool DX = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rc_wgrad_kernel(RcArgs p) {
     constexpr int KB = C / 16, CB = C / 32;
     constexpr int TP = 32 * 128;                     // one plane of a [32 tokens][64 c] tile (C = 64: 128-byte rows)
     static_assert(C == 64, "token-tile staging below is written for C = 64");
     __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * TP];      // [2 buffers][x hi, x lo, gm hi, gm lo]
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];          // DX: [2 planes][64 c][RC_WT_ROW] W1^T slice | [8 waves][2 planes][32 hidden][64 B] du^T
+    char* sWt = dsm;
+    char* sDu = dsm + 2 * 64 * RC_WT_ROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5, l15 = lane & 15;
     const int roles = p.Hd >> 8;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -870,6 +889,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<rc_u2*>(b + 3 * TP + soff) = rc_u2{lo.x, lo.y};
     };
 
+    if (DX) {                                        // W1^T[c][role's 256 hidden], both planes: 4096 16-byte chunks
+        for (int i = tid; i < 2 * 64 * 32; i += 512) {
+            const int pl = i >> 11, c = (i >> 5) & 63, ch = i & 31;
+            const rc_u4 v = *reinterpret_cast<const rc_u4*>(p.W1tp + pl * wplane + (long)c * p.Hd + role * 256 + ch * 8);
+            *reinterpret_cast<rc_u4*>(sWt + (pl * 64 + c) * RC_WT_ROW + ch * 16) = v;
+        }
+    }
     if (t_beg < t_end) {
         load_tile(t_beg);
         store_tile(0);
@@ -930,6 +956,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             const rc_bf16x8 hhf = __builtin_bit_cast(rc_bf16x8, hh), hlf = __builtin_bit_cast(rc_bf16x8, hl);
             const rc_bf16x8 dhf = __builtin_bit_cast(rc_bf16x8, dh), dlf = __builtin_bit_cast(rc_bf16x8, dl);
+            if (DX) {
+                // du^T row of this lane's hidden unit: the packed pairs are tokens 16 ks + 4 lhi + {0..3} (dh[0], dh[1]) and 16 ks + 8 + 4 lhi + {0..3} (dh[2], dh[3]) -- two 8-byte
+                // pieces per plane; 16-byte chunks XOR-swizzled by (row >> 1) & 3 (the 32 rows of a wave share their column: 2-way instead of 8-way bank conflicts)
+                char* base = sDu + wave * 4096 + l31 * 64 + 8 * lhi;
+                const int f = (l31 >> 1) & 3;
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    const int ch = (2 * ks + pc) ^ f;
+                    *reinterpret_cast<rc_u2*>(base + (ch << 4)) = rc_u2{dh[2 * pc], dh[2 * pc + 1]};
+                    *reinterpret_cast<rc_u2*>(base + 2048 + (ch << 4)) = rc_u2{dl[2 * pc], dl[2 * pc + 1]};
+                }
+            }
             const int t0 = 16 * ks + 4 * lhi;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
@@ -941,6 +979,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const rc_bf16x8 agh = rc_tr8(ghi, t0, col0, l15), agl = rc_tr8(glo, t0, col0, l15);
                 RC_MFMA3_ACT_A(aw2[cb], agh, agl, hhf, hlf);
             }
+        }
+        if (DX) {
+            __syncthreads();                            // every wave's du^T is in LDS
+            const int cblk = wave & 3, tblk = wave >> 2, g4 = lane >> 4;
+            rc_acc4 acc = {0.f, 0.f, 0.f, 0.f};
+            // B piece of this lane inside a 4-row block: row r0 + (l15 >> 2), token columns 16 tblk + 4 (l15 & 3) ..+3; the transposing read returns column 16 tblk + l15
+            const int pr = l15 >> 2, pcb = 32 * tblk + 8 * (l15 & 3);
+            // (measured, profiles/r05_mlp_rc_bwd.txt: requesting the operands of step k + 1 / k + 2 ahead of step k's MFMAs does not help -- 830 against 800 us, more spills: the
+            //  phase is bound by its LDS bytes, 32 KB per wave and tile, not by the round trips)
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {            // the 32 hidden units of wave k8 = one K = 32 step
+                const char* wa = sWt + (cblk * 16 + l15) * RC_WT_ROW + (4 * k8 + g4) * 16;
+                const rc_bf16x8 ah = __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(wa));
+                const rc_bf16x8 al = __builtin_bit_cast(rc_bf16x8, *reinterpret_cast<const rc_u4*>(wa + 64 * RC_WT_ROW));
+                const char* dplane = sDu + k8 * 4096;
+                const int ra = 8 * g4 + pr, rb = ra + 4;
+                const int oa = ra * 64 + (((pcb >> 4) ^ ((ra >> 1) & 3)) << 4) + (pcb & 15), ob = rb * 64 + (((pcb >> 4) ^ ((rb >> 1) & 3)) << 4) + (pcb & 15);
+                const rc_v4i16 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(dplane + oa)), h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(dplane + ob));
+                const rc_v4i16 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(dplane + 2048 + oa)), l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(dplane + 2048 + ob));
+                const rc_bf16x8 bh = __builtin_bit_cast(rc_bf16x8, (rc_v8i16{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}));
+                const rc_bf16x8 bl = __builtin_bit_cast(rc_bf16x8, (rc_v8i16{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]}));
+                RC16_MFMA3_BWD(acc, ah, al, bh, bl);
+            }
+            const int tok = t * 32 + tblk * 16 + l15;    // D: lane <-> token column, registers <-> rows c = 16 cblk + 4 g4 + r
+            if (tok < p.M) *reinterpret_cast<float4*>(p.dx + ((long)role * p.M + tok) * C + cblk * 16 + 4 * g4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
         if (t + 1 < t_end) store_tile(buf ^ 1);
         __syncthreads();
@@ -1826,6 +1889,41 @@ extern "C" int mdvit_mlp_rc_wgrad(const float* gm, const float* x, const void* W
     const int roles = Hd / 256;
     if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, false>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
+    MDVIT_LAUNCH_CHECK();
+    const int n0 = Hd * C, n2 = Hd;
+    hipLaunchKernelGGL(rc_reduce_kernel, dim3(cdiv((2L * n0 + n2) / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, a.groups, (long)(2L * n0 + n2), n0, dW1,
+                       n0, dW2, n2, db1, accumulate);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+/* The whole backward of the C = 64 MLP in ONE kernel + its partial-sum fold (round 5): mdvit_mlp_rc_dgrad and mdvit_mlp_rc_wgrad recompute u = x W1^T + b1, d = gm W2 and
+ * the activation twice; here they are formed once and feed all three products -- dW1 = du^T x, dW2 = gm^T h (as mdvit_mlp_rc_wgrad, bit for bit) and dx = du W1.
+ * dx_parts [hidden / 256][M][C]: one partial of dx per 256-wide hidden role (the consumer adds them: mdvit_layernorm_bwd's dy2, mdvit_sum_batch); hidden in {256, 512}. */
+extern "C" int mdvit_mlp_rc_bwd(const float* gm, const float* x, const void* W1p, const float* b1, const void* W2tp, const void* W1tp, float* dx_parts,
+                                float* dW1, float* db1, float* dW2, void* ws, size_t ws_bytes, int32_t M, int32_t C, int32_t Hd, float drop_p,
+                                uint32_t key1_0, uint32_t key1_1, const uint32_t* drop_seed, int32_t accumulate, void* stream) {
+    MDVIT_CHECK_ARG(C == 64, MDVIT_E_SHAPE, "mlp_rc_bwd: built for C = 64 (got %d)", C);
+    MDVIT_CHECK_ARG(M > 0 && (Hd == 256 || Hd == 512), MDVIT_E_SHAPE, "mlp_rc_bwd: need M > 0, hidden in {256, 512} (M=%d hidden=%d)", M, Hd);
+    MDVIT_CHECK_ARG(gm && x && W1p && b1 && W2tp && W1tp && dx_parts && dW1 && db1 && dW2, MDVIT_E_SHAPE, "mlp_rc_bwd: null operand");
+    MDVIT_CHECK_ARG(aligned16(gm) && aligned16(x) && aligned16(W1p) && aligned16(W2tp) && aligned16(W1tp) && aligned16(dx_parts) && aligned16(dW1) && aligned16(db1) &&
+                    aligned16(dW2) && aligned16(ws), MDVIT_E_ALIGN, "mlp_rc_bwd: operands must be 16-byte aligned");
+    MDVIT_CHECK_ARG(!(drop_p > 0.f) || (long)M * Hd < (1L << 32), MDVIT_E_SHAPE, "mlp_rc_bwd: dropout index space exceeds 2^32");
+    const size_t need = mdvit_mlp_rc_wgrad_ws_bytes(M, C, Hd);
+    MDVIT_CHECK_ARG(ws && ws_bytes >= need, MDVIT_E_WORKSPACE, "mlp_rc_bwd: workspace too small: need %zu bytes (mdvit_mlp_rc_wgrad_ws_bytes), got %zu", need, ws_bytes);
+    RcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gm = gm; a.x = x; a.W1p = (const uint16_t*)W1p; a.b1 = b1; a.W2tp = (const uint16_t*)W2tp; a.W1tp = (const uint16_t*)W1tp; a.dx = dx_parts; a.part = (float*)ws;
+    rc_fill(a, M, Hd, drop_p, key1_0, key1_1, 0, 0, drop_seed);
+    a.groups = rc_wgrad_groups(M);
+    a.tiles_per_group = cdiv((M + 31) / 32, a.groups);
+    const int roles = Hd / 256;
+    static bool f0[64] = {false}, f1[64] = {false};
+    int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_wgrad_kernel<64, true, true>), RC_BWD_LDS, f0);
+    if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_wgrad_kernel<64, false, true>), RC_BWD_LDS, f1);
+    if (rc != MDVIT_OK) return rc;
+    if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true, true>), dim3(a.groups * roles), dim3(512), RC_BWD_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, false, true>), dim3(a.groups * roles), dim3(512), RC_BWD_LDS, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
     const int n0 = Hd * C, n2 = Hd;
     hipLaunchKernelGGL(rc_reduce_kernel, dim3(cdiv((2L * n0 + n2) / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, a.groups, (long)(2L * n0 + n2), n0, dW1,

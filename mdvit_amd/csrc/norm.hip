@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const float* __restrict__
 // optional second output of the LayerNorm backward: dx * dropout mask * DropPath row scale of the Linear that produced the LayerNorm's input
 struct LnMasked {
     float* out; float drop_p; uint32_t k0, k1, thresh; float inv_keep; const float* rowscale; int rows_per_scale; const uint32_t* seed;
+    const float* dy2;       // a second partial of the upstream gradient, added to dy on the fly (mdvit_mlp_rc_bwd writes dx as one partial per hidden role)
 };
 
 template <int VPL>
@@ -181,7 +182,11 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const float* __restrict__
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-            const float4 g4 = *reinterpret_cast<const float4*>(dy + row * C + 4 * (sub + 16 * j));
+            float4 g4 = *reinterpret_cast<const float4*>(dy + row * C + 4 * (sub + 16 * j));
+            if (mk.dy2) {
+                const float4 h4 = *reinterpret_cast<const float4*>(mk.dy2 + (grow0 + row) * C + 4 * (sub + 16 * j));
+                g4.x += h4.x; g4.y += h4.y; g4.z += h4.z; g4.w += h4.w;
+            }
             const float4 x4 = *reinterpret_cast<const float4*>(x + row * C + 4 * (sub + 16 * j));
             xh[j] = make_float4((x4.x - mu) * rs, (x4.y - mu) * rs, (x4.z - mu) * rs, (x4.w - mu) * rs);
             d[j] = make_float4(g4.x * ga[j].x, g4.y * ga[j].y, g4.z * ga[j].z, g4.w * ga[j].w);
@@ -815,10 +820,18 @@ int mdvit_layernorm_bwd_parts(const float* dy, const float* x, const float* gamm
     return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, &dummy, &dummy, ws, ws_bytes, M, C, groups, mk, stream, nblk);
 }
 
+// A second upstream-gradient partial for the NEXT LayerNorm backward call of this thread (block.hip: the C = 64 MLP backward in one kernel leaves dx as one partial
+// per 256-wide hidden role; the LayerNorm in front of the MLP adds them while it reads them -- no separate sum pass).  Consumed and cleared by that call.
+static thread_local const float* g_ln_dy2 = nullptr;
+void mdvit_layernorm_bwd_next_dy2(const float* dy2) { g_ln_dy2 = dy2; }
+
 static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream, int* defer_nblk) {
+                              int32_t M, int32_t C, int32_t groups, const LnMasked& mk_in, void* stream, int* defer_nblk) {
     hipStream_t s = (hipStream_t)stream;
+    LnMasked mk = mk_in;
+    mk.dy2 = g_ln_dy2; g_ln_dy2 = nullptr;
+    MDVIT_CHECK_ARG(mk.dy2 == nullptr || ((C == 64 || C == 128 || C == 320 || C == 512) && aligned16(mk.dy2)), MDVIT_E_SHAPE, "layernorm_bwd: a second dy partial needs C in 64/128/320/512");
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
     MDVIT_CHECK_ARG(groups > 0 && groups <= 64 && M % groups == 0, MDVIT_E_SHAPE, "layernorm_bwd: M=%d is not a multiple of groups=%d", M, groups);
     const int Mg = M / groups;

@@ -1254,6 +1254,12 @@ _mlp_fused = os.environ.get("MDVIT_MLP_FUSED", "1") != "0"
 _mlp_recompute_maxc = int(os.environ.get("MDVIT_MLP_RECOMPUTE_MAXC", "128"))
 _mlp_rc = os.environ.get("MDVIT_MLP_RC", "1") != "0"      # csrc/mlp_rc.hip: no [tokens, hidden] tensor in HBM in either pass (0: round 2's kernels, A/B)
 _mlp_rc16 = os.environ.get("MDVIT_MLP_RC16", "1") != "0"  # C = 128: the backward data path in one kernel on 16-token waves (0: the two data-gradient GEMMs, A/B)
+# C = 64, full sweep: data AND weight gradients from one evaluation of u, d and the activation (mdvit_mlp_rc_bwd) instead of mlp_rc_dgrad + mlp_rc_wgrad, which
+# recompute them twice.  "auto": when the weight gradients would NOT run on the side stream anyway (there the separate weight-gradient kernel overlaps the main
+# stream's chain and the fused kernel would lengthen it); "1": always; "0": never (A/B)
+_mlp_rc_bwd = os.environ.get("MDVIT_MLP_RC_BWD", "auto")
+if _mlp_rc_bwd in ("0", "1"):
+    _lib.load().mdvit_block_config(int(_mlp_rc_bwd))          # the C-level block entry follows the same switch (its default is the same rule)
 
 
 def _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M) -> bool:
@@ -1363,6 +1369,27 @@ class _MlpResidual(torch.autograd.Function):
                 call("mdvit_colsum_f32", _p(g), Cin, _p(sinks[3] if sunk else db2) if want_w else None, _p(gm) if masked else None, wsp, wsb, M, Cin,
                      drop_p, k2[0], k2[1], _p(rowscale), rps, int(sunk), _seed_ptr() if drop_p > 0 else None, _stream())
             W1p, W2tp, W1tp = _wplanes(W1, False, 2), _wplanes(W2, True, 2), _wplanes(W1, True, 2)
+            fused = want_w and Hd in (256, 512) and (_mlp_rc_bwd == "1" or (_mlp_rc_bwd == "auto" and not (sunk and _side_stream is not None)))
+            if fused:
+                roles = Hd // 256
+                parts = _empty((roles, M, Cin), device=dev, dtype=torch.float32)
+                wsb = _lib.load().mdvit_mlp_rc_wgrad_ws_bytes(M, Cin, Hd)
+                ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
+                if sunk:
+                    tgt, accf = (sinks[0], sinks[1], sinks[2]), 1
+                    db2 = None
+                else:
+                    dW1, db1, dW2 = _empty_like(W1), _empty((Hd,), device=dev, dtype=torch.float32), _empty_like(W2)
+                    tgt, accf = (dW1, db1, dW2), 0
+                call("mdvit_mlp_rc_bwd", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(W1tp), _p(parts), _p(tgt[0]), _p(tgt[1]), _p(tgt[2]), _p(ws), wsb,
+                     M, Cin, Hd, drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, accf, _stream())
+                if roles == 1:
+                    dx = parts[0]
+                else:
+                    dx = _empty_like(x)
+                    call("mdvit_sum_batch", _p(parts), _p(dx), roles, M * Cin, _stream())
+                del W1p, W2tp, W1tp
+                return dx, g, dW1, db1, dW2, db2, None, None, None
             dx = _empty_like(x)
             call("mdvit_mlp_rc_dgrad", _p(gm), _p(x), _p(W1p), _p(ctx.b1_ref), _p(W2tp), _p(W1tp), _p(dx), M, Cin, Hd,
                  drop_p, k1[0], k1[1], _seed_ptr() if drop_p > 0 else None, _stream())

@@ -90,6 +90,9 @@ def test_block_entry_with_gradient_buckets_and_side_stream(monkeypatch):
     label = torch.nn.functional.one_hot(torch.tensor([0, 1, 2, 3]), 4).float().to(dev())
     g = torch.randn(B, H * W, C, device=dev())
     st = make_stage(C, 8, True)
+    # (the C = 64 MLP backward runs as ONE kernel where no weight-gradient stream exists and as data-gradient + weight-gradient kernels where one does: dx then differs in
+    #  the summation order over the hidden axis.  This test compares the two paths bit for bit, so both take the two-kernel form; the one-kernel form has its own test.)
+    monkeypatch.setattr(ops, "_mlp_rc_bwd", "0")
     ref = run(st, x, label, H, W, g, False, monkeypatch)
     sinks = {p: torch.full_like(p, 0.25) for p in st.parameters()}
     ops.enable_side_stream(True)

@@ -83,13 +83,16 @@ def survey_bound(B, N, C, r, heads, num_domains=4):
 
 
 def bound_seconds(ops_list, precision):
+    """precision "bf16": the bound of the mode BASELINE configs[1] / [3] name -- every tensor at 2 bytes per element, every product (the attention's small ones too) on the
+    dense bf16 MFMA roof -- whatever the implementation stores today (it keeps fp32 activations except the C = 128 MLP's hidden tensors: the gap is the point of the figure)."""
+    eb = 2.0 if precision == "bf16" else 4.0
     tot = 0.0
     rows = []
     for name, floats, flops, kind in ops_list:
-        tb = 4.0 * floats / HBM
-        tf = flops / (MFMA[precision] if kind == "gemm" else ATT_MFMA) if kind else 0.0
+        tb = eb * floats / HBM
+        tf = flops / (MFMA[precision] if (kind == "gemm" or precision == "bf16") else ATT_MFMA) if kind else 0.0
         tot += max(tb, tf)
-        rows.append({"op": name, "bytes": 4.0 * floats, "flops": float(flops), "bound_us": 1e6 * max(tb, tf), "by": "hbm" if tb >= tf else "mfma"})
+        rows.append({"op": name, "bytes": eb * floats, "flops": float(flops), "bound_us": 1e6 * max(tb, tf), "by": "hbm" if tb >= tf else "mfma"})
     return tot, rows
 
 
@@ -282,7 +285,7 @@ def main():
         fo, bo = block_ops(T, C, Hd, heads)
         bf, rows_f = bound_seconds(fo, args.precision)
         bb, rows_b = bound_seconds(bo, args.precision)
-        by = sum(4.0 * o[1] for o in fo + bo)
+        by = sum((2.0 if args.precision == "bf16" else 4.0) * o[1] for o in fo + bo)
         fl = sum(o[2] for o in fo + bo)
         sfo, sbo = block_ops_strict(T, C, Hd, heads)
         bfs, _ = bound_seconds(sfo, args.precision)

@@ -56,6 +56,11 @@ def entries(M, C, Hd, drop, t):
             "wgrad+reduce": lambda: call("mdvit_mlp_rc_wgrad", _p(t["gm"]), _p(t["x"]), _p(W1p), _p(t["b1"]), _p(W2tp), _p(dW1), _p(db1), _p(dW2), _p(ws), wsb, M, C, Hd,
                                          drop, k[0], k[1], None, 0, st),
         }
+        if hasattr(_lib.load(), "mdvit_mlp_rc_bwd"):
+            parts = torch.empty(Hd // 256, M, C, device=dev)
+            fns["bwd fused (dx parts + dW, +reduce)"] = lambda: call("mdvit_mlp_rc_bwd", _p(t["gm"]), _p(t["x"]), _p(W1p), _p(t["b1"]), _p(W2tp), _p(W1tp), _p(parts), _p(dW1),
+                                                                      _p(db1), _p(dW2), _p(ws), wsb, M, C, Hd, drop, k[0], k[1], None, 0, st)
+            fns["sum of the dx parts"] = lambda: call("mdvit_sum_batch", _p(parts), _p(dx), Hd // 256, M * C, st)
     else:
         h, du = torch.empty(M, Hd, device=dev), torch.empty(M, Hd, device=dev)
         out.update(h=h, du=du)
