@@ -638,30 +638,39 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const float hks = 0.5f * p.inv_keep, pks = 0.39894228040143268f * p.inv_keep;
     const long wplane = (long)p.Hd * C;
 
-    auto issue_a = [&](int slot_s, int src_s, int pc) __attribute__((always_inline)) {       // pc in [0, 4 T1 / 1024): W1 hi, lo, W2^T hi, lo
-        constexpr int PP = T1 / 1024;
-        const int t = pc / PP, q = pc % PP, pl = t & 1;
-        const uint16_t* src = (t < 2 ? p.W1p : p.W2tp) + pl * wplane + (long)(src_s * 32) * C;
-        rc_glds_piece<RB1>(src, C, q, lane, (t < 2 ? sW1 : sW2t) + ((slot_s % 3) * 2 + pl) * T1);
-    };
-    auto issue_b = [&](int s, int pc) __attribute__((always_inline)) {
-        constexpr int PP = T3 / 1024;
-        const int pl = pc / PP, q = pc % PP;
-        rc_glds_piece<64>(p.W1tp + pl * wplane + s * 32, p.Hd, q, lane, sW1t + ((s % 3) * 2 + pl) * T3);
-    };
-    auto issue_group = [&](int g) __attribute__((always_inline)) {          // {W1 / W2^T sub (g + 2), W1^T sub g}
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int pc = wave + i * NW;
-            if (pc < 4 * T1 / 1024) issue_a(g + 2, min(g + 2, n - 1), pc);
-            else issue_b(g, pc - 4 * T1 / 1024);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < (4 * T1 / 1024 + NW - 1) / NW; ++i) {
-        const int pc = wave + i * NW;
-        if (pc < 4 * T1 / 1024) { issue_a(0, 0, pc); issue_a(1, 1, pc); }
+    // Weight rings (round 5: as in mlp_rc_fwd3_kernel): wave w brings piece w of each of the six planes of a hidden step -- W1 hi, lo, W2^T hi, lo (sub-tile [32 hidden][C]), W1^T hi,
+    // lo (sub-tile [C][32 hidden]).  A lane's source offset inside a sub-tile never changes, the sub-tile's base is wave-uniform: nothing to compute or to branch on per step.
+    static_assert(T1 / 1024 == NW && T3 / 1024 == NW, "one 1 KiB piece of each of the six planes per wave and hidden step");
+    uint32_t voff1, voff3;
+    {
+        constexpr int LPR = RB1 / 16, RPP = 1024 / RB1;
+        const int r1 = wave * RPP + lane / LPR;
+        voff1 = (uint32_t)(r1 * C + (((lane % LPR) ^ rc_swz<RB1>(r1)) << 3)) * 2u;
+        const int r3 = wave * 16 + (lane >> 2);
+        voff3 = (uint32_t)(r3 * p.Hd + (((lane & 3) ^ rc_swz<64>(r3)) << 3)) * 2u;
     }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue_a = [&](int slot_s, int src_s) __attribute__((always_inline)) {          // W1 / W2^T sub-tile src_s -> slot slot_s % 3
+        const int sl = slot_s % 3;
+        const char* b1p = reinterpret_cast<const char*>(p.W1p) + (long)src_s * (32 * C * 2);
+        const char* b2p = reinterpret_cast<const char*>(p.W2tp) + (long)src_s * (32 * C * 2);
+        __builtin_amdgcn_global_load_lds(b1p + voff1, (lds_ptr)(sW1 + (sl * 2 + 0) * T1 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b1p + wplane * 2 + voff1, (lds_ptr)(sW1 + (sl * 2 + 1) * T1 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b2p + voff1, (lds_ptr)(sW2t + (sl * 2 + 0) * T1 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b2p + wplane * 2 + voff1, (lds_ptr)(sW2t + (sl * 2 + 1) * T1 + wave * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int s) __attribute__((always_inline)) {                           // W1^T sub-tile s -> slot s % 3
+        const int sl = s % 3;
+        const char* b3p = reinterpret_cast<const char*>(p.W1tp) + (long)s * (32 * 2);
+        __builtin_amdgcn_global_load_lds(b3p + voff3, (lds_ptr)(sW1t + (sl * 2 + 0) * T3 + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b3p + wplane * 2 + voff3, (lds_ptr)(sW1t + (sl * 2 + 1) * T3 + wave * 1024), 16, 0, 0);
+    };
+    auto issue_group = [&](int g) __attribute__((always_inline)) {          // {W1 / W2^T sub (g + 2), W1^T sub g}: PPW = 6 loads per wave
+        issue_a(g + 2, min(g + 2, n - 1));
+        issue_b(g);
+    };
+    issue_a(0, 0);
+    issue_a(1, 1);
     issue_group(0);
     for (int i = tid; i < p.Hd / 4; i += NW * 64) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
     rc_bf16x8 xh[KB], xl[KB], gh[KB], gl[KB];

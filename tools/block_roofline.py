@@ -97,55 +97,52 @@ def bound_seconds(ops_list, precision):
 
 
 def stage0_mlp_kernels(B, img, drop, iters=10):
-    """The largest kernels of the stage-0 block at this batch -- the three mlp_rc.hip kernels -- timed one by one with events on the launch stream
-    (ops.mlp_residual's own calls: forward; data-gradient-only backward = mask pass + dgrad; full backward adds the recomputing weight-gradient
-    kernel + its partial-sum fold).  Priced against BOTH roofs with their ALGORITHMIC bytes / flops (recomputation is not useful work)."""
-    from mdvit_amd import ops
+    """The largest kernels of the stage-0 block at this batch -- the fused-MLP kernels of mlp_rc.hip -- each ALONE on the GPU: the C entry points called back to back with
+    events around `iters` launches (round 5; rounds 3-4 timed ops.mlp_residual's Python calls and took differences of three passes: the forward figure carried ~60 us of host
+    work per call).  Priced against BOTH chip roofs with their ALGORITHMIC bytes / flops (recomputation is not useful work); what bounds them is neither: see `bound`."""
+    from mdvit_amd import ops, _lib
+    from mdvit_amd._lib import call
     dev = torch.device("cuda:0")
     side = img // 4
     T, C, Hd = B * side * side, 64, 512
-    torch.manual_seed(3)
-    W1 = (torch.randn(Hd, C, device=dev) * C ** -0.5).requires_grad_(True); b1 = (torch.randn(Hd, device=dev) * 0.1).requires_grad_(True)
-    W2 = (torch.randn(C, Hd, device=dev) * Hd ** -0.5).requires_grad_(True); b2 = (torch.randn(C, device=dev) * 0.1).requires_grad_(True)
-    x = torch.randn(T, C, device=dev, requires_grad=True); res = torch.randn(T, C, device=dev); g = torch.randn(T, C, device=dev)
-    rs = (torch.rand(B, device=dev) < 0.9).float() / 0.9
+    g_ = torch.Generator(device="cpu").manual_seed(3)
+    r = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g_) * sc).to(dev)
+    x, res, gm = r(T, C), r(T, C), r(T, C)
+    W1, b1, W2, b2 = r(Hd, C, sc=C ** -0.5), r(Hd, sc=0.1), r(C, Hd, sc=Hd ** -0.5), r(C, sc=0.1)
+    rs = (torch.rand(B, generator=g_) < 0.9).float().to(dev) / 0.9
+    W1p, W2p, W2tp, W1tp = ops._wplanes(W1, False, 2), ops._wplanes(W2, False, 2), ops._wplanes(W2, True, 2), ops._wplanes(W1, True, 2)
+    y, dx, parts = torch.empty(T, C, device=dev), torch.empty(T, C, device=dev), torch.empty(Hd // 256, T, C, device=dev)
+    dW1, db1, dW2 = torch.empty(Hd, C, device=dev), torch.empty(Hd, device=dev), torch.empty(C, Hd, device=dev)
+    wsb = _lib.load().mdvit_mlp_rc_wgrad_ws_bytes(T, C, Hd)
+    ws = torch.empty(wsb // 4, device=dev)
+    P, st, k = ops._p, ops._stream(), (11, 22, 33, 44)
 
-    def timed(fn, n):
-        for _ in range(2):
+    def timed(fn):
+        for _ in range(30):                  # (the first ~30 launches after an idle stretch run ~20 % slower: the clock is still ramping -- tools/mlp_rc_time.py's round 0)
             fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(n):
+        for _ in range(iters):
             fn()
         e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n * 1e-3
+        return e0.elapsed_time(e1) / iters * 1e-3
 
-    def fwd():
-        return ops.mlp_residual(x, res, W1, b1, W2, b2, rowscale=rs, drop_p=drop, rows_per_scale=side * side)
-
-    with torch.no_grad():
-        t_f = timed(fwd, iters)
-
-    def fb():
-        fwd().backward(g)
-    t_fb = timed(fb, iters)
-    ops.set_dgrad_only(True)
-    try:
-        t_fd = timed(fb, iters)
-    finally:
-        ops.set_dgrad_only(False)
-    mask_pass = 8.0 * T * C / 5.5e12                 # the g -> gm mask pass (chan_reduce<2>: measured 5.5 TB/s), part of both backward figures
+    t_f = timed(lambda: call("mdvit_mlp_rc_fwd", P(x), P(W1p), P(b1), P(W2p), P(b2), P(res), P(rs), side * side, P(y), T, C, Hd, drop, *k, None, st))
+    t_d = timed(lambda: call("mdvit_mlp_rc_dgrad", P(gm), P(x), P(W1p), P(b1), P(W2tp), P(W1tp), P(dx), T, C, Hd, drop, k[0], k[1], None, st))
+    t_w = timed(lambda: call("mdvit_mlp_rc_wgrad", P(gm), P(x), P(W1p), P(b1), P(W2tp), P(dW1), P(db1), P(dW2), P(ws), wsb, T, C, Hd, drop, k[0], k[1], None, 0, st))
+    t_b = timed(lambda: call("mdvit_mlp_rc_bwd", P(gm), P(x), P(W1p), P(b1), P(W2tp), P(W1tp), P(parts), P(dW1), P(db1), P(dW2), P(ws), wsb, T, C, Hd, drop, k[0], k[1], None, 0, st))
     rows = []
-    for name, secs, nbytes, flops in (("mlp_rc_fwd_kernel (x, res -> y)", t_f, 4.0 * (3 * T * C + 2 * C * Hd), 4.0 * T * C * Hd),
-                                      ("mlp_rc_dgrad_kernel (gm, x -> dx)", t_fd - t_f - mask_pass, 4.0 * (3 * T * C + 3 * C * Hd), 4.0 * T * C * Hd),
-                                      ("mlp_rc_wgrad_kernel + rc_reduce (gm, x -> dW1, db1, dW2)", t_fb - t_fd, 4.0 * (2 * T * C + 2 * C * Hd), 4.0 * T * C * Hd)):
+    for name, secs, nbytes, flops in (("mlp_rc_fwd3_kernel (x, res -> y)", t_f, 4.0 * (3 * T * C + 2 * C * Hd), 4.0 * T * C * Hd),
+                                      ("mlp_rc_dgrad_kernel (gm, x -> dx)", t_d, 4.0 * (3 * T * C + 3 * C * Hd), 4.0 * T * C * Hd),
+                                      ("mlp_rc_wgrad_kernel + rc_reduce (gm, x -> dW1, db1, dW2)", t_w, 4.0 * (2 * T * C + 2 * C * Hd), 4.0 * T * C * Hd),
+                                      ("mlp_rc_wgrad_kernel<DX> + rc_reduce = the whole backward (gm, x -> dx parts, dW1, db1, dW2)", t_b, 4.0 * (4 * T * C + 3 * C * Hd), 8.0 * T * C * Hd)):
         rows.append({"kernel": name, "us": secs * 1e6, "algorithmic_bytes": nbytes, "algorithmic_flop": flops, "hbm_GBps": nbytes / secs / 1e9,
                      "frac_hbm": nbytes / secs / HBM, "useful_TFLOPs": flops / secs / 1e12, "frac_mfma_bf16x3": flops / secs / MFMA["bf16x3"],
                      "bound": "VALU + MFMA in series (on one SIMD an MFMA does not run beside a saturated VALU pipe: profiles/r05_mfma_valu_overlap.txt; erf-GELU / dropout / "
                               "hi-lo split ~70 VALU cycles per hidden element + 48 MFMA cycles of bf16x3 products) -- neither chip roof; see DESIGN.md section 3"})
-    return {"rows": T, "C": C, "hidden": Hd, "timer": "torch events around ops.mlp_residual forward / backward on the launch stream, differences of the three passes",
-            "kernels": rows, "largest": max(rows, key=lambda r: r["us"])}
+    return {"rows": T, "C": C, "hidden": Hd, "timer": "torch events around 10 back-to-back launches of the C entry point on the launch stream, nothing else on the GPU",
+            "kernels": rows, "largest": max(rows[:3], key=lambda r_: r_["us"])}
 
 
 def stage0_attention_core(B, img, iters=10):
@@ -181,7 +178,7 @@ def stage0_attention_core(B, img, iters=10):
 
     res = {}
     for name, fn in (("fwd", fwd), ("bwd", bwd)):
-        for _ in range(3):
+        for _ in range(20):
             fn()
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
