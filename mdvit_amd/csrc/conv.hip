@@ -896,8 +896,11 @@ extern "C" int mdvit_upsample_multi_fwd(const float* const* xs, const int32_t* H
         bool ok = tile_on && Ho % UT_H == 0 && Wo % UT_W == 0 && C % UT_C == 0 && (long)(Ho / UT_H) * (Wo / UT_W) < (1L << 30) && C / UT_C < 65536 && B < 65536;
         int pool = 0;
         for (int i = 0; i < n && ok; ++i) {
-            ok = Ho % Hi[i] == 0 && Wo % Wi[i] == 0 && Ho / Hi[i] >= 2 && Wo / Wi[i] >= 2;
-            if (ok) pool += (UT_H / (Ho / Hi[i]) + 2) * (UT_W / (Wo / Wi[i]) + 2);         // rows h0(first) .. h1(last) of the tile: at most tile / factor + 2
+            // power-of-two factors only: for them a tile's source patch is at most tile / factor + 2 rows (columns) -- the bound the pool is sized with; a factor of 3
+            // puts one more row under some tiles (105 staged pixels against 96 estimated), and nothing in the models asks for it
+            const int fh = Ho / Hi[i], fw = Wo / Wi[i];
+            ok = Ho % Hi[i] == 0 && Wo % Wi[i] == 0 && fh >= 2 && fw >= 2 && fh <= 16 && fw <= 16 && (fh & (fh - 1)) == 0 && (fw & (fw - 1)) == 0;
+            if (ok) pool += (UT_H / fh + 2) * (UT_W / fw + 2);         // rows h0(first) .. h1(last) of the tile: at most tile / factor + 2
         }
         if (ok && pool <= UT_POOL) {
             hipLaunchKernelGGL(upsample_multi_tile_kernel, dim3((Ho / UT_H) * (Wo / UT_W), C / UT_C, B), dim3(256), 0, (hipStream_t)stream, p, base, y, Ho, Wo, C);

@@ -310,8 +310,10 @@ class _on_side:
     main stream; the listed main-stream tensors are protected from reuse until the side work is done (bounded: _side_protect)."""
 
     def __init__(self, *tensors, foreign=True):
+        """foreign: True -- the first tensor is the upstream gradient (the one protected tensor a node of another stream may have allocated); "all" -- every listed tensor
+        is an upstream gradient (a node with several of them: _ComposeHeads.backward); False -- none"""
         self.tensors = [t for t in tensors if t is not None]
-        self.foreign = foreign and bool(tensors) and tensors[0] is not None
+        self.foreign = foreign if (foreign and bool(tensors) and tensors[0] is not None) else False
         self.ctx = None
 
     def __enter__(self):
@@ -332,7 +334,8 @@ class _on_side:
             if self.tensors and self.foreign:
                 # the FIRST tensor is the upstream gradient: the one protected tensor a node of ANOTHER stream may have allocated (a peer-head / branch-stream
                 # join).  Its block goes back to THAT stream's pool, which never waits for the side stream -- so the allocator is told.
-                self.tensors[0].record_stream(_side_stream)
+                for t in (self.tensors if self.foreign == "all" else self.tensors[:1]):
+                    t.record_stream(_side_stream)
         else:
             for t in self.tensors:
                 t.record_stream(_side_stream)
@@ -1060,6 +1063,10 @@ def _zeros_once(n: int, device):
             ev = None
         elif cur.cuda_stream != fs:
             cur.wait_event(ev)
+    if slab is not None and cur.cuda_stream != fs:
+        # a consumer on another stream than the filler's: the slab's block goes back to the FILLER's pool when its last slice dies, and nothing else orders that with this
+        # stream's kernel that still writes the slice (peer / branch streams only)
+        slab.record_stream(cur)
     _zero_slab[:] = [slab, off + n4, ev, fs]
     return slab[off:off + n]
 
@@ -1226,7 +1233,7 @@ class _ComposeHeads(torch.autograd.Function):
         if sunk:
             # into the gradient buckets, like every other sunk weight gradient: on the weight-gradient stream (joined before the buckets are read);
             # a sink written on whatever stream this node runs on -- a peer stream, the sweep stream -- is ordered with nothing
-            with _on_side(*dWc, *dbc):
+            with _on_side(*dWc, *dbc, foreign="all"):      # all 2 G Q of them are upstream gradients of other nodes (with peer streams: other streams' pools)
                 param_grads()
         else:
             param_grads()
@@ -2137,8 +2144,16 @@ def audit_sweep_graph(root):
             if nf is not None:
                 consumers[(nf, idx)] += 1
                 stack.append(nf)
-    fanin = sorted({type(nf).__name__ + (":" + str(idx) if idx else "") for (nf, idx), c in consumers.items() if c > 1 and type(nf).__name__ != "AccumulateGrad"})
-    return sorted(set(native)), fanin
+    fanin = {type(nf).__name__ + (":" + str(idx) if idx else "") for (nf, idx), c in consumers.items() if c > 1 and type(nf).__name__ != "AccumulateGrad"}
+    if _sinks:
+        # with gradient sinks active every parameter the sweep reaches is expected to have one (this package's Functions then write the gradient themselves and hand
+        # autograd None); a parameter WITHOUT a sink gets its gradient from the engine's AccumulateGrad -- an add on the stream of the forward
+        for (nf, idx), c in consumers.items():
+            if type(nf).__name__ == "AccumulateGrad":
+                var = getattr(nf, "variable", None)
+                if var is not None and var.requires_grad and _sink_of(var) is None:
+                    fanin.add("AccumulateGrad without a gradient sink: parameter of shape " + "x".join(str(d) for d in var.shape))
+    return sorted(set(native)), sorted(fanin)
 
 
 def fork(x, n: int):

@@ -210,15 +210,21 @@ def _aux_graph_is_ours(model, aux_sum) -> bool:
     the stream the FORWARD ran on -- unordered with a sweep that was moved elsewhere.  (Found with the DeepLabV3 peer heads before ASPP's five-consumer input went
     behind ops.fork: the adapters' gradients ~100 % off in one of eight cold steps.)  The graph's structure does not change from step to step: audited once per
     model object (ops.audit_sweep_graph, a Python walk of ~1000 nodes), the verdict and the findings cached on it."""
-    ok = getattr(model, "_aux_sweep_graph_ok", None)
-    if ok is None:
-        native, fanin = ops.audit_sweep_graph(aux_sum)
-        ok = not native and not fanin
-        try:
-            model._aux_sweep_graph_ok = ok
-            model._aux_sweep_graph_findings = (native, fanin)
-        except Exception:           # (an object that refuses attributes: audit every step)
-            pass
+    # the verdict is cached per (model object, what shapes its aux graph): the peer-head family, train / eval, how many domain batches the forward fused, whether
+    # gradient sinks are attached -- a swapped head, another fusion width or a detached accumulator is audited again (ADVICE r04: the cache used to live as long as the object)
+    sig = (getattr(model, "decoder_name", None), bool(model.training), tuple(aux_sum.shape), type(aux_sum.grad_fn).__name__, bool(ops._sinks),
+           tuple(type(getattr(model, f"debranch{i}", None)).__name__ for i in range(1, 5)))
+    cache = getattr(model, "_aux_sweep_graph_cache", None)
+    if cache is not None and cache[0] == sig:
+        return cache[1]
+    native, fanin = ops.audit_sweep_graph(aux_sum)
+    ok = not native and not fanin
+    try:
+        model._aux_sweep_graph_cache = (sig, ok)
+        model._aux_sweep_graph_ok = ok
+        model._aux_sweep_graph_findings = (native, fanin)
+    except Exception:           # (an object that refuses attributes: audit every step)
+        pass
     return ok
 
 

@@ -1580,3 +1580,17 @@ def test_armed_gemm_launch_records_its_own_begin_and_end():
     (name, rec), = t.items()
     assert name.startswith("gemm_f32_kernel<") and rec["launches"] == 8 and 1 <= rec["n"] <= 8 and rec["ms"] > 0
     assert rec["timer"].startswith("kernel begin/end") and rec["flop"] == rec["n"] * 2.0 * M * N * K
+
+
+def test_upsample_multi_with_a_factor_of_three_takes_the_flat_kernel():
+    """the LDS-tiled resize-and-sum sizes its source-patch pool with tile / factor + 2 rows per axis, which holds for power-of-two factors only -- three factor-3
+    sources (Ho = 48 from 16) would stage 105 pixels into a 96-pixel pool.  Such shapes now go to the flat kernel; the result must equal torch's bilinear resize."""
+    from mdvit_amd import ops
+    B, Ho, C = 2, 48, 128
+    xs = [rnd(B, 16, 16, C, seed=900 + i).to(dev()) for i in range(3)]
+    base = rnd(B, Ho, Ho, C, seed=910).to(dev())
+    got = ops.upsample_sum(base, xs, Ho, Ho)
+    ref = base.double()
+    for x in xs:
+        ref = ref + F.interpolate(x.double().permute(0, 3, 1, 2), size=(Ho, Ho), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    check(got, ref, tol=2e-6, name="upsample_sum, factor 3")
