@@ -318,6 +318,10 @@ size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
 int mdvit_gemm_ledger(int32_t enable);
 int mdvit_gemm_ledger_read(int32_t index, char* name, int32_t cap, int64_t* launches, double* flop, double* bytes);
 int mdvit_mlp_rc_config(int32_t fwd_variant);
+/* The arithmetic of the register-chained MLP kernels (mdvit_mlp_rc_* / mdvit_mlp_rc16_*): 2 (default) = bf16x3, the parity mode -- every operand as hi + lo bf16 planes,
+ * three MFMAs per product; 1 = the bf16 speed mode of BASELINE configs[1] / [3] -- the hi plane alone, one MFMA per product and no lo split of the chained hidden operand
+ * (~2^-9 per product instead of ~2^-17).  Process-wide, like the GEMM precision it follows (mdvit_amd.ops.set_gemm_precision sets both); operands and workspaces are the same. */
+int mdvit_mlp_rc_planes(int32_t planes);
 /* tuning hook: whether mdvit_block_bwd runs the C = 64 MLP backward as ONE kernel (mdvit_mlp_rc_bwd) -- 0 never, 1 always, 2 (default) when the call has no weight-gradient
  * stream (with one, the separate weight-gradient kernel overlaps the main stream's chain).  Set it before mdvit_block_bwd_ws_bytes: the workspace layout follows it. */
 int mdvit_block_config(int32_t mlp_bwd_fused);

@@ -109,6 +109,7 @@ _SIGS = {
     "mdvit_gemm_ph_prefers_epi": [i32, i32, i32, i32, i32],
     "mdvit_mlp_config": [i32, i32],
     "mdvit_mlp_rc_config": [i32],
+    "mdvit_mlp_rc_planes": [i32],
     "mdvit_block_config": [i32],
     "mdvit_gemm_ledger": [i32],
     "mdvit_gemm_ledger_read": [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)],

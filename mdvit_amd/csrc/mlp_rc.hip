@@ -74,6 +74,16 @@ __device__ __forceinline__ rc_bf16x8 rc_frag_perm(const char* tile, int row, int
     return __builtin_bit_cast(rc_bf16x8, (rc_u4{a[0], a[1], b[0], b[1]}));
 }
 
+// P1 (round 5, the bf16 speed mode: mdvit_mlp_rc_planes(1)): ONE bf16 plane per operand -- the hi x hi product alone, a third of the MFMA work and no lo split of the chained
+// operand; the lo planes still travel through the rings (L2 -> LDS is not what binds these kernels) and their fragment reads are dead code
+#define RC_MFMA3P(P1, acc, ah, al, bh, bl)                                          \
+    do {                                                                            \
+        if constexpr (!(P1)) {                                                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);    \
+        }                                                                           \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);        \
+    } while (0)
 #define RC_MFMA3(acc, ah, al, bh, bl)                                           \
     do {                                                                        \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    \
@@ -171,8 +181,10 @@ __device__ __forceinline__ void rc_gelu_both_k(float x, float hk, float d, float
 }
 typedef float rc_f2 __attribute__((ext_vector_type(2)));
 // hi / lo bf16 planes of a pair of values: mdvit_split_bf16x3's arithmetic (RNE hi, RNE (x - hi))
+template <bool P1 = false>
 __device__ __forceinline__ void rc_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((rc_f2{a, b}), mdvit_bf16x2));
+    if constexpr (P1) { lo = 0u; return; }          // one plane: the lo half is never multiplied
     const rc_f2 l = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(l, mdvit_bf16x2));
 }
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // per CU); the overlap of one wave's MFMAs with another's activation VALU comes from the third wave instead.  Group g = {W1 sub g, W2 sub g},
 // issued two steps ahead into a three-slot ring.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int C, int NW, bool DROP, int OCC = 3, bool STORE = false, bool LNP = false>
+template <int C, int NW, bool DROP, int OCC = 3, bool STORE = false, bool LNP = false, bool P1 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc_fwd3_kernel(RcArgs p) {
     constexpr int KB = C / 16, CB = C / 32;
     constexpr int RB1 = C * 2;
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const rc_bf16x8 ah = rc_frag<RB1>(w1h, l31, 2 * kb + lhi), al = rc_frag<RB1>(w1l, l31, 2 * kb + lhi);
-            RC_MFMA3(u, ah, al, xh[kb], xl[kb]);
+            RC_MFMA3P(P1, u, ah, al, xh[kb], xl[kb]);
         }
 #else
 #pragma unroll
@@ -554,8 +566,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             const float h0 = rc_gelu_k(u[4 * q + 0], hk[0]), h1 = rc_gelu_k(u[4 * q + 1], hk[1]), h2 = rc_gelu_k(u[4 * q + 2], hk[2]), h3 = rc_gelu_k(u[4 * q + 3], hk[3]);
 #endif
             if (STORE) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + t * 32 + 8 * q + 4 * lhi) = make_float4(h0, h1, h2, h3); }
-            rc_split2(h0, h1, ph[2 * q], pl[2 * q]);
-            rc_split2(h2, h3, ph[2 * q + 1], pl[2 * q + 1]);
+            rc_split2<P1>(h0, h1, ph[2 * q], pl[2 * q]);
+            rc_split2<P1>(h2, h3, ph[2 * q + 1], pl[2 * q + 1]);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -564,8 +576,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #if RC_ABL != 3 && RC_ABL != 4
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const rc_bf16x8 ah = rc_frag_perm(w2h, cb * 32 + l31, half, lhi), al = rc_frag_perm(w2l, cb * 32 + l31, half, lhi);
-                RC_MFMA3(yacc[cb], ah, al, hh, hl);
+                const rc_bf16x8 ah = rc_frag_perm(w2h, cb * 32 + l31, half, lhi);
+                rc_bf16x8 al = ah;
+                if constexpr (!P1) al = rc_frag_perm(w2l, cb * 32 + l31, half, lhi);
+                RC_MFMA3P(P1, yacc[cb], ah, al, hh, hl);
             }
 #else
             asm volatile("" ::"v"(hh), "v"(hl));       // ablation: no product 2
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 // Same structure; per hidden step u = x W1s^T and d = gm W2s as D[hidden][token], du = d * gelu'(u + b1) * mask in registers,
 // dx^T += W1s^T-tile * du (the chained operand).  Rings: W1 sub, W2^T sub (needed one step ahead), W1^T sub (one step behind).
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int C, int NW, bool DROP>
+template <int C, int NW, bool DROP, bool P1 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rc_dgrad_kernel(RcArgs p) {
     constexpr int KB = C / 16, CB = C / 32;
     constexpr int RB1 = C * 2;
@@ -697,9 +711,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const rc_bf16x8 ah = rc_frag<RB1>(w1h, l31, 2 * kb + lhi), al = rc_frag<RB1>(w1l, l31, 2 * kb + lhi);
-            RC_MFMA3(u, ah, al, xh[kb], xl[kb]);
+            RC_MFMA3P(P1, u, ah, al, xh[kb], xl[kb]);
             const rc_bf16x8 ch = rc_frag<RB1>(w2h, l31, 2 * kb + lhi), cl = rc_frag<RB1>(w2l, l31, 2 * kb + lhi);
-            RC_MFMA3(d, ch, cl, gh[kb], gl[kb]);
+            RC_MFMA3P(P1, d, ch, cl, gh[kb], gl[kb]);
         }
     };
     auto prod3 = [&](int s, const rc_bf16x8 (&dh)[2], const rc_bf16x8 (&dl)[2]) __attribute__((always_inline)) {
@@ -708,8 +722,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const rc_bf16x8 ah = rc_frag_perm(hi, cb * 32 + l31, half, lhi), al = rc_frag_perm(lo, cb * 32 + l31, half, lhi);
-                RC_MFMA3(dxacc[cb], ah, al, dh[half], dl[half]);
+                const rc_bf16x8 ah = rc_frag_perm(hi, cb * 32 + l31, half, lhi);
+                rc_bf16x8 al = ah;
+                if constexpr (!P1) al = rc_frag_perm(lo, cb * 32 + l31, half, lhi);
+                RC_MFMA3P(P1, dxacc[cb], ah, al, dh[half], dl[half]);
             }
     };
     auto act = [&](int s, const rc_f32x16& u, const rc_f32x16& d, rc_bf16x8 (&dh)[2], rc_bf16x8 (&dl)[2]) __attribute__((always_inline)) {
@@ -725,8 +741,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             const float g0 = rc_dgelu_k(u[4 * q + 0], dm[0], hks, pks), g1 = rc_dgelu_k(u[4 * q + 1], dm[1], hks, pks);
             const float g2 = rc_dgelu_k(u[4 * q + 2], dm[2], hks, pks), g3 = rc_dgelu_k(u[4 * q + 3], dm[3], hks, pks);
-            rc_split2(g0, g1, ph[2 * q], pl[2 * q]);
-            rc_split2(g2, g3, ph[2 * q + 1], pl[2 * q + 1]);
+            rc_split2<P1>(g0, g1, ph[2 * q], pl[2 * q]);
+            rc_split2<P1>(g2, g3, ph[2 * q + 1], pl[2 * q + 1]);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -791,6 +807,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // go to `part`, added in a fixed order by rc_reduce_kernel (deterministic).  Workgroups of one token range (all roles) sit on one XCD
 // at adjacent dispatch slots: the second role reads x / gm out of that XCD's L2.
 // ------------------------------------------------------------------------------------------------------------------------------
+#define RC_MFMA3_ACT_AP(P1, acc, ah, al, bh, bl)                                    \
+    do {                                                                            \
+        if constexpr (!(P1)) {                                                      \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);    \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    \
+        }                                                                           \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);        \
+    } while (0)
 #define RC_MFMA3_ACT_A(acc, ah, al, bh, bl)                                     \
     do {                                                                        \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);    \
@@ -826,6 +850,14 @@ __device__ __forceinline__ rc_bf16x8 rc_tr8(const char* plane, int t0, int col0,
 // the 16 x 16 block dx^T[16 cblk ..][16 tblk ..] over ALL 256 hidden units of the role on v_mfma_f32_16x16x32_bf16 -- A = W1^T rows (the role's [64][256] slice, resident
 // in LDS), B = du^T read back with ds_read_b64_tr_b16 (k = hidden down the rows) -- so no partial sums cross waves.  Roles (256-wide hidden ranges) write their own
 // dx partial [role][tokens][C]; the consumer adds them (mdvit_layernorm_bwd's dy2, or rc_sum_parts_kernel).
+#define RC16_MFMA3_BWDP(P1, acc, ah, al, bh, bl)                                    \
+    do {                                                                            \
+        if constexpr (!(P1)) {                                                      \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);    \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);    \
+        }                                                                           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);        \
+    } while (0)
 #define RC16_MFMA3_BWD(acc, ah, al, bh, bl)                                     \
     do {                                                                        \
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);    \
@@ -836,7 +868,7 @@ typedef float rc_acc4 __attribute__((ext_vector_type(4)));
 constexpr int RC_WT_ROW = 528;                       // bytes per row of the W1^T slice in LDS: 256 hidden x 2 bytes + 16 (rows 4 banks apart)
 constexpr int RC_BWD_LDS = 2 * 64 * RC_WT_ROW + 8 * 2 * 2048;
 
-template <int C, bool DROP, bool DX = false>
+template <int C, bool DROP, bool DX = false, bool P1 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rc_wgrad_kernel(RcArgs p) {
     constexpr int KB = C / 16, CB = C / 32;
     constexpr int TP = 32 * 128;                     // one plane of a [32 tokens][64 c] tile (C = 64: 128-byte rows)
@@ -922,9 +954,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             const rc_bf16x8 ah = rc_frag<128>(xhi, l31, 2 * kb + lhi), al = rc_frag<128>(xlo, l31, 2 * kb + lhi);
-            RC_MFMA3_ACT_A(u, ah, al, w1h[kb], w1l[kb]);
+            RC_MFMA3_ACT_AP(P1, u, ah, al, w1h[kb], w1l[kb]);
             const rc_bf16x8 ch = rc_frag<128>(ghi, l31, 2 * kb + lhi), cl = rc_frag<128>(glo, l31, 2 * kb + lhi);
-            RC_MFMA3_ACT_A(d, ch, cl, w2h[kb], w2l[kb]);
+            RC_MFMA3_ACT_AP(P1, d, ch, cl, w2h[kb], w2l[kb]);
         }
         // per 16-token half: h, du in registers (lane <-> hidden unit, register r <-> token (r & 3) + 8 (r >> 2) + 4 lhi), then the
         // weight-gradient products over k = those 16 tokens in the order the registers hold them
@@ -959,8 +991,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     db1 += gv[e];
                 }
                 uint32_t a0, a1, a2, a3;
-                rc_split2(hv[0], hv[1], a0, a1);
-                rc_split2(gv[0], gv[1], a2, a3);
+                rc_split2<P1>(hv[0], hv[1], a0, a1);
+                rc_split2<P1>(gv[0], gv[1], a2, a3);
                 hh[i] = a0; hl[i] = a1; dh[i] = a2; dl[i] = a3;
             }
             const rc_bf16x8 hhf = __builtin_bit_cast(rc_bf16x8, hh), hlf = __builtin_bit_cast(rc_bf16x8, hl);
@@ -983,10 +1015,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int col0 = cb * 32 + 16 * ((lane >> 4) & 1);
                 // dW1[hid][c] += du^T x : A = du^T (registers), B = x[k = token][c] (transposing read)
                 const rc_bf16x8 bxh = rc_tr8(xhi, t0, col0, l15), bxl = rc_tr8(xlo, t0, col0, l15);
-                RC_MFMA3_ACT_A(aw1[cb], dhf, dlf, bxh, bxl);
+                RC_MFMA3_ACT_AP(P1, aw1[cb], dhf, dlf, bxh, bxl);
                 // dW2[c][hid] += gm^T h : A = gm^T[c][k = token] (transposing read), B = h (registers)
                 const rc_bf16x8 agh = rc_tr8(ghi, t0, col0, l15), agl = rc_tr8(glo, t0, col0, l15);
-                RC_MFMA3_ACT_A(aw2[cb], agh, agl, hhf, hlf);
+                RC_MFMA3_ACT_AP(P1, aw2[cb], agh, agl, hhf, hlf);
             }
         }
         if (DX) {
@@ -1009,7 +1041,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const rc_v4i16 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(dplane + 2048 + oa)), l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rc_lds_v4i16_ptr)(dplane + 2048 + ob));
                 const rc_bf16x8 bh = __builtin_bit_cast(rc_bf16x8, (rc_v8i16{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}));
                 const rc_bf16x8 bl = __builtin_bit_cast(rc_bf16x8, (rc_v8i16{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]}));
-                RC16_MFMA3_BWD(acc, ah, al, bh, bl);
+                RC16_MFMA3_BWDP(P1, acc, ah, al, bh, bl);
             }
             const int tok = t * 32 + tblk * 16 + l15;    // D: lane <-> token column, registers <-> rows c = 16 cblk + 4 g4 + r
             if (tok < p.M) *reinterpret_cast<float4*>(p.dx + ((long)role * p.M + tok) * C + cblk * 16 + 4 * g4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -1070,6 +1102,14 @@ __device__ __forceinline__ rc_bf16x8 rc16_frag_perm(const char* tile, int row, i
     return __builtin_bit_cast(rc_bf16x8, (rc_u4{a[0], a[1], b[0], b[1]}));
 }
 
+#define RC16_MFMA3P(P1, acc, ah, al, bh, bl)                                        \
+    do {                                                                            \
+        if constexpr (!(P1)) {                                                      \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);    \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);    \
+        }                                                                           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);        \
+    } while (0)
 #define RC16_MFMA3(acc, ah, al, bh, bl)                                         \
     do {                                                                        \
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);    \
@@ -1160,7 +1200,7 @@ __device__ __forceinline__ void rc16_ln_rows128(float4 (&a)[4], float4 (&b)[4], 
     if (g == 0 && row < M) { ln.mean[row] = mu; ln.rstd[row] = rs; }
 }
 
-template <int C, int NW, int OCC, bool DROP, bool STORE, bool LNP = false>
+template <int C, int NW, int OCC, bool DROP, bool STORE, bool LNP = false, bool P1 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc16_fwd_kernel(RcArgs p) {
     constexpr int KS = C / 32, CT = C / 16;
     constexpr int RB1 = C * 2;
@@ -1224,15 +1264,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const rc_bf16x8 ah = rc16_frag<RB1>(w1h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w1l, 16 * ht + c16, 4 * ks + g);
-                RC16_MFMA3(u, ah, al, xh[ks], xl[ks]);
+                RC16_MFMA3P(P1, u, ah, al, xh[ks], xl[ks]);
             }
             float hk[4] = {0.5f, 0.5f, 0.5f, 0.5f};
             if (DROP) rc_keep_sel4(mdvit_drop_bits_q(k1a, k1b, dq0 + t * 8 + 4 * ht), thresh16, hki, 0.f, hk);
             const float h0 = rc_gelu_k(u[0], hk[0]), h1 = rc_gelu_k(u[1], hk[1]), h2 = rc_gelu_k(u[2], hk[2]), h3 = rc_gelu_k(u[3], hk[3]);
             if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.h + (long)row * p.Hd + hd) = make_float4(h0, h1, h2, h3); }
             uint32_t a0, a1, a2, a3;
-            rc_split2(h0, h1, a0, a1);
-            rc_split2(h2, h3, a2, a3);
+            rc_split2<P1>(h0, h1, a0, a1);
+            rc_split2<P1>(h2, h3, a2, a3);
             hh4[2 * ht] = a0; hl4[2 * ht] = a1; hh4[2 * ht + 1] = a2; hl4[2 * ht + 1] = a3;
         }
         if (STORE && p.hbf && row < p.M) {         // the hi plane IS bf16(h): two 8-byte stores (the two 4-unit groups of this lane) instead of two 16-byte ones
@@ -1244,7 +1284,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const rc_bf16x8 ah = rc16_frag_perm(w2h, 16 * ct + c16, g), al = rc16_frag_perm(w2l, 16 * ct + c16, g);
-            RC16_MFMA3(yacc[ct], ah, al, hh, hl);
+            RC16_MFMA3P(P1, yacc[ct], ah, al, hh, hl);
         }
     }
     RC_WAIT_VM(0);
@@ -1276,7 +1316,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     }
 }
 
-template <int C, int NW, int OCC, bool DROP, bool STORE>
+template <int C, int NW, int OCC, bool DROP, bool STORE, bool P1 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mlp_rc16_dgrad_kernel(RcArgs p) {
     constexpr int KS = C / 32, CT = C / 16;
     constexpr int RB1 = C * 2;                       // row bytes of the [32 hidden][C] sub-tiles of W1 and W2^T
@@ -1349,12 +1389,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const rc_bf16x8 ah = rc16_frag<RB1>(w1h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w1l, 16 * ht + c16, 4 * ks + g);
-                RC16_MFMA3(u, ah, al, xh[ks], xl[ks]);
+                RC16_MFMA3P(P1, u, ah, al, xh[ks], xl[ks]);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const rc_bf16x8 ah = rc16_frag<RB1>(w2h, 16 * ht + c16, 4 * ks + g), al = rc16_frag<RB1>(w2l, 16 * ht + c16, 4 * ks + g);
-                RC16_MFMA3(d, ah, al, mh[ks], ml[ks]);
+                RC16_MFMA3P(P1, d, ah, al, mh[ks], ml[ks]);
             }
             float dm[4] = {d[0], d[1], d[2], d[3]};
             if (DROP) {
@@ -1366,8 +1406,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
             const float g0 = rc_dgelu_k(u[0], dm[0], hks, pks), g1 = rc_dgelu_k(u[1], dm[1], hks, pks), g2 = rc_dgelu_k(u[2], dm[2], hks, pks), g3 = rc_dgelu_k(u[3], dm[3], hks, pks);
             if (STORE && !p.hbf) { if (row < p.M) *reinterpret_cast<float4*>(p.du + (long)row * p.Hd + hd) = make_float4(g0, g1, g2, g3); }
             uint32_t a0, a1, a2, a3;
-            rc_split2(g0, g1, a0, a1);
-            rc_split2(g2, g3, a2, a3);
+            rc_split2<P1>(g0, g1, a0, a1);
+            rc_split2<P1>(g2, g3, a2, a3);
             dh4[2 * ht] = a0; dl4[2 * ht] = a1; dh4[2 * ht + 1] = a2; dl4[2 * ht + 1] = a3;
         }
         if (STORE && p.hbf && row < p.M) {
@@ -1379,7 +1419,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const rc_bf16x8 ah = rc16_frag_perm(w3h, 16 * ct + c16, g), al = rc16_frag_perm(w3l, 16 * ct + c16, g);
-            RC16_MFMA3(dacc[ct], ah, al, dh, dl);
+            RC16_MFMA3P(P1, dacc[ct], ah, al, dh, dl);
         }
     }
     RC_WAIT_VM(0);
@@ -1551,6 +1591,26 @@ void rc_fill(RcArgs& a, int M, int Hd, float drop_p, uint32_t k10, uint32_t k11,
 
 }  // namespace
 
+// One bf16 plane per operand in the register-chained MLP kernels (the bf16 speed mode) instead of the bf16x3 hi / lo pair: mdvit_mlp_rc_planes(1 | 2).  A process-wide
+// arithmetic switch like ops.set_gemm_precision, which sets it; 2 (the parity arithmetic) unless told otherwise.
+int g_rc_planes = 2;
+extern "C" int mdvit_mlp_rc_planes(int32_t planes) {
+    if (planes != 1 && planes != 2) return mdvit_set_error(MDVIT_E_SHAPE, "mlp_rc_planes: 1 or 2");
+    g_rc_planes = planes;
+    return MDVIT_OK;
+}
+// launch one instantiation: its dynamic-LDS limit raised once per device (lds_cap > 0), then the launch
+template <auto KERNEL>
+static int rc_launch(int lds_cap, dim3 grid, dim3 block, int smem, hipStream_t s, const RcArgs& a) {
+    static bool fl[64] = {false};
+    if (lds_cap > 0) {
+        const int rc = rc_set_lds(reinterpret_cast<const void*>(KERNEL), lds_cap, fl);
+        if (rc != MDVIT_OK) return rc;
+    }
+    hipLaunchKernelGGL(KERNEL, grid, block, smem, s, a);
+    return MDVIT_OK;
+}
+
 int g_rc_fwd_variant = 3;       // 2: software-pipelined wave, 2 waves per SIMD; 3: plain wave, 3 waves per SIMD (tuning hook: mdvit_mlp_rc_config)
 int g_rc_fwd128_variant = 16;   // C = 128 forward: 16-token waves (16x16x32 tiles; 327-352 us at 131072 tokens) or 32-token waves (32x32x16; 388-431 us: measured, not the default)
 extern "C" int mdvit_mlp_rc_config(int32_t fwd_variant) {
@@ -1585,8 +1645,13 @@ extern "C" int mdvit_mlp_rc_fwd(const float* x, const void* W1p, const float* b1
         rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, false>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f3);
         if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, true>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f4);
         if (rc != MDVIT_OK) return rc;
-        if (a.drop) hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, false>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+        constexpr int CAP = 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4;
+        const dim3 grid(cdiv(M, NW * 32)), block(NW * 64);
+        hipStream_t s = (hipStream_t)stream;
+        if (g_rc_planes == 1) rc = a.drop ? rc_launch<&mlp_rc_fwd3_kernel<64, NW, true, 3, false, false, true>>(CAP, grid, block, smem, s, a)
+                                          : rc_launch<&mlp_rc_fwd3_kernel<64, NW, false, 3, false, false, true>>(CAP, grid, block, smem, s, a);
+        else rc = a.drop ? rc_launch<&mlp_rc_fwd3_kernel<64, NW, true>>(CAP, grid, block, smem, s, a) : rc_launch<&mlp_rc_fwd3_kernel<64, NW, false>>(CAP, grid, block, smem, s, a);
+        if (rc != MDVIT_OK) return rc;
     } else if (a.drop) hipLaunchKernelGGL((mlp_rc_fwd_kernel<64, NW, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((mlp_rc_fwd_kernel<64, NW, false>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
@@ -1612,7 +1677,12 @@ extern "C" int mdvit_mlp_rc_dgrad(const float* gm, const float* x, const void* W
     int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_dgrad_kernel<64, NW, false>), 3 * 4 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, flags);
     if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_dgrad_kernel<64, NW, true>), 3 * 4 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, flags2);
     if (rc != MDVIT_OK) return rc;
-    if (a.drop) hipLaunchKernelGGL((mlp_rc_dgrad_kernel<64, NW, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+    if (g_rc_planes == 1) {
+        constexpr int CAP = 3 * 4 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4;
+        rc = a.drop ? rc_launch<&mlp_rc_dgrad_kernel<64, NW, true, true>>(CAP, dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a)
+                    : rc_launch<&mlp_rc_dgrad_kernel<64, NW, false, true>>(CAP, dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
+        if (rc != MDVIT_OK) return rc;
+    } else if (a.drop) hipLaunchKernelGGL((mlp_rc_dgrad_kernel<64, NW, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((mlp_rc_dgrad_kernel<64, NW, false>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
@@ -1681,7 +1751,10 @@ static int rc16_fwd_impl(int hbf, const float* x, const void* W1p, const float* 
         const int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV>),                  \
                                   3 * 2 * (32 * CV * 2) + 3 * 2 * (CV * 64) + 4096 * 4, fl);                                         \
         if (rc != MDVIT_OK) return rc;                                                                                               \
-        hipLaunchKernelGGL((mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV>), grid, block, smem, s, a);                             \
+        if (g_rc_planes == 1) {                                                                                                      \
+            const int rc1 = rc_launch<&mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV, false, true>>(3 * 2 * (32 * CV * 2) + 3 * 2 * (CV * 64) + 4096 * 4, grid, block, smem, s, a); \
+            if (rc1 != MDVIT_OK) return rc1;                                                                                         \
+        } else hipLaunchKernelGGL((mlp_rc16_fwd_kernel<CV, NW, OCCV, DROPV, STOREV>), grid, block, smem, s, a);                     \
     } while (0)
     if (C == 128 && g_rc_fwd128_variant == 32 && !a.hbf) {
         // 32-token waves on 32x32x16 tiles: the forward's registers allow it (x fragments 64 + y accumulator 64), and every weight fragment read
@@ -1750,7 +1823,12 @@ static int rc_fwd_ln_impl(int hbf, const float* x2, const float* gamma, const fl
         int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, false, 3, false, true>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f0);
         if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_fwd3_kernel<64, NW, true, 3, false, true>), 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4, f1);
         if (rc != MDVIT_OK) return rc;
-        if (a.drop) hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, true, 3, false, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, s, a);
+        if (g_rc_planes == 1) {
+            constexpr int CAP = 3 * 2 * (32 * 128) + 3 * 2 * (64 * 64) + 4096 * 4;
+            rc = a.drop ? rc_launch<&mlp_rc_fwd3_kernel<64, NW, true, 3, false, true, true>>(CAP, dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, s, a)
+                        : rc_launch<&mlp_rc_fwd3_kernel<64, NW, false, 3, false, true, true>>(CAP, dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, s, a);
+            if (rc != MDVIT_OK) return rc;
+        } else if (a.drop) hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, true, 3, false, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, s, a);
         else hipLaunchKernelGGL((mlp_rc_fwd3_kernel<64, NW, false, 3, false, true>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), smem, s, a);
     } else {
         constexpr int NW = 8;
@@ -1762,6 +1840,10 @@ static int rc_fwd_ln_impl(int hbf, const float* x2, const float* gamma, const fl
         const int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc16_fwd_kernel<128, NW, 2, DROPV, STOREV, true>),              \
                                   3 * 2 * (32 * 128 * 2) + 3 * 2 * (128 * 64) + 4096 * 4, fl);                                       \
         if (rc != MDVIT_OK) return rc;                                                                                               \
+        if (g_rc_planes == 1) {                                                                                                      \
+            const int rc1 = rc_launch<&mlp_rc16_fwd_kernel<128, NW, 2, DROPV, STOREV, true, true>>(3 * 2 * (32 * 256) + 3 * 2 * (128 * 64) + 4096 * 4, grid, block, smem, s, a); \
+            if (rc1 != MDVIT_OK) return rc1;                                                                                         \
+        } else                                                                                                                       \
         hipLaunchKernelGGL((mlp_rc16_fwd_kernel<128, NW, 2, DROPV, STOREV, true>), grid, block, smem, s, a);                         \
     } while (0)
         if (a.drop) { if (h) RC16_FWD_LN_LAUNCH(true, true); else RC16_FWD_LN_LAUNCH(true, false); }
@@ -1811,6 +1893,10 @@ static int rc16_dgrad_impl(int hbf, const float* gm, const float* x, const void*
         const int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc16_dgrad_kernel<CV, NW, OCCV, DROPV, STOREV>),                \
                                   3 * 4 * (32 * CV * 2) + 3 * 2 * (CV * 64) + 4096 * 4, fl);                                         \
         if (rc != MDVIT_OK) return rc;                                                                                               \
+        if (g_rc_planes == 1) {                                                                                                      \
+            const int rc1 = rc_launch<&mlp_rc16_dgrad_kernel<CV, NW, OCCV, DROPV, STOREV, true>>(3 * 4 * (32 * CV * 2) + 3 * 2 * (CV * 64) + 4096 * 4, grid, block, smem, s, a); \
+            if (rc1 != MDVIT_OK) return rc1;                                                                                         \
+        } else                                                                                                                       \
         hipLaunchKernelGGL((mlp_rc16_dgrad_kernel<CV, NW, OCCV, DROPV, STOREV>), grid, block, smem, s, a);                           \
     } while (0)
     if (C == 128) {
@@ -1896,7 +1982,10 @@ extern "C" int mdvit_mlp_rc_wgrad(const float* gm, const float* x, const void* W
     a.groups = rc_wgrad_groups(M);
     a.tiles_per_group = cdiv((M + 31) / 32, a.groups);
     const int roles = Hd / 256;
-    if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
+    if (g_rc_planes == 1) {
+        if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true, false, true>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, false, false, true>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
+    } else if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, false>), dim3(a.groups * roles), dim3(512), 0, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
     const int n0 = Hd * C, n2 = Hd;
@@ -1931,7 +2020,11 @@ extern "C" int mdvit_mlp_rc_bwd(const float* gm, const float* x, const void* W1p
     int rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_wgrad_kernel<64, true, true>), RC_BWD_LDS, f0);
     if (rc == MDVIT_OK) rc = rc_set_lds(reinterpret_cast<const void*>(&mlp_rc_wgrad_kernel<64, false, true>), RC_BWD_LDS, f1);
     if (rc != MDVIT_OK) return rc;
-    if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true, true>), dim3(a.groups * roles), dim3(512), RC_BWD_LDS, (hipStream_t)stream, a);
+    if (g_rc_planes == 1) {
+        rc = a.drop ? rc_launch<&mlp_rc_wgrad_kernel<64, true, true, true>>(RC_BWD_LDS, dim3(a.groups * roles), dim3(512), RC_BWD_LDS, (hipStream_t)stream, a)
+                    : rc_launch<&mlp_rc_wgrad_kernel<64, false, true, true>>(RC_BWD_LDS, dim3(a.groups * roles), dim3(512), RC_BWD_LDS, (hipStream_t)stream, a);
+        if (rc != MDVIT_OK) return rc;
+    } else if (a.drop) hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, true, true>), dim3(a.groups * roles), dim3(512), RC_BWD_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((mlp_rc_wgrad_kernel<64, false, true>), dim3(a.groups * roles), dim3(512), RC_BWD_LDS, (hipStream_t)stream, a);
     MDVIT_LAUNCH_CHECK();
     const int n0 = Hd * C, n2 = Hd;

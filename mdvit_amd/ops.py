@@ -459,6 +459,8 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
 #            never the parity mode.  (Layouts the plane kernels do not cover fall back to the bf16x3 kernels.)
 _PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 _gemm_precision = _PRECISIONS[os.environ.get("MDVIT_GEMM_PRECISION", "bf16x3")]
+if _gemm_precision == 2 and os.environ.get("MDVIT_MLP_RC_ONE_PLANE", "1") != "0":
+    _lib.load().mdvit_mlp_rc_planes(1)
 _use_plane_gemm = os.environ.get("MDVIT_PLANE_GEMM", "1") != "0"      # 0: the split-while-staging kernels of gemm.hip everywhere
 # bf16x3: plane kernels for K >= this.  Measured in the step (profiles/r02g_ab.txt): the plane NT kernel is a wash-to-slower against the
 # split-while-staging kernel at equal arithmetic (both sit at the same ~30 % of the MFMA roof: the limit is not the split VALU), so
@@ -473,9 +475,13 @@ if not _ph_gemm:
 _plane_rc = os.environ.get("MDVIT_PLANE_RC", "0") != "0"              # the recomputing fc2 data gradient of the C = 128 MLPs on the plane kernel
 
 
+_mlp_rc_one_plane = os.environ.get("MDVIT_MLP_RC_ONE_PLANE", "1") != "0"      # bf16 mode: the register-chained MLP kernels on one plane per operand too (0: bf16x3 there, round 4's mixed mode; A/B)
+
+
 def set_gemm_precision(name: str):
     global _gemm_precision
     _gemm_precision = _PRECISIONS[name]
+    _lib.load().mdvit_mlp_rc_planes(1 if (_gemm_precision == 2 and _mlp_rc_one_plane) else 2)
 
 
 def gemm_precision() -> str:

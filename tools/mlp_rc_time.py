@@ -15,6 +15,7 @@ ap.add_argument("--tokens128", type=int, default=131072)
 ap.add_argument("--drop", type=float, default=0.1)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--save", default=None)
+ap.add_argument("--planes", type=int, default=2, help="mdvit_mlp_rc_planes: 2 = bf16x3 (parity), 1 = one bf16 plane per operand (the bf16 speed mode)")
 ap.add_argument("--variant", type=int, default=0, help="mdvit_mlp_rc_config value (C = 64 forward kernel variant)")
 a = ap.parse_args()
 _p, dev = ops._p, "cuda"
@@ -72,9 +73,10 @@ def entries(M, C, Hd, drop, t):
     return fns, out, (W1p, W2p, W2tp, W1tp)
 
 
-print(f"library: {_lib.LIB_PATH}  variant {a.variant}", flush=True)
+print(f"library: {_lib.LIB_PATH}  variant {a.variant}  planes {a.planes}", flush=True)
 if a.variant:
     call("mdvit_mlp_rc_config", a.variant)
+call("mdvit_mlp_rc_planes", a.planes)
 if a.save:
     saved = {}
     for C, Hd, M in ((64, 512, 4173), (128, 1024, 1031)):
