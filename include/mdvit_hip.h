@@ -322,8 +322,8 @@ int mdvit_mlp_rc_config(int32_t fwd_variant);
  * three MFMAs per product; 1 = the bf16 speed mode of BASELINE configs[1] / [3] -- the hi plane alone, one MFMA per product and no lo split of the chained hidden operand
  * (~2^-9 per product instead of ~2^-17).  Process-wide, like the GEMM precision it follows (mdvit_amd.ops.set_gemm_precision sets both); operands and workspaces are the same. */
 int mdvit_mlp_rc_planes(int32_t planes);
-/* tuning hook: whether mdvit_block_bwd runs the C = 64 MLP backward as ONE kernel (mdvit_mlp_rc_bwd) -- 0 never, 1 always, 2 (default) when the call has no weight-gradient
- * stream (with one, the separate weight-gradient kernel overlaps the main stream's chain).  Set it before mdvit_block_bwd_ws_bytes: the workspace layout follows it. */
+/* tuning hook: whether mdvit_block_bwd runs the C = 64 MLP backward as ONE kernel (mdvit_mlp_rc_bwd) -- 0 never, 1 always (default), 2 only when the call has no
+ * weight-gradient stream (with one, the separate weight-gradient kernel overlaps the main stream's chain; measured, the one kernel still wins or ties).  Set it before mdvit_block_bwd_ws_bytes: the workspace layout follows it. */
 int mdvit_block_config(int32_t mlp_bwd_fused);
 /* tuning hook (tools/attn_time.py --apply-mode): how the attention backward's apply kernel (Ch = 8 / 16) orders its loads -- 0: each 32-token tile's rows in front of
  * the tile (default), 1: the MFMA operand rows one tile ahead at two waves per SIMD, 2: the same at one wave per SIMD.  Same arithmetic in every mode. */

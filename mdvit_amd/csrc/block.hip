@@ -61,8 +61,9 @@ void gemm_init(MdvitGemmDesc& g, const MdvitBlockDesc& d) {
     g.drop_seed = nullptr;
 }
 
-// the C = 64 MLP backward as ONE kernel (mdvit_mlp_rc_bwd): 0 never, 1 always, 2 (default) when the call has no weight-gradient stream (tuning hook: mdvit_block_config)
-static int g_blk_mlp_bwd = 2;
+// the C = 64 MLP backward as ONE kernel (mdvit_mlp_rc_bwd): 0 never, 1 always (default: >= neutral in the three-stream step in both arithmetic modes, see mdvit_amd/ops.py),
+// 2 when the call has no weight-gradient stream (tuning hook: mdvit_block_config)
+static int g_blk_mlp_bwd = 1;
 extern "C" int mdvit_block_config(int32_t mlp_bwd_fused) {
     if (mlp_bwd_fused < 0 || mlp_bwd_fused > 2) return mdvit_set_error(MDVIT_E_SHAPE, "block_config: mlp_bwd_fused in 0..2");
     g_blk_mlp_bwd = mlp_bwd_fused;
@@ -291,9 +292,9 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
                                          acc, seed, s));
             }
         }
-        // Full sweep without a weight-gradient stream: the WHOLE MLP backward from one evaluation of u, d and the activation (mdvit_mlp_rc_bwd, round 5) -- dx arrives as one
-        // partial per 256-wide hidden role and the LayerNorm backward below adds them while it reads them.  With a side stream the separate weight-gradient kernel overlaps the
-        // main stream's chain, and the fused kernel would lengthen that chain: there the two kernels stay (g_blk_mlp_bwd: 0 never, 1 always, 2 by that rule).
+        // Full sweep: the WHOLE MLP backward from one evaluation of u, d and the activation (mdvit_mlp_rc_bwd, round 5) -- dx arrives as one partial per 256-wide hidden role
+        // and the LayerNorm backward below adds them while it reads them.  (With a side stream the separate weight-gradient kernel would overlap the main stream's chain and
+        // the one kernel lengthens that chain -- but it removes more work than it serialises: g_blk_mlp_bwd above.)
         const bool fuse_bwd = want_w && (Hd == 256 || Hd == 512) && (g_blk_mlp_bwd == 1 || (g_blk_mlp_bwd == 2 && !have_side));
         if (fuse_bwd) {
             const int roles = Hd / 256;

@@ -290,9 +290,10 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s);
 #include <mutex>
 namespace {
 struct LedgerRow { char name[160]; long launches; double flop, bytes; };
-LedgerRow g_ledger[96];
+constexpr int LEDGER_ROWS = 512;
+LedgerRow g_ledger[LEDGER_ROWS];
 int g_ledger_n = 0;
-bool g_ledger_on = false;
+bool g_ledger_on = false, g_ledger_shapes = false;          // enable = 2: one row per (kernel, M, N, K, epilogue operands) instead of one per kernel (tools/gemm_shapes.py)
 std::mutex g_ledger_mu;
 }
 extern "C" int mdvit_gemm_kernel_name(const MdvitGemmDesc* d, char* out, int32_t cap);
@@ -300,6 +301,7 @@ extern "C" int mdvit_gemm_ledger(int32_t enable) {
     std::lock_guard<std::mutex> lk(g_ledger_mu);
     if (enable) g_ledger_n = 0;
     g_ledger_on = enable != 0;
+    g_ledger_shapes = enable == 2;
     return MDVIT_OK;
 }
 extern "C" int mdvit_gemm_ledger_read(int32_t index, char* name, int32_t cap, int64_t* launches, double* flop, double* bytes) {
@@ -315,10 +317,15 @@ static void ledger_note(const MdvitGemmDesc* d) {
     if (mdvit_gemm_kernel_name(d, nm, sizeof(nm)) != MDVIT_OK) return;
     if (char* plus = strchr(nm, '+')) *plus = 0;                            // the main kernel (a slab reduction is its own launch)
     std::lock_guard<std::mutex> lk(g_ledger_mu);
+    if (g_ledger_shapes) {
+        const size_t n = strlen(nm);
+        snprintf(nm + n, sizeof(nm) - n, " M=%d N=%d K=%d ta=%d tb=%d%s%s%s%s", d->M, d->N, d->K, (int)d->trans_a, (int)d->trans_b, d->C2 ? " +C2" : "", d->residual ? " +res" : "",
+                 d->gelu_u ? " +u" : "", d->rc_a ? " +rc" : "");
+    }
     int i = 0;
     while (i < g_ledger_n && strcmp(g_ledger[i].name, nm) != 0) ++i;
     if (i == g_ledger_n) {
-        if (g_ledger_n == 96) return;
+        if (g_ledger_n == LEDGER_ROWS) return;
         snprintf(g_ledger[i].name, sizeof(g_ledger[i].name), "%s", nm);
         g_ledger[i].launches = 0; g_ledger[i].flop = 0.0; g_ledger[i].bytes = 0.0;
         ++g_ledger_n;

@@ -1268,11 +1268,11 @@ _mlp_recompute_maxc = int(os.environ.get("MDVIT_MLP_RECOMPUTE_MAXC", "128"))
 _mlp_rc = os.environ.get("MDVIT_MLP_RC", "1") != "0"      # csrc/mlp_rc.hip: no [tokens, hidden] tensor in HBM in either pass (0: round 2's kernels, A/B)
 _mlp_rc16 = os.environ.get("MDVIT_MLP_RC16", "1") != "0"  # C = 128: the backward data path in one kernel on 16-token waves (0: the two data-gradient GEMMs, A/B)
 # C = 64, full sweep: data AND weight gradients from one evaluation of u, d and the activation (mdvit_mlp_rc_bwd) instead of mlp_rc_dgrad + mlp_rc_wgrad, which
-# recompute them twice.  "auto": when the weight gradients would NOT run on the side stream anyway (there the separate weight-gradient kernel overlaps the main
-# stream's chain and the fused kernel would lengthen it); "1": always; "0": never (A/B)
-_mlp_rc_bwd = os.environ.get("MDVIT_MLP_RC_BWD", "auto")
-if _mlp_rc_bwd in ("0", "1"):
-    _lib.load().mdvit_block_config(int(_mlp_rc_bwd))          # the C-level block entry follows the same switch (its default is the same rule)
+# recompute them twice.  "1" (default): always -- measured in the three-stream step against the two kernels (the weight-gradient kernel on the side stream): parity mode
+# 474 = 474 images/s at bs=4, 557 against 553 at bs=32; bf16 mode 520 against 517 at bs=4, 614 against 601 at bs=16.  "auto": only where the weight gradients would not
+# run on a side stream; "0": never (A/B)
+_mlp_rc_bwd = os.environ.get("MDVIT_MLP_RC_BWD", "1")
+_lib.load().mdvit_block_config({"0": 0, "1": 1}.get(_mlp_rc_bwd, 2))          # the C-level block entry follows the same switch
 
 
 def _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M) -> bool:

@@ -93,6 +93,8 @@ def test_block_entry_with_gradient_buckets_and_side_stream(monkeypatch):
     # (the C = 64 MLP backward runs as ONE kernel where no weight-gradient stream exists and as data-gradient + weight-gradient kernels where one does: dx then differs in
     #  the summation order over the hidden axis.  This test compares the two paths bit for bit, so both take the two-kernel form; the one-kernel form has its own test.)
     monkeypatch.setattr(ops, "_mlp_rc_bwd", "0")
+    from mdvit_amd._lib import call
+    call("mdvit_block_config", 0)
     ref = run(st, x, label, H, W, g, False, monkeypatch)
     sinks = {p: torch.full_like(p, 0.25) for p in st.parameters()}
     ops.enable_side_stream(True)
@@ -110,6 +112,7 @@ def test_block_entry_with_gradient_buckets_and_side_stream(monkeypatch):
     finally:
         ops.set_grad_sinks(None)
         ops.enable_side_stream(False)
+        call("mdvit_block_config", 1)
 
 
 def test_block_entry_first_adapter_of_the_aux_sweep(monkeypatch):

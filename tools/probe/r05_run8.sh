@@ -1,10 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu -k "mlp or block or layernorm" 2>&1 | tail -4
-python tools/block_roofline.py --batch 32 --stages 0 2>&1 | grep -v amdgpu | tail -12
-python - <<'PY'
-from mdvit_amd._lib import call
-call("mdvit_block_config", 0)
-import runpy, sys
-sys.argv = ["block_roofline.py", "--batch", "32", "--stages", "0"]
-runpy.run_path("tools/block_roofline.py", run_name="__main__")
-PY
+O=gpurun_out/r05e; mkdir -p $O
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+MDVIT_BENCH_GEMM_SHAPES=$O/gemm_shapes_bs4.txt python bench.py --steps 10 --warmup 3 --no-extra-legs --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bs4', d['value'], d['ms_per_step'], d['roofline']['frac'])"
+head -70 $O/gemm_shapes_bs4.txt
