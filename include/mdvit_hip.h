@@ -583,7 +583,8 @@ int mdvit_seg_metrics(const float* out, const float* aux, const float* label, ui
 int mdvit_image_normalize_u8(const uint8_t* img_nhwc, float* out_nchw, int32_t B, int32_t H, int32_t W, void* stream);
 
 /* ---- AdamW over all parameters in one launch (optim.AdamW, multi_train_MDViT.py:91-93) --------------------
- * table_dev: device array [n_tensors][5] of int64 {param, grad, exp_avg, exp_avg_sq (pointers), numel}.  step_dev[0] (float
+ * table_dev: device array [n_tensors][5] of int64 {param, grad, exp_avg, exp_avg_sq (pointers), numel}; every row gets blocks_per_tensor
+ * workgroups, so a caller with very unequal tensors hands in one row per CHUNK of a tensor (mdvit_amd/optim.py: 32768 elements).  step_dev[0] (float
  * step count) is incremented first, lr_dev[0] is the current learning rate -- both in device memory so that a captured
  * HIP graph replays the update unchanged while the host moves the schedule.  zero_grad != 0 clears each gradient after use.
  * Math: torch.optim.AdamW (decoupled decay, bias-corrected, amsgrad off). */

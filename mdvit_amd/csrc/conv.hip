@@ -410,6 +410,65 @@ __global__ __launch_bounds__(256) void stemconv_wgrad_kernel(const float* __rest
     for (int i = threadIdx.x; i < Cout * KK; i += blockDim.x) part[(long)blockIdx.x * Cout * KK + i] = s_acc[i];
 }
 
+// The same sums on the matrix pipe (round 5; Cout % 32 == 0): D[co][tap] += dy[px][co] * tap(px) as v_mfma_f32_32x32x2_f32 over PAIRS of output pixels -- exact fp32
+// products, fp32 accumulate.  The kernel above issues 27 image loads per output pixel from every one of its 32 channel lanes (two addresses per wave-instruction:
+// 396 us for the 16 x 512 x 512 images of a bs=4 step, 215 MB of HBM traffic at 0.5 TB/s).  Here lane (pixel l >> 5, co l & 31) loads ONE dy value (a wave reads two
+// 128-byte rows) and lane (pixel l >> 5, tap l & 31) gathers ONE image value per pixel pair; a wave walks its pixels with eight pairs in flight.  The four waves'
+// accumulators are added in wave order through LDS: one partial row [Cout][27] per workgroup, summed by mdvit_reduce_partials as before (deterministic).
+template <int CIN>
+__global__ __launch_bounds__(256) void stemconv_wgrad_mfma_kernel(const float* __restrict__ img, const float* __restrict__ dy,
+                                                                  float* __restrict__ part, int B, int H, int W, int Cout, int pix_per_block) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int KK = CIN * 9;
+    static_assert(KK <= 32, "one 32-wide tap block");
+    __shared__ float s_acc[4][32 * 33];
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long npix = (long)B * Ho * Wo;
+    const long p_beg = (long)blockIdx.x * pix_per_block, p_end = min(npix, p_beg + pix_per_block);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int tap = min(l31, KK - 1), ci = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+    const bool tap_ok = l31 < KK;
+    constexpr int UN = 8;                            // pixel pairs in flight per wave
+    for (int cb = 0; cb < Cout; cb += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (long p0 = p_beg + wave * 2 * UN; p0 < p_end; p0 += 4 * 2 * UN) {
+            float a[UN], x[UN];
+            // (image, row, column) of p0 once per pass, on the scalar unit (p0 is wave-uniform); the 16 pixels of the pass follow by carries
+            const long p0s = ((long)__builtin_amdgcn_readfirstlane((int)(p0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)p0);
+            const int wo0 = (int)(p0s % Wo), ho0 = (int)((p0s / Wo) % Ho), b0 = (int)(p0s / Wo / Ho);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long px = p0 + 2 * u + lhi;
+                const bool pok = px < p_end;
+                const long pc = pok ? px : p_end - 1;
+                int wo = wo0 + 2 * u + lhi - (int)(px - pc), ho = ho0, b = b0;
+                while (wo >= Wo) { wo -= Wo; ++ho; }
+                while (ho >= Ho) { ho -= Ho; ++b; }
+                const int hi = 2 * ho + kh - 1, wi = 2 * wo + kw - 1;
+                const bool ok = pok && tap_ok && hi >= 0 && hi < H && wi >= 0 && wi < W;
+                const float g = dy[pc * Cout + cb + l31];
+                const float v = img[(((long)b * CIN + ci) * H + min(max(hi, 0), H - 1)) * W + min(max(wi, 0), W - 1)];
+                a[u] = pok ? g : 0.f;
+                x[u] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], x[u], acc, 0, 0, 0);
+        }
+        // D[i = co][j = tap]: lane holds column j = l31, rows i = (r & 3) + 8 (r >> 2) + 4 lhi
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[wave][((r & 3) + 8 * (r >> 2) + 4 * lhi) * 33 + l31] = acc[r];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * KK; i += 256) {
+            const int co = i / KK, k = i % KK;
+            const float t = ((s_acc[0][co * 33 + k] + s_acc[1][co * 33 + k]) + s_acc[2][co * 33 + k]) + s_acc[3][co * 33 + k];
+            part[(long)blockIdx.x * Cout * KK + (cb + co) * KK + k] = t;
+        }
+    }
+}
+
 // ---- bilinear, align_corners=False (ATen upsample_bilinear2d index rule) ------------------------
 __device__ __forceinline__ void bilin_src(int o, int in_size, float scale, int& i0, int& i1, float& l1) {
     float src = scale * ((float)o + 0.5f) - 0.5f;
@@ -839,6 +898,14 @@ extern "C" int mdvit_stemconv_wgrad(const float* img, const float* dy, float* dw
     int ppb = (int)max(64L, (npix + 2047) / 2048);
     const int nblk = cdiv(npix, ppb);
     MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk, 27 * Cout, "stemconv_wgrad");
+    static const bool mfma = [] { const char* e = getenv("MDVIT_STEM_WGRAD_MFMA"); return !(e && e[0] == '0'); }();          // 0: the scalar kernel (A/B)
+    if (mfma && Cout % 32 == 0) {                    // half the partial rows: a workgroup's pixels are walked by four waves with eight pairs in flight each
+        ppb = (int)max(128L, (npix + 1023) / 1024);
+        const int nb2 = cdiv(npix, ppb);
+        hipLaunchKernelGGL((stemconv_wgrad_mfma_kernel<3>), dim3(nb2), dim3(256), 0, s, img, dy, (float*)ws, B, H, W, Cout, ppb);
+        MDVIT_LAUNCH_CHECK();
+        return mdvit_reduce_partials((const float*)ws, nb2, 27L * Cout, 27 * Cout, dw, 0, nullptr, accumulate, s);
+    }
     hipLaunchKernelGGL((stemconv_wgrad_kernel<3>), dim3(nblk), dim3(256), sizeof(float) * 27 * Cout, s, img, dy, (float*)ws, B, H, W, Cout, ppb);
     MDVIT_LAUNCH_CHECK();
     return mdvit_reduce_partials((const float*)ws, nblk, 27L * Cout, 27 * Cout, dw, 0, nullptr, accumulate, s);
