@@ -364,6 +364,56 @@ __global__ __launch_bounds__(256) void stemconv_fwd_kernel(const float* __restri
     }
 }
 
+// Cout == 32 (the stem of every model here) on the matrix pipe (round 5): y[px][co] = sum_k tap_k(px) w[co][k] as v_mfma_f32_32x32x2_f32 over k pairs -- exact fp32
+// products, fp32 accumulate in ascending k.  A wave owns 32 output pixels per pass: lane (pixel l & 31, k parity l >> 5) gathers ONE image value per k pair (14 loads for
+// the 27 taps; the kernel above issues 27 loads from each of a pixel's eight channel-quad threads: 150 us for the 16 images of a bs=4 step, alone on the GPU at the top of
+// the forward), the weights sit in 14 registers per lane, and the accumulator's rows leave as 128-byte channel rows.  (A pixel per thread with the 32 channels in registers
+// and the weights as LDS broadcasts was built first: 218 us -- 216 ds_read_b128 per pixel.)
+template <int CIN>
+__global__ __launch_bounds__(256) void stemconv_fwd32_kernel(const float* __restrict__ img, const float* __restrict__ w, float* __restrict__ y, int B, int H, int W) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int Cout = 32, KK = CIN * 9, KP = (KK + 1) / 2;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)B * Ho * Wo;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+    float wk[KP];                                    // B operand: lane (co = l31, k = 2 s + lhi)
+    int toff[KP];                                    // the tap's (ci, kh, kw) packed: ci << 4 | kh << 2 | kw; -1 past the last tap
+#pragma unroll
+    for (int s = 0; s < KP; ++s) {
+        const int k = 2 * s + lhi;
+        wk[s] = k < KK ? w[l31 * KK + k] : 0.f;
+        toff[s] = k < KK ? ((k / 9) << 4 | ((k % 9) / 3) << 2 | (k % 3)) : -1;
+    }
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6), wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (long p0 = wid * 32; p0 < total; p0 += nwaves * 32) {
+        const long px = min(p0 + l31, total - 1);
+        long r = px;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float xv[KP];
+#pragma unroll
+        for (int s = 0; s < KP; ++s) {
+            const int t = toff[s], ci = max(t, 0) >> 4, kh = (t >> 2) & 3, kw = t & 3;
+            const int hi = 2 * ho + kh - 1, wi = 2 * wo + kw - 1;
+            const bool ok = t >= 0 && hi >= 0 && hi < H && wi >= 0 && wi < W;
+            const float v = img[(((long)b * CIN + ci) * H + min(max(hi, 0), H - 1)) * W + min(max(wi, 0), W - 1)];
+            xv[s] = ok ? v : 0.f;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KP; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s], wk[s], acc, 0, 0, 0);
+        // D[i = pixel][j = co]: lane holds column co = l31, rows i = (q & 3) + 8 (q >> 2) + 4 lhi
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const long po = p0 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
+            if (po < total) y[po * Cout + l31] = acc[q];
+        }
+    }
+}
+
 // dw[co,ci,kh,kw] = sum_{b,ho,wo} dy[b,ho,wo,co] * img[b,ci,2ho+kh-1,2wo+kw-1]
 // thread = (co, pixel lane); 27 register accumulators; LDS atomics -> global atomics.
 template <int CIN>
@@ -882,8 +932,12 @@ extern "C" int mdvit_stemconv_fwd(const float* img, const float* w, float* y, in
     MDVIT_CHECK_ARG(Cin == 3, MDVIT_E_SHAPE, "stemconv_fwd: only in_chans == 3 is built (got %d)", Cin);
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 4 == 0 && Cout <= 256, MDVIT_E_SHAPE, "stemconv_fwd: bad shape");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    hipLaunchKernelGGL((stemconv_fwd_kernel<3>), dim3(ew_grid((long)B * Ho * Wo * Cout / 4)), dim3(256), sizeof(float) * 27 * Cout, (hipStream_t)stream,
-                       img, w, y, B, H, W, Cout);
+    static const bool px32 = [] { const char* e = getenv("MDVIT_STEM_FWD32"); return !(e && e[0] == '0'); }();          // 0: the channel-quad kernel (A/B)
+    if (px32 && Cout == 32)
+        hipLaunchKernelGGL((stemconv_fwd32_kernel<3>), dim3((int)min(((long)B * Ho * Wo + 127) / 128, 8192L)), dim3(256), 0, (hipStream_t)stream, img, w, y, B, H, W);
+    else
+        hipLaunchKernelGGL((stemconv_fwd_kernel<3>), dim3(ew_grid((long)B * Ho * Wo * Cout / 4)), dim3(256), sizeof(float) * 27 * Cout, (hipStream_t)stream,
+                           img, w, y, B, H, W, Cout);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

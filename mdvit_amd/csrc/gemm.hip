@@ -461,20 +461,45 @@ __global__ __launch_bounds__(256) void conv_weight_relayout_kernel(const float* 
     }
 }
 
-// the same for many weights in ONE launch (modes 0 / 1 only): items [n][5] int64 in device memory = {w, out, Cout, Cin, mode}; grid.y = item
+// the same for many weights in ONE launch (modes 0 / 1 only): items [n][5] int64 in device memory = {w, out, Cout, Cin, mode}; grid.y = item.  Both modes move
+// whole 128-byte lines on both sides through an LDS tile (round 5; the element-per-thread walk above read with a 36-byte stride and ran the step's ~40 layouts --
+// 80 MB, alone on the GPU at the top of every forward -- at 0.5 TB/s: 158 us):
+//   mode 0: tile = (co, 256 input channels): 2304 contiguous floats in, nine runs of 256 contiguous floats out
+//   mode 1: tile = (32 output channels, 8 input channels): 32 runs of 72 contiguous floats in, 72 runs of 32 contiguous floats out
 __global__ __launch_bounds__(256) void conv_weight_relayout_many_kernel(const long long* __restrict__ items) {
+    __shared__ float s_t[32 * 73];
     const long long* it = items + 5 * (long)blockIdx.y;
     const float* w = reinterpret_cast<const float*>(it[0]);
     float* out = reinterpret_cast<float*>(it[1]);
     const int Cout = (int)it[2], Cin = (int)it[3], mode = (int)it[4];
-    const long total = (long)Cout * Cin * 9;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        if (mode == 0) {          // out[co][t][ci]
-            const int ci = (int)(e % Cin); const int t = (int)((e / Cin) % 9); const int co = (int)(e / (9L * Cin));
-            out[e] = w[((long)co * Cin + ci) * 9 + t];
-        } else {                  // out[ci][t][co] = w[co][ci][8 - t]
-            const int co = (int)(e % Cout); const int t = (int)((e / Cout) % 9); const int ci = (int)(e / (9L * Cout));
-            out[e] = w[((long)co * Cin + ci) * 9 + (8 - t)];
+    const int tid = threadIdx.x;
+    if (mode == 0) {              // out[co][t][ci] = w[co][ci][t]
+        const int nch = (Cin + 255) / 256, ntiles = Cout * nch;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int co = tile / nch, ci0 = (tile % nch) * 256, nci = min(256, Cin - ci0);
+            const float* src = w + ((long)co * Cin + ci0) * 9;
+            for (int i = tid; i < nci * 9; i += 256) s_t[i] = src[i];
+            __syncthreads();
+            for (int i = tid; i < nci * 9; i += 256) {
+                const int t = i / nci, c = i - t * nci;
+                out[((long)co * 9 + t) * Cin + ci0 + c] = s_t[c * 9 + t];
+            }
+            __syncthreads();
+        }
+    } else {                      // out[ci][t'][co] = w[co][ci][8 - t']
+        const int ncb = (Cout + 31) / 32, nib = (Cin + 7) / 8, ntiles = ncb * nib;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int co0 = (tile / nib) * 32, ci0 = (tile % nib) * 8, ncl = min(32, Cout - co0), run = min(8, Cin - ci0) * 9;
+            for (int i = tid; i < ncl * 72; i += 256) {
+                const int c = i / 72, r = i - c * 72;
+                if (r < run) s_t[c * 73 + r] = w[((long)(co0 + c) * Cin + ci0) * 9 + r];
+            }
+            __syncthreads();
+            for (int i = tid; i < 72 * 32; i += 256) {
+                const int c = i & 31, r = i >> 5, k = r / 9, tp = r - k * 9;
+                if (c < ncl && k * 9 < run) out[((long)(ci0 + k) * 9 + tp) * Cout + co0 + c] = s_t[c * 73 + k * 9 + 8 - tp];
+            }
+            __syncthreads();
         }
     }
 }

@@ -1674,8 +1674,8 @@ def refresh_conv_weights():
         if torch.cuda.is_current_stream_capturing():
             return                            # host-built table: the warm-up steps before a capture build it
         dev = entries[0][1].device
-        blocks = max((w.shape[0] * w.shape[1] * 9 + 255) // 256 for _, w, _ in entries)
-        _conv_w_table = (sig, torch.tensor([list(r) for r in sig], dtype=torch.int64, device=dev), int(min(blocks, 64)))
+        blocks = max((w.shape[0] * w.shape[1] * 9 + 2303) // 2304 for _, w, _ in entries)          # tiles of the largest weight (2304 floats each in both modes)
+        _conv_w_table = (sig, torch.tensor([list(r) for r in sig], dtype=torch.int64, device=dev), int(min(blocks, 256)))
     call("mdvit_conv_weight_relayout_many", _p(_conv_w_table[1]), len(entries), _conv_w_table[2], _stream())
     for key, w, hit in entries:
         _conv_w_cache[key] = (hit[0], (w._version, _weights_epoch, w.data_ptr()), hit[2])

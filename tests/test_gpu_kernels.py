@@ -790,6 +790,31 @@ def test_stem_conv(B, H, W):
     check(wh.grad, wr.grad, name="dw")
 
 
+def test_conv_weight_layouts_of_many_weights_in_one_launch():
+    """mdvit_conv_weight_relayout_many (the per-step refresh of every implicit-convolution weight layout, LDS-tiled since round 5) against the index definition
+    (include/mdvit_hip.h: mode 0 out[co][tap][ci], mode 1 out[ci][8 - tap][co]) -- channel counts off the tile sizes included"""
+    from mdvit_amd import ops
+    from mdvit_amd._lib import call
+    shapes = [(32, 3), (64, 64), (40, 20), (512, 320), (33, 257), (7, 5)]
+    ws = [rnd(co, ci, 3, 3, seed=300 + i).to(dev()) for i, (co, ci) in enumerate(shapes)]
+    rows, outs = [], []
+    for w in ws:
+        for mode in (0, 1):
+            o = torch.full((w.numel(),), float("nan"), device=dev())
+            outs.append((w, mode, o))
+            rows.append([w.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1], mode])
+    table = torch.tensor(rows, dtype=torch.int64, device=dev())
+    for blocks in (1, 7, 256):
+        for _, _, o in outs:
+            o.fill_(float("nan"))
+        call("mdvit_conv_weight_relayout_many", ops._p(table), len(rows), blocks, ops._stream())
+        torch.cuda.synchronize()
+        for w, mode, o in outs:
+            co, ci = w.shape[:2]
+            ref = w.reshape(co, ci, 9).permute(0, 2, 1) if mode == 0 else w.reshape(co, ci, 9).flip(2).permute(1, 2, 0)
+            assert torch.equal(o, ref.contiguous().reshape(-1)), (tuple(w.shape), mode, blocks)
+
+
 @pytest.mark.parametrize("act", ["hswish", "relu"])
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (4, 3, 5, 320), (1, 8, 8, 1024)])
 def test_bn_act_train(act, B, H, W, C):
