@@ -212,6 +212,12 @@ int mdvit_gemm_ph_prefers(int32_t M, int32_t N, int32_t K, int32_t planes);
  * mdvit.py:353,357-360, an accumulating C): one workgroup per CU hides no load latency, such launches are taken only when the tiles fill whole rounds */
 int mdvit_gemm_ph_prefers_epi(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t epi_reads);
 int mdvit_gemm_ph_config(int32_t mode);
+/* The same phase-split structure on a 128-row tile (csrc/gemm_pm.hip, round 5) for the MID-SIZE products of the C = 320 / 512 blocks (mdvit.py:267,307, mpvit.py:71-78
+ * at 16-128 images: proj, fc2, the qkv / fc1 data gradients): 128 x 160 output tiles for N % 160 == 0 (16384 x 320 is exactly one workgroup per CU), 128 x 128 for
+ * N % 128 == 0; fp32 A split while staged, two weight planes, one K range; results bit-identical to the other tiles.  mdvit_gemm_pm_prefers: the tile width
+ * mdvit_gemm_planes would route [M, K] x [N, K]^T to (6: 128 x 160, 7: 128 x 128) or 0; mdvit_gemm_pm_config: -1 never, 0 by the rule (default), 1 whenever legal. */
+int mdvit_gemm_pm_prefers(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32);
+int mdvit_gemm_pm_config(int32_t mode);
 /* fp32 [rows, cols] (ld_in) -> planes [planes][rows][ld_out]; cols % 8 == 0 */
 int mdvit_split_planes(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t plane_stride, int64_t rows, int32_t cols, int32_t planes, void* stream);
 /* one tensor, any shape, optionally transposed (out = planes of in^T, [cols][rows]): non-leaf / sliced weights */

@@ -100,6 +100,8 @@ _SIGS = {
     "mdvit_gemm_planes_plan": [C.POINTER(PlaneGemmDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     "mdvit_gemm_planes_force_plan": [i32, i32],
     "mdvit_gemm_ph_config": [i32],
+    "mdvit_gemm_pm_config": [i32],
+    "mdvit_gemm_pm_prefers": [i32, i32, i32, i32, i32],
     "mdvit_gemm_f32_grouped": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
     "mdvit_gemm_f32_grouped_bias": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
     "mdvit_transpose_batch": [i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp],

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmdvit_hip.so")
-SOURCES = ["abi.hip", "gemm.hip", "gemm_tn.hip", "gemm_bp.hip", "gemm_ph.hip", "mlp.hip", "mlp_rc.hip", "block.hip", "norm.hip", "conv.hip", "attn.hip", "loss.hip", "optim.hip", "transfuse.hip", "sdpa.hip"]
+SOURCES = ["abi.hip", "gemm.hip", "gemm_tn.hip", "gemm_bp.hip", "gemm_ph.hip", "gemm_pm.hip", "mlp.hip", "mlp_rc.hip", "block.hip", "norm.hip", "conv.hip", "attn.hip", "loss.hip", "optim.hip", "transfuse.hip", "sdpa.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # per-file extras.  -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 adds / muls of an activation into v_pk_* instructions,
 # which next to MFMAs cost ~20 cycles more than the two plain VALU they replace (MI355X_MICROARCH.md, per-instruction constants)
@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # ([65536 x 1024]^T [65536 x 128] 96.5 -> 87.8 us), bs=32 515-521 -> 527-529 images/s, bs=4 +0.3 %.  attn.hip / sdpa.hip / mlp.hip measured too: no change / -0.4 %
 # on TransFuse, so they keep the default.  `-mllvm -amdgpu-sched-strategy=max-ilp` on gemm.hip / gemm_tn.hip / mlp_rc.hip: no change either (step and block_bs32
 # within noise), not used.
-EXTRA_FLAGS = {"mlp_rc.hip": ["-fno-slp-vectorize"], "gemm.hip": ["-fno-slp-vectorize"], "gemm_tn.hip": ["-fno-slp-vectorize"], "gemm_bp.hip": ["-fno-slp-vectorize"], "gemm_ph.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"mlp_rc.hip": ["-fno-slp-vectorize"], "gemm.hip": ["-fno-slp-vectorize"], "gemm_tn.hip": ["-fno-slp-vectorize"], "gemm_bp.hip": ["-fno-slp-vectorize"], "gemm_ph.hip": ["-fno-slp-vectorize"], "gemm_pm.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -80,8 +80,9 @@ extern "C" int mdvit_block_config(int32_t mlp_bwd_fused) {
 
 // An NT product of the block on the 256-wide plane kernel (gemm_ph.hip through mdvit_gemm_planes: fp32 activations split while staged, the weight as its
 // per-step bf16 planes [2][N][K]) -- when the weight's planes were handed in and mdvit_gemm_ph_prefers takes the shape.  Same arithmetic, same results.
+// ... or on the 128-row phase-split tile of the mid-size products (gemm_pm.hip, round 5; mdvit_gemm_planes picks between the two by the same rules)
 bool ph_takes(const MdvitBlockDesc& d, const void* planes, int M, int N, int K, int epi_reads) {
-    return d.precision == 1 && planes != nullptr && mdvit_gemm_ph_prefers_epi(M, N, K, 2, epi_reads) != 0;
+    return d.precision == 1 && planes != nullptr && (mdvit_gemm_ph_prefers_epi(M, N, K, 2, epi_reads) != 0 || mdvit_gemm_pm_prefers(M, N, K, 2, 1) != 0);
 }
 int epi_reads_of(const MdvitGemmDesc& g) { return g.gelu_u != nullptr || g.residual != nullptr || g.accumulate != 0; }
 int gemm_planes_nt(Arena& A, const MdvitGemmDesc& g, const void* planes, hipStream_t s) {

@@ -28,3 +28,8 @@ enum { BEPI_PLAIN = 0, BEPI_GELU = 1, BEPI_DGELU = 2, BEPI_FULL = 3, BEPI_DGELU_
 // epi = BEPI_*; a.tiles_m / tiles_n / splits / k_per_split set by the caller for the cfg's tile.  Returns 0, or 1 when the combination is not built.
 int mdvit_gemm_ph_launch(const BpArgs& a, int cfg, int planes, int epi, hipStream_t s);
 bool mdvit_gemm_ph_ok(const BpArgs& a, int cfg, int planes, int epi, int kps);
+
+// gemm_pm.hip: the phase-split 8-wave kernels on a 128-row tile (cfg 6: 128 x 160, cfg 7: 128 x 128) for the mid-size products; fp32 A, two weight planes, one K range.
+int mdvit_gemm_pm_launch(const BpArgs& a, int cfg, int epi, hipStream_t s);
+bool mdvit_gemm_pm_ok(const BpArgs& a, int cfg, int planes, int epi);
+extern "C" int mdvit_gemm_pm_prefers(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32);

@@ -343,11 +343,16 @@ BpPlan plan_ph(const MdvitPlaneGemmDesc* d, int cfg) {
 
 
 BpPlan plan_bp(const MdvitPlaneGemmDesc* d) {
+    if (g_bp_force_cfg >= 6) return BpPlan{g_bp_force_cfg, cdiv(d->M, 128), cdiv(d->N, g_bp_force_cfg == 6 ? 160 : 128), 1, d->K};
     if (g_bp_force_cfg >= 3) return plan_ph(d, g_bp_force_cfg);
     const int epi_reads = d->gelu_u != nullptr || d->residual != nullptr || d->accumulate != 0;
     if (g_bp_force_cfg < 0 && !d->rc_a && mdvit_gemm_ph_prefers_epi(d->M, d->N, d->K, d->planes, epi_reads)) {
         BpPlan pl = plan_ph(d, 3);
         if (pl.splits == 1) return pl;
+    }
+    if (g_bp_force_cfg < 0 && !d->rc_a && !d->Cp) {            // the 128-row phase-split tile (gemm_pm.hip): mid-size products
+        const int cfg = mdvit_gemm_pm_prefers(d->M, d->N, d->K, d->planes, d->a_f32);
+        if (cfg) return BpPlan{cfg, cdiv(d->M, 128), cdiv(d->N, cfg == 6 ? 160 : 128), 1, d->K};
     }
     static const int BMs[3] = {128, 128, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 3, 5};
     static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
@@ -416,7 +421,7 @@ extern "C" size_t mdvit_gemm_planes_ws_bytes(const MdvitPlaneGemmDesc* d) {
 }
 
 extern "C" int mdvit_gemm_planes_force_plan(int32_t cfg, int32_t splits) {
-    g_bp_force_cfg = (cfg >= 0 && cfg <= 5) ? cfg : -1;
+    g_bp_force_cfg = (cfg >= 0 && cfg <= 7) ? cfg : -1;
     g_bp_force_splits = splits > 0 ? splits : 0;
     return MDVIT_OK;
 }
@@ -424,8 +429,8 @@ extern "C" int mdvit_gemm_planes_force_plan(int32_t cfg, int32_t splits) {
 extern "C" int mdvit_gemm_planes_plan(const MdvitPlaneGemmDesc* d, int32_t* tile_m, int32_t* tile_n, int32_t* splits) {
     MDVIT_CHECK_ARG(d != nullptr && d->M > 0 && d->N > 0 && d->K > 0, MDVIT_E_SHAPE, "gemm_planes_plan: bad descriptor");
     const BpPlan pl = plan_bp(d);
-    if (tile_m) *tile_m = pl.cfg >= 3 ? 256 : (pl.cfg == 2 ? 64 : 128);
-    if (tile_n) *tile_n = pl.cfg >= 3 ? 256 : (pl.cfg == 0 ? 128 : 64);
+    if (tile_m) *tile_m = pl.cfg >= 6 ? 128 : (pl.cfg >= 3 ? 256 : (pl.cfg == 2 ? 64 : 128));
+    if (tile_n) *tile_n = pl.cfg == 6 ? 160 : (pl.cfg == 7 ? 128 : (pl.cfg >= 3 ? 256 : (pl.cfg == 0 ? 128 : 64)));
     if (splits) *splits = pl.splits;
     return MDVIT_OK;
 }
@@ -487,7 +492,12 @@ extern "C" int mdvit_gemm_planes(const MdvitPlaneGemmDesc* d, void* stream) {
         a.slab = (float*)d->ws;
     }
     int rc;
-    if (pl.cfg >= 3) {
+    if (pl.cfg >= 6) {
+        MDVIT_CHECK_ARG(mdvit_gemm_pm_ok(a, pl.cfg, d->planes, epi), MDVIT_E_SHAPE,
+                        "gemm_planes: the 128-row phase-split kernel needs fp32 A, two weight planes, one K range and K %% 32 == 0 (K=%d planes=%d a_f32=%d)", d->K, d->planes, d->a_f32);
+        rc = mdvit_gemm_pm_launch(a, pl.cfg, epi, s);
+    }
+    else if (pl.cfg >= 3) {
         MDVIT_CHECK_ARG(mdvit_gemm_ph_ok(a, pl.cfg, d->planes, epi, pl.kps), MDVIT_E_SHAPE,
                         "gemm_planes: the 256-wide phase-split kernel needs plane operands, K (per split) a multiple of %d and >= %d (K=%d, per split %d)",
                         d->planes == 2 ? 32 : 64, d->planes == 2 ? 64 : 128, d->K, pl.kps);

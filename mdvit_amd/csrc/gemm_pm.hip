@@ -1,0 +1,341 @@
+// Phase-split plane GEMM on a 128-row tile: C[M,N] = A[M,K] B[N,K]^T for the MID-SIZE products of the C = 320 / 512 blocks (proj, fc2, the qkv / fc1 data gradients
+// and their forward layers at 16-128 images: mdvit.py:267,307, mpvit.py:71-78) -- the shapes where 256 x 256 tiles (gemm_ph.hip) leave half the chip empty and the
+// 64 / 128 lock-step tiles (gemm.hip, gemm_bp.hip) reach ~22 % of the bf16x3 matrix roof (tools/gemm_shapes_time.py, profiles/r05_gemm_shapes_alone.txt).
+//
+//   * Output tile 128 x BN, BN = 32 (NX + NY): 160 (NX = 3, NY = 2) for N = 320 / 960 / 1280 -- 16384 x 320 is exactly 256 workgroups, one per CU -- or 128 (2, 2).
+//     EIGHT waves: wave w and wave w + 4 share SIMD w and the tile's row block w (32 rows); waves 0-3 ("X") own the first NX 32 x 32 column blocks of it, waves 4-7
+//     ("Y") the other NY.  The two waves of a SIMD do unequal work, the four SIMDs equal work.
+//   * Same operands and arithmetic as gemm_bp.hip / gemm_ph.hip (fp32 A split while it is staged, the weight as its per-step bf16 planes; per accumulator and
+//     k step of 16: lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_bf16 in ascending k): results are BIT-IDENTICAL to their tiles, so the planner may pick by shape.
+//   * A K tile is 32 k.  Ring of FOUR LDS stages, each A hi | A lo (128 rows x 64 B) | B hi | B lo (BN rows x 64 B).  B travels L2 -> LDS by global_load_lds
+//     (1 KiB = 16 rows per wave-instruction), A HBM -> registers (three sets in flight) -> planes -> ds_write_b128.
+//   * Y runs ONE BARRIER behind X: a K tile is a load phase L (fragment reads, counted vmcnt) and a multiply phase M (MFMAs, with this tile's loads issued and an older
+//     tile's A registers converted behind the first MFMAs); while X multiplies, Y reads, and the other way round.  Phase schedule (interval k between barriers k, k+1):
+//         X:  L(0) M(0) L(1) M(1) ...           M(u) issues B(u+3) (LDS-DMA) and A(u+4) (registers) and writes A(u+2) to LDS
+//         Y:       L(0) M(0) L(1) ...           L(u) ends with vmcnt(what is younger than B(u+1))
+//     RAW: data is waited for / written at least one barrier before the first phase that reads it (A(u+2): written in intervals 2u+1 / 2u+2, read from 2u+4;
+//     B(u+3): waited for in L(u+2), intervals 2u+4 / 2u+5, read from 2u+6).  WAR: stage (u+3) & 3 held tile u-1, last read in interval 2u-1; stage (u+2) & 3 held
+//     tile u-2.  Tiles past the end are loaded from the last tile's address into stages nobody reads again, so every phase issues the same number of vector-memory
+//     operations and the vmcnt immediates are constants.
+#include "common.h"
+#include "gemm_bp.h"
+#include <type_traits>
+
+typedef float pm_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 pm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float pm_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned pm_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int PM_THREADS = 512;
+constexpr int PM_AP = 128 * 64;          // bytes of one A plane of a stage
+
+#define PM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define PM_BAR()                                  \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("s_barrier" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
+__device__ __forceinline__ int pm_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int NX, int NY, int EPI>
+__global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(224))) void gemm_pm_kernel(BpArgs p) {
+    constexpr int BN = 32 * (NX + NY);
+    constexpr int BP = BN * 64;                              // bytes of one B plane of a stage
+    constexpr int STAGE = 2 * PM_AP + 2 * BP;
+    constexpr int NPIECE = 2 * BN / 16, PPW = (NPIECE + 7) / 8;      // 1 KiB LDS-DMA pieces of a stage's B planes; per wave
+    constexpr int NV = PPW + 2;                              // vector-memory operations a wave issues per multiply phase
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5, wr = wave & 3;
+    uint32_t s0 = 0, s1 = 0;
+    if (p.seed) { s0 = p.seed[0]; s1 = p.seed[1]; }
+    const uint32_t ek0 = p.e_k0 ^ s0, ek1 = p.e_k1 + s1;
+    const int tile = pm_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * 128, n0 = tn * BN;
+    const int nt = p.K / 32;
+
+    // ---- B: wave w brings pieces w, w + 8 (, w + 16): piece pc = plane pc / (BN/16), rows 16 (pc % (BN/16)) ..+15; lane i lands at row (i >> 2), physical 16-byte chunk
+    // i & 3 and fetches logical chunk (i & 3) ^ ((row >> 2) & 3) (the swizzle lives on the SOURCE address: the LDS side of global_load_lds is lane-linear).  A piece index
+    // past the last one repeats the wave's previous piece (same bytes to the same place).
+    static_assert(PPW <= 3, "three pieces per wave at most");
+    const uint16_t* gb[3]; int ob[3];          // (fixed extents, and a local copy at the builtin below: with an element of a template-sized array as the builtin's
+    //                                             argument hipcc's HOST pass silently emits no stub for the kernel -- the library then fails to load)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        int pc = wave + 8 * i;
+        if (pc >= NPIECE) pc -= 8;
+        const int pl = pc / (BN / 16), rg = pc % (BN / 16);
+        const int row = rg * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
+        gb[i] = p.B + (long)pl * p.b_plane + (long)min(n0 + row, p.N - 1) * p.ldb + chunk * 8;
+        ob[i] = 2 * PM_AP + pl * BP + rg * 1024;
+    }
+    auto issue_b = [&](int t) __attribute__((always_inline)) {
+        const int ts = min(t, nt - 1);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const uint16_t* g = gb[i] + (long)ts * 32;
+            char* dst = smem + (t & 3) * STAGE + ob[i];
+            __builtin_amdgcn_global_load_lds(g, dst, 16, 0, 0);
+        }
+    };
+    // ---- A (fp32): thread (row = tid / 4, c = tid % 4) owns k = 8 c .. 8 c + 7 of its row of a tile: two 16-byte loads into one of three register sets
+    const int qrow = tid >> 2, qc = tid & 3;
+    const float* ga = reinterpret_cast<const float*>(p.A) + (long)min(m0 + qrow, p.M - 1) * p.lda + qc * 8;
+    // The three in-flight A sets live in FIXED registers v[232:239], v[240:247], v[248:255], above the range the compiler may allocate (amdgpu_num_vgpr(224) on the
+    // kernel): as compiler-visible asm outputs they were COPIED while still in flight -- hipcc placed v_mov_b64 of the prologue's A(2) / A(3) registers in front of the loop
+    // (register assignment at a control-flow merge), and a copy of a register whose load has not landed copies garbage (the first build of this kernel: results changed
+    // from run to run).  A set is read back (v_mov into compiler registers) only behind its counted s_waitcnt.  S is a constant after inlining.
+    auto load_a = [&](int t, int S) __attribute__((always_inline)) {
+        const float* g = ga + (long)min(t, nt - 1) * 32;
+        if (S == 0) asm volatile("global_load_dwordx4 v[232:235], %0, off\n\tglobal_load_dwordx4 v[236:239], %0, off offset:16" ::"v"(g)
+                                 : "memory", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239");
+        else if (S == 1) asm volatile("global_load_dwordx4 v[240:243], %0, off\n\tglobal_load_dwordx4 v[244:247], %0, off offset:16" ::"v"(g)
+                                      : "memory", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
+        else asm volatile("global_load_dwordx4 v[248:251], %0, off\n\tglobal_load_dwordx4 v[252:255], %0, off offset:16" ::"v"(g)
+                          : "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+    };
+    auto read_set = [&](int S, float (&f)[8]) __attribute__((always_inline)) {
+#define PM_RD8(b0, b1, b2, b3, b4, b5, b6, b7)                                                                                                                        \
+    asm volatile("v_mov_b32 %0, v" #b0 "\n\tv_mov_b32 %1, v" #b1 "\n\tv_mov_b32 %2, v" #b2 "\n\tv_mov_b32 %3, v" #b3 "\n\tv_mov_b32 %4, v" #b4 "\n\tv_mov_b32 %5, v" #b5       \
+                 "\n\tv_mov_b32 %6, v" #b6 "\n\tv_mov_b32 %7, v" #b7                                                                                                   \
+                 : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7])::"memory")
+        if (S == 0) PM_RD8(232, 233, 234, 235, 236, 237, 238, 239);
+        else if (S == 1) PM_RD8(240, 241, 242, 243, 244, 245, 246, 247);
+        else PM_RD8(248, 249, 250, 251, 252, 253, 254, 255);
+#undef PM_RD8
+    };
+    const int woff = qrow * 64 + ((qc ^ ((qrow >> 2) & 3)) << 4);
+    auto lds_store16 = [&](uint32_t addr, const uint4 v4) __attribute__((always_inline)) {
+        const pm_u32x4 v = {v4.x, v4.y, v4.z, v4.w};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+    };
+    auto write_a = [&](int t, int S) __attribute__((always_inline)) {
+        const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (t & 3) * STAGE + woff;
+        float f[8];
+        read_set(S, f);
+        uint2 h0, l0, h1, l1;
+        mdvit_split_bf16x3(make_float4(f[0], f[1], f[2], f[3]), h0, l0);
+        mdvit_split_bf16x3(make_float4(f[4], f[5], f[6], f[7]), h1, l1);
+        lds_store16(dst, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        lds_store16(dst + PM_AP, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    };
+
+    // ---- fragments: lane (l31, lhi) of a 32-row block reads row l31, logical chunk 2 ks + lhi; ks = 1 flips bit 5 of the byte offset
+    const int swz = (l31 >> 2) & 3;
+    const int fr = l31 * 64 + ((lhi ^ swz) << 4);
+
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
+
+    // prologue: tiles 0 and 1 of A converted, B(0) landed; then, in the order the multiply phases M(-2), M(-1) would have issued them: B(1) A(2) B(2) A(3)
+    issue_b(0);
+    load_a(0, 0);
+    load_a(1, 1);
+    PM_WAIT_VM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    write_a(0, 0);
+    write_a(1, 1);
+    issue_b(1);
+    load_a(2, 2);
+    issue_b(2);
+    load_a(3, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PM_BAR();
+
+    auto run = [&](auto grpc) __attribute__((always_inline)) {
+        constexpr int G = decltype(grpc)::value;
+        constexpr int NC = G == 0 ? NX : NY, CB0 = G == 0 ? 0 : NX;
+        pm_f32x16 acc[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        pm_bf16x8 af[2][2], bf[NC][2][2];                     // [plane][k step]
+        // one K tile: L(t), barrier, M(t), barrier.  U = t % 3: M(t) loads A(t + 4) into set (U + 1) % 3 and converts A(t + 2) from set (U + 2) % 3
+        auto tile_body = [&](int t, auto uc) __attribute__((always_inline)) {
+            constexpr int U = decltype(uc)::value;
+            const char* st = smem + (t & 3) * STAGE;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    af[h][ks] = __builtin_bit_cast(pm_bf16x8, *reinterpret_cast<const uint4*>(st + h * PM_AP + wr * 2048 + (ks ? (fr ^ 32) : fr)));
+#pragma unroll
+                    for (int j = 0; j < NC; ++j)
+                        bf[j][h][ks] = __builtin_bit_cast(pm_bf16x8, *reinterpret_cast<const uint4*>(st + 2 * PM_AP + h * BP + (CB0 + j) * 2048 + (ks ? (fr ^ 32) : fr)));
+                }
+            PM_WAIT_VM(2 + NV);                               // B(t + 1) has landed (younger: A(t + 2), B(t + 2), A(t + 3))
+            PM_BAR();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1][ks], af[0][ks], acc[j], 0, 0, 0);
+                if (ks == 0) {
+                    issue_b(t + 3);
+                    load_a(t + 4, (U + 1) % 3);
+                    PM_WAIT_VM(2 * NV);                       // A(t + 2) is in its registers (younger: B(t + 2), A(t + 3), B(t + 3), A(t + 4))
+                    __builtin_amdgcn_sched_barrier(0);
+                    write_a(t + 2, (U + 2) % 3);
+                }
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0][ks], af[1][ks], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0][ks], af[0][ks], acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PM_BAR();
+        };
+        if (G == 1) PM_BAR();                                 // the second half of the workgroup runs one barrier behind the first
+        for (int t = 0; t < nt; t += 3) {
+            tile_body(t, C0{});
+            if (t + 1 < nt) tile_body(t + 1, C1{});
+            if (t + 2 < nt) tile_body(t + 2, C2{});
+        }
+        if (G == 0) PM_BAR();
+        PM_WAIT_VM(0);                                        // the tail tiles' loads (registers of this wave, LDS nobody reads) before the epilogue's own counting
+
+        // ---- epilogue (gemm_bp.hip's arithmetic on this kernel's block map): the MFMA ran as B^T x A -> D[row = n][col = m] per 32 x 32 block: for each register
+        // quad q a lane holds FOUR CONSECUTIVE output columns n = 8 q + 4 (lane >> 5) + (r & 3) of output row m = lane & 31.  Loads are unconditional (clamped address,
+        // the value dropped by a select): a load under a branch makes every later store wait for vmcnt(0).
+        constexpr bool HAS_IN = EPI == BEPI_PLAIN || EPI == BEPI_DGELU || EPI == BEPI_FULL;
+        const bool use_in = EPI == BEPI_PLAIN ? (p.accumulate != 0) : (EPI == BEPI_DGELU ? true : p.residual != nullptr);
+        const float* in_p = EPI == BEPI_PLAIN ? p.C : (EPI == BEPI_DGELU ? p.gelu_u : p.residual);
+        const long in_ld = EPI == BEPI_PLAIN ? p.ldc : (EPI == BEPI_DGELU ? p.ldu : p.ldr);
+        if (!use_in || in_p == nullptr) in_p = reinterpret_cast<const float*>(p.B);
+        const bool use_bias = p.bias != nullptr;
+        const float* bias_p = use_bias ? p.bias : reinterpret_cast<const float*>(p.B);
+        const int row = m0 + wr * 32 + l31;
+        const int rowc = min(row, p.M - 1);
+        const bool row_ok = row < p.M;
+        float rsc = 1.f;
+        if constexpr (EPI == BEPI_FULL) {
+            const bool use_rs = p.e_rowscale != nullptr;
+            const float* rs_p = use_rs ? p.e_rowscale : reinterpret_cast<const float*>(p.B);
+            const float v = rs_p[use_rs ? rowc / p.e_rows_per_scale : 0];
+            rsc = use_rs ? v : 1.f;
+        }
+        float4 inq[2][4];
+        auto load_in = [&](int j) __attribute__((always_inline)) {
+            if constexpr (HAS_IN) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = min(n0 + (CB0 + j) * 32 + 8 * q + 4 * lhi, p.N - 4);
+                    inq[j & 1][q] = *reinterpret_cast<const float4*>(in_p + (use_in ? (long)rowc * in_ld + col : 0L));
+                }
+            }
+        };
+        load_in(0);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            if (j + 1 < NC) load_in(j + 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + (CB0 + j) * 32 + 8 * q + 4 * lhi;
+                const bool ok = row_ok && col < p.N;
+                float4 v = make_float4(acc[j][4 * q + 0], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+                {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias_p + (use_bias ? min(col, p.N - 4) : 0));
+                    if (use_bias) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                }
+                const uint32_t didx = (uint32_t)((long)row * p.N + col);
+                float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HAS_IN) { o4 = inq[j & 1][q]; if (EPI != BEPI_DGELU && !use_in) o4 = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if (EPI == BEPI_PLAIN) { v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w; }
+                if (EPI == BEPI_GELU) {
+                    if (p.U && ok) *reinterpret_cast<float4*>(p.U + (long)row * p.ldu_out + col) = v;
+                    v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+                }
+                if (EPI == BEPI_DGELU) { v.x *= gelu_grad_f(o4.x); v.y *= gelu_grad_f(o4.y); v.z *= gelu_grad_f(o4.z); v.w *= gelu_grad_f(o4.w); }
+                if (EPI != BEPI_PLAIN && p.e_drop) {
+                    const float4 ds = mdvit_drop_scale4(ek0, ek1, didx, p.e_thresh, p.e_inv_keep);
+                    v.x *= ds.x; v.y *= ds.y; v.z *= ds.z; v.w *= ds.w;
+                }
+                if (EPI == BEPI_FULL) {
+#pragma clang fp contract(off)
+                    v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;       // (a multiply and an add, never fused: gemm_bp.hip / gemm_ph.hip / gemm_body.inc do the same arithmetic, bit for bit)
+                    v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
+                }
+                if (p.C && ok) *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col) = v;
+                if (p.Cp && ok) {
+                    uint2 hi, lo;
+                    mdvit_split_bf16x3(v, hi, lo);
+                    uint16_t* d = p.Cp + (long)row * p.ldcp + col;
+                    *reinterpret_cast<uint2*>(d) = hi;
+                    *reinterpret_cast<uint2*>(d + p.c_plane) = lo;
+                }
+            }
+        }
+    };
+    if (wave < 4) run(C0{});
+    else run(C1{});
+}
+
+template <int NX, int NY>
+int launch_pm(const BpArgs& a, int epi, hipStream_t s) {
+    constexpr int BN = 32 * (NX + NY), LDS = 4 * (2 * PM_AP + 2 * BN * 64);
+    dim3 grid(a.tiles_m * a.tiles_n), block(PM_THREADS);
+#define PM_LAUNCH(EPI_)                                                                                                                         \
+    do {                                                                                                                                        \
+        static bool attr[64];                                                                                                                   \
+        int dev = 0;                                                                                                                            \
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;                                                                  \
+        if (!attr[dev]) {                                                                                                                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pm_kernel<NX, NY, EPI_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return 2; \
+            attr[dev] = true;                                                                                                                   \
+        }                                                                                                                                       \
+        MDVIT_TIMED_LAUNCH((gemm_pm_kernel<NX, NY, EPI_>), grid, block, LDS, s, a);                                                            \
+    } while (0)
+    switch (epi) {
+        case BEPI_PLAIN: PM_LAUNCH(BEPI_PLAIN); break;
+        case BEPI_GELU: PM_LAUNCH(BEPI_GELU); break;
+        case BEPI_DGELU: PM_LAUNCH(BEPI_DGELU); break;
+        case BEPI_FULL: PM_LAUNCH(BEPI_FULL); break;
+        default: return 1;
+    }
+#undef PM_LAUNCH
+    return 0;
+}
+
+}  // namespace
+
+// cfg 6: 128 x 160, cfg 7: 128 x 128.  Built for what the step hands in: fp32 A, two weight planes (bf16x3), one K range, K % 32 == 0.
+bool mdvit_gemm_pm_ok(const BpArgs& a, int cfg, int planes, int epi) {
+    return (cfg == 6 || cfg == 7) && planes == 2 && a.a_f32 && a.splits == 1 && epi != BEPI_DGELU_RC && a.K % 32 == 0 && a.K >= 32 && a.N % 4 == 0;
+}
+
+int mdvit_gemm_pm_launch(const BpArgs& a, int cfg, int epi, hipStream_t s) {
+    if (cfg == 6) return launch_pm<3, 2>(a, epi, s);
+    if (cfg == 7) return launch_pm<2, 2>(a, epi, s);
+    return 1;
+}
+
+// Does the 128-row phase-split kernel take this NT product?  mode -1: never, 0: by the rule, 1: whenever legal (tools/gemm_ph_check.py).  Returns the cfg (6 / 7) or 0.
+int g_pm_mode = 0;
+extern "C" int mdvit_gemm_pm_config(int32_t mode) {
+    g_pm_mode = mode;
+    return MDVIT_OK;
+}
+extern "C" int mdvit_gemm_pm_prefers(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32) {
+    if (g_pm_mode < 0 || planes != 2 || !a_f32 || M <= 0 || N <= 0 || K < 64 || K % 32 != 0 || N % 4 != 0) return 0;
+    const int cfg = N % 160 == 0 ? 6 : (N % 128 == 0 ? 7 : 0);
+    if (cfg == 0) return 0;
+    if (g_pm_mode > 0) return cfg;
+    // One workgroup per CU: what decides is how much of the chip's round(s) of tiles is real work, and whether the K loop is long enough to pay for a prologue and an
+    // epilogue that nothing overlaps.  Measured against gemm.hip (tools/gemm_pm_check.py, profiles/r05_gemm_pm_check.txt): 16384 x 320 x 320 / 960 / 1280 (one round)
+    // 18 / 36 / 44 us against 23 / 55 / 67, 8192 x 512 x 512 / 2048 20 / 56 against 27 / 80, 32768 x 320 x 1280 (two rounds) 88 against 110; with K = 320 over
+    // several rounds it loses (16384 x 1280 x 320 65 against 54, 32768 x 960 x 320 94 against 85); 131072 x 320 x 1280 (eight rounds) ties.
+    const long tiles = (long)cdiv(M, 128) * (N / (cfg == 6 ? 160 : 128)), rounds = (tiles + 255) / 256;
+    const double eff = (double)tiles / ((double)rounds * 256.0);
+    if (eff < 0.7) return 0;
+    return ((K >= 640 && rounds <= 4) || (K >= 256 && rounds == 1)) ? cfg : 0;
+}

@@ -33,6 +33,7 @@ constexpr int BK = 32, NTH = 256;
 struct TnArgs {
     const float* A; const float* B; float* C; float* slab; float* colsum; float* cs_part; const float* bias;
     long lda, ldb, ldc;
+    long slab_stride, cs_stride;                          // floats between the rows of two K-splits in slab / cs_part (M N and M; M N + M for both when the rows are joint)
     int M, N, K, kps, splits, tiles_m, tiles_n, accumulate, grid_xcd, perm_cin;
     int cv_c, cv_h, cv_w, cv_ho, cv_wo, cv_s, cv_d;      // CONVB: B is the NHWC image x, gathered as the im2col matrix [token][tap * C + c]
     int ngroups; const float* gA[MDVIT_GEMM_MAX_GROUPS]; const float* gB[MDVIT_GEMM_MAX_GROUPS]; float* gC[MDVIT_GEMM_MAX_GROUPS];      // grouped launch: blockIdx.z = group
@@ -347,13 +348,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(BM * BN == 
         for (int i = tid; i < BM; i += NTH) {
             if (m0 + i >= p.M) continue;
             const float t = (s_cs[i] + s_cs[BM + i]) + (s_cs[2 * BM + i] + s_cs[3 * BM + i]);
-            if (p.splits > 1) p.cs_part[(long)split * p.M + m0 + i] = t;     // one row per K-split, summed by the slab reduction
+            if (p.splits > 1) p.cs_part[(long)split * p.cs_stride + m0 + i] = t;     // one row per K-split, summed by the slab reduction
             else p.colsum[m0 + i] += t;                                          // (this workgroup is the only writer of these columns)
         }
     }
 
     // epilogue: the MFMA ran as D = B-tile^T x A-tile -> D[row = n][col = m]; a lane holds four consecutive n per register quad
-    float* slab = p.splits > 1 ? p.slab + (long)split * p.M * p.N : nullptr;
+    float* slab = p.splits > 1 ? p.slab + (long)split * p.slab_stride : nullptr;
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
         const int row = m0 + wm0 + i * 32 + l31;
@@ -463,6 +464,7 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
                         "gemm (wgrad): a bf16-stored operand needs precision 1, no convolution, the other operand in fp32, leading dimensions %% 4 == 0");
     const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
     TnArgs a;
+    bool joint = false;
     memset(&a, 0, sizeof(a));
     a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum_a; a.bias = d->bias;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K;
@@ -485,6 +487,12 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
                         "gemm (wgrad): split reduction needs %zu bytes of workspace (mdvit_gemm_ws_bytes), got %zu", need, (size_t)d->ws_bytes);
         a.slab = (float*)d->ws;
         a.cs_part = a.slab + (size_t)pl.splits * d->M * d->N;
+        a.slab_stride = (long)d->M * d->N; a.cs_stride = d->M;
+        // Joint rows (round 5): a K-split's product and its column sums side by side, [splits][M N + M] -- ONE fixed-order reduction launch then produces dW and db
+        // (mdvit_reduce_partials: n0 = M N -> C, n1 = M -> colsum) instead of the slab reduction + a second launch for the M column sums.  Needs what that reduction
+        // assumes: a dense C, no bias / layout permutation in the reduction, both outputs accumulating (the column sums always do).
+        joint = d->colsum_a && !d->bias && a.perm_cin <= 0 && d->ldc == d->N && d->accumulate != 0;
+        if (joint) { a.slab_stride = a.cs_stride = (long)d->M * d->N + d->M; a.cs_part = a.slab + (long)d->M * d->N; }
     }
     if (const GemmGroups* gg = mdvit_gemm_groups_active()) {
         MDVIT_CHECK_ARG(pl.splits == 1 && !d->colsum_a && d->conv_c <= 0 && !d->a_bf16 && !d->b_bf16, MDVIT_E_SHAPE, "gemm (wgrad, grouped): one K range, no column sums, no gather");
@@ -516,6 +524,7 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
 #undef MDVIT_TN_LAUNCH
     MDVIT_LAUNCH_CHECK();
     if (pl.splits > 1) {
+        if (joint) return mdvit_reduce_partials(a.slab, pl.splits, a.slab_stride, d->M * d->N, d->C, d->M, d->colsum_a, 1, s);
         int rc = mdvit_gemm_splitk_reduce_perm(a.slab, d->bias, d->C, d->ldc, d->M, d->N, pl.splits, d->accumulate, a.perm_cin, s);
         if (rc == MDVIT_OK && d->colsum_a)        // the K-splits' column-sum rows, added in slab order
             rc = mdvit_reduce_partials(a.cs_part, pl.splits, d->M, d->M, d->colsum_a, 0, nullptr, 1, s);

@@ -470,6 +470,9 @@ _tn_kernel = os.environ.get("MDVIT_TN_KERNEL", "1") != "0"
 if not _tn_kernel:                                                      # A/B: weight-gradient GEMMs on the general template instead of gemm_tn.hip
     _lib.load().mdvit_gemm_tn_config(0, -1, 0)                          # (the implicit-convolution weight gradient lives in gemm_tn.hip: conv3x3_dense then takes im2col + GEMM)
 _ph_gemm = os.environ.get("MDVIT_PH_GEMM", "1") != "0"                # the 256-wide phase-split kernel for the products it prefers (0: A/B switch)
+_pm_gemm = os.environ.get("MDVIT_PM_GEMM", "1") != "0"                # the 128-row phase-split kernel for the mid-size products (0: A/B switch; the C-level block entry follows)
+if not _pm_gemm:
+    _lib.load().mdvit_gemm_pm_config(-1)
 if not _ph_gemm:
     _lib.load().mdvit_gemm_ph_config(-1)
 _plane_rc = os.environ.get("MDVIT_PLANE_RC", "0") != "0"              # the recomputing fc2 data gradient of the C = 128 MLPs on the plane kernel
@@ -690,11 +693,13 @@ _ph_cache = {}
 
 
 def _ph_prefers(M, N, K, planes=2, reads=False) -> bool:
-    """the 256-wide phase-split plane kernel (csrc/gemm_ph.hip) takes [M, K] x [N, K]^T (mdvit_gemm_ph_prefers_epi; reads: the epilogue reads an [M, N] operand)"""
+    """a phase-split plane kernel takes [M, K] x [N, K]^T: the 256-wide one (csrc/gemm_ph.hip, mdvit_gemm_ph_prefers_epi; reads: the epilogue reads an [M, N] operand)
+    or, for fp32 activations against two weight planes, the 128-row one of the mid-size products (csrc/gemm_pm.hip, mdvit_gemm_pm_prefers)"""
     k = (M, N, K, planes, bool(reads))
     r = _ph_cache.get(k)
     if r is None:
-        r = _ph_cache[k] = bool(_lib.load().mdvit_gemm_ph_prefers_epi(M, N, K, planes, int(bool(reads))))
+        lib = _lib.load()
+        r = _ph_cache[k] = bool(lib.mdvit_gemm_ph_prefers_epi(M, N, K, planes, int(bool(reads)))) or bool(_pm_gemm and lib.mdvit_gemm_pm_prefers(M, N, K, planes, 1))
     return r
 
 
@@ -768,6 +773,8 @@ def gemm_nt(x, W, out, M, N, K, *, w_transposed=False, bias=None, epi=_lib.EPI_N
         plan = _plan_cache[pkey] = (tm.value, tn.value, sp.value)
     if plan[0] == 256:       # csrc/gemm_ph.hip, as rocprofv3 prints it
         name = "gemm_ph_kernel<%d, %s, %d>%s" % (P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
+    elif plan[1] == 160 or (plan[0] == 128 and plan[1] == 128 and a_f32 and P == 2 and _lib.load().mdvit_gemm_pm_prefers(M, N, K, P, 1) == 7):
+        name = "gemm_pm_kernel<%d, 2, %d>" % (3 if plan[1] == 160 else 2, kepi)          # csrc/gemm_pm.hip
     else:
         name = "gemm_bp_nt_kernel<%d, %d, %d, %s, %d>%s" % (plan[0], plan[1], P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
     if _events_by_shape:

@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 --kernel-trace csv: per-kernel totals per step, per-stream busy time, idle gaps.
-usage: python tools/trace_summary.py <dir or *_kernel_trace.csv> [--steps K] [--skip-frac F] [--main-stream]
+usage: python tools/trace_summary.py <dir or *_kernel_trace.csv> [--steps K] [--skip-frac F] [--main-stream] [--forward]
 --main-stream: the breakdown of the BUSIEST stream only (the critical path of the step: the other streams overlap it), with the
 gaps between its consecutive kernels."""
 import csv, glob, os, sys, collections
@@ -17,8 +17,35 @@ def main():
     if "--last-ms" in sys.argv:
         cut = t1 - float(sys.argv[sys.argv.index("--last-ms") + 1]) * 1e6
     rows = [r for r in rows if int(r["Start_Timestamp"]) >= cut]
+    if "--forward" in sys.argv:
+        # the forward passes only: from the end of an optimizer launch to the first backward kernel of the losses (one stream, every kernel on the step's critical path)
+        keep, inside, nwin = [], False, 0
+        for r in rows:
+            nm = r["Kernel_Name"]
+            if "adamw_kernel" in nm:
+                inside = True; nwin += 1
+                continue
+            if inside and ("seg_losses_bwd" in nm or "_bwd_kernel" in nm and "loss" in nm):
+                inside = False
+            if inside:
+                keep.append(r)
+        rows = keep
+        steps = max(1, nwin - (1 if inside else 0))
+        t1 = int(rows[-1]["End_Timestamp"])
+        print(f"forward windows: {steps} (adamw_kernel .. first loss-backward kernel)")
     t0 = int(rows[0]["Start_Timestamp"])
     span = (t1 - t0) / 1e6
+    if "--stream-rank" in sys.argv:
+        # the breakdown of ONE stream, chosen by its rank in kernel time (0 = busiest = the main stream, 1 / 2 = the weight-gradient and aux-sweep streams)
+        key = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
+        tot_s = collections.defaultdict(float)
+        for r in rows:
+            tot_s[r[key]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        order = sorted(tot_s, key=tot_s.get, reverse=True)
+        sid = order[min(int(sys.argv[sys.argv.index("--stream-rank") + 1]), len(order) - 1)]
+        rows = [r for r in rows if r[key] == sid]
+        print(f"stream {sid} (rank {order.index(sid)} by kernel time): {len(rows)} kernels, first at {(int(rows[0]['Start_Timestamp']) - t0) / 1e6:.2f} ms, last ends at "
+              f"{(int(rows[-1]['End_Timestamp']) - t0) / 1e6:.2f} ms of the window")
     if "--main-stream" in sys.argv:
         key = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
         tot_s = collections.defaultdict(float)
