@@ -78,14 +78,14 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         gb[i] = p.B + (long)pl * p.b_plane + (long)min(n0 + row, p.N - 1) * p.ldb + chunk * 8;
         ob[i] = 2 * PM_AP + pl * BP + rg * 1024;
     }
+    auto issue_b1 = [&](int t, int i) __attribute__((always_inline)) {
+        const uint16_t* g = gb[i] + (long)min(t, nt - 1) * 32;
+        char* dst = smem + (t & 3) * STAGE + ob[i];
+        __builtin_amdgcn_global_load_lds(g, dst, 16, 0, 0);
+    };
     auto issue_b = [&](int t) __attribute__((always_inline)) {
-        const int ts = min(t, nt - 1);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const uint16_t* g = gb[i] + (long)ts * 32;
-            char* dst = smem + (t & 3) * STAGE + ob[i];
-            __builtin_amdgcn_global_load_lds(g, dst, 16, 0, 0);
-        }
+        for (int i = 0; i < PPW; ++i) issue_b1(t, i);
     };
     // ---- A (fp32): thread (row = tid / 4, c = tid % 4) owns k = 8 c .. 8 c + 7 of its row of a tile: two 16-byte loads into one of three register sets
     const int qrow = tid >> 2, qc = tid & 3;
@@ -175,22 +175,36 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             PM_WAIT_VM(2 + NV);                               // B(t + 1) has landed (younger: A(t + 2), B(t + 2), A(t + 3))
             PM_BAR();
             __builtin_amdgcn_s_setprio(1);
+            // six groups of NC MFMAs (k step x product); this tile's vector-memory issue is dealt out BETWEEN them, one operation behind each group (sched_barrier pins
+            // the order).  Measured against all of it behind the first group: no difference (16384 x 320 x 1280 45.7 against 44.1 us, profiles/r05_gemm_pm_check.txt) --
+            // the K tile takes ~2600 cycles against 960 of MFMA either way; what is left is in the two barriers per tile and the split / address VALU work of two
+            // waves per SIMD, which the matrix pipe does not overlap (profiles/r05_mfma_valu_overlap.txt).
+            auto group = [&](int g) __attribute__((always_inline)) {
+                const int ks = g / 3, pr = g % 3;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1][ks], af[0][ks], acc[j], 0, 0, 0);
-                if (ks == 0) {
-                    issue_b(t + 3);
-                    load_a(t + 4, (U + 1) % 3);
-                    PM_WAIT_VM(2 * NV);                       // A(t + 2) is in its registers (younger: B(t + 2), A(t + 3), B(t + 3), A(t + 4))
-                    __builtin_amdgcn_sched_barrier(0);
-                    write_a(t + 2, (U + 2) % 3);
-                }
-#pragma unroll
-                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0][ks], af[1][ks], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0][ks], af[0][ks], acc[j], 0, 0, 0);
-            }
+                for (int j = 0; j < NC; ++j)
+                    acc[j] = pr == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1][ks], af[0][ks], acc[j], 0, 0, 0)
+                           : (pr == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0][ks], af[1][ks], acc[j], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0][ks], af[0][ks], acc[j], 0, 0, 0));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            group(0);
+            issue_b1(t + 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            group(1);
+            issue_b1(t + 3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            group(2);
+            if constexpr (PPW == 3) issue_b1(t + 3, 2);
+            load_a(t + 4, (U + 1) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            group(3);
+            PM_WAIT_VM(2 * NV);                               // A(t + 2) is in its registers (younger: B(t + 2), A(t + 3), B(t + 3), A(t + 4))
+            __builtin_amdgcn_sched_barrier(0);
+            write_a(t + 2, (U + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            group(4);
+            group(5);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PM_BAR();
