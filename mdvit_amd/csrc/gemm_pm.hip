@@ -17,6 +17,13 @@
 //     B(u+3): waited for in L(u+2), intervals 2u+4 / 2u+5, read from 2u+6).  WAR: stage (u+3) & 3 held tile u-1, last read in interval 2u-1; stage (u+2) & 3 held
 //     tile u-2.  Tiles past the end are loaded from the last tile's address into stages nobody reads again, so every phase issues the same number of vector-memory
 //     operations and the vmcnt immediates are constants.
+//
+// Measured (tools/gemm_pm_check.py, profiles/r05_gemm_pm_check.txt): 16384 x 320 x 1280 in 44-46 us = ~300 TF/s useful against 200 on gemm.hip's 64 x 64 tiles -- a K tile
+// takes ~2600 cycles against 960 of MFMA.  Two other main loops were built on the same ring and measure THE SAME: this tile's vector-memory issue dealt between the MFMA
+// groups instead of behind the first one, and all eight waves in step with ONE barrier per K tile and the fragment registers as the pipeline
+// (profiles/r05_gemm_pm_schedules.txt: 45.5 against 44.0 us).  What the schedules share is the traffic: every one of the 256 workgroups streams the WHOLE weight (both planes,
+// 1.6 MB at 320 x 1280) from L2 in 64-byte row pieces -- half of every 128-byte line -- on top of its own A rows from HBM, ~9.3 TB/s of useful bytes into the CUs.  A K tile
+// of 64 (whole lines) needs 72 KB per stage, and the ring needs four; k-tile-major weight planes would make every 1 KiB piece contiguous -- not built.
 #include "common.h"
 #include "gemm_bp.h"
 #include <type_traits>
