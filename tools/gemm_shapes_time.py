@@ -13,8 +13,8 @@ from mdvit_amd import _lib, ops
 HBM, MFMA3 = 8.0e12, 2.5e15 / 3
 
 
-def timed(fn, n=8):
-    for _ in range(3):
+def timed(fn, n=10):
+    for _ in range(30):          # (the first ~30 launches after an idle gap run ~20 % slower: clock ramp)
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
