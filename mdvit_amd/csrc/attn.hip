@@ -692,7 +692,20 @@ __global__ __launch_bounds__(256) void da_fwd_kernel(const float* __restrict__ l
         float s = 0.f;
         const float* wr = W2 + (long)c * hid;
         if ((hid & 3) == 0 && (reinterpret_cast<uintptr_t>(wr) & 15) == 0) {
-            for (int i = 0; i < hid; i += 4) {           // same summation order, a quarter of the dependent loads
+            // same summation order; the row's loads are requested EIGHT quads at a time (round 5: one quad per trip was hid / 4 L2 round trips in a row -- 15 us per
+            // launch, 16 launches on the single-stream forward of a bs=4 step)
+            int i = 0;
+            for (; i + 32 <= hid; i += 32) {
+                float4 w4[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w4[q] = *reinterpret_cast<const float4*>(wr + i + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s = fmaf(h1[i + 4 * q], w4[q].x, s); s = fmaf(h1[i + 4 * q + 1], w4[q].y, s);
+                    s = fmaf(h1[i + 4 * q + 2], w4[q].z, s); s = fmaf(h1[i + 4 * q + 3], w4[q].w, s);
+                }
+            }
+            for (; i < hid; i += 4) {
                 const float4 w4 = *reinterpret_cast<const float4*>(wr + i);
                 s = fmaf(h1[i], w4.x, s); s = fmaf(h1[i + 1], w4.y, s); s = fmaf(h1[i + 2], w4.z, s); s = fmaf(h1[i + 3], w4.w, s);
             }

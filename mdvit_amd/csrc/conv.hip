@@ -793,6 +793,42 @@ __global__ __launch_bounds__(256) void upsample_multi_bwd_w_kernel(UpMulti p, co
     }
 }
 
+// The same width folds with the dy row read ONCE (round 5): workgroup = (dy row o, 32 channels); the row's [Wo][32] slice is staged in LDS (whole 128-byte lines), then
+// every (source column, channel quad) item folds its 2 s taps from there -- same taps, same order, same fmaf as above: bit-identical.  The kernel above reads every dy row
+// ~6 times through L2 (252 MB of traffic per launch for 134 MB of dy in the peer heads: 71 us, eight launches on the two sweeps' chains of a bs=4 step).
+__global__ __launch_bounds__(256) void upsample_multi_bwd_w_lds_kernel(UpMulti p, const float* __restrict__ dy, int Wo, int C) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];          // [Wo][32]
+    const long o = blockIdx.x;
+    const int c0 = blockIdx.y * 32;
+    const float* src = dy + o * Wo * C + c0;
+    for (int e = threadIdx.x; e < Wo * 8; e += 256) {
+        const int t = e >> 3, q = e & 7;
+        *reinterpret_cast<float4*>(s_row + t * 32 + 4 * q) = *reinterpret_cast<const float4*>(src + (long)t * C + 4 * q);
+    }
+    __syncthreads();
+    const int Wsum = p.Wi[0] + (p.n > 1 ? p.Wi[1] : 0) + (p.n > 2 ? p.Wi[2] : 0);
+    float* dsts[3] = {p.d[0], p.d[1], p.d[2]};
+    for (int e = threadIdx.x; e < Wsum * 8; e += 256) {
+        const int q = e & 7;
+        int j = e >> 3, sidx = 0;
+        if (j >= p.Wi[0]) { j -= p.Wi[0]; sidx = 1; if (j >= p.Wi[1]) { j -= p.Wi[1]; sidx = 2; } }
+        const int Wi = p.Wi[sidx];
+        const float sc = (float)Wi / (float)Wo;
+        int lo, hi;
+        out_range(j, Wi, Wo, lo, hi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int t = lo; t < hi; ++t) {
+            int i0, i1; float l;
+            bilin_src(t, Wi, sc, i0, i1, l);
+            const float wgt = (i0 == j ? 1.f - l : 0.f) + (i1 == j ? l : 0.f);
+            const float4 g = *reinterpret_cast<const float4*>(s_row + t * 32 + 4 * q);
+            acc.x = fmaf(wgt, g.x, acc.x); acc.y = fmaf(wgt, g.y, acc.y); acc.z = fmaf(wgt, g.z, acc.z); acc.w = fmaf(wgt, g.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(dsts[sidx] + (o * Wi + j) * C + c0 + 4 * q) = acc;
+    }
+}
+
 // y = x * dropmask / (1 - p): one hash per aligned float4 (mdvit_drop_scale4), n % 4 == 0
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, uint32_t k0, uint32_t k1,
                                                       const uint32_t* __restrict__ seed, uint32_t thresh, float inv_keep) {
@@ -1061,7 +1097,11 @@ extern "C" int mdvit_upsample_multi_bwd(const float* dy, float* const* dxs, cons
     const long cq = C / 4;
     const int bpr = (int)cdiv((long)wsum * cq, 256L);
     MDVIT_CHECK_ARG((long)B * Ho * bpr < (1L << 31), MDVIT_E_SHAPE, "upsample_multi_bwd: too many workgroups");
-    hipLaunchKernelGGL(upsample_multi_bwd_w_kernel, dim3((unsigned)((long)B * Ho * bpr)), dim3(256), 0, s, p, dy, (long)B * Ho, Wo, C, bpr);
+    static const bool lds_rows = [] { const char* e = getenv("MDVIT_UPSAMPLE_BWD_LDS"); return !(e && e[0] == '0'); }();          // 0: the L2 re-reading kernel (A/B)
+    if (lds_rows && C % 32 == 0 && Wo <= 384 && (long)B * Ho < (1L << 31) && C / 32 <= 65535)
+        hipLaunchKernelGGL(upsample_multi_bwd_w_lds_kernel, dim3((unsigned)((long)B * Ho), C / 32), dim3(256), sizeof(float) * Wo * 32, s, p, dy, Wo, C);
+    else
+        hipLaunchKernelGGL(upsample_multi_bwd_w_kernel, dim3((unsigned)((long)B * Ho * bpr)), dim3(256), 0, s, p, dy, (long)B * Ho, Wo, C, bpr);
     for (int i = 0; i < n; ++i)          // pass H per source: tmp_i [B][Ho][Wi*C] -> dx_i [B][Hi][Wi*C]
         hipLaunchKernelGGL((upsample_bwd_pass_kernel<false>), dim3(ew_grid((long)B * Hi[i] * Wi[i] * cq)), dim3(256), 0, s, p.d[i], dxs[i], (long)B, Hi[i], Ho,
                            (long)Wi[i] * cq, 1);

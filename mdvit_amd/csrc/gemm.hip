@@ -266,10 +266,6 @@ int mdvit_gemm_splitk_reduce(const float* slab, const float* bias, float* C, lon
 // perm_cin > 0: the columns are (tap, ci) pairs of a 3x3 convolution's weight gradient and land at [ci][tap] (the PyTorch layout) -- the relayout launch folded in
 int mdvit_gemm_splitk_reduce_perm(const float* slab, const float* bias, float* C, long ldc, int M, int N, int splits, int accumulate, int perm_cin, hipStream_t s) {
     const long total = (long)M * N / 4;
-    // many K-splits of a small dense output (the 64 x 64 ... 192 x 64 weight gradients over 65536+ tokens: 384 slabs): the R = 64 form below gives every lane a 16-byte
-    // piece of a different slab row (63 us for 6 MB, as long as the product itself); the partial-row kernel reads whole 128-byte lines (round 5)
-    if (total < 4096 && splits >= 64 && !bias && perm_cin <= 0 && ldc == N)
-        return mdvit_reduce_partials(slab, splits, (long)M * N, M * N, C, 0, nullptr, accumulate, s);
 #define MDVIT_REDUCE_LAUNCH(R_) \
     hipLaunchKernelGGL((gemm_splitk_reduce_kernel<R_>), dim3((int)min((total * R_ + 255) / 256, 4096L)), dim3(256), 0, s, \
                        slab, bias, C, ldc, M, N, splits, accumulate, perm_cin)

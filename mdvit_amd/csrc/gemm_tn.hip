@@ -464,7 +464,6 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
                         "gemm (wgrad): a bf16-stored operand needs precision 1, no convolution, the other operand in fp32, leading dimensions %% 4 == 0");
     const TnPlan pl = plan_tn(d->M, d->N, d->K, d->allow_split);
     TnArgs a;
-    bool joint = false;
     memset(&a, 0, sizeof(a));
     a.A = d->A; a.B = d->B; a.C = d->C; a.colsum = d->colsum_a; a.bias = d->bias;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.K = d->K;
@@ -488,11 +487,10 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
         a.slab = (float*)d->ws;
         a.cs_part = a.slab + (size_t)pl.splits * d->M * d->N;
         a.slab_stride = (long)d->M * d->N; a.cs_stride = d->M;
-        // Joint rows (round 5): a K-split's product and its column sums side by side, [splits][M N + M] -- ONE fixed-order reduction launch then produces dW and db
-        // (mdvit_reduce_partials: n0 = M N -> C, n1 = M -> colsum) instead of the slab reduction + a second launch for the M column sums.  Needs what that reduction
-        // assumes: a dense C, no bias / layout permutation in the reduction, both outputs accumulating (the column sums always do).
-        joint = d->colsum_a && !d->bias && a.perm_cin <= 0 && d->ldc == d->N && d->accumulate != 0;
-        if (joint) { a.slab_stride = a.cs_stride = (long)d->M * d->N + d->M; a.cs_part = a.slab + (long)d->M * d->N; }
+        // (Round 5 tried joint rows -- a K-split's product and its column sums side by side, [splits][M N + M], ONE launch of the partial-row kernel for dW and db -- and the
+        // many-split reductions of the small outputs through that kernel as well: 63 launches per step fewer on the weight-gradient stream, but the partial-row kernels
+        // are slower than gemm_splitk_reduce on wide outputs: 4.36 against 3.78 ms of reduction kernels per bs=4 step (rocprofv3, profiles/r05d / r05c kernel stats), the
+        // step unchanged in three interleaved A/B pairs.  Not kept; slab_stride / cs_stride stay as kernel arguments.)
     }
     if (const GemmGroups* gg = mdvit_gemm_groups_active()) {
         MDVIT_CHECK_ARG(pl.splits == 1 && !d->colsum_a && d->conv_c <= 0 && !d->a_bf16 && !d->b_bf16, MDVIT_E_SHAPE, "gemm (wgrad, grouped): one K range, no column sums, no gather");
@@ -524,7 +522,6 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
 #undef MDVIT_TN_LAUNCH
     MDVIT_LAUNCH_CHECK();
     if (pl.splits > 1) {
-        if (joint) return mdvit_reduce_partials(a.slab, pl.splits, a.slab_stride, d->M * d->N, d->C, d->M, d->colsum_a, 1, s);
         int rc = mdvit_gemm_splitk_reduce_perm(a.slab, d->bias, d->C, d->ldc, d->M, d->N, pl.splits, d->accumulate, a.perm_cin, s);
         if (rc == MDVIT_OK && d->colsum_a)        // the K-splits' column-sum rows, added in slab order
             rc = mdvit_reduce_partials(a.cs_part, pl.splits, d->M, d->M, d->colsum_a, 0, nullptr, 1, s);
