@@ -1354,6 +1354,48 @@ def test_phase_split_256_tile_is_the_128_tile_bit_for_bit_in_every_epilogue():
     assert mod.correctness([3])
 
 
+def test_phase_split_128_row_tile_is_the_128_tile_bit_for_bit_in_every_epilogue():
+    """csrc/gemm_pm.hip (round 5: 128 x 160 / 128 x 128 tile, eight waves of unequal work on equal SIMDs, four-stage ring, the in-flight fp32 A rows in fixed registers)
+    through mdvit_gemm_planes with the plan forced: fp32 A against two weight planes, ragged M / N, K from ONE tile up, every epilogue (bias, accumulate, GELU + u +
+    dropout, DropPath + residual + dropout, gelu' x u) -- bit for bit against the 128 x 128 plane tile and against fp64; 20 repeats of every shape must agree bit for
+    bit (the first build of this kernel read registers whose loads had not landed: results changed from run to run).  tools/gemm_pm_check.py"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gemm_pm_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gemm_pm_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.correctness()
+
+
+def test_mid_size_products_take_the_128_row_tile_and_equal_the_split_while_staging_kernel_bit_for_bit():
+    """mdvit_gemm_pm_prefers: the rule's two sides at the step's shapes; ops.linear on a shape it takes (16384 x 320 x 1280: fc2 of stage 2 at 16 images) runs
+    gemm_pm_kernel and equals gemm.hip's forward, data gradient and weight gradient bit for bit (MDVIT_PM_GEMM / mdvit_gemm_pm_config(-1) switch it off)."""
+    from mdvit_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.mdvit_gemm_pm_prefers(16384, 320, 1280, 2, 1) == 6 and lib.mdvit_gemm_pm_prefers(16384, 320, 320, 2, 1) == 6 and lib.mdvit_gemm_pm_prefers(8192, 512, 2048, 2, 1) == 7
+    assert lib.mdvit_gemm_pm_prefers(16384, 1280, 320, 2, 1) == 0 and lib.mdvit_gemm_pm_prefers(4096, 512, 2048, 2, 1) == 0 and lib.mdvit_gemm_pm_prefers(16384, 320, 1280, 1, 1) == 0
+    assert lib.mdvit_gemm_pm_prefers(16384, 320, 1280, 2, 0) == 0 and lib.mdvit_gemm_pm_prefers(16384, 324, 1280, 2, 1) == 0
+    M, N, K = 16384, 320, 1280
+    x, W, b, g = rnd(M, K, seed=1).to(dev()), rnd(N, K, seed=2, scale=K ** -0.5).to(dev()), rnd(N, seed=3).to(dev()), rnd(M, N, seed=4).to(dev())
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision("bf16x3")
+    try:
+        res = {}
+        for mode in (0, -1):
+            lib.mdvit_gemm_pm_config(mode); ops._ph_cache.clear()
+            ops.kernel_events_begin()
+            out, go = grads_of(lambda x, W, b: ops.linear(x, W, b), [x, W, b], g)
+            names = list(ops.kernel_events_end())
+            res[mode] = (out, go, names)
+    finally:
+        lib.mdvit_gemm_pm_config(0); ops._ph_cache.clear()
+        ops.set_gemm_precision(prev)
+    assert any(n.startswith("gemm_pm_kernel<3, 2") for n in res[0][2]), res[0][2]
+    assert not any(n.startswith("gemm_pm_kernel") for n in res[-1][2]), res[-1][2]
+    assert torch.equal(res[0][0], res[-1][0])
+    for a, r in zip(res[0][1], res[-1][1]):
+        assert torch.equal(a, r)
+
+
 def test_linear_on_the_256_tile_equals_the_split_while_staging_kernel_bit_for_bit():
     """ops.linear routes the products mdvit_gemm_ph_prefers accepts to the 256-wide plane kernel (MDVIT_PH_GEMM); forward, data gradient and the fused
     FULL epilogue equal gemm.hip's results bit for bit (same products, same order), so a block may mix the two freely."""
