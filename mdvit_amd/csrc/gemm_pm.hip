@@ -21,9 +21,12 @@
 // Measured (tools/gemm_pm_check.py, profiles/r05_gemm_pm_check.txt): 16384 x 320 x 1280 in 44-46 us = ~300 TF/s useful against 200 on gemm.hip's 64 x 64 tiles -- a K tile
 // takes ~2600 cycles against 960 of MFMA.  Two other main loops were built on the same ring and measure THE SAME: this tile's vector-memory issue dealt between the MFMA
 // groups instead of behind the first one, and all eight waves in step with ONE barrier per K tile and the fragment registers as the pipeline
-// (profiles/r05_gemm_pm_schedules.txt: 45.5 against 44.0 us).  What the schedules share is the traffic: every one of the 256 workgroups streams the WHOLE weight (both planes,
-// 1.6 MB at 320 x 1280) from L2 in 64-byte row pieces -- half of every 128-byte line -- on top of its own A rows from HBM, ~9.3 TB/s of useful bytes into the CUs.  A K tile
-// of 64 (whole lines) needs 72 KB per stage, and the ring needs four; k-tile-major weight planes would make every 1 KiB piece contiguous -- not built.
+// (profiles/r05_gemm_pm_schedules.txt: 45.5 against 44.0 us).  Counters (profiles/r05_gemm_pm_pmc_stalls.txt): matrix pipes 36 % busy, a wave waits 44 % of its life, 4.4 VALU
+// instructions per MFMA, no LDS bank conflicts.  NOT the weight's traffic either: every workgroup streams the whole weight from L2 in 64-byte row pieces (half of every
+// 128-byte line), but a probe build with k-tile-major planes -- every 1 KiB piece one contiguous KiB -- runs the one-round shapes no faster (16384 x 320 x 1280 54.5 against
+// 49.4 us, x 960 38.0 / 39.0; only the eight-round 131072 x 320 x 1280 gains, 357 against 411: tools/probe/gemm_pm_tiled_probe.py, profiles/r05_gemm_pm_tiled_probe.txt).
+// What is left is the per-tile chain itself: barrier -> fragment reads -> MFMAs of one half -> barrier, twice per K tile, with the split / address VALU work of two waves per
+// SIMD that the matrix pipe does not overlap (profiles/r05_mfma_valu_overlap.txt).
 #include "common.h"
 #include "gemm_bp.h"
 #include <type_traits>
