@@ -9,13 +9,16 @@
 //     k step of 16: lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_bf16 in ascending k): results are BIT-IDENTICAL to their tiles, so the planner may pick by shape.
 //   * A K tile is 32 k.  Ring of FOUR LDS stages, each A hi | A lo (128 rows x 64 B) | B hi | B lo (BN rows x 64 B).  B travels L2 -> LDS by global_load_lds
 //     (1 KiB = 16 rows per wave-instruction), A HBM -> registers (three sets in flight) -> planes -> ds_write_b128.
-//   * Y runs ONE BARRIER behind X: a K tile is a load phase L (fragment reads, counted vmcnt) and a multiply phase M (MFMAs, with this tile's loads issued and an older
-//     tile's A registers converted behind the first MFMAs); while X multiplies, Y reads, and the other way round.  Phase schedule (interval k between barriers k, k+1):
-//         X:  L(0) M(0) L(1) M(1) ...           M(u) issues B(u+3) (LDS-DMA) and A(u+4) (registers) and writes A(u+2) to LDS
-//         Y:       L(0) M(0) L(1) ...           L(u) ends with vmcnt(what is younger than B(u+1))
-//     RAW: data is waited for / written at least one barrier before the first phase that reads it (A(u+2): written in intervals 2u+1 / 2u+2, read from 2u+4;
-//     B(u+3): waited for in L(u+2), intervals 2u+4 / 2u+5, read from 2u+6).  WAR: stage (u+3) & 3 held tile u-1, last read in interval 2u-1; stage (u+2) & 3 held
-//     tile u-2.  Tiles past the end are loaded from the last tile's address into stages nobody reads again, so every phase issues the same number of vector-memory
+//   * Y runs ONE BARRIER behind X: a K tile is a load phase L (fragment reads of tile u, the LDS-DMA issue of B(u+3), the register loads of A(u+4), counted vmcnt) and a
+//     multiply phase M (MFMAs); while X multiplies, Y loads, and the other way round.  The conversion of an older tile's A registers (A(u+2): 8 v_mov + the split + 2
+//     ds_write_b128) sits where its half has room: in X's LOAD phase (X has 18 MFMAs per tile) and in Y's MULTIPLY phase (12 MFMAs).  Schedule (interval k between
+//     barriers k, k+1):
+//         X:  L(0) M(0) L(1) M(1) ...
+//         Y:       L(0) M(0) L(1) ...
+//     RAW: data is waited for / written at least one barrier before the first phase that reads it (A(u+2): written in intervals 2u (X) / 2u+2 (Y), read from 2u+4;
+//     B(u+1): waited for at the end of L(u), intervals 2u / 2u+1, read from 2u+2).  WAR: B(u+3) goes to stage (u+3) & 3, which held tile u-1 -- read in L(u-1), intervals
+//     2u-2 / 2u-1, every wave's reads COMPLETE (lgkmcnt(0)) before the barrier that ends its load phase; A(u+2) goes to the stage of tile u-2.  Tiles past the end are
+//     loaded from the last tile's address into stages nobody reads again, so every phase issues the same number of vector-memory
 //     operations and the vmcnt immediates are constants.
 //
 // Measured (tools/gemm_pm_check.py, profiles/r05_gemm_pm_check.txt): 16384 x 320 x 1280 in 44-46 us = ~300 TF/s useful against 200 on gemm.hip's 64 x 64 tiles -- a K tile
@@ -25,8 +28,10 @@
 // instructions per MFMA, no LDS bank conflicts.  NOT the weight's traffic either: every workgroup streams the whole weight from L2 in 64-byte row pieces (half of every
 // 128-byte line), but a probe build with k-tile-major planes -- every 1 KiB piece one contiguous KiB -- runs the one-round shapes no faster (16384 x 320 x 1280 54.5 against
 // 49.4 us, x 960 38.0 / 39.0; only the eight-round 131072 x 320 x 1280 gains, 357 against 411: tools/probe/gemm_pm_tiled_probe.py, profiles/r05_gemm_pm_tiled_probe.txt).
-// What is left is the per-tile chain itself: barrier -> fragment reads -> MFMAs of one half -> barrier, twice per K tile, with the split / address VALU work of two waves per
-// SIMD that the matrix pipe does not overlap (profiles/r05_mfma_valu_overlap.txt).
+// Shader-clock stamps (tools/probe/gemm_pm_phases.py on the -DMDVIT_PM_STAMPS build, profiles/r05_gemm_pm_phases.txt) say what is: per K tile a SIMD issues 30 MFMAs
+// (960 cycles) + 28 ds_read_b128 + 10 vector-memory operations + ~76 VALU instructions from its two waves, and the tile takes ~2080 cycles wherever the non-MFMA
+// instructions stand -- inside the multiply phases (first build) or in the load phases (now): the two waves of a SIMD slow each other's issue down by what they overlap, as
+// profiles/r05_mfma_valu_overlap.txt found for VALU.  At 3 MFMAs per four fragment reads (bf16x3 on 32 x 32 blocks) this tile shape has too few MFMAs per other instruction.
 #include "common.h"
 #include "gemm_bp.h"
 #include <type_traits>
@@ -48,6 +53,14 @@ constexpr int PM_AP = 128 * 64;          // bytes of one A plane of a stage
         asm volatile("s_barrier" ::: "memory");   \
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
+
+// Variant build -DMDVIT_PM_STAMPS (tools/build_variant.py; tools/probe/gemm_pm_phases.py): shader-clock stamps of lane 0 of waves 0 (X) and 4 (Y) of workgroup 0 around the
+// parts of a K tile, written to the buffer handed in as BpArgs.slab (unused otherwise: the kernel has one K range): [wave half][tile][8]
+#ifdef MDVIT_PM_STAMPS
+#define PM_STAMP(t_, k_) do { if (stamps && (t_) < 64) stamps[(t_) * 8 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PM_STAMP(t_, k_) do { } while (0)
+#endif
 
 __device__ __forceinline__ int pm_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -169,10 +182,14 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         pm_bf16x8 af[2][2], bf[NC][2][2];                     // [plane][k step]
+#ifdef MDVIT_PM_STAMPS
+        long long* stamps = (p.slab && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) ? reinterpret_cast<long long*>(p.slab) + (wave >> 2) * 64 * 8 : nullptr;
+#endif
         // one K tile: L(t), barrier, M(t), barrier.  U = t % 3: M(t) loads A(t + 4) into set (U + 1) % 3 and converts A(t + 2) from set (U + 2) % 3
         auto tile_body = [&](int t, auto uc) __attribute__((always_inline)) {
             constexpr int U = decltype(uc)::value;
             const char* st = smem + (t & 3) * STAGE;
+            PM_STAMP(t, 0);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -182,13 +199,27 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     for (int j = 0; j < NC; ++j)
                         bf[j][h][ks] = __builtin_bit_cast(pm_bf16x8, *reinterpret_cast<const uint4*>(st + 2 * PM_AP + h * BP + (CB0 + j) * 2048 + (ks ? (fr ^ 32) : fr)));
                 }
-            PM_WAIT_VM(2 + NV);                               // B(t + 1) has landed (younger: A(t + 2), B(t + 2), A(t + 3))
+            // The tile's vector-memory issue and the conversion of an older tile's A registers are NOT in the multiply phase of the half that has the most MFMAs: stamped
+            // (tools/probe/gemm_pm_phases.py, profiles/r05_gemm_pm_phases.txt), a multiply phase that carried both took its MFMA time PLUS ~450 cycles (3 LDS-DMA issues,
+            // 2 loads, 8 v_mov + the 24-instruction split + 2 ds_write: the matrix pipe idles behind a wave's non-MFMA issue), 1032 / 838 cycles for X / Y, while the other
+            // half's load phase (~390) waited at the barrier -- 2078 cycles per K tile.  Now both halves issue in their LOAD phase; X (18 MFMAs per tile) also converts
+            // there, Y (12 MFMAs) converts in its multiply phase: the two intervals of a tile hold max(X.M, Y.L) and max(Y.M, X.L) with the extras on the short sides.
+            issue_b(t + 3);
+            load_a(t + 4, (U + 1) % 3);
+            PM_STAMP(t, 1);
+            if constexpr (G == 0) {
+                PM_WAIT_VM(2 * NV);                           // A(t + 2) is in its registers (younger: B(t + 2), A(t + 3), B(t + 3), A(t + 4)) -- and B(t + 1), older, has landed
+                __builtin_amdgcn_sched_barrier(0);
+                write_a(t + 2, (U + 2) % 3);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                PM_WAIT_VM(2 + 2 * NV);                       // B(t + 1) has landed (younger: A(t + 2), B(t + 2), A(t + 3), B(t + 3), A(t + 4))
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this tile's fragment reads are DONE before the barrier: X refills stage (t) & 3 ... (t + 4) from its next load phase on
+            }
+            PM_STAMP(t, 2);
             PM_BAR();
+            PM_STAMP(t, 3);
             __builtin_amdgcn_s_setprio(1);
-            // six groups of NC MFMAs (k step x product); this tile's vector-memory issue is dealt out BETWEEN them, one operation behind each group (sched_barrier pins
-            // the order).  Measured against all of it behind the first group: no difference (16384 x 320 x 1280 45.7 against 44.1 us, profiles/r05_gemm_pm_check.txt) --
-            // the K tile takes ~2600 cycles against 960 of MFMA either way; what is left is in the two barriers per tile and the split / address VALU work of two
-            // waves per SIMD, which the matrix pipe does not overlap (profiles/r05_mfma_valu_overlap.txt).
             auto group = [&](int g) __attribute__((always_inline)) {
                 const int ks = g / 3, pr = g % 3;
 #pragma unroll
@@ -199,25 +230,24 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 __builtin_amdgcn_sched_barrier(0);
             };
             group(0);
-            issue_b1(t + 3, 0);
-            __builtin_amdgcn_sched_barrier(0);
             group(1);
-            issue_b1(t + 3, 1);
-            __builtin_amdgcn_sched_barrier(0);
             group(2);
-            if constexpr (PPW == 3) issue_b1(t + 3, 2);
-            load_a(t + 4, (U + 1) % 3);
-            __builtin_amdgcn_sched_barrier(0);
             group(3);
-            PM_WAIT_VM(2 * NV);                               // A(t + 2) is in its registers (younger: B(t + 2), A(t + 3), B(t + 3), A(t + 4))
-            __builtin_amdgcn_sched_barrier(0);
-            write_a(t + 2, (U + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);
+            PM_STAMP(t, 4);
+            if constexpr (G == 1) {
+                PM_WAIT_VM(2 * NV);                           // A(t + 2) is in its registers
+                __builtin_amdgcn_sched_barrier(0);
+                PM_STAMP(t, 5);
+                write_a(t + 2, (U + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             group(4);
             group(5);
+            PM_STAMP(t, 6);
             __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PM_BAR();
+            PM_STAMP(t, 7);
         };
         if (G == 1) PM_BAR();                                 // the second half of the workgroup runs one barrier behind the first
         for (int t = 0; t < nt; t += 3) {
@@ -304,8 +334,17 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     else run(C1{});
 }
 
+#ifdef MDVIT_PM_STAMPS
+static long long* g_pm_stamps = nullptr;
+extern "C" void mdvit_pm_debug_buffer(long long* buf) { g_pm_stamps = buf; }
+#endif
+
 template <int NX, int NY>
-int launch_pm(const BpArgs& a, int epi, hipStream_t s) {
+int launch_pm(const BpArgs& a0, int epi, hipStream_t s) {
+    BpArgs a = a0;
+#ifdef MDVIT_PM_STAMPS
+    a.slab = reinterpret_cast<float*>(g_pm_stamps);
+#endif
     constexpr int BN = 32 * (NX + NY), LDS = 4 * (2 * PM_AP + 2 * BN * 64);
     dim3 grid(a.tiles_m * a.tiles_n), block(PM_THREADS);
 #define PM_LAUNCH(EPI_)                                                                                                                         \
