@@ -370,6 +370,9 @@ typedef struct MdvitBlockDesc {
                                                 * [tokens, hidden] tensors the block still moves, operands of weight-gradient GEMMs only -- are stored as bf16:
                                                 * y and dx do not change by a bit, the fc1 / fc2 weight (and fc1 bias) gradients see bf16-rounded operands
                                                 * (~2e-3 relative).  Ignored where the block has no such tensor (C = 64) or the 16-token MLP kernels do not run. */
+    const float* a_pre;                        /* optional (round 5): the adapter's output a [B, C] for `label`, computed ahead by mdvit_da_fwd_many -- the forward then
+                                                * launches no adapter kernel and the backward reads a from HERE (hand the same pointer to mdvit_block_bwd; the slot of a
+                                                * in `save` stays unused).  NULL: the block computes a itself. */
 } MdvitBlockDesc;
 /* Gradient outputs of the backward.  The sixteen "weight-class" outputs (cpe, qkv, crpe windows, proj, fc1, fc2) are overwritten
  * (accumulate == 0: fresh buffers) or added into (accumulate != 0: gradient buckets; the weight-gradient kernels then run on the side
@@ -522,6 +525,17 @@ int mdvit_upsample_multi_bwd(const float* dy, float* const* dxs, const int32_t* 
  * dgrad-only aux sweep pre-subtract its adapter gradient (mdvit_amd/train.py, multi_train_MDViT.py:198-207). */
 int mdvit_da_fwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, float* a,
                  int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream);
+/* The same for up to MDVIT_DA_MANY_MAX adapters and ONE label batch in one launch (round 5): an adapter's output depends on the labels and its own four tensors only, so a
+ * model computes all of them at the top of its forward (mdvit_amd.ops.da_precomputed) and hands each block its slice through MdvitBlockDesc.a_pre -- instead of one ~13 us
+ * launch inside every block on the single-stream forward.  a[i]: [B, C[i]] fp32.  Same arithmetic as mdvit_da_fwd, bit for bit. */
+#define MDVIT_DA_MANY_MAX 32
+typedef struct MdvitDaMany {
+    int32_t n;
+    int32_t hid[MDVIT_DA_MANY_MAX], C[MDVIT_DA_MANY_MAX], heads[MDVIT_DA_MANY_MAX];
+    const float* W1[MDVIT_DA_MANY_MAX]; const float* b1[MDVIT_DA_MANY_MAX]; const float* W2[MDVIT_DA_MANY_MAX]; const float* b2[MDVIT_DA_MANY_MAX];
+    float* a[MDVIT_DA_MANY_MAX];
+} MdvitDaMany;
+int mdvit_da_fwd_many(const MdvitDaMany* m, const float* label, int32_t B, int32_t D, void* stream);
 size_t mdvit_da_ws_bytes(int32_t B, int32_t hid, int32_t C);
 int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,
                  const float* e, float scale, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,

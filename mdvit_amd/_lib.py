@@ -78,11 +78,19 @@ class BlockDesc(C.Structure):
                 + [(n, vp) for n in ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",
                                      "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
                 + [(n, vp) for n in ("qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "fc1_p", "fc2_p", "fc2t_p", "fc1t_p", "qkv_p", "proj_p", "projt_p", "qkvt_p")]
-                + [("store_bf16", i32)])
+                + [("store_bf16", i32), ("a_pre", vp)])
 
 
 BLOCK_PARAMS = ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",
                 "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+DA_MANY_MAX = 32
+
+
+class DaMany(C.Structure):
+    _fields_ = [("n", i32), ("hid", i32 * DA_MANY_MAX), ("C", i32 * DA_MANY_MAX), ("heads", i32 * DA_MANY_MAX), ("W1", vp * DA_MANY_MAX), ("b1", vp * DA_MANY_MAX),
+                ("W2", vp * DA_MANY_MAX), ("b2", vp * DA_MANY_MAX), ("a", vp * DA_MANY_MAX)]
 
 
 class BlockGrads(C.Structure):
@@ -101,6 +109,7 @@ _SIGS = {
     "mdvit_gemm_planes_force_plan": [i32, i32],
     "mdvit_gemm_ph_config": [i32],
     "mdvit_gemm_pm_config": [i32],
+    "mdvit_da_fwd_many": [C.POINTER(DaMany), vp, i32, i32, vp],
     "mdvit_gemm_pm_prefers": [i32, i32, i32, i32, i32],
     "mdvit_gemm_f32_grouped": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
     "mdvit_gemm_f32_grouped_bias": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],

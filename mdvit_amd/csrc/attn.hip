@@ -674,48 +674,64 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(CH >= 64 ? 
 }
 
 // ---- Domain Adapter -----------------------------------------------------------------------------
-// grid = B; h1 = relu(W1 label + b1) in LDS, z = W2 h1 + b2 in LDS, a = softmax over heads per ch.
-__global__ __launch_bounds__(256) void da_fwd_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
-                                                     const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ a,
-                                                     int D, int hid, int C, int heads) {
-    extern __shared__ float sm[];   // h1[hid], z[C]
-    float* h1 = sm;
+// grid = B; h1 = relu(W1 label + b1) in LDS, z = W2 h1 + b2 in LDS, a = softmax over heads per ch.  Round 5: 1024 threads, a row of W2 is walked by G = 1024 / C
+// threads (a contiguous run of quads each, all of its loads in flight at once), the G partial sums are added in segment order through LDS -- one thread per row was
+// hid / 4 dependent L2 round trips (13-15 us per launch, 16 launches on the single-stream forward of a bs=4 step).  The result depends on (C, hid) only, never on
+// the batch: the domain-batched forward stays the per-domain forwards bit for bit.
+__device__ __forceinline__ void da_fwd_body(float* sm, const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
+                                            const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ a, int D, int hid, int C, int heads) {
+    float* h1 = sm;                 // h1[hid], z[C], zpart[G][C]
     float* z = sm + hid;
-    const int b = blockIdx.x, Ch = C / heads;
-    for (int i = threadIdx.x; i < hid; i += blockDim.x) {
+    float* zpart = z + C;
+    const int b = blockIdx.x, Ch = C / heads, BD = blockDim.x;
+    for (int i = threadIdx.x; i < hid; i += BD) {
         float s = 0.f;
         for (int d = 0; d < D; ++d) s = fmaf(label[(long)b * D + d], W1[(long)i * D + d], s);
         h1[i] = fmaxf(s + b1[i], 0.f);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.f;
-        const float* wr = W2 + (long)c * hid;
-        if ((hid & 3) == 0 && (reinterpret_cast<uintptr_t>(wr) & 15) == 0) {
-            // same summation order; the row's loads are requested EIGHT quads at a time (round 5: one quad per trip was hid / 4 L2 round trips in a row -- 15 us per
-            // launch, 16 launches on the single-stream forward of a bs=4 step)
-            int i = 0;
-            for (; i + 32 <= hid; i += 32) {
-                float4 w4[8];
+    const bool vec = (hid & 3) == 0 && (reinterpret_cast<uintptr_t>(W2) & 15) == 0;
+    const int nq = vec ? hid >> 2 : hid;                       // walk units per row: quads, or single elements
+    int G = BD / C;
+    if (G < 1) G = 1;
+    if (G > nq) G = nq;
+    for (int c0 = 0; c0 < C; c0 += BD / G) {
+        const int c = c0 + (int)threadIdx.x / G, seg = (int)threadIdx.x % G;
+        if (c < C && (int)threadIdx.x < (BD / G) * G) {
+            const int u0 = (int)((long)nq * seg / G), u1 = (int)((long)nq * (seg + 1) / G);
+            const float* wr = W2 + (long)c * hid;
+            float s = 0.f;
+            if (vec) {
+                int u = u0;
+                for (; u + 8 <= u1; u += 8) {
+                    float4 w4[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) w4[q] = *reinterpret_cast<const float4*>(wr + i + 4 * q);
+                    for (int q = 0; q < 8; ++q) w4[q] = *reinterpret_cast<const float4*>(wr + 4 * (u + q));
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    s = fmaf(h1[i + 4 * q], w4[q].x, s); s = fmaf(h1[i + 4 * q + 1], w4[q].y, s);
-                    s = fmaf(h1[i + 4 * q + 2], w4[q].z, s); s = fmaf(h1[i + 4 * q + 3], w4[q].w, s);
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = 4 * (u + q);
+                        s = fmaf(h1[i], w4[q].x, s); s = fmaf(h1[i + 1], w4[q].y, s); s = fmaf(h1[i + 2], w4[q].z, s); s = fmaf(h1[i + 3], w4[q].w, s);
+                    }
                 }
+                for (; u < u1; ++u) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wr + 4 * u);
+                    const int i = 4 * u;
+                    s = fmaf(h1[i], w4.x, s); s = fmaf(h1[i + 1], w4.y, s); s = fmaf(h1[i + 2], w4.z, s); s = fmaf(h1[i + 3], w4.w, s);
+                }
+            } else {
+                for (int i = u0; i < u1; ++i) s = fmaf(h1[i], wr[i], s);
             }
-            for (; i < hid; i += 4) {
-                const float4 w4 = *reinterpret_cast<const float4*>(wr + i);
-                s = fmaf(h1[i], w4.x, s); s = fmaf(h1[i + 1], w4.y, s); s = fmaf(h1[i + 2], w4.z, s); s = fmaf(h1[i + 3], w4.w, s);
-            }
-        } else {
-            for (int i = 0; i < hid; ++i) s = fmaf(h1[i], wr[i], s);
+            zpart[seg * C + c] = s;
         }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += BD) {
+        float s = zpart[c];
+        for (int g = 1; g < G; ++g) s += zpart[g * C + c];
         z[c] = s + b2[c];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c = threadIdx.x; c < C; c += BD) {
         const int ch = c % Ch;
         float m = -INFINITY;
         for (int hh = 0; hh < heads; ++hh) m = fmaxf(m, z[hh * Ch + ch]);
@@ -723,6 +739,19 @@ __global__ __launch_bounds__(256) void da_fwd_kernel(const float* __restrict__ l
         for (int hh = 0; hh < heads; ++hh) s += expf(z[hh * Ch + ch] - m);
         a[(long)b * C + c] = expf(z[c] - m) / s;
     }
+}
+__global__ __launch_bounds__(1024) void da_fwd_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                      const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ a,
+                                                      int D, int hid, int C, int heads) {
+    extern __shared__ float sm[];
+    da_fwd_body(sm, label, W1, b1, W2, b2, a, D, hid, C, heads);
+}
+// every adapter of a network for one label batch in ONE launch (grid = B x adapters): the adapters depend on the labels and their own weights only, so the model computes
+// them at the top of its forward instead of one 13 us launch inside each of its 16 blocks (mdvit_da_fwd_many; MdvitBlockDesc.a_pre)
+__global__ __launch_bounds__(1024) void da_fwd_many_kernel(MdvitDaMany m, const float* __restrict__ label, int D) {
+    extern __shared__ float sm[];
+    const int i = blockIdx.y;
+    da_fwd_body(sm, label, m.W1[i], m.b1[i], m.W2[i], m.b2[i], m.a[i], D, m.hid[i], m.C[i], m.heads[i]);
 }
 
 // backward from e = a * dL/da:  dz[c] = e[c] - a[c] * sum_{heads} e[., ch]   (softmax over heads)
@@ -1051,7 +1080,24 @@ extern "C" int mdvit_factoratt_wgrad(const float* qkv, void* ws, size_t ws_bytes
 extern "C" int mdvit_da_fwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, float* a,
                             int32_t B, int32_t D, int32_t hid, int32_t C, int32_t heads, void* stream) {
     MDVIT_CHECK_ARG(B > 0 && D > 0 && hid > 0 && C > 0 && heads > 0 && C % heads == 0, MDVIT_E_SHAPE, "da_fwd: bad shape");
-    hipLaunchKernelGGL(da_fwd_kernel, dim3(B), dim3(256), sizeof(float) * (hid + C), (hipStream_t)stream, label, W1, b1, W2, b2, a, D, hid, C, heads);
+    const int G = max(1, min(1024 / C, hid));            // (an upper bound of the kernel's G: it walks quads when it can)
+    hipLaunchKernelGGL(da_fwd_kernel, dim3(B), dim3(1024), sizeof(float) * (hid + C + (size_t)(G + 1) * C), (hipStream_t)stream, label, W1, b1, W2, b2, a, D, hid, C, heads);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
+}
+
+extern "C" int mdvit_da_fwd_many(const MdvitDaMany* m, const float* label, int32_t B, int32_t D, void* stream) {
+    MDVIT_CHECK_ARG(m && label && B > 0 && D > 0 && m->n > 0 && m->n <= MDVIT_DA_MANY_MAX, MDVIT_E_SHAPE, "da_fwd_many: bad arguments");
+    size_t smem = 0;
+    for (int i = 0; i < m->n; ++i) {
+        const int C = m->C[i], hid = m->hid[i];
+        MDVIT_CHECK_ARG(m->W1[i] && m->b1[i] && m->W2[i] && m->b2[i] && m->a[i] && hid > 0 && C > 0 && m->heads[i] > 0 && C % m->heads[i] == 0, MDVIT_E_SHAPE,
+                        "da_fwd_many: bad adapter %d", i);
+        const int G = max(1, min(1024 / C, hid));
+        smem = std::max(smem, sizeof(float) * (hid + C + (size_t)(G + 1) * C));
+    }
+    MDVIT_CHECK_ARG(smem <= 64 * 1024, MDVIT_E_SHAPE, "da_fwd_many: an adapter needs %zu bytes of LDS", smem);
+    hipLaunchKernelGGL(da_fwd_many_kernel, dim3(B, m->n), dim3(1024), smem, (hipStream_t)stream, *m, label, D);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }

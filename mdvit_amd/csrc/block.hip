@@ -48,6 +48,7 @@ void layout_saved(const MdvitBlockDesc& d, Arena& A, Saved& s) {
     s.x1 = A.take(T * C); s.mean1 = A.take(T); s.rstd1 = A.take(T); s.cur1 = A.take(T * C);
     s.qkv = A.take(T * 3 * C);
     s.a = d.label ? A.take((long)d.B * C) : nullptr;
+    if (d.label && d.a_pre) s.a = const_cast<float*>(d.a_pre);          // computed ahead for every adapter of the network (mdvit_da_fwd_many): the slot above stays unused
     s.att = A.take(T * C); s.U = A.take(T * C);
     s.kmax = A.take((long)d.B * C); s.ksum = A.take((long)d.B * C); s.Mmat = A.take((long)d.B * C * Ch);
     s.x2 = A.take(T * C); s.mean2 = A.take(T); s.rstd2 = A.take(T); s.cur2 = A.take(T * C);
@@ -180,7 +181,7 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
         if (rc != MDVIT_OK) return rc;
     }
     // a = softmax_heads(MLP(one_hot));  att = a * (scale * q (softmax_tokens(k)^T v) + q * crpe(v))      (mdvit.py:293-304)
-    if (d.label) BLK_RUN(mdvit_da_fwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, B, d.D, d.da_hidden, C, d.heads, s));
+    if (d.label && !d.a_pre) BLK_RUN(mdvit_da_fwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, B, d.D, d.da_hidden, C, d.heads, s));
     {
         const size_t fab = mdvit_factoratt_ws_bytes(B, N_tok, C, d.heads);
         void* faws = A.take_bytes(fab);

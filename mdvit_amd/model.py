@@ -81,7 +81,15 @@ class _EncoderDecoder(nn.Module):
         blocks = [blk for st in list(self.mhsa_stages) + list(self.mhsa_list) for blk in st.mhca_blks]
         keep = 1.0 - blocks[0].drop_path_p
         uniform = all(blk.drop_path_p == blocks[0].drop_path_p for blk in blocks)
-        with ops.bn_groups(groups), droppath_pool(len(blocks), x.shape[0], keep, x.device, enabled=self.training and uniform):
+        # every block's domain adapter (mdvit.py:272-276,301-303: a function of the labels and its own weights) in ONE launch at the top of the forward
+        adapters = []
+        if domain_label is not None:
+            for blk in blocks:
+                att = blk.factoratt_crpe
+                if hasattr(att, "domain_layer"):
+                    d0, d2 = att.domain_layer[0], att.domain_layer[2]
+                    adapters.append((d0.weight, d0.bias, d2.weight, d2.bias, att.num_heads))
+        with ops.bn_groups(groups), droppath_pool(len(blocks), x.shape[0], keep, x.device, enabled=self.training and uniform), ops.da_precomputed(domain_label, adapters):
             return self._trunk_impl(x, domain_label, groups if split_for_heads else 1)
 
     def _trunk_impl(self, x, domain_label, head_groups: int = 1):

@@ -2372,6 +2372,58 @@ def rowdot(x, w, b=None):
 # ------------------------------------------------------------------------------------------------
 # Domain adapter + factorized attention core
 # ------------------------------------------------------------------------------------------------
+_da_pre = None          # inside da_precomputed(): {W2.data_ptr(): a [B, C]} for the label batch of the forward in progress
+_da_many = os.environ.get("MDVIT_DA_MANY", "1") != "0"      # 0: every block launches its own adapter kernel (A/B)
+
+
+class da_precomputed:
+    """Every domain adapter of a network for ONE label batch in one launch (mdvit_da_fwd_many) at the top of the forward: an adapter's output depends on the labels
+    and its own four tensors only.  Inside the context the attention nodes (_FactorAtt, the C-level block through MdvitBlockDesc.a_pre) pick their `a` up by the
+    adapter's second weight instead of launching mdvit_da_fwd (16 launches of ~13 us on the single-stream forward of an MDViT); each node keeps its tensor for
+    the backward.  adapters: [(W1, b1, W2, b2, heads)].  Same arithmetic as the per-block launch, bit for bit."""
+
+    def __init__(self, label, adapters):
+        self.label, self.adapters = label, adapters
+
+    def __enter__(self):
+        global _da_pre
+        self.prev = _da_pre
+        ad = self.adapters
+        if not (_da_many and self.label is not None and ad and len(ad) <= _lib.DA_MANY_MAX and self.label.is_cuda):
+            return self
+        label = _c(self.label.float())
+        B, D = label.shape
+        m = _lib.DaMany()
+        m.n = len(ad)
+        sizes = [W2.shape[0] for (_, _, W2, _, _) in ad]
+        flat = _empty((B * sum(sizes),), device=label.device, dtype=torch.float32)
+        table, off = {}, 0
+        for i, (W1, b1, W2, b2, heads) in enumerate(ad):
+            if not all(t.is_contiguous() and t.dtype == torch.float32 for t in (W1, b1, W2, b2)):
+                return self
+            a = flat[off:off + B * sizes[i]].view(B, sizes[i])
+            off += B * sizes[i]
+            m.hid[i], m.C[i], m.heads[i] = W1.shape[0], sizes[i], int(heads)
+            m.W1[i], m.b1[i], m.W2[i], m.b2[i], m.a[i] = _p(W1), _p(b1), _p(W2), _p(b2), _p(a)
+            table[W2.data_ptr()] = a
+        call("mdvit_da_fwd_many", C.byref(m), _p(label), B, D, _stream())
+        self.label_c = label          # (kept alive with the table)
+        _da_pre = table
+        return self
+
+    def __exit__(self, *exc):
+        global _da_pre
+        _da_pre = self.prev
+        return False
+
+
+def _da_lookup(W2, B):
+    if _da_pre is None or W2 is None:
+        return None
+    a = _da_pre.get(W2.data_ptr())
+    return a if (a is not None and a.shape[0] == B) else None
+
+
 class _FactorAtt(torch.autograd.Function):
     """Attention core + Domain Adapter as ONE node: the adapter's backward consumes e = a * dL/da straight
     from the attention backward (no division by a).  label is None -> no adapter (BASE / mpvit flavour)."""
@@ -2387,8 +2439,10 @@ class _FactorAtt(torch.autograd.Function):
         dev = qkv.device
         a = None
         if label is not None:
-            a = _empty((B, Cn), device=dev, dtype=torch.float32)
-            call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, label.shape[1], W1.shape[0], Cn, heads, _stream())
+            a = _da_lookup(W2, B)
+            if a is None:
+                a = _empty((B, Cn), device=dev, dtype=torch.float32)
+                call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, label.shape[1], W1.shape[0], Cn, heads, _stream())
         out = _empty((B, N, Cn), device=dev, dtype=torch.float32)
         U = _empty_like(out)
         kmax = _empty((B, Cn), device=dev, dtype=torch.float32)
@@ -2574,10 +2628,11 @@ def _side_protect(*tensors, foreign=None):
 _store_bf16 = os.environ.get("MDVIT_STORE_BF16", "1") != "0"      # 0: fp32 storage in the bf16 mode too (A/B)
 
 
-def _block_desc(x, label, rs1, rs2, meta, keys, params, backward):
+def _block_desc(x, label, rs1, rs2, meta, keys, params, backward, a_pre=None):
     H, W_, heads, splits, eps, drop_p, ln_groups = meta[:7]
     B, N, Cn = x.shape
     d = _lib.BlockDesc()
+    d.a_pre = _p(a_pre)
     d.B, d.H, d.W, d.C, d.heads, d.hidden = B, H, W_, Cn, heads, params[20].shape[0]
     d.s3, d.s5, d.s7 = splits
     d.ln_groups = ln_groups
@@ -2642,7 +2697,8 @@ class _SerialBlock(torch.autograd.Function):
         _chk(x, label, rs1, rs2, *params)
         drop_p = meta[5]
         keys = tuple(_next_key() if drop_p > 0 else (0, 0) for _ in range(3))          # proj, fc1, fc2: the order of the operator-level path
-        d, keep = _block_desc(x, label, rs1, rs2, meta, keys, params, False)
+        a_pre = _da_lookup(params[14], x.shape[0]) if label is not None else None          # params[14] = da_w2
+        d, keep = _block_desc(x, label, rs1, rs2, meta, keys, params, False, a_pre)
         lib = _lib.load()
         sb, wb = lib.mdvit_block_save_bytes(C.byref(d)), lib.mdvit_block_fwd_ws_bytes(C.byref(d))
         if not sb:
@@ -2653,7 +2709,7 @@ class _SerialBlock(torch.autograd.Function):
         call("mdvit_block_fwd", C.byref(d), _p(x), _p(y), _p(save), sb, _p(ws), wb, _stream())
         del keep
         ctx.save_for_backward(x, save, label, rs1, rs2, *params)
-        ctx.meta, ctx.keys = meta, keys
+        ctx.meta, ctx.keys, ctx.a_pre = meta, keys, a_pre
         return y
 
     @staticmethod
@@ -2666,7 +2722,7 @@ class _SerialBlock(torch.autograd.Function):
         aux_first = meta[7]
         g = _c(g)
         dev = x.device
-        d, keep = _block_desc(x, label, rs1, rs2, meta, ctx.keys, params, True)
+        d, keep = _block_desc(x, label, rs1, rs2, meta, ctx.keys, params, True, ctx.a_pre)
         G = _lib.BlockGrads()
         G.dgrad_only, G.aux_first = int(_dgrad_only), int(aux_first)
         want_w = not _dgrad_only

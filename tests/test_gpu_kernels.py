@@ -2,6 +2,7 @@
 torch CPU reference of the same op on the same seeded inputs.  fp32 tolerance: 1e-4 relative to the
 tensor's max magnitude unless stated (north_star bar: 1e-3 rel)."""
 import math
+import contextlib
 import os
 
 import numpy as np
@@ -788,6 +789,42 @@ def test_stem_conv(B, H, W):
     out.backward(nhwc(g).to(dev()))
     check(nchw(out), ref, name="y")
     check(wh.grad, wr.grad, name="dw")
+
+
+def test_every_adapter_of_a_network_in_one_launch_equals_the_per_block_launches():
+    """mdvit_da_fwd_many (ops.da_precomputed: the model computes every block's domain adapter at the top of its forward) against mdvit_da_fwd per adapter, bit for
+    bit; and an attention node inside the context picks its adapter output up instead of launching (same result, gradients included)."""
+    from mdvit_amd import ops
+    B, D = 6, 4
+    label = F.one_hot(torch.arange(B) % D, D).float().to(dev())
+    ads = []
+    for i, (Cn, heads) in enumerate(((64, 8), (128, 8), (320, 8), (512, 8), (64, 8))):
+        hid = max(Cn // 2, 4)
+        ads.append((rnd(hid, D, seed=500 + i).to(dev()), rnd(hid, seed=510 + i).to(dev()), rnd(Cn, hid, seed=520 + i, scale=hid ** -0.5).to(dev()), rnd(Cn, seed=530 + i).to(dev()), heads))
+    ref = [ops.domain_adapter(label, W1, b1, W2, b2, h) for (W1, b1, W2, b2, h) in ads]
+    with ops.da_precomputed(label, ads):
+        for (W1, b1, W2, b2, h), r in zip(ads, ref):
+            got = ops._da_lookup(W2, B)
+            assert got is not None and torch.equal(got, r)
+        assert ops._da_lookup(ads[0][2], B + 1) is None
+    assert ops._da_pre is None
+    # through the attention node: with and without the context
+    Cn, heads, H, W_ = 64, 8, 8, 8
+    W1, b1, W2, b2, _ = ads[0]
+    qkv = rnd(B, H * W_, 3 * Cn, seed=540).to(dev())
+    crpe = [rnd(*sh, seed=550 + i, scale=0.2).to(dev()) for i, sh in enumerate(((16, 1, 3, 3), (16,), (24, 1, 5, 5), (24,), (24, 1, 7, 7), (24,)))]
+    g = rnd(B, H * W_, Cn, seed=560).to(dev())
+    outs = []
+    for pre in (False, True):
+        ins = [t.clone().requires_grad_(True) for t in (qkv, W1, b1, W2, b2)]
+        ctx = ops.da_precomputed(label, [(ins[1], ins[2], ins[3], ins[4], heads)]) if pre else contextlib.nullcontext()
+        with ctx:
+            y = ops.factor_att(ins[0], crpe, H, W_, heads, (2, 3, 3), label, (ins[1], ins[2], ins[3], ins[4]))
+        y.backward(g)
+        outs.append([y.detach()] + [t.grad for t in ins])
+    assert torch.equal(outs[0][0], outs[1][0])                      # the forward: bit for bit
+    for a_, b_ in zip(outs[0][1:], outs[1][1:]):                    # (the adapter's e sums float adds in LDS: run-to-run order, last-bit differences in either mode)
+        assert float((a_ - b_).abs().max()) <= 1e-5 * float(b_.abs().max())
 
 
 def test_conv_weight_layouts_of_many_weights_in_one_launch():
