@@ -221,6 +221,23 @@ __global__ __launch_bounds__(256) void gconv2_dgrad_kernel(const float* __restri
     }
 }
 
+// The same two passes on LDS tiles (round 5; C % 32 == 0): w [C][2][3][3] IS a depthwise filter bank over the 2 C concat channels, so the forward is conv_tile.h's
+// 8 x 16 x 32 tile pass over each source + the sum of channel pairs, the data gradient the flipped-tap pass with one dy channel feeding its group's two concat channels.
+// The element-per-thread kernels above issue nine loads under nine branches per output: 85 / 73 us per launch at the four decoder stages of a bs=4 step, 14 % of their
+// bytes' HBM time, on the forward's single stream and on both backward sweeps.  blockIdx.y = 32-channel block of the CONCAT axis.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void gconv2_tile_kernel(const float* __restrict__ a0, const float* __restrict__ a1, const float* __restrict__ w,
+                                                          float* __restrict__ o0, float* __restrict__ o1, int H, int W, int C, int tiles_w) {
+    __shared__ __attribute__((aligned(16))) float sx[(CT_TH + 2) * (CT_TW + 2) * CT_CL];
+    __shared__ float sw[CT_CL * 9];
+    const int cb = blockIdx.y, half = C / CT_CL;
+    const bool first = cb < half;
+    const int lb = first ? cb : cb - half;                     // block inside its source
+    const float* wh = w + (first ? 0L : (long)C * 9);
+    if (!DGRAD) conv_tile_body<3, false, 1, true>(sx, sw, lb, first ? a0 : a1, (long)C, 0, wh, nullptr, o0, (long)C, first ? 0 : C / 2, H, W, C, tiles_w, 0);
+    else conv_tile_body<3, true, 2, false>(sx, sw, lb, a0 + (first ? 0 : C / 2), (long)C, 0, wh, nullptr, first ? o0 : o1, (long)C, 0, H, W, C, tiles_w, 0);
+}
+
 // wgrad: dw[g,j,kh,kw] = sum dy[b,ho,wo,g] * cat[b,ho+kh-1,wo+kw-1,2g+j]
 __global__ __launch_bounds__(256) void gconv2_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ skip,
                                                            const float* __restrict__ up, float* __restrict__ part,
@@ -902,7 +919,12 @@ extern "C" int mdvit_dwconv3x3_bwd(const float* dy, const float* x, const float*
 extern "C" int mdvit_gconv2_3x3_fwd(const float* skip, const float* up, const float* w, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 2048, MDVIT_E_SHAPE, "gconv2_fwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     const long total = (long)B * H * W * C / 2;
-    hipLaunchKernelGGL(gconv2_fwd_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, (hipStream_t)stream, skip, up, w, y, B, H, W, C);
+    static const bool tiled = [] { const char* e = getenv("MDVIT_GCONV2_TILES"); return !(e && e[0] == '0'); }();          // 0: the element-per-thread kernels (A/B)
+    const int tiles_w = cdiv(W, CT_TW), tiles = tiles_w * cdiv(H, CT_TH);
+    if (tiled && C % 32 == 0 && aligned16(skip) && aligned16(up) && B <= 65535)
+        hipLaunchKernelGGL((gconv2_tile_kernel<false>), dim3(tiles, 2 * C / CT_CL, B), dim3(256), 0, (hipStream_t)stream, skip, up, w, y, (float*)nullptr, H, W, C, tiles_w);
+    else
+        hipLaunchKernelGGL(gconv2_fwd_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, (hipStream_t)stream, skip, up, w, y, B, H, W, C);
     MDVIT_LAUNCH_CHECK();
     return MDVIT_OK;
 }
@@ -913,7 +935,11 @@ extern "C" int mdvit_gconv2_3x3_bwd(const float* dy, const float* skip, const fl
     MDVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024, MDVIT_E_SHAPE, "gconv2_bwd: bad shape B=%d H=%d W=%d C=%d", B, H, W, C);
     const long total = (long)B * H * W * C / 2;
     MDVIT_CHECK_ARG((dskip == nullptr) == (dup == nullptr), MDVIT_E_SHAPE, "gconv2_bwd: dskip and dup go together");
-    if (dskip) hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
+    static const bool tiled = [] { const char* e = getenv("MDVIT_GCONV2_TILES"); return !(e && e[0] == '0'); }();
+    const int tiles_w = cdiv(W, CT_TW), tiles = tiles_w * cdiv(H, CT_TH);
+    if (dskip && tiled && C % 64 == 0 && aligned16(dy) && B <= 65535)          // (C % 64: a 32-channel concat block reads 16 dy channels = whole float4 quads of one source half)
+        hipLaunchKernelGGL((gconv2_tile_kernel<true>), dim3(tiles, 2 * C / CT_CL, B), dim3(256), 0, s, dy, (const float*)nullptr, w, dskip, dup, H, W, C, tiles_w);
+    else if (dskip) hipLaunchKernelGGL(gconv2_dgrad_kernel, dim3(ew_grid(total)), dim3(256), sizeof(float) * 18 * C, s, dy, w, dskip, dup, B, H, W, C);
     if (dw) {
         // dw[g][j][tap] = sum dy[.., g] cat[.. + tap, 2g + j]: per concat half a depthwise-style weight gradient on the LDS tiles of
         // conv_tile.h (input read once instead of nine times), the gradient channel of input channel c being c / 2

@@ -54,7 +54,10 @@ __device__ __forceinline__ void ct_stage_window(float* __restrict__ sx, const fl
 }
 
 // body of one (tile, 32-channel block, image) workgroup; sx / sw: LDS of at least (8+2R)(16+2R)*32 and 32*WIN*WIN floats
-template <int WIN, bool FLIP>
+// GD = 2: output channel c reads INPUT channel c / 2 (the data gradient of the grouped decoder convolution: one dy channel feeds the two concat channels of its group);
+// PAIR: the outputs of channels 2 g, 2 g + 1 are added and stored as channel g (its forward: a depthwise pass over the concat channels + the group sum).  Both need
+// ncls % 32 == 0.
+template <int WIN, bool FLIP, int GD = 1, bool PAIR = false>
 __device__ __forceinline__ void conv_tile_body(float* __restrict__ sx, float* __restrict__ sw, int cblock,
                                                const float* __restrict__ x, long ldx, int xoff,
                                                const float* __restrict__ w, const float* __restrict__ bias,
@@ -68,7 +71,7 @@ __device__ __forceinline__ void conv_tile_body(float* __restrict__ sx, float* __
     // the window AND the 32 x WIN^2 weights are requested before anything is stored to LDS: one exposed load latency per workgroup
     // (a load -> LDS-store loop over the weights paid it up to seven more times)
     CtWindow<LH, LW> win;
-    win.load(x + xoff + c0, ldx, img, th0 - R, tw0 - R, H, W, ncls - c0);
+    win.load(x + xoff + c0 / GD, ldx, img, th0 - R, tw0 - R, H, W, (ncls - c0) / GD);
     constexpr int NWQ = (CT_CL * WIN * WIN + 255) / 256;
     float wq[NWQ];
 #pragma unroll
@@ -95,7 +98,7 @@ __device__ __forceinline__ void conv_tile_body(float* __restrict__ sx, float* __
     for (int i = 0; i < WIN; ++i) {
         float row[LW], wr[WIN];
 #pragma unroll
-        for (int t = 0; t < LW; ++t) row[t] = sx[((rl + i) * LW + t) * CT_CL + cl];
+        for (int t = 0; t < LW; ++t) row[t] = sx[((rl + i) * LW + t) * CT_CL + cl / GD];
         if (i == R && add_center) {          // y = x + conv(x)  (ConvPosEnc) / dx = g + conv^T(g)
 #pragma unroll
             for (int t = 0; t < CT_TW; ++t) acc[t] += row[t + R];
@@ -106,6 +109,14 @@ __device__ __forceinline__ void conv_tile_body(float* __restrict__ sx, float* __
         for (int t = 0; t < CT_TW; ++t)
 #pragma unroll
             for (int j = 0; j < WIN; ++j) acc[t] = fmaf(wr[j], row[t + j], acc[t]);
+    }
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int t = 0; t < CT_TW; ++t) {
+            const float s2 = acc[t] + __shfl_xor(acc[t], 1);
+            if (!(cl & 1) && tw0 + t < W) y[(img + (long)h * W + tw0 + t) * ldy + yoff + (c0 + cl) / 2] = s2;
+        }
+        return;
     }
 #pragma unroll
     for (int t = 0; t < CT_TW; ++t)
