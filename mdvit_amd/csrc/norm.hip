@@ -289,15 +289,16 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mu[j] = p.mean[grp * p.C + c + j]; rs[j] = p.rstd[grp * p.C + c + j]; ga[j] = p.gamma[grp * p.affine_stride + c + j]; be[j] = p.beta[grp * p.affine_stride + c + j]; }
     }
-    for (long e = t0; e < total; e += T) {
-        const long row = row0 + e / QC;
-        const float4 av = *reinterpret_cast<const float4*>(p.a + row * p.lda + c);
+    // rows t0 / QC, + T / QC, ... in increasing order (grid * 256 is a multiple of QC: chan_grid), FOUR rows' loads in flight per trip: one row per trip with a 64-bit
+    // division in front of its load was a chain of dependent round trips (the 1 M-row reductions of the peer heads: 64 trips per thread, 75 us for 140 MB)
+    (void)total;
+    const long rstep = T / QC;
+    auto one_row = [&](long row, const float4 av, const float4 yv) __attribute__((always_inline)) {
         const float a4[4] = {av.x, av.y, av.z, av.w};
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s1[j] += a4[j]; s2[j] += a4[j] * a4[j]; }
         } else if (MODE == 1) {
-            const float4 yv = *reinterpret_cast<const float4*>(p.b + row * p.C + c);
             const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
             float ds[4] = {1.f, 1.f, 1.f, 1.f};
             if (p.drop_p > 0.f) {
@@ -311,9 +312,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
                 s1[j] += g; s2[j] += g * xh;
             }
         } else {
-            float r = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
+            const float rsc_ = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
             float v4[4];
-            float ds[4] = {r, r, r, r};
+            float ds[4] = {rsc_, rsc_, rsc_, rsc_};
             if (p.drop_p > 0.f) {
                 const float4 d4 = mdvit_drop_scale4(k0e, k1e, (uint32_t)(row * p.C + c), p.thresh, p.inv_keep);
                 ds[0] *= d4.x; ds[1] *= d4.y; ds[2] *= d4.z; ds[3] *= d4.w;
@@ -325,6 +326,24 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(ChanArgs p) {
             }
             if (p.masked) *reinterpret_cast<float4*>(p.masked + row * p.C + c) = make_float4(v4[0], v4[1], v4[2], v4[3]);
         }
+    };
+    long r = t0 / QC;
+    for (; r + 3 * rstep < p.M; r += 4 * rstep) {
+        float4 av[4], yv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long row = row0 + r + k * rstep;
+            av[k] = *reinterpret_cast<const float4*>(p.a + row * p.lda + c);
+            yv[k] = MODE == 1 ? *reinterpret_cast<const float4*>(p.b + row * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) one_row(row0 + r + k * rstep, av[k], yv[k]);
+    }
+    for (; r < p.M; r += rstep) {
+        const long row = row0 + r;
+        const float4 av = *reinterpret_cast<const float4*>(p.a + row * p.lda + c);
+        const float4 yv = MODE == 1 ? *reinterpret_cast<const float4*>(p.b + row * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        one_row(row, av, yv);
     }
     if (MODE == 2) {
         if (!p.out) return;                   // masked copy only
@@ -645,10 +664,9 @@ __global__ __launch_bounds__(256) void bn_rowdot_reduce_kernel(ChanArgs p, const
 #pragma unroll
     for (int j = 0; j < 4; ++j) { mu[j] = p.mean[c + j]; rs[j] = p.rstd[c + j]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; wv[j] = w[c + j]; }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, s3[4] = {0.f, 0.f, 0.f, 0.f}, s4 = 0.f;
-    for (long e = t0; e < total; e += T) {
-        const long row = e / QC;
-        const float gr = g[row];
-        const float4 yv = *reinterpret_cast<const float4*>(p.a + row * p.C + c);
+    (void)total;
+    const long rstep = T / QC;                // (grid * 256 is a multiple of QC: chan_grid) -- rows in increasing order, four rows' loads in flight, as chan_reduce_kernel
+    auto one_row = [&](long row, const float gr, const float4 yv) __attribute__((always_inline)) {
         const float y4[4] = {yv.x, yv.y, yv.z, yv.w};
         float ds[4] = {1.f, 1.f, 1.f, 1.f};
         if (p.drop_p > 0.f) {
@@ -663,7 +681,16 @@ __global__ __launch_bounds__(256) void bn_rowdot_reduce_kernel(ChanArgs p, const
             s1[j] += G; s2[j] += G * xh;
             if (want_w) s3[j] += gr * (act_fwd(p.act, pre) * ds[j]);
         }
+    };
+    long r = t0 / QC;
+    for (; r + 3 * rstep < p.M; r += 4 * rstep) {
+        float gr[4]; float4 yv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { gr[k] = g[r + k * rstep]; yv[k] = *reinterpret_cast<const float4*>(p.a + (r + k * rstep) * p.C + c); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) one_row(r + k * rstep, gr[k], yv[k]);
     }
+    for (; r < p.M; r += rstep) one_row(r, g[r], *reinterpret_cast<const float4*>(p.a + r * p.C + c));
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s_part[threadIdx.x * 13 + j] = s1[j]; s_part[threadIdx.x * 13 + 4 + j] = s2[j]; s_part[threadIdx.x * 13 + 8 + j] = s3[j]; }
     s_part[threadIdx.x * 13 + 12] = s4;
