@@ -385,6 +385,8 @@ typedef struct MdvitBlockGrads {
     int32_t accumulate, dgrad_only, aux_first;
     int32_t ln_accumulate;      /* != 0 (needs accumulate != 0 and a side stream): n1_g / n1_b / n2_g / n2_b and fc2_b are gradient buckets too -- their
                                    second-stage reductions ADD into them, on the side stream */
+    float* e_out;               /* optional (round 5): [B, C]; the block writes e = a * dL/da of its adapter HERE and launches no adapter backward (da_w1 .. da_b2 are
+                                   not touched) -- the caller forms every adapter's gradients in one go with mdvit_da_bwd_many.  NULL: the block runs mdvit_da_bwd itself. */
 } MdvitBlockGrads;
 /* main: the stream of the data-gradient chain; side: the stream of the weight-gradient kernels (NULL or == main: everything on main).
  * events: n_events HIP events owned by the caller (mdvit_event_create) for the main -> side ordering, used round robin from *next_event. */
@@ -536,6 +538,16 @@ typedef struct MdvitDaMany {
     float* a[MDVIT_DA_MANY_MAX];
 } MdvitDaMany;
 int mdvit_da_fwd_many(const MdvitDaMany* m, const float* label, int32_t B, int32_t D, void* stream);
+/* The backward of all of them in two launches per sweep: e[i] [B, C[i]] = a * dL/da as the attention backward of adapter i's block hands it out
+ * (MdvitBlockGrads.e_out; mdvit_factoratt_bwd's e), m->a[i] the forward's outputs; the four gradients of every adapter with e[i] != NULL are OVERWRITTEN with
+ * scale * (the gradient) -- scale = -1 in the data-gradient-only sweep, as mdvit_da_bwd.  e[i] == NULL: adapter i is skipped.  ws: mdvit_da_many_ws_bytes(m, B).
+ * Same arithmetic as mdvit_da_bwd per adapter, bit for bit. */
+typedef struct MdvitDaManyGrads {
+    const float* e[MDVIT_DA_MANY_MAX];
+    float* dW1[MDVIT_DA_MANY_MAX]; float* db1[MDVIT_DA_MANY_MAX]; float* dW2[MDVIT_DA_MANY_MAX]; float* db2[MDVIT_DA_MANY_MAX];
+} MdvitDaManyGrads;
+size_t mdvit_da_many_ws_bytes(const MdvitDaMany* m, int32_t B);
+int mdvit_da_bwd_many(const MdvitDaMany* m, const MdvitDaManyGrads* g, const float* label, float scale, void* ws, size_t ws_bytes, int32_t B, int32_t D, void* stream);
 size_t mdvit_da_ws_bytes(int32_t B, int32_t hid, int32_t C);
 int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,
                  const float* e, float scale, float* dW1, float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes,

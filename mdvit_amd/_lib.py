@@ -93,8 +93,12 @@ class DaMany(C.Structure):
                 ("W2", vp * DA_MANY_MAX), ("b2", vp * DA_MANY_MAX), ("a", vp * DA_MANY_MAX)]
 
 
+class DaManyGrads(C.Structure):
+    _fields_ = [("e", vp * DA_MANY_MAX), ("dW1", vp * DA_MANY_MAX), ("db1", vp * DA_MANY_MAX), ("dW2", vp * DA_MANY_MAX), ("db2", vp * DA_MANY_MAX)]
+
+
 class BlockGrads(C.Structure):
-    _fields_ = [(n, vp) for n in BLOCK_PARAMS] + [("accumulate", i32), ("dgrad_only", i32), ("aux_first", i32), ("ln_accumulate", i32)]
+    _fields_ = [(n, vp) for n in BLOCK_PARAMS] + [("accumulate", i32), ("dgrad_only", i32), ("aux_first", i32), ("ln_accumulate", i32), ("e_out", vp)]
 
 
 class BlockStreams(C.Structure):
@@ -110,6 +114,7 @@ _SIGS = {
     "mdvit_gemm_ph_config": [i32],
     "mdvit_gemm_pm_config": [i32],
     "mdvit_da_fwd_many": [C.POINTER(DaMany), vp, i32, i32, vp],
+    "mdvit_da_bwd_many": [C.POINTER(DaMany), C.POINTER(DaManyGrads), vp, f32, vp, C.c_size_t, i32, i32, vp],
     "mdvit_gemm_pm_prefers": [i32, i32, i32, i32, i32],
     "mdvit_gemm_f32_grouped": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
     "mdvit_gemm_f32_grouped_bias": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
@@ -286,6 +291,8 @@ def load():
     lib.mdvit_block_bwd_ws_bytes.argtypes = [C.POINTER(BlockDesc), C.POINTER(BlockGrads), i32, C.POINTER(C.c_size_t)]
     lib.mdvit_da_ws_bytes.restype = C.c_size_t
     lib.mdvit_da_ws_bytes.argtypes = [i32, i32, i32]
+    lib.mdvit_da_many_ws_bytes.restype = C.c_size_t
+    lib.mdvit_da_many_ws_bytes.argtypes = [C.POINTER(DaMany), i32]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int

@@ -756,12 +756,11 @@ __global__ __launch_bounds__(1024) void da_fwd_many_kernel(MdvitDaMany m, const 
 
 // backward from e = a * dL/da:  dz[c] = e[c] - a[c] * sum_{heads} e[., ch]   (softmax over heads)
 // stage 1 (grid = B): dz -> dzbuf [B,C], relu(h1) -> hbuf [B,hid], dh -> dhbuf [B,hid]
-__global__ __launch_bounds__(1024) void da_bwd_stage1_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
-                                                            const float* __restrict__ W2, const float* __restrict__ a, const float* __restrict__ e,
-                                                            float* __restrict__ dzbuf, float* __restrict__ hbuf, float* __restrict__ dhbuf,
-                                                            int D, int hid, int C, int heads, float scale) {
-    extern __shared__ float sm[];   // dz[C]
-    float* dz = sm;
+__device__ __forceinline__ void da_bwd_stage1_body(float* sm, const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                   const float* __restrict__ W2, const float* __restrict__ a, const float* __restrict__ e,
+                                                   float* __restrict__ dzbuf, float* __restrict__ hbuf, float* __restrict__ dhbuf,
+                                                   int D, int hid, int C, int heads, float scale) {
+    float* dz = sm;                 // dz[C]
     const int b = blockIdx.x, Ch = C / heads;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int ch = c % Ch;
@@ -798,11 +797,18 @@ __global__ __launch_bounds__(1024) void da_bwd_stage1_kernel(const float* __rest
         dhbuf[(long)b * hid + i] = h > 0.f ? t : 0.f;
     }
 }
+__global__ __launch_bounds__(1024) void da_bwd_stage1_kernel(const float* __restrict__ label, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                            const float* __restrict__ W2, const float* __restrict__ a, const float* __restrict__ e,
+                                                            float* __restrict__ dzbuf, float* __restrict__ hbuf, float* __restrict__ dhbuf,
+                                                            int D, int hid, int C, int heads, float scale) {
+    extern __shared__ float sm[];
+    da_bwd_stage1_body(sm, label, W1, b1, W2, a, e, dzbuf, hbuf, dhbuf, D, hid, C, heads, scale);
+}
 // stage 2: one thread per weight element, loop over the batch (no atomics, deterministic)
-__global__ __launch_bounds__(256) void da_bwd_stage2_kernel(const float* __restrict__ label, const float* __restrict__ dzbuf,
-                                                            const float* __restrict__ hbuf, const float* __restrict__ dhbuf,
-                                                            float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
-                                                            int B, int D, int hid, int C) {
+__device__ __forceinline__ void da_bwd_stage2_body(const float* __restrict__ label, const float* __restrict__ dzbuf,
+                                                   const float* __restrict__ hbuf, const float* __restrict__ dhbuf,
+                                                   float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                                   int B, int D, int hid, int C) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nW2 = (long)C * hid, nW1 = (long)hid * D;
     if (i < nW2) {
@@ -827,6 +833,39 @@ __global__ __launch_bounds__(256) void da_bwd_stage2_kernel(const float* __restr
         for (int b = 0; b < B; ++b) s += dhbuf[(long)b * hid + j];
         db1[j] = s;
     }
+}
+__global__ __launch_bounds__(256) void da_bwd_stage2_kernel(const float* __restrict__ label, const float* __restrict__ dzbuf,
+                                                            const float* __restrict__ hbuf, const float* __restrict__ dhbuf,
+                                                            float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                                            int B, int D, int hid, int C) {
+    da_bwd_stage2_body(label, dzbuf, hbuf, dhbuf, dW1, db1, dW2, db2, B, D, hid, C);
+}
+// every adapter of a network in TWO launches per backward sweep (grids B x adapters and weight-element blocks x adapters) instead of two launches of 8-12 us inside each
+// of its 16 blocks on the sweep's data-gradient chain (mdvit_da_bwd_many): the blocks hand their e = a * dL/da out (MdvitBlockGrads.e_out), the adapters'
+// parameter gradients are formed once the sweep has passed the first block.  An adapter with e[i] == NULL is skipped.  Same bodies, same bits.
+__device__ __forceinline__ long da_many_ws_offset(const MdvitDaMany& m, int i, int B) {
+    long off = 0;
+    for (int j = 0; j < i; ++j) off += (long)B * m.C[j] + 2L * B * m.hid[j];
+    return off;
+}
+__global__ __launch_bounds__(1024) void da_bwd_many_stage1_kernel(MdvitDaMany m, MdvitDaManyGrads g, const float* __restrict__ label, float* __restrict__ ws, int B, int D,
+                                                                 float scale) {
+    extern __shared__ float sm[];
+    const int i = blockIdx.y;
+    if (!g.e[i]) return;
+    float* dzbuf = ws + da_many_ws_offset(m, i, B);
+    float* hbuf = dzbuf + (long)B * m.C[i];
+    float* dhbuf = hbuf + (long)B * m.hid[i];
+    da_bwd_stage1_body(sm, label, m.W1[i], m.b1[i], m.W2[i], m.a[i], g.e[i], dzbuf, hbuf, dhbuf, D, m.hid[i], m.C[i], m.heads[i], scale);
+}
+__global__ __launch_bounds__(256) void da_bwd_many_stage2_kernel(MdvitDaMany m, MdvitDaManyGrads g, const float* __restrict__ label, const float* __restrict__ ws, int B, int D) {
+    const int i = blockIdx.y;
+    const int hid = m.hid[i], C = m.C[i];
+    if (!g.e[i] || (long)blockIdx.x * blockDim.x >= (long)C * hid + (long)hid * D + C + hid) return;
+    const float* dzbuf = ws + da_many_ws_offset(m, i, B);
+    const float* hbuf = dzbuf + (long)B * C;
+    const float* dhbuf = hbuf + (long)B * hid;
+    da_bwd_stage2_body(label, dzbuf, hbuf, dhbuf, g.dW1[i], g.db1[i], g.dW2[i], g.db2[i], B, D, hid, C);
 }
 
 bool make_geom(FaGeom& g, int B, int H, int W, int C, int heads, int s3, int s5, int s7) {
@@ -1105,6 +1144,36 @@ extern "C" int mdvit_da_fwd_many(const MdvitDaMany* m, const float* label, int32
 extern "C" size_t mdvit_da_ws_bytes(int32_t B, int32_t hid, int32_t C) {
     if (B <= 0 || hid <= 0 || C <= 0) return 0;
     return sizeof(float) * ((size_t)B * C + 2 * (size_t)B * hid);
+}
+
+extern "C" size_t mdvit_da_many_ws_bytes(const MdvitDaMany* m, int32_t B) {
+    if (!m || m->n <= 0 || m->n > MDVIT_DA_MANY_MAX || B <= 0) return 0;
+    size_t t = 0;
+    for (int i = 0; i < m->n; ++i) t += mdvit_da_ws_bytes(B, m->hid[i], m->C[i]);
+    return t;
+}
+
+extern "C" int mdvit_da_bwd_many(const MdvitDaMany* m, const MdvitDaManyGrads* g, const float* label, float scale, void* ws, size_t ws_bytes, int32_t B, int32_t D,
+                                 void* stream) {
+    MDVIT_CHECK_ARG(m && g && m->n > 0 && m->n <= MDVIT_DA_MANY_MAX && B > 0 && D > 0, MDVIT_E_SHAPE, "da_bwd_many: bad shape");
+    MDVIT_CHECK_ARG(ws_bytes >= mdvit_da_many_ws_bytes(m, B), MDVIT_E_WORKSPACE, "da_bwd_many: workspace too small");
+    size_t smem = 0;
+    long most = 0;
+    bool any = false;
+    for (int i = 0; i < m->n; ++i) {
+        MDVIT_CHECK_ARG(m->hid[i] > 0 && m->C[i] > 0 && m->heads[i] > 0 && m->C[i] % m->heads[i] == 0, MDVIT_E_SHAPE, "da_bwd_many: bad adapter shape");
+        if (!g->e[i]) continue;
+        MDVIT_CHECK_ARG(g->dW1[i] && g->db1[i] && g->dW2[i] && g->db2[i], MDVIT_E_SHAPE, "da_bwd_many: an adapter with e needs its four gradient outputs");
+        any = true;
+        smem = max(smem, sizeof(float) * (m->C[i] + (size_t)max(m->hid[i], 1024)));
+        most = max(most, (long)m->C[i] * m->hid[i] + (long)m->hid[i] * D + m->C[i] + m->hid[i]);
+    }
+    if (!any) return MDVIT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(da_bwd_many_stage1_kernel, dim3(B, m->n), dim3(1024), smem, s, *m, *g, label, (float*)ws, B, D, scale);
+    hipLaunchKernelGGL(da_bwd_many_stage2_kernel, dim3(cdiv(most, 256), m->n), dim3(256), 0, s, *m, *g, label, (const float*)ws, B, D);
+    MDVIT_LAUNCH_CHECK();
+    return MDVIT_OK;
 }
 
 extern "C" int mdvit_da_bwd(const float* label, const float* W1, const float* b1, const float* W2, const float* b2, const float* a,

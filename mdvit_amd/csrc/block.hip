@@ -397,15 +397,17 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
     // ---- attention core + adapter ---------------------------------------------------------------------------------------------------
     const size_t fab = mdvit_factoratt_ws_bytes(B, N_tok, C, d.heads);
     void* faws = S.take_bytes(fab);            // holds dU, which the deferred window-weight gradients read
-    float* e = d.label ? A.take((long)B * C) : nullptr;
+    float* e = !d.label ? nullptr : G.e_out ? G.e_out : A.take((long)B * C);      // (e_out: the caller runs every adapter's backward at once, mdvit_da_bwd_many)
     if (dgrad_only && G.aux_first && d.label) {
         // the first adapter of the network in the data-gradient-only sweep: e = sum_n g * att alone, the adapter's (negated) gradient, and
         // nothing is handed on -- nothing below carries an adapter (ops._FactorAtt, aux_first)
         BLK_RUN(mdvit_factoratt_bwd(datt, sv.qkv, sv.att, sv.U, d.w3, d.b3, d.w5, d.b5, d.w7, d.b7, sv.a, sv.kmax, sv.ksum, sv.Mmat, nullptr, e, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, faws, fab, B, H, W, C, d.heads, d.s3, d.s5, d.s7, s));
-        const size_t dab = mdvit_da_ws_bytes(B, d.da_hidden, C);
-        void* daws = A.take_bytes(dab);
-        BLK_RUN(mdvit_da_bwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, e, -1.0f, G.da_w1, G.da_b1, G.da_w2, G.da_b2, daws, dab, B, d.D, d.da_hidden, C, d.heads, s));
+        if (!G.e_out) {
+            const size_t dab = mdvit_da_ws_bytes(B, d.da_hidden, C);
+            void* daws = A.take_bytes(dab);
+            BLK_RUN(mdvit_da_bwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, e, -1.0f, G.da_w1, G.da_b1, G.da_w2, G.da_b2, daws, dab, B, d.D, d.da_hidden, C, d.heads, s));
+        }
         return MDVIT_OK;
     }
     float* dqkv = S.take(T * 3 * C);
@@ -423,7 +425,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
         if (inl && acc) return mdvit_set_error(MDVIT_E_SHAPE, "block_bwd: accumulating window-weight gradients need the side stream");
     }
-    if (d.label) {
+    if (d.label && !G.e_out) {
         const size_t dab = mdvit_da_ws_bytes(B, d.da_hidden, C);
         void* daws = A.take_bytes(dab);
         BLK_RUN(mdvit_da_bwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, e, dgrad_only ? -1.0f : 1.0f, G.da_w1, G.da_b1, G.da_w2, G.da_b2, daws, dab, B, d.D,
@@ -552,7 +554,7 @@ extern "C" int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g
         MDVIT_CHECK_ARG(g->cpe_w && g->cpe_b && g->n1_g && g->n1_b && g->qkv_w && g->w3 && g->b3 && g->w5 && g->b5 && g->w7 && g->b7 && g->proj_w && g->proj_b && g->n2_g &&
                             g->n2_b && g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b && (!d->qkv_b || g->qkv_b), MDVIT_E_SHAPE, "block_bwd: null gradient output");
     }
-    MDVIT_CHECK_ARG(!d->label || (g->da_w1 && g->da_b1 && g->da_w2 && g->da_b2), MDVIT_E_SHAPE, "block_bwd: the adapter's gradient outputs are missing");
+    MDVIT_CHECK_ARG(!d->label || g->e_out || (g->da_w1 && g->da_b1 && g->da_w2 && g->da_b2), MDVIT_E_SHAPE, "block_bwd: the adapter's gradient outputs are missing");
     MDVIT_CHECK_ARG(d->precision == 0 || (d->qkv_wt && d->proj_wt && (mlp_mode(*d) == MLP_RC || (mlp_rc16(*d) && d->fc2t_p && d->fc1t_p) || (d->fc1_wt && d->fc2_wt))), MDVIT_E_SHAPE,
                     "block_bwd: the bf16x3 data-gradient GEMMs need the transposed weights");
     Arena SV{(char*)const_cast<void*>(save), 0, save_bytes, false}, A{(char*)ws, 0, ws_bytes, false}, S{(char*)ws_side, 0, ws_side_bytes, false};

@@ -2373,14 +2373,69 @@ def rowdot(x, w, b=None):
 # Domain adapter + factorized attention core
 # ------------------------------------------------------------------------------------------------
 _da_pre = None          # inside da_precomputed(): {W2.data_ptr(): a [B, C]} for the label batch of the forward in progress
-_da_many = os.environ.get("MDVIT_DA_MANY", "1") != "0"      # 0: every block launches its own adapter kernel (A/B)
+_da_many = os.environ.get("MDVIT_DA_MANY", "1") != "0"      # 0: every block launches its own adapter kernels, forward and backward (A/B)
+_da_many_bwd = os.environ.get("MDVIT_DA_MANY_BWD", "1") != "0"      # 0: the forward in one launch, the backward inside each block (A/B)
+
+
+def _da_many_desc(label, params, heads, outs):
+    m = _lib.DaMany()
+    m.n = len(heads)
+    for i in range(m.n):
+        W1, b1, W2, b2 = params[4 * i:4 * i + 4]
+        m.hid[i], m.C[i], m.heads[i] = W1.shape[0], W2.shape[0], int(heads[i])
+        m.W1[i], m.b1[i], m.W2[i], m.b2[i], m.a[i] = _p(W1), _p(b1), _p(W2), _p(b2), _p(outs[i])
+    return m
+
+
+class _DaMany(torch.autograd.Function):
+    """Every domain adapter of a network as ONE node: forward = mdvit_da_fwd_many (one launch), backward = mdvit_da_bwd_many (two launches) once the attention
+    backward of every block has handed its e = a * dL/da in as the 'gradient' of that block's a (the nodes below return e, not dL/da: no division by a)."""
+
+    @staticmethod
+    def forward(ctx, label, heads, *params):
+        ctx.set_materialize_grads(False)
+        B, D = label.shape
+        outs = tuple(_empty((B, params[4 * i + 2].shape[0]), device=label.device, dtype=torch.float32) for i in range(len(heads)))
+        m = _da_many_desc(label, params, heads, outs)
+        call("mdvit_da_fwd_many", C.byref(m), _p(label), B, D, _stream())
+        ctx.save_for_backward(label, *params, *outs)
+        ctx.heads = heads
+        return outs
+
+    @staticmethod
+    def backward(ctx, *es):
+        heads = ctx.heads
+        n = len(heads)
+        label, *rest = ctx.saved_tensors
+        params, outs = rest[:4 * n], rest[4 * n:]
+        if all(e is None for e in es):
+            return (None,) * (2 + 4 * n)
+        B, D = label.shape
+        m = _da_many_desc(label, params, heads, outs)
+        g = _lib.DaManyGrads()
+        grads = [None] * (4 * n)
+        live = [i for i in range(n) if es[i] is not None]
+        bufs = _flat_like(*[params[4 * i + j] for i in live for j in range(4)])
+        keep = []
+        for k, i in enumerate(live):
+            e = _c(es[i])
+            keep.append(e)
+            g.e[i] = _p(e)
+            grads[4 * i:4 * i + 4] = bufs[4 * k:4 * k + 4]
+            g.dW1[i], g.db1[i], g.dW2[i], g.db2[i] = (_p(t) for t in bufs[4 * k:4 * k + 4])
+        wsb = _lib.load().mdvit_da_many_ws_bytes(C.byref(m), B)
+        ws = _empty((wsb // 4,), device=label.device, dtype=torch.float32)
+        # dgrad-only (aux) sweep: MINUS the adapters' gradients, cancelled against the merged sweep's (see set_dgrad_only)
+        call("mdvit_da_bwd_many", C.byref(m), C.byref(g), _p(label), -1.0 if _dgrad_only else 1.0, _p(ws), wsb, B, D, _stream())
+        return (None, None, *grads)
 
 
 class da_precomputed:
     """Every domain adapter of a network for ONE label batch in one launch (mdvit_da_fwd_many) at the top of the forward: an adapter's output depends on the labels
     and its own four tensors only.  Inside the context the attention nodes (_FactorAtt, the C-level block through MdvitBlockDesc.a_pre) pick their `a` up by the
-    adapter's second weight instead of launching mdvit_da_fwd (16 launches of ~13 us on the single-stream forward of an MDViT); each node keeps its tensor for
-    the backward.  adapters: [(W1, b1, W2, b2, heads)].  Same arithmetic as the per-block launch, bit for bit."""
+    adapter's second weight instead of launching mdvit_da_fwd (16 launches of ~13 us on the single-stream forward of an MDViT), and hand their e = a * dL/da back
+    to the one node that owns all adapters (_DaMany) instead of launching mdvit_da_bwd (two launches of 8-12 us per block and sweep on the data-gradient chains).
+    adapters: [(W1, b1, W2, b2, heads)].  Same arithmetic as the per-block launches, bit for bit."""
 
     def __init__(self, label, adapters):
         self.label, self.adapters = label, adapters
@@ -2392,23 +2447,16 @@ class da_precomputed:
         if not (_da_many and self.label is not None and ad and len(ad) <= _lib.DA_MANY_MAX and self.label.is_cuda):
             return self
         label = _c(self.label.float())
-        B, D = label.shape
-        m = _lib.DaMany()
-        m.n = len(ad)
-        sizes = [W2.shape[0] for (_, _, W2, _, _) in ad]
-        flat = _empty((B * sum(sizes),), device=label.device, dtype=torch.float32)
-        table, off = {}, 0
-        for i, (W1, b1, W2, b2, heads) in enumerate(ad):
-            if not all(t.is_contiguous() and t.dtype == torch.float32 for t in (W1, b1, W2, b2)):
-                return self
-            a = flat[off:off + B * sizes[i]].view(B, sizes[i])
-            off += B * sizes[i]
-            m.hid[i], m.C[i], m.heads[i] = W1.shape[0], sizes[i], int(heads)
-            m.W1[i], m.b1[i], m.W2[i], m.b2[i], m.a[i] = _p(W1), _p(b1), _p(W2), _p(b2), _p(a)
-            table[W2.data_ptr()] = a
-        call("mdvit_da_fwd_many", C.byref(m), _p(label), B, D, _stream())
-        self.label_c = label          # (kept alive with the table)
-        _da_pre = table
+        params = [t for (W1, b1, W2, b2, _) in ad for t in (W1, b1, W2, b2)]
+        if not all(t.is_contiguous() and t.dtype == torch.float32 for t in params):
+            return self
+        heads = tuple(int(h) for (_, _, _, _, h) in ad)
+        if _da_many_bwd:
+            outs = _DaMany.apply(label, heads, *params)
+        else:
+            with torch.no_grad():
+                outs = _DaMany.apply(label, heads, *params)
+        _da_pre = {ad[i][2].data_ptr(): outs[i] for i in range(len(ad))}
         return self
 
     def __exit__(self, *exc):
@@ -2429,8 +2477,8 @@ class _FactorAtt(torch.autograd.Function):
     from the attention backward (no division by a).  label is None -> no adapter (BASE / mpvit flavour)."""
 
     @staticmethod
-    def forward(ctx, qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, H, W_, heads, splits, aux_first=False):
-        _chk(qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2)
+    def forward(ctx, qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, a_pre, H, W_, heads, splits, aux_first=False):
+        _chk(qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, a_pre)
         ctx.set_materialize_grads(False)
         ctx.aux_first = bool(aux_first)
         B, N, C3 = qkv.shape
@@ -2438,8 +2486,10 @@ class _FactorAtt(torch.autograd.Function):
         Ch = Cn // heads
         dev = qkv.device
         a = None
+        ctx.e_out = False          # True: a is an output of the all-adapters node (_DaMany) -- e goes back to it as a's gradient, no adapter backward here
         if label is not None:
-            a = _da_lookup(W2, B)
+            a = a_pre
+            ctx.e_out = a_pre is not None and ctx.needs_input_grad[12]
             if a is None:
                 a = _empty((B, Cn), device=dev, dtype=torch.float32)
                 call("mdvit_da_fwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), B, label.shape[1], W1.shape[0], Cn, heads, _stream())
@@ -2459,7 +2509,7 @@ class _FactorAtt(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 17
+            return (None,) * 18
         qkv, w3, b3, w5, b5, w7, b7, label, W1, b1, W2, b2, a, out, U, kmax, ksum, Mmat = ctx.saved_tensors
         H, W_, heads, splits = ctx.meta
         g = _c(g)
@@ -2473,13 +2523,15 @@ class _FactorAtt(torch.autograd.Function):
             ws = _empty((wsb // 4,), device=dev, dtype=torch.float32)
             call("mdvit_factoratt_bwd", _p(g), _p(qkv), _p(out), _p(U), _p(w3), _p(b3), _p(w5), _p(b5), _p(w7), _p(b7), _p(a), _p(kmax), _p(ksum),
                  _p(Mmat), None, _p(e), None, None, None, None, None, None, _p(ws), wsb, B, H, W_, Cn, heads, splits[0], splits[1], splits[2], _stream())
+            if ctx.e_out:
+                return (None,) * 12 + (e,) + (None,) * 5
             hid = W1.shape[0]
             dW1, db1, dW2, db2 = _empty_like(W1), _empty_like(b1), _empty_like(W2), _empty_like(b2)
             dab = _lib.load().mdvit_da_ws_bytes(B, hid, Cn)
             daws = _empty((dab // 4,), device=dev, dtype=torch.float32)
             call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), -1.0, _p(dW1), _p(db1), _p(dW2), _p(db2), _p(daws), dab,
                  B, label.shape[1], hid, Cn, heads, _stream())
-            return (None,) * 8 + (dW1, db1, dW2, db2) + (None,) * 5
+            return (None,) * 8 + (dW1, db1, dW2, db2) + (None,) * 6
         dqkv = _empty_like(qkv)
         crpe = (w3, b3, w5, b5, w7, b7)
         sinks = [_sink_of(t) for t in crpe] if (not _dgrad_only and _side_stream is not None) else [None] * 6
@@ -2499,7 +2551,7 @@ class _FactorAtt(torch.autograd.Function):
                 call("mdvit_factoratt_wgrad", _p(qkv), _p(ws), wsb, *[_p(t) for t in sinks], B, H, W_, Cn, heads,
                      splits[0], splits[1], splits[2], 1, _stream())
         dW1 = db1 = dW2 = db2 = None
-        if a is not None:
+        if a is not None and not ctx.e_out:
             hid = W1.shape[0]
             dW1, db1, dW2, db2 = _empty_like(W1), _empty_like(b1), _empty_like(W2), _empty_like(b2)
             dab = _lib.load().mdvit_da_ws_bytes(B, hid, Cn)
@@ -2507,7 +2559,7 @@ class _FactorAtt(torch.autograd.Function):
             # dgrad-only (aux) sweep: MINUS the adapter gradient, cancelled against the merged sweep's (see set_dgrad_only)
             call("mdvit_da_bwd", _p(label), _p(W1), _p(b1), _p(W2), _p(b2), _p(a), _p(e), -1.0 if _dgrad_only else 1.0,
                  _p(dW1), _p(db1), _p(dW2), _p(db2), _p(daws), dab, B, label.shape[1], hid, Cn, heads, _stream())
-        return (dqkv, *dws, None, dW1, db1, dW2, db2, None, None, None, None, None)
+        return (dqkv, *dws, None, dW1, db1, dW2, db2, e if ctx.e_out else None, None, None, None, None, None)
 
 
 class _AuxStop(torch.autograd.Function):
@@ -2534,9 +2586,9 @@ def factor_att(qkv, crpe_params, H, W_, heads, splits=(2, 3, 3), domain_label=No
     adapter gradient only and hands no gradient on (nothing below carries an adapter)."""
     w3, b3, w5, b5, w7, b7 = crpe_params
     if domain_label is None:
-        return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, None, None, None, None, None, int(H), int(W_), int(heads), tuple(splits), False)
+        return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, None, None, None, None, None, None, int(H), int(W_), int(heads), tuple(splits), False)
     W1, b1, W2, b2 = da_params
-    return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, _c(domain_label.float()), W1, b1, W2, b2, int(H), int(W_), int(heads), tuple(splits),
+    return _FactorAtt.apply(_c(qkv), w3, b3, w5, b5, w7, b7, _c(domain_label.float()), W1, b1, W2, b2, _da_lookup(W2, qkv.shape[0]), int(H), int(W_), int(heads), tuple(splits),
                             bool(aux_first))
 
 
@@ -2692,12 +2744,14 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward, a_pre=None):
 
 class _SerialBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, label, rs1, rs2, meta, *params):
+    def forward(ctx, x, label, rs1, rs2, meta, a_pre, *params):
         ctx.set_materialize_grads(False)
-        _chk(x, label, rs1, rs2, *params)
+        _chk(x, label, rs1, rs2, a_pre, *params)
         drop_p = meta[5]
         keys = tuple(_next_key() if drop_p > 0 else (0, 0) for _ in range(3))          # proj, fc1, fc2: the order of the operator-level path
-        a_pre = _da_lookup(params[14], x.shape[0]) if label is not None else None          # params[14] = da_w2
+        if label is None:
+            a_pre = None
+        ctx.e_out = a_pre is not None and ctx.needs_input_grad[5]          # a is an output of the all-adapters node (_DaMany): e goes back to it, no adapter backward here
         d, keep = _block_desc(x, label, rs1, rs2, meta, keys, params, False, a_pre)
         lib = _lib.load()
         sb, wb = lib.mdvit_block_save_bytes(C.byref(d)), lib.mdvit_block_fwd_ws_bytes(C.byref(d))
@@ -2714,7 +2768,7 @@ class _SerialBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        n_in = 5 + len(_lib.BLOCK_PARAMS)
+        n_in = 6 + len(_lib.BLOCK_PARAMS)
         if g is None:
             return (None,) * n_in
         x, save, label, rs1, rs2, *params = ctx.saved_tensors
@@ -2733,7 +2787,11 @@ class _SerialBlock(torch.autograd.Function):
             acc = _side_stream is not None and all((s is not None) or (params[i] is None) for s, i in zip(sinks, _BLOCK_SINKABLE))
         ln_sinks = [_sink_of(params[i]) for i in _BLOCK_LN] if (acc and _block_ln_sinks and d.C in (64, 128, 320, 512)) else None
         ln_acc = ln_sinks is not None and all(s_ is not None for s_ in ln_sinks)
-        fresh_idx = [i for i in _BLOCK_FRESH if params[i] is not None and (want_w or 12 <= i <= 15) and not (ln_acc and i in _BLOCK_LN)]
+        e_out = None
+        if ctx.e_out:
+            e_out = _empty((x.shape[0], d.C), device=dev, dtype=torch.float32)
+            G.e_out = _p(e_out)
+        fresh_idx = [i for i in _BLOCK_FRESH if params[i] is not None and ((e_out is None) if 12 <= i <= 15 else want_w) and not (ln_acc and i in _BLOCK_LN)]
         if want_w and not acc:
             fresh_idx = sorted(fresh_idx + [i for i in _BLOCK_SINKABLE if params[i] is not None])
         bufs = _flat_like(*[params[i] for i in fresh_idx]) if fresh_idx else []
@@ -2763,13 +2821,14 @@ class _SerialBlock(torch.autograd.Function):
         if side is not None:
             _side_protect(ws_side, save, g, x, *keep, foreign=g)
         del keep
-        return (dx, None, None, None, None, *out)
+        return (dx, None, None, None, None, e_out, *out)
 
 
 def serial_block(x, label, rs1, rs2, meta, params):
     """x [B, N, C] -> [B, N, C]: one SerialBlock_adapt (mdvit.py:346-361).  meta = (H, W, heads, head_splits, eps, drop_p, ln_groups, aux_first);
     params in _lib.BLOCK_PARAMS order (the adapter's four are None without a domain label)."""
-    return _SerialBlock.apply(_c(x), None if label is None else _c(label.float()), rs1, rs2, meta, *params)
+    a_pre = _da_lookup(params[14], x.shape[0]) if label is not None else None          # params[14] = da_w2
+    return _SerialBlock.apply(_c(x), None if label is None else _c(label.float()), rs1, rs2, meta, a_pre, *params)
 
 
 def block_entry_ok(Cn, hidden, params) -> bool:

@@ -135,6 +135,43 @@ def test_block_entry_first_adapter_of_the_aux_sweep(monkeypatch):
             assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-12), n
 
 
+@pytest.mark.parametrize("entry", [False, True])
+@pytest.mark.parametrize("dgrad_only", [False, True])
+def test_adapters_owned_by_one_node_give_the_blocks_own_adapter_gradients(entry, dgrad_only, monkeypatch):
+    """Inside ops.da_precomputed the blocks take their adapter output from the all-adapters node (_DaMany) and hand e = a * dL/da back to it (MdvitBlockGrads.e_out /
+    _FactorAtt's a_pre input) instead of running mdvit_da_fwd / mdvit_da_bwd themselves: same output and data gradient bit for bit, every parameter gradient the
+    same (e is summed with float adds in LDS: last-bit differences run to run in either mode), in the full and in the data-gradient-only sweep (first adapter included)."""
+    from mdvit_amd import ops
+    B, H, W, C = 3, 12, 20, 64
+    x = torch.randn(B, H * W, C, device=dev())
+    label = torch.nn.functional.one_hot(torch.tensor([2, 1, 3]), 4).float().to(dev())
+    g = torch.randn(B, H * W, C, device=dev())
+    st = make_stage(C, 8, True)
+    st.mhca_blks[0].factoratt_crpe.aux_first = True
+    ref = run(st, x, label, H, W, g, entry, monkeypatch, dgrad_only=dgrad_only)
+    ads = []
+    for blk in st.mhca_blks:
+        att = blk.factoratt_crpe
+        d0, d2 = att.domain_layer[0], att.domain_layer[2]
+        ads.append((d0.weight, d0.bias, d2.weight, d2.bias, att.num_heads))
+    launches = []
+    orig = ops._DaMany.backward
+    monkeypatch.setattr(ops._DaMany, "backward", staticmethod(lambda ctx, *es: (launches.append(sum(e is not None for e in es)), orig(ctx, *es))[1]))
+    with ops.da_precomputed(label, ads):
+        got = run(st, x, label, H, W, g, entry, monkeypatch, dgrad_only=dgrad_only)
+    assert launches == [len(ads)]                       # one backward for every adapter of the stage
+    assert torch.equal(got[0], ref[0])
+    if ref[1] is None or got[1] is None:
+        assert got[1] is None or dgrad_only          # (the operator path hands the residual branch's gradient on in the aux sweep; model._trunk drops it)
+    else:
+        assert torch.equal(got[1], ref[1])
+    for n in ref[2]:
+        a, b = got[2][n], ref[2][n]
+        assert (a is None) == (b is None), n
+        if a is not None:
+            assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-12), n
+
+
 def test_mixed_mode_stores_the_c128_mlp_hidden_tensors_as_bf16(monkeypatch):
     """MdvitBlockDesc.store_bf16 (the bf16 / "mixed" mode, BASELINE configs[3]): h = drop1(gelu(u)) of the forward and du of the backward -- the two
     [tokens, hidden] tensors the C = 128 block still moves, operands of the fc2 / fc1 weight-gradient GEMMs only -- live in HBM as bf16.  What is stored is

@@ -827,6 +827,61 @@ def test_every_adapter_of_a_network_in_one_launch_equals_the_per_block_launches(
         assert float((a_ - b_).abs().max()) <= 1e-5 * float(b_.abs().max())
 
 
+def test_every_adapter_backward_of_a_sweep_in_two_launches_equals_the_per_block_launches():
+    """mdvit_da_bwd_many (ops._DaMany.backward: the blocks hand their e = a * dL/da out and the adapters' parameter gradients are formed once per sweep) against
+    mdvit_da_bwd per adapter, bit for bit: both signs of the scale, an adapter without e skipped (its outputs untouched); and the same through autograd."""
+    import ctypes as C
+    from mdvit_amd import ops, _lib
+    from mdvit_amd._lib import call
+    B, D = 6, 4
+    label = F.one_hot(torch.arange(B) % D, D).float().to(dev())
+    ads = []
+    for i, (Cn, heads) in enumerate(((64, 8), (128, 8), (320, 8), (512, 8), (64, 8), (216, 8))):
+        hid = max(Cn // 2, 4)
+        ads.append((rnd(hid, D, seed=600 + i).to(dev()), rnd(hid, seed=610 + i).to(dev()), rnd(Cn, hid, seed=620 + i, scale=hid ** -0.5).to(dev()), rnd(Cn, seed=630 + i).to(dev()), heads))
+    params = [t for ad in ads for t in ad[:4]]
+    heads = tuple(ad[4] for ad in ads)
+    outs = ops._DaMany.apply(label, heads, *params)
+    es = [rnd(B, ad[2].shape[0], seed=640 + i).to(dev()) for i, ad in enumerate(ads)]
+    skip = 2
+    for scale in (1.0, -1.0):
+        m = ops._da_many_desc(label, params, heads, outs)
+        g = _lib.DaManyGrads()
+        got = []
+        for i, ad in enumerate(ads):
+            bufs = [torch.full_like(t, float("nan")) for t in ad[:4]]
+            got.append(bufs)
+            if i != skip:
+                g.e[i] = ops._p(es[i])
+                g.dW1[i], g.db1[i], g.dW2[i], g.db2[i] = (ops._p(t) for t in bufs)
+        wsb = _lib.load().mdvit_da_many_ws_bytes(C.byref(m), B)
+        ws = torch.empty(wsb // 4, device=dev())
+        call("mdvit_da_bwd_many", C.byref(m), C.byref(g), ops._p(label), scale, ops._p(ws), wsb, B, D, ops._stream())
+        for i, (W1, b1, W2, b2, h) in enumerate(ads):
+            if i == skip:
+                assert all(bool(torch.isnan(t).all()) for t in got[i])
+                continue
+            ref = [torch.full_like(t, float("nan")) for t in (W1, b1, W2, b2)]
+            dab = _lib.load().mdvit_da_ws_bytes(B, W1.shape[0], W2.shape[0])
+            daws = torch.empty(dab // 4, device=dev())
+            call("mdvit_da_bwd", ops._p(label), ops._p(W1), ops._p(b1), ops._p(W2), ops._p(b2), ops._p(outs[i]), ops._p(es[i]), scale, *[ops._p(t) for t in ref],
+                 ops._p(daws), dab, B, D, W1.shape[0], W2.shape[0], h, ops._stream())
+            for a_, b_ in zip(got[i], ref):
+                assert torch.equal(a_, b_), (i, scale)
+    # through autograd: the node's backward with one e missing
+    ps = [t.clone().requires_grad_(True) for t in params]
+    outs2 = ops._DaMany.apply(label, heads, *ps)
+    live = [i for i in range(len(ads)) if i != skip]
+    torch.autograd.backward([outs2[i] for i in live], [es[i] for i in live])
+    for i in range(len(ads)):
+        for j in range(4):
+            if i == skip:
+                assert ps[4 * i + j].grad is None
+            else:
+                ref_ = got  # (scale -1 was the last direct run)
+                assert torch.equal(ps[4 * i + j].grad, -ref_[i][j])
+
+
 def test_conv_weight_layouts_of_many_weights_in_one_launch():
     """mdvit_conv_weight_relayout_many (the per-step refresh of every implicit-convolution weight layout, LDS-tiled since round 5) against the index definition
     (include/mdvit_hip.h: mode 0 out[co][tap][ci], mode 1 out[ci][8 - tap][co]) -- channel counts off the tile sizes included"""
