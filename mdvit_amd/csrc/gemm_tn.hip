@@ -498,7 +498,10 @@ int mdvit_gemm_tn_launch(const MdvitGemmDesc* d, hipStream_t s) {
         for (int g = 0; g < gg->n; ++g) { a.gA[g] = gg->A[g]; a.gB[g] = gg->B[g]; a.gC[g] = gg->C[g]; }
     }
     const dim3 grid(pl.tiles_m * pl.tiles_n, pl.splits, a.ngroups > 0 ? a.ngroups : 1), block(NTH);
-    const bool one = d->precision == 2;
+    // (MDVIT_EXP_TN_ONE_PLANE=1: an EXPERIMENT switch, not a mode -- every weight-gradient product on one bf16 plane, to measure how much of the step a faster
+    //  weight-gradient kernel could buy: tools/experiments/README.md)
+    static const bool exp_one = [] { const char* e = getenv("MDVIT_EXP_TN_ONE_PLANE"); return e && e[0] == '1'; }();
+    const bool one = d->precision == 2 || (exp_one && !d->a_bf16 && !d->b_bf16);
 #define MDVIT_TN_LAUNCH(BM_, BN_)                                                                                   \
     do {                                                                                                            \
         if (a.cv_c > 0) {                                                                                           \

@@ -27,6 +27,7 @@ from .parallel import GradAccumulator, GradBucketReducer
 _GROUPED_LOSSES = os.environ.get("MDVIT_GROUPED_LOSSES", "1") != "0"      # the G domain batches' losses in one launch each way (0: one op per domain + additions, A/B)
 _AUX_STREAM_FORCE = os.environ.get("MDVIT_AUX_SWEEP_STREAM_FORCE", "0") == "1"      # probes only: the aux sweep on its own stream whatever the model declares
 _two_stream_sweeps = os.environ.get("MDVIT_SWEEP_STREAMS", "1") != "0"      # A/B switch: 0 = both sweeps on the main stream
+_EXP_SKIP_AUX_SWEEP = os.environ.get("MDVIT_EXP_SKIP_AUX_SWEEP", "0") == "1"      # an EXPERIMENT (wrong adapter gradients): what the data-gradient-only sweep costs the step
 _timeline = None      # tools/sweep_timeline.py: a list here collects (tag, event, host seconds) at the sweeps' stream ends
 
 
@@ -121,6 +122,13 @@ def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: flo
                     # a cold step: the full sweep just (re)built derived-weight cache entries (W^T / planes / conv layouts) on the main
                     # stream; the aux sweep would hit them by host-side tag with no stream ordering -- order it after the fills
                     ops.stream_wait(s2, ops.current_stream_obj())
+                if _EXP_SKIP_AUX_SWEEP:
+                    if accumulator is not None:          # (the end-of-step bookkeeping only)
+                        accumulator.begin_sweep(last)
+                    ops.join_side_stream()
+                    if accumulator is not None:
+                        accumulator.end_sweep(last)
+                    return
                 ops.set_dgrad_only(True)
                 try:
                     sweep(aux_sum, last, on_stream=s2)
