@@ -866,7 +866,11 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamm
     float* part = want_params ? (float*)ws : nullptr;                      // [group][workgroup][dgamma | dbeta]
     int nblk;
     if (C == 64 || C == 128 || C == 320 || C == 512) {
-        nblk = min(cdiv(Mg, 64), 1024 / groups);
+        // rows per workgroup: 64 (four passes of 16) where the grid fills the chip anyway; 16 for the short tensors of stages 2 / 3 (C >= 320: 4096-16384 rows at
+        // bs=4), which otherwise run as 256 four-wave workgroups with four dependent load rounds each (MDVIT_LN_BWD_ROWS=64: the old grid, A/B)
+        static const int rows_env = [] { const char* e = getenv("MDVIT_LN_BWD_ROWS"); return e ? atoi(e) : 0; }();
+        const int rows_wg = rows_env > 0 ? rows_env : ((C >= 320 && (long)M * C <= (16384L * 512)) ? 16 : 64);
+        nblk = min(cdiv(Mg, rows_wg), 1024 / groups);
         if (want_params) MDVIT_CHECK_PARTIALS_WS(ws, ws_bytes, nblk * groups, 2 * C, "layernorm_bwd");
         dim3 grid16(nblk, groups);
         if (C == 64) hipLaunchKernelGGL((ln_bwd16_kernel<1>), grid16, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, part, Mg, mk);
