@@ -249,6 +249,17 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(mdvit_[a-z0-9_]+)\s*\(", text)))
 
 
+_on_load = []          # process-wide configuration calls queued by modules imported BEFORE the library exists (a fresh tree: `python -m mdvit_amd.build` imports the package)
+
+
+def on_load(fn):
+    """run fn(lib) now if the library is loaded (or loadable), else right after the first successful load() -- importing mdvit_amd never needs the .so, using it does"""
+    if _lib is not None or os.path.exists(LIB_PATH):
+        fn(load())
+    else:
+        _on_load.append(fn)
+
+
 def load():
     """dlopen the library (works without a GPU) and attach prototypes.  Raises if it is not built."""
     global _lib
@@ -298,6 +309,8 @@ def load():
         fn.restype = C.c_int
         fn.argtypes = sig
     _lib = lib
+    while _on_load:
+        _on_load.pop(0)(lib)
     return lib
 
 

@@ -460,7 +460,7 @@ def gemm(A, B, out, M, N, K, *, lda, ldb, ldc, trans_a=False, trans_b=True, bias
 _PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 _gemm_precision = _PRECISIONS[os.environ.get("MDVIT_GEMM_PRECISION", "bf16x3")]
 if _gemm_precision == 2 and os.environ.get("MDVIT_MLP_RC_ONE_PLANE", "1") != "0":
-    _lib.load().mdvit_mlp_rc_planes(1)
+    _lib.on_load(lambda lib: lib.mdvit_mlp_rc_planes(1))
 _use_plane_gemm = os.environ.get("MDVIT_PLANE_GEMM", "1") != "0"      # 0: the split-while-staging kernels of gemm.hip everywhere
 # bf16x3: plane kernels for K >= this.  Measured in the step (profiles/r02g_ab.txt): the plane NT kernel is a wash-to-slower against the
 # split-while-staging kernel at equal arithmetic (both sit at the same ~30 % of the MFMA roof: the limit is not the split VALU), so
@@ -468,13 +468,13 @@ _use_plane_gemm = os.environ.get("MDVIT_PLANE_GEMM", "1") != "0"      # 0: the s
 _plane_min_k = int(os.environ.get("MDVIT_PLANE_MIN_K", "1000000"))
 _tn_kernel = os.environ.get("MDVIT_TN_KERNEL", "1") != "0"
 if not _tn_kernel:                                                      # A/B: weight-gradient GEMMs on the general template instead of gemm_tn.hip
-    _lib.load().mdvit_gemm_tn_config(0, -1, 0)                          # (the implicit-convolution weight gradient lives in gemm_tn.hip: conv3x3_dense then takes im2col + GEMM)
+    _lib.on_load(lambda lib: lib.mdvit_gemm_tn_config(0, -1, 0))                      # (the implicit-convolution weight gradient lives in gemm_tn.hip: conv3x3_dense then takes im2col + GEMM)
 _ph_gemm = os.environ.get("MDVIT_PH_GEMM", "1") != "0"                # the 256-wide phase-split kernel for the products it prefers (0: A/B switch)
 _pm_gemm = os.environ.get("MDVIT_PM_GEMM", "1") != "0"                # the 128-row phase-split kernel for the mid-size products (0: A/B switch; the C-level block entry follows)
 if not _pm_gemm:
-    _lib.load().mdvit_gemm_pm_config(-1)
+    _lib.on_load(lambda lib: lib.mdvit_gemm_pm_config(-1))
 if not _ph_gemm:
-    _lib.load().mdvit_gemm_ph_config(-1)
+    _lib.on_load(lambda lib: lib.mdvit_gemm_ph_config(-1))
 _plane_rc = os.environ.get("MDVIT_PLANE_RC", "0") != "0"              # the recomputing fc2 data gradient of the C = 128 MLPs on the plane kernel
 
 
@@ -1279,7 +1279,7 @@ _mlp_rc16 = os.environ.get("MDVIT_MLP_RC16", "1") != "0"  # C = 128: the backwar
 # 474 = 474 images/s at bs=4, 557 against 553 at bs=32; bf16 mode 520 against 517 at bs=4, 614 against 601 at bs=16.  "auto": only where the weight gradients would not
 # run on a side stream; "0": never (A/B)
 _mlp_rc_bwd = os.environ.get("MDVIT_MLP_RC_BWD", "1")
-_lib.load().mdvit_block_config({"0": 0, "1": 1}.get(_mlp_rc_bwd, 2))          # the C-level block entry follows the same switch
+_lib.on_load(lambda lib: lib.mdvit_block_config({"0": 0, "1": 1}.get(_mlp_rc_bwd, 2)))          # the C-level block entry follows the same switch (applied when the library loads)
 
 
 def _mlp_rc_ok(Cin, Hd, b1, b2, res, W1, W2, M) -> bool:

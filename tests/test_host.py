@@ -215,7 +215,7 @@ def test_ctypes_mirrors_have_the_layout_of_the_public_header(tmp_path):
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = (("MdvitGemmDesc", _lib.GemmDesc), ("MdvitPlaneGemmDesc", _lib.PlaneGemmDesc), ("MdvitBlockDesc", _lib.BlockDesc),
-             ("MdvitBlockGrads", _lib.BlockGrads), ("MdvitBlockStreams", _lib.BlockStreams))
+             ("MdvitBlockGrads", _lib.BlockGrads), ("MdvitBlockStreams", _lib.BlockStreams), ("MdvitDaMany", _lib.DaMany), ("MdvitDaManyGrads", _lib.DaManyGrads))
     lines = ['#include <stdio.h>', '#include "mdvit_hip.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append(f'    printf("{cname} %zu\\n", sizeof({cname}));')
@@ -232,6 +232,37 @@ def test_ctypes_mirrors_have_the_layout_of_the_public_header(tmp_path):
         assert int(out[cname]) == C.sizeof(cls), (cname, out[cname], C.sizeof(cls))
         for fname, _t in cls._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname, out[f"{cname}.{fname}"], getattr(cls, fname).offset)
+
+
+def test_the_package_imports_in_a_tree_without_the_library_and_its_use_fails_loudly(tmp_path):
+    """a fresh checkout: `python -m mdvit_amd.build` and __graft_entry__.build() import the package BEFORE the library exists -- importing must not need the .so
+    (process-wide configuration calls are queued, _lib.on_load), using it must raise (no CPU or PyTorch fallback), and the queued calls run at the first load"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import mdvit_amd\n"
+        "from mdvit_amd import _lib, ops\n"
+        "assert _lib._lib is None and len(_lib._on_load) >= 1, (_lib._lib, len(_lib._on_load))\n"
+        "try:\n"
+        "    _lib.load()\n"
+        "except _lib.MdvitHipError as e:\n"
+        "    assert 'is missing' in str(e) and 'no CPU or PyTorch fallback' in str(e)\n"
+        "else:\n"
+        "    raise SystemExit('load() of a missing library did not raise')\n"
+        "try:\n"
+        "    ops.call('mdvit_gemm_pm_config', 0)\n"
+        "except _lib.MdvitHipError:\n"
+        "    pass\n"
+        "else:\n"
+        "    raise SystemExit('a library call ran without the library')\n"
+        "_lib.LIB_PATH = %r\n"
+        "lib = _lib.load()\n"
+        "assert len(_lib._on_load) == 0\n"
+        "print('ok')\n") % (root, os.path.join(root, "mdvit_amd", "lib", "libmdvit_hip.so"))
+    env = dict(os.environ, MDVIT_HIP_LIB=str(tmp_path / "not_built" / "libmdvit_hip.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_ctypes_prototypes_have_the_arity_of_the_header_declarations():
