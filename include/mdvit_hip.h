@@ -218,6 +218,10 @@ int mdvit_gemm_ph_config(int32_t mode);
  * mdvit_gemm_planes would route [M, K] x [N, K]^T to (6: 128 x 160, 7: 128 x 128) or 0; mdvit_gemm_pm_config: -1 never, 0 by the rule (default), 1 whenever legal. */
 int mdvit_gemm_pm_prefers(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32);
 int mdvit_gemm_pm_config(int32_t mode);
+/* The K ranges (2-4, or 1: none) mdvit_gemm_planes gives that tile for a PLAIN product (no epilogue operand, allow_split, workspace from mdvit_gemm_planes_ws_bytes) whose
+ * tiles alone would leave most of the chip idle -- the stage-3 data gradients at 16 images (4096 x 512 x 1536 / 2048: 128 tiles); the slabs are added in split order by
+ * the split-K reduction kernel, so the result is that of the 128 x 128 plane tile with the same K ranges, bit for bit. */
+int mdvit_gemm_pm_splits(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32);
 /* fp32 [rows, cols] (ld_in) -> planes [planes][rows][ld_out]; cols % 8 == 0 */
 int mdvit_split_planes(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t plane_stride, int64_t rows, int32_t cols, int32_t planes, void* stream);
 /* one tensor, any shape, optionally transposed (out = planes of in^T, [cols][rows]): non-leaf / sliced weights */

@@ -116,6 +116,7 @@ _SIGS = {
     "mdvit_da_fwd_many": [C.POINTER(DaMany), vp, i32, i32, vp],
     "mdvit_da_bwd_many": [C.POINTER(DaMany), C.POINTER(DaManyGrads), vp, f32, vp, C.c_size_t, i32, i32, vp],
     "mdvit_gemm_pm_prefers": [i32, i32, i32, i32, i32],
+    "mdvit_gemm_pm_splits": [i32, i32, i32, i32, i32],
     "mdvit_gemm_f32_grouped": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
     "mdvit_gemm_f32_grouped_bias": [C.POINTER(GemmDesc), i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
     "mdvit_transpose_batch": [i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp],

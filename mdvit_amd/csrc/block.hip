@@ -86,7 +86,12 @@ bool ph_takes(const MdvitBlockDesc& d, const void* planes, int M, int N, int K, 
     return d.precision == 1 && planes != nullptr && (mdvit_gemm_ph_prefers_epi(M, N, K, 2, epi_reads) != 0 || mdvit_gemm_pm_prefers(M, N, K, 2, 1) != 0);
 }
 int epi_reads_of(const MdvitGemmDesc& g) { return g.gelu_u != nullptr || g.residual != nullptr || g.accumulate != 0; }
-int gemm_planes_nt(Arena& A, const MdvitGemmDesc& g, const void* planes, hipStream_t s) {
+// ... or, a plain product with a long K and few tiles (the stage-3 data gradients at 16 images), on that tile over 2-4 K ranges (mdvit_gemm_pm_splits)
+bool pm_split_takes(const MdvitBlockDesc& d, const MdvitGemmDesc& g, const void* planes, int M, int N, int K) {
+    return d.precision == 1 && planes != nullptr && g.allow_split && g.epi == MDVIT_EPI_NONE && !epi_reads_of(g) && !(g.e_drop_p > 0.f) && !g.e_rowscale && !g.rc_a &&
+           mdvit_gemm_pm_splits(M, N, K, 2, 1) > 1;
+}
+int gemm_planes_nt(Arena& A, const MdvitGemmDesc& g, const void* planes, hipStream_t s, bool k_splits = false) {
     MdvitPlaneGemmDesc pd;
     memset(&pd, 0, sizeof(pd));
     pd.A = g.A; pd.lda = g.lda; pd.a_f32 = 1;
@@ -98,6 +103,9 @@ int gemm_planes_nt(Arena& A, const MdvitGemmDesc& g, const void* planes, hipStre
     pd.e_drop_p = g.e_drop_p; pd.e_key0 = g.e_key0; pd.e_key1 = g.e_key1; pd.e_rowscale = g.e_rowscale; pd.e_rows_per_scale = g.e_rows_per_scale;
     pd.residual = g.residual; pd.ldr = g.ldr; pd.gelu_u = g.gelu_u; pd.ldu = g.ldu;
     pd.drop_seed = g.drop_seed;
+    pd.allow_split = k_splits ? 1 : 0;          // (only where pm_split_takes routed the product here: the planner's other routes keep their one K range)
+    const size_t need = pd.allow_split ? mdvit_gemm_planes_ws_bytes(&pd) : 0;          // the slabs of the K splits
+    pd.ws = need ? A.take_bytes(need) : nullptr; pd.ws_bytes = need;
     BLK_RUN(mdvit_gemm_planes(&pd, s));
     return MDVIT_OK;
 }
@@ -117,6 +125,7 @@ int gemm_dgrad(Arena& A, const MdvitBlockDesc& d, MdvitGemmDesc& g, const float*
                const void* planes_t = nullptr) {
     g.A = gy; g.C = dx; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldc = K;
     if (ph_takes(d, planes_t, M, K, N, epi_reads_of(g)) && !g.rc_a) return gemm_planes_nt(A, g, planes_t, s);
+    if (pm_split_takes(d, g, planes_t, M, K, N)) return gemm_planes_nt(A, g, planes_t, s, true);
     if (d.precision >= 1) { g.B = Wt; g.ldb = N; g.trans_a = 0; g.trans_b = 1; g.precision = 1; }
     else { g.B = W; g.ldb = K; g.trans_a = 0; g.trans_b = 0; g.precision = 0; }
     const size_t need = g.allow_split ? mdvit_gemm_ws_bytes(&g) : 0;

@@ -33,3 +33,4 @@ bool mdvit_gemm_ph_ok(const BpArgs& a, int cfg, int planes, int epi, int kps);
 int mdvit_gemm_pm_launch(const BpArgs& a, int cfg, int epi, hipStream_t s);
 bool mdvit_gemm_pm_ok(const BpArgs& a, int cfg, int planes, int epi);
 extern "C" int mdvit_gemm_pm_prefers(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32);
+extern "C" int mdvit_gemm_pm_splits(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32);

@@ -343,7 +343,12 @@ BpPlan plan_ph(const MdvitPlaneGemmDesc* d, int cfg) {
 
 
 BpPlan plan_bp(const MdvitPlaneGemmDesc* d) {
-    if (g_bp_force_cfg >= 6) return BpPlan{g_bp_force_cfg, cdiv(d->M, 128), cdiv(d->N, g_bp_force_cfg == 6 ? 160 : 128), 1, d->K};
+    if (g_bp_force_cfg >= 6) {
+        BpPlan pl{g_bp_force_cfg, cdiv(d->M, 128), cdiv(d->N, g_bp_force_cfg == 6 ? 160 : 128), 1, d->K};
+        const bool plain_ = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual && !d->Cp;
+        if (g_bp_force_splits > 1 && d->allow_split && plain_) { pl.kps = cdiv(cdiv(d->K, g_bp_force_splits), 32) * 32; pl.splits = cdiv(d->K, pl.kps); }
+        return pl;
+    }
     if (g_bp_force_cfg >= 3) return plan_ph(d, g_bp_force_cfg);
     const int epi_reads = d->gelu_u != nullptr || d->residual != nullptr || d->accumulate != 0;
     if (g_bp_force_cfg < 0 && !d->rc_a && mdvit_gemm_ph_prefers_epi(d->M, d->N, d->K, d->planes, epi_reads)) {
@@ -353,6 +358,14 @@ BpPlan plan_bp(const MdvitPlaneGemmDesc* d) {
     if (g_bp_force_cfg < 0 && !d->rc_a && !d->Cp) {            // the 128-row phase-split tile (gemm_pm.hip): mid-size products
         const int cfg = mdvit_gemm_pm_prefers(d->M, d->N, d->K, d->planes, d->a_f32);
         if (cfg) return BpPlan{cfg, cdiv(d->M, 128), cdiv(d->N, cfg == 6 ? 160 : 128), 1, d->K};
+        // ... and as 2-4 K ranges where its tiles alone would leave most of the chip idle (stage 3 at bs=4); plain products only
+        const bool plain_ = d->epi == MDVIT_EPI_NONE && !(d->e_drop_p > 0.f) && !d->e_rowscale && !d->residual;
+        const int sp = (d->allow_split && plain_) ? mdvit_gemm_pm_splits(d->M, d->N, d->K, d->planes, d->a_f32) : 1;
+        if (sp > 1) {
+            const int c2 = d->N % 160 == 0 ? 6 : 7;
+            const int kps = cdiv(cdiv(d->K, sp), 32) * 32;
+            return BpPlan{c2, cdiv(d->M, 128), cdiv(d->N, c2 == 6 ? 160 : 128), cdiv(d->K, kps), kps};
+        }
     }
     static const int BMs[3] = {128, 128, 64}, BNs[3] = {128, 64, 64}, OCC[3] = {2, 3, 5};
     static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};

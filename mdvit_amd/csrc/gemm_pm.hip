@@ -84,7 +84,11 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int tile = pm_xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
     const int m0 = tm * 128, n0 = tn * BN;
-    const int nt = p.K / 32;
+    // a K split (grid.y; BEPI_PLAIN only, gemm_bp.hip's planner): this workgroup multiplies k = k0 .. k0 + 32 nt - 1 and leaves the raw sums in its slab
+    // [split][M][N]; gemm_splitk_reduce_kernel adds the slabs in split order (+ bias, accumulate)
+    const bool split = EPI == BEPI_PLAIN && p.splits > 1;
+    const int k0 = split ? (int)blockIdx.y * p.k_per_split : 0;
+    const int nt = (split ? min(p.k_per_split, p.K - k0) : p.K) / 32;
 
     // ---- B: wave w brings pieces w, w + 8 (, w + 16): piece pc = plane pc / (BN/16), rows 16 (pc % (BN/16)) ..+15; lane i lands at row (i >> 2), physical 16-byte chunk
     // i & 3 and fetches logical chunk (i & 3) ^ ((row >> 2) & 3) (the swizzle lives on the SOURCE address: the LDS side of global_load_lds is lane-linear).  A piece index
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         if (pc >= NPIECE) pc -= 8;
         const int pl = pc / (BN / 16), rg = pc % (BN / 16);
         const int row = rg * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
-        gb[i] = p.B + (long)pl * p.b_plane + (long)min(n0 + row, p.N - 1) * p.ldb + chunk * 8;
+        gb[i] = p.B + (long)pl * p.b_plane + (long)min(n0 + row, p.N - 1) * p.ldb + chunk * 8 + k0;
         ob[i] = 2 * PM_AP + pl * BP + rg * 1024;
     }
     auto issue_b1 = [&](int t, int i) __attribute__((always_inline)) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     };
     // ---- A (fp32): thread (row = tid / 4, c = tid % 4) owns k = 8 c .. 8 c + 7 of its row of a tile: two 16-byte loads into one of three register sets
     const int qrow = tid >> 2, qc = tid & 3;
-    const float* ga = reinterpret_cast<const float*>(p.A) + (long)min(m0 + qrow, p.M - 1) * p.lda + qc * 8;
+    const float* ga = reinterpret_cast<const float*>(p.A) + (long)min(m0 + qrow, p.M - 1) * p.lda + qc * 8 + k0;
     // The three in-flight A sets live in FIXED registers v[232:239], v[240:247], v[248:255], above the range the compiler may allocate (amdgpu_num_vgpr(224) on the
     // kernel): as compiler-visible asm outputs they were COPIED while still in flight -- hipcc placed v_mov_b64 of the prologue's A(2) / A(3) registers in front of the loop
     // (register assignment at a control-flow merge), and a copy of a register whose load has not landed copies garbage (the first build of this kernel: results changed
@@ -262,11 +266,14 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // quad q a lane holds FOUR CONSECUTIVE output columns n = 8 q + 4 (lane >> 5) + (r & 3) of output row m = lane & 31.  Loads are unconditional (clamped address,
         // the value dropped by a select): a load under a branch makes every later store wait for vmcnt(0).
         constexpr bool HAS_IN = EPI == BEPI_PLAIN || EPI == BEPI_DGELU || EPI == BEPI_FULL;
-        const bool use_in = EPI == BEPI_PLAIN ? (p.accumulate != 0) : (EPI == BEPI_DGELU ? true : p.residual != nullptr);
+        const bool use_in = EPI == BEPI_PLAIN ? (p.accumulate != 0 && !split) : (EPI == BEPI_DGELU ? true : p.residual != nullptr);
         const float* in_p = EPI == BEPI_PLAIN ? p.C : (EPI == BEPI_DGELU ? p.gelu_u : p.residual);
         const long in_ld = EPI == BEPI_PLAIN ? p.ldc : (EPI == BEPI_DGELU ? p.ldu : p.ldr);
         if (!use_in || in_p == nullptr) in_p = reinterpret_cast<const float*>(p.B);
-        const bool use_bias = p.bias != nullptr;
+        const bool use_bias = p.bias != nullptr && !split;
+        float* const c_out = split ? p.slab + (long)blockIdx.y * p.M * p.N : p.C;
+        const long c_ld = split ? (long)p.N : p.ldc;
+        uint16_t* const cp_out = split ? nullptr : p.Cp;
         const float* bias_p = use_bias ? p.bias : reinterpret_cast<const float*>(p.B);
         const int row = m0 + wr * 32 + l31;
         const int rowc = min(row, p.M - 1);
@@ -319,11 +326,11 @@ __global__ __launch_bounds__(PM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;       // (a multiply and an add, never fused: gemm_bp.hip / gemm_ph.hip / gemm_body.inc do the same arithmetic, bit for bit)
                     v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
                 }
-                if (p.C && ok) *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col) = v;
-                if (p.Cp && ok) {
+                if (c_out && ok) *reinterpret_cast<float4*>(c_out + (long)row * c_ld + col) = v;
+                if (cp_out && ok) {
                     uint2 hi, lo;
                     mdvit_split_bf16x3(v, hi, lo);
-                    uint16_t* d = p.Cp + (long)row * p.ldcp + col;
+                    uint16_t* d = cp_out + (long)row * p.ldcp + col;
                     *reinterpret_cast<uint2*>(d) = hi;
                     *reinterpret_cast<uint2*>(d + p.c_plane) = lo;
                 }
@@ -346,7 +353,7 @@ int launch_pm(const BpArgs& a0, int epi, hipStream_t s) {
     a.slab = reinterpret_cast<float*>(g_pm_stamps);
 #endif
     constexpr int BN = 32 * (NX + NY), LDS = 4 * (2 * PM_AP + 2 * BN * 64);
-    dim3 grid(a.tiles_m * a.tiles_n), block(PM_THREADS);
+    dim3 grid(a.tiles_m * a.tiles_n, a.splits > 1 ? a.splits : 1), block(PM_THREADS);
 #define PM_LAUNCH(EPI_)                                                                                                                         \
     do {                                                                                                                                        \
         static bool attr[64];                                                                                                                   \
@@ -373,7 +380,9 @@ int launch_pm(const BpArgs& a0, int epi, hipStream_t s) {
 
 // cfg 6: 128 x 160, cfg 7: 128 x 128.  Built for what the step hands in: fp32 A, two weight planes (bf16x3), one K range, K % 32 == 0.
 bool mdvit_gemm_pm_ok(const BpArgs& a, int cfg, int planes, int epi) {
-    return (cfg == 6 || cfg == 7) && planes == 2 && a.a_f32 && a.splits == 1 && epi != BEPI_DGELU_RC && a.K % 32 == 0 && a.K >= 32 && a.N % 4 == 0;
+    if (!((cfg == 6 || cfg == 7) && planes == 2 && a.a_f32 && epi != BEPI_DGELU_RC && a.K % 32 == 0 && a.K >= 32 && a.N % 4 == 0)) return false;
+    // K splits (round 5, last): plain epilogue, no plane output, every split a whole number of 32-wide K tiles (four at least: the ring's prologue), the slab handed in
+    return a.splits == 1 || (epi == BEPI_PLAIN && !a.Cp && a.slab && a.k_per_split % 32 == 0 && a.k_per_split >= 128 && a.K - (a.splits - 1) * a.k_per_split >= 128);
 }
 
 int mdvit_gemm_pm_launch(const BpArgs& a, int cfg, int epi, hipStream_t s) {
@@ -399,6 +408,28 @@ extern "C" int mdvit_gemm_pm_prefers(int32_t M, int32_t N, int32_t K, int32_t pl
     // several rounds it loses (16384 x 1280 x 320 65 against 54, 32768 x 960 x 320 94 against 85); 131072 x 320 x 1280 (eight rounds) ties.
     const long tiles = (long)cdiv(M, 128) * (N / (cfg == 6 ? 160 : 128)), rounds = (tiles + 255) / 256;
     const double eff = (double)tiles / ((double)rounds * 256.0);
-    if (eff < 0.7) return 0;
+    if (eff < 0.7) return 0;          // (a PLAIN product with a long K may still come here as K splits: mdvit_gemm_pm_splits)
     return ((K >= 640 && rounds <= 4) || (K >= 256 && rounds == 1)) ? cfg : 0;
+}
+// The K splits of a PLAIN product whose tiles leave half of the chip idle and whose K is long: 4096 x 512 x 2048 (the fc1 data gradient of stage 3 at 16 images, 128 tiles of
+// 128 x 128) as two K ranges of 1024 fills the 256 CUs; the slabs go through gemm_splitk_reduce_kernel in split order.  Measured alone (tools/gemm_pm_check.py,
+// profiles/r05_gemm_pm_splits.txt): 42.9 us with the reduction against 50.0 on the 64 x 64 tile of gemm.hip it ran before (and 50.8 unsplit).  Ranges shorter than 1024
+// LOSE -- 4096 x 512 x 1536 as 2 x 768: 37.6 against 33.8; 2048 x 512 x 2048 as 4 x 512: 33.0 against 31.2; 4096 x 320 x 1280 as 2 x 640: 32.9 against 28.4 (the reduction
+// launch and a prologue / epilogue per range that nothing overlaps) -- so the rule asks for ranges >= 1024 and >= 192 workgroups.  In the step: +0.3 % (profiles/r05_ab_pm_split.txt,
+// within the boxes' noise).  1: no split (or not this kernel's product).  MDVIT_PM_SPLIT=0: never.
+extern "C" int mdvit_gemm_pm_splits(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t a_f32) {
+    static const bool on = [] { const char* e = getenv("MDVIT_PM_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!on || g_pm_mode != 0 || planes != 2 || !a_f32 || M <= 0 || N <= 0 || K < 1024 || K % 32 != 0 || N % 4 != 0) return 1;
+    const int cfg = N % 160 == 0 ? 6 : (N % 128 == 0 ? 7 : 0);
+    if (cfg == 0) return 1;
+    const long tiles = (long)cdiv(M, 128) * (N / (cfg == 6 ? 160 : 128));
+    if (tiles > 128 || tiles < 32) return 1;
+    int best = 1;
+    for (int s = 2; s <= 4; ++s) {
+        const int kps = cdiv(cdiv(K, s), 32) * 32;
+        if (kps < 1024 || K - (cdiv(K, kps) - 1) * kps < 128) continue;
+        const long wgs = tiles * cdiv(K, kps);
+        if (wgs >= 192 && wgs <= 256) best = cdiv(K, kps);
+    }
+    return best;
 }

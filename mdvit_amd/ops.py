@@ -692,23 +692,25 @@ def to_planes(x2d):
 _ph_cache = {}
 
 
-def _ph_prefers(M, N, K, planes=2, reads=False) -> bool:
+def _ph_prefers(M, N, K, planes=2, reads=False, plain=False) -> bool:
     """a phase-split plane kernel takes [M, K] x [N, K]^T: the 256-wide one (csrc/gemm_ph.hip, mdvit_gemm_ph_prefers_epi; reads: the epilogue reads an [M, N] operand)
-    or, for fp32 activations against two weight planes, the 128-row one of the mid-size products (csrc/gemm_pm.hip, mdvit_gemm_pm_prefers)"""
-    k = (M, N, K, planes, bool(reads))
+    or, for fp32 activations against two weight planes, the 128-row one of the mid-size products (csrc/gemm_pm.hip, mdvit_gemm_pm_prefers) -- and, plain: a product
+    with no epilogue (a data gradient) that may be split along K, that tile over 2-4 K ranges (mdvit_gemm_pm_splits: long K, few tiles)"""
+    k = (M, N, K, planes, bool(reads), bool(plain))
     r = _ph_cache.get(k)
     if r is None:
         lib = _lib.load()
-        r = _ph_cache[k] = bool(lib.mdvit_gemm_ph_prefers_epi(M, N, K, planes, int(bool(reads)))) or bool(_pm_gemm and lib.mdvit_gemm_pm_prefers(M, N, K, planes, 1))
+        r = _ph_cache[k] = bool(lib.mdvit_gemm_ph_prefers_epi(M, N, K, planes, int(bool(reads)))) or bool(_pm_gemm and lib.mdvit_gemm_pm_prefers(M, N, K, planes, 1)) \
+            or bool(_pm_gemm and plain and not reads and lib.mdvit_gemm_pm_splits(M, N, K, planes, 1) > 1)
     return r
 
 
-def _plane_ok(M, N, K, reads=False) -> bool:
+def _plane_ok(M, N, K, reads=False, plain=False) -> bool:
     """the plane kernels cover this product (otherwise: the split-while-staging kernels of gemm.hip).  bf16x3: the products the 256-wide kernel
     takes (the 64 / 128 plane tiles lose to gemm.hip in the step: profiles/r02_gemm_step_ab.txt); bf16: every legal one."""
     if not (_use_plane_gemm and _gemm_precision >= 1 and K % 32 == 0 and N % 4 == 0):
         return False
-    return _gemm_precision == 2 or K >= _plane_min_k or (_ph_gemm and _ph_prefers(M, N, K, 2, reads))
+    return _gemm_precision == 2 or K >= _plane_min_k or (_ph_gemm and _ph_prefers(M, N, K, 2, reads, plain))
 
 
 def _pp(v):
@@ -773,8 +775,9 @@ def gemm_nt(x, W, out, M, N, K, *, w_transposed=False, bias=None, epi=_lib.EPI_N
         plan = _plan_cache[pkey] = (tm.value, tn.value, sp.value)
     if plan[0] == 256:       # csrc/gemm_ph.hip, as rocprofv3 prints it
         name = "gemm_ph_kernel<%d, %s, %d>%s" % (P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
-    elif plan[1] == 160 or (plan[0] == 128 and plan[1] == 128 and a_f32 and P == 2 and _lib.load().mdvit_gemm_pm_prefers(M, N, K, P, 1) == 7):
-        name = "gemm_pm_kernel<%d, 2, %d>" % (3 if plan[1] == 160 else 2, kepi)          # csrc/gemm_pm.hip
+    elif plan[1] == 160 or (plan[0] == 128 and plan[1] == 128 and a_f32 and P == 2 and (_lib.load().mdvit_gemm_pm_prefers(M, N, K, P, 1) == 7 or
+                                                                                          (plan[2] > 1 and _lib.load().mdvit_gemm_pm_splits(M, N, K, P, 1) == plan[2]))):
+        name = "gemm_pm_kernel<%d, 2, %d>%s" % (3 if plan[1] == 160 else 2, kepi, "+splitk_reduce" if plan[2] > 1 else "")          # csrc/gemm_pm.hip
     else:
         name = "gemm_bp_nt_kernel<%d, %d, %d, %s, %d>%s" % (plan[0], plan[1], P, "true" if a_f32 else "false", kepi, "+splitk_reduce" if plan[2] > 1 else "")
     if _events_by_shape:
@@ -815,7 +818,7 @@ def _dgrad(g, W, dx, M, K, N, ldb, **kw):
     if _lin_rc_ok(M, K, N) and ldb == K and not (set(kw) - {"allow_split"}):
         _linear_rc(g, W, True, None, dx, M, K, N)
         return
-    if _plane_ok(M, K, N, kw.get("gelu_u") is not None) and "rc" not in kw and "precision" not in kw:
+    if _plane_ok(M, K, N, kw.get("gelu_u") is not None, plain=set(kw) == {"allow_split"} and bool(kw["allow_split"])) and "rc" not in kw and "precision" not in kw:
         gemm_nt(g, W, dx, M, K, N, w_transposed=True, **kw)
         return
     if _gemm_precision:
@@ -2729,7 +2732,7 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward, a_pre=None):
             want = [("fc2t_p", W2, True, (M_, d.hidden, Cn), 1), ("fc1t_p", W1, True, (M_, Cn, d.hidden), 0), ("projt_p", params[16], True, (M_, Cn, Cn), 0),
                     ("qkvt_p", params[4], True, (M_, Cn, 3 * Cn), 0)]
         for name, Wx, tr, shp, rd in want:
-            if _ph_prefers(*shp, 2, rd):
+            if _ph_prefers(*shp, 2, rd, plain=backward and not rd):          # (plain: the data gradients block.hip may split along K, pm_split_takes)
                 pl = _wplanes(Wx, tr, 2)
                 setattr(d, name, _p(pl))
                 keep.append(pl)

@@ -1488,6 +1488,64 @@ def test_mid_size_products_take_the_128_row_tile_and_equal_the_split_while_stagi
         assert torch.equal(a, r)
 
 
+def test_few_tile_long_k_data_gradients_run_the_128_row_tile_over_k_ranges():
+    """mdvit_gemm_pm_splits: a plain product whose 128-row tiles alone would leave most of the chip idle (the stage-3 data gradients at 16 images: 4096 x 512 x 1536 /
+    2048) runs gemm_pm_kernel over 2 K ranges + the split-K reduction.  Per K range the kernel is the 128 x 128 plane tile bit for bit, the slabs are added in split
+    order by the same reduction kernel: the result equals that tile forced to the same split bit for bit (and the unsplit product to round-off); the rule leaves
+    short K, many-tile and epilogue-carrying products alone; ops._dgrad takes the route and MDVIT_PM_GEMM=0 / mdvit_gemm_pm_config(-1) switches it off."""
+    from mdvit_amd import _lib, ops
+    from mdvit_amd._lib import call
+    lib = _lib.load()
+    assert lib.mdvit_gemm_pm_splits(4096, 512, 2048, 2, 1) == 2 and lib.mdvit_gemm_pm_splits(4000, 512, 2048, 2, 1) == 2 and lib.mdvit_gemm_pm_splits(2048, 512, 4096, 2, 1) == 4
+    assert lib.mdvit_gemm_pm_splits(4096, 512, 1536, 2, 1) == 1 and lib.mdvit_gemm_pm_splits(2048, 512, 2048, 2, 1) == 1         # ranges under 1024 lose to gemm.hip (measured)
+    assert lib.mdvit_gemm_pm_splits(4096, 512, 512, 2, 1) == 1 and lib.mdvit_gemm_pm_splits(16384, 512, 2048, 2, 1) == 1 and lib.mdvit_gemm_pm_splits(4096, 512, 2048, 1, 1) == 1
+    prev = ops.gemm_precision()
+    ops.set_gemm_precision("bf16x3")
+    try:
+        for (M, N, K) in ((4096, 512, 2048), (2048, 512, 4096), (4000, 512, 2048)):
+            g, W = rnd(M, K, seed=11).to(dev()), rnd(K, N, seed=12, scale=K ** -0.5).to(dev())          # dx[M, N] = g[M, K] W[K, N]: the NT product against W^T's planes
+            ref64 = (g.double() @ W.double())
+            outs = {}
+            sp_rule = lib.mdvit_gemm_pm_splits(M, N, K, 2, 1)
+            for tag, cfg, sp in (("pm split", 7, sp_rule), ("128x128 split", 0, sp_rule), ("planner", -1, 0)):
+                call("mdvit_gemm_planes_force_plan", cfg, sp)
+                ops._plan_cache.clear()          # (the event names come from the cached plan of a shape)
+                try:
+                    dx = torch.full((M, N), float("nan"), device=dev())
+                    ops.kernel_events_begin()
+                    ops.gemm_nt(g, W, dx, M, N, K, w_transposed=True, allow_split=True)
+                    names = list(ops.kernel_events_end())
+                finally:
+                    call("mdvit_gemm_planes_force_plan", -1, 0)
+                outs[tag] = (dx, names)
+            assert torch.equal(outs["pm split"][0], outs["128x128 split"][0]), (M, N, K)
+            assert torch.equal(outs["planner"][0], outs["pm split"][0]), (M, N, K)              # the planner's own choice IS the two-range pm launch
+            assert any(n.startswith("gemm_pm_kernel<2, 2, 0>+splitk_reduce") for n in outs["planner"][1]), outs["planner"][1]
+            err = float((outs["planner"][0].double() - ref64).abs().max() / ref64.abs().max())
+            assert err < 2e-5, err
+            for _ in range(5):                                                                   # race screen
+                dx2 = torch.full((M, N), float("nan"), device=dev())
+                ops.gemm_nt(g, W, dx2, M, N, K, w_transposed=True, allow_split=True)
+                assert torch.equal(dx2, outs["planner"][0])
+        # the data-gradient route of ops (what the operator path and, through the same predicates, the C-level block take)
+        M, N, K = 4096, 2048, 512          # Linear(512 -> 2048): dx = g[M, 2048] W[2048, 512]
+        x, Wl, g = rnd(M, K, seed=21).to(dev()), rnd(N, K, seed=22, scale=K ** -0.5).to(dev()), rnd(M, N, seed=23).to(dev())
+        res = {}
+        for mode in (0, -1):
+            lib.mdvit_gemm_pm_config(mode); ops._ph_cache.clear()
+            ops.kernel_events_begin()
+            out, go = grads_of(lambda x, W: ops.linear(x, W, None), [x, Wl], g)
+            res[mode] = (out, go, list(ops.kernel_events_end()))
+    finally:
+        lib.mdvit_gemm_pm_config(0); ops._ph_cache.clear()
+        ops.set_gemm_precision(prev)
+    assert any(n.startswith("gemm_pm_kernel<2, 2, 0>+splitk_reduce") for n in res[0][2]), res[0][2]
+    assert not any(n.startswith("gemm_pm_kernel") for n in res[-1][2]), res[-1][2]
+    assert torch.equal(res[0][0], res[-1][0]) and torch.equal(res[0][1][1], res[-1][1][1])          # forward and weight gradient: untouched
+    dxa, dxb = res[0][1][0], res[-1][1][0]
+    assert float((dxa - dxb).abs().max()) <= 2e-6 * float(dxb.abs().max())                            # the data gradient: another summation order
+
+
 def test_linear_on_the_256_tile_equals_the_split_while_staging_kernel_bit_for_bit():
     """ops.linear routes the products mdvit_gemm_ph_prefers accepts to the 256-wide plane kernel (MDVIT_PH_GEMM); forward, data gradient and the fused
     FULL epilogue equal gemm.hip's results bit for bit (same products, same order), so a block may mix the two freely."""

@@ -121,9 +121,33 @@ def timing():
               f"| {t_old_full:7.1f} | {t_pm_full:7.1f} us | rule takes it: {takes}", flush=True)
 
 
+def timing_splits():
+    """the few-tile long-K data gradients of stage 3 at 16 images: gemm.hip (what ran before) against the 128-row tile over the rule's K ranges (+ the reduction launch)"""
+    print("\nplain products with few tiles and a long K: gemm.hip (planner) | 128-row tile unsplit | over the rule's K ranges (+ reduce) | the 128 x 128 plane tile, same ranges", flush=True)
+    for (M, N, K, note) in ((4096, 512, 2048, "fc1^T dgrad s3 bs4"), (4096, 512, 1536, "qkv^T dgrad s3 bs4"), (2048, 512, 2048, "fc1^T dgrad s3 bs2"), (4096, 320, 1280, "fc1^T dgrad s2 bs1")):
+        g = torch.randn(M, K, device="cuda"); W = torch.randn(K, N, device="cuda") * 0.1
+        Wt = W.t().contiguous()
+        out = torch.empty((M, N), device="cuda")
+        sp_rule = _lib.load().mdvit_gemm_pm_splits(M, N, K, 2, 1)
+        sp = sp_rule if sp_rule > 1 else 2          # (where the rule declines: what two ranges would cost)
+        fl = 2.0 * M * N * K
+        force(-1)
+        t_old = time_it(lambda: ops.gemm(ops._p(g), ops._p(Wt), ops._p(out), M, N, K, lda=K, ldb=K, ldc=N, precision=1, allow_split=True))
+        cfg = 6 if N % 160 == 0 else 7
+        call("mdvit_gemm_planes_force_plan", cfg, 0)
+        t_un = time_it(lambda: ops.gemm_nt(g, W, out, M, N, K, w_transposed=True, allow_split=True))
+        call("mdvit_gemm_planes_force_plan", cfg, sp)
+        t_sp = time_it(lambda: ops.gemm_nt(g, W, out, M, N, K, w_transposed=True, allow_split=True))
+        call("mdvit_gemm_planes_force_plan", 0, sp)
+        t_bp = time_it(lambda: ops.gemm_nt(g, W, out, M, N, K, w_transposed=True, allow_split=True))
+        force(-1)
+        print(f"{note:20s} {M:6d}x{N:5d}x{K:5d}  {t_old:7.1f} us {fl / t_old / 1e6:5.0f} TF | {t_un:7.1f} us | {sp} ranges: {t_sp:7.1f} us {fl / t_sp / 1e6:5.0f} TF | {t_bp:7.1f} us | rule: {sp_rule}", flush=True)
+
+
 if __name__ == "__main__":
     good = correctness()
     print("CORRECTNESS", "OK" if good else "FAILED", flush=True)
     if "--no-timing" not in sys.argv:
         timing()
+        timing_splits()
     sys.exit(0 if good else 1)
