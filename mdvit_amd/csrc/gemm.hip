@@ -221,6 +221,20 @@ GemmPlan plan_gemm(const MdvitGemmDesc* d) {
     const bool can_split = d->allow_split && plain && d->K >= 512 && (d->N % 4 == 0);
     GemmPlan best; best.cfg = 0; best.tiles_m = cdiv(d->M, 128); best.tiles_n = cdiv(d->N, 128); best.splits = 1;
     best.kps = cdiv(d->K, BK) * BK;
+    // The dense 3x3 convolutions of the bridge at 16 images (implicit GEMM, 4096 pixels x 512 / 1024 channels, K = 4608 / 9216): the model below prices the gathered A
+    // operand like a matrix and picked the 64 x 64 tile in one K range for 512 -> 1024 (228 us) -- measured (tools/probe/conv_bridge_plans.py,
+    // profiles/r05_conv_bridge_plans.txt): 128 x 128 tiles over K ranges that make ~512 workgroups (two per CU) run 512 -> 1024 in 158-165 us, 512 -> 512 in 92 (106),
+    // 1024 -> 512 in 158 (157); at 128 images (>= 1024 tiles) the one-range plans stand.  MDVIT_CONV_SPLIT_PLAN=0: the model's choice (A/B).
+    static const bool conv_rule = [] { const char* e = getenv("MDVIT_CONV_SPLIT_PLAN"); return !(e && e[0] == '0'); }();
+    if (conv_rule && g_force_cfg < 0 && g_force_splits == 0 && d->conv_c > 0 && d->conv_up <= 1 && d->conv_stride == 1 && !d->trans_a && can_split && d->K >= 2304 && !d->rc_a) {
+        const long tiles = (long)cdiv(d->M, 128) * cdiv(d->N, 128);
+        if (tiles >= 64 && tiles <= 256) {
+            const int want = (int)max(1L, min(4L, (512 + tiles / 2) / tiles));
+            best.kps = cdiv(cdiv(d->K, want), BK) * BK;
+            best.splits = cdiv(d->K, best.kps);
+            return best;
+        }
+    }
     double best_cost = 1e300;
     for (int c = 0; c < 3; ++c) {
         if (g_force_cfg >= 0 && c != g_force_cfg && !d->rc_a) continue;
