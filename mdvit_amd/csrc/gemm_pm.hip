@@ -350,6 +350,7 @@ template <int NX, int NY>
 int launch_pm(const BpArgs& a0, int epi, hipStream_t s) {
     BpArgs a = a0;
 #ifdef MDVIT_PM_STAMPS
+    if (a.splits > 1) return 1;          // (the stamps travel in the slab pointer: the probe build has one K range)
     a.slab = reinterpret_cast<float*>(g_pm_stamps);
 #endif
     constexpr int BN = 32 * (NX + NY), LDS = 4 * (2 * PM_AP + 2 * BN * 64);
