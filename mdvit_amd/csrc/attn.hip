@@ -513,13 +513,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CH <= 16 &
 template <int CH, int ROLE>
 __device__ __forceinline__ void fa_apply3_tiles(const float* __restrict__ dout, const float* __restrict__ qkv, const float* __restrict__ U, const float* __restrict__ dVc,
                                                 float* __restrict__ dqkv, const FaGeom& g, const float* sKV, const float* sD, const float* s_a, const float* s_km,
-                                                const float* s_ks, const float* s_tc, int b, int g0, int slot, int tiles_per_block) {
+                                                const float* s_ks, const float* s_tc, int b, int g0, int slot, int tiles_per_block, int bx) {
     constexpr int GW = CH, NB = (GW + 31) / 32, NQ = GW / 8, KS = GW / 2, LD = GW + 1;
     const int C = g.C, C3 = 3 * C;
     const int lane = threadIdx.x & 63;
     const int t = lane & 31, half = lane >> 5;
     const int ntiles = (g.N + 31) / 32;
-    const int tile_beg = blockIdx.x * tiles_per_block, tile_end = min(ntiles, tile_beg + tiles_per_block);
+    const int tile_beg = bx * tiles_per_block, tile_end = min(ntiles, tile_beg + tiles_per_block);
     const float inv_scale = 1.0f / g.scale;
     // Round 5: the tile's two operand rows are requested one tile AHEAD (unconditional, clamped token) and fly under the MFMAs of the tile in front of them -- the per-tile chain
     // load -> exp -> CH / 2 dependent MFMAs -> store had nothing to overlap with (profiles/r04_fa_bwd_apply3_pmc_stalls.txt: a wave waited 65 % of its life)
@@ -631,13 +631,23 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(CH >= 64 ? 
                                                            const float* __restrict__ Mmat, const float* __restrict__ a,
                                                            const float* __restrict__ kmax, const float* __restrict__ ksum,
                                                            const float* __restrict__ dMp, int NTS,
-                                                           float* __restrict__ dqkv, FaGeom g, int tiles_per_block) {
+                                                           float* __restrict__ dqkv, FaGeom g, int tiles_per_block, int gx, int xcd_map) {
     static_assert(CH >= 32 && CH % 8 == 0, "one head per channel group");
     constexpr int GW = CH, NB = (GW + 31) / 32, NQ = GW / 8, KS = GW / 2, LD = GW + 1, NTH = 384;
     __shared__ float sKV[GW * LD], sD[GW * LD];
     __shared__ __attribute__((aligned(16))) float s_a[GW], s_km[GW], s_ks[GW], s_tc[GW];
     const int C = g.C, C3 = 3 * C;
-    const int b = blockIdx.z, g0 = blockIdx.y * GW;
+    // Workgroup -> (token range bx, head by, image bz).  A head's operand rows are Ch-float pieces of [tokens, C] rows: at Ch = 40 a 160-byte piece straddles two 128-byte
+    // lines, each shared with the neighbouring head.  Dealt (x, y, z) the heads of one token range land on two XCDs alternately (round-robin dispatch) and every L2 fetches
+    // its own copy of the shared lines: the PMC passes count 12.8 [tokens, C] reads per launch where the operands are 6-7 (profiles/pmc_traffic.json).  xcd_map: the launch
+    // is one-dimensional and the heads of a token range get CONSECUTIVE slots of ONE XCD (workgroup i runs on XCD i % 8: slot = (i % 8) * (n / 8) + i / 8).
+    int bx, by, bz;
+    if (xcd_map) {
+        const int nwg = gridDim.x, heads = C / GW;
+        const int i = blockIdx.x, slot = (i & 7) * (nwg >> 3) + (i >> 3);
+        by = slot % heads; bx = (slot / heads) % gx; bz = slot / (heads * gx);
+    } else { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }
+    const int b = bz, g0 = by * GW;
     for (int i = threadIdx.x; i < GW * GW; i += NTH) {
         const int r = i / GW, cc = i % GW;
         sKV[r * LD + cc] = Mmat[((long)b * C + g0 + r) * CH + cc];
@@ -668,9 +678,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(CH >= 64 ? 
     const int role = wave % 3, slot = wave / 3;
     // one straight-line tile loop per role (a role test INSIDE the loop put every load under a branch, and the compiler drains the vector-memory queue at
     // each join: five serialised load round trips per tile)
-    if (role == 0) fa_apply3_tiles<CH, 0>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block);
-    else if (role == 1) fa_apply3_tiles<CH, 1>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block);
-    else fa_apply3_tiles<CH, 2>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block);
+    if (role == 0) fa_apply3_tiles<CH, 0>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block, bx);
+    else if (role == 1) fa_apply3_tiles<CH, 1>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block, bx);
+    else fa_apply3_tiles<CH, 2>(dout, qkv, U, dVc, dqkv, g, sKV, sD, s_a, s_km, s_ks, s_tc, b, g0, slot, tiles_per_block, bx);
 }
 
 // ---- Domain Adapter -----------------------------------------------------------------------------
@@ -1066,9 +1076,13 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         int tpb = 8;
         while (tpb > 2 && (long)cdiv(ntiles, tpb) * (C / GW) * B < 256) tpb /= 2;
         if (g_fa_apply_tiles > 0) tpb = g_fa_apply_tiles;
-        dim3 grid(cdiv(ntiles, tpb), C / GW, B);
-        if (Ch == 40) hipLaunchKernelGGL((fa_bwd_apply3_kernel<40>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb);
-        else if (Ch == 64) hipLaunchKernelGGL((fa_bwd_apply3_kernel<64>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb);
+        const int gx = cdiv(ntiles, tpb);
+        const long nwg = (long)gx * (C / GW) * B;
+        static const bool xcd_env = [] { const char* e = getenv("MDVIT_FA_APPLY3_XCD"); return !(e && e[0] == '0'); }();
+        const int xcd_map = xcd_env && nwg % 8 == 0 && nwg < (1L << 30);          // (see the kernel: the heads of a token range on one XCD)
+        dim3 grid = xcd_map ? dim3((unsigned)nwg, 1, 1) : dim3(gx, C / GW, B);
+        if (Ch == 40) hipLaunchKernelGGL((fa_bwd_apply3_kernel<40>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb, gx, xcd_map);
+        else if (Ch == 64) hipLaunchKernelGGL((fa_bwd_apply3_kernel<64>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb, gx, xcd_map);
         else return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_bwd: head dim %d not built (8/16/40/64)", Ch);
         MDVIT_LAUNCH_CHECK();
         return MDVIT_OK;
