@@ -608,7 +608,8 @@ def test_gconv2(B, H, W, C):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,bias", [(2, 16, 16, 32, 64, 2, False), (1, 8, 8, 512, 512, 1, True), (2, 5, 6, 64, 128, 1, True), (1, 9, 9, 32, 64, 2, False),
-                                                        (2, 32, 32, 32, 64, 2, False), (1, 64, 32, 64, 32, 2, True)])       # (the last two: the parity-class order of the strided data gradient)
+                                                        (2, 32, 32, 32, 64, 2, False), (1, 64, 32, 64, 32, 2, True),        # (these two: the parity-class order of the strided data gradient)
+                                                        (16, 16, 16, 512, 1024, 1, True), (12, 16, 16, 512, 512, 1, True)])  # (the bridge at 16 / 12 images: 128 x 128 tiles over K ranges, gemm.hip's conv rule)
 def test_conv3x3_dense(B, H, W, Cin, Cout, stride, bias):
     from mdvit_amd import ops
     x, w = rnd(B, Cin, H, W, seed=60), rnd(Cout, Cin, 3, 3, seed=61, scale=(Cin * 9) ** -0.5)
