@@ -457,7 +457,8 @@ def main():
             ledger[nm.value.decode()] = {"launches": int(nl.value), "flop": float(fl.value), "bytes": float(by.value)}
             i += 1
         shapes_out = os.environ.get("MDVIT_BENCH_GEMM_SHAPES")
-        if shapes_out and rank == 0:          # measurement aid: one more untimed step with the ledger keyed by (kernel, shape, epilogue operands) -> a text table
+        if shapes_out:          # measurement aid: one more untimed step with the ledger keyed by (kernel, shape, epilogue operands) -> a text table
+            # EVERY rank runs the extra step (it issues the bucket all-reduces and fence() holds a barrier: ADVICE r05); rank 0 writes the file
             _L.call("mdvit_gemm_ledger", 2)
             step(args.warmup + args.steps + 1)
             fence()
@@ -467,9 +468,10 @@ def main():
             while _L.load().mdvit_gemm_ledger_read(i, nm2, 256, _C.byref(nl), _C.byref(fl), _C.byref(by)) == 0:
                 rows.append((nm2.value.decode(), int(nl.value), float(fl.value), float(by.value)))
                 i += 1
-            with open(shapes_out, "w") as f:
-                for r in sorted(rows, key=lambda r: -r[3]):
-                    f.write(f"{r[1]:4d} x {r[3] / r[1] / 1e6:9.2f} MB {r[2] / r[1] / 1e9:9.2f} GF  {r[0]}\n")
+            if rank == 0:
+                with open(shapes_out, "w") as f:
+                    for r in sorted(rows, key=lambda r: -r[3]):
+                        f.write(f"{r[1]:4d} x {r[3] / r[1] / 1e6:9.2f} MB {r[2] / r[1] / 1e9:9.2f} GF  {r[0]}\n")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -254,15 +254,16 @@ _on_load = []          # process-wide configuration calls queued by modules impo
 
 
 def on_load(fn):
-    """run fn(lib) now if the library is loaded (or loadable), else right after the first successful load() -- importing mdvit_amd never needs the .so, using it does"""
-    if _lib is not None or os.path.exists(LIB_PATH):
-        fn(load())
+    """run fn(lib) now if the library is ALREADY loaded, else right after the first explicit load().  Importing mdvit_amd never dlopens anything (a
+    stale git-ignored .so from an earlier tree made `import mdvit_amd` -- and therefore `python -m mdvit_amd.build`, the command that rebuilds it -- raise)"""
+    if _lib is not None:
+        fn(_lib)
     else:
         _on_load.append(fn)
 
 
 def load():
-    """dlopen the library (works without a GPU) and attach prototypes.  Raises if it is not built."""
+    """dlopen the library (works without a GPU) and attach prototypes.  Raises if it is not built or was built from an earlier tree."""
     global _lib
     if _lib is not None:
         return _lib
@@ -271,6 +272,17 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m mdvit_amd.build` (hipcc, gfx950). "
             "mdvit_amd has no CPU or PyTorch fallback.")
     lib = C.CDLL(LIB_PATH)
+    try:
+        _attach_prototypes(lib)
+    except AttributeError as e:
+        raise MdvitHipError(f"{LIB_PATH} is stale ({e}): rebuild it with `python -m mdvit_amd.build`.") from None
+    _lib = lib
+    while _on_load:
+        _on_load.pop(0)(lib)
+    return lib
+
+
+def _attach_prototypes(lib):
     lib.mdvit_last_error.restype = C.c_char_p
     lib.mdvit_last_error.argtypes = []
     lib.mdvit_version.restype = C.c_int
@@ -306,13 +318,13 @@ def load():
     lib.mdvit_da_many_ws_bytes.restype = C.c_size_t
     lib.mdvit_da_many_ws_bytes.argtypes = [C.POINTER(DaMany), i32]
     for name, sig in _SIGS.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise MdvitHipError(f"{LIB_PATH} is stale: it does not export `{name}` (built from an earlier tree). "
+                                "Rebuild it with `python -m mdvit_amd.build`.") from None
         fn.restype = C.c_int
         fn.argtypes = sig
-    _lib = lib
-    while _on_load:
-        _on_load.pop(0)(lib)
-    return lib
 
 
 def check(code: int, what: str):

@@ -804,7 +804,15 @@ extern "C" int mdvit_layernorm_fwd(const float* x, const float* gamma, const flo
     return MDVIT_OK;
 }
 
-static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+// A second upstream-gradient partial for the NEXT LayerNorm backward call of this thread (block.hip: the C = 64 MLP backward in one kernel leaves dx as one partial
+// per 256-wide hidden role; the LayerNorm in front of the MLP adds them while it reads them -- no separate sum pass).  EVERY public LayerNorm backward entry takes
+// (reads and clears) it as its first statement, before any argument check can return: a call that fails early must not leave the pointer armed for a later,
+// unrelated LayerNorm backward of this thread.
+static thread_local const float* g_ln_dy2 = nullptr;
+void mdvit_layernorm_bwd_next_dy2(const float* dy2) { g_ln_dy2 = dy2; }
+static inline const float* ln_take_dy2() { const float* p = g_ln_dy2; g_ln_dy2 = nullptr; return p; }
+
+static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                               int32_t M, int32_t C, int32_t groups, const LnMasked& mk, void* stream, int* defer_nblk = nullptr);
 
@@ -812,14 +820,16 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamm
 extern "C" int mdvit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                    const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                    int32_t M, int32_t C, int32_t groups, void* stream) {
+    const float* dy2 = ln_take_dy2();
     LnMasked mk; memset(&mk, 0, sizeof(mk));
-    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
+    return layernorm_bwd_impl(dy, dy2, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
 }
 
 extern "C" int mdvit_layernorm_bwd_masked(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                           const float* add, float* dx, float* dx_masked, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                           int32_t M, int32_t C, int32_t groups, float drop_p, uint32_t key0, uint32_t key1, const float* rowscale,
                                           int32_t rows_per_scale, const uint32_t* seed, void* stream) {
+    const float* dy2 = ln_take_dy2();
     MDVIT_CHECK_ARG(C == 64 || C == 128 || C == 320 || C == 512, MDVIT_E_SHAPE, "layernorm_bwd_masked: C=%d not built (64/128/320/512)", C);
     MDVIT_CHECK_ARG(dx_masked != nullptr && drop_p >= 0.f && drop_p < 1.f && (rowscale == nullptr || rows_per_scale > 0), MDVIT_E_SHAPE,
                     "layernorm_bwd_masked: bad mask arguments");
@@ -827,7 +837,7 @@ extern "C" int mdvit_layernorm_bwd_masked(const float* dy, const float* x, const
     LnMasked mk; memset(&mk, 0, sizeof(mk));
     mk.out = dx_masked; mk.drop_p = drop_p; mk.k0 = key0; mk.k1 = key1; mk.thresh = mdvit_drop_thresh(drop_p);
     mk.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; mk.rowscale = rowscale; mk.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; mk.seed = seed;
-    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
+    return layernorm_bwd_impl(dy, dy2, x, gamma, mean, rstd, add, dx, dgamma, dbeta, ws, ws_bytes, M, C, groups, mk, stream);
 }
 
 // The LayerNorm backward WITHOUT its second stage: the partial rows [groups][*nblk][dgamma | dbeta] stay in `ws`; the caller adds them up
@@ -835,6 +845,7 @@ extern "C" int mdvit_layernorm_bwd_masked(const float* dy, const float* x, const
 int mdvit_layernorm_bwd_parts(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* add, float* dx,
                               float* dx_masked, void* ws, size_t ws_bytes, int M, int C, int groups, float drop_p, uint32_t key0, uint32_t key1,
                               const float* rowscale, int rows_per_scale, const uint32_t* seed, hipStream_t stream, int* nblk) {
+    const float* dy2 = ln_take_dy2();
     MDVIT_CHECK_ARG(C == 64 || C == 128 || C == 320 || C == 512, MDVIT_E_SHAPE, "layernorm_bwd_parts: C=%d not built (64/128/320/512)", C);
     MDVIT_CHECK_ARG(nblk != nullptr && ws != nullptr, MDVIT_E_SHAPE, "layernorm_bwd_parts: null argument");
     LnMasked mk; memset(&mk, 0, sizeof(mk));
@@ -844,20 +855,15 @@ int mdvit_layernorm_bwd_parts(const float* dy, const float* x, const float* gamm
         mk.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; mk.rowscale = rowscale; mk.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; mk.seed = seed;
     }
     float dummy;
-    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, add, dx, &dummy, &dummy, ws, ws_bytes, M, C, groups, mk, stream, nblk);
+    return layernorm_bwd_impl(dy, dy2, x, gamma, mean, rstd, add, dx, &dummy, &dummy, ws, ws_bytes, M, C, groups, mk, stream, nblk);
 }
 
-// A second upstream-gradient partial for the NEXT LayerNorm backward call of this thread (block.hip: the C = 64 MLP backward in one kernel leaves dx as one partial
-// per 256-wide hidden role; the LayerNorm in front of the MLP adds them while it reads them -- no separate sum pass).  Consumed and cleared by that call.
-static thread_local const float* g_ln_dy2 = nullptr;
-void mdvit_layernorm_bwd_next_dy2(const float* dy2) { g_ln_dy2 = dy2; }
-
-static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* add, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                               int32_t M, int32_t C, int32_t groups, const LnMasked& mk_in, void* stream, int* defer_nblk) {
     hipStream_t s = (hipStream_t)stream;
     LnMasked mk = mk_in;
-    mk.dy2 = g_ln_dy2; g_ln_dy2 = nullptr;
+    mk.dy2 = dy2;
     MDVIT_CHECK_ARG(mk.dy2 == nullptr || ((C == 64 || C == 128 || C == 320 || C == 512) && aligned16(mk.dy2)), MDVIT_E_SHAPE, "layernorm_bwd: a second dy partial needs C in 64/128/320/512");
     MDVIT_CHECK_ARG(M > 0 && C > 0 && C <= 1024, MDVIT_E_SHAPE, "layernorm_bwd: need 0 < C <= 1024 (M=%d C=%d)", M, C);
     MDVIT_CHECK_ARG(groups > 0 && groups <= 64 && M % groups == 0, MDVIT_E_SHAPE, "layernorm_bwd: M=%d is not a multiple of groups=%d", M, groups);

@@ -64,7 +64,11 @@ extern "C" int mdvit_adamw_step(const void* table_dev, int32_t n_tensors, int32_
     MDVIT_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, MDVIT_E_SHAPE, "adamw_step: bad hyper-parameters");
     hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, s, step_dev);
     AdamScalars h{beta1, beta2, eps, weight_decay, zero_grad};
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks_per_tensor, n_tensors), dim3(256), 0, s, (const long long*)table_dev, lr_dev, (const float*)step_dev, h);
-    MDVIT_LAUNCH_CHECK();
+    // gridDim.y is limited to 65535: a table with more rows (one row per 32768-element chunk: > 2.1 G parameters) goes out in slices of the table
+    for (int32_t r0 = 0; r0 < n_tensors; r0 += 65535) {
+        const int32_t nr = n_tensors - r0 < 65535 ? n_tensors - r0 : 65535;
+        hipLaunchKernelGGL(adamw_kernel, dim3(blocks_per_tensor, nr), dim3(256), 0, s, (const long long*)table_dev + 5 * (long long)r0, lr_dev, (const float*)step_dev, h);
+        MDVIT_LAUNCH_CHECK();
+    }
     return MDVIT_OK;
 }

@@ -2,7 +2,8 @@
 lr_scheduler.StepLR(step_size=50, gamma=0.5)) as ONE HIP launch per step over every parameter.
 
 FusedAdamW works on a parallel.GradAccumulator: the gradients are the accumulator's flat bucket views, the two moments
-are flat buffers with the same layout, and a device table of pointers drives the kernel; the step counter and the
+are flat buffers with the same layout, and a device table of pointers drives the kernel -- one table row per 32768-element CHUNK
+of a parameter (the library slices tables of more than 65535 rows over several launches); the step counter and the
 learning rate live in device memory (HIP-graph replay safe).
 
 Deviation from torch.optim.AdamW, by construction: the kernel updates EVERY parameter of the accumulator on every step (gradient =

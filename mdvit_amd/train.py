@@ -220,7 +220,10 @@ def _aux_graph_is_ours(model, aux_sum) -> bool:
     model object (ops.audit_sweep_graph, a Python walk of ~1000 nodes), the verdict and the findings cached on it."""
     # the verdict is cached per (model object, what shapes its aux graph): the peer-head family, train / eval, how many domain batches the forward fused, whether
     # gradient sinks are attached -- a swapped head, another fusion width or a detached accumulator is audited again (ADVICE r04: the cache used to live as long as the object)
-    sig = (getattr(model, "decoder_name", None), bool(model.training), tuple(aux_sum.shape), type(aux_sum.grad_fn).__name__, bool(ops._sinks),
+    # (ADVICE r05: aux_sum is a scalar -- its shape says nothing; the fusion width is the number of loss groups / peer heads its node carries, and WHICH parameters have
+    #  sinks is the identity of the sink table, not whether one exists)
+    sig = (getattr(model, "decoder_name", None), bool(model.training), type(aux_sum.grad_fn).__name__, len(getattr(aux_sum.grad_fn, "next_functions", ())),
+           _fusion_width(aux_sum), id(ops._sinks), len(ops._sinks),
            tuple(type(getattr(model, f"debranch{i}", None)).__name__ for i in range(1, 5)))
     cache = getattr(model, "_aux_sweep_graph_cache", None)
     if cache is not None and cache[0] == sig:
@@ -234,6 +237,23 @@ def _aux_graph_is_ours(model, aux_sum) -> bool:
     except Exception:           # (an object that refuses attributes: audit every step)
         pass
     return ok
+
+
+def _fusion_width(aux_sum) -> int:
+    """how many domain batches the forward behind this aux loss fused: the group count of the grouped loss node (ops._SegLossesGroups) when there is one, else 1"""
+    seen, stack = set(), [aux_sum.grad_fn]
+    for _ in range(64):          # the loss node sits within a few additions / multiplications of the root
+        if not stack:
+            break
+        fn = stack.pop()
+        if fn is None or id(fn) in seen:
+            continue
+        seen.add(id(fn))
+        G = getattr(fn, "G", None)
+        if isinstance(G, int):
+            return G
+        stack.extend(nf for nf, _ in getattr(fn, "next_functions", ()))
+    return 1
 
 
 def _fuse_batches(batches, fuse_domains, num_domains, use_domain_label):

@@ -265,6 +265,34 @@ def test_the_package_imports_in_a_tree_without_the_library_and_its_use_fails_lou
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_a_stale_library_neither_breaks_the_import_nor_the_build_command_and_its_use_says_rebuild(tmp_path):
+    """a git-ignored .so left over from an EARLIER tree lacks the newest entry points.  Importing the package (which `python -m mdvit_amd.build`,
+    the command that would rebuild it, does first) must not dlopen it; load() must name the problem and the remedy"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "stale.c"
+    src.write_text("const char* mdvit_last_error(void) { return \"\"; }\nint mdvit_version(void) { return 1; }\nint mdvit_gemm_f32(void* d, void* s) { return 0; }\n")
+    so = tmp_path / "libmdvit_hip.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True, timeout=60)
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import mdvit_amd\n"
+        "import mdvit_amd.build\n"
+        "from mdvit_amd import _lib\n"
+        "assert _lib._lib is None, 'importing the package loaded the library'\n"
+        "try:\n"
+        "    _lib.load()\n"
+        "except _lib.MdvitHipError as e:\n"
+        "    assert 'stale' in str(e) and 'python -m mdvit_amd.build' in str(e), str(e)\n"
+        "else:\n"
+        "    raise SystemExit('load() of a stale library did not raise')\n"
+        "assert _lib._lib is None and len(_lib._on_load) >= 1\n"
+        "print('ok')\n") % (root,)
+    env = dict(os.environ, MDVIT_HIP_LIB=str(so))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_ctypes_prototypes_have_the_arity_of_the_header_declarations():
     """every function mdvit_amd/_lib.py gives argtypes to: as many arguments as its declaration in include/mdvit_hip.h (a parameter added to one side only
     would pass garbage for everything behind it); and every declared function that the Python side calls has a prototype"""
