@@ -45,6 +45,10 @@ class UnetDecodingBlockTransformer(nn.Module):
 _COMPOSE_GROUPED = os.environ.get("MDVIT_COMPOSE_GROUPED", "1") != "0"
 _LOWS_GROUPED = os.environ.get("MDVIT_LOWS_GROUPED", "1") != "0"      # A/B: 0 = one launch per head for the low-resolution projections
 _WT_BATCH = os.environ.get("MDVIT_WT_BATCH", "1") != "0"      # A/B: 0 = one transpose per use of a composed weight
+# Round 6: the two full-resolution features of an 'MLPFM' head (the first encoder stage's and the main decoder's last: both H/4, 64 channels) go through ONE product
+# over the concatenated K = C_0 + C_5 axis -- the [tokens, hidden] sum is written once in the forward (it was: written, read back as the second product's residual and
+# written again) and its gradient is read by ONE data-gradient and ONE weight-gradient product per sweep instead of two each.  0: the two products (A/B)
+_HEAD_CAT = os.environ.get("MDVIT_HEAD_CAT", "1") != "0"
 
 
 class MLPDecoderFM(nn.Module):
@@ -81,9 +85,16 @@ class MLPDecoderFM(nn.Module):
             return [(blocks[g][1], [(ops.matmul(blocks[g][0][:, q * hid:(q + 1) * hid], l.weight.view(hid, -1)), ops.rowdot(blocks[g][0][:, q * hid:(q + 1) * hid], l.bias))
                                     for q, l in enumerate(lins[g])]) for g in range(len(heads))]
         comp = ops.compose_heads([b[0] for b in blocks], [[l.weight for l in ls] for ls in lins], [[l.bias for l in ls] for ls in lins])
+        cat = _HEAD_CAT and all(h.with_fm for h in heads)
+        if cat:
+            # comp[g][4] = ([Wc_0 | W_5] [hid, C_0 + C_5], bc_0 + b_fuse): the operands of the one product over both full-resolution features (forward uses it
+            # when features[0] and features[4] have one resolution)
+            for g, h in enumerate(heads):
+                comp[g].append((torch.cat([comp[g][0][0], blocks[g][1]], 1), comp[g][0][1] + h.linear_fuse[0].bias))
         if _WT_BATCH and ops._gemm_precision >= 1 and torch.is_grad_enabled():
             # the W^T every data-gradient product of the heads' 1x1 convolutions reads (both sweeps): one launch for all heads instead of one per use
-            ops.transpose_weights_batch([w for g in range(len(heads)) for (w, _) in comp[g]] + [blocks[g][1] for g in range(len(heads))])
+            # (with the concatenated product: its [hid, C_0 + C_5] weight instead of the two blocks it replaces)
+            ops.transpose_weights_batch([w for g in range(len(heads)) for (w, _) in (comp[g][1:] if cat else comp[g])] + ([] if cat else [blocks[g][1] for g in range(len(heads))]))
         return [(blocks[g][1], comp[g]) for g in range(len(heads))]
 
     @staticmethod
@@ -114,9 +125,15 @@ class MLPDecoderFM(nn.Module):
         # fused = Wf_5 x5 + bf + sum_q upsample((Wf_q W_q) x_q + Wf_q b_q)      (MLPDecoder: no x5 term, bf rides on q = 0)
         W5, comp = (composed if composed is not None else MLPDecoderFM.compose_many([self])[0])[:2]
         pre = composed[2] if (composed is not None and len(composed) > 2) else {}       # q -> this head's projected feature, computed with the other heads' (grouped_lows)
-        acc = ops.linear(features[4], W5, bias) if self.with_fm else None                      # [B,h,w,hid]
         lows = []                                                                              # the projected lower-resolution features
-        for q in range(4):
+        q0 = 0
+        if self.with_fm and len(comp) > 4 and features[0].shape[1:3] == features[4].shape[1:3]:
+            Wcat, bcat = comp[4]
+            acc = ops.linear(ops.cat_channels(features[0], features[4]), Wcat, bcat)           # both full-resolution terms + both biases in ONE product: [B,h,w,hid]
+            q0 = 1
+        else:
+            acc = ops.linear(features[4], W5, bias) if self.with_fm else None                  # [B,h,w,hid]
+        for q in range(q0, 4):
             Wc, bc = comp[q]                                                                   # [hid, C_q], [hid]
             fq = features[q]
             if acc is None:

@@ -2225,6 +2225,29 @@ class _SplitCols(torch.autograd.Function):
         return torch.cat(parts, 1), None
 
 
+class _CatChannels(torch.autograd.Function):
+    """[.., C0] | [.., C1] -> [.., C0 + C1] (one copy launch); the backward hands each source its own CONTIGUOUS gradient block (two strided copies on the stream the
+    sweep runs on -- a native CatBackward0 would hand column-slice views that every consumer then copies for itself).  Used where two features of one resolution feed
+    the same 1x1 convolution sum: ONE product over the concatenated K axis writes the [tokens, hidden] tensor once (decode.MLPDecoderFM)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)
+        ctx.sizes = (a.shape[-1], b.shape[-1])
+        return torch.cat([a, b], dim=-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        c0, _c1 = ctx.sizes
+        return (g[..., :c0].contiguous() if ctx.needs_input_grad[0] else None), (g[..., c0:].contiguous() if ctx.needs_input_grad[1] else None)
+
+
+def cat_channels(a, b):
+    return _CatChannels.apply(_c(a), _c(b))
+
+
 def split_cols(W, sizes):
     assert W.dim() == 2 and sum(sizes) == W.shape[1]
     return _SplitCols.apply(W, tuple(int(n) for n in sizes))

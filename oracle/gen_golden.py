@@ -95,6 +95,13 @@ def gen_mdvit_deeplab_step(ns, S=64, B=2, seed=8):
     return gen_mdvit_step(ns, S, B, seed, decoder_name="DeepLabV3")
 
 
+def gen_mdvit_deeplab_step_b4(ns, S=64, B=4, seed=8):
+    """the DeepLabV3-peer step with FOUR images per domain: the ASPP pooling branch (Utils/_deeplab.py:124-135 via mdvit.py:607-612) normalises the B pooled vectors
+    of a domain batch with a train-mode BatchNorm; with B = 2 that backward divides by a two-sample variance and amplifies fp32 round-off of its input by ~1e5 (the
+    B = 2 fixture then pins nothing about the branch's gradients: VERDICT r05).  Four samples condition it; this is the fixture the gradient bounds are held against."""
+    return gen_mdvit_step(ns, S, B, seed, decoder_name="DeepLabV3")
+
+
 def gen_mdvit_step(ns, S=64, B=2, seed=0, decoder_name="MLPFM"):
     """4-domain two-sweep step, train mode -- multi_train_MDViT.py:129-207."""
     pn = make_params(seed, model="MDViT", adapt_method="Sup", decoder_name=decoder_name)
@@ -356,7 +363,7 @@ def main():
     torch.set_num_threads(8)
     ns = import_reference()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    jobs = {"transfuse_step_256": gen_transfuse_step, "base_dsn_step_64": gen_base_dsn_step, "mdvit_deeplab_step_64": gen_mdvit_deeplab_step, "mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
+    jobs = {"transfuse_step_256": gen_transfuse_step, "base_dsn_step_64": gen_base_dsn_step, "mdvit_deeplab_step_64": gen_mdvit_deeplab_step, "mdvit_deeplab_step_64_b4": gen_mdvit_deeplab_step_b4, "mdvit_transformer_step_64": gen_mdvit_transformer_step, "mdvit_mlp_step_64": gen_mdvit_mlp_step, "mdvit_dsn_step_64": gen_mdvit_dsn_step, "mdvit_step_64": gen_mdvit_step, "mdvit_eval_64": gen_mdvit_eval, "mdvit_fwd_96x128": gen_mdvit_fwd_rect,
             "base_step_64": gen_base_step, "factoratt_small": gen_factoratt, "losses_small": gen_losses}
     only = set(sys.argv[1:])
     for name, fn in jobs.items():

@@ -41,7 +41,8 @@ def test_generator_is_stable():
 
 
 @pytest.mark.parametrize("fixture,decoder_name", [("mdvit_step_64", "MLPFM"), ("mdvit_mlp_step_64", "MLP"),
-                                                  ("mdvit_transformer_step_64", "Transformer"), ("mdvit_deeplab_step_64", "DeepLabV3")])
+                                                  ("mdvit_transformer_step_64", "Transformer"), ("mdvit_deeplab_step_64", "DeepLabV3"),
+                                                  ("mdvit_deeplab_step_64_b4", "DeepLabV3")])
 def test_mdvit_two_sweep_step(golden, fixture, decoder_name):
     """decoder_name='MLP': the peer heads without the main decoder's feature (MLPDecoder, Decoders.py:239-286);
     'Transformer': per-domain transformer peer decoders (mdvit.py:614-642,705-713)"""

@@ -144,7 +144,31 @@ def timing_splits():
         print(f"{note:20s} {M:6d}x{N:5d}x{K:5d}  {t_old:7.1f} us {fl / t_old / 1e6:5.0f} TF | {t_un:7.1f} us | {sp} ranges: {t_sp:7.1f} us {fl / t_sp / 1e6:5.0f} TF | {t_bp:7.1f} us | rule: {sp_rule}", flush=True)
 
 
+def timing_presplit():
+    """VERDICT r05 item 8 -- "producer-written hi / lo planes" (Next (1)) priced with what exists: on the nine mid-size shapes, the A operand as fp32
+    (split while staged: what the step runs) against A ALREADY split into bf16 planes by its producer (half the A bytes per plane pair, no split VALU in the main loop),
+    on every tile that takes plane A (the 128 x 128 / 64-row tiles of gemm_bp.hip and the 256-wide phase-split tile; gemm_pm.hip takes fp32 A only)."""
+    print("\nA fp32 (split while staged) against A pre-split into planes -- shape: gemm_pm fp32 A | 128x128 plane tile fp32 A | same tile, plane A | planner, plane A | best plane-A / gemm_pm", flush=True)
+    for (M, N, K, cfg, note) in SHAPES[:17]:
+        x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.1
+        out = torch.empty((M, N), device="cuda")
+        wp = planes_of(w); xp = planes_of(x)
+        call("mdvit_gemm_pm_config", 0)
+        force(cfg)
+        t_pm = time_it(lambda: run_bp(x, wp, M, N, K, a_f32=True, C_out=out))
+        force(0)
+        t_bp_f32 = time_it(lambda: run_bp(x, wp, M, N, K, a_f32=True, C_out=out))
+        t_bp_pl = time_it(lambda: run_bp(xp, wp, M, N, K, a_f32=False, C_out=out))
+        force(-1)
+        t_auto_pl = time_it(lambda: run_bp(xp, wp, M, N, K, a_f32=False, C_out=out))
+        best = min(t_bp_pl, t_auto_pl)
+        print(f"{note:18s} {M:6d}x{N:5d}x{K:5d}  {t_pm:7.1f} us | {t_bp_f32:7.1f} us | {t_bp_pl:7.1f} us | {t_auto_pl:7.1f} us | pm / best plane-A = {t_pm / best:4.2f}x", flush=True)
+
+
 if __name__ == "__main__":
+    if "--presplit" in sys.argv:
+        timing_presplit()
+        sys.exit(0)
     good = correctness()
     print("CORRECTNESS", "OK" if good else "FAILED", flush=True)
     if "--no-timing" not in sys.argv:
