@@ -327,6 +327,12 @@ size_t mdvit_mlp_rc_wgrad_ws_bytes(int32_t M, int32_t C, int32_t hidden);
  * flops 2 M N K and bytes 4 (M K + N K + M N (1 + extra outputs / epilogue operands)).  mdvit_gemm_ledger_read(i, ...) returns row i, MDVIT_E_SHAPE past the last row. */
 int mdvit_gemm_ledger(int32_t enable);
 int mdvit_gemm_ledger_read(int32_t index, char* name, int32_t cap, int64_t* launches, double* flop, double* bytes);
+/* Launch sampler of mdvit_gemm_f32 (measurement only; bench.py's roofline line -- mdvit_amd has no reference counterpart: the reference has no native code): kernel begin / end
+ * timestamps around a hashed 1-in-`stride` sample of the launches of `symbol` (NULL / "": of every kernel symbol), whoever issues them -- mdvit_block_fwd / _bwd included;
+ * stride <= 0 switches it off.  mdvit_gemm_sampler_read(i, ...) waits for the sampled launches and returns symbol i's launches seen / timed and the summed duration [ms];
+ * MDVIT_E_SHAPE past the last symbol.  One thread. */
+int mdvit_gemm_sampler(const char* symbol, int32_t stride);
+int mdvit_gemm_sampler_read(int32_t index, char* name, int32_t cap, int64_t* seen, int64_t* timed, double* ms);
 int mdvit_mlp_rc_config(int32_t fwd_variant);
 /* The arithmetic of the register-chained MLP kernels (mdvit_mlp_rc_* / mdvit_mlp_rc16_*): 2 (default) = bf16x3, the parity mode -- every operand as hi + lo bf16 planes,
  * three MFMAs per product; 1 = the bf16 speed mode of BASELINE configs[1] / [3] -- the hi plane alone, one MFMA per product and no lo split of the chained hidden operand

@@ -130,6 +130,8 @@ _SIGS = {
     "mdvit_block_config": [i32],
     "mdvit_gemm_ledger": [i32],
     "mdvit_gemm_ledger_read": [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "mdvit_gemm_sampler": [C.c_char_p, i32],
+    "mdvit_gemm_sampler_read": [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)],
     "mdvit_factoratt_config": [i32, i32],
     "mdvit_mlp_rc_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, u32, u32, u32, u32, vp, vp],
     "mdvit_linear_rc": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, f32, u32, u32, vp, i32, vp, i64, vp, vp],

@@ -44,7 +44,14 @@ def _backward(loss, **kw):
 
 
 def _da_params(model):
-    return [p for n, p in model.named_parameters() if "domain_layer" in n]
+    """the domain adapters' parameters (multi_train_MDViT.py:198-200 walks named_parameters() twice per step; here the walk -- ~1 ms of host time for the 432 tensors --
+    runs once per model object: Module.to / .cuda / load_state_dict keep the Parameter objects, so the list stays valid; `del model._mdvit_da_params` after surgery)"""
+    hit = model.__dict__.get("_mdvit_da_params")
+    if hit is not None:
+        return hit
+    da = [p for n, p in model.named_parameters() if "domain_layer" in n]
+    model.__dict__["_mdvit_da_params"] = da          # (a plain attribute: not a registered submodule / buffer, never in the state_dict)
+    return da
 
 
 def mdvit_train_step(model, batches: Sequence[tuple], optimizer=None, alpha: float = 0.5, num_domains: int = 4,
