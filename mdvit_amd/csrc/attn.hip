@@ -20,6 +20,11 @@ namespace {
 
 constexpr int FA_T = 64;      // tokens per tile in the partial (K^T V / Q^T dFA) kernels
 
+// the value of lane ^ 1 (a DPP quad permute [1, 0, 3, 2]: no LDS crossbar, no address register -- __shfl_xor compiles to ds_bpermute_b32)
+__device__ __forceinline__ float fa_dpp_xor1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+
 struct FaGeom {
     int B, H, W, N, C, heads, Ch, s3, s5, s7;
     float scale;
@@ -223,6 +228,147 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
         const int c = o / CH, el = o % CH, e = (c / CH) * CH + el;       // head-diagonal entry (c, e) of the group
         const float v = (sm[c * RW + e] + sm[RW * RW + c * RW + e]) + (sm[2 * RW * RW + c * RW + e] + sm[3 * RW * RW + c * RW + e]);
         ws_P[(((long)b * NTS + stile) * g.C + c0 + c) * CH + el] = v;
+    }
+}
+
+// ---- the same tile partials at Ch = 8, C = 64 as a STREAM (round 6; see fa_bwd_apply_s8_kernel for the layout) ------------------------------------------
+// 16 lanes x float4 cover one token's 64 channels; a lane owns four channels c and keeps P[c][.] (its head's 8 columns, local order [mine | the neighbour lane's]) in
+// 32 registers for its whole token run; the neighbour's half of the head's Y vector comes by one DPP exchange per value.  No LDS staging, no MFMA (8 multiply-adds per
+// element of X), whole 256-byte rows per load instruction.  A workgroup walks the SAME `NSUB` 64-token tiles as fa_partial_kernel and writes the same partial row (the
+// combine kernel / the apply kernel's fixed-order sum over the NTS rows do not change); its 16 token slots meet in LDS in slot order.
+// SOFTMAX: the running column max is advanced once per group of four tokens (one rescale of the 36 accumulators per group); slots merge with exp(m_slot - m).
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void fa_partial_s8_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
+                                                            const float* __restrict__ ysc, float yscale,
+                                                            float* __restrict__ ws_m, float* __restrict__ ws_s, float* __restrict__ ws_P,
+                                                            FaGeom g, int NT, int NSUB,
+                                                            const float* __restrict__ outp, float* __restrict__ dU, float* __restrict__ e_part) {
+    constexpr int C = 64, CH = 8, NACC = 4 * CH + 8;          // per lane: P[4][8] | (SOFTMAX: m[4], s[4]; else e[4], unused[4])
+    // tokens per lane and group (their loads are in flight together; two groups alternate): 4 for the two-operand forward (2: 80.9 against 74.1 us at 32 images);
+    // 2 for the backward's three operands (160 VGPRs; at 4 it needs 256 -- one wave per SIMD -- for the same 117-123 us)
+    constexpr int FA_S8_G = SOFTMAX ? 4 : 2;
+    __shared__ float red[16][16][NACC + 1];
+    const int stile = blockIdx.x, b = blockIdx.z;
+    const int NTS = (NT + NSUB - 1) / NSUB;
+    const int q = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int c0 = 4 * q, j0 = 4 * (q & 1), jo = j0 ^ 4, hb = (q >> 1) * CH;
+    const int n_beg = stile * NSUB * FA_T, n_end = min(g.N, n_beg + NSUB * FA_T);
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[j][l] = 0.f;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, ssum[4] = {0.f, 0.f, 0.f, 0.f}, eacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float sc[4] = {yscale, yscale, yscale, yscale}, av[4] = {1.f, 1.f, 1.f, 1.f};
+    if (!SOFTMAX && ysc) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ysc + (long)b * C + c0);
+        av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j] *= av[j];
+    }
+    struct Rows { float4 x[FA_S8_G], y[FA_S8_G], o[(!SOFTMAX) ? FA_S8_G : 1]; };
+    auto request = [&](Rows& r, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < FA_S8_G; ++u) {
+            const long tok = (long)b * g.N + min(n0 + 16 * u, g.N - 1);
+            r.x[u] = *reinterpret_cast<const float4*>(X + tok * ldx + c0);
+            r.y[u] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0);
+            if (!SOFTMAX && e_part) r.o[u] = *reinterpret_cast<const float4*>(outp + tok * (long)C + c0);
+        }
+    };
+    auto compute = [&](const Rows& r, int n0) __attribute__((always_inline)) {
+        float xv[FA_S8_G][4], yv[FA_S8_G][4];
+        bool ok[FA_S8_G];
+#pragma unroll
+        for (int u = 0; u < FA_S8_G; ++u) {
+            ok[u] = n0 + 16 * u < n_end;
+            xv[u][0] = r.x[u].x; xv[u][1] = r.x[u].y; xv[u][2] = r.x[u].z; xv[u][3] = r.x[u].w;
+            yv[u][0] = r.y[u].x; yv[u][1] = r.y[u].y; yv[u][2] = r.y[u].z; yv[u][3] = r.y[u].w;
+        }
+        if (SOFTMAX) {
+            float mn[4], f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mn[j] = m[j];
+#pragma unroll
+                for (int u = 0; u < FA_S8_G; ++u) mn[j] = fmaxf(mn[j], ok[u] ? xv[u][j] : -INFINITY);
+                f[j] = (mn[j] == -INFINITY) ? 1.f : expf(m[j] - mn[j]);          // (a slot that has seen no token yet keeps its zeros)
+                m[j] = mn[j];
+                ssum[j] *= f[j];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[j][l] *= f[j];
+            }
+#pragma unroll
+            for (int u = 0; u < FA_S8_G; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xv[u][j] = ok[u] ? expf(xv[u][j] - mn[j]) : 0.f; ssum[j] += xv[u][j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < FA_S8_G; ++u) {
+            float yh[8];
+            if (!SOFTMAX) {
+                if (dU && ok[u]) {          // dU = a G q   (fa_bwd_prep_kernel's product, term for term)
+                    const long tok = (long)b * g.N + n0 + 16 * u;
+                    *reinterpret_cast<float4*>(dU + tok * C + c0) = make_float4(av[0] * yv[u][0] * xv[u][0], av[1] * yv[u][1] * xv[u][1], av[2] * yv[u][2] * xv[u][2], av[3] * yv[u][3] * xv[u][3]);
+                }
+                if (e_part && ok[u]) {
+                    eacc[0] = fmaf(yv[u][0], r.o[u].x, eacc[0]); eacc[1] = fmaf(yv[u][1], r.o[u].y, eacc[1]);
+                    eacc[2] = fmaf(yv[u][2], r.o[u].z, eacc[2]); eacc[3] = fmaf(yv[u][3], r.o[u].w, eacc[3]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { yh[j] = ok[u] ? yv[u][j] * sc[j] : 0.f; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yh[j] = yv[u][j];          // (its weight exp(k - m) is zero past the end)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yh[4 + j] = fa_dpp_xor1(yh[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[j][l] = fmaf(xv[u][j], yh[l], acc[j][l]);
+        }
+    };
+    Rows ra, rb;
+    int n = n_beg + slot;
+    request(ra, n);
+    for (; n < n_end; n += 2 * 16 * FA_S8_G) {
+        request(rb, n + 16 * FA_S8_G);
+        compute(ra, n);
+        request(ra, n + 2 * 16 * FA_S8_G);
+        compute(rb, n + 16 * FA_S8_G);
+    }
+    // ---- the 16 token slots meet in LDS, added in slot order by thread (q, channel j of the quad): one partial row per workgroup
+    float* mine = &red[slot][q][0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) mine[8 * j + l] = acc[j][l];
+        mine[32 + j] = SOFTMAX ? m[j] : eacc[j];
+        mine[36 + j] = ssum[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int qq = threadIdx.x >> 2, j = threadIdx.x & 3, c = 4 * qq + j;
+        const int jj0 = 4 * (qq & 1), jjo = jj0 ^ 4;
+        float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, t1 = 0.f, mm = -INFINITY;
+        if (SOFTMAX) {
+            for (int sl = 0; sl < 16; ++sl) mm = fmaxf(mm, red[sl][qq][32 + j]);
+        }
+        for (int sl = 0; sl < 16; ++sl) {
+            const float* r = &red[sl][qq][0];
+            float f = 1.f;
+            if (SOFTMAX) { const float ms = r[32 + j]; f = (ms == -INFINITY) ? 0.f : expf(ms - mm); t1 = fmaf(r[36 + j], f, t1); }
+            else t1 += r[32 + j];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) tot[l] = SOFTMAX ? fmaf(r[8 * j + l], f, tot[l]) : tot[l] + r[8 * j + l];
+        }
+        const long orow = ((long)b * NTS + stile) * C + c;
+        float* P = ws_P + orow * CH;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) P[l < 4 ? jj0 + l : jjo + (l - 4)] = tot[l];          // local order -> the head's channel order
+        if (SOFTMAX) { ws_m[orow] = mm; ws_s[orow] = t1; }
+        else if (e_part) e_part[orow] = t1;
     }
 }
 
@@ -506,6 +652,113 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CH <= 16 &
             request(ra, min(tile + 8, ntiles - 1));
             compute(rb, tile + 4);
         }
+    }
+}
+
+// ---- bwd 5 at Ch = 8, C = 64 as a STREAM (round 6) --------------------------------------------------------------------------------------------
+// fa_bwd_apply_kernel<8> runs the three token x 8 x 8 products of every head on 32 x 32 fp32 MFMA tiles of block-diagonal matrices (15/16 of every tile is zero) with
+// operand quads of 32 bytes per token and load instruction -- 32 cache lines per wave-wide load -- and sits at 3.3-3.9 TB/s of its eight [tokens, C] streams.  At Ch = 8
+// the products are 24 fused multiply-adds per output element: cheap enough for the VALU (the arithmetic below prices out at ~6x the HBM rate), so here the layout is
+// chosen for the MEMORY system instead: 16 lanes x float4 cover one token's 64 channels (every load / store instruction moves whole 256-byte rows, four tokens per wave),
+// a lane keeps the matrix rows / columns of ITS four channels in registers for its whole token run (96 values: M[c][.], dM[c][.], dM[.][c]) and gets the other half of
+// its head's 8-vector from the neighbouring lane with three 4-value DPP exchanges per token.  The next token's five rows are requested before the current one is used.
+// Same products; the sums run in the head's local channel order instead of the MFMA's (fp32 round-off only: tests compare against fp64 at 1e-4).
+__global__ __launch_bounds__(256) void fa_bwd_apply_s8_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                              const float* __restrict__ U, const float* __restrict__ dVc,
+                                                              const float* __restrict__ Mmat, const float* __restrict__ a,
+                                                              const float* __restrict__ kmax, const float* __restrict__ ksum,
+                                                              const float* __restrict__ dMp, int NTS,
+                                                              float* __restrict__ dqkv, FaGeom g, int tokens_per_block) {
+    constexpr int C = 64, CH = 8, C3 = 192;
+    __shared__ float sM[C * CH], sD[C * CH];
+    __shared__ float s_tc[C];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < C * CH; i += 256) {
+        sM[i] = Mmat[(long)b * C * CH + i];
+        float dm = 0.f;
+        const float* pp = dMp + ((long)b * NTS) * C * CH + i;
+        const long rs = (long)C * CH;
+        for (int t0 = 0; t0 < NTS; t0 += 8) {          // (the summation order of fa_bwd_apply_kernel: eight independent loads at a time)
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = t0 + u; v8[u] = pp[(long)(t < NTS ? t : NTS - 1) * rs]; if (t >= NTS) v8[u] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dm += v8[u];
+        }
+        sD[i] = dm;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float tc = 0.f;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) tc = fmaf(sD[threadIdx.x * CH + e], sM[threadIdx.x * CH + e], tc);
+        s_tc[threadIdx.x] = tc;
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int c0 = 4 * q, hb = (q >> 1) * CH, j0 = 4 * (q & 1), jo = j0 ^ 4;          // my four channels; my head; my / my neighbour's offset inside the head
+    // local order of a head's 8-vector: [mine (4) | the neighbour lane's (4)]
+    float Mr[4][8], Dr[4][8], Dc[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const int e = l < 4 ? j0 + l : jo + (l - 4);
+            Mr[j][l] = sM[(c0 + j) * CH + e];          // dq[c] = sum_e dfa[e] M[c][e]
+            Dr[j][l] = sD[(c0 + j) * CH + e];          // dk[c] = P[c] (sum_e v[e] dM[c][e] - t[c])
+            Dc[l][j] = sD[(hb + e) * CH + j0 + j];     // dv[e'] = sum_c P[c] dM[c][e'],  e' = my channel j, c = the head's channel e
+        }
+    const long ci = (long)b * C + c0;
+    const float4 a4 = a ? *reinterpret_cast<const float4*>(a + ci) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 km4 = *reinterpret_cast<const float4*>(kmax + ci);
+    float4 is4 = *reinterpret_cast<const float4*>(ksum + ci);
+    is4 = make_float4(1.0f / is4.x, 1.0f / is4.y, 1.0f / is4.z, 1.0f / is4.w);
+    const float4 tc4 = *reinterpret_cast<const float4*>(s_tc + c0);
+    const float inv_scale = 1.0f / g.scale;
+    const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
+    struct Rows { float4 g, k, v, u, c; };
+    auto request = [&](Rows& r, int n) __attribute__((always_inline)) {
+        const long tok = (long)b * g.N + min(n, g.N - 1);
+        r.g = *reinterpret_cast<const float4*>(dout + tok * C + c0);
+        r.k = *reinterpret_cast<const float4*>(qkv + tok * C3 + C + c0);
+        r.v = *reinterpret_cast<const float4*>(qkv + tok * C3 + 2 * C + c0);
+        r.u = *reinterpret_cast<const float4*>(U + tok * C + c0);
+        r.c = *reinterpret_cast<const float4*>(dVc + tok * C + c0);
+    };
+    auto compute = [&](const Rows& r, int n) __attribute__((always_inline)) {
+        float dfa[8], vv[8], pp[8];
+        dfa[0] = g.scale * a4.x * r.g.x; dfa[1] = g.scale * a4.y * r.g.y; dfa[2] = g.scale * a4.z * r.g.z; dfa[3] = g.scale * a4.w * r.g.w;
+        vv[0] = r.v.x; vv[1] = r.v.y; vv[2] = r.v.z; vv[3] = r.v.w;
+        pp[0] = expf(r.k.x - km4.x) * is4.x; pp[1] = expf(r.k.y - km4.y) * is4.y; pp[2] = expf(r.k.z - km4.z) * is4.z; pp[3] = expf(r.k.w - km4.w) * is4.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dfa[4 + j] = fa_dpp_xor1(dfa[j]); vv[4 + j] = fa_dpp_xor1(vv[j]); pp[4 + j] = fa_dpp_xor1(pp[j]); }
+        float dq[4], dk[4], dv[4];
+        const float uu[4] = {r.u.x, r.u.y, r.u.z, r.u.w}, cc[4] = {r.c.x, r.c.y, r.c.z, r.c.w}, tcv[4] = {tc4.x, tc4.y, tc4.z, tc4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) { s1 = fmaf(dfa[l], Mr[j][l], s1); s2 = fmaf(vv[l], Dr[j][l], s2); s3 = fmaf(pp[l], Dc[l][j], s3); }
+            dq[j] = fmaf(dfa[j] * inv_scale, uu[j], s1);
+            dk[j] = pp[j] * (s2 - tcv[j]);
+            dv[j] = s3 + cc[j];
+        }
+        if (n < n_end) {
+            float* drow = dqkv + ((long)b * g.N + n) * C3 + c0;
+            *reinterpret_cast<float4*>(drow) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            *reinterpret_cast<float4*>(drow + C) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+            *reinterpret_cast<float4*>(drow + 2 * C) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        }
+    };
+    // (every lane of a 16-lane row group runs the same trip count: the DPP exchange partners are always alive)
+    Rows ra, rb;
+    int n = n_beg + slot;
+    request(ra, n);
+    for (; n < n_end; n += 32) {
+        request(rb, n + 16);
+        compute(ra, n);
+        request(ra, n + 32);
+        compute(rb, n + 16);
     }
 }
 
@@ -952,6 +1205,11 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
         MDVIT_CHECK_ARG(C % GW == 0, MDVIT_E_SHAPE, "factoratt_fwd: C=%d is not a multiple of the %d-channel group", C, GW);
 #define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, true>), dim3(NT, C / GW, B), dim3(256), 0, s, \
                        qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, NT0, NSUB)
+        static const bool s8_env = [] { const char* e = getenv("MDVIT_FA_PARTIAL_STREAM"); return !(e && e[0] == '0'); }();
+        if (g.Ch == 8 && C == 64 && s8_env)          // the streaming form (MDVIT_FA_PARTIAL_STREAM=0: the LDS / MFMA tiles, A/B)
+            hipLaunchKernelGGL((fa_partial_s8_kernel<true>), dim3(NT, 1, B), dim3(256), 0, s, qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f,
+                               ws_m, ws_s, ws_P, g, NT0, NSUB, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+        else
         switch (g.Ch) {
             case 8: FA_PART_LAUNCH(8); break;
             case 16: FA_PART_LAUNCH(16); break;
@@ -1037,6 +1295,11 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
     {
 #define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, false>), dim3(NTS, C / GWp, B), dim3(256), 0, s, \
                        qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, NT, NSUBb, out, dU, e ? e_part : (float*)nullptr)
+        static const bool s8p_env = [] { const char* e = getenv("MDVIT_FA_PARTIAL_STREAM"); return !(e && e[0] == '0'); }();
+        if (Ch == 8 && C == 64 && s8p_env)
+            hipLaunchKernelGGL((fa_partial_s8_kernel<false>), dim3(NTS, 1, B), dim3(256), 0, s, qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr,
+                               ws_P, g, NT, NSUBb, out, dU, e ? e_part : (float*)nullptr);
+        else
         switch (Ch) {
             case 8: FA_PART_LAUNCH(8); break;
             case 16: FA_PART_LAUNCH(16); break;
@@ -1084,6 +1347,15 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         if (Ch == 40) hipLaunchKernelGGL((fa_bwd_apply3_kernel<40>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb, gx, xcd_map);
         else if (Ch == 64) hipLaunchKernelGGL((fa_bwd_apply3_kernel<64>), grid, dim3(384), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpb, gx, xcd_map);
         else return mdvit_set_error(MDVIT_E_SHAPE, "factoratt_bwd: head dim %d not built (8/16/40/64)", Ch);
+        MDVIT_LAUNCH_CHECK();
+        return MDVIT_OK;
+    }
+    static const bool s8_env = [] { const char* e = getenv("MDVIT_FA_APPLY_STREAM"); return !(e && e[0] == '0'); }();
+    if (Ch == 8 && C == 64 && s8_env && g_fa_apply_mode == 0) {          // the streaming VALU form (MDVIT_FA_APPLY_STREAM=0: the MFMA tiles, A/B)
+        int tpbk = 1024;                                              // tokens per workgroup: halved while the launch has fewer than two workgroups per CU
+        while (tpbk > 128 && (long)cdiv(g.N, tpbk) * B < 512) tpbk /= 2;
+        if (g_fa_apply_tiles > 0) tpbk = 32 * g_fa_apply_tiles;
+        hipLaunchKernelGGL(fa_bwd_apply_s8_kernel, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
         MDVIT_LAUNCH_CHECK();
         return MDVIT_OK;
     }
