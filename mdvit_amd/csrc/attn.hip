@@ -231,33 +231,41 @@ __global__ __launch_bounds__(256) void fa_partial_kernel(const float* __restrict
     }
 }
 
-// ---- the same tile partials at Ch = 8, C = 64 as a STREAM (round 6; see fa_bwd_apply_s8_kernel for the layout) ------------------------------------------
-// 16 lanes x float4 cover one token's 64 channels; a lane owns four channels c and keeps P[c][.] (its head's 8 columns, local order [mine | the neighbour lane's]) in
-// 32 registers for its whole token run; the neighbour's half of the head's Y vector comes by one DPP exchange per value.  No LDS staging, no MFMA (8 multiply-adds per
-// element of X), whole 256-byte rows per load instruction.  A workgroup walks the SAME `NSUB` 64-token tiles as fa_partial_kernel and writes the same partial row (the
-// combine kernel / the apply kernel's fixed-order sum over the NTS rows do not change); its 16 token slots meet in LDS in slot order.
-// SOFTMAX: the running column max is advanced once per group of four tokens (one rescale of the 36 accumulators per group); slots merge with exp(m_slot - m).
-template <bool SOFTMAX>
-__global__ __launch_bounds__(256) void fa_partial_s8_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
+// ---- the same tile partials at Ch = 8 / 16 (C = 64 / 128) as a STREAM (round 6; see fa_bwd_apply_s8_kernel for the layout) ------------------------------
+// C / 4 lanes x float4 cover one token's channels (16 lanes at C = 64: four tokens per wave; 32 at C = 128: two); a lane owns four channels c and keeps P[c][.] (its
+// head's Ch columns, local order [mine | lane ^ 1's | lane ^ 2's | lane ^ 3's]) in 4 Ch registers for its whole token run; the other lanes' parts of the head's Y vector
+// come by DPP quad permutes (a head is 2 or 4 neighbouring lanes: always inside a quad).  No LDS staging, no MFMA (Ch multiply-adds per element of X), whole rows per load
+// instruction.  A workgroup walks the SAME `NSUB` 64-token tiles as fa_partial_kernel and writes the same partial row (the combine kernel / the apply kernel's fixed-order
+// sum over the NTS rows do not change); its token slots meet in LDS in slot order.
+// SOFTMAX: the running column max is advanced once per group of tokens (one rescale of the accumulators per group); slots merge with exp(m_slot - m).
+template <int P> __device__ __forceinline__ float fa_dpp_quad_xor(float x) {
+    constexpr int ctrl = P == 1 ? 0xB1 : (P == 2 ? 0x4E : 0x1B);          // quad_perm [1,0,3,2] | [2,3,0,1] | [3,2,1,0]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true));
+}
+// (two waves per SIMD by declaration: with the slot rows in DYNAMIC LDS hipcc otherwise plans for four -- 128 registers -- and serialises the token groups' loads behind
+//  their arithmetic: the Ch = 8 forward 74 -> 85 us)
+template <int CH, bool SOFTMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fa_partial_s8_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ Y, long ldy,
                                                             const float* __restrict__ ysc, float yscale,
                                                             float* __restrict__ ws_m, float* __restrict__ ws_s, float* __restrict__ ws_P,
                                                             FaGeom g, int NT, int NSUB,
                                                             const float* __restrict__ outp, float* __restrict__ dU, float* __restrict__ e_part) {
-    constexpr int C = 64, CH = 8, NACC = 4 * CH + 8;          // per lane: P[4][8] | (SOFTMAX: m[4], s[4]; else e[4], unused[4])
-    // tokens per lane and group (their loads are in flight together; two groups alternate): 4 for the two-operand forward (2: 80.9 against 74.1 us at 32 images);
-    // 2 for the backward's three operands (160 VGPRs; at 4 it needs 256 -- one wave per SIMD -- for the same 117-123 us)
-    constexpr int FA_S8_G = SOFTMAX ? 4 : 2;
-    __shared__ float red[16][16][NACC + 1];
+    constexpr int C = 8 * CH, LPT = C / 4, SLOTS = 256 / LPT, LPH = CH / 4;          // lanes per token row; token slots per workgroup; lanes per head
+    constexpr int NACC = 4 * CH + 8;          // per lane: P[4][CH] | (SOFTMAX: m[4], s[4]; else e[4], unused[4])
+    // tokens per lane and group (their loads are in flight together; two groups alternate): 4 for the two-operand forward at Ch = 8 (2: 80.9 against 74.1 us at 32 images);
+    // 2 for the backward's three operands (160 VGPRs; at 4 it needs 256 -- one wave per SIMD -- for the same 117-123 us) and at Ch = 16 (64 accumulators)
+    constexpr int GRP = (SOFTMAX && CH == 8) ? 4 : 2;
+    extern __shared__ float fa_s_red[];          // [SLOTS][LPT][NACC + 1]
     const int stile = blockIdx.x, b = blockIdx.z;
     const int NTS = (NT + NSUB - 1) / NSUB;
-    const int q = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const int c0 = 4 * q, j0 = 4 * (q & 1), jo = j0 ^ 4, hb = (q >> 1) * CH;
+    const int q = threadIdx.x % LPT, slot = threadIdx.x / LPT;
+    const int c0 = 4 * q, hl = q % LPH;          // my four channels; my lane's place inside its head
     const int n_beg = stile * NSUB * FA_T, n_end = min(g.N, n_beg + NSUB * FA_T);
-    float acc[4][8];
+    float acc[4][CH];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int l = 0; l < 8; ++l) acc[j][l] = 0.f;
+        for (int l = 0; l < CH; ++l) acc[j][l] = 0.f;
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, ssum[4] = {0.f, 0.f, 0.f, 0.f}, eacc[4] = {0.f, 0.f, 0.f, 0.f};
     float sc[4] = {yscale, yscale, yscale, yscale}, av[4] = {1.f, 1.f, 1.f, 1.f};
     if (!SOFTMAX && ysc) {
@@ -266,22 +274,22 @@ __global__ __launch_bounds__(256) void fa_partial_s8_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) sc[j] *= av[j];
     }
-    struct Rows { float4 x[FA_S8_G], y[FA_S8_G], o[(!SOFTMAX) ? FA_S8_G : 1]; };
+    struct Rows { float4 x[GRP], y[GRP], o[(!SOFTMAX) ? GRP : 1]; };
     auto request = [&](Rows& r, int n0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < FA_S8_G; ++u) {
-            const long tok = (long)b * g.N + min(n0 + 16 * u, g.N - 1);
+        for (int u = 0; u < GRP; ++u) {
+            const long tok = (long)b * g.N + min(n0 + SLOTS * u, g.N - 1);
             r.x[u] = *reinterpret_cast<const float4*>(X + tok * ldx + c0);
             r.y[u] = *reinterpret_cast<const float4*>(Y + tok * ldy + c0);
             if (!SOFTMAX && e_part) r.o[u] = *reinterpret_cast<const float4*>(outp + tok * (long)C + c0);
         }
     };
     auto compute = [&](const Rows& r, int n0) __attribute__((always_inline)) {
-        float xv[FA_S8_G][4], yv[FA_S8_G][4];
-        bool ok[FA_S8_G];
+        float xv[GRP][4], yv[GRP][4];
+        bool ok[GRP];
 #pragma unroll
-        for (int u = 0; u < FA_S8_G; ++u) {
-            ok[u] = n0 + 16 * u < n_end;
+        for (int u = 0; u < GRP; ++u) {
+            ok[u] = n0 + SLOTS * u < n_end;
             xv[u][0] = r.x[u].x; xv[u][1] = r.x[u].y; xv[u][2] = r.x[u].z; xv[u][3] = r.x[u].w;
             yv[u][0] = r.y[u].x; yv[u][1] = r.y[u].y; yv[u][2] = r.y[u].z; yv[u][3] = r.y[u].w;
         }
@@ -291,24 +299,24 @@ __global__ __launch_bounds__(256) void fa_partial_s8_kernel(const float* __restr
             for (int j = 0; j < 4; ++j) {
                 mn[j] = m[j];
 #pragma unroll
-                for (int u = 0; u < FA_S8_G; ++u) mn[j] = fmaxf(mn[j], ok[u] ? xv[u][j] : -INFINITY);
+                for (int u = 0; u < GRP; ++u) mn[j] = fmaxf(mn[j], ok[u] ? xv[u][j] : -INFINITY);
                 f[j] = (mn[j] == -INFINITY) ? 1.f : expf(m[j] - mn[j]);          // (a slot that has seen no token yet keeps its zeros)
                 m[j] = mn[j];
                 ssum[j] *= f[j];
 #pragma unroll
-                for (int l = 0; l < 8; ++l) acc[j][l] *= f[j];
+                for (int l = 0; l < CH; ++l) acc[j][l] *= f[j];
             }
 #pragma unroll
-            for (int u = 0; u < FA_S8_G; ++u)
+            for (int u = 0; u < GRP; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { xv[u][j] = ok[u] ? expf(xv[u][j] - mn[j]) : 0.f; ssum[j] += xv[u][j]; }
         }
 #pragma unroll
-        for (int u = 0; u < FA_S8_G; ++u) {
-            float yh[8];
+        for (int u = 0; u < GRP; ++u) {
+            float yh[CH];
             if (!SOFTMAX) {
                 if (dU && ok[u]) {          // dU = a G q   (fa_bwd_prep_kernel's product, term for term)
-                    const long tok = (long)b * g.N + n0 + 16 * u;
+                    const long tok = (long)b * g.N + n0 + SLOTS * u;
                     *reinterpret_cast<float4*>(dU + tok * C + c0) = make_float4(av[0] * yv[u][0] * xv[u][0], av[1] * yv[u][1] * xv[u][1], av[2] * yv[u][2] * xv[u][2], av[3] * yv[u][3] * xv[u][3]);
                 }
                 if (e_part && ok[u]) {
@@ -322,54 +330,68 @@ __global__ __launch_bounds__(256) void fa_partial_s8_kernel(const float* __restr
                 for (int j = 0; j < 4; ++j) yh[j] = yv[u][j];          // (its weight exp(k - m) is zero past the end)
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) yh[4 + j] = fa_dpp_xor1(yh[j]);
+            for (int j = 0; j < 4; ++j) {
+                yh[4 + j] = fa_dpp_quad_xor<1>(yh[j]);
+                if (CH == 16) { yh[8 + j] = fa_dpp_quad_xor<2>(yh[j]); yh[12 + j] = fa_dpp_quad_xor<3>(yh[j]); }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int l = 0; l < 8; ++l) acc[j][l] = fmaf(xv[u][j], yh[l], acc[j][l]);
+                for (int l = 0; l < CH; ++l) acc[j][l] = fmaf(xv[u][j], yh[l], acc[j][l]);
         }
     };
     Rows ra, rb;
     int n = n_beg + slot;
     request(ra, n);
-    for (; n < n_end; n += 2 * 16 * FA_S8_G) {
-        request(rb, n + 16 * FA_S8_G);
+    for (; n < n_end; n += 2 * SLOTS * GRP) {
+        request(rb, n + SLOTS * GRP);
         compute(ra, n);
-        request(ra, n + 2 * 16 * FA_S8_G);
-        compute(rb, n + 16 * FA_S8_G);
+        request(ra, n + 2 * SLOTS * GRP);
+        compute(rb, n + SLOTS * GRP);
     }
-    // ---- the 16 token slots meet in LDS, added in slot order by thread (q, channel j of the quad): one partial row per workgroup
-    float* mine = &red[slot][q][0];
+    // ---- the token slots meet in LDS, added in slot order by thread (q, channel j of the quad): one partial row per workgroup
+    float* mine = fa_s_red + ((long)slot * LPT + q) * (NACC + 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int l = 0; l < 8; ++l) mine[8 * j + l] = acc[j][l];
-        mine[32 + j] = SOFTMAX ? m[j] : eacc[j];
-        mine[36 + j] = ssum[j];
+        for (int l = 0; l < CH; ++l) mine[CH * j + l] = acc[j][l];
+        mine[4 * CH + j] = SOFTMAX ? m[j] : eacc[j];
+        mine[4 * CH + 4 + j] = ssum[j];
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < C) {
         const int qq = threadIdx.x >> 2, j = threadIdx.x & 3, c = 4 * qq + j;
-        const int jj0 = 4 * (qq & 1), jjo = jj0 ^ 4;
-        float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, t1 = 0.f, mm = -INFINITY;
-        if (SOFTMAX) {
-            for (int sl = 0; sl < 16; ++sl) mm = fmaxf(mm, red[sl][qq][32 + j]);
-        }
-        for (int sl = 0; sl < 16; ++sl) {
-            const float* r = &red[sl][qq][0];
-            float f = 1.f;
-            if (SOFTMAX) { const float ms = r[32 + j]; f = (ms == -INFINITY) ? 0.f : expf(ms - mm); t1 = fmaf(r[36 + j], f, t1); }
-            else t1 += r[32 + j];
+        const int hq = qq % LPH;
+        float tot[CH], t1 = 0.f, mm = -INFINITY;
 #pragma unroll
-            for (int l = 0; l < 8; ++l) tot[l] = SOFTMAX ? fmaf(r[8 * j + l], f, tot[l]) : tot[l] + r[8 * j + l];
+        for (int l = 0; l < CH; ++l) tot[l] = 0.f;
+        if (SOFTMAX) {
+            for (int sl = 0; sl < SLOTS; ++sl) mm = fmaxf(mm, fa_s_red[((long)sl * LPT + qq) * (NACC + 1) + 4 * CH + j]);
+        }
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const float* r = fa_s_red + ((long)sl * LPT + qq) * (NACC + 1);
+            float f = 1.f;
+            if (SOFTMAX) { const float ms = r[4 * CH + j]; f = (ms == -INFINITY) ? 0.f : expf(ms - mm); t1 = fmaf(r[4 * CH + 4 + j], f, t1); }
+            else t1 += r[4 * CH + j];
+#pragma unroll
+            for (int l = 0; l < CH; ++l) tot[l] = SOFTMAX ? fmaf(r[CH * j + l], f, tot[l]) : tot[l] + r[CH * j + l];
         }
         const long orow = ((long)b * NTS + stile) * C + c;
         float* P = ws_P + orow * CH;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) P[l < 4 ? jj0 + l : jjo + (l - 4)] = tot[l];          // local order -> the head's channel order
+        for (int l = 0; l < CH; ++l) P[4 * (hq ^ (l >> 2)) + (l & 3)] = tot[l];          // local order -> the head's channel order
         if (SOFTMAX) { ws_m[orow] = mm; ws_s[orow] = t1; }
         else if (e_part) e_part[orow] = t1;
     }
+}
+template <int CH, bool SOFTMAX>
+static void fa_partial_stream_launch(dim3 grid, hipStream_t s, const float* X, long ldx, const float* Y, long ldy, const float* ysc, float yscale, float* ws_m, float* ws_s,
+                                     float* ws_P, const FaGeom& g, int NT, int NSUB, const float* outp, float* dU, float* e_part) {
+    constexpr int C = 8 * CH, LPT = C / 4, SLOTS = 256 / LPT;
+    constexpr int smem = SLOTS * LPT * (4 * CH + 8 + 1) * (int)sizeof(float);
+    static bool attr = false;
+    if (!attr && smem > 48 * 1024) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_partial_s8_kernel<CH, SOFTMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    hipLaunchKernelGGL((fa_partial_s8_kernel<CH, SOFTMAX>), grid, dim3(256), smem, s, X, ldx, Y, ldy, ysc, yscale, ws_m, ws_s, ws_P, g, NT, NSUB, outp, dU, e_part);
 }
 
 // Combine the token-tile partials of the softmax(K)^T V product: online-softmax rescale by exp(m_t - m).  LPO lanes walk the
@@ -1206,9 +1228,11 @@ extern "C" int mdvit_factoratt_fwd(const float* qkv, const float* w3, const floa
 #define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, true>), dim3(NT, C / GW, B), dim3(256), 0, s, \
                        qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f, ws_m, ws_s, ws_P, g, NT0, NSUB)
         static const bool s8_env = [] { const char* e = getenv("MDVIT_FA_PARTIAL_STREAM"); return !(e && e[0] == '0'); }();
+        static const bool s16_env = [] { const char* e = getenv("MDVIT_FA_PARTIAL_STREAM16"); return !(e && e[0] == '0'); }();
         if (g.Ch == 8 && C == 64 && s8_env)          // the streaming form (MDVIT_FA_PARTIAL_STREAM=0: the LDS / MFMA tiles, A/B)
-            hipLaunchKernelGGL((fa_partial_s8_kernel<true>), dim3(NT, 1, B), dim3(256), 0, s, qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, (const float*)nullptr, 1.f,
-                               ws_m, ws_s, ws_P, g, NT0, NSUB, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+            fa_partial_stream_launch<8, true>(dim3(NT, 1, B), s, qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, nullptr, 1.f, ws_m, ws_s, ws_P, g, NT0, NSUB, nullptr, nullptr, nullptr);
+        else if (g.Ch == 16 && C == 128 && s8_env && s16_env)
+            fa_partial_stream_launch<16, true>(dim3(NT, 1, B), s, qkv + C, (long)3 * C, qkv + 2 * C, (long)3 * C, nullptr, 1.f, ws_m, ws_s, ws_P, g, NT0, NSUB, nullptr, nullptr, nullptr);
         else
         switch (g.Ch) {
             case 8: FA_PART_LAUNCH(8); break;
@@ -1296,9 +1320,11 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
 #define FA_PART_LAUNCH(CHV) hipLaunchKernelGGL((fa_partial_kernel<CHV, false>), dim3(NTS, C / GWp, B), dim3(256), 0, s, \
                        qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr, ws_P, g, NT, NSUBb, out, dU, e ? e_part : (float*)nullptr)
         static const bool s8p_env = [] { const char* e = getenv("MDVIT_FA_PARTIAL_STREAM"); return !(e && e[0] == '0'); }();
+        static const bool s16p_env = [] { const char* e = getenv("MDVIT_FA_PARTIAL_STREAM16"); return !(e && e[0] == '0'); }();
         if (Ch == 8 && C == 64 && s8p_env)
-            hipLaunchKernelGGL((fa_partial_s8_kernel<false>), dim3(NTS, 1, B), dim3(256), 0, s, qkv, (long)3 * C, dout, (long)C, a, g.scale, (float*)nullptr, (float*)nullptr,
-                               ws_P, g, NT, NSUBb, out, dU, e ? e_part : (float*)nullptr);
+            fa_partial_stream_launch<8, false>(dim3(NTS, 1, B), s, qkv, (long)3 * C, dout, (long)C, a, g.scale, nullptr, nullptr, ws_P, g, NT, NSUBb, out, dU, e ? e_part : nullptr);
+        else if (Ch == 16 && C == 128 && s8p_env && s16p_env)
+            fa_partial_stream_launch<16, false>(dim3(NTS, 1, B), s, qkv, (long)3 * C, dout, (long)C, a, g.scale, nullptr, nullptr, ws_P, g, NT, NSUBb, out, dU, e ? e_part : nullptr);
         else
         switch (Ch) {
             case 8: FA_PART_LAUNCH(8); break;
