@@ -784,6 +784,127 @@ __global__ __launch_bounds__(256) void fa_bwd_apply_s8_kernel(const float* __res
     }
 }
 
+// ---- bwd 5 at Ch = 16, C = 128 as a stream (round 6) ---------------------------------------------------------------------------------------------
+// The layout of fa_bwd_apply_s8_kernel with 32 lanes x float4 per token (two tokens per wave) and a head on the four lanes of a quad.  A lane's matrix rows / columns are
+// 192 values here -- more than the register file leaves next to two token sets in flight -- so they live in an LDS table [48 float4 slots][32 lane classes]: a wave-wide
+// ds_read_b128 of one slot is 512 contiguous bytes (conflict-free; the second token's lanes read the same addresses: broadcast).  48 reads per token and lane price out at
+// ~2.6x the HBM rate of the kernel's eight streams; the three 16-vectors of the head come by quad-permute DPP.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fa_bwd_apply_s16_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+                                                               const float* __restrict__ U, const float* __restrict__ dVc,
+                                                               const float* __restrict__ Mmat, const float* __restrict__ a,
+                                                               const float* __restrict__ kmax, const float* __restrict__ ksum,
+                                                               const float* __restrict__ dMp, int NTS,
+                                                               float* __restrict__ dqkv, FaGeom g, int tokens_per_block) {
+    constexpr int C = 128, CH = 16, C3 = 384, LPT = 32, SLOTS = 8;
+    __shared__ __attribute__((aligned(16))) float sM[C * CH], sD[C * CH];
+    __shared__ __attribute__((aligned(16))) float4 tab[48][LPT];
+    __shared__ float s_tc[C];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < C * CH; i += 256) {
+        sM[i] = Mmat[(long)b * C * CH + i];
+        float dm = 0.f;
+        const float* pp = dMp + ((long)b * NTS) * C * CH + i;
+        const long rs = (long)C * CH;
+        for (int t0 = 0; t0 < NTS; t0 += 8) {          // (the summation order of fa_bwd_apply_kernel: eight independent loads at a time)
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = t0 + u; v8[u] = pp[(long)(t < NTS ? t : NTS - 1) * rs]; if (t >= NTS) v8[u] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dm += v8[u];
+        }
+        sD[i] = dm;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float tc = 0.f;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) tc = fmaf(sD[threadIdx.x * CH + e], sM[threadIdx.x * CH + e], tc);
+        s_tc[threadIdx.x] = tc;
+    }
+    // the table: slots 0-15 M[c0 + j][local 4 l4 ..], 16-31 dM[c0 + j][local 4 l4 ..] (slot = 4 j + l4), 32-47 dM[head's channel e(l)][my four columns] (slot = 32 + l);
+    // local index l <-> the head's channel e(l) = 4 ((q % 4) ^ (l / 4)) + l % 4
+    for (int i = threadIdx.x; i < 48 * LPT; i += 256) {
+        const int slot = i / LPT, qq = i % LPT, hl = qq & 3, hb = (qq >> 2) * CH, cc0 = 4 * qq;
+        float4 v;
+        if (slot < 32) {
+            const float* src = (slot < 16 ? sM : sD) + (cc0 + ((slot & 15) >> 2)) * CH + 4 * (hl ^ (slot & 3));
+            v = *reinterpret_cast<const float4*>(src);
+        } else {
+            const int l = slot - 32, e = 4 * (hl ^ (l >> 2)) + (l & 3);
+            v = *reinterpret_cast<const float4*>(sD + (hb + e) * CH + 4 * hl);
+        }
+        tab[slot][qq] = v;
+    }
+    __syncthreads();
+    const int q = threadIdx.x % LPT, slot = threadIdx.x / LPT;
+    const int c0 = 4 * q;
+    const long ci = (long)b * C + c0;
+    const float4 a4 = a ? *reinterpret_cast<const float4*>(a + ci) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 km4 = *reinterpret_cast<const float4*>(kmax + ci);
+    float4 is4 = *reinterpret_cast<const float4*>(ksum + ci);
+    is4 = make_float4(1.0f / is4.x, 1.0f / is4.y, 1.0f / is4.z, 1.0f / is4.w);
+    const float4 tc4 = *reinterpret_cast<const float4*>(s_tc + c0);
+    const float inv_scale = 1.0f / g.scale;
+    const int n_beg = blockIdx.x * tokens_per_block, n_end = min(g.N, n_beg + tokens_per_block);
+    struct Rows { float4 g, k, v, u, c; };
+    auto request = [&](Rows& r, int n) __attribute__((always_inline)) {
+        const long tok = (long)b * g.N + min(n, g.N - 1);
+        r.g = *reinterpret_cast<const float4*>(dout + tok * C + c0);
+        r.k = *reinterpret_cast<const float4*>(qkv + tok * C3 + C + c0);
+        r.v = *reinterpret_cast<const float4*>(qkv + tok * C3 + 2 * C + c0);
+        r.u = *reinterpret_cast<const float4*>(U + tok * C + c0);
+        r.c = *reinterpret_cast<const float4*>(dVc + tok * C + c0);
+    };
+    auto compute = [&](const Rows& r, int n) __attribute__((always_inline)) {
+        float dfa[16], vv[16], pp[16];
+        dfa[0] = g.scale * a4.x * r.g.x; dfa[1] = g.scale * a4.y * r.g.y; dfa[2] = g.scale * a4.z * r.g.z; dfa[3] = g.scale * a4.w * r.g.w;
+        vv[0] = r.v.x; vv[1] = r.v.y; vv[2] = r.v.z; vv[3] = r.v.w;
+        pp[0] = expf(r.k.x - km4.x) * is4.x; pp[1] = expf(r.k.y - km4.y) * is4.y; pp[2] = expf(r.k.z - km4.z) * is4.z; pp[3] = expf(r.k.w - km4.w) * is4.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dfa[4 + j] = fa_dpp_quad_xor<1>(dfa[j]); dfa[8 + j] = fa_dpp_quad_xor<2>(dfa[j]); dfa[12 + j] = fa_dpp_quad_xor<3>(dfa[j]);
+            vv[4 + j] = fa_dpp_quad_xor<1>(vv[j]); vv[8 + j] = fa_dpp_quad_xor<2>(vv[j]); vv[12 + j] = fa_dpp_quad_xor<3>(vv[j]);
+            pp[4 + j] = fa_dpp_quad_xor<1>(pp[j]); pp[8 + j] = fa_dpp_quad_xor<2>(pp[j]); pp[12 + j] = fa_dpp_quad_xor<3>(pp[j]);
+        }
+        float dq[4], dk[4], dv[4] = {0.f, 0.f, 0.f, 0.f};
+        const float uu[4] = {r.u.x, r.u.y, r.u.z, r.u.w}, cc[4] = {r.c.x, r.c.y, r.c.z, r.c.w}, tcv[4] = {tc4.x, tc4.y, tc4.z, tc4.w};
+        // (the table is re-read from LDS for every token: hoisted out of the token loop -- 192 registers -- it spills)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int l4 = 0; l4 < 4; ++l4) {
+                const float4 m4 = tab[4 * j + l4][q], d4 = tab[16 + 4 * j + l4][q];
+                s1 = fmaf(dfa[4 * l4 + 0], m4.x, s1); s1 = fmaf(dfa[4 * l4 + 1], m4.y, s1); s1 = fmaf(dfa[4 * l4 + 2], m4.z, s1); s1 = fmaf(dfa[4 * l4 + 3], m4.w, s1);
+                s2 = fmaf(vv[4 * l4 + 0], d4.x, s2); s2 = fmaf(vv[4 * l4 + 1], d4.y, s2); s2 = fmaf(vv[4 * l4 + 2], d4.z, s2); s2 = fmaf(vv[4 * l4 + 3], d4.w, s2);
+            }
+            dq[j] = fmaf(dfa[j] * inv_scale, uu[j], s1);
+            dk[j] = pp[j] * (s2 - tcv[j]);
+        }
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            const float4 dc = tab[32 + l][q];
+            dv[0] = fmaf(pp[l], dc.x, dv[0]); dv[1] = fmaf(pp[l], dc.y, dv[1]); dv[2] = fmaf(pp[l], dc.z, dv[2]); dv[3] = fmaf(pp[l], dc.w, dv[3]);
+        }
+        if (n < n_end) {
+            float* drow = dqkv + ((long)b * g.N + n) * C3 + c0;
+            *reinterpret_cast<float4*>(drow) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            *reinterpret_cast<float4*>(drow + C) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+            *reinterpret_cast<float4*>(drow + 2 * C) = make_float4(dv[0] + cc[0], dv[1] + cc[1], dv[2] + cc[2], dv[3] + cc[3]);
+        }
+    };
+    Rows ra, rb;
+    int n = n_beg + slot;
+    request(ra, n);
+    for (; n < n_end; n += 2 * SLOTS) {
+        request(rb, n + SLOTS);
+        compute(ra, n);
+        request(ra, n + 2 * SLOTS);
+        compute(rb, n + SLOTS);
+    }
+}
+
 // role 0: dq = a*scale*G . KV^T (+ G*a*U);  1: dk = P * (v . dM^T - t);  2: dv = P . dM + conv^T(dU)      -- fa_bwd_apply3_kernel's wave roles
 template <int CH, int ROLE>
 __device__ __forceinline__ void fa_apply3_tiles(const float* __restrict__ dout, const float* __restrict__ qkv, const float* __restrict__ U, const float* __restrict__ dVc,
@@ -1382,6 +1503,15 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         while (tpbk > 128 && (long)cdiv(g.N, tpbk) * B < 512) tpbk /= 2;
         if (g_fa_apply_tiles > 0) tpbk = 32 * g_fa_apply_tiles;
         hipLaunchKernelGGL(fa_bwd_apply_s8_kernel, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
+        MDVIT_LAUNCH_CHECK();
+        return MDVIT_OK;
+    }
+    static const bool s16_env = [] { const char* e = getenv("MDVIT_FA_APPLY_STREAM16"); return !(e && e[0] == '0'); }();
+    if (Ch == 16 && C == 128 && s8_env && s16_env && g_fa_apply_mode == 0) {
+        int tpbk = 512;
+        while (tpbk > 128 && (long)cdiv(g.N, tpbk) * B < 512) tpbk /= 2;
+        if (g_fa_apply_tiles > 0) tpbk = 32 * g_fa_apply_tiles;
+        hipLaunchKernelGGL(fa_bwd_apply_s16_kernel, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
         MDVIT_LAUNCH_CHECK();
         return MDVIT_OK;
     }
