@@ -383,6 +383,11 @@ typedef struct MdvitBlockDesc {
     const float* a_pre;                        /* optional (round 5): the adapter's output a [B, C] for `label`, computed ahead by mdvit_da_fwd_many -- the forward then
                                                 * launches no adapter kernel and the backward reads a from HERE (hand the same pointer to mdvit_block_bwd; the slot of a
                                                 * in `save` stays unused).  NULL: the block computes a itself. */
+    int32_t attn_kind;                         /* 0: SerialBlock_adapt (ConvPosEnc + factorised attention with ConvRelPosEnc, mdvit.py:346-361).
+                                                * 1 (round 6): Block_adapt of the DeiT trunk of TransFuse_S_adapt (vision_transformer.py:191-211 with Attention_Sup,
+                                                *    :125-169): x + proj(a * softmax(q k^T / sqrt(d)) v) of LN1(x), then x + Mlp(LN2(x)) -- no ConvPosEnc, no crpe windows
+                                                *    (cpe_* / w3..b7 NULL, s3 = s5 = s7 = 0); the attention runs on mdvit_sdpa_mfma_fwd / _bwd, so H * W == 256 tokens,
+                                                *    C == 64 heads, heads <= 6.  Same kernels in the same order as the operator-level path of mdvit_amd/transfuse.py. */
 } MdvitBlockDesc;
 /* Gradient outputs of the backward.  The sixteen "weight-class" outputs (cpe, qkv, crpe windows, proj, fc1, fc2) are overwritten
  * (accumulate == 0: fresh buffers) or added into (accumulate != 0: gradient buckets; the weight-gradient kernels then run on the side

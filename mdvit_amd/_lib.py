@@ -78,7 +78,7 @@ class BlockDesc(C.Structure):
                 + [(n, vp) for n in ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",
                                      "proj_w", "proj_b", "n2_g", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
                 + [(n, vp) for n in ("qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "fc1_p", "fc2_p", "fc2t_p", "fc1t_p", "qkv_p", "proj_p", "projt_p", "qkvt_p")]
-                + [("store_bf16", i32), ("a_pre", vp)])
+                + [("store_bf16", i32), ("a_pre", vp), ("attn_kind", i32)])
 
 
 BLOCK_PARAMS = ("cpe_w", "cpe_b", "n1_g", "n1_b", "qkv_w", "qkv_b", "w3", "b3", "w5", "b5", "w7", "b7", "da_w1", "da_b1", "da_w2", "da_b2",

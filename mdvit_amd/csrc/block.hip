@@ -39,18 +39,26 @@ inline bool mlp_rc16(const MdvitBlockDesc& d) {
 inline bool hbf16(const MdvitBlockDesc& d) { return d.store_bf16 && mlp_rc16(d); }
 
 struct Saved {        // the block's saved-for-backward tensors inside the caller's `save` buffer
-    float *x1, *mean1, *rstd1, *cur1, *qkv, *a, *att, *U, *kmax, *ksum, *Mmat, *x2, *mean2, *rstd2, *cur2, *h, *u;
+    float *x1, *mean1, *rstd1, *cur1, *qkv, *a, *att, *U, *kmax, *ksum, *Mmat, *x2, *mean2, *rstd2, *cur2, *h, *u, *lse;
 };
+
+inline bool sdpa_kind(const MdvitBlockDesc& d) { return d.attn_kind == 1; }
 
 void layout_saved(const MdvitBlockDesc& d, Arena& A, Saved& s) {
     const long T = (long)d.B * d.H * d.W, C = d.C, Ch = d.C / d.heads;
     const int mode = mlp_mode(d);
-    s.x1 = A.take(T * C); s.mean1 = A.take(T); s.rstd1 = A.take(T); s.cur1 = A.take(T * C);
+    s.lse = nullptr;
+    s.x1 = sdpa_kind(d) ? nullptr : A.take(T * C);          // (Block_adapt: no ConvPosEnc -- x1 IS the block's input, which the caller keeps)
+    s.mean1 = A.take(T); s.rstd1 = A.take(T); s.cur1 = A.take(T * C);
     s.qkv = A.take(T * 3 * C);
     s.a = d.label ? A.take((long)d.B * C) : nullptr;
     if (d.label && d.a_pre) s.a = const_cast<float*>(d.a_pre);          // computed ahead for every adapter of the network (mdvit_da_fwd_many): the slot above stays unused
-    s.att = A.take(T * C); s.U = A.take(T * C);
+    s.att = A.take(T * C);
+    if (sdpa_kind(d)) { s.U = s.kmax = s.ksum = s.Mmat = nullptr; s.lse = A.take((long)d.B * d.heads * d.H * d.W); }
+    else {
+    s.U = A.take(T * C);
     s.kmax = A.take((long)d.B * C); s.ksum = A.take((long)d.B * C); s.Mmat = A.take((long)d.B * C * Ch);
+    }
     s.x2 = A.take(T * C); s.mean2 = A.take(T); s.rstd2 = A.take(T); s.cur2 = A.take(T * C);
     s.h = mode != MLP_RC ? A.take(hbf16(d) ? (T * d.hidden + 1) / 2 : T * d.hidden) : nullptr;
     s.u = mode == MLP_STORED ? A.take(T * d.hidden) : nullptr;
@@ -169,8 +177,9 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
     const int mode = mlp_mode(d);
     Saved sv;
     layout_saved(d, SV, sv);
-    // x1 = x + dwconv3x3(x) + bias            (ConvPosEnc, mpvit.py:239-248)
-    BLK_RUN(mdvit_dwconv3x3_fwd(x, d.cpe_w, d.cpe_b, sv.x1, B, H, W, C, 1, 1, s));
+    // x1 = x + dwconv3x3(x) + bias            (ConvPosEnc, mpvit.py:239-248)        [Block_adapt: x1 = x]
+    if (sdpa_kind(d)) sv.x1 = const_cast<float*>(x);
+    else BLK_RUN(mdvit_dwconv3x3_fwd(x, d.cpe_w, d.cpe_b, sv.x1, B, H, W, C, 1, 1, s));
     // cur1 = LN1(x1);  qkv = cur1 Wqkv^T + b                    (mdvit.py:286-288)
     const bool lin_rc = d.precision == 1 && (C == 64 || C == 128) && d.qkv_p && d.proj_p && M >= 1024;       // the streaming short-K Linear (mlp_rc.hip)
     static const bool ln_prologue = [] { const char* e = getenv("MDVIT_LN_PROLOGUE"); return !(e && e[0] == '0'); }();
@@ -191,7 +200,10 @@ int block_fwd(const MdvitBlockDesc& d, const float* x, float* y, Arena& SV, Aren
     }
     // a = softmax_heads(MLP(one_hot));  att = a * (scale * q (softmax_tokens(k)^T v) + q * crpe(v))      (mdvit.py:293-304)
     if (d.label && !d.a_pre) BLK_RUN(mdvit_da_fwd(d.label, d.da_w1, d.da_b1, d.da_w2, d.da_b2, sv.a, B, d.D, d.da_hidden, C, d.heads, s));
-    {
+    if (sdpa_kind(d)) {
+        // att = a * softmax(q k^T / sqrt(64)) v on the fp32 matrix cores, the row log-sum-exp kept for the backward      (vision_transformer.py:148-163)
+        BLK_RUN(mdvit_sdpa_mfma_fwd(sv.qkv, sv.a, sv.att, sv.lse, B, N_tok, C, d.heads, s));
+    } else {
         const size_t fab = mdvit_factoratt_ws_bytes(B, N_tok, C, d.heads);
         void* faws = A.take_bytes(fab);
         BLK_RUN(mdvit_factoratt_fwd(sv.qkv, d.w3, d.b3, d.w5, d.b5, d.w7, d.b7, sv.a, sv.att, sv.U, sv.kmax, sv.ksum, sv.Mmat, faws, fab, B, H, W, C, d.heads,
@@ -266,6 +278,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
     hipStream_t s = (hipStream_t)st.main, side = s;
     Saved sv;
     layout_saved(d, SV, sv);
+    if (sdpa_kind(d)) sv.x1 = const_cast<float*>(x);
     const uint32_t* seed = d.drop_p > 0.f ? d.drop_seed : nullptr;
     const bool fast_ln = C == 64 || C == 128 || C == 320 || C == 512;
 
@@ -404,9 +417,16 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
     }
     // ---- attention core + adapter ---------------------------------------------------------------------------------------------------
+    float* e = !d.label ? nullptr : G.e_out ? G.e_out : A.take((long)B * C);      // (e_out: the caller runs every adapter's backward at once, mdvit_da_bwd_many)
+    float* dqkv = nullptr;
+    if (sdpa_kind(d)) {
+        // Attention_Sup's core backward (sdpa.hip): the probabilities are recomputed from the row log-sum-exp; e = sum_n g * att for the adapter
+        dqkv = S.take(T * 3 * C);
+        float* delta = A.take(2L * B * d.heads * N_tok);
+        BLK_RUN(mdvit_sdpa_mfma_bwd(tmp, sv.qkv, sv.lse, sv.att, sv.a, dqkv, e, delta, B, N_tok, C, d.heads, s));
+    } else {
     const size_t fab = mdvit_factoratt_ws_bytes(B, N_tok, C, d.heads);
     void* faws = S.take_bytes(fab);            // holds dU, which the deferred window-weight gradients read
-    float* e = !d.label ? nullptr : G.e_out ? G.e_out : A.take((long)B * C);      // (e_out: the caller runs every adapter's backward at once, mdvit_da_bwd_many)
     if (dgrad_only && G.aux_first && d.label) {
         // the first adapter of the network in the data-gradient-only sweep: e = sum_n g * att alone, the adapter's (negated) gradient, and
         // nothing is handed on -- nothing below carries an adapter (ops._FactorAtt, aux_first)
@@ -419,7 +439,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
         return MDVIT_OK;
     }
-    float* dqkv = S.take(T * 3 * C);
+    dqkv = S.take(T * 3 * C);
     {
         // window-weight gradients: deferred to the side stream when they accumulate into buckets (they read dU in the SAME workspace and v);
         // otherwise produced by the backward call itself, into the fresh buffers
@@ -433,6 +453,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
             BLK_RUN(mdvit_factoratt_wgrad(sv.qkv, faws, fab, G.w3, G.b3, G.w5, G.b5, G.w7, G.b7, B, H, W, C, d.heads, d.s3, d.s5, d.s7, 1, side));
         }
         if (inl && acc) return mdvit_set_error(MDVIT_E_SHAPE, "block_bwd: accumulating window-weight gradients need the side stream");
+    }
     }
     if (d.label && !G.e_out) {
         const size_t dab = mdvit_da_ws_bytes(B, d.da_hidden, C);
@@ -455,7 +476,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
     }
     // ---- LN1 (+ dx2 along the residual branch) ------------------------------------------------------------------------------------
-    float* dx1 = S.take(T * C);
+    float* dx1 = (sdpa_kind(d) && dx) ? dx : S.take(T * C);          // (Block_adapt: no ConvPosEnc below -- this IS the block's input gradient)
     {
         const bool lnw = want_w || !fast_ln;
         const size_t pb = lnw ? mdvit_partials_ws_bytes(2 * C) : 0;
@@ -481,6 +502,7 @@ int block_bwd(const MdvitBlockDesc& d, const MdvitBlockGrads& G, const MdvitBloc
         }
     }
     // ---- ConvPosEnc -----------------------------------------------------------------------------------------------------------------
+    if (sdpa_kind(d)) return MDVIT_OK;
     if (dx) BLK_RUN(mdvit_dwconv3x3_bwd(dx1, x, d.cpe_w, dx, nullptr, nullptr, nullptr, 0, B, H, W, C, 1, 1, 0, s));
     if (want_w) {
         const size_t pb = mdvit_partials_ws_bytes(10 * C);
@@ -496,8 +518,12 @@ int check_desc(const MdvitBlockDesc& d, const char* what) {
                     "%s: bad geometry B=%d H=%d W=%d C=%d heads=%d hidden=%d", what, d.B, d.H, d.W, d.C, d.heads, d.hidden);
     MDVIT_CHECK_ARG(d.precision == 0 || d.precision == 1, MDVIT_E_SHAPE, "%s: precision %d (0: fp32, 1: bf16x3)", what, d.precision);
     MDVIT_CHECK_ARG(d.ln_groups >= 1 && ((long)d.B * d.H * d.W) % d.ln_groups == 0, MDVIT_E_SHAPE, "%s: %d LayerNorm groups do not divide the rows", what, d.ln_groups);
-    MDVIT_CHECK_ARG(d.cpe_w && d.cpe_b && d.n1_g && d.n1_b && d.qkv_w && d.w3 && d.b3 && d.w5 && d.b5 && d.w7 && d.b7 && d.proj_w && d.proj_b && d.n2_g && d.n2_b && d.fc1_w &&
-                        d.fc1_b && d.fc2_w && d.fc2_b, MDVIT_E_SHAPE, "%s: null parameter", what);
+    MDVIT_CHECK_ARG(d.attn_kind == 0 || d.attn_kind == 1, MDVIT_E_SHAPE, "%s: attn_kind %d (0: SerialBlock_adapt, 1: the DeiT Block_adapt)", what, d.attn_kind);
+    if (d.attn_kind == 1)
+        MDVIT_CHECK_ARG(d.H * d.W == 256 && d.heads <= 6 && d.C == 64 * d.heads && d.drop_p == 0.f && !d.rowscale1 && !d.rowscale2 && !d.store_bf16, MDVIT_E_SHAPE,
+                        "%s: attn_kind 1 is built for 256 tokens, head dimension 64, <= 6 heads, no dropout (H=%d W=%d C=%d heads=%d)", what, d.H, d.W, d.C, d.heads);
+    MDVIT_CHECK_ARG((d.attn_kind == 1 || (d.cpe_w && d.cpe_b && d.w3 && d.b3 && d.w5 && d.b5 && d.w7 && d.b7)) && d.n1_g && d.n1_b && d.qkv_w && d.proj_w && d.proj_b && d.n2_g &&
+                        d.n2_b && d.fc1_w && d.fc1_b && d.fc2_w && d.fc2_b, MDVIT_E_SHAPE, "%s: null parameter", what);
     MDVIT_CHECK_ARG(!d.label || (d.da_w1 && d.da_b1 && d.da_w2 && d.da_b2 && d.D > 0 && d.da_hidden > 0), MDVIT_E_SHAPE, "%s: a domain label needs the adapter's parameters", what);
     return MDVIT_OK;
 }
@@ -560,8 +586,9 @@ extern "C" int mdvit_block_bwd(const MdvitBlockDesc* d, const MdvitBlockGrads* g
     MDVIT_CHECK_ARG(ws_bytes >= need && ws_side_bytes >= need_side, MDVIT_E_WORKSPACE,
                     "block_bwd: workspace too small: need %zu + %zu bytes (mdvit_block_bwd_ws_bytes), got %zu + %zu", need, need_side, ws_bytes, ws_side_bytes);
     if (!g->dgrad_only) {
-        MDVIT_CHECK_ARG(g->cpe_w && g->cpe_b && g->n1_g && g->n1_b && g->qkv_w && g->w3 && g->b3 && g->w5 && g->b5 && g->w7 && g->b7 && g->proj_w && g->proj_b && g->n2_g &&
-                            g->n2_b && g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b && (!d->qkv_b || g->qkv_b), MDVIT_E_SHAPE, "block_bwd: null gradient output");
+        MDVIT_CHECK_ARG((d->attn_kind == 1 || (g->cpe_w && g->cpe_b && g->w3 && g->b3 && g->w5 && g->b5 && g->w7 && g->b7)) && g->n1_g && g->n1_b && g->qkv_w && g->proj_w &&
+                            g->proj_b && g->n2_g && g->n2_b && g->fc1_w && g->fc1_b && g->fc2_w && g->fc2_b && (!d->qkv_b || g->qkv_b), MDVIT_E_SHAPE,
+                        "block_bwd: null gradient output");
     }
     MDVIT_CHECK_ARG(!d->label || g->e_out || (g->da_w1 && g->da_b1 && g->da_w2 && g->da_b2), MDVIT_E_SHAPE, "block_bwd: the adapter's gradient outputs are missing");
     MDVIT_CHECK_ARG(d->precision == 0 || (d->qkv_wt && d->proj_wt && (mlp_mode(*d) == MLP_RC || (mlp_rc16(*d) && d->fc2t_p && d->fc1t_p) || (d->fc1_wt && d->fc2_wt))), MDVIT_E_SHAPE,

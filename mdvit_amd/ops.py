@@ -2715,6 +2715,7 @@ def _block_desc(x, label, rs1, rs2, meta, keys, params, backward, a_pre=None):
     d.a_pre = _p(a_pre)
     d.B, d.H, d.W, d.C, d.heads, d.hidden = B, H, W_, Cn, heads, params[20].shape[0]
     d.s3, d.s5, d.s7 = splits
+    d.attn_kind = int(meta[8]) if len(meta) > 8 else 0          # 1: the DeiT Block_adapt of TransFuse (include/mdvit_hip.h: MdvitBlockDesc.attn_kind)
     d.ln_groups = ln_groups
     d.precision = min(_gemm_precision, 1)
     d.store_bf16 = int(_gemm_precision == 2 and _store_bf16)      # the mixed mode: h / du of the C = 128 MLP as bf16 (include/mdvit_hip.h: MdvitBlockDesc.store_bf16)
@@ -2857,6 +2858,20 @@ def serial_block(x, label, rs1, rs2, meta, params):
     params in _lib.BLOCK_PARAMS order (the adapter's four are None without a domain label)."""
     a_pre = _da_lookup(params[14], x.shape[0]) if label is not None else None          # params[14] = da_w2
     return _SerialBlock.apply(_c(x), None if label is None else _c(label.float()), rs1, rs2, meta, a_pre, *params)
+
+
+_deit_block_entry = os.environ.get("MDVIT_DEIT_BLOCK_ENTRY", "1") != "0"      # TransFuse's DeiT blocks through the C-level block entry (0: the operator-level path, A/B)
+
+
+def deit_block_entry_ok(x, heads, params) -> bool:
+    """the C-level entry covers this Block_adapt (vision_transformer.py:191-211): 256 tokens, head dimension 64, <= 6 heads (the fp32-matrix-core attention of sdpa.hip),
+    the parity arithmetic (fp32 / bf16x3), contiguous fp32 parameters"""
+    B, N, Cn = x.shape
+    return (_block_entry and _deit_block_entry and _use_mfma_sdpa_entry and x.is_cuda and torch.is_grad_enabled() and N == 256 and heads <= 6 and Cn == heads * 64
+            and _gemm_precision <= 1 and all(p is None or (p.is_contiguous() and p.dtype == torch.float32) for p in params))
+
+
+_use_mfma_sdpa_entry = os.environ.get("MDVIT_SDPA_MFMA", "1") != "0"
 
 
 def block_entry_ok(Cn, hidden, params) -> bool:

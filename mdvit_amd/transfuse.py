@@ -642,10 +642,20 @@ class Block_adapt(nn.Module):                                      # vision_tran
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, domain_label):
+        # Round 6: the whole block as ONE C call per pass (csrc/block.hip, MdvitBlockDesc.attn_kind = 1: the kernels of the operator-level path below, in its order -- LN1,
+        # qkv, adapter, softmax(q k^T) v on sdpa.hip, proj + residual, LN2, the two MLP products -- enqueued from C with the weight-gradient work forked onto the side
+        # stream): 14 autograd nodes, ~25 library calls and as many torch.empty per block and step become 2 (the TransFuse step is bound by the host's enqueue time on the
+        # slower hosts of the pool: profiles/r06_host_cprofile_transfuse.txt)
+        a, m = self.attn, self.mlp
+        d0, d2 = a.domain_layer[0], a.domain_layer[2]
+        params = [None, None, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, None, None, None, None, None, None, d0.weight, d0.bias, d2.weight, d2.bias,
+                  a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+        if domain_label is not None and ops.deit_block_entry_ok(x, a.num_heads, params) and ops.block_entry_ok(x.shape[-1], m.fc1.weight.shape[0], params):
+            meta = (16, 16, a.num_heads, (0, 0, 0), float(self.norm1.eps), 0.0, 1, False, 1)
+            return ops.serial_block(x, domain_label, None, None, meta, params)
         cur, x = self.norm1.fork(x)
         x = self.attn(cur, domain_label, x)
         cur, x = self.norm2.fork(x)
-        m = self.mlp
         return ops.mlp_residual(cur, x, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, None, 0.0, x.shape[1])
 
 
