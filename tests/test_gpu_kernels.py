@@ -1212,17 +1212,18 @@ def _attn_ref(qkv, crpe, a, H, W, heads):
 
 
 @pytest.mark.parametrize("B,H,W,C,use_a", [(2, 16, 16, 64, True), (1, 9, 14, 128, True), (2, 8, 8, 320, True), (2, 4, 4, 512, True), (2, 12, 12, 64, False), (1, 40, 40, 64, True),
-                                              (1, 64, 64, 64, True), (1, 70, 66, 128, False)])
+                                              (1, 64, 64, 64, True), (1, 70, 66, 128, False), (3, 33, 47, 64, True), (2, 50, 50, 128, True)])
 def test_factor_att_core(B, H, W, C, use_a):
     """attention core + domain adapter node: forward, dqkv, crpe gradients and the adapter's parameter gradients
-    (the last two shapes have >= 4096 tokens per image: the packed two-row stencil tiles of conv_tile.h, the second with ragged tile edges)"""
+    (shapes 7 / 8 have >= 4096 tokens per image: the packed two-row stencil tiles of conv_tile.h, the second with ragged tile edges; the last two walk several
+    64-token tiles per workgroup with a ragged last one on three / two images: round 6's streaming kernels fa_partial_s8 / fa_bwd_apply_s8 / _s16 at C = 64 / 128)"""
     from mdvit_amd import ops
     heads, Ch, N, hid = 8, C // 8, H * W, max(C // 2, 4)
     qkv = rnd(B, N, 3 * C, seed=130, scale=1.5)
     crpe = [rnd(2 * Ch, 1, 3, 3, seed=131, scale=0.3), rnd(2 * Ch, seed=132, scale=0.1), rnd(3 * Ch, 1, 5, 5, seed=133, scale=0.2), rnd(3 * Ch, seed=134, scale=0.1),
             rnd(3 * Ch, 1, 7, 7, seed=135, scale=0.15), rnd(3 * Ch, seed=136, scale=0.1)]
     da = [rnd(hid, 4, seed=137, scale=1.5), rnd(hid, seed=138, scale=0.1), rnd(C, hid, seed=139, scale=3 / hid ** 0.5), rnd(C, seed=140, scale=0.1)]
-    lab = F.one_hot(torch.tensor([2, 0][:B]), 4).float()
+    lab = F.one_hot(torch.tensor([2, 0, 3][:B]), 4).float()
     g = rnd(B, N, C, seed=141)
     ins = [qkv] + crpe + (da if use_a else [])
 
