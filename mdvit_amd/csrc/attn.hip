@@ -1298,7 +1298,11 @@ size_t fa_ws_floats(int B, int N, int C, int heads) {
 // 64-token tiles a workgroup of the partial kernels walks.  A function of the IMAGE's token count alone -- never of the batch: an image's arithmetic (which
 // tiles meet in which partial row, in which order) must not depend on how many images share the launch, or the domain-batched forward stops being the
 // per-domain forwards bit for bit (tests/test_gpu_model.py: test_bench_step_fused_forward_equals_per_domain_at_512).
-int fa_nsub(int NT, int /*groups*/, int /*B*/) { return NT >= 128 ? 8 : (NT >= 64 ? 4 : (NT >= 16 ? 2 : 1)); }
+int fa_nsub(int NT, int /*groups*/, int /*B*/) {
+    static const int env = [] { const char* e = getenv("MDVIT_FA_NSUB"); return e ? atoi(e) : 0; }();          // (experiments only: a fixed number of tiles per workgroup)
+    if (env > 0) return env < NT ? env : NT;
+    return NT >= 128 ? 8 : (NT >= 64 ? 4 : (NT >= 16 ? 2 : 1));
+}
 
 int quad_grid(long work_quads, int QC, int max_blocks) {
     // smallest grid >= wanted with (grid*256) % QC == 0
