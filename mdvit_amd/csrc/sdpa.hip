@@ -118,24 +118,36 @@ __global__ __launch_bounds__(256) void sdpa_mfma_fwd_kernel(const float* __restr
 }
 
 // delta[b,h,n] = sum_d g out over the head's channels; e_part[b][j][c] = sum over the j-th quarter of the tokens of g out (the rows kernel
-// adds the four quarters in order: e[b,c] = sum_n g out, the adapter's gradient carrier).  Workgroup = (sample, token quarter), 4 wavefronts, lane = d.
+// adds the four quarters in order: e[b,c] = sum_n g out, the adapter's gradient carrier).  Workgroup = (sample, token quarter), 4 wavefronts.
+// Round 6: the products are formed with lane = channel (coalesced 256-byte head rows; the per-channel e sums need no exchange), parked in LDS [token][65] and the
+// per-token sums are taken with lane = TOKEN (a conflict-free walk of its row) -- the first form reduced every (token, head) over the wave with six dependent
+// ds_bpermute rounds, 16 tokens x 6 heads in series per wave: 76 us for 25 MB on 128 workgroups (8 launches per TransFuse step on the DeiT branch's chain).
 __global__ __launch_bounds__(256) void sdpa_prep_kernel(const float* __restrict__ g, const float* __restrict__ out, float* __restrict__ delta,
                                                         float* __restrict__ e_part, int C, int heads) {
     __shared__ float s_e[4][6 * 64];
+    __shared__ float s_p[64][65];          // one head at a time: [token of the quarter][channel], 65-float rows
     const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int TQ = SN / 4;             // 64 tokens per workgroup
     float ecol[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int n = j * (SN / 4) + wave; n < (j + 1) * (SN / 4); n += 4) {
-        const float* gr = g + ((long)b * SN + n) * C;
-        const float* orow = out + ((long)b * SN + n) * C;
+    for (int h = 0; h < heads; ++h) {
+        float pv[TQ / 4];
 #pragma unroll
-        for (int h = 0; h < 6; ++h) {
-            if (h >= heads) break;
-            float p = gr[h * SD + lane] * orow[h * SD + lane];
-            ecol[h] += p;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
-            if (lane == 0) delta[((long)b * heads + h) * SN + n] = p;
+        for (int i = 0; i < TQ / 4; ++i) {          // this wave's 16 tokens of the quarter: all loads in flight
+            const long row = ((long)b * SN + j * TQ + wave + 4 * i) * C + h * SD + lane;
+            pv[i] = g[row] * out[row];
         }
+        float ec = 0.f;
+#pragma unroll
+        for (int i = 0; i < TQ / 4; ++i) { ec += pv[i]; s_p[wave + 4 * i][lane] = pv[i]; }          // (tokens in increasing order per wave, as before)
+        ecol[h] = ec;
+        __syncthreads();
+        if (threadIdx.x < TQ) {                     // lane = token: the 64 channels of its row, in channel order
+            float d = 0.f;
+#pragma unroll 16
+            for (int c = 0; c < SD; ++c) d += s_p[threadIdx.x][c];
+            delta[((long)b * heads + h) * SN + j * TQ + threadIdx.x] = d;
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int h = 0; h < 6; ++h) s_e[wave][h * 64 + lane] = ecol[h];
