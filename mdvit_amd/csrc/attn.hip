@@ -389,8 +389,13 @@ static void fa_partial_stream_launch(dim3 grid, hipStream_t s, const float* X, l
                                      float* ws_P, const FaGeom& g, int NT, int NSUB, const float* outp, float* dU, float* e_part) {
     constexpr int C = 8 * CH, LPT = C / 4, SLOTS = 256 / LPT;
     constexpr int smem = SLOTS * LPT * (4 * CH + 8 + 1) * (int)sizeof(float);
-    static bool attr = false;
-    if (!attr && smem > 48 * 1024) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_partial_s8_kernel<CH, SOFTMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+    static bool attr[64] = {false};          // per device: the limit is a property of the function ON a device (one process per GPU is the supported mode; a second device must not inherit the flag)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr[dev] && smem > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_partial_s8_kernel<CH, SOFTMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr[dev] = true;
+    }
     hipLaunchKernelGGL((fa_partial_s8_kernel<CH, SOFTMAX>), grid, dim3(256), smem, s, X, ldx, Y, ldy, ysc, yscale, ws_m, ws_s, ws_P, g, NT, NSUB, outp, dU, e_part);
 }
 
