@@ -794,15 +794,16 @@ __global__ __launch_bounds__(256) void fa_bwd_apply_s8_kernel(const float* __res
 // 192 values here -- more than the register file leaves next to two token sets in flight -- so they live in an LDS table [48 float4 slots][32 lane classes]: a wave-wide
 // ds_read_b128 of one slot is 512 contiguous bytes (conflict-free; the second token's lanes read the same addresses: broadcast).  48 reads per token and lane price out at
 // ~2.6x the HBM rate of the kernel's eight streams; the three 16-vectors of the head come by quad-permute DPP.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fa_bwd_apply_s16_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
+template <int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fa_bwd_apply_tab_kernel(const float* __restrict__ dout, const float* __restrict__ qkv,
                                                                const float* __restrict__ U, const float* __restrict__ dVc,
                                                                const float* __restrict__ Mmat, const float* __restrict__ a,
                                                                const float* __restrict__ kmax, const float* __restrict__ ksum,
                                                                const float* __restrict__ dMp, int NTS,
                                                                float* __restrict__ dqkv, FaGeom g, int tokens_per_block) {
-    constexpr int C = 128, CH = 16, C3 = 384, LPT = 32, SLOTS = 8;
+    constexpr int C = 8 * CH, C3 = 3 * C, LPT = C / 4, SLOTS = 256 / LPT, LPH = CH / 4, L4 = CH / 4, NS = 8 * L4 + CH;          // table slots: M rows, dM rows (4 j x L4), dM columns (CH)
     __shared__ __attribute__((aligned(16))) float sM[C * CH], sD[C * CH];
-    __shared__ __attribute__((aligned(16))) float4 tab[48][LPT];
+    __shared__ __attribute__((aligned(16))) float4 tab[NS][LPT];
     __shared__ float s_tc[C];
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < C * CH; i += 256) {
@@ -826,16 +827,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int e = 0; e < CH; ++e) tc = fmaf(sD[threadIdx.x * CH + e], sM[threadIdx.x * CH + e], tc);
         s_tc[threadIdx.x] = tc;
     }
-    // the table: slots 0-15 M[c0 + j][local 4 l4 ..], 16-31 dM[c0 + j][local 4 l4 ..] (slot = 4 j + l4), 32-47 dM[head's channel e(l)][my four columns] (slot = 32 + l);
-    // local index l <-> the head's channel e(l) = 4 ((q % 4) ^ (l / 4)) + l % 4
-    for (int i = threadIdx.x; i < 48 * LPT; i += 256) {
-        const int slot = i / LPT, qq = i % LPT, hl = qq & 3, hb = (qq >> 2) * CH, cc0 = 4 * qq;
+    // the table: slots [0, 4 L4) M[c0 + j][local 4 l4 ..], [4 L4, 8 L4) dM[c0 + j][local 4 l4 ..] (slot = L4 j + l4), then CH slots dM[head's channel e(l)][my four columns];
+    // local index l <-> the head's channel e(l) = 4 ((q % LPH) ^ (l / 4)) + l % 4
+    for (int i = threadIdx.x; i < NS * LPT; i += 256) {
+        const int slot = i / LPT, qq = i % LPT, hl = qq % LPH, hb = (qq / LPH) * CH, cc0 = 4 * qq;
         float4 v;
-        if (slot < 32) {
-            const float* src = (slot < 16 ? sM : sD) + (cc0 + ((slot & 15) >> 2)) * CH + 4 * (hl ^ (slot & 3));
+        if (slot < 8 * L4) {
+            const int sl = slot % (4 * L4);
+            const float* src = (slot < 4 * L4 ? sM : sD) + (cc0 + sl / L4) * CH + 4 * (hl ^ (sl % L4));
             v = *reinterpret_cast<const float4*>(src);
         } else {
-            const int l = slot - 32, e = 4 * (hl ^ (l >> 2)) + (l & 3);
+            const int l = slot - 8 * L4, e = 4 * (hl ^ (l >> 2)) + (l & 3);
             v = *reinterpret_cast<const float4*>(sD + (hb + e) * CH + 4 * hl);
         }
         tab[slot][qq] = v;
@@ -861,15 +863,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         r.c = *reinterpret_cast<const float4*>(dVc + tok * C + c0);
     };
     auto compute = [&](const Rows& r, int n) __attribute__((always_inline)) {
-        float dfa[16], vv[16], pp[16];
+        float dfa[CH], vv[CH], pp[CH];
         dfa[0] = g.scale * a4.x * r.g.x; dfa[1] = g.scale * a4.y * r.g.y; dfa[2] = g.scale * a4.z * r.g.z; dfa[3] = g.scale * a4.w * r.g.w;
         vv[0] = r.v.x; vv[1] = r.v.y; vv[2] = r.v.z; vv[3] = r.v.w;
         pp[0] = expf(r.k.x - km4.x) * is4.x; pp[1] = expf(r.k.y - km4.y) * is4.y; pp[2] = expf(r.k.z - km4.z) * is4.z; pp[3] = expf(r.k.w - km4.w) * is4.w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            dfa[4 + j] = fa_dpp_quad_xor<1>(dfa[j]); dfa[8 + j] = fa_dpp_quad_xor<2>(dfa[j]); dfa[12 + j] = fa_dpp_quad_xor<3>(dfa[j]);
-            vv[4 + j] = fa_dpp_quad_xor<1>(vv[j]); vv[8 + j] = fa_dpp_quad_xor<2>(vv[j]); vv[12 + j] = fa_dpp_quad_xor<3>(vv[j]);
-            pp[4 + j] = fa_dpp_quad_xor<1>(pp[j]); pp[8 + j] = fa_dpp_quad_xor<2>(pp[j]); pp[12 + j] = fa_dpp_quad_xor<3>(pp[j]);
+            dfa[4 + j] = fa_dpp_quad_xor<1>(dfa[j]); vv[4 + j] = fa_dpp_quad_xor<1>(vv[j]); pp[4 + j] = fa_dpp_quad_xor<1>(pp[j]);
+            if constexpr (CH == 16) {
+                dfa[8 + j] = fa_dpp_quad_xor<2>(dfa[j]); dfa[12 + j] = fa_dpp_quad_xor<3>(dfa[j]);
+                vv[8 + j] = fa_dpp_quad_xor<2>(vv[j]); vv[12 + j] = fa_dpp_quad_xor<3>(vv[j]);
+                pp[8 + j] = fa_dpp_quad_xor<2>(pp[j]); pp[12 + j] = fa_dpp_quad_xor<3>(pp[j]);
+            }
         }
         float dq[4], dk[4], dv[4] = {0.f, 0.f, 0.f, 0.f};
         const float uu[4] = {r.u.x, r.u.y, r.u.z, r.u.w}, cc[4] = {r.c.x, r.c.y, r.c.z, r.c.w}, tcv[4] = {tc4.x, tc4.y, tc4.z, tc4.w};
@@ -879,8 +884,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < 4; ++j) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int l4 = 0; l4 < 4; ++l4) {
-                const float4 m4 = tab[4 * j + l4][q], d4 = tab[16 + 4 * j + l4][q];
+            for (int l4 = 0; l4 < L4; ++l4) {
+                const float4 m4 = tab[L4 * j + l4][q], d4 = tab[4 * L4 + L4 * j + l4][q];
                 s1 = fmaf(dfa[4 * l4 + 0], m4.x, s1); s1 = fmaf(dfa[4 * l4 + 1], m4.y, s1); s1 = fmaf(dfa[4 * l4 + 2], m4.z, s1); s1 = fmaf(dfa[4 * l4 + 3], m4.w, s1);
                 s2 = fmaf(vv[4 * l4 + 0], d4.x, s2); s2 = fmaf(vv[4 * l4 + 1], d4.y, s2); s2 = fmaf(vv[4 * l4 + 2], d4.z, s2); s2 = fmaf(vv[4 * l4 + 3], d4.w, s2);
             }
@@ -888,8 +893,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dk[j] = pp[j] * (s2 - tcv[j]);
         }
 #pragma unroll
-        for (int l = 0; l < 16; ++l) {
-            const float4 dc = tab[32 + l][q];
+        for (int l = 0; l < CH; ++l) {
+            const float4 dc = tab[8 * L4 + l][q];
             dv[0] = fmaf(pp[l], dc.x, dv[0]); dv[1] = fmaf(pp[l], dc.y, dv[1]); dv[2] = fmaf(pp[l], dc.z, dv[2]); dv[3] = fmaf(pp[l], dc.w, dv[3]);
         }
         if (n < n_end) {
@@ -1511,7 +1516,10 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         int tpbk = 1024;                                              // tokens per workgroup: halved while the launch has fewer than two workgroups per CU
         while (tpbk > 128 && (long)cdiv(g.N, tpbk) * B < 512) tpbk /= 2;
         if (g_fa_apply_tiles > 0) tpbk = 32 * g_fa_apply_tiles;
-        hipLaunchKernelGGL(fa_bwd_apply_s8_kernel, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
+        // the Ch = 8 matrices in the LDS table too (214.8 against 221.7 us at 32 images with them in 96 registers; MDVIT_FA_APPLY_S8_TABLE=0: the register form, A/B)
+        static const bool s8_tab = [] { const char* e = getenv("MDVIT_FA_APPLY_S8_TABLE"); return !(e && e[0] == '0'); }();
+        if (s8_tab) hipLaunchKernelGGL(fa_bwd_apply_tab_kernel<8>, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
+        else hipLaunchKernelGGL(fa_bwd_apply_s8_kernel, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
         MDVIT_LAUNCH_CHECK();
         return MDVIT_OK;
     }
@@ -1520,7 +1528,7 @@ extern "C" int mdvit_factoratt_bwd(const float* dout, const float* qkv, const fl
         int tpbk = 512;
         while (tpbk > 128 && (long)cdiv(g.N, tpbk) * B < 512) tpbk /= 2;
         if (g_fa_apply_tiles > 0) tpbk = 32 * g_fa_apply_tiles;
-        hipLaunchKernelGGL(fa_bwd_apply_s16_kernel, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
+        hipLaunchKernelGGL(fa_bwd_apply_tab_kernel<16>, dim3(cdiv(g.N, tpbk), B), dim3(256), 0, s, dout, qkv, U, dVc, Mmat, a, kmax, ksum, ws_P, NTS, dqkv, g, tpbk);
         MDVIT_LAUNCH_CHECK();
         return MDVIT_OK;
     }
