@@ -417,24 +417,36 @@ void launch_conv_tile(const float* x, long ldx, int xoff, const float* w, const 
                        x, ldx, xoff, w, bias, y, ldy, yoff, g.H, g.W, ncls, tiles_w, add_center);
 }
 
-// fixed-order sum of the partial rows of one 32-channel block: 32 columns x 8 row lanes per workgroup
+// fixed-order sum of the partial rows of one 32-channel block: 32 columns x 32 row lanes per workgroup (1024 threads), eight independent loads in flight per thread.
+// (Round 6: with 8 row lanes and a plain `sacc += base[..]` loop every thread walked rows / 8 partial rows one HBM round trip at a time -- 50 us per launch for the 7 x 7
+// class at 256 rows, 1.3 ms per bs=4 step over the three classes on the weight-gradient stream.)
+constexpr int CT_FIN_LANES = 32;
 template <int WIN>
-__global__ __launch_bounds__(256) void fa_conv_wgrad_finish_kernel(const float* __restrict__ part, int nrows, float* __restrict__ dw,
-                                                                   float* __restrict__ db, int ncls, int accumulate) {
+__global__ __launch_bounds__(1024) void fa_conv_wgrad_finish_kernel(const float* __restrict__ part, int nrows, float* __restrict__ dw,
+                                                                    float* __restrict__ db, int ncls, int accumulate) {
     constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
-    __shared__ float s_sum[8][33];
+    __shared__ float s_sum[CT_FIN_LANES][33];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + cl;
     const float* base = part + (long)blockIdx.y * nrows * ROW;
     float sacc = 0.f;
-    if (i < ROW)
-        for (int b = rl; b < nrows; b += 8) sacc += base[(long)b * ROW + i];
+    if (i < ROW) {
+        int b = rl;
+        for (; b + 7 * CT_FIN_LANES < nrows; b += 8 * CT_FIN_LANES) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(long)(b + u * CT_FIN_LANES) * ROW + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc += v[u];
+        }
+        for (; b < nrows; b += CT_FIN_LANES) sacc += base[(long)b * ROW + i];
+    }
     s_sum[rl][cl] = sacc;
     __syncthreads();
     if (rl == 0 && i < ROW) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += s_sum[r][cl];
+        for (int r = 0; r < CT_FIN_LANES; ++r) t += s_sum[r][cl];
         const int c = blockIdx.y * CT_CL + i / T, tap = i % T;
         if (c < ncls) {
             float* dst = tap < WIN * WIN ? dw + (long)c * WIN * WIN + tap : (db ? db + c : nullptr);
@@ -463,7 +475,7 @@ int launch_conv_tile_wgrad(const float* gsrc, long ldg, int goff, const float* x
                        gsrc, ldg, goff, x, ldx, xoff, part, g.H, g.W, ncls, tiles_w, tiles, tpb);
     // second stage, per 32-channel block y: rows [y][gx*B] of 32*(WIN^2+1) floats -> dw [c][WIN^2], db [c]
     constexpr int T = WIN * WIN + 1, ROW = CT_CL * T;
-    hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<WIN>), dim3(cdiv(ROW, 32), gy), dim3(256), 0, s, part, gx * g.B, dw, db, ncls, accumulate);
+    hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<WIN>), dim3(cdiv(ROW, 32), gy), dim3(32 * CT_FIN_LANES), 0, s, part, gx * g.B, dw, db, ncls, accumulate);
     return MDVIT_OK;
 }
 
@@ -494,9 +506,9 @@ inline int launch_conv3_wgrad(const float* gsrc, long ldg, const int goff[3], co
     }
     if (tcb == 0) return MDVIT_OK;
     hipLaunchKernelGGL(fa_conv3_wgrad_kernel, dim3((unsigned)((long)g.B * gx * tcb)), dim3(256), 0, s, a);
-    if (a.cbs[0]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<3>), dim3(cdiv(CT_CL * 10, 32), a.cbs[0]), dim3(256), 0, s, a.part[0], (int)rows, dw[0], db[0], ncls[0], accumulate);
-    if (a.cbs[1]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<5>), dim3(cdiv(CT_CL * 26, 32), a.cbs[1]), dim3(256), 0, s, a.part[1], (int)rows, dw[1], db[1], ncls[1], accumulate);
-    if (a.cbs[2]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<7>), dim3(cdiv(CT_CL * 50, 32), a.cbs[2]), dim3(256), 0, s, a.part[2], (int)rows, dw[2], db[2], ncls[2], accumulate);
+    if (a.cbs[0]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<3>), dim3(cdiv(CT_CL * 10, 32), a.cbs[0]), dim3(32 * CT_FIN_LANES), 0, s, a.part[0], (int)rows, dw[0], db[0], ncls[0], accumulate);
+    if (a.cbs[1]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<5>), dim3(cdiv(CT_CL * 26, 32), a.cbs[1]), dim3(32 * CT_FIN_LANES), 0, s, a.part[1], (int)rows, dw[1], db[1], ncls[1], accumulate);
+    if (a.cbs[2]) hipLaunchKernelGGL((fa_conv_wgrad_finish_kernel<7>), dim3(cdiv(CT_CL * 50, 32), a.cbs[2]), dim3(32 * CT_FIN_LANES), 0, s, a.part[2], (int)rows, dw[2], db[2], ncls[2], accumulate);
     return MDVIT_OK;
 }
 
