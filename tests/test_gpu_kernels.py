@@ -1842,3 +1842,44 @@ def test_mlp_register_chained_kernels_on_one_plane_in_the_bf16_mode(C, r, M):
     for name, a, b in zip(("y", "dx", "dres", "dW1", "db1", "dW2", "db2"), res["bf16x3"], [ref] + gr):
         check(a, b, tol=3e-4, name=name + " (bf16x3 afterwards / before) vs fp64")
     assert not torch.equal(res["bf16"][0], res["bf16x3"][0]) and float((res["bf16"][0] - res["bf16x3"][0]).abs().max()) > 1e-4
+
+
+def test_launch_sampler_times_the_launches_of_one_symbol_from_every_site():
+    """mdvit_gemm_sampler (round 6): every launch of a symbol is SEEN, a hashed 1-in-stride sample of them is TIMED with the kernel's own begin / end timestamps, other
+    symbols are ignored; what bench.py's roofline line divides by"""
+    import ctypes as C
+    from mdvit_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = 4096, 128, 256
+    x, w = rnd(M, K, seed=901).to(dev()), rnd(N, K, seed=902).to(dev())
+    g = rnd(M, N, seed=903).to(dev())
+    out, dW = torch.empty(M, N, device=dev()), torch.empty(N, K, device=dev())
+
+    def nt():
+        ops.gemm(ops._p(x), ops._p(w), ops._p(out), M, N, K, lda=K, ldb=K, ldc=N, precision=1)
+
+    def tn():
+        ops.gemm(ops._p(g), ops._p(x), ops._p(dW), N, K, M, lda=N, ldb=K, ldc=K, trans_a=True, trans_b=False, allow_split=True, precision=1)
+
+    def read():
+        rows, i = {}, 0
+        nm, seen, timed, ms = C.create_string_buffer(160), C.c_int64(), C.c_int64(), C.c_double()
+        while lib.mdvit_gemm_sampler_read(i, nm, 160, C.byref(seen), C.byref(timed), C.byref(ms)) == 0:
+            rows[nm.value.decode()] = (seen.value, timed.value, ms.value)
+            i += 1
+        return rows
+
+    lib.mdvit_gemm_sampler(None, 1)
+    for _ in range(6):
+        nt(); tn()
+    rows = read()
+    assert len(rows) == 2 and all(v[0] == 6 and v[1] == 6 and 0.0 < v[2] < 50.0 for v in rows.values()), rows
+    tn_name = next(k for k in rows if k.startswith("gemm_tn_kernel"))
+    lib.mdvit_gemm_sampler(tn_name.encode(), 4)
+    for _ in range(32):
+        nt(); tn()
+    rows = read()
+    assert list(rows) == [tn_name] and rows[tn_name][0] == 32 and 2 <= rows[tn_name][1] <= 16 and rows[tn_name][2] > 0.0, rows
+    nt(); tn()                      # reading ended the sampling: nothing is armed any more
+    assert read() == rows
+    torch.cuda.synchronize()

@@ -38,6 +38,23 @@ def test_bad_arguments_return_error_codes_without_gpu():
     assert b"in_chans" in lib.mdvit_last_error()
 
 
+def test_launch_sampler_is_off_and_empty_without_launches():
+    """mdvit_gemm_sampler / _read (round 6, bench.py's roofline): arming and reading without a launch touches no GPU state -- an empty table ends at index 0 -- and a
+    rejected GEMM call (bad shape) is not counted"""
+    import ctypes as C
+    from mdvit_amd import _lib
+    lib = _lib.load()
+    assert lib.mdvit_gemm_sampler(None, 1) == 0
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K = 0, 4, 4
+    assert lib.mdvit_gemm_f32(C.byref(d), None) == 1
+    nm, seen, timed, ms = C.create_string_buffer(160), C.c_int64(), C.c_int64(), C.c_double()
+    assert lib.mdvit_gemm_sampler_read(0, nm, 160, C.byref(seen), C.byref(timed), C.byref(ms)) != 0
+    assert lib.mdvit_gemm_sampler(b"gemm_tn_kernel<128, 128, 2, true, false, false, false>", 4) == 0
+    assert lib.mdvit_gemm_sampler(None, 0) == 0          # off
+    assert lib.mdvit_gemm_sampler_read(0, nm, 160, C.byref(seen), C.byref(timed), C.byref(ms)) != 0
+
+
 def test_bf16_stored_operands_are_validated_before_any_launch():
     """MdvitGemmDesc.a_bf16 / b_bf16 (the mixed mode's saved hidden activations): a layout of the weight-gradient (TN, precision 1) kernel only -- any other
     product, both operands at once, or a leading dimension that breaks the 8-byte quads is refused with MDVIT_E_SHAPE before anything touches a GPU."""
