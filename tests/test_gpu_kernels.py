@@ -1883,3 +1883,19 @@ def test_launch_sampler_times_the_launches_of_one_symbol_from_every_site():
     nt(); tn()                      # reading ended the sampling: nothing is armed any more
     assert read() == rows
     torch.cuda.synchronize()
+
+
+def test_the_ab_forms_behind_round_6_switches_still_hold():
+    """The forms round 6 replaced stay reachable as A/B switches (read once per process): the MFMA tiles of the attention core at Ch = 8 / 16 (MDVIT_FA_*_STREAM* = 0, the
+    register form of the Ch = 8 apply kernel) and the peer heads' two chained products (MDVIT_HEAD_CAT=0) -- run the tests that pin them in a child process with the switches
+    off, so that an A/B run compares two CORRECT paths"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDVIT_FA_APPLY_STREAM="0", MDVIT_FA_PARTIAL_STREAM="0", MDVIT_HEAD_CAT="0", MDVIT_DEIT_BLOCK_ENTRY="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"), "-k", "factor_att_core or factor_att_softmax",
+                        os.path.join(root, "tests", "test_gpu_model.py") + "::test_mdvit_two_sweep_step_vs_golden"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    env2 = dict(os.environ, MDVIT_FA_APPLY_S8_TABLE="0", MDVIT_FA_APPLY_STREAM16="0", MDVIT_FA_PARTIAL_STREAM16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_kernels.py"), "-k", "factor_att_core"],
+                       capture_output=True, text=True, timeout=900, env=env2, cwd=root)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
